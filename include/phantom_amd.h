@@ -1,0 +1,234 @@
+/*
+ * phantom_amd.h -- C ABI of the MI355X-native PhantomEnv.step() hot path.
+ *
+ * The reference (jpmorganchase/Phantom v2.2.0) has NO FFI: the path is a Python class
+ * API.  This header is the boundary a maintainer would bind (ctypes stub shown in
+ * INTEGRATION.md) to replace the bodies of
+ *
+ *   PhantomEnv.reset            phantom/env.py:185-237
+ *   PhantomEnv.step             phantom/env.py:239-303
+ *   FiniteStateMachineEnv.step  phantom/fsm.py:253-380      (reset: fsm.py:195-251)
+ *   StackelbergEnv.step         phantom/stackelberg.py:111-196 (reset: :53-109)
+ *   Network.send / resolve      phantom/network.py:233-265
+ *   BatchResolver.resolve       phantom/resolvers.py:128-163
+ *
+ * for a whole batch of B independent env instances per call.  All pointers are plain
+ * device pointers (hipMalloc'ed / torch tensors' data_ptr()); the library allocates only
+ * its own copy of the small static spec tables.  Every call is stream-ordered and
+ * asynchronous; functions return 0 or a negative PHX_E* code and never throw.
+ *
+ * Agent behaviour is a closed set of *kinds* with hand-written device handlers
+ * (arbitrary Python handler bodies cannot be compiled); see phx_kind below.
+ */
+#ifndef PHANTOM_AMD_H
+#define PHANTOM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHX_ABI_VERSION 1
+
+/* ---- return codes (host-side failures) ---------------------------------------------- */
+#define PHX_OK            0
+#define PHX_EINVAL       -1   /* malformed spec / argument                                  */
+#define PHX_EUNSUPPORTED -2   /* spec valid but outside what the device engine implements   */
+#define PHX_EHIP         -3   /* HIP runtime error (text in phx_last_error)                 */
+#define PHX_ECAPACITY    -4   /* LDS / queue capacity exceeded at create time               */
+
+/* ---- per-env soft error codes written to err[B] (first error wins, sticky until reset)
+ *      each maps 1:1 to the exception the reference raises inside step().                 */
+#define PHX_ERR_NONE        0
+#define PHX_ERR_NETWORK     1 /* NetworkError: send along a missing edge  network.py:246-249 */
+#define PHX_ERR_PAYLOAD     2 /* NetworkError: payload sender/receiver whitelist :311-331    */
+#define PHX_ERR_UNKNOWN_MSG 3 /* ValueError: no handler for payload type  agents.py:140-143  */
+#define PHX_ERR_ROUND_LIMIT 4 /* RuntimeError: msgs left after round_limit resolvers.py:160  */
+#define PHX_ERR_QUEUE_FULL  5 /* build-specific: per-round message capacity exceeded         */
+
+/* ---- agent kinds (closed set) -------------------------------------------------------- */
+typedef enum phx_kind {
+  PHX_KIND_NONE       = 0,
+  /* examples/environments/supply_chain/supply_chain.py */
+  PHX_KIND_FACTORY    = 1,  /* FactoryAgent  :36-45                                        */
+  PHX_KIND_SHOP       = 2,  /* ShopAgent     :70-150   pi0=factory, pi1=max_sales_per_step */
+  PHX_KIND_CUSTOMER   = 3,  /* CustomerAgent :48-67    pi0=shop                            */
+  /* build-authored Stackelberg market, run on ph.StackelbergEnv     */
+  PHX_KIND_SELLER     = 4,  /* leader:   price setter                                      */
+  PHX_KIND_BUYER      = 5,  /* follower: best-response buyer   pf0=value                   */
+  /* kinds mirroring the agents of the reference's own known-answer tests                 */
+  PHX_KIND_HALVER     = 6,  /* tests/network/test_tracking.py:21-28  _TestActor            */
+  PHX_KIND_CASHBOX    = 7,  /* tests/network/test_network.py:17-34   MockAgent             */
+  PHX_KIND_REQRESP    = 8,  /* tests/network/test_resolver.py:24-46  _TestAgent            */
+  PHX_KIND_FORWARDER  = 9,  /* tests/network/test_resolver.py:89-96  _TestAgent2 pi0=target*/
+  PHX_KIND_MOCK_STRAT = 10, /* tests/__init__.py:32-65 MockStrategicAgent  pi0=num_steps   */
+  PHX_KIND_MOCK_AGENT = 11, /* tests/__init__.py:25-29 MockAgent (no handlers)             */
+  PHX_KIND_COUNT      = 12
+} phx_kind;
+
+/* ---- message payload types ------------------------------------------------------------ */
+typedef enum phx_msg_type {
+  PHX_MSG_NONE           = 0,
+  PHX_MSG_STOCK_REQUEST  = 1, /* i32 size   ShopAgent     -> FactoryAgent  supply_chain.py:26-28 */
+  PHX_MSG_STOCK_RESPONSE = 2, /* i32 size   FactoryAgent  -> ShopAgent     :31-33                */
+  PHX_MSG_ORDER_REQUEST  = 3, /* i32 size   CustomerAgent -> ShopAgent     :16-18                */
+  PHX_MSG_ORDER_RESPONSE = 4, /* i32 size   ShopAgent     -> CustomerAgent :21-23                */
+  PHX_MSG_PRICE          = 5, /* f64 price  Seller -> Buyer                                      */
+  PHX_MSG_ORDER          = 6, /* i32 vol    Buyer  -> Seller                                     */
+  PHX_MSG_HALVE          = 7, /* i32 value  any->any   test_tracking.py:16-18                    */
+  PHX_MSG_CASH           = 8, /* f64 cash   any->any   test_network.py:12-14                     */
+  PHX_MSG_REQUEST        = 9, /* f64 cash   any->any   test_resolver.py:14-16                    */
+  PHX_MSG_RESPONSE       = 10,/* f64 cash   any->any   test_resolver.py:19-21                    */
+  PHX_MSG_PING           = 11,/* (bool)     undecorated payload, test_resolver.py:94             */
+  PHX_MSG_COUNT          = 12
+} phx_msg_type;
+
+#define PHX_NPI 4   /* int32 params per agent  */
+#define PHX_NPF 2   /* double params per agent */
+
+/* env flavours */
+#define PHX_ENV_PLAIN       0  /* PhantomEnv            env.py  */
+#define PHX_ENV_FSM         1  /* FiniteStateMachineEnv fsm.py  */
+#define PHX_ENV_STACKELBERG 2  /* StackelbergEnv        stackelberg.py */
+
+/* spec flags */
+#define PHX_F_IGNORE_CONN_ERRORS 1u  /* Network(ignore_connection_errors=True) network.py:62 */
+#define PHX_F_NO_PAYLOAD_CHECKS  2u  /* Network(enforce_msg_payload_checks=False)  :63       */
+#define PHX_F_FORCE_GENERIC      4u  /* never use a fused static-schedule kernel             */
+
+/*
+ * Flat description of one env class: what the Python host compiles a
+ * Network + PhantomEnv construction into.  All arrays are HOST pointers, copied at create.
+ */
+typedef struct phx_spec {
+  int32_t abi_version;          /* PHX_ABI_VERSION                                           */
+  int32_t n_agents;             /* A: agents in Network insertion order (env.py:142-144)     */
+  int32_t batch;                /* B: env instances owned by this handle (local shard)       */
+  int32_t num_steps;            /* PhantomEnv(num_steps) env.py:64                           */
+  int32_t round_limit;          /* BatchResolver(round_limit); -1 = None resolvers.py:117    */
+  int32_t env_type;             /* PHX_ENV_*                                                 */
+  uint32_t flags;               /* PHX_F_*                                                   */
+  int32_t queue_cap;            /* max messages alive in one resolver round (per env)        */
+  int32_t trace_cap;            /* message-log capacity per env per step (0 = tracing off)   */
+  const uint8_t* kind;          /* [A] phx_kind                                              */
+  const int32_t* param_i;       /* [A][PHX_NPI]                                              */
+  const double*  param_f;       /* [A][PHX_NPF]                                              */
+  const int32_t* row_ptr;       /* [A+1] CSR of directed edges u->v, neighbours in           */
+  const int32_t* col;           /* [nnz]  nx adjacency (insertion) order network.py:122-123  */
+  /* FSM (fsm.py:26-63): ordered acting lists, rewarded masks, handler-less next stage      */
+  int32_t n_stages;
+  int32_t initial_stage;
+  const int32_t* stage_act_ptr; /* [n_stages+1]                                              */
+  const int32_t* stage_act_idx; /* agent indices, in FSMStage.acting_agents order            */
+  const uint8_t* stage_rewarded;/* [n_stages][A]; ignored where stage_rewarded_all           */
+  const uint8_t* stage_rewarded_all; /* [n_stages] 1 <=> rewarded_agents is None fsm.py:315  */
+  const int32_t* stage_next;    /* [n_stages] next_stages[0]  fsm.py:292                     */
+  /* Stackelberg (stackelberg.py:30-51): ordered leader / follower lists                    */
+  int32_t n_leaders, n_followers;
+  const int32_t* leaders;
+  const int32_t* followers;
+  /* device RNG (used when exo == NULL): Philox4x32-10, key = (seed, env_offset + b)        */
+  uint64_t seed;
+  int64_t  env_offset;          /* global index of local env 0 (multi-GPU sharding)          */
+} phx_spec;
+
+typedef struct phx_env phx_env;   /* opaque */
+
+/* State lives in ONE caller-owned device blob, struct-of-arrays by kind:
+ * field f is `count` x B contiguous elements laid out [slot][B... see DESIGN.md] */
+typedef struct phx_field {
+  int32_t  field_id;
+  int32_t  dtype;       /* 0=i32 1=f64 2=u8 3=f32 */
+  int64_t  offset;      /* byte offset in the state blob */
+  int32_t  dim0, dim1, dim2;  /* logical shape (dim2 = 1 when unused) */
+  int32_t  kind;        /* owning phx_kind, 0 = env-level */
+  char     name[24];
+} phx_field;
+
+/* one message-log record (Resolver.tracked_messages, resolvers.py:35-60) */
+typedef struct phx_msg_rec {
+  uint16_t sender, receiver, type, round;
+  union { int64_t i; double f; } payload;
+} phx_msg_rec;
+
+/* ---- step I/O: every pointer is a device pointer, NULL where noted --------------------
+ * S = number of strategic agents (rank order = agent order), D = obs_dim (phx_obs_dim).   */
+typedef struct phx_step_io {
+  const float*   actions;      /* [B][S]    one float per strategic agent                   */
+  const uint8_t* action_valid; /* [B][S] or NULL (= every strategic agent has an action);
+                                  0 <=> aid not in actions -> generate_messages env.py:330   */
+  const uint8_t* exo;          /* [B][n_exo] exogenous draws (np.random.randint(5) of
+                                  CustomerAgent, supply_chain.py:64) or NULL -> device RNG   */
+  float*    obs;               /* [B][S][D]                                                 */
+  uint8_t*  obs_valid;         /* [B][S]   1 <=> aid in step.observations                   */
+  double*   reward;            /* [B][S]                                                    */
+  uint8_t*  reward_valid;      /* [B][S]   0 absent, 1 value, 2 present-but-None fsm.py:378 */
+  uint8_t*  terminated;        /* [B][S]                                                    */
+  uint8_t*  truncated;         /* [B][S]                                                    */
+  uint8_t*  done_valid;        /* [B][S]   1 <=> aid in step.terminations                   */
+  uint8_t*  all_terminated;    /* [B]      terminations["__all__"]  env.py:297              */
+  uint8_t*  all_truncated;     /* [B]      truncations["__all__"]   env.py:298              */
+  int32_t*  err;               /* [B]      PHX_ERR_*                                        */
+  phx_msg_rec* msg_log;        /* [B][trace_cap] or NULL                                    */
+  int32_t*  msg_count;         /* [B] or NULL                                               */
+} phx_step_io;
+
+/* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end */
+typedef struct phx_rollout_io {
+  int32_t T;
+  const float*   actions;      /* [T][B][S] replayed policy, or NULL -> random U[0,100)     */
+  const uint8_t* exo;          /* [T][B][n_exo] or NULL -> device RNG                       */
+  float*    obs;               /* [T][B][S][D]  post-step observation                       */
+  float*    action_out;        /* [T][B][S]     action taken                                */
+  float*    reward;            /* [T][B][S]     f64 reward rounded to f32                   */
+  uint8_t*  terminated;        /* [T][B][S]                                                 */
+  uint8_t*  truncated;         /* [T][B][S]     per-agent flag OR'ed with __all__ truncation */
+  float*    last_obs;          /* [B][S][D]     observation the next fragment starts from   */
+  int32_t*  err;               /* [B]                                                       */
+} phx_rollout_io;
+
+/* ---- entry points ---------------------------------------------------------------------- */
+int         phx_abi_version(void);
+const char* phx_last_error(void);
+
+/* sizes derived from the spec, so the caller (torch) can own every buffer */
+int64_t phx_state_nbytes(const phx_spec* spec);
+int     phx_obs_dim(const phx_spec* spec);
+int     phx_n_strategic(const phx_spec* spec);
+int     phx_n_exo(const phx_spec* spec);
+
+/* replaces PhantomEnv.__init__ bookkeeping (env.py:55-124): validates the spec, uploads the
+ * tables to `device`, binds the caller's state blob (zero-initialised by this call).       */
+int  phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state_nbytes,
+                phx_env** out);
+void phx_destroy(phx_env* env);
+
+int  phx_n_fields(const phx_env* env);
+int  phx_field_info(const phx_env* env, int index, phx_field* out);
+/* 1 when step/rollout run a fused static-schedule kernel, 0 for the generic engine        */
+int  phx_uses_fused(const phx_env* env);
+
+/* PhantomEnv.reset (env.py:185-237 / fsm.py:195-251 / stackelberg.py:53-109) for every env
+ * with reset_mask[b] != 0 (NULL = all).  Writes the initial observations.                 */
+int  phx_reset(phx_env* env, const uint8_t* reset_mask, float* obs, uint8_t* obs_valid,
+               void* stream);
+
+/* one PhantomEnv.step for all B envs */
+int  phx_step(phx_env* env, const phx_step_io* io, void* stream);
+
+/* Network.send from outside a step (network.py:233-254; tests/network/ tests): queue n host
+ * messages, the same for every env, delivered by the next phx_resolve / phx_step.          */
+int  phx_inject(phx_env* env, const phx_msg_rec* host_msgs, int n);
+/* Network.resolve(contexts) alone (network.py:256-265): no clock tick, no observations     */
+int  phx_resolve(phx_env* env, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count,
+                 void* stream);
+
+/* T fused steps (supply-chain static schedule only; PHX_EUNSUPPORTED otherwise)            */
+int  phx_rollout(phx_env* env, const phx_rollout_io* io, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHANTOM_AMD_H */

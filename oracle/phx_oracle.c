@@ -1,0 +1,934 @@
+/*
+ * phx_oracle.c -- CPU ORACLE (test infrastructure, see phx_oracle.h).
+ *
+ * Sequential restatement of jpmorganchase/Phantom v2.2.0's PhantomEnv.step() path.  Each env
+ * instance of the batch is stepped on its own by the same code the reference runs once per
+ * Python env object; "file:line" comments point into /root/reference.
+ *
+ * Deliberately NOT optimised the way the device code is: inboxes are an insertion-ordered
+ * map receiver -> list (the reference's DefaultDict), handlers run one message at a time.
+ */
+#include "phx_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SHOP_MAX_STOCK 100          /* supply_chain.py:13 */
+
+static char g_err[256];
+static int g_threads = 1;
+const char* phxo_last_error(void) { return g_err; }
+void phxo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int phxo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  int src, dst, type;
+  union { int64_t i; double f; } p;
+} omsg;
+
+typedef struct {          /* python attributes of one agent object */
+  int32_t i[4];
+  double f[2];
+  double* vec;            /* BuyerAgent.prices[deg] */
+} ostate;
+
+typedef struct {          /* one BatchResolver.messages DefaultDict  resolvers.py:120 */
+  omsg* pool;
+  int* next;              /* next message of the same receiver */
+  int n;
+  int* order;             /* receivers in first-arrival (dict insertion) order */
+  int n_recv;
+  int* head;              /* [A] first message per receiver, -1 = key absent */
+  int* tail;
+} oinbox;
+
+typedef struct {
+  ostate* ag;             /* [A] */
+  double* vecpool;
+  int32_t step;           /* PhantomEnv._current_step env.py:63 */
+  int32_t stage, prev_stage;   /* fsm.py:126-127 */
+  uint32_t tick;          /* device-RNG draw counter (never reset) */
+  int32_t clock;          /* handle_message invocation counter (stands in for time.time()) */
+  uint8_t* term;          /* [S] PhantomEnv._terminations env.py:71 */
+  uint8_t* trunc;         /* [S] PhantomEnv._truncations  env.py:72 */
+  double* rew_cache;      /* [S] FSM/Stackelberg _rewards */
+  uint8_t* rew_cache_valid;
+  float* obs_cache;       /* [S][D] FSM _observations */
+  uint8_t* obs_cache_valid;
+  oinbox box[2];
+  int cur;                /* which box is self.messages */
+  int32_t err;
+  phx_msg_rec* log;       /* Resolver._tracked_messages resolvers.py:37 */
+  int log_cap, log_n;
+  int round;
+} oenv;
+
+struct phxo_env {
+  phx_spec s;             /* deep copy */
+  int A, S, B, D, n_exo, nnz;
+  int* strat_rank;        /* [A] rank among strategic agents or -1 */
+  int* strat_idx;         /* [S] */
+  int* kind_rank;         /* [A] rank among agents of the same kind */
+  int kind_count[PHX_KIND_COUNT];
+  int* exo_rank;          /* [A] rank among CUSTOMER agents or -1 */
+  int* nbr_slot_base;     /* unused */
+  omsg* injected; int n_injected;
+  oenv* env;              /* [B] */
+};
+
+static int is_strategic_kind(int k) {
+  return k == PHX_KIND_SHOP || k == PHX_KIND_SELLER || k == PHX_KIND_BUYER ||
+         k == PHX_KIND_MOCK_STRAT;
+}
+static int obs_dim_of_kind(int k) {
+  switch (k) {
+    case PHX_KIND_SHOP: return 3;
+    case PHX_KIND_SELLER: return 2;
+    case PHX_KIND_BUYER: return 2;
+    case PHX_KIND_MOCK_STRAT: return 1;
+    default: return 0;
+  }
+}
+
+/* @msg_payload(sender_type, receiver_type) whitelists, message.py:20-42; 0 = None (any).  */
+static void payload_types(int type, int* sender_kind, int* receiver_kind, int* decorated) {
+  *decorated = 1; *sender_kind = 0; *receiver_kind = 0;
+  switch (type) {
+    case PHX_MSG_ORDER_REQUEST:  *sender_kind = PHX_KIND_CUSTOMER; *receiver_kind = PHX_KIND_SHOP; break;     /* supply_chain.py:16 */
+    case PHX_MSG_ORDER_RESPONSE: *sender_kind = PHX_KIND_SHOP; *receiver_kind = PHX_KIND_CUSTOMER; break;     /* :21 */
+    case PHX_MSG_STOCK_REQUEST:  *sender_kind = PHX_KIND_SHOP; *receiver_kind = PHX_KIND_FACTORY; break;      /* :26 */
+    case PHX_MSG_STOCK_RESPONSE: *sender_kind = PHX_KIND_FACTORY; *receiver_kind = PHX_KIND_SHOP; break;      /* :31 */
+    case PHX_MSG_PRICE:          *sender_kind = PHX_KIND_SELLER; *receiver_kind = PHX_KIND_BUYER; break;
+    case PHX_MSG_ORDER:          *sender_kind = PHX_KIND_BUYER; *receiver_kind = PHX_KIND_SELLER; break;
+    case PHX_MSG_PING:           *decorated = 0; break;       /* bare `True`, test_resolver.py:94 */
+    default: break;                                           /* @msg_payload() : any -> any */
+  }
+}
+
+static int has_edge(const phxo_env* E, int u, int v) {        /* network.py:224-231 */
+  for (int k = E->s.row_ptr[u]; k < E->s.row_ptr[u + 1]; ++k)
+    if (E->s.col[k] == v) return 1;
+  return 0;
+}
+static int nbr_slot(const phxo_env* E, int u, int v) {        /* index of v in ctx.neighbour_ids of u */
+  for (int k = E->s.row_ptr[u]; k < E->s.row_ptr[u + 1]; ++k)
+    if (E->s.col[k] == v) return k - E->s.row_ptr[u];
+  return -1;
+}
+
+static void set_err(oenv* e, int code) { if (e->err == 0) e->err = code; }
+
+static void inbox_clear(const phxo_env* E, oinbox* b) {       /* resolvers.py:122-123 */
+  b->n = 0; b->n_recv = 0;
+  for (int a = 0; a < E->A; ++a) b->head[a] = b->tail[a] = -1;
+}
+
+/* Resolver.push + BatchResolver.handle_push  resolvers.py:39-46,125-126 */
+static void resolver_push(const phxo_env* E, oenv* e, const omsg* m) {
+  if (e->log && e->log_n < e->log_cap) {                      /* enable_tracking */
+    phx_msg_rec* r = &e->log[e->log_n];
+    r->sender = (uint16_t)m->src; r->receiver = (uint16_t)m->dst;
+    r->type = (uint16_t)m->type; r->round = (uint16_t)e->round;
+    r->payload.i = m->p.i;
+  }
+  if (e->log) e->log_n++;
+  oinbox* b = &e->box[e->cur];
+  if (b->n >= E->s.queue_cap) { set_err(e, PHX_ERR_QUEUE_FULL); return; }
+  int id = b->n++;
+  b->pool[id] = *m; b->next[id] = -1;
+  if (b->head[m->dst] < 0) {                                  /* new dict key */
+    b->head[m->dst] = id; b->order[b->n_recv++] = m->dst;
+  } else {
+    b->next[b->tail[m->dst]] = id;
+  }
+  b->tail[m->dst] = id;
+}
+
+/* Network.send  network.py:233-254 (+ _enforce_payload_checks :297-331) */
+static void network_send(const phxo_env* E, oenv* e, int src, int dst, int type, omsg payload) {
+  if (!(E->s.flags & PHX_F_IGNORE_CONN_ERRORS) && !has_edge(E, src, dst)) {
+    set_err(e, PHX_ERR_NETWORK); return;                      /* raise NetworkError :246-249 */
+  }
+  if (!(E->s.flags & PHX_F_NO_PAYLOAD_CHECKS)) {
+    int sk, rk, dec; payload_types(type, &sk, &rk, &dec);
+    if (!dec) { set_err(e, PHX_ERR_PAYLOAD); return; }        /* :311-313 */
+    if (sk && E->s.kind[src] != sk) { set_err(e, PHX_ERR_PAYLOAD); return; }   /* :317-323 */
+    if (rk && E->s.kind[dst] != rk) { set_err(e, PHX_ERR_PAYLOAD); return; }   /* :325-331 */
+  }
+  payload.src = src; payload.dst = dst; payload.type = type;
+  resolver_push(E, e, &payload);
+}
+
+static omsg mk_i(int64_t v) { omsg m; memset(&m, 0, sizeof m); m.p.i = v; return m; }
+static omsg mk_f(double v)  { omsg m; memset(&m, 0, sizeof m); m.p.f = v; return m; }
+
+/* ---- device-RNG definition (build-owned; replaces the global np.random stream) -------- */
+void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* np.random.randint(5) draws 3 random bits and rejects values > 4 (masked rejection,
+ * SURVEY Appendix B).  The device stream keeps that mapping over Philox words: the K
+ * customers of one shop consume successive accepted 3-bit fields (10 per 32-bit word)
+ * of blocks ctr = (env_lo, env_hi, tick, shop | blk<<20).                              */
+void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  int got = 0;
+  for (uint32_t blk = 0; got < K; ++blk) {
+    uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
+                       (uint32_t)shop | (blk << 20)};
+    uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
+    for (int j = 0; j < 4 && got < K; ++j)
+      for (int f = 0; f < 10 && got < K; ++f) {
+        uint32_t v = (w[j] >> (3 * f)) & 7u;
+        if (v <= 4u) out[got++] = (uint8_t)v;
+      }
+  }
+}
+/* random policy of the rollout: U[0,100) with 24 bits, one Philox word per strategic agent */
+float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int r) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
+                     0x80000000u | (uint32_t)(r >> 2)};
+  uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
+  return (float)(w[r & 3] >> 8) * (100.0f / 16777216.0f);
+}
+
+/* ---- per-kind agent behaviour --------------------------------------------------------- */
+
+/* Agent.reset / subclasses: agents.py:160-175 */
+static void agent_reset(const phxo_env* E, oenv* e, int a) {
+  ostate* st = &e->ag[a];
+  switch (E->s.kind[a]) {
+    case PHX_KIND_SHOP: st->i[0] = 0; break;                  /* self.stock = 0  supply_chain.py:149-150 */
+    case PHX_KIND_CASHBOX: st->f[0] = 0.0; break;             /* test_network.py:23-24 */
+    case PHX_KIND_SELLER: st->f[0] = 0.0; st->f[1] = 0.0; st->i[0] = 0; break;
+    case PHX_KIND_BUYER: {
+      int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
+      for (int k = 0; k < deg; ++k) st->vec[k] = 1.0;
+      st->f[0] = 0.0; st->i[0] = 0; break;
+    }
+    default: break;
+  }
+}
+
+static int int_round_half_even(float a) {
+  /* int(round(np.float32)) : round-half-to-even supply_chain.py:139 */
+  double r = rint((double)a);
+  if (r > 1073741824.0) r = 1073741824.0;      /* keep inside int32 (documented domain limit) */
+  if (r < -1073741824.0) r = -1073741824.0;
+  return (int)r;
+}
+
+/* decode_action (env.py:330-331) or generate_messages (:332-333) of agent a */
+static void agent_act(const phxo_env* E, oenv* e, int b, int a, int has_action, float action,
+                      const uint8_t* exo_b) {
+  ostate* st = &e->ag[a];
+  const int32_t* pi = &E->s.param_i[a * PHX_NPI];
+  switch (E->s.kind[a]) {
+    case PHX_KIND_SHOP:
+      if (has_action) {                                       /* supply_chain.py:136-142 */
+        int req = int_round_half_even(action);
+        int room = SHOP_MAX_STOCK - st->i[0];
+        int stock_to_request = req < room ? req : room;
+        network_send(E, e, a, pi[0], PHX_MSG_STOCK_REQUEST, mk_i(stock_to_request));
+      }                                                       /* else Agent.generate_messages -> [] agents.py:157 */
+      break;
+    case PHX_KIND_CUSTOMER: {                                 /* supply_chain.py:61-67 */
+      int order_size;
+      if (exo_b) order_size = exo_b[E->exo_rank[a]];
+      else {
+        /* device stream: k-th accepted field of the shop's block sequence */
+        uint8_t tmp[4096];
+        int K = pi[1] + 1;
+        phxo_rng_orders(E->s.seed, E->s.env_offset + b, e->tick, E->kind_rank[pi[0]], K, tmp);
+        order_size = tmp[K - 1];
+      }
+      network_send(E, e, a, pi[0], PHX_MSG_ORDER_REQUEST, mk_i(order_size));
+      break;
+    }
+    case PHX_KIND_SELLER:
+      if (has_action) {
+        st->f[0] = (double)action;                            /* self.price = float(action[0]) */
+        for (int k = E->s.row_ptr[a]; k < E->s.row_ptr[a + 1]; ++k)   /* ctx.neighbour_ids order */
+          network_send(E, e, a, E->s.col[k], PHX_MSG_PRICE, mk_f(st->f[0]));
+      }
+      break;
+    case PHX_KIND_BUYER:
+      if (has_action) {
+        int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
+        if (action > 0.5f && deg > 0) {
+          int j = 0;                                          /* first minimum */
+          for (int k = 1; k < deg; ++k) if (st->vec[k] < st->vec[j]) j = k;
+          st->i[0] = 1; st->f[0] = st->vec[j];
+          network_send(E, e, a, E->s.col[E->s.row_ptr[a] + j], PHX_MSG_ORDER, mk_i(1));
+        } else { st->i[0] = 0; st->f[0] = 0.0; }
+      }
+      break;
+    case PHX_KIND_MOCK_STRAT:
+      if (has_action) st->i[1] += 1;                          /* decode_action_count tests/__init__.py:53-55 */
+      break;
+    default: break;                                           /* generate_messages -> [] */
+  }
+}
+
+static void agent_pre_resolution(const phxo_env* E, oenv* e, int a) {
+  ostate* st = &e->ag[a];
+  switch (E->s.kind[a]) {
+    case PHX_KIND_SHOP: st->i[1] = 0; st->i[2] = 0; break;    /* sales, missed_sales supply_chain.py:93-96 */
+    case PHX_KIND_SELLER:
+      if (e->step % 2 == 0) { st->f[1] = 0.0; st->i[0] = 0; } /* revenue, tx of the buying round */
+      break;
+    default: break;
+  }
+}
+
+/* Agent.handle_message agents.py:122-155 -- type dispatch to the @msg_handler methods */
+static void agent_handle_message(const phxo_env* E, oenv* e, int a, const omsg* m) {
+  ostate* st = &e->ag[a];
+  const int32_t* pi = &E->s.param_i[a * PHX_NPI];
+  int clock = e->clock++;
+  switch (E->s.kind[a]) {
+    case PHX_KIND_FACTORY:
+      if (m->type == PHX_MSG_STOCK_REQUEST) {                 /* supply_chain.py:40-45 */
+        network_send(E, e, a, m->src, PHX_MSG_STOCK_RESPONSE, mk_i(m->p.i));
+        return;
+      }
+      break;
+    case PHX_KIND_SHOP:
+      if (m->type == PHX_MSG_STOCK_RESPONSE) {                /* supply_chain.py:98-103 */
+        st->i[3] = (int32_t)m->p.i;                           /* delivered_stock */
+        int ns = st->i[0] + st->i[3];
+        st->i[0] = ns < SHOP_MAX_STOCK ? ns : SHOP_MAX_STOCK;
+        return;
+      }
+      if (m->type == PHX_MSG_ORDER_REQUEST) {                 /* supply_chain.py:105-122 */
+        int amount_requested = (int)m->p.i, stock_to_sell;
+        if (amount_requested > st->i[0]) {
+          st->i[2] += amount_requested - st->i[0];
+          stock_to_sell = st->i[0];
+          st->i[0] = 0;
+        } else {
+          stock_to_sell = amount_requested;
+          st->i[0] -= amount_requested;
+        }
+        st->i[1] += stock_to_sell;
+        network_send(E, e, a, m->src, PHX_MSG_ORDER_RESPONSE, mk_i(stock_to_sell));
+        return;
+      }
+      break;
+    case PHX_KIND_CUSTOMER:
+      if (m->type == PHX_MSG_ORDER_RESPONSE) return;          /* supply_chain.py:55-59 */
+      break;
+    case PHX_KIND_SELLER:
+      if (m->type == PHX_MSG_ORDER) {
+        double vol = (double)m->p.i;
+        double amount = st->f[0] * vol;                       /* self.revenue += self.price * vol */
+        st->f[1] = st->f[1] + amount;
+        st->i[0] += (int)m->p.i;
+        return;
+      }
+      break;
+    case PHX_KIND_BUYER:
+      if (m->type == PHX_MSG_PRICE) {
+        int slot = nbr_slot(E, a, m->src);
+        if (slot >= 0) st->vec[slot] = m->p.f;
+        return;
+      }
+      break;
+    case PHX_KIND_HALVER:
+      if (m->type == PHX_MSG_HALVE) {                         /* test_tracking.py:22-27 */
+        if (m->p.i > 1) {
+          int64_t v = m->p.i / 2;                             /* value // 2, value > 1 */
+          network_send(E, e, a, m->src, PHX_MSG_HALVE, mk_i(v));
+        }
+        return;
+      }
+      break;
+    case PHX_KIND_CASHBOX:
+      if (m->type == PHX_MSG_CASH) {                          /* test_network.py:26-34 */
+        if (m->p.f > 25) {
+          st->f[0] += m->p.f / 2.0;
+          network_send(E, e, a, m->src, PHX_MSG_CASH, mk_f(m->p.f / 2.0));
+        }
+        return;
+      }
+      break;
+    case PHX_KIND_REQRESP:
+      if (m->type == PHX_MSG_REQUEST) {                       /* test_resolver.py:31-37 */
+        st->i[0] = clock;                                     /* self.req_time = time.time() */
+        network_send(E, e, a, m->src, PHX_MSG_RESPONSE, mk_f(m->p.f / 2.0));
+        return;
+      }
+      if (m->type == PHX_MSG_RESPONSE) { st->i[1] = clock; return; }   /* :39-45 */
+      break;
+    case PHX_KIND_FORWARDER:                                  /* overrides handle_message test_resolver.py:93-96 */
+      if (pi[0] >= 0) network_send(E, e, a, pi[0], PHX_MSG_PING, mk_i(1));
+      return;
+    default: break;
+  }
+  set_err(e, PHX_ERR_UNKNOWN_MSG);                            /* raise ValueError agents.py:140-143 */
+}
+
+static void agent_encode_obs(const phxo_env* E, const oenv* e, int a, float* o) {
+  const ostate* st = &e->ag[a];
+  const int32_t* pi = &E->s.param_i[a * PHX_NPI];
+  switch (E->s.kind[a]) {
+    case PHX_KIND_SHOP: {                                     /* supply_chain.py:124-134 */
+      double max_sales_per_step = (double)pi[1];
+      o[0] = (float)((double)st->i[0] / (double)SHOP_MAX_STOCK);
+      o[1] = (float)((double)st->i[1] / max_sales_per_step);
+      o[2] = (float)((double)st->i[2] / max_sales_per_step);
+      break;
+    }
+    case PHX_KIND_SELLER: {
+      int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
+      o[0] = (float)((double)st->i[0] / (double)deg);
+      o[1] = (float)st->f[0];
+      break;
+    }
+    case PHX_KIND_BUYER: {
+      int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
+      double mn = st->vec[0];
+      for (int k = 1; k < deg; ++k) if (st->vec[k] < mn) mn = st->vec[k];
+      o[0] = (float)mn;
+      o[1] = (float)E->s.param_f[a * PHX_NPF + 0];
+      break;
+    }
+    case PHX_KIND_MOCK_STRAT:                                 /* tests/__init__.py:49-51 */
+      ((ostate*)st)->i[0] += 1;                               /* encode_obs_count */
+      o[0] = (float)((double)e->step / (double)E->s.num_steps);   /* views.py:33-34, env.py:168 */
+      break;
+    default: break;
+  }
+}
+
+static double agent_compute_reward(const phxo_env* E, oenv* e, int a) {
+  ostate* st = &e->ag[a];
+  switch (E->s.kind[a]) {
+    case PHX_KIND_SHOP: {                                     /* supply_chain.py:144-147 */
+      volatile double penalty = 0.1 * (double)st->i[0];       /* volatile: no fma contraction */
+      return (double)st->i[1] - penalty;
+    }
+    case PHX_KIND_SELLER: return st->f[1];
+    case PHX_KIND_BUYER:
+      if (st->i[0]) return E->s.param_f[a * PHX_NPF + 0] - st->f[0];
+      return 0.0;
+    case PHX_KIND_MOCK_STRAT: st->i[2] += 1; return 0.0;      /* tests/__init__.py:57-59 */
+    default: return 0.0;
+  }
+}
+static int agent_is_terminated(const phxo_env* E, const oenv* e, int a) {
+  if (E->s.kind[a] == PHX_KIND_MOCK_STRAT)                    /* tests/__init__.py:61-62 */
+    return e->step == E->s.param_i[a * PHX_NPI + 0];
+  return 0;                                                   /* agents.py:292-307 */
+}
+static int agent_is_truncated(const phxo_env* E, const oenv* e, int a) {
+  if (E->s.kind[a] == PHX_KIND_MOCK_STRAT)                    /* tests/__init__.py:64-65 */
+    return e->step == E->s.param_i[a * PHX_NPI + 0];
+  return 0;                                                   /* agents.py:309-323 */
+}
+
+/* ---- resolver ---------------------------------------------------------------------------- */
+
+/* BatchResolver.resolve resolvers.py:128-163; `live` = receiver_id in contexts */
+static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
+  e->round = 0;
+  for (int i = 0;; ++i) {
+    if (E->s.round_limit >= 0 && i >= E->s.round_limit) break;        /* range(round_limit) :129-131 */
+    oinbox* proc = &e->box[e->cur];
+    if (proc->n_recv == 0) break;                                     /* :134-135 */
+    e->cur ^= 1;                                                      /* self.messages = defaultdict(list) :139-140 */
+    inbox_clear(E, &e->box[e->cur]);
+    e->round = i + 1;
+    for (int r = 0; r < proc->n_recv; ++r) {                          /* dict order :142 */
+      int receiver = proc->order[r];
+      if (!live[receiver]) continue;                                  /* :143-144 */
+      for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) {
+        const omsg* m = &proc->pool[id];
+        if (!has_edge(E, m->src, m->dst)) continue;                   /* :146-148 */
+        agent_handle_message(E, e, receiver, m);                      /* handle_batch agents.py:96-120 */
+      }
+    }
+  }
+  if (e->box[e->cur].n_recv > 0) set_err(e, PHX_ERR_ROUND_LIMIT);     /* :160-163 */
+  inbox_clear(E, &e->box[e->cur]);                                    /* Network.resolve -> resolver.reset network.py:265 */
+}
+
+/* PhantomEnv.is_terminated / is_truncated env.py:308-318 */
+static int env_is_terminated(const phxo_env* E, const oenv* e) {
+  int n = 0; for (int s = 0; s < E->S; ++s) n += e->term[s];
+  return n == E->S;
+}
+static int env_is_truncated(const phxo_env* E, const oenv* e) {
+  int n = 0; for (int s = 0; s < E->S; ++s) n += e->trunc[s];
+  return (e->step == E->s.num_steps) || n == E->S;
+}
+
+static void env_reset_one(const phxo_env* E, oenv* e, float* obs, uint8_t* obs_valid) {
+  /* PhantomEnv.reset env.py:185-237; fsm.py:195-251; stackelberg.py:53-109 */
+  e->step = 0;
+  if (E->s.env_type == PHX_ENV_FSM) e->stage = E->s.initial_stage;    /* fsm.py:217 */
+  inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]); e->cur = 0; /* network.reset -> resolver.reset */
+  for (int a = 0; a < E->A; ++a) agent_reset(E, e, a);                /* network.py:183-184 */
+  memset(e->term, 0, E->S); memset(e->trunc, 0, E->S);                /* env.py:223-224 */
+  e->err = 0;
+  if (E->s.env_type != PHX_ENV_PLAIN)                                 /* fsm.py:234 / stackelberg.py:92 */
+    memset(e->rew_cache_valid, 0, E->S);
+  if (obs_valid) memset(obs_valid, 0, E->S);
+  if (obs) memset(obs, 0, sizeof(float) * E->S * E->D);
+  if (!obs) return;
+  if (E->s.env_type == PHX_ENV_PLAIN) {                               /* env.py:227-237 */
+    for (int s = 0; s < E->S; ++s) {
+      agent_encode_obs(E, e, E->strat_idx[s], obs + s * E->D);
+      if (obs_valid) obs_valid[s] = 1;
+    }
+  } else if (E->s.env_type == PHX_ENV_FSM) {                          /* fsm.py:237-251 */
+    int st = e->stage;
+    for (int k = E->s.stage_act_ptr[st]; k < E->s.stage_act_ptr[st + 1]; ++k) {
+      int a = E->s.stage_act_idx[k], s = E->strat_rank[a];
+      if (s < 0) continue;
+      agent_encode_obs(E, e, a, obs + s * E->D);
+      if (obs_valid) obs_valid[s] = 1;
+    }
+  } else {                                                            /* stackelberg.py:95-109 */
+    for (int k = 0; k < E->s.n_leaders; ++k) {
+      int a = E->s.leaders[k], s = E->strat_rank[a];
+      if (s < 0) continue;
+      agent_encode_obs(E, e, a, obs + s * E->D);
+      if (obs_valid) obs_valid[s] = 1;
+    }
+  }
+}
+
+static int in_list(const int32_t* lst, int n, int a) {
+  for (int k = 0; k < n; ++k) if (lst[k] == a) return 1;
+  return 0;
+}
+
+/* one env, one step.  out pointers address THIS env's rows. */
+static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions,
+                         const uint8_t* action_valid, const uint8_t* exo_b, float* obs,
+                         uint8_t* obs_valid, double* reward, uint8_t* reward_valid,
+                         uint8_t* terminated, uint8_t* truncated, uint8_t* done_valid,
+                         uint8_t* all_term, uint8_t* all_trunc) {
+  const int A = E->A, S = E->S, D = E->D;
+  e->step += 1;                                                       /* env.py:252 */
+
+  /* _make_ctxs env.py:338-348: contexts exist for agents that are not done */
+  uint8_t* live = (uint8_t*)alloca(A);
+  for (int a = 0; a < A; ++a) {
+    int s = E->strat_rank[a];
+    live[a] = (s < 0) ? 1 : !(e->term[s] || e->trunc[s]);
+  }
+  uint8_t* live0 = (uint8_t*)alloca(S);
+  for (int s = 0; s < S; ++s) live0[s] = live[E->strat_idx[s]];
+
+  /* which agents act, in which order */
+  const int32_t* act_list = NULL; int n_act = 0;
+  const int32_t* next_act_list = NULL; int n_next_act = 0;
+  int cur_stage = 0, next_stage = 0;
+  if (E->s.env_type == PHX_ENV_FSM) {                                 /* fsm.py:276-277 */
+    cur_stage = e->stage;
+    act_list = E->s.stage_act_idx + E->s.stage_act_ptr[cur_stage];
+    n_act = E->s.stage_act_ptr[cur_stage + 1] - E->s.stage_act_ptr[cur_stage];
+  } else if (E->s.env_type == PHX_ENV_STACKELBERG) {                  /* stackelberg.py:133-137 */
+    if (e->step % 2 == 1) { act_list = E->s.leaders; n_act = E->s.n_leaders;
+                            next_act_list = E->s.followers; n_next_act = E->s.n_followers; }
+    else { act_list = E->s.followers; n_act = E->s.n_followers;
+           next_act_list = E->s.leaders; n_next_act = E->s.n_leaders; }
+  }
+
+  /* injected Network.send calls made before the step are already in the inbox */
+  /* _handle_acting_agents env.py:320-336 */
+  int n_iter = (E->s.env_type == PHX_ENV_PLAIN) ? A : n_act;
+  for (int k = 0; k < n_iter; ++k) {
+    int a = (E->s.env_type == PHX_ENV_PLAIN) ? k : act_list[k];
+    if (!live[a]) continue;                                           /* :324-325 */
+    int s = E->strat_rank[a];
+    int has_action = (s >= 0) && actions && (!action_valid || action_valid[s]);   /* aid in actions :330 */
+    agent_act(E, e, b, a, has_action, has_action ? actions[s] : 0.0f, exo_b);
+  }
+
+  /* resolve_network env.py:180-183 */
+  for (int a = 0; a < A; ++a) if (live[a]) agent_pre_resolution(E, e, a);     /* :170-173 */
+  batch_resolve(E, e, live);                                                   /* network.py:256-265 */
+  /* post_message_resolution: no kind overrides it (agents.py:93-94) */
+
+  if (E->s.env_type == PHX_ENV_FSM) next_stage = E->s.stage_next[cur_stage];  /* fsm.py:281-292 */
+
+  memset(obs_valid, 0, S); memset(reward_valid, 0, S); memset(done_valid, 0, S);
+  memset(terminated, 0, S); memset(truncated, 0, S);
+  memset(obs, 0, sizeof(float) * S * D);
+  for (int s = 0; s < S; ++s) reward[s] = 0.0;
+  uint8_t* observed = (uint8_t*)alloca(S); memset(observed, 0, S);
+
+  for (int s = 0; s < S; ++s) {                                       /* env.py:273 / fsm.py:320 / stackelberg.py:150 */
+    int a = E->strat_idx[s];
+    if (!live0[s]) continue;                                          /* env.py:274-275 */
+    int do_obs, do_rew;
+    if (E->s.env_type == PHX_ENV_PLAIN) { do_obs = 1; do_rew = 1; }
+    else if (E->s.env_type == PHX_ENV_FSM) {
+      if (E->s.stage_rewarded_all[cur_stage]) { do_obs = 1; do_rew = 1; }     /* fsm.py:315-317 */
+      else {
+        do_rew = E->s.stage_rewarded[cur_stage * A + a];                      /* :319 */
+        do_obs = in_list(E->s.stage_act_idx + E->s.stage_act_ptr[next_stage], /* :320 */
+                         E->s.stage_act_ptr[next_stage + 1] - E->s.stage_act_ptr[next_stage], a);
+      }
+    } else {
+      do_obs = in_list(next_act_list, n_next_act, a);                 /* stackelberg.py:156 */
+      do_rew = in_list(act_list, n_act, a);                           /* :162 */
+    }
+    if (do_obs) {
+      agent_encode_obs(E, e, a, obs + s * D);                         /* obs is never None for these kinds */
+      observed[s] = 1;
+    }
+    if (E->s.env_type == PHX_ENV_PLAIN) {
+      reward[s] = agent_compute_reward(E, e, a);                      /* env.py:283 */
+      reward_valid[s] = 1;
+    } else if (do_rew) {
+      e->rew_cache[s] = agent_compute_reward(E, e, a);                /* fsm.py:335,350 / stackelberg.py:163 */
+      e->rew_cache_valid[s] = 1;
+    }
+    terminated[s] = (uint8_t)agent_is_terminated(E, e, a);            /* env.py:285-286 */
+    truncated[s] = (uint8_t)agent_is_truncated(E, e, a);
+    done_valid[s] = 1;
+    if (terminated[s]) e->term[s] = 1;                                /* :288-292 */
+    if (truncated[s]) e->trunc[s] = 1;
+  }
+
+  if (E->s.env_type == PHX_ENV_FSM) {
+    for (int s = 0; s < S; ++s) if (observed[s]) {                    /* self._observations.update fsm.py:349 */
+      memcpy(e->obs_cache + s * D, obs + s * D, sizeof(float) * D);
+      e->obs_cache_valid[s] = 1;
+    }
+    e->prev_stage = cur_stage; e->stage = next_stage;                 /* fsm.py:355 */
+  }
+
+  *all_term = (uint8_t)env_is_terminated(E, e);                       /* env.py:297 */
+  *all_trunc = (uint8_t)env_is_truncated(E, e);                       /* env.py:298 */
+  int terminal = *all_term || *all_trunc;
+
+  if (E->s.env_type == PHX_ENV_PLAIN) {
+    for (int s = 0; s < S; ++s) obs_valid[s] = observed[s];
+  } else if (E->s.env_type == PHX_ENV_FSM) {
+    if (terminal) {                                                   /* fsm.py:360-375: cached dicts of ALL agents */
+      for (int s = 0; s < S; ++s) {
+        obs_valid[s] = e->obs_cache_valid[s];
+        if (obs_valid[s]) memcpy(obs + s * D, e->obs_cache + s * D, sizeof(float) * D);
+        else memset(obs + s * D, 0, sizeof(float) * D);
+        reward_valid[s] = e->rew_cache_valid[s] ? 1 : 2;
+        reward[s] = e->rew_cache_valid[s] ? e->rew_cache[s] : 0.0;
+      }
+    } else {                                                          /* fsm.py:378 */
+      for (int s = 0; s < S; ++s) {
+        obs_valid[s] = observed[s];
+        if (observed[s]) {
+          reward_valid[s] = e->rew_cache_valid[s] ? 1 : 2;
+          reward[s] = e->rew_cache_valid[s] ? e->rew_cache[s] : 0.0;
+        }
+      }
+    }
+  } else {
+    for (int s = 0; s < S; ++s) obs_valid[s] = observed[s];
+    if (terminal) {                                                   /* stackelberg.py:180-187 */
+      for (int s = 0; s < S; ++s) {
+        reward_valid[s] = e->rew_cache_valid[s] ? 1 : 2;
+        reward[s] = e->rew_cache_valid[s] ? e->rew_cache[s] : 0.0;
+      }
+    } else {                                                          /* :190-194 */
+      for (int s = 0; s < S; ++s)
+        if (observed[s] && e->rew_cache_valid[s]) { reward_valid[s] = 1; reward[s] = e->rew_cache[s]; }
+    }
+  }
+  e->tick += 1;
+}
+
+/* ---- construction -------------------------------------------------------------------------- */
+static void* dup_arr(const void* p, size_t n) {
+  if (!p || !n) return NULL;
+  void* q = malloc(n); memcpy(q, p, n); return q;
+}
+
+static int inbox_alloc(const phxo_env* E, oinbox* b) {
+  int cap = E->s.queue_cap > 0 ? E->s.queue_cap : 1;
+  b->pool = (omsg*)calloc(cap, sizeof(omsg));
+  b->next = (int*)calloc(cap, sizeof(int));
+  b->order = (int*)calloc(E->A, sizeof(int));
+  b->head = (int*)calloc(E->A, sizeof(int));
+  b->tail = (int*)calloc(E->A, sizeof(int));
+  return b->pool && b->next && b->order && b->head && b->tail;
+}
+
+phxo_env* phxo_create(const phx_spec* sp) {
+  if (!sp || sp->abi_version != PHX_ABI_VERSION || sp->n_agents <= 0 || sp->batch <= 0) {
+    snprintf(g_err, sizeof g_err, "bad spec"); return NULL;
+  }
+  phxo_env* E = (phxo_env*)calloc(1, sizeof *E);
+  E->s = *sp; E->A = sp->n_agents; E->B = sp->batch;
+  const int A = E->A;
+  E->nnz = sp->row_ptr[A];
+  E->s.kind = (const uint8_t*)dup_arr(sp->kind, A);
+  E->s.param_i = (const int32_t*)dup_arr(sp->param_i, sizeof(int32_t) * A * PHX_NPI);
+  E->s.param_f = (const double*)dup_arr(sp->param_f, sizeof(double) * A * PHX_NPF);
+  E->s.row_ptr = (const int32_t*)dup_arr(sp->row_ptr, sizeof(int32_t) * (A + 1));
+  E->s.col = (const int32_t*)dup_arr(sp->col, sizeof(int32_t) * (E->nnz ? E->nnz : 1));
+  if (sp->env_type == PHX_ENV_FSM) {
+    int ns = sp->n_stages;
+    E->s.stage_act_ptr = (const int32_t*)dup_arr(sp->stage_act_ptr, sizeof(int32_t) * (ns + 1));
+    int na = sp->stage_act_ptr[ns];
+    E->s.stage_act_idx = (const int32_t*)dup_arr(sp->stage_act_idx, sizeof(int32_t) * (na ? na : 1));
+    E->s.stage_rewarded = (const uint8_t*)dup_arr(sp->stage_rewarded, (size_t)ns * A);
+    E->s.stage_rewarded_all = (const uint8_t*)dup_arr(sp->stage_rewarded_all, ns);
+    E->s.stage_next = (const int32_t*)dup_arr(sp->stage_next, sizeof(int32_t) * ns);
+  }
+  if (sp->env_type == PHX_ENV_STACKELBERG) {
+    E->s.leaders = (const int32_t*)dup_arr(sp->leaders, sizeof(int32_t) * (sp->n_leaders ? sp->n_leaders : 1));
+    E->s.followers = (const int32_t*)dup_arr(sp->followers, sizeof(int32_t) * (sp->n_followers ? sp->n_followers : 1));
+  }
+  E->strat_rank = (int*)calloc(A, sizeof(int));
+  E->kind_rank = (int*)calloc(A, sizeof(int));
+  E->exo_rank = (int*)calloc(A, sizeof(int));
+  E->strat_idx = (int*)calloc(A, sizeof(int));
+  int S = 0, D = 0, nx = 0;
+  for (int a = 0; a < A; ++a) {
+    int k = E->s.kind[a];
+    if (k <= 0 || k >= PHX_KIND_COUNT) { snprintf(g_err, sizeof g_err, "bad kind"); return NULL; }
+    E->kind_rank[a] = E->kind_count[k]++;
+    if (is_strategic_kind(k)) {                                       /* isinstance(a, StrategicAgent) env.py:151-159 */
+      E->strat_rank[a] = S; E->strat_idx[S++] = a;
+      if (obs_dim_of_kind(k) > D) D = obs_dim_of_kind(k);
+    } else E->strat_rank[a] = -1;
+    E->exo_rank[a] = (k == PHX_KIND_CUSTOMER) ? nx++ : -1;
+  }
+  E->S = S; E->D = D > 0 ? D : 1; E->n_exo = nx;
+  E->env = (oenv*)calloc(E->B, sizeof(oenv));
+  for (int b = 0; b < E->B; ++b) {
+    oenv* e = &E->env[b];
+    e->ag = (ostate*)calloc(A, sizeof(ostate));
+    e->vecpool = (double*)calloc(E->nnz ? E->nnz : 1, sizeof(double));
+    for (int a = 0; a < A; ++a) e->ag[a].vec = e->vecpool + E->s.row_ptr[a];
+    e->term = (uint8_t*)calloc(S ? S : 1, 1); e->trunc = (uint8_t*)calloc(S ? S : 1, 1);
+    e->rew_cache = (double*)calloc(S ? S : 1, sizeof(double));
+    e->rew_cache_valid = (uint8_t*)calloc(S ? S : 1, 1);
+    e->obs_cache = (float*)calloc((size_t)(S ? S : 1) * E->D, sizeof(float));
+    e->obs_cache_valid = (uint8_t*)calloc(S ? S : 1, 1);
+    if (!inbox_alloc(E, &e->box[0]) || !inbox_alloc(E, &e->box[1])) return NULL;
+    inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]);
+    e->stage = sp->initial_stage; e->prev_stage = -1;
+    for (int a = 0; a < A; ++a) agent_reset(E, e, a);                 /* env.py:122-124 */
+  }
+  return E;
+}
+
+void phxo_destroy(phxo_env* E) {
+  if (!E) return;
+  for (int b = 0; b < E->B; ++b) {
+    oenv* e = &E->env[b];
+    free(e->ag); free(e->vecpool); free(e->term); free(e->trunc); free(e->rew_cache);
+    free(e->rew_cache_valid); free(e->obs_cache); free(e->obs_cache_valid);
+    for (int k = 0; k < 2; ++k) {
+      free(e->box[k].pool); free(e->box[k].next); free(e->box[k].order);
+      free(e->box[k].head); free(e->box[k].tail);
+    }
+  }
+  free(E->env); free(E->strat_rank); free(E->kind_rank); free(E->exo_rank); free(E->strat_idx);
+  free(E->injected);
+  free((void*)E->s.kind); free((void*)E->s.param_i); free((void*)E->s.param_f);
+  free((void*)E->s.row_ptr); free((void*)E->s.col);
+  if (E->s.env_type == PHX_ENV_FSM) {
+    free((void*)E->s.stage_act_ptr); free((void*)E->s.stage_act_idx);
+    free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next);
+  }
+  if (E->s.env_type == PHX_ENV_STACKELBERG) { free((void*)E->s.leaders); free((void*)E->s.followers); }
+  free(E);
+}
+
+int phxo_obs_dim(const phxo_env* E) { return E->D; }
+int phxo_n_strategic(const phxo_env* E) { return E->S; }
+int phxo_n_exo(const phxo_env* E) { return E->n_exo; }
+
+/* ---- batch entry points ---------------------------------------------------------------------- */
+void phxo_reset(phxo_env* E, const uint8_t* mask, float* obs, uint8_t* obs_valid) {
+  const int S = E->S, D = E->D;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int b = 0; b < E->B; ++b) {
+    if (mask && !mask[b]) continue;
+    env_reset_one(E, &E->env[b], obs ? obs + (size_t)b * S * D : NULL,
+                  obs_valid ? obs_valid + (size_t)b * S : NULL);
+  }
+}
+
+static void apply_injected(const phxo_env* E, oenv* e) {
+  for (int k = 0; k < E->n_injected; ++k) {
+    const omsg* m = &E->injected[k];
+    network_send(E, e, m->src, m->dst, m->type, *m);                  /* n.send(...) from test code */
+  }
+}
+
+void phxo_inject(phxo_env* E, const phx_msg_rec* msgs, int n) {
+  E->injected = (omsg*)realloc(E->injected, sizeof(omsg) * (E->n_injected + n + 1));
+  for (int k = 0; k < n; ++k) {
+    omsg m; memset(&m, 0, sizeof m);
+    m.src = msgs[k].sender; m.dst = msgs[k].receiver; m.type = msgs[k].type; m.p.i = msgs[k].payload.i;
+    E->injected[E->n_injected++] = m;
+  }
+}
+
+void phxo_step(phxo_env* E, const phx_step_io* io) {
+  const int S = E->S, D = E->D;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int b = 0; b < E->B; ++b) {
+    oenv* e = &E->env[b];
+    e->log = io->msg_log ? io->msg_log + (size_t)b * E->s.trace_cap : NULL;
+    e->log_cap = E->s.trace_cap;
+    e->err = io->err ? io->err[b] : 0;
+    e->log_n = 0; e->round = 0;
+    apply_injected(E, e);
+    uint8_t at = 0, au = 0;
+    env_step_one(E, e, b, io->actions ? io->actions + (size_t)b * S : NULL,
+                 io->action_valid ? io->action_valid + (size_t)b * S : NULL,
+                 io->exo ? io->exo + (size_t)b * E->n_exo : NULL,
+                 io->obs + (size_t)b * S * D, io->obs_valid + (size_t)b * S,
+                 io->reward + (size_t)b * S, io->reward_valid + (size_t)b * S,
+                 io->terminated + (size_t)b * S, io->truncated + (size_t)b * S,
+                 io->done_valid + (size_t)b * S, &at, &au);
+    io->all_terminated[b] = at; io->all_truncated[b] = au;
+    if (io->err) io->err[b] = e->err;
+    if (io->msg_count) io->msg_count[b] = e->log_n;
+  }
+  E->n_injected = 0;
+}
+
+void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count) {
+  uint8_t* live = (uint8_t*)malloc(E->A); memset(live, 1, E->A);     /* contexts for every agent */
+  for (int b = 0; b < E->B; ++b) {
+    oenv* e = &E->env[b];
+    e->log = msg_log ? msg_log + (size_t)b * E->s.trace_cap : NULL;
+    e->log_cap = E->s.trace_cap; e->log_n = 0; e->round = 0;
+    e->err = err ? err[b] : 0;
+    apply_injected(E, e);
+    batch_resolve(E, e, live);
+    if (err) err[b] = e->err;
+    if (msg_count) msg_count[b] = e->log_n;
+  }
+  free(live);
+  E->n_injected = 0;
+}
+
+/* rollout = the list-of-envs loop of utils/rllib/rollout.py:361-363, with the caller's
+ * reset-after-num_steps folded in (auto-reset at the end of the terminal step).          */
+static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
+  const int S = E->S, D = E->D, B = E->B, T = io->T;
+  oenv* e = &E->env[b];
+  float* act = (float*)alloca(sizeof(float) * (S ? S : 1));
+  float* o = (float*)alloca(sizeof(float) * (S ? S : 1) * D);
+  double* rw = (double*)alloca(sizeof(double) * (S ? S : 1));
+  uint8_t* u8 = (uint8_t*)alloca(5 * (S ? S : 1));
+  e->log = NULL; e->err = io->err ? io->err[b] : 0;
+  for (int t = 0; t < T; ++t) {
+    for (int s = 0; s < S; ++s)
+      act[s] = io->actions ? io->actions[((size_t)t * B + b) * S + s]
+                           : phxo_rng_action(E->s.seed, E->s.env_offset + b, e->tick, s);
+    uint8_t at = 0, au = 0;
+    env_step_one(E, e, b, act, NULL, io->exo ? io->exo + ((size_t)t * B + b) * E->n_exo : NULL,
+                 o, u8, rw, u8 + S, u8 + 2 * S, u8 + 3 * S, u8 + 4 * S, &at, &au);
+    size_t base = ((size_t)t * B + b) * S;
+    for (int s = 0; s < S; ++s) {
+      for (int d = 0; d < D; ++d) io->obs[(base + s) * D + d] = o[s * D + d];
+      io->action_out[base + s] = act[s];
+      io->reward[base + s] = (float)rw[s];
+      io->terminated[base + s] = (uint8_t)(u8[2 * S + s] | at);
+      io->truncated[base + s] = (uint8_t)(u8[3 * S + s] | au);
+    }
+    if (at || au) env_reset_one(E, e, o, u8);                         /* caller's env.reset() */
+  }
+  if (io->last_obs) memcpy(io->last_obs + (size_t)b * S * D, o, sizeof(float) * S * D);
+  if (io->err) io->err[b] = e->err;
+}
+
+void phxo_rollout(phxo_env* E, const phx_rollout_io* io) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (int b = 0; b < E->B; ++b) rollout_one(E, io, b);
+}
+
+/* ---- state read-back -------------------------------------------------------------------------- */
+typedef struct { const char* name; int kind; int is_f; int slot; } ofield;
+static const ofield FIELDS[] = {
+  {"shop.stock", PHX_KIND_SHOP, 0, 0}, {"shop.sales", PHX_KIND_SHOP, 0, 1},
+  {"shop.missed_sales", PHX_KIND_SHOP, 0, 2}, {"shop.delivered_stock", PHX_KIND_SHOP, 0, 3},
+  {"seller.tx", PHX_KIND_SELLER, 0, 0}, {"seller.price", PHX_KIND_SELLER, 1, 0},
+  {"seller.revenue", PHX_KIND_SELLER, 1, 1},
+  {"buyer.bought", PHX_KIND_BUYER, 0, 0}, {"buyer.paid", PHX_KIND_BUYER, 1, 0},
+  {"cashbox.total_cash", PHX_KIND_CASHBOX, 1, 0},
+  {"reqresp.req_time", PHX_KIND_REQRESP, 0, 0}, {"reqresp.res_time", PHX_KIND_REQRESP, 0, 1},
+  {"mock.encode_obs_count", PHX_KIND_MOCK_STRAT, 0, 0},
+  {"mock.decode_action_count", PHX_KIND_MOCK_STRAT, 0, 1},
+  {"mock.compute_reward_count", PHX_KIND_MOCK_STRAT, 0, 2},
+};
+static const ofield* find_field(const char* n) {
+  for (size_t k = 0; k < sizeof FIELDS / sizeof FIELDS[0]; ++k)
+    if (!strcmp(FIELDS[k].name, n)) return &FIELDS[k];
+  return NULL;
+}
+
+int64_t phxo_get_i32(const phxo_env* E, const char* field, int32_t* out) {
+  if (!strcmp(field, "env.step")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].step; return E->B; }
+  if (!strcmp(field, "env.stage")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].stage; return E->B; }
+  if (!strcmp(field, "env.prev_stage")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].prev_stage; return E->B; }
+  if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) out[b] = (int32_t)E->env[b].tick; return E->B; }
+  const ofield* f = find_field(field);
+  if (!f || f->is_f) return -1;
+  int n = E->kind_count[f->kind];
+  for (int b = 0; b < E->B; ++b)
+    for (int a = 0; a < E->A; ++a)
+      if (E->s.kind[a] == f->kind) out[(size_t)b * n + E->kind_rank[a]] = E->env[b].ag[a].i[f->slot];
+  return (int64_t)E->B * n;
+}
+int64_t phxo_set_i32(phxo_env* E, const char* field, const int32_t* in) {
+  if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) E->env[b].tick = (uint32_t)in[b]; return E->B; }
+  const ofield* f = find_field(field);
+  if (!f || f->is_f) return -1;
+  int n = E->kind_count[f->kind];
+  for (int b = 0; b < E->B; ++b)
+    for (int a = 0; a < E->A; ++a)
+      if (E->s.kind[a] == f->kind) E->env[b].ag[a].i[f->slot] = in[(size_t)b * n + E->kind_rank[a]];
+  return (int64_t)E->B * n;
+}
+int64_t phxo_get_f64(const phxo_env* E, const char* field, double* out) {
+  if (!strcmp(field, "buyer.prices")) {
+    /* [B][nnz-of-buyers] flattened in agent order */
+    size_t w = 0;
+    for (int b = 0; b < E->B; ++b)
+      for (int a = 0; a < E->A; ++a)
+        if (E->s.kind[a] == PHX_KIND_BUYER)
+          for (int k = 0; k < E->s.row_ptr[a + 1] - E->s.row_ptr[a]; ++k) out[w++] = E->env[b].ag[a].vec[k];
+    return (int64_t)w;
+  }
+  const ofield* f = find_field(field);
+  if (!f || !f->is_f) return -1;
+  int n = E->kind_count[f->kind];
+  for (int b = 0; b < E->B; ++b)
+    for (int a = 0; a < E->A; ++a)
+      if (E->s.kind[a] == f->kind) out[(size_t)b * n + E->kind_rank[a]] = E->env[b].ag[a].f[f->slot];
+  return (int64_t)E->B * n;
+}
