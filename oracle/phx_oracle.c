@@ -303,10 +303,9 @@ static void agent_pre_resolution(const phxo_env* E, oenv* e, int a) {
 }
 
 /* Agent.handle_message agents.py:122-155 -- type dispatch to the @msg_handler methods */
-static void agent_handle_message(const phxo_env* E, oenv* e, int a, const omsg* m) {
+static void agent_handle_message(const phxo_env* E, oenv* e, int a, const omsg* m, int clock) {
   ostate* st = &e->ag[a];
   const int32_t* pi = &E->s.param_i[a * PHX_NPI];
-  int clock = e->clock++;
   switch (E->s.kind[a]) {
     case PHX_KIND_FACTORY:
       if (m->type == PHX_MSG_STOCK_REQUEST) {                 /* supply_chain.py:40-45 */
@@ -462,11 +461,14 @@ static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
     e->round = i + 1;
     for (int r = 0; r < proc->n_recv; ++r) {                          /* dict order :142 */
       int receiver = proc->order[r];
-      if (!live[receiver]) continue;                                  /* :143-144 */
       for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) {
+        /* logical time = position of the message in the processing order, counting every
+         * queued message whether it is handled or dropped (stands in for time.time()) */
+        int clock = e->clock++;
+        if (!live[receiver]) continue;                                /* :143-144 */
         const omsg* m = &proc->pool[id];
         if (!has_edge(E, m->src, m->dst)) continue;                   /* :146-148 */
-        agent_handle_message(E, e, receiver, m);                      /* handle_batch agents.py:96-120 */
+        agent_handle_message(E, e, receiver, m, clock);               /* handle_batch agents.py:96-120 */
       }
     }
   }

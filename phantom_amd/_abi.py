@@ -1,0 +1,132 @@
+"""ctypes mirror of include/phantom_amd.h and the loader of libphantom_amd.so.
+
+The product path has no CPU fallback: if the HIP library is missing, ``load_library`` raises.
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+NPI, NPF = 4, 2
+
+# phx_kind
+KIND_FACTORY, KIND_SHOP, KIND_CUSTOMER, KIND_SELLER, KIND_BUYER = 1, 2, 3, 4, 5
+KIND_HALVER, KIND_CASHBOX, KIND_REQRESP, KIND_FORWARDER = 6, 7, 8, 9
+KIND_MOCK_STRAT, KIND_MOCK_AGENT = 10, 11
+KIND_NAMES = {1: "factory", 2: "shop", 3: "customer", 4: "seller", 5: "buyer", 6: "halver",
+              7: "cashbox", 8: "reqresp", 9: "forwarder", 10: "mock", 11: "mock_agent"}
+STRATEGIC_KINDS = (KIND_SHOP, KIND_SELLER, KIND_BUYER, KIND_MOCK_STRAT)
+OBS_DIM = {KIND_SHOP: 3, KIND_SELLER: 2, KIND_BUYER: 2, KIND_MOCK_STRAT: 1}
+
+# phx_msg_type
+(MSG_STOCK_REQUEST, MSG_STOCK_RESPONSE, MSG_ORDER_REQUEST, MSG_ORDER_RESPONSE, MSG_PRICE,
+ MSG_ORDER, MSG_HALVE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE, MSG_PING) = range(1, 12)
+FLOAT_PAYLOAD_TYPES = (MSG_PRICE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE)
+
+ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
+F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC = 1, 2, 4
+
+ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL = range(6)
+
+_u8p, _i32p, _f32p, _f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                             C.POINTER(C.c_double))
+
+
+class PhxSpec(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_agents", C.c_int32), ("batch", C.c_int32),
+        ("num_steps", C.c_int32), ("round_limit", C.c_int32), ("env_type", C.c_int32),
+        ("flags", C.c_uint32), ("queue_cap", C.c_int32), ("trace_cap", C.c_int32),
+        ("kind", C.c_void_p), ("param_i", C.c_void_p), ("param_f", C.c_void_p),
+        ("row_ptr", C.c_void_p), ("col", C.c_void_p),
+        ("n_stages", C.c_int32), ("initial_stage", C.c_int32),
+        ("stage_act_ptr", C.c_void_p), ("stage_act_idx", C.c_void_p),
+        ("stage_rewarded", C.c_void_p), ("stage_rewarded_all", C.c_void_p),
+        ("stage_next", C.c_void_p),
+        ("n_leaders", C.c_int32), ("n_followers", C.c_int32),
+        ("leaders", C.c_void_p), ("followers", C.c_void_p),
+        ("seed", C.c_uint64), ("env_offset", C.c_int64),
+    ]
+
+
+class PhxField(C.Structure):
+    _fields_ = [("field_id", C.c_int32), ("dtype", C.c_int32), ("offset", C.c_int64),
+                ("dim0", C.c_int32), ("dim1", C.c_int32), ("dim2", C.c_int32),
+                ("kind", C.c_int32), ("name", C.c_char * 24)]
+
+
+class _Payload(C.Union):
+    _fields_ = [("i", C.c_int64), ("f", C.c_double)]
+
+
+class PhxMsgRec(C.Structure):
+    _fields_ = [("sender", C.c_uint16), ("receiver", C.c_uint16), ("type", C.c_uint16),
+                ("round", C.c_uint16), ("payload", _Payload)]
+
+
+class PhxStepIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "actions", "action_valid", "exo", "obs", "obs_valid", "reward", "reward_valid",
+        "terminated", "truncated", "done_valid", "all_terminated", "all_truncated", "err",
+        "msg_log", "msg_count")]
+
+
+class PhxRolloutIO(C.Structure):
+    _fields_ = [("T", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "last_obs",
+        "err")]
+
+
+assert C.sizeof(PhxMsgRec) == 16
+
+_LIB = None
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libphantom_amd.so")
+
+EXPORTS = ("phx_abi_version", "phx_last_error", "phx_state_nbytes", "phx_obs_dim",
+           "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",
+           "phx_field_info", "phx_uses_fused", "phx_reset", "phx_step", "phx_inject",
+           "phx_resolve", "phx_rollout")
+
+
+def load_library():
+    """Load libphantom_amd.so (built in-tree by ``phantom_amd.build``); never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback).")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.phx_abi_version.restype = i32
+    lib.phx_last_error.restype = C.c_char_p
+    lib.phx_state_nbytes.restype = i64
+    lib.phx_state_nbytes.argtypes = [C.POINTER(PhxSpec)]
+    for n in ("phx_obs_dim", "phx_n_strategic", "phx_n_exo"):
+        getattr(lib, n).restype = i32
+        getattr(lib, n).argtypes = [C.POINTER(PhxSpec)]
+    lib.phx_create.restype = i32
+    lib.phx_create.argtypes = [C.POINTER(PhxSpec), i32, vp, i64, C.POINTER(vp)]
+    lib.phx_destroy.restype = None
+    lib.phx_destroy.argtypes = [vp]
+    lib.phx_n_fields.restype = i32
+    lib.phx_n_fields.argtypes = [vp]
+    lib.phx_field_info.restype = i32
+    lib.phx_field_info.argtypes = [vp, i32, C.POINTER(PhxField)]
+    lib.phx_uses_fused.restype = i32
+    lib.phx_uses_fused.argtypes = [vp]
+    lib.phx_reset.restype = i32
+    lib.phx_reset.argtypes = [vp, vp, vp, vp, vp]
+    lib.phx_step.restype = i32
+    lib.phx_step.argtypes = [vp, C.POINTER(PhxStepIO), vp]
+    lib.phx_inject.restype = i32
+    lib.phx_inject.argtypes = [vp, C.POINTER(PhxMsgRec), i32]
+    lib.phx_resolve.restype = i32
+    lib.phx_resolve.argtypes = [vp, vp, vp, vp, vp]
+    lib.phx_rollout.restype = i32
+    lib.phx_rollout.argtypes = [vp, C.POINTER(PhxRolloutIO), vp]
+    if lib.phx_abi_version() != ABI_VERSION:
+        raise RuntimeError("libphantom_amd.so ABI version mismatch")
+    _LIB = lib
+    return lib

@@ -1,0 +1,291 @@
+"""DeviceEnv: the thin ctypes layer between the Python host surface and libphantom_amd.so.
+
+PyTorch-ROCm tensors own every buffer (state blob, inputs, outputs); the library receives raw
+device pointers plus torch's current HIP stream, so all calls are stream-ordered with the
+caller's other torch work and nothing synchronises unless the caller reads values back.
+There is NO CPU fallback: without a visible GPU or the built HIP library this raises.
+"""
+import ctypes as C
+from typing import Dict, List, NamedTuple, Optional
+
+import numpy as np
+
+from . import _abi
+from .message import Message, payload_to_record, record_to_payload
+from .spec import EnvSpec
+
+_DTYPES = None
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class StepTensors(NamedTuple):
+    """Device-resident result of one batched step (views of persistent buffers; valid until
+    the next step call on the same env)."""
+    observations: "object"   # f32 [B, S, D]
+    rewards: "object"        # f64 [B, S]
+    terminations: "object"   # u8  [B, S]
+    truncations: "object"    # u8  [B, S]
+    obs_valid: "object"      # u8  [B, S]
+    reward_valid: "object"   # u8  [B, S]  0 absent / 1 value / 2 None
+    done_valid: "object"     # u8  [B, S]
+    all_terminated: "object" # u8  [B]
+    all_truncated: "object"  # u8  [B]
+
+
+class Trajectory(NamedTuple):
+    """Device-resident rollout fragment, time-major."""
+    observations: "object"   # f32 [T, B, S, D]
+    actions: "object"        # f32 [T, B, S]
+    rewards: "object"        # f32 [T, B, S]
+    terminations: "object"   # u8  [T, B, S]
+    truncations: "object"    # u8  [T, B, S]
+    last_obs: "object"       # f32 [B, S, D]
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+class DeviceEnv:
+    def __init__(self, spec: EnvSpec, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise DeviceError("phantom_amd needs a visible AMD GPU (torch.cuda.is_available() is "
+                              "False); the PhantomEnv.step() path has no CPU fallback")
+        self.lib = _abi.load_library()
+        self.spec = spec
+        self.device = torch.device(device if device is not None
+                                   else f"cuda:{torch.cuda.current_device()}")
+        if self.device.index is None:
+            self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
+        self._cspec, self._keep = spec.to_ctypes()
+        cs = C.byref(self._cspec)
+        self.B, self.S = spec.batch, spec.n_strategic
+        self.D = self.lib.phx_obs_dim(cs)
+        self.n_exo = self.lib.phx_n_exo(cs)
+        assert self.lib.phx_n_strategic(cs) == self.S
+        nbytes = self.lib.phx_state_nbytes(cs)
+        if nbytes <= 0:
+            raise DeviceError("phx_state_nbytes failed: " + self._err())
+        self.state = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.phx_create(cs, self.device.index, self.state.data_ptr(), nbytes,
+                                     C.byref(handle))
+        if rc != 0:
+            raise DeviceError(f"phx_create failed ({rc}): " + self._err())
+        self.handle = handle
+        self.uses_fused = bool(self.lib.phx_uses_fused(handle))
+        self._kind_rank = spec.kind_rank()
+        self._fields: Dict[str, "object"] = {}
+        dt = {0: torch.int32, 1: torch.float64, 2: torch.uint8, 3: torch.float32}
+        for k in range(self.lib.phx_n_fields(handle)):
+            f = _abi.PhxField()
+            self.lib.phx_field_info(handle, k, C.byref(f))
+            n = f.dim0 * f.dim1 * f.dim2
+            esz = {0: 4, 1: 8, 2: 1, 3: 4}[f.dtype]
+            view = self.state[f.offset:f.offset + n * esz].view(dt[f.dtype])
+            shape = [f.dim0, f.dim1] + ([f.dim2] if f.dim2 > 1 else [])
+            self._fields[f.name.decode()] = view.view(*shape)
+        B, S, D = self.B, max(self.S, 1), self.D
+        z = lambda *s, dtype: torch.zeros(*s, dtype=dtype, device=self.device)
+        self.obs = z(B, S, D, dtype=torch.float32)
+        self.reward = z(B, S, dtype=torch.float64)
+        self.obs_valid = z(B, S, dtype=torch.uint8)
+        self.reward_valid = z(B, S, dtype=torch.uint8)
+        self.terminated = z(B, S, dtype=torch.uint8)
+        self.truncated = z(B, S, dtype=torch.uint8)
+        self.done_valid = z(B, S, dtype=torch.uint8)
+        self.all_terminated = z(B, dtype=torch.uint8)
+        self.all_truncated = z(B, dtype=torch.uint8)
+        self.err = z(B, dtype=torch.int32)
+        self.ones_valid = None
+        self.msg_log = self.msg_count = None
+        if spec.trace_cap > 0:
+            self.msg_log = z(B, spec.trace_cap, 16, dtype=torch.uint8)
+            self.msg_count = z(B, dtype=torch.int32)
+        self.topology_version = 0
+
+    # ---- helpers --------------------------------------------------------------------------
+    def _err(self) -> str:
+        return (self.lib.phx_last_error() or b"").decode()
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise DeviceError(f"{what} failed ({rc}): {self._err()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.phx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def field(self, name: str):
+        """torch view [B, n] into the state blob (zero-copy)."""
+        return self._fields[name]
+
+    def field_names(self) -> List[str]:
+        return list(self._fields)
+
+    def _read_agent_state(self, agent, field_name: str):
+        a = self.spec.index_of(agent.id)
+        col = int(self._kind_rank[a])
+        v = self._fields[field_name][:, col].cpu().numpy()
+        return v[0].item() if self.B == 1 else v
+
+    # ---- entry points ---------------------------------------------------------------------
+    def reset(self, mask=None):
+        torch = _torch()
+        mp = None
+        if mask is not None:
+            mask = torch.as_tensor(mask, dtype=torch.uint8, device=self.device).contiguous()
+            mp = mask.data_ptr()
+            self.err.masked_fill_(mask.bool(), 0)
+        else:
+            self.err.zero_()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.phx_reset(self.handle, mp, self.obs.data_ptr(),
+                                           self.obs_valid.data_ptr(), self._stream()), "phx_reset")
+        return self.obs, self.obs_valid
+
+    def reset_agents(self):
+        """Network.reset() without an env: agent.reset() for every agent."""
+        self.reset()
+
+    def step(self, actions, action_valid=None, exo=None) -> StepTensors:
+        torch = _torch()
+        io = _abi.PhxStepIO()
+        if self.S > 0:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() \
+                    or actions.shape != (self.B, self.S):
+                raise ValueError(f"actions must be a contiguous f32 tensor [{self.B}, {self.S}]")
+            io.actions = actions.data_ptr()
+        if action_valid is not None:
+            io.action_valid = action_valid.data_ptr()
+        if exo is not None:
+            if exo.dtype != torch.uint8 or exo.shape != (self.B, self.n_exo) or not exo.is_contiguous():
+                raise ValueError(f"exo must be a contiguous u8 tensor [{self.B}, {self.n_exo}]")
+            io.exo = exo.data_ptr()
+        io.obs, io.obs_valid = self.obs.data_ptr(), self.obs_valid.data_ptr()
+        io.reward, io.reward_valid = self.reward.data_ptr(), self.reward_valid.data_ptr()
+        io.terminated, io.truncated = self.terminated.data_ptr(), self.truncated.data_ptr()
+        io.done_valid = self.done_valid.data_ptr()
+        io.all_terminated = self.all_terminated.data_ptr()
+        io.all_truncated = self.all_truncated.data_ptr()
+        io.err = self.err.data_ptr()
+        if self.msg_log is not None:
+            io.msg_log, io.msg_count = self.msg_log.data_ptr(), self.msg_count.data_ptr()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.phx_step(self.handle, C.byref(io), self._stream()), "phx_step")
+        return StepTensors(self.obs, self.reward, self.terminated, self.truncated, self.obs_valid,
+                           self.reward_valid, self.done_valid, self.all_terminated,
+                           self.all_truncated)
+
+    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
+        torch = _torch()
+        B, S, D = self.B, self.S, self.D
+        if out is None:
+            e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=self.device)
+            out = Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
+                             e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
+                             e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32))
+        io = _abi.PhxRolloutIO()
+        io.T = T
+        if actions is not None:
+            assert actions.dtype == torch.float32 and actions.shape == (T, B, S) and actions.is_contiguous()
+            io.actions = actions.data_ptr()
+        if exo is not None:
+            assert exo.dtype == torch.uint8 and exo.shape == (T, B, self.n_exo) and exo.is_contiguous()
+            io.exo = exo.data_ptr()
+        io.obs, io.action_out, io.reward = (out.observations.data_ptr(), out.actions.data_ptr(),
+                                            out.rewards.data_ptr())
+        io.terminated, io.truncated = out.terminations.data_ptr(), out.truncations.data_ptr()
+        io.last_obs = out.last_obs.data_ptr()
+        io.err = self.err.data_ptr()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.phx_rollout(self.handle, C.byref(io), self._stream()), "phx_rollout")
+        return out
+
+    def inject(self, messages: List[Message]):
+        if not messages:
+            return
+        arr = (_abi.PhxMsgRec * len(messages))()
+        for k, m in enumerate(messages):
+            t, is_f, v = payload_to_record(m.payload)
+            arr[k].sender = self.spec.index_of(m.sender_id)
+            arr[k].receiver = self.spec.index_of(m.receiver_id)
+            arr[k].type = t
+            if is_f:
+                arr[k].payload.f = float(v)
+            else:
+                arr[k].payload.i = int(v)
+        self._check(self.lib.phx_inject(self.handle, arr, len(messages)), "phx_inject")
+
+    def resolve(self, pending: List[Message], network=None):
+        torch = _torch()
+        self.inject(pending)
+        lp = self.msg_log.data_ptr() if self.msg_log is not None else None
+        cp = self.msg_count.data_ptr() if self.msg_count is not None else None
+        self.err.zero_()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.phx_resolve(self.handle, self.err.data_ptr(), lp, cp,
+                                             self._stream()), "phx_resolve")
+        self.raise_errors(network)
+        if network is not None and network.resolver.enable_tracking:
+            network.resolver._tracked_messages.extend(self.read_log(0))
+
+    # ---- read-back ----------------------------------------------------------------------------
+    def read_log_records(self, b: int = 0) -> np.ndarray:
+        """structured array (sender, receiver, type, round, raw i64) of env b's last step."""
+        if self.msg_log is None:
+            raise DeviceError("tracking is disabled (BatchResolver(enable_tracking=True))")
+        n = int(self.msg_count[b].item())
+        if n > self.spec.trace_cap:
+            raise DeviceError(f"message log overflow: {n} > trace capacity {self.spec.trace_cap}")
+        raw = self.msg_log[b, :n].cpu().numpy().tobytes()
+        dt = np.dtype([("sender", "<u2"), ("receiver", "<u2"), ("type", "<u2"), ("round", "<u2"),
+                       ("raw", "<i8")])
+        return np.frombuffer(raw, dtype=dt)
+
+    def read_log(self, b: int = 0) -> List[Message]:
+        recs = self.read_log_records(b)
+        ids = self.spec.agent_ids
+        out = []
+        for r in recs:
+            raw_i = int(r["raw"])
+            raw_f = np.array([raw_i], dtype="<i8").view("<f8")[0].item()
+            out.append(Message(ids[int(r["sender"])], ids[int(r["receiver"])],
+                               record_to_payload(int(r["type"]), raw_i, raw_f)))
+        return out
+
+    def raise_errors(self, network=None):
+        """Re-raise per-env soft error codes as the exceptions the reference raises in step()."""
+        err = self.err.cpu().numpy()
+        bad = np.flatnonzero(err)
+        if bad.size == 0:
+            return
+        from .network import NetworkError
+        b, code = int(bad[0]), int(err[bad[0]])
+        where = f"env instance {b} (+{bad.size - 1} more)" if bad.size > 1 else f"env instance {b}"
+        if code == _abi.ERR_NETWORK:
+            raise NetworkError(f"No connection between sender and receiver ({where}).")
+        if code == _abi.ERR_PAYLOAD:
+            raise NetworkError(f"Message payload not allowed between these agent types ({where}).")
+        if code == _abi.ERR_UNKNOWN_MSG:
+            raise ValueError(f"Unknown message type: receiving agent has no handler ({where}).")
+        if code == _abi.ERR_ROUND_LIMIT:
+            raise RuntimeError("message(s) still in queue after BatchResolver round limit "
+                               f"reached ({where}).")
+        raise DeviceError(f"per-round message capacity exceeded ({where}); raise queue capacity")

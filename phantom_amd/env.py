@@ -1,0 +1,286 @@
+"""PhantomEnv: the drop-in, batched, device-resident env (mirrors phantom/env.py:25-351).
+
+Construction, ``reset(seed, options)`` and ``step(actions) -> PhantomEnv.Step`` keep the
+reference's signatures.  One object now stands for ``batch_size`` independent env instances
+(the reference's "vectorised env" is a Python list of envs stepped in a for loop,
+utils/rllib/rollout.py:289-291,361-363); with ``batch_size == 1`` the dict-shaped results are
+exactly what the reference returns, with larger batches every leaf gains a leading [B] axis.
+``step_tensors`` / ``rollout`` are the tensor-native fast paths that never leave the GPU.
+"""
+from typing import Any, Dict, List, Mapping, NamedTuple, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from .agents import Agent, StrategicAgent
+from .message import AgentID
+from .network import Network
+from .spec import EnvSpec, compile_spec
+from .views import EnvView
+
+
+class PhantomEnv:
+    class Step(NamedTuple):                     # env.py:48-53
+        observations: Dict[AgentID, Any]
+        rewards: Dict[AgentID, float]
+        terminations: Dict[AgentID, bool]
+        truncations: Dict[AgentID, bool]
+        infos: Dict[AgentID, Any]
+
+    _env_type = _abi.ENV_PLAIN
+
+    def __init__(self, num_steps: int, network: Optional[Network] = None, env_supertype=None,
+                 agent_supertypes=None, *, batch_size: int = 1, device=None, seed: int = 0,
+                 env_offset: int = 0, exogenous: Optional[str] = None,
+                 force_generic: bool = False) -> None:
+        if env_supertype is not None or agent_supertypes is not None:
+            raise NotImplementedError("Supertypes are reset-time host features outside the "
+                                      "device hot path (SURVEY.md 8f-3)")
+        self.network = network or Network()
+        self.num_steps = num_steps
+        self.batch_size = int(batch_size)
+        self.env_supertype = None
+        self.env_type = None
+        self._device_name = device
+        self._seed, self._env_offset = seed, env_offset
+        self._force_generic = force_generic
+        #: where CustomerAgent's np.random.randint(5) (supply_chain.py:64) comes from:
+        #: "numpy" = the global legacy numpy stream consumed in the reference's order
+        #: (bit-parity with the reference for the same np.random.seed); "device" = Philox
+        self.exogenous = exogenous or ("numpy" if self.batch_size == 1 else "device")
+        self._dev = None
+        self._spec: Optional[EnvSpec] = None
+        self._h_step = np.zeros(self.batch_size, dtype=np.int64)
+        self._h_stage = np.zeros(self.batch_size, dtype=np.int64)
+        self.network._owner = self
+        for a in self.network.agents.values():
+            a._env = self
+
+    # ---- spec / device (lazy, so that construction and validation work without a GPU) -------
+    def _compile(self) -> EnvSpec:
+        return compile_spec(self.network, self.num_steps, self.batch_size, self._env_type,
+                            seed=self._seed, env_offset=self._env_offset,
+                            force_generic=self._force_generic)
+
+    @property
+    def spec(self) -> EnvSpec:
+        if self._spec is None:
+            self._spec = self._compile()
+        return self._spec
+
+    def _device(self):
+        if self._dev is None:
+            from .device import DeviceEnv
+            self._dev = DeviceEnv(self.spec, self._device_name)
+        return self._dev
+
+    def _read_agent_state(self, agent, field_name):
+        return self._device()._read_agent_state(agent, field_name)
+
+    # ---- introspection (env.py:126-164) ---------------------------------------------------------
+    @property
+    def current_step(self):
+        return int(self._h_step[0]) if self.batch_size == 1 else self._h_step.copy()
+
+    @property
+    def n_agents(self) -> int:
+        return len(self.agent_ids)
+
+    @property
+    def agents(self) -> Dict[AgentID, Agent]:
+        return self.network.agents
+
+    @property
+    def agent_ids(self) -> List[AgentID]:
+        return list(self.network.agent_ids)
+
+    @property
+    def strategic_agents(self) -> List[StrategicAgent]:
+        return [a for a in self.agents.values() if isinstance(a, StrategicAgent)]
+
+    @property
+    def non_strategic_agents(self) -> List[Agent]:
+        return [a for a in self.agents.values() if not isinstance(a, StrategicAgent)]
+
+    @property
+    def strategic_agent_ids(self) -> List[AgentID]:
+        return [a.id for a in self.agents.values() if isinstance(a, StrategicAgent)]
+
+    @property
+    def non_strategic_agent_ids(self) -> List[AgentID]:
+        return [a.id for a in self.agents.values() if not isinstance(a, StrategicAgent)]
+
+    def view(self, agent_views=None) -> EnvView:           # env.py:166-168
+        s = int(self._h_step[0])
+        return EnvView(s, s / self.num_steps)
+
+    def __getitem__(self, agent_id: AgentID) -> Agent:
+        return self.network[agent_id]
+
+    def is_terminated(self):                               # env.py:308-310
+        v = self._device().field("env.term").sum(dim=1).cpu().numpy() == self.spec.n_strategic
+        return bool(v[0]) if self.batch_size == 1 else v
+
+    def is_truncated(self):                                # env.py:312-318
+        dev = self._device()
+        n = dev.field("env.trunc").sum(dim=1).cpu().numpy() == self.spec.n_strategic
+        at_max = dev.field("env.step")[:, 0].cpu().numpy() == self.num_steps
+        v = n | at_max
+        return bool(v[0]) if self.batch_size == 1 else v
+
+    def render(self) -> None:
+        return None
+
+    # ---- exogenous draws ---------------------------------------------------------------------
+    def _acting_customers(self, b: int) -> Sequence[int]:
+        """agent indices of the CustomerAgents that generate messages this step, acting order."""
+        return self._customers_all
+
+    def _draw_exo(self):
+        """np.random.randint(CUSTOMER_MAX_ORDER_SIZE) per acting customer, consumed from the
+        global numpy stream env by env in acting order -- the order in which a list of
+        reference envs stepped in a loop would consume it (rollout.py:361-363)."""
+        import torch
+        spec = self.spec
+        if spec.n_exo == 0 or self.exogenous != "numpy":
+            return None
+        if not hasattr(self, "_customers_all"):
+            self._customers_all = [a for a in range(spec.n_agents)
+                                   if spec.kind[a] == _abi.KIND_CUSTOMER]
+            rank = {a: r for r, a in enumerate(self._customers_all)}
+            self._exo_rank = rank
+        exo = np.zeros((self.batch_size, spec.n_exo), dtype=np.uint8)
+        for b in range(self.batch_size):
+            acting = self._acting_customers(b)
+            if len(acting):
+                draws = np.random.randint(5, size=len(acting))
+                exo[b, [self._exo_rank[a] for a in acting]] = draws
+        return torch.from_numpy(exo).to(self._device().device)
+
+    # ---- reset / step ----------------------------------------------------------------------------
+    def _host_reset(self, mask=None):
+        sel = slice(None) if mask is None else np.asarray(mask, dtype=bool)
+        self._h_step[sel] = 0
+
+    def _host_advance(self):
+        self._h_step += 1
+
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None,
+              *, mask=None) -> Tuple[Dict[AgentID, Any], Dict[str, Any]]:
+        """env.py:185-237.  ``seed`` is accepted and ignored exactly as in the reference, where
+        it only seeds ``self.np_random`` which nothing consumes."""
+        dev = self._device()
+        obs, valid = dev.reset(mask)
+        self._host_reset(mask)
+        return self._obs_dict(obs.cpu().numpy(), valid.cpu().numpy()), {}
+
+    def _obs_dict(self, obs: np.ndarray, valid: np.ndarray) -> Dict[AgentID, Any]:
+        out = {}
+        spec = self.spec
+        for s, a in enumerate(spec.strategic_idx):
+            d = _abi.OBS_DIM[int(spec.kind[a])]
+            if self.batch_size == 1:
+                if valid[0, s]:
+                    out[spec.agent_ids[a]] = obs[0, s, :d].copy()
+            elif valid[:, s].any():
+                self._require_uniform(valid[:, s])
+                out[spec.agent_ids[a]] = obs[:, s, :d].copy()
+        return out
+
+    @staticmethod
+    def _require_uniform(col: np.ndarray):
+        if not (col == col[0]).all():
+            raise ValueError("dict-shaped results need the same key set in every env instance; "
+                             "use step_tensors() for batches whose envs are out of phase")
+
+    def _actions_tensor(self, actions: Mapping[AgentID, Any]):
+        import torch
+        spec = self.spec
+        B, S = self.batch_size, spec.n_strategic
+        act = np.zeros((B, S), dtype=np.float32)
+        valid = np.zeros((B, S), dtype=np.uint8)
+        for s, a in enumerate(spec.strategic_idx):
+            aid = spec.agent_ids[a]
+            if aid in actions:                             # env.py:330
+                v = np.asarray(actions[aid], dtype=np.float32)
+                if v.size == 1 or B == 1:
+                    act[:, s] = v.reshape(-1)[0]
+                else:
+                    act[:, s] = v.reshape(B, -1)[:, 0]
+                valid[:, s] = 1
+        dev = self._device().device
+        return torch.from_numpy(act).to(dev), torch.from_numpy(valid).to(dev)
+
+    def step(self, actions: Mapping[AgentID, Any]) -> "PhantomEnv.Step":
+        """env.py:239-303 for every env instance of the batch, in one kernel launch."""
+        dev = self._device()
+        act, valid = self._actions_tensor(actions)
+        exo = self._draw_exo()
+        out = dev.step(act, valid, exo)
+        self._host_advance()
+        dev.raise_errors(self.network)
+        if self.network.resolver.enable_tracking:
+            self.network.resolver._tracked_messages.extend(dev.read_log(0))
+        return self._step_dicts(out)
+
+    def step_tensors(self, actions, action_valid=None, exo=None, check_errors: bool = False):
+        """Tensor-native step: ``actions`` f32 [B, S] on the env's device; returns StepTensors
+        (device views, no host synchronisation).  ``exo`` u8 [B, n_exo] replays exogenous
+        draws; None -> numpy stream or device RNG according to ``self.exogenous``."""
+        dev = self._device()
+        if exo is None:
+            exo = self._draw_exo()
+        out = dev.step(actions, action_valid, exo)
+        self._host_advance()
+        if check_errors:
+            dev.raise_errors(self.network)
+        return out
+
+    def rollout(self, T: int, actions=None, exo=None, out=None):
+        """T fused steps on the device with auto-reset at episode end (the loop of
+        utils/rllib/rollout.py:300-363 in one launch).  Returns a device Trajectory."""
+        traj = self._device().rollout(T, actions, exo, out)
+        self._h_step = (self._h_step + T) % max(self.num_steps, 1)
+        return traj
+
+    def _step_dicts(self, out) -> "PhantomEnv.Step":
+        spec = self.spec
+        B = self.batch_size
+        obs = out.observations.cpu().numpy()
+        rew = out.rewards.cpu().numpy()
+        term = out.terminations.cpu().numpy().astype(bool)
+        trunc = out.truncations.cpu().numpy().astype(bool)
+        ov, rv, dv = (out.obs_valid.cpu().numpy(), out.reward_valid.cpu().numpy(),
+                      out.done_valid.cpu().numpy())
+        at, au = out.all_terminated.cpu().numpy().astype(bool), out.all_truncated.cpu().numpy().astype(bool)
+        observations, rewards, terminations, truncations, infos = {}, {}, {}, {}, {}
+        for s, a in enumerate(spec.strategic_idx):
+            aid = spec.agent_ids[a]
+            d = _abi.OBS_DIM[int(spec.kind[a])]
+            if B == 1:
+                if ov[0, s]:
+                    observations[aid] = obs[0, s, :d].copy()
+                    infos[aid] = {}
+                if rv[0, s] == 1:
+                    rewards[aid] = float(rew[0, s])
+                elif rv[0, s] == 2:
+                    rewards[aid] = None
+                if dv[0, s]:
+                    terminations[aid] = bool(term[0, s])
+                    truncations[aid] = bool(trunc[0, s])
+            else:
+                for col in (ov[:, s], rv[:, s], dv[:, s]):
+                    self._require_uniform(col)
+                if ov[0, s]:
+                    observations[aid] = obs[:, s, :d].copy()
+                    infos[aid] = {}
+                if rv[0, s] == 1:
+                    rewards[aid] = rew[:, s].copy()
+                elif rv[0, s] == 2:
+                    rewards[aid] = None
+                if dv[0, s]:
+                    terminations[aid] = term[:, s].copy()
+                    truncations[aid] = trunc[:, s].copy()
+        terminations["__all__"] = bool(at[0]) if B == 1 else at          # env.py:297
+        truncations["__all__"] = bool(au[0]) if B == 1 else au           # env.py:298
+        return self.Step(observations, rewards, terminations, truncations, infos)

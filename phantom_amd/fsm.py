@@ -1,0 +1,138 @@
+"""FiniteStateMachineEnv (mirrors phantom/fsm.py:12-380) with table-driven stages.
+
+Stage masking -- which agents act, which observe (the next stage's acting agents) and which
+are rewarded -- is compiled into per-stage tables and applied inside the step kernel with the
+reward cache / emit-on-observe semantics of fsm.py:309-380.  Stage *handlers* are Python
+callbacks that would have to run between message resolution and the observation loop; only
+handler-less stages (exactly one next stage, fsm.py:281-292) can run on the device.
+"""
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from .env import PhantomEnv
+from .message import AgentID
+from .network import Network
+from .spec import compile_spec
+from .views import FSMEnvView
+
+StageID = Any
+
+
+class FSMValidationError(Exception):
+    """fsm.py:12-16"""
+
+
+class FSMRuntimeError(Exception):
+    """fsm.py:19-23"""
+
+
+class FSMStage:
+    """fsm.py:26-63"""
+
+    def __init__(self, stage_id: StageID, acting_agents: Sequence[AgentID],
+                 rewarded_agents: Optional[Sequence[AgentID]] = None,
+                 next_stages: Optional[Sequence[StageID]] = None,
+                 handler: Optional[Callable[[], StageID]] = None) -> None:
+        self.id = stage_id
+        self.acting_agents = acting_agents
+        self.rewarded_agents = rewarded_agents
+        self.next_stages = next_stages or []
+        self.handler = handler
+
+    def __call__(self, handler_fn):
+        setattr(handler_fn, "_decorator", self)
+        self.handler = handler_fn
+        return handler_fn
+
+
+class FiniteStateMachineEnv(PhantomEnv):
+    _env_type = _abi.ENV_FSM
+
+    def __init__(self, num_steps: int, network: Network, initial_stage: StageID,
+                 env_supertype=None, agent_supertypes=None,
+                 stages: Optional[Sequence[FSMStage]] = None, **device_kwargs) -> None:
+        super().__init__(num_steps, network, env_supertype, agent_supertypes, **device_kwargs)
+        self._initial_stage = initial_stage
+        self._stages: Dict[StageID, FSMStage] = {}
+        self.previous_stage_idx = np.full(self.batch_size, -1, dtype=np.int64)
+
+        for stage in stages or []:                        # fsm.py:130-132
+            if stage.id not in self._stages:
+                self._stages[stage.id] = stage
+        for attr_name in dir(type(self)):                 # fsm.py:135-145 (decorator registration)
+            attr = getattr(type(self), attr_name, None)
+            if callable(attr) and hasattr(attr, "_decorator"):
+                if attr._decorator.id in self._stages:
+                    raise FSMValidationError(
+                        f"Found multiple stages with ID '{attr._decorator.id}'")
+                self._stages[attr._decorator.id] = attr._decorator
+        if len(self._stages) == 0:                        # fsm.py:148-151
+            raise FSMValidationError(
+                "No registered stages. Please use the 'FSMStage' decorator or the "
+                "stage_definitions init parameter")
+        if self.initial_stage not in self._stages:        # fsm.py:154-157
+            raise FSMValidationError(f"Initial stage '{self.initial_stage}' is not a valid stage")
+        for stage in self._stages.values():               # fsm.py:160-165
+            for next_stage in stage.next_stages:
+                if next_stage not in self._stages:
+                    raise FSMValidationError(
+                        f"Next stage '{next_stage}' given in stage '{stage.id}' is not a valid stage")
+        for stage in self._stages.values():               # fsm.py:168-173
+            if len(stage.next_stages) != 1 and stage.handler is None:
+                raise FSMValidationError(
+                    f"Stage '{stage.id}' without handler must have exactly one next stage "
+                    f"(got {len(stage.next_stages)})")
+        for stage in self._stages.values():
+            if stage.handler is not None:
+                raise NotImplementedError(
+                    f"stage '{stage.id}' has a Python env handler; only handler-less, "
+                    "table-driven stages can run inside the device step (fsm.py:281-292)")
+        self._stage_list = list(self._stages.values())
+        self._stage_index = {s.id: i for i, s in enumerate(self._stage_list)}
+        self._h_stage[:] = self._stage_index[initial_stage]
+
+    def _compile(self):
+        return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_FSM,
+                            stages=self._stage_list, initial_stage=self._initial_stage,
+                            seed=self._seed, env_offset=self._env_offset,
+                            force_generic=self._force_generic)
+
+    @property
+    def initial_stage(self) -> StageID:
+        return self._initial_stage
+
+    @property
+    def current_stage(self):
+        ids = [self._stage_list[i].id for i in self._h_stage]
+        return ids[0] if self.batch_size == 1 else ids
+
+    @property
+    def previous_stage(self):
+        ids = [None if i < 0 else self._stage_list[i].id for i in self.previous_stage_idx]
+        return ids[0] if self.batch_size == 1 else ids
+
+    def is_fsm_deterministic(self) -> bool:               # fsm.py:185-187
+        return all(len(s.next_stages) == 1 for s in self._stages.values())
+
+    def view(self, agent_views=None) -> FSMEnvView:       # fsm.py:189-193
+        s = int(self._h_step[0])
+        return FSMEnvView(s, s / self.num_steps, self.current_stage)
+
+    def _acting_customers(self, b: int):
+        st = self._stage_list[int(self._h_stage[b])]
+        spec = self.spec
+        return [spec.index_of(aid) for aid in st.acting_agents
+                if spec.kind[spec.index_of(aid)] == _abi.KIND_CUSTOMER]
+
+    def _host_reset(self, mask=None):
+        sel = slice(None) if mask is None else np.asarray(mask, dtype=bool)
+        self._h_step[sel] = 0
+        self._h_stage[sel] = self._stage_index[self._initial_stage]      # fsm.py:217
+
+    def _host_advance(self):
+        self._h_step += 1
+        nxt = np.asarray([self._stage_index[s.next_stages[0]] for s in self._stage_list])
+        self.previous_stage_idx = self._h_stage.copy()                   # fsm.py:355
+        self._h_stage = nxt[self._h_stage]

@@ -1,0 +1,228 @@
+"""Env-spec compiler: Network + env options -> the flat tables of ``phx_spec``.
+
+Everything the reference re-derives per step from Python objects -- agent order
+(env.py:142-144), the strategic-agent scan (env.py:151-159), neighbour order
+(network.py:217-220), edge and payload checks (network.py:246-252) -- is static for a compiled
+topology and is flattened once here.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+
+@dataclass
+class EnvSpec:
+    agent_ids: List
+    kind: np.ndarray            # u8 [A]
+    param_i: np.ndarray         # i32 [A, NPI]
+    param_f: np.ndarray         # f64 [A, NPF]
+    row_ptr: np.ndarray         # i32 [A+1]
+    col: np.ndarray             # i32 [nnz]
+    batch: int
+    num_steps: int
+    round_limit: int
+    env_type: int
+    flags: int
+    queue_cap: int
+    trace_cap: int
+    seed: int = 0
+    env_offset: int = 0
+    # FSM
+    stage_ids: List = field(default_factory=list)
+    initial_stage: int = 0
+    stage_act_ptr: Optional[np.ndarray] = None
+    stage_act_idx: Optional[np.ndarray] = None
+    stage_rewarded: Optional[np.ndarray] = None
+    stage_rewarded_all: Optional[np.ndarray] = None
+    stage_next: Optional[np.ndarray] = None
+    # Stackelberg
+    leaders: Optional[np.ndarray] = None
+    followers: Optional[np.ndarray] = None
+
+    # ---- derived ------------------------------------------------------------------------
+    @property
+    def n_agents(self) -> int:
+        return len(self.agent_ids)
+
+    @property
+    def strategic_idx(self) -> np.ndarray:
+        return np.flatnonzero(np.isin(self.kind, _abi.STRATEGIC_KINDS)).astype(np.int32)
+
+    @property
+    def strategic_ids(self) -> List:
+        return [self.agent_ids[i] for i in self.strategic_idx]
+
+    @property
+    def n_strategic(self) -> int:
+        return int(len(self.strategic_idx))
+
+    @property
+    def obs_dim(self) -> int:
+        d = [_abi.OBS_DIM[k] for k in self.kind.tolist() if k in _abi.OBS_DIM]
+        return max(d) if d else 1
+
+    @property
+    def n_exo(self) -> int:
+        return int((self.kind == _abi.KIND_CUSTOMER).sum())
+
+    def kind_rank(self) -> np.ndarray:
+        """rank of each agent among the agents of its own kind (state column)."""
+        r = np.zeros(self.n_agents, dtype=np.int32)
+        cnt: Dict[int, int] = {}
+        for a, k in enumerate(self.kind.tolist()):
+            r[a] = cnt.get(k, 0)
+            cnt[k] = r[a] + 1
+        return r
+
+    def index_of(self, agent_id) -> int:
+        return self.agent_ids.index(agent_id)
+
+    def to_ctypes(self):
+        """(PhxSpec, keepalive) -- keepalive holds the numpy buffers the struct points into."""
+        keep = []
+
+        def ptr(arr, dtype):
+            if arr is None:
+                return None
+            a = np.ascontiguousarray(arr, dtype=dtype)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dtype)
+            keep.append(a)
+            return a.ctypes.data
+
+        s = _abi.PhxSpec()
+        s.abi_version = _abi.ABI_VERSION
+        s.n_agents, s.batch, s.num_steps = self.n_agents, self.batch, self.num_steps
+        s.round_limit, s.env_type, s.flags = self.round_limit, self.env_type, self.flags
+        s.queue_cap, s.trace_cap = self.queue_cap, self.trace_cap
+        s.kind = ptr(self.kind, np.uint8)
+        s.param_i = ptr(self.param_i, np.int32)
+        s.param_f = ptr(self.param_f, np.float64)
+        s.row_ptr = ptr(self.row_ptr, np.int32)
+        s.col = ptr(self.col, np.int32)
+        s.n_stages = len(self.stage_ids)
+        s.initial_stage = self.initial_stage
+        s.stage_act_ptr = ptr(self.stage_act_ptr, np.int32)
+        s.stage_act_idx = ptr(self.stage_act_idx, np.int32)
+        s.stage_rewarded = ptr(self.stage_rewarded, np.uint8)
+        s.stage_rewarded_all = ptr(self.stage_rewarded_all, np.uint8)
+        s.stage_next = ptr(self.stage_next, np.int32)
+        s.n_leaders = 0 if self.leaders is None else len(self.leaders)
+        s.n_followers = 0 if self.followers is None else len(self.followers)
+        s.leaders = ptr(self.leaders, np.int32)
+        s.followers = ptr(self.followers, np.int32)
+        s.seed = self.seed & 0xFFFFFFFFFFFFFFFF
+        s.env_offset = self.env_offset
+        return s, keep
+
+
+def _max_emissions(kind: int, deg: int) -> int:
+    """upper bound of messages one acting agent of this kind sends in the acting phase."""
+    if kind in (_abi.KIND_SHOP, _abi.KIND_CUSTOMER, _abi.KIND_BUYER):
+        return 1
+    if kind == _abi.KIND_SELLER:
+        return deg
+    return 0
+
+
+def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _abi.ENV_PLAIN,
+                 stages: Optional[Sequence] = None, initial_stage=None,
+                 leaders: Optional[Sequence] = None, followers: Optional[Sequence] = None,
+                 seed: int = 0, env_offset: int = 0, force_generic: bool = False,
+                 extra_queue: int = 16) -> EnvSpec:
+    from .agents import Agent, StrategicAgent
+    agent_ids = list(network.agents.keys())
+    A = len(agent_ids)
+    if A == 0:
+        raise ValueError("network has no agents")
+    if A > 65535:
+        raise ValueError("at most 65535 agents per env (message records carry u16 ids)")
+    index = {aid: i for i, aid in enumerate(agent_ids)}
+
+    def index_of(aid):
+        if aid not in index:
+            raise ValueError(f"Agent with ID = '{aid}' does not exist.")
+        return index[aid]
+
+    kind = np.zeros(A, dtype=np.uint8)
+    param_i = np.zeros((A, _abi.NPI), dtype=np.int32)
+    param_f = np.zeros((A, _abi.NPF), dtype=np.float64)
+    for a, aid in enumerate(agent_ids):
+        agent = network.agents[aid]
+        if not isinstance(agent, Agent):
+            raise TypeError(f"{agent!r} is not a phantom_amd.Agent")
+        k = int(agent.device_kind)
+        if isinstance(agent, StrategicAgent) != (k in _abi.STRATEGIC_KINDS):
+            raise TypeError(f"agent '{aid}': StrategicAgent-ness and device kind disagree")
+        kind[a] = k
+        pi, pf = agent.device_params(index_of)
+        param_i[a, :len(pi)] = pi
+        param_f[a, :len(pf)] = pf
+
+    # CustomerAgent.pi1 = index among the customers of its shop, in agent order (keys the
+    # device RNG stream so that results do not depend on how lanes are mapped)
+    per_shop: Dict[int, int] = {}
+    for a in range(A):
+        if kind[a] == _abi.KIND_CUSTOMER:
+            shop = int(param_i[a, 0])
+            param_i[a, 1] = per_shop.get(shop, 0)
+            per_shop[shop] = param_i[a, 1] + 1
+
+    row_ptr = np.zeros(A + 1, dtype=np.int32)
+    col: List[int] = []
+    for a, aid in enumerate(agent_ids):
+        nb = network.neighbors(aid)
+        col.extend(index[n] for n in nb)
+        row_ptr[a + 1] = len(col)
+    col_arr = np.asarray(col, dtype=np.int32)
+
+    resolver = network.resolver
+    round_limit = -1 if getattr(resolver, "round_limit", None) is None else int(resolver.round_limit)
+    flags = 0
+    if network.ignore_connection_errors:
+        flags |= _abi.F_IGNORE_CONN_ERRORS
+    if not network.enforce_msg_payload_checks:
+        flags |= _abi.F_NO_PAYLOAD_CHECKS
+    if force_generic:
+        flags |= _abi.F_FORCE_GENERIC
+
+    deg = np.diff(row_ptr)
+    queue_cap = int(sum(_max_emissions(int(kind[a]), int(deg[a])) for a in range(A))) + extra_queue
+    trace_cap = 0
+    if getattr(resolver, "enable_tracking", False):
+        trace_cap = getattr(resolver, "trace_capacity", None) or 8 * queue_cap
+
+    spec = EnvSpec(agent_ids=agent_ids, kind=kind, param_i=param_i, param_f=param_f,
+                   row_ptr=row_ptr, col=col_arr, batch=int(batch_size), num_steps=int(num_steps),
+                   round_limit=round_limit, env_type=env_type, flags=flags, queue_cap=queue_cap,
+                   trace_cap=int(trace_cap), seed=int(seed), env_offset=int(env_offset))
+
+    if env_type == _abi.ENV_FSM:
+        stage_ids = [s.id for s in stages]
+        sidx = {sid: i for i, sid in enumerate(stage_ids)}
+        spec.stage_ids = stage_ids
+        spec.initial_stage = sidx[initial_stage]
+        ptr, idx = [0], []
+        rewarded = np.zeros((len(stages), A), dtype=np.uint8)
+        rewarded_all = np.zeros(len(stages), dtype=np.uint8)
+        nxt = np.zeros(len(stages), dtype=np.int32)
+        for i, st in enumerate(stages):
+            idx.extend(index_of(aid) for aid in st.acting_agents)
+            ptr.append(len(idx))
+            if st.rewarded_agents is None:
+                rewarded_all[i] = 1
+            else:
+                for aid in st.rewarded_agents:
+                    rewarded[i, index_of(aid)] = 1
+            nxt[i] = sidx[st.next_stages[0]]
+        spec.stage_act_ptr = np.asarray(ptr, dtype=np.int32)
+        spec.stage_act_idx = np.asarray(idx, dtype=np.int32)
+        spec.stage_rewarded, spec.stage_rewarded_all, spec.stage_next = rewarded, rewarded_all, nxt
+    elif env_type == _abi.ENV_STACKELBERG:
+        spec.leaders = np.asarray([index_of(a) for a in leaders], dtype=np.int32)
+        spec.followers = np.asarray([index_of(a) for a in followers], dtype=np.int32)
+    return spec

@@ -1,0 +1,67 @@
+"""Shared builders for parity tests: the same topologies the golden generator built from the
+reference's classes, expressed through the phantom_amd host API."""
+import os
+
+import numpy as np
+
+import phantom_amd as ph
+from phantom_amd import _abi
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def supply_chain_env(n_shops, ks, num_steps, batch, fsm=False, norm_customers=None, tracking=False,
+                     **kw):
+    resolver = ph.BatchResolver(enable_tracking=tracking)
+    cls = ph.SupplyChainFSMEnv if fsm else ph.SupplyChainEnv
+    env = cls(n_shops=n_shops, customers_per_shop=[int(k) for k in ks], num_steps=int(num_steps),
+              resolver=resolver, batch_size=batch, **kw)
+    if norm_customers is not None:
+        for a in env.agents.values():
+            if isinstance(a, ph.ShopAgent):
+                a.num_customers = int(norm_customers)
+    return env
+
+
+def env_from_golden(g, batch=None, tracking=False, **kw):
+    return supply_chain_env(int(g["n_shops"]), g["ks"], int(g["num_steps"]),
+                            batch or len(g["seeds"]), fsm=bool(g["fsm"]),
+                            norm_customers=int(g["norm_customers"]), tracking=tracking, **kw)
+
+
+def market_topology(L, Fw, d):
+    return [[(f * d + j * 17) % L for j in range(d)] for f in range(Fw)]
+
+
+def market_env(L, Fw, d, num_steps, batch, tracking=False, **kw):
+    leaders = [f"S{i}" for i in range(L)]
+    followers = [f"B{i}" for i in range(Fw)]
+    agents = [ph.SellerAgent(s) for s in leaders] + \
+             [ph.BuyerAgent(b, ((f % 7) + 1) / 8.0) for f, b in enumerate(followers)]
+    net = ph.Network(agents, resolver=ph.BatchResolver(enable_tracking=tracking))
+    for f, nb in enumerate(market_topology(L, Fw, d)):
+        for l in nb:
+            net.add_connection(followers[f], leaders[l])
+    return ph.StackelbergEnv(num_steps, net, leaders, followers, batch_size=batch, **kw)
+
+
+def f32_bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def f64_bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def log_matrix(recs):
+    """(sender, receiver, type, value-as-float) rows from structured log records."""
+    out = np.zeros((len(recs), 4), np.float64)
+    for k, r in enumerate(recs):
+        raw = np.array([r["raw"]], "<i8")
+        v = raw.view("<f8")[0] if int(r["type"]) in _abi.FLOAT_PAYLOAD_TYPES else float(raw[0])
+        out[k] = (r["sender"], r["receiver"], r["type"], v)
+    return out

@@ -1,0 +1,86 @@
+"""CPU: pin the C oracle (oracle/phx_oracle.c) to golden vectors produced by running the real
+reference (tests/golden/gen_goldens.py).  Integers/routing/stages bit-exact; the float obs and
+rewards are compared by BIT PATTERN as well (stricter than the 1e-6 the task allows)."""
+import numpy as np
+import pytest
+
+from helpers import (env_from_golden, f32_bits, f64_bits, golden, log_matrix, market_env)
+from oracle import OracleEnv
+
+SC_CASES = ["sc7_fixed20", "sc7_mixed", "sc64", "sc_ragged", "sc256_fsm", "sc_fsm_small"]
+
+
+def replay_supply_chain(g, make_runner):
+    """drive a runner (oracle or device adapter) with the golden inputs and compare outputs."""
+    T, B = int(g["T"]), len(g["seeds"])
+    env = env_from_golden(g, tracking=int(g["n_logs"]) > 0)
+    run = make_runner(env.spec)
+    for t in range(T):
+        rb = g["reset_before"][t]
+        if rb.any():
+            obs, valid = run.reset(rb)
+            m = rb.astype(bool)
+            np.testing.assert_array_equal(valid[m], g["reset_obs_valid"][t][m])
+            sel = g["reset_obs_valid"][t].astype(bool) & m[:, None]
+            np.testing.assert_array_equal(f32_bits(obs[sel]), f32_bits(g["reset_obs"][t][sel]))
+        exo = g["exo"][t]
+        run.step(g["actions"][t], None, exo)
+        assert (run.err == 0).all()
+        np.testing.assert_array_equal(run.get_i32("shop.stock"), g["stock"][t], err_msg=f"stock t={t}")
+        np.testing.assert_array_equal(run.get_i32("shop.sales"), g["sales"][t])
+        np.testing.assert_array_equal(run.get_i32("shop.missed_sales"), g["missed"][t])
+        np.testing.assert_array_equal(run.obs_valid, g["obs_valid"][t], err_msg=f"obs_valid t={t}")
+        np.testing.assert_array_equal(run.reward_valid, g["reward_valid"][t], err_msg=f"rv t={t}")
+        np.testing.assert_array_equal(run.done_valid, g["done_valid"][t])
+        ov = g["obs_valid"][t].astype(bool)
+        np.testing.assert_array_equal(f32_bits(run.obs[ov]), f32_bits(g["obs"][t][ov]), err_msg=f"obs t={t}")
+        rv = g["reward_valid"][t] == 1
+        np.testing.assert_array_equal(f64_bits(run.reward[rv]), f64_bits(g["reward"][t][rv]))
+        np.testing.assert_array_equal(run.terminated, g["terminated"][t])
+        np.testing.assert_array_equal(run.truncated, g["truncated"][t])
+        np.testing.assert_array_equal(run.all_terminated, g["all_terminated"][t])
+        np.testing.assert_array_equal(run.all_truncated, g["all_truncated"][t])
+        if bool(g["fsm"]) and t + 1 < T and not g["reset_before"][t + 1].any():
+            np.testing.assert_array_equal(run.get_i32("env.stage")[:, 0], g["stage"][t + 1])
+        if t < int(g["n_logs"]):
+            np.testing.assert_array_equal(log_matrix(run.log(0)), g[f"log{t}"], err_msg=f"log t={t}")
+
+
+@pytest.mark.parametrize("name", SC_CASES)
+def test_oracle_supply_chain_matches_reference(name):
+    replay_supply_chain(golden(name), lambda spec: OracleEnv(spec))
+
+
+def replay_market(g, make_runner):
+    L, Fw, d, T = int(g["L"]), int(g["Fw"]), int(g["d"]), int(g["T"])
+    env = market_env(L, Fw, d, int(g["num_steps"]), 1, tracking=True)
+    run = make_runner(env.spec)
+    for t in range(T):
+        if g["reset_before"][t]:
+            obs, valid = run.reset()
+            np.testing.assert_array_equal(valid[0], g["reset_obs_valid"][t])
+            sel = g["reset_obs_valid"][t].astype(bool)
+            np.testing.assert_array_equal(f32_bits(obs[0][sel]), f32_bits(g["reset_obs"][t][sel]))
+        run.step(g["actions"][t][None], g["action_valid"][t][None], None)
+        assert (run.err == 0).all()
+        np.testing.assert_array_equal(run.obs_valid[0], g["obs_valid"][t], err_msg=f"ov t={t}")
+        np.testing.assert_array_equal(run.reward_valid[0], g["reward_valid"][t], err_msg=f"rv t={t}")
+        np.testing.assert_array_equal(run.done_valid[0], g["done_valid"][t])
+        ov = g["obs_valid"][t].astype(bool)
+        np.testing.assert_array_equal(f32_bits(run.obs[0][ov]), f32_bits(g["obs"][t][ov]), err_msg=f"obs t={t}")
+        rv = g["reward_valid"][t] == 1
+        np.testing.assert_array_equal(f64_bits(run.reward[0][rv]), f64_bits(g["reward"][t][rv]))
+        np.testing.assert_array_equal(run.get_i32("seller.tx")[0], g["seller_tx"][t])
+        np.testing.assert_array_equal(f64_bits(run.get_f64("seller.revenue")[0]), f64_bits(g["seller_revenue"][t]))
+        np.testing.assert_array_equal(f64_bits(run.get_f64("seller.price")[0]), f64_bits(g["seller_price"][t]))
+        np.testing.assert_array_equal(run.get_i32("buyer.bought")[0], g["buyer_bought"][t])
+        np.testing.assert_array_equal(f64_bits(run.get_f64("buyer.paid")[0]), f64_bits(g["buyer_paid"][t]))
+        np.testing.assert_array_equal(run.all_truncated[0], g["all_truncated"][t])
+        assert int(run.msg_count[0]) == int(g["n_msgs"][t])
+        if t < 4:
+            np.testing.assert_array_equal(log_matrix(run.log(0)), g[f"log{t}"], err_msg=f"log t={t}")
+
+
+@pytest.mark.parametrize("name", ["stk_small", "stk_full"])
+def test_oracle_market_matches_reference(name):
+    replay_market(golden(name), lambda spec: OracleEnv(spec))
