@@ -1,0 +1,417 @@
+// phx_api.hip -- the C ABI of include/phantom_amd.h: spec validation, table upload, state-blob
+// layout and kernel dispatch.  No torch types cross this boundary; the caller owns the state
+// blob and every I/O buffer, the library owns only its copy of the static spec tables.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "phx_dev.h"
+
+
+size_t phx_generic_queue_bytes(int A, int Q, int scan_cap);
+hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
+hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, float* obs, uint8_t* obs_valid, hipStream_t st);
+hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
+hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(PHX_EHIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+static const int GENERIC_LDS_LIMIT = 60 * 1024;
+
+static bool kind_is_strategic(int k) {
+  return k == PHX_KIND_SHOP || k == PHX_KIND_SELLER || k == PHX_KIND_BUYER || k == PHX_KIND_MOCK_STRAT;
+}
+static int kind_obs_dim(int k) {
+  switch (k) { case PHX_KIND_SHOP: return 3; case PHX_KIND_SELLER: case PHX_KIND_BUYER: return 2;
+               case PHX_KIND_MOCK_STRAT: return 1; default: return 0; }
+}
+
+// ---- derived quantities of a spec (host) ---------------------------------------------------------
+struct Derived {
+  int A = 0, S = 0, D = 1, n_exo = 0, nnz = 0, buyer_nnz = 0, n_lists = 1, scan_cap = 0;
+  int kind_count[PHX_KIND_COUNT] = {0};
+  std::vector<int32_t> strat_rank, strat_idx, kind_rank, exo_rank, buyer_off;
+  std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
+  std::vector<uint8_t> act_mask, obs_mask, rew_mask;
+  // supply-chain schedule
+  bool sc_static = false;
+  std::vector<int32_t> shop_agent, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
+  std::vector<uint8_t> shop_cust_act;
+  int max_cust = 0;
+};
+
+static int derive(const phx_spec* sp, Derived& d) {
+  if (!sp) return fail(PHX_EINVAL, "null spec");
+  if (sp->abi_version != PHX_ABI_VERSION) return fail(PHX_EINVAL, "abi_version %d != %d", sp->abi_version, PHX_ABI_VERSION);
+  if (sp->n_agents <= 0 || sp->n_agents > 65535) return fail(PHX_EINVAL, "n_agents out of range");
+  if (sp->batch <= 0) return fail(PHX_EINVAL, "batch must be positive");
+  if (!sp->kind || !sp->param_i || !sp->param_f || !sp->row_ptr || !sp->col) return fail(PHX_EINVAL, "null table");
+  if (sp->queue_cap <= 0) return fail(PHX_EINVAL, "queue_cap must be positive");
+  const int A = sp->n_agents;
+  d.A = A; d.nnz = sp->row_ptr[A];
+  if (sp->row_ptr[0] != 0) return fail(PHX_EINVAL, "row_ptr[0] != 0");
+  for (int a = 0; a < A; ++a) if (sp->row_ptr[a + 1] < sp->row_ptr[a]) return fail(PHX_EINVAL, "row_ptr not monotone");
+  for (int k = 0; k < d.nnz; ++k) if (sp->col[k] < 0 || sp->col[k] >= A) return fail(PHX_EINVAL, "col out of range");
+  d.strat_rank.assign(A, -1); d.kind_rank.assign(A, 0); d.exo_rank.assign(A, -1); d.buyer_off.assign(A, 0);
+  for (int a = 0; a < A; ++a) {
+    const int k = sp->kind[a];
+    if (k <= 0 || k >= PHX_KIND_COUNT) return fail(PHX_EINVAL, "agent %d: unknown kind %d", a, k);
+    d.kind_rank[a] = d.kind_count[k]++;
+    if (kind_is_strategic(k)) { d.strat_rank[a] = d.S++; d.strat_idx.push_back(a); d.D = std::max(d.D, kind_obs_dim(k)); }
+    if (k == PHX_KIND_CUSTOMER) d.exo_rank[a] = d.n_exo++;
+    if (k == PHX_KIND_BUYER) { d.buyer_off[a] = d.buyer_nnz; d.buyer_nnz += sp->row_ptr[a + 1] - sp->row_ptr[a]; }
+    const int32_t* pi = sp->param_i + a * PHX_NPI;
+    if ((k == PHX_KIND_SHOP || k == PHX_KIND_CUSTOMER) && (pi[0] < 0 || pi[0] >= A))
+      return fail(PHX_EINVAL, "agent %d: target agent index out of range", a);
+    if (k == PHX_KIND_SHOP && pi[1] <= 0) return fail(PHX_EINVAL, "agent %d: ShopAgent max_sales_per_step must be > 0", a);
+    if (k == PHX_KIND_FORWARDER && pi[0] >= A) return fail(PHX_EINVAL, "agent %d: forward target out of range", a);
+    if (k == PHX_KIND_CUSTOMER && sp->kind[pi[0]] != PHX_KIND_SHOP)
+      return fail(PHX_EINVAL, "agent %d: CustomerAgent.shop_id is not a ShopAgent", a);
+  }
+  // acting lists + masks
+  if (sp->env_type == PHX_ENV_PLAIN) {
+    d.n_lists = 1; d.act_ptr = {0, A};
+    for (int a = 0; a < A; ++a) d.act_idx.push_back(a);
+    d.obs_mask.assign(A, 1); d.rew_mask.assign(A, 1); d.stage_next = {0};
+    d.reset_obs_idx = d.strat_idx;                                            // env.py:227
+  } else if (sp->env_type == PHX_ENV_FSM) {
+    const int ns = sp->n_stages;
+    if (ns <= 0 || !sp->stage_act_ptr || !sp->stage_act_idx || !sp->stage_rewarded || !sp->stage_rewarded_all || !sp->stage_next)
+      return fail(PHX_EINVAL, "FSM tables missing");
+    if (sp->initial_stage < 0 || sp->initial_stage >= ns) return fail(PHX_EINVAL, "initial_stage out of range");
+    d.n_lists = ns;
+    d.act_ptr.assign(sp->stage_act_ptr, sp->stage_act_ptr + ns + 1);
+    d.act_idx.assign(sp->stage_act_idx, sp->stage_act_idx + sp->stage_act_ptr[ns]);
+    for (int v : d.act_idx) if (v < 0 || v >= A) return fail(PHX_EINVAL, "acting agent out of range");
+    d.stage_next.assign(sp->stage_next, sp->stage_next + ns);
+    d.obs_mask.assign((size_t)ns * A, 0); d.rew_mask.assign((size_t)ns * A, 0);
+    for (int st = 0; st < ns; ++st) {
+      const int nx = sp->stage_next[st];
+      if (nx < 0 || nx >= ns) return fail(PHX_EINVAL, "stage_next out of range");
+      if (sp->stage_rewarded_all[st]) {                                       // fsm.py:315-317
+        for (int a = 0; a < A; ++a) d.obs_mask[(size_t)st * A + a] = d.rew_mask[(size_t)st * A + a] = 1;
+      } else {                                                                // fsm.py:319-320
+        for (int a = 0; a < A; ++a) d.rew_mask[(size_t)st * A + a] = sp->stage_rewarded[(size_t)st * A + a];
+        for (int k = sp->stage_act_ptr[nx]; k < sp->stage_act_ptr[nx + 1]; ++k)
+          d.obs_mask[(size_t)st * A + sp->stage_act_idx[k]] = 1;
+      }
+    }
+    const int i0 = sp->initial_stage;                                         // fsm.py:237-241
+    for (int k = sp->stage_act_ptr[i0]; k < sp->stage_act_ptr[i0 + 1]; ++k) d.reset_obs_idx.push_back(sp->stage_act_idx[k]);
+  } else if (sp->env_type == PHX_ENV_STACKELBERG) {
+    if ((sp->n_leaders && !sp->leaders) || (sp->n_followers && !sp->followers)) return fail(PHX_EINVAL, "leader/follower lists missing");
+    d.n_lists = 2; d.act_ptr = {0, sp->n_leaders, sp->n_leaders + sp->n_followers};
+    d.obs_mask.assign((size_t)2 * A, 0); d.rew_mask.assign((size_t)2 * A, 0); d.stage_next = {0, 0};
+    for (int k = 0; k < sp->n_leaders; ++k) {
+      const int a = sp->leaders[k]; if (a < 0 || a >= A) return fail(PHX_EINVAL, "leader out of range");
+      d.act_idx.push_back(a); d.rew_mask[a] = 1; d.obs_mask[(size_t)A + a] = 1; d.reset_obs_idx.push_back(a);
+    }
+    for (int k = 0; k < sp->n_followers; ++k) {
+      const int a = sp->followers[k]; if (a < 0 || a >= A) return fail(PHX_EINVAL, "follower out of range");
+      d.act_idx.push_back(a); d.obs_mask[a] = 1; d.rew_mask[(size_t)A + a] = 1;
+    }
+  } else return fail(PHX_EINVAL, "unknown env_type %d", sp->env_type);
+  d.act_mask.assign((size_t)d.n_lists * A, 0);
+  int longest = 0;
+  for (int l = 0; l < d.n_lists; ++l) {
+    longest = std::max(longest, d.act_ptr[l + 1] - d.act_ptr[l]);
+    for (int k = d.act_ptr[l]; k < d.act_ptr[l + 1]; ++k) d.act_mask[(size_t)l * A + d.act_idx[k]] = 1;
+  }
+  d.scan_cap = std::max(sp->queue_cap, longest + PHX_MAX_INJECT);
+
+  // ---- static supply-chain schedule? (fused kernels) ------------------------------------------
+  bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 &&
+            !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
+            (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS);
+  auto edge = [&](int u, int v) { for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k) if (sp->col[k] == v) return true; return false; };
+  for (int a = 0; a < A && sc; ++a) {
+    const int k = sp->kind[a]; const int32_t* pi = sp->param_i + a * PHX_NPI;
+    if (k == PHX_KIND_SHOP) sc = sp->kind[pi[0]] == PHX_KIND_FACTORY && edge(a, pi[0]) && edge(pi[0], a);
+    else if (k == PHX_KIND_CUSTOMER) sc = edge(a, pi[0]) && edge(pi[0], a);
+    else if (k != PHX_KIND_FACTORY) sc = false;
+  }
+  d.sc_static = sc;
+  if (d.kind_count[PHX_KIND_SHOP] > 0) {
+    const int nS = d.kind_count[PHX_KIND_SHOP];
+    d.shop_agent.assign(nS, 0);
+    std::vector<std::vector<int>> cust(nS);
+    for (int a = 0; a < A; ++a) {
+      if (sp->kind[a] == PHX_KIND_SHOP) d.shop_agent[d.kind_rank[a]] = a;
+      if (sp->kind[a] == PHX_KIND_CUSTOMER) cust[d.kind_rank[sp->param_i[a * PHX_NPI]]].push_back(a);
+    }
+    d.shop_cust_ptr.push_back(0);
+    for (int s = 0; s < nS; ++s) {
+      for (int a : cust[s]) { d.shop_cust_agent.push_back(a); d.shop_cust_exo.push_back(d.exo_rank[a]); }
+      d.shop_cust_ptr.push_back((int)d.shop_cust_agent.size());
+      d.max_cust = std::max(d.max_cust, (int)cust[s].size());
+    }
+    d.shop_cust_act.assign((size_t)d.n_lists * std::max(d.n_exo, 1), 0);
+    for (int l = 0; l < d.n_lists; ++l)
+      for (size_t k = 0; k < d.shop_cust_agent.size(); ++k)
+        d.shop_cust_act[(size_t)l * d.n_exo + k] = d.act_mask[(size_t)l * A + d.shop_cust_agent[k]];
+  }
+  return PHX_OK;
+}
+
+// ---- state blob layout ------------------------------------------------------------------------------
+struct FieldDef { int id; const char* name; int dtype; int kind; int64_t dim0, dim1, dim2; int64_t offset; };
+
+static int64_t esize(int dtype) { return dtype == 1 ? 8 : (dtype == 2 ? 1 : 4); }
+
+static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef>& out, int64_t* ws_stride) {
+  const int64_t B = sp->batch, S = std::max(d.S, 1);
+  auto kc = [&](int k) { return (int64_t)std::max(d.kind_count[k], 0); };
+  std::vector<FieldDef> f = {
+    {F_ENV_STEP, "env.step", 0, 0, B, 1, 1, 0}, {F_ENV_STAGE, "env.stage", 0, 0, B, 1, 1, 0},
+    {F_ENV_PREV_STAGE, "env.prev_stage", 0, 0, B, 1, 1, 0}, {F_ENV_TICK, "env.tick", 0, 0, B, 1, 1, 0},
+    {F_ENV_CLOCK, "env.clock", 0, 0, B, 1, 1, 0},
+    {F_ENV_TERM, "env.term", 2, 0, B, S, 1, 0}, {F_ENV_TRUNC, "env.trunc", 2, 0, B, S, 1, 0},
+    {F_ENV_REW_CACHE, "env.rew_cache", 1, 0, B, S, 1, 0}, {F_ENV_REW_CACHE_VALID, "env.rew_cache_valid", 2, 0, B, S, 1, 0},
+    {F_ENV_OBS_CACHE, "env.obs_cache", 3, 0, B, S, d.D, 0}, {F_ENV_OBS_CACHE_VALID, "env.obs_cache_valid", 2, 0, B, S, 1, 0},
+    {F_SHOP_STOCK, "shop.stock", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
+    {F_SHOP_SALES, "shop.sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
+    {F_SHOP_MISSED, "shop.missed_sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
+    {F_SHOP_DELIVERED, "shop.delivered_stock", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
+    {F_SELLER_PRICE, "seller.price", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
+    {F_SELLER_REVENUE, "seller.revenue", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
+    {F_SELLER_TX, "seller.tx", 0, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
+    {F_BUYER_PRICES, "buyer.prices", 1, PHX_KIND_BUYER, B, d.buyer_nnz, 1, 0},
+    {F_BUYER_PAID, "buyer.paid", 1, PHX_KIND_BUYER, B, kc(PHX_KIND_BUYER), 1, 0},
+    {F_BUYER_BOUGHT, "buyer.bought", 0, PHX_KIND_BUYER, B, kc(PHX_KIND_BUYER), 1, 0},
+    {F_CASHBOX_TOTAL, "cashbox.total_cash", 1, PHX_KIND_CASHBOX, B, kc(PHX_KIND_CASHBOX), 1, 0},
+    {F_REQRESP_REQ, "reqresp.req_time", 0, PHX_KIND_REQRESP, B, kc(PHX_KIND_REQRESP), 1, 0},
+    {F_REQRESP_RES, "reqresp.res_time", 0, PHX_KIND_REQRESP, B, kc(PHX_KIND_REQRESP), 1, 0},
+    {F_MOCK_ENC, "mock.encode_obs_count", 0, PHX_KIND_MOCK_STRAT, B, kc(PHX_KIND_MOCK_STRAT), 1, 0},
+    {F_MOCK_DEC, "mock.decode_action_count", 0, PHX_KIND_MOCK_STRAT, B, kc(PHX_KIND_MOCK_STRAT), 1, 0},
+    {F_MOCK_REW, "mock.compute_reward_count", 0, PHX_KIND_MOCK_STRAT, B, kc(PHX_KIND_MOCK_STRAT), 1, 0},
+  };
+  int64_t off = 0;
+  out.clear();
+  for (auto& x : f) {
+    const int64_t n = x.dim0 * x.dim1 * x.dim2;
+    if (n == 0) continue;
+    x.offset = off;
+    off += (n * esize(x.dtype) + 255) & ~(int64_t)255;
+    out.push_back(x);
+  }
+  // workspace of the generic engine when its queues do not fit LDS
+  const size_t qb = phx_generic_queue_bytes(d.A, sp->queue_cap, d.scan_cap);
+  *ws_stride = 0;
+  if (qb > (size_t)GENERIC_LDS_LIMIT) {
+    *ws_stride = ((int64_t)qb + 255) & ~(int64_t)255;
+    FieldDef w = {F_WORKSPACE, "workspace", 2, 0, B, *ws_stride, 1, off};
+    off += B * *ws_stride;
+    out.push_back(w);
+  }
+  return std::max<int64_t>(off, 256);
+}
+
+// ---- handle ----------------------------------------------------------------------------------------------
+struct phx_env {
+  DevSpec d;
+  Derived der;
+  std::vector<FieldDef> fields;
+  std::vector<void*> dev_allocs;
+  int device = 0;
+  bool use_fused = false, lds_ok = true;
+  DevMsg* inject_dev = nullptr;
+  DevMsg inject_host[PHX_MAX_INJECT];
+  int n_inject = 0;
+};
+
+template <typename T>
+static int upload(phx_env* e, const T* host, size_t n, const T** out) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  HIPCHK(hipMalloc(&p, bytes));
+  e->dev_allocs.push_back(p);
+  if (n) HIPCHK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return PHX_OK;
+}
+
+extern "C" {
+
+int phx_abi_version(void) { return PHX_ABI_VERSION; }
+const char* phx_last_error(void) { return g_err; }
+
+int64_t phx_state_nbytes(const phx_spec* spec) {
+  Derived d; if (derive(spec, d) != PHX_OK) return -1;
+  std::vector<FieldDef> f; int64_t ws;
+  return layout(spec, d, f, &ws);
+}
+int phx_obs_dim(const phx_spec* spec) { Derived d; return derive(spec, d) == PHX_OK ? d.D : -1; }
+int phx_n_strategic(const phx_spec* spec) { Derived d; return derive(spec, d) == PHX_OK ? d.S : -1; }
+int phx_n_exo(const phx_spec* spec) { Derived d; return derive(spec, d) == PHX_OK ? d.n_exo : -1; }
+
+int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state_nbytes, phx_env** out) {
+  if (!out) return fail(PHX_EINVAL, "null out");
+  *out = nullptr;
+  phx_env* e = new phx_env();
+  int rc = derive(spec, e->der);
+  if (rc != PHX_OK) { delete e; return rc; }
+  const Derived& der = e->der;
+  int64_t ws_stride = 0;
+  const int64_t need = layout(spec, der, e->fields, &ws_stride);
+  if (!state_blob || state_nbytes < need) { delete e; return fail(PHX_EINVAL, "state blob too small: %lld < %lld", (long long)state_nbytes, (long long)need); }
+  if (((uintptr_t)state_blob & 255) != 0) { delete e; return fail(PHX_EINVAL, "state blob must be 256-byte aligned"); }
+  e->device = device;
+  hipError_t he = hipSetDevice(device);
+  if (he != hipSuccess) { delete e; return fail(PHX_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(he)); }
+  DevSpec& d = e->d;
+  memset(&d, 0, sizeof d);
+  d.A = der.A; d.S = der.S; d.B = spec->batch; d.D = der.D; d.n_exo = der.n_exo; d.nnz = der.nnz;
+  d.num_steps = spec->num_steps; d.round_limit = spec->round_limit; d.env_type = spec->env_type;
+  d.flags = spec->flags; d.queue_cap = spec->queue_cap; d.trace_cap = spec->trace_cap; d.scan_cap = der.scan_cap;
+  d.n_lists = der.n_lists; d.initial_stage = spec->initial_stage; d.buyer_nnz = der.buyer_nnz;
+  d.seed = spec->seed; d.env_offset = spec->env_offset;
+  memcpy(d.kind_count, der.kind_count, sizeof d.kind_count);
+  const int A = der.A;
+#define UP(dst, ptr, n) do { rc = upload(e, ptr, (size_t)(n), &d.dst); if (rc != PHX_OK) { phx_destroy(e); return rc; } } while (0)
+  UP(kind, spec->kind, A); UP(param_i, spec->param_i, A * PHX_NPI); UP(param_f, spec->param_f, A * PHX_NPF);
+  UP(row_ptr, spec->row_ptr, A + 1); UP(col, spec->col, der.nnz);
+  UP(strat_rank, der.strat_rank.data(), A); UP(strat_idx, der.strat_idx.data(), der.strat_idx.size());
+  UP(kind_rank, der.kind_rank.data(), A); UP(exo_rank, der.exo_rank.data(), A); UP(buyer_off, der.buyer_off.data(), A);
+  UP(act_ptr, der.act_ptr.data(), der.act_ptr.size()); UP(act_idx, der.act_idx.data(), der.act_idx.size());
+  UP(act_mask, der.act_mask.data(), der.act_mask.size());
+  UP(obs_mask, der.obs_mask.data(), der.obs_mask.size()); UP(rew_mask, der.rew_mask.data(), der.rew_mask.size());
+  UP(stage_next, der.stage_next.data(), der.stage_next.size());
+  UP(reset_obs_idx, der.reset_obs_idx.data(), der.reset_obs_idx.size());
+  d.n_reset_obs = (int)der.reset_obs_idx.size();
+  UP(shop_agent, der.shop_agent.data(), der.shop_agent.size());
+  UP(shop_cust_ptr, der.shop_cust_ptr.data(), der.shop_cust_ptr.size());
+  UP(shop_cust_exo, der.shop_cust_exo.data(), der.shop_cust_exo.size());
+  UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());
+  UP(shop_cust_act, der.shop_cust_act.data(), der.shop_cust_act.size());
+#undef UP
+  d.max_cust = der.max_cust;
+  for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
+  d.ws_stride = ws_stride;
+  e->lds_ok = ws_stride == 0;
+  e->use_fused = der.sc_static;
+  he = hipMalloc((void**)&e->inject_dev, sizeof(DevMsg) * PHX_MAX_INJECT);
+  if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMalloc: %s", hipGetErrorString(he)); }
+  // constructor state: zero blob, then Agent.reset() for every agent (env.py:122-124)
+  he = hipMemset(state_blob, 0, (size_t)need);
+  if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMemset: %s", hipGetErrorString(he)); }
+  if (d.env_type == PHX_ENV_FSM) {
+    std::vector<int32_t> st((size_t)d.B, spec->initial_stage), pv((size_t)d.B, -1);
+    (void)hipMemcpy(d.f[F_ENV_STAGE], st.data(), st.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d.f[F_ENV_PREV_STAGE], pv.data(), pv.size() * 4, hipMemcpyHostToDevice);
+  }
+  he = phx_launch_reset(d, nullptr, nullptr, nullptr, 0);
+  if (he == hipSuccess) he = hipDeviceSynchronize();
+  if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "initial reset: %s", hipGetErrorString(he)); }
+  *out = e;
+  return PHX_OK;
+}
+
+void phx_destroy(phx_env* e) {
+  if (!e) return;
+  for (void* p : e->dev_allocs) (void)hipFree(p);
+  if (e->inject_dev) (void)hipFree(e->inject_dev);
+  delete e;
+}
+
+int phx_n_fields(const phx_env* e) { return e ? (int)e->fields.size() : 0; }
+
+int phx_field_info(const phx_env* e, int index, phx_field* out) {
+  if (!e || !out || index < 0 || index >= (int)e->fields.size()) return fail(PHX_EINVAL, "bad field index");
+  const FieldDef& f = e->fields[index];
+  memset(out, 0, sizeof *out);
+  out->field_id = f.id; out->dtype = f.dtype; out->offset = f.offset;
+  out->dim0 = (int32_t)f.dim0; out->dim1 = (int32_t)f.dim1; out->dim2 = (int32_t)f.dim2; out->kind = f.kind;
+  strncpy(out->name, f.name, sizeof(out->name) - 1);
+  return PHX_OK;
+}
+
+int phx_uses_fused(const phx_env* e) { return e && e->use_fused ? 1 : 0; }
+
+int phx_reset(phx_env* e, const uint8_t* reset_mask, float* obs, uint8_t* obs_valid, void* stream) {
+  if (!e) return fail(PHX_EINVAL, "null env");
+  HIPCHK(phx_launch_reset(e->d, reset_mask, obs, obs_valid, (hipStream_t)stream));
+  return PHX_OK;
+}
+
+static int check_step_io(const phx_env* e, const phx_step_io* io) {
+  if (!io) return fail(PHX_EINVAL, "null io");
+  if (e->d.S > 0 && !io->actions && !io->action_valid) return fail(PHX_EINVAL, "actions is NULL");
+  if (!io->obs || !io->obs_valid || !io->reward || !io->reward_valid || !io->terminated || !io->truncated ||
+      !io->done_valid || !io->all_terminated || !io->all_truncated)
+    return fail(PHX_EINVAL, "a required output pointer is NULL");
+  if ((io->msg_log || io->msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
+  return PHX_OK;
+}
+
+static int upload_inject(phx_env* e, hipStream_t st) {
+  if (e->n_inject > 0)
+    HIPCHK(hipMemcpyAsync(e->inject_dev, e->inject_host, sizeof(DevMsg) * e->n_inject, hipMemcpyHostToDevice, st));
+  return PHX_OK;
+}
+
+int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
+  if (!e) return fail(PHX_EINVAL, "null env");
+  int rc = check_step_io(e, io);
+  if (rc != PHX_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (e->use_fused && e->n_inject == 0) {
+    HIPCHK(phx_launch_sc_step(e->d, *io, st));
+    return PHX_OK;
+  }
+  GenArgs g; g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0;
+  rc = upload_inject(e, st);
+  if (rc != PHX_OK) return rc;
+  if (e->n_inject) HIPCHK(hipStreamSynchronize(st));   // inject_host is reused right after
+  e->n_inject = 0;
+  HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
+  return PHX_OK;
+}
+
+int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) {
+  if (!e || (n > 0 && !msgs)) return fail(PHX_EINVAL, "null argument");
+  if (e->n_inject + n > PHX_MAX_INJECT) return fail(PHX_ECAPACITY, "at most %d injected messages per resolve", PHX_MAX_INJECT);
+  for (int k = 0; k < n; ++k) {
+    if (msgs[k].sender >= e->d.A || msgs[k].receiver >= e->d.A) return fail(PHX_EINVAL, "agent index out of range");
+    DevMsg m; m.src = msgs[k].sender; m.dst = msgs[k].receiver; m.type = msgs[k].type; m.pad = 0; m.p.i = msgs[k].payload.i;
+    e->inject_host[e->n_inject++] = m;
+  }
+  return PHX_OK;
+}
+
+int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count, void* stream) {
+  if (!e) return fail(PHX_EINVAL, "null env");
+  if ((msg_log || msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
+  hipStream_t st = (hipStream_t)stream;
+  GenArgs g; memset(&g, 0, sizeof g);
+  g.io.err = err; g.io.msg_log = msg_log; g.io.msg_count = msg_count;
+  g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 1;
+  int rc = upload_inject(e, st);
+  if (rc != PHX_OK) return rc;
+  if (e->n_inject) HIPCHK(hipStreamSynchronize(st));
+  e->n_inject = 0;
+  HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
+  return PHX_OK;
+}
+
+int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
+  if (!e || !io) return fail(PHX_EINVAL, "null argument");
+  if (!e->use_fused || e->d.env_type != PHX_ENV_PLAIN)
+    return fail(PHX_EUNSUPPORTED, "phx_rollout needs a plain env with a static supply-chain schedule");
+  if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
+    return fail(PHX_EINVAL, "bad rollout io");
+  HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
+  return PHX_OK;
+}
+
+}  // extern "C"

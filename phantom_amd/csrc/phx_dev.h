@@ -1,0 +1,289 @@
+// phx_dev.h -- device-side view of a compiled env spec + the per-kind agent behaviour.
+//
+// The reference executes these bodies as Python methods on agent objects; here they are
+// inlined device functions over struct-of-arrays state in HBM.  One field of one kind is a
+// dense [B][n_kind] array so that lanes mapped to (env, agent-of-kind) touch consecutive
+// addresses.  Reference line numbers refer to /root/reference.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/phantom_amd.h"
+
+#define PHX_SHOP_MAX_STOCK 100   // supply_chain.py:13
+#define PHX_MAX_INJECT 16
+
+// message record as it travels through the per-env queues (LDS or workspace)
+struct __attribute__((aligned(16))) DevMsg {
+  uint16_t src, dst, type, pad;
+  union { int64_t i; double f; } p;
+};
+static_assert(sizeof(DevMsg) == 16, "DevMsg must be 16 bytes");
+
+// state field ids (index into DevSpec::f[])
+enum {
+  F_ENV_STEP = 0, F_ENV_STAGE, F_ENV_PREV_STAGE, F_ENV_TICK, F_ENV_CLOCK,
+  F_ENV_TERM, F_ENV_TRUNC, F_ENV_REW_CACHE, F_ENV_REW_CACHE_VALID, F_ENV_OBS_CACHE,
+  F_ENV_OBS_CACHE_VALID,
+  F_SHOP_STOCK, F_SHOP_SALES, F_SHOP_MISSED, F_SHOP_DELIVERED,
+  F_SELLER_PRICE, F_SELLER_REVENUE, F_SELLER_TX,
+  F_BUYER_PRICES, F_BUYER_PAID, F_BUYER_BOUGHT,
+  F_CASHBOX_TOTAL,
+  F_REQRESP_REQ, F_REQRESP_RES,
+  F_MOCK_ENC, F_MOCK_DEC, F_MOCK_REW,
+  F_WORKSPACE,
+  F_COUNT
+};
+
+struct DevSpec {
+  int32_t A, S, B, D, n_exo, nnz;
+  int32_t num_steps, round_limit, env_type;
+  uint32_t flags;
+  int32_t queue_cap, trace_cap;
+  int32_t scan_cap;              // >= max(queue_cap, longest acting list + PHX_MAX_INJECT)
+  int32_t n_lists;               // acting lists: PLAIN 1, FSM n_stages, STACKELBERG 2
+  int32_t initial_stage;
+  int32_t buyer_nnz;             // total price slots of all buyers (per env)
+  uint64_t seed;
+  int64_t env_offset;
+  int32_t kind_count[PHX_KIND_COUNT];
+  // static tables (device memory)
+  const uint8_t* kind;           // [A]
+  const int32_t* param_i;        // [A][PHX_NPI]
+  const double*  param_f;        // [A][PHX_NPF]
+  const int32_t* row_ptr;        // [A+1]
+  const int32_t* col;            // [nnz]
+  const int32_t* strat_rank;     // [A]  -1 for non-strategic
+  const int32_t* strat_idx;      // [S]
+  const int32_t* kind_rank;      // [A]
+  const int32_t* exo_rank;       // [A]  -1 unless CUSTOMER
+  const int32_t* buyer_off;      // [A]  first price slot of a BUYER in buyer.prices
+  const int32_t* act_ptr;        // [n_lists+1] ordered acting lists
+  const int32_t* act_idx;
+  const uint8_t* act_mask;       // [n_lists][A] 1 <=> agent is in the acting list
+  const uint8_t* obs_mask;       // [n_lists][A] who observes after a step in this list/stage
+  const uint8_t* rew_mask;       // [n_lists][A] who is rewarded
+  const int32_t* stage_next;     // [n_lists]  (FSM)
+  const int32_t* reset_obs_ptr;  // agents that observe at reset: CSR with a single row
+  const int32_t* reset_obs_idx;
+  int32_t n_reset_obs;
+  // supply-chain static schedule (fused kernels)
+  const int32_t* shop_agent;     // [nS] agent index of each shop (kind-rank order)
+  const int32_t* shop_cust_ptr;  // [nS+1]
+  const int32_t* shop_cust_exo;  // exo rank of each customer of the shop, acting order
+  const int32_t* shop_cust_agent;// agent index of each customer
+  const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
+  int32_t max_cust;              // max customers of one shop
+  // state blob field pointers
+  void* f[F_COUNT];
+  int64_t ws_stride;             // workspace bytes per env
+};
+
+struct GenArgs {               // arguments of the generic engine kernel
+  phx_step_io io;
+  const DevMsg* inject;         // device copy of host-injected messages (same for every env)
+  int32_t n_inject;
+  int32_t resolve_only;         // Network.resolve() alone: no clock tick, no acting, no epilogue
+};
+
+template <typename T>
+__device__ __forceinline__ T* fld(const DevSpec& sp, int id) { return (T*)sp.f[id]; }
+
+// ---- payload whitelists (message.py:20-42): 0 = any -----------------------------------------
+__device__ __forceinline__ void dev_payload_types(int type, int& sk, int& rk, int& decorated) {
+  decorated = 1; sk = 0; rk = 0;
+  switch (type) {
+    case PHX_MSG_ORDER_REQUEST:  sk = PHX_KIND_CUSTOMER; rk = PHX_KIND_SHOP; break;
+    case PHX_MSG_ORDER_RESPONSE: sk = PHX_KIND_SHOP; rk = PHX_KIND_CUSTOMER; break;
+    case PHX_MSG_STOCK_REQUEST:  sk = PHX_KIND_SHOP; rk = PHX_KIND_FACTORY; break;
+    case PHX_MSG_STOCK_RESPONSE: sk = PHX_KIND_FACTORY; rk = PHX_KIND_SHOP; break;
+    case PHX_MSG_PRICE:          sk = PHX_KIND_SELLER; rk = PHX_KIND_BUYER; break;
+    case PHX_MSG_ORDER:          sk = PHX_KIND_BUYER; rk = PHX_KIND_SELLER; break;
+    case PHX_MSG_PING:           decorated = 0; break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ int dev_nbr_slot(const DevSpec& sp, int u, int v) {
+  const int lo = sp.row_ptr[u], hi = sp.row_ptr[u + 1];
+  for (int k = lo; k < hi; ++k)
+    if (sp.col[k] == v) return k - lo;
+  return -1;
+}
+__device__ __forceinline__ bool dev_has_edge(const DevSpec& sp, int u, int v) {   // network.py:224-231
+  return dev_nbr_slot(sp, u, v) >= 0;
+}
+
+// Network.send checks (network.py:246-252, 297-331); returns PHX_ERR_* (0 = deliverable)
+__device__ __forceinline__ int dev_send_check(const DevSpec& sp, int src, int dst, int type) {
+  if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, src, dst)) return PHX_ERR_NETWORK;
+  if (!(sp.flags & PHX_F_NO_PAYLOAD_CHECKS)) {
+    int sk, rk, dec;
+    dev_payload_types(type, sk, rk, dec);
+    if (!dec) return PHX_ERR_PAYLOAD;
+    if (sk && sp.kind[src] != sk) return PHX_ERR_PAYLOAD;
+    if (rk && sp.kind[dst] != rk) return PHX_ERR_PAYLOAD;
+  }
+  return 0;
+}
+
+// ---- device RNG (the definition is stated in DESIGN.md; the oracle restates it) ---------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Order sizes of the K customers of one shop: the first K accepted 3-bit fields (10 per 32-bit
+// word, values > 4 rejected -- numpy's masked rejection for randint(5)) of the shop's Philox
+// block sequence ctr = (env_lo, env_hi, tick, shop | blk << 20).  Returns the sum over the
+// customers selected by `actmask` (NULL = all) or, with kth >= 0, only customer kth's draw.
+__device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
+                                               int K, const uint8_t* actmask, int kth) {
+  int got = 0, sum = 0;
+  for (uint32_t blk = 0; got < K; ++blk) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
+                  (uint32_t)shop | (blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t x = w[j];
+#pragma unroll
+      for (int f = 0; f < 10; ++f) {
+        const uint32_t v = x & 7u; x >>= 3;
+        if (v <= 4u && got < K) {
+          const bool use = kth >= 0 ? (got == kth) : (actmask == nullptr || actmask[got] != 0);
+          sum += use ? (int)v : 0;
+          ++got;
+        }
+      }
+    }
+  }
+  return sum;
+}
+
+__device__ __forceinline__ float rng_action(uint64_t seed, int64_t genv, uint32_t tick, int r) {
+  uint32_t w[4];
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick, 0x80000000u | (uint32_t)(r >> 2),
+                (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const uint32_t u = (r & 3) == 0 ? w[0] : (r & 3) == 1 ? w[1] : (r & 3) == 2 ? w[2] : w[3];
+  return (float)(u >> 8) * (100.0f / 16777216.0f);
+}
+
+// int(round(np.float32(a))) -- round-half-to-even, supply_chain.py:139
+__device__ __forceinline__ int dev_round_half_even(float a) {
+  double r = rint((double)a);
+  r = r > 1073741824.0 ? 1073741824.0 : r;
+  r = r < -1073741824.0 ? -1073741824.0 : r;
+  return (int)r;
+}
+
+// ShopAgent.compute_reward: sales - 0.1 * stock in f64, product and difference rounded
+// separately (supply_chain.py:147); the library is compiled with -ffp-contract=off.
+__device__ __forceinline__ double shop_reward(int sales, int stock) {
+  const double penalty = __dmul_rn(0.1, (double)stock);
+  return __dsub_rn((double)sales, penalty);
+}
+
+// ShopAgent.encode_observation (supply_chain.py:124-134): python-float quotient cast to f32
+__device__ __forceinline__ void shop_obs(int stock, int sales, int missed, int norm, float* o) {
+  const double n = (double)norm;
+  o[0] = (float)((double)stock / (double)PHX_SHOP_MAX_STOCK);
+  o[1] = (float)((double)sales / n);
+  o[2] = (float)((double)missed / n);
+}
+
+// ---- generic per-kind behaviour used by the generic engine ---------------------------------
+struct AgentRef {          // where one agent's state lives for env b
+  int a, kind, kr;         // agent index, kind, rank within kind
+  int64_t base;            // b * kind_count[kind] + kr
+};
+
+__device__ __forceinline__ AgentRef agent_ref(const DevSpec& sp, int b, int a) {
+  AgentRef r;
+  r.a = a; r.kind = sp.kind[a]; r.kr = sp.kind_rank[a];
+  r.base = (int64_t)b * sp.kind_count[r.kind] + r.kr;
+  return r;
+}
+
+// Agent.reset and subclasses (agents.py:160-175; supply_chain.py:149-150; test_network.py:23-24)
+__device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, int b, int a) {
+  const AgentRef r = agent_ref(sp, b, a);
+  switch (r.kind) {
+    case PHX_KIND_SHOP: fld<int32_t>(sp, F_SHOP_STOCK)[r.base] = 0; break;
+    case PHX_KIND_CASHBOX: fld<double>(sp, F_CASHBOX_TOTAL)[r.base] = 0.0; break;
+    case PHX_KIND_SELLER:
+      fld<double>(sp, F_SELLER_PRICE)[r.base] = 0.0;
+      fld<double>(sp, F_SELLER_REVENUE)[r.base] = 0.0;
+      fld<int32_t>(sp, F_SELLER_TX)[r.base] = 0;
+      break;
+    case PHX_KIND_BUYER: {
+      const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
+      double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
+      for (int k = 0; k < deg; ++k) pr[k] = 1.0;
+      fld<double>(sp, F_BUYER_PAID)[r.base] = 0.0;
+      fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
+      break;
+    }
+    default: break;
+  }
+}
+
+// encode_observation of a strategic agent; `step` is ctx.env_view.current_step
+__device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, int b, int a, int step, float* o) {
+  const AgentRef r = agent_ref(sp, b, a);
+  switch (r.kind) {
+    case PHX_KIND_SHOP:
+      shop_obs(fld<int32_t>(sp, F_SHOP_STOCK)[r.base], fld<int32_t>(sp, F_SHOP_SALES)[r.base],
+               fld<int32_t>(sp, F_SHOP_MISSED)[r.base], sp.param_i[a * PHX_NPI + 1], o);
+      break;
+    case PHX_KIND_SELLER: {
+      const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
+      o[0] = (float)((double)fld<int32_t>(sp, F_SELLER_TX)[r.base] / (double)deg);
+      o[1] = (float)fld<double>(sp, F_SELLER_PRICE)[r.base];
+      break;
+    }
+    case PHX_KIND_BUYER: {
+      const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
+      const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
+      double mn = pr[0];
+      for (int k = 1; k < deg; ++k) mn = pr[k] < mn ? pr[k] : mn;
+      o[0] = (float)mn;
+      o[1] = (float)sp.param_f[a * PHX_NPF];
+      break;
+    }
+    case PHX_KIND_MOCK_STRAT:                                  // tests/__init__.py:49-51
+      fld<int32_t>(sp, F_MOCK_ENC)[r.base] += 1;
+      o[0] = (float)((double)step / (double)sp.num_steps);
+      break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, int b, int a) {
+  const AgentRef r = agent_ref(sp, b, a);
+  switch (r.kind) {
+    case PHX_KIND_SHOP:
+      return shop_reward(fld<int32_t>(sp, F_SHOP_SALES)[r.base], fld<int32_t>(sp, F_SHOP_STOCK)[r.base]);
+    case PHX_KIND_SELLER: return fld<double>(sp, F_SELLER_REVENUE)[r.base];
+    case PHX_KIND_BUYER:
+      if (fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base])
+        return __dsub_rn(sp.param_f[a * PHX_NPF], fld<double>(sp, F_BUYER_PAID)[r.base]);
+      return 0.0;
+    case PHX_KIND_MOCK_STRAT: fld<int32_t>(sp, F_MOCK_REW)[r.base] += 1; return 0.0;
+    default: return 0.0;
+  }
+}
+
+__device__ __forceinline__ bool dev_is_done(const DevSpec& sp, int a, int step) {
+  // is_terminated == is_truncated for the only kind that overrides them (tests/__init__.py:61-65)
+  return sp.kind[a] == PHX_KIND_MOCK_STRAT && step == sp.param_i[a * PHX_NPI];
+}

@@ -1,0 +1,555 @@
+// phx_generic.hip -- the generic message-passing engine: one workgroup per env instance.
+//
+// Replaces, for a whole batch per launch, the interpreter loops of
+//   PhantomEnv.step / _handle_acting_agents / resolve_network   phantom/env.py:239-336
+//   Network.send / resolve                                      phantom/network.py:233-265
+//   BatchResolver.resolve (round loop)                          phantom/resolvers.py:128-163
+//   Agent.handle_batch / handle_message                         phantom/agents.py:96-155
+//   FiniteStateMachineEnv.step masks + reward cache             phantom/fsm.py:309-380
+//   StackelbergEnv.step masks + reward cache                    phantom/stackelberg.py:133-196
+//
+// Layout of one round (the reference's insertion-ordered dict of lists, resolvers.py:120/142,
+// rebuilt without any sequential walk over the queue):
+//   * the round's messages sit in a dense queue in SEND order (q[i], i = send sequence number);
+//   * LDS atomics give every message its slot in the receiver's inbox and every receiver its
+//     first-arrival index; an exclusive block scan over "head" messages turns first-arrival
+//     order into inbox offsets, so inbox order[] holds receivers in dict order and, after a
+//     short per-receiver sort by sequence number, each batch in send order;
+//   * one lane per receiver walks its batch (handlers are sequential in the reference too) and
+//     leaves at most one response per message in processing order; a second block scan
+//     compacts the responses into the next round's queue = the order network.send was called.
+// Queues live in LDS (template LDSQ = true); envs whose queue does not fit use a per-env
+// workspace carved from the caller's state blob.
+#include "phx_dev.h"
+
+#define ERRKEY_NONE 0x7fffffff
+
+
+template <int NT>
+__device__ __forceinline__ int block_exscan(int* arr, int n, int* wave_sums) {
+  // in-place exclusive scan of arr[0..n); returns the total.  All NT threads must call.
+  const int tid = threadIdx.x;
+  const int chunk = (n + NT - 1) / NT;
+  const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+  int local = 0;
+  for (int i = lo; i < hi; ++i) local += arr[i];
+  int incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if ((tid & 63) >= off) incl += v;
+  }
+  if ((tid & 63) == 63) wave_sums[tid >> 6] = incl;
+  __syncthreads();
+  int wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const int s = wave_sums[w];
+    if (w < (tid >> 6)) wave_off += s;
+    total += s;
+  }
+  int running = wave_off + incl - local;
+  for (int i = lo; i < hi; ++i) {
+    const int v = arr[i];
+    arr[i] = running;
+    running += v;
+  }
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ void set_errkey(int* errkey, int seq, int code) {
+  atomicMin(errkey, (seq << 4) | code);
+}
+
+// ---- acting phase: decode_action (env.py:330-331) / generate_messages (:332-333) -------------
+__device__ __forceinline__ int act_count(const DevSpec& sp, int b, int a, bool has_action, float action) {
+  switch (sp.kind[a]) {
+    case PHX_KIND_SHOP: return has_action ? 1 : 0;
+    case PHX_KIND_CUSTOMER: return 1;
+    case PHX_KIND_SELLER: return has_action ? sp.row_ptr[a + 1] - sp.row_ptr[a] : 0;
+    case PHX_KIND_BUYER: return (has_action && action > 0.5f && sp.row_ptr[a + 1] > sp.row_ptr[a]) ? 1 : 0;
+    default: return 0;
+  }
+}
+
+template <typename Q>
+__device__ __forceinline__ void act_emit(const DevSpec& sp, int b, int a, bool has_action, float action,
+                                         const uint8_t* exo_b, uint32_t tick, Q* out) {
+  const AgentRef r = agent_ref(sp, b, a);
+  const int32_t* pi = sp.param_i + a * PHX_NPI;
+  DevMsg m;
+  m.src = (uint16_t)a; m.pad = 0;
+  switch (r.kind) {
+    case PHX_KIND_SHOP:
+      if (has_action) {                                        // supply_chain.py:136-142
+        const int req = dev_round_half_even(action);
+        const int room = PHX_SHOP_MAX_STOCK - fld<int32_t>(sp, F_SHOP_STOCK)[r.base];
+        m.dst = (uint16_t)pi[0]; m.type = PHX_MSG_STOCK_REQUEST; m.p.i = req < room ? req : room;
+        out[0] = m;
+      }
+      break;
+    case PHX_KIND_CUSTOMER: {                                  // supply_chain.py:61-67
+      int order;
+      if (exo_b) order = exo_b[sp.exo_rank[a]];
+      else order = rng_shop_orders(sp.seed, sp.env_offset + b, tick, sp.kind_rank[pi[0]], pi[1] + 1,
+                                   nullptr, pi[1]);
+      m.dst = (uint16_t)pi[0]; m.type = PHX_MSG_ORDER_REQUEST; m.p.i = order;
+      out[0] = m;
+      break;
+    }
+    case PHX_KIND_SELLER:
+      if (has_action) {
+        const double price = (double)action;
+        fld<double>(sp, F_SELLER_PRICE)[r.base] = price;
+        m.type = PHX_MSG_PRICE; m.p.f = price;
+        const int lo = sp.row_ptr[a], hi = sp.row_ptr[a + 1];
+        for (int k = lo; k < hi; ++k) { m.dst = (uint16_t)sp.col[k]; out[k - lo] = m; }
+      }
+      break;
+    case PHX_KIND_BUYER:
+      if (has_action) {
+        const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
+        if (action > 0.5f && deg > 0) {
+          const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
+          int j = 0; double best = pr[0];
+          for (int k = 1; k < deg; ++k) if (pr[k] < best) { best = pr[k]; j = k; }
+          fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 1;
+          fld<double>(sp, F_BUYER_PAID)[r.base] = best;
+          m.dst = (uint16_t)sp.col[sp.row_ptr[a] + j]; m.type = PHX_MSG_ORDER; m.p.i = 1;
+          out[0] = m;
+        } else {
+          fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
+          fld<double>(sp, F_BUYER_PAID)[r.base] = 0.0;
+        }
+      }
+      break;
+    case PHX_KIND_MOCK_STRAT:
+      if (has_action) fld<int32_t>(sp, F_MOCK_DEC)[r.base] += 1;     // tests/__init__.py:53-55
+      break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ void pre_resolution(const DevSpec& sp, int b, int a, int step) {
+  const AgentRef r = agent_ref(sp, b, a);
+  switch (r.kind) {
+    case PHX_KIND_SHOP:                                        // supply_chain.py:93-96
+      fld<int32_t>(sp, F_SHOP_SALES)[r.base] = 0;
+      fld<int32_t>(sp, F_SHOP_MISSED)[r.base] = 0;
+      break;
+    case PHX_KIND_SELLER:
+      if ((step & 1) == 0) {
+        fld<double>(sp, F_SELLER_REVENUE)[r.base] = 0.0;
+        fld<int32_t>(sp, F_SELLER_TX)[r.base] = 0;
+      }
+      break;
+    default: break;
+  }
+}
+
+// Agent.handle_message (agents.py:122-155): returns true and fills `resp` (dst/type/payload)
+// when the handler answers; sets `code` to PHX_ERR_UNKNOWN_MSG for an unhandled payload type.
+__device__ __forceinline__ bool handle_message(const DevSpec& sp, int b, int a, const DevMsg& m,
+                                               int clock, DevMsg& resp, int& code) {
+  const AgentRef r = agent_ref(sp, b, a);
+  const int32_t* pi = sp.param_i + a * PHX_NPI;
+  resp.src = (uint16_t)a; resp.dst = m.src; resp.pad = 0; resp.type = 0;
+  switch (r.kind) {
+    case PHX_KIND_FACTORY:
+      if (m.type == PHX_MSG_STOCK_REQUEST) {                   // supply_chain.py:40-45
+        resp.type = PHX_MSG_STOCK_RESPONSE; resp.p.i = m.p.i; return true;
+      }
+      break;
+    case PHX_KIND_SHOP: {
+      int32_t* stock = fld<int32_t>(sp, F_SHOP_STOCK) + r.base;
+      if (m.type == PHX_MSG_STOCK_RESPONSE) {                  // supply_chain.py:98-103
+        fld<int32_t>(sp, F_SHOP_DELIVERED)[r.base] = (int32_t)m.p.i;
+        const int ns = *stock + (int32_t)m.p.i;
+        *stock = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
+        return false;
+      }
+      if (m.type == PHX_MSG_ORDER_REQUEST) {                   // supply_chain.py:105-122
+        const int req = (int)m.p.i;
+        int sell;
+        if (req > *stock) {
+          fld<int32_t>(sp, F_SHOP_MISSED)[r.base] += req - *stock;
+          sell = *stock; *stock = 0;
+        } else { sell = req; *stock -= req; }
+        fld<int32_t>(sp, F_SHOP_SALES)[r.base] += sell;
+        resp.type = PHX_MSG_ORDER_RESPONSE; resp.p.i = sell; return true;
+      }
+      break;
+    }
+    case PHX_KIND_CUSTOMER:
+      if (m.type == PHX_MSG_ORDER_RESPONSE) return false;      // supply_chain.py:55-59
+      break;
+    case PHX_KIND_SELLER:
+      if (m.type == PHX_MSG_ORDER) {
+        const double amount = __dmul_rn(fld<double>(sp, F_SELLER_PRICE)[r.base], (double)m.p.i);
+        fld<double>(sp, F_SELLER_REVENUE)[r.base] = __dadd_rn(fld<double>(sp, F_SELLER_REVENUE)[r.base], amount);
+        fld<int32_t>(sp, F_SELLER_TX)[r.base] += (int32_t)m.p.i;
+        return false;
+      }
+      break;
+    case PHX_KIND_BUYER:
+      if (m.type == PHX_MSG_PRICE) {
+        const int slot = dev_nbr_slot(sp, a, m.src);
+        if (slot >= 0)
+          fld<double>(sp, F_BUYER_PRICES)[(int64_t)b * sp.buyer_nnz + sp.buyer_off[a] + slot] = m.p.f;
+        return false;
+      }
+      break;
+    case PHX_KIND_HALVER:
+      if (m.type == PHX_MSG_HALVE) {                           // test_tracking.py:22-27
+        if (m.p.i > 1) { resp.type = PHX_MSG_HALVE; resp.p.i = m.p.i / 2; return true; }
+        return false;
+      }
+      break;
+    case PHX_KIND_CASHBOX:
+      if (m.type == PHX_MSG_CASH) {                            // test_network.py:26-34
+        if (m.p.f > 25) {
+          fld<double>(sp, F_CASHBOX_TOTAL)[r.base] += m.p.f / 2.0;
+          resp.type = PHX_MSG_CASH; resp.p.f = m.p.f / 2.0; return true;
+        }
+        return false;
+      }
+      break;
+    case PHX_KIND_REQRESP:
+      if (m.type == PHX_MSG_REQUEST) {                         // test_resolver.py:31-37
+        fld<int32_t>(sp, F_REQRESP_REQ)[r.base] = clock;
+        resp.type = PHX_MSG_RESPONSE; resp.p.f = m.p.f / 2.0; return true;
+      }
+      if (m.type == PHX_MSG_RESPONSE) { fld<int32_t>(sp, F_REQRESP_RES)[r.base] = clock; return false; }
+      break;
+    case PHX_KIND_FORWARDER:                                   // test_resolver.py:93-96
+      if (pi[0] >= 0) { resp.dst = (uint16_t)pi[0]; resp.type = PHX_MSG_PING; resp.p.i = 1; return true; }
+      return false;
+    default: break;
+  }
+  code = PHX_ERR_UNKNOWN_MSG;                                  // agents.py:140-143
+  return false;
+}
+
+template <int NT, bool LDSQ>
+__global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, const GenArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int wave_sums[NT / 64];
+  __shared__ int s_errkey, s_nterm, s_ntrunc;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int A = sp.A, S = sp.S, D = sp.D, Q = sp.queue_cap;
+
+  char* mem = LDSQ ? smem : ((char*)sp.f[F_WORKSPACE] + (int64_t)b * sp.ws_stride);
+  DevMsg* q0 = (DevMsg*)mem;
+  DevMsg* q1 = q0 + Q;
+  DevMsg* resp = q1 + Q;
+  int* order = (int*)(resp + Q);
+  int* slot = order + Q;
+  int* scanbuf = slot + Q;
+  int* cnt = scanbuf + sp.scan_cap;
+  int* first = cnt + A;
+  int* goff = first + A;
+  uint8_t* live = (uint8_t*)(goff + A);
+
+  int32_t* step_p = fld<int32_t>(sp, F_ENV_STEP) + b;
+  int32_t* stage_p = fld<int32_t>(sp, F_ENV_STAGE) + b;
+  uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
+  uint8_t* trunc = fld<uint8_t>(sp, F_ENV_TRUNC) + (int64_t)b * S;
+
+  const bool full = !g.resolve_only;
+  const int t = full ? *step_p + 1 : *step_p;                  // env.py:252
+  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  const int clock0 = fld<int32_t>(sp, F_ENV_CLOCK)[b];
+  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? *stage_p : 0;
+  int list = 0;                                                // which acting list / mask row
+  if (sp.env_type == PHX_ENV_FSM) list = cur_stage;                          // fsm.py:276
+  else if (sp.env_type == PHX_ENV_STACKELBERG) list = (t & 1) ? 0 : 1;       // stackelberg.py:133-137
+
+  if (tid == 0) { s_errkey = ERRKEY_NONE; s_nterm = 0; s_ntrunc = 0; }
+  // _make_ctxs (env.py:338-348): contexts only for agents that are not done
+  for (int a = tid; a < A; a += NT) {
+    const int s = sp.strat_rank[a];
+    live[a] = (g.resolve_only || s < 0) ? 1 : !(term[s] | trunc[s]);
+  }
+  __syncthreads();
+
+  // ---- round-0 queue: host-injected sends, then the acting agents in list order -------------
+  const int n_act = full ? sp.act_ptr[list + 1] - sp.act_ptr[list] : 0;
+  const int32_t* act_list = sp.act_idx + sp.act_ptr[list];
+  const int n_items = g.n_inject + n_act;
+  const float* actions_b = g.io.actions ? g.io.actions + (int64_t)b * S : nullptr;
+  const uint8_t* av_b = g.io.action_valid ? g.io.action_valid + (int64_t)b * S : nullptr;
+  const uint8_t* exo_b = g.io.exo ? g.io.exo + (int64_t)b * sp.n_exo : nullptr;
+
+  // per-item message counts -> exclusive scan -> queue offsets (scanbuf holds scan_cap >= n_items)
+  for (int it = tid; it < n_items; it += NT) {
+    int c = 0;
+    if (it < g.n_inject) {
+      const DevMsg m = g.inject[it];
+      const int code = dev_send_check(sp, m.src, m.dst, m.type);
+      if (code) set_errkey(&s_errkey, it, code); else c = 1;
+    } else {
+      const int a = act_list[it - g.n_inject];
+      if (live[a]) {                                           // env.py:324-325
+        const int s = sp.strat_rank[a];
+        const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);        // aid in actions, env.py:330
+        c = act_count(sp, b, a, has, has ? actions_b[s] : 0.0f);
+      }
+    }
+    scanbuf[it] = c;
+  }
+  __syncthreads();
+  int n = block_exscan<NT>(scanbuf, n_items, wave_sums);
+  if (n > Q) { if (tid == 0) set_errkey(&s_errkey, n_items, PHX_ERR_QUEUE_FULL); n = 0; }
+  else {
+    for (int it = tid; it < n_items; it += NT) {
+      const int off = scanbuf[it];
+      if (it < g.n_inject) {
+        const DevMsg m = g.inject[it];
+        if (dev_send_check(sp, m.src, m.dst, m.type) == 0) q0[off] = m;
+      } else {
+        const int a = act_list[it - g.n_inject];
+        if (live[a]) {
+          const int s = sp.strat_rank[a];
+          const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);
+          // decode_action's state mutation happens exactly once, here; an agent that sends
+          // nothing writes nothing
+          act_emit(sp, b, a, has, has ? actions_b[s] : 0.0f, exo_b, tick, q0 + off);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // acting-phase sends are checked like any Network.send (static topologies always pass)
+  for (int i = tid; i < n; i += NT) {
+    const DevMsg m = q0[i];
+    const int code = dev_send_check(sp, m.src, m.dst, m.type);
+    if (code) { set_errkey(&s_errkey, g.n_inject + i, code); q0[i].type = 0; }
+  }
+  __syncthreads();
+
+  // pre_message_resolution for every live agent (env.py:170-173)
+  if (full)
+    for (int a = tid; a < A; a += NT) if (live[a]) pre_resolution(sp, b, a, t);
+
+  phx_msg_rec* log_b = g.io.msg_log ? g.io.msg_log + (int64_t)b * sp.trace_cap : nullptr;
+  if (log_b)                                                    // Resolver.push tracking, resolvers.py:41-42
+    for (int i = tid; i < n; i += NT)
+      if (i < sp.trace_cap) {
+        phx_msg_rec r; r.sender = q0[i].src; r.receiver = q0[i].dst; r.type = q0[i].type; r.round = 0;
+        r.payload.i = q0[i].p.i; log_b[i] = r;
+      }
+  int log_n = n;
+  int seq_base = n_items;          // error ordering key continues after the acting items
+  int clock = clock0;
+  __syncthreads();
+
+  // ---- BatchResolver.resolve round loop (resolvers.py:128-163) ---------------------------------
+  DevMsg* qc = q0; DevMsg* qn = q1;
+  int round = 0;
+  while (n > 0 && (sp.round_limit < 0 || round < sp.round_limit)) {
+    for (int a = tid; a < A; a += NT) { cnt[a] = 0; first[a] = 0x7fffffff; }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+      const int d = qc[i].dst;
+      slot[i] = atomicAdd(&cnt[d], 1);
+      atomicMin(&first[d], i);
+    }
+    __syncthreads();
+    // receivers in dict (first-arrival) order -> inbox offsets
+    for (int i = tid; i < n; i += NT) {
+      const int d = qc[i].dst;
+      scanbuf[i] = (first[d] == i) ? cnt[d] : 0;
+    }
+    __syncthreads();
+    block_exscan<NT>(scanbuf, n, wave_sums);
+    for (int i = tid; i < n; i += NT) {
+      const int d = qc[i].dst;
+      if (first[d] == i) goff[d] = scanbuf[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) order[goff[qc[i].dst] + slot[i]] = i;
+    __syncthreads();
+    // one lane per receiver: batch in send order, handled one message at a time (agents.py:96-120)
+    for (int a = tid; a < A; a += NT) {
+      const int c = cnt[a];
+      if (c == 0) continue;
+      int* seg = order + goff[a];
+      for (int x = 1; x < c; ++x) {                             // insertion sort by sequence number
+        const int v = seg[x]; int y = x - 1;
+        while (y >= 0 && seg[y] > v) { seg[y + 1] = seg[y]; --y; }
+        seg[y + 1] = v;
+      }
+      for (int k = 0; k < c; ++k) {
+        const int P = goff[a] + k;
+        DevMsg out; out.type = 0;
+        const DevMsg m = qc[seg[k]];
+        // dropped: receiver not in contexts (resolvers.py:143-144), edge filter (:146-148),
+        // or a send that already failed its checks (type 0)
+        if (live[a] && m.type != 0 && dev_has_edge(sp, m.src, m.dst)) {
+          int code = 0;
+          const bool answered = handle_message(sp, b, a, m, clock + P, out, code);
+          if (code) set_errkey(&s_errkey, seq_base + P, code);
+          if (answered) {                                       // network.send(receiver, sub_receiver, payload) :156-158
+            const int sc = dev_send_check(sp, out.src, out.dst, out.type);
+            if (sc) { set_errkey(&s_errkey, seq_base + P, sc); out.type = 0; }
+          } else out.type = 0;
+        }
+        resp[P] = out;
+        scanbuf[P] = out.type != 0;
+      }
+    }
+    __syncthreads();
+    const int n_next = block_exscan<NT>(scanbuf, n, wave_sums);
+    for (int P = tid; P < n; P += NT)
+      if (resp[P].type != 0) {
+        const int off = scanbuf[P];
+        qn[off] = resp[P];
+        if (log_b && log_n + off < sp.trace_cap) {
+          phx_msg_rec r; r.sender = resp[P].src; r.receiver = resp[P].dst; r.type = resp[P].type;
+          r.round = (uint16_t)(round + 1); r.payload.i = resp[P].p.i; log_b[log_n + off] = r;
+        }
+      }
+    __syncthreads();
+    log_n += n_next; seq_base += n; clock += n;
+    n = n_next; ++round;
+    DevMsg* tq = qc; qc = qn; qn = tq;
+  }
+  if (n > 0 && tid == 0) set_errkey(&s_errkey, seq_base + 1, PHX_ERR_ROUND_LIMIT);   // resolvers.py:160-163
+  __syncthreads();
+
+  if (tid == 0) {
+    fld<int32_t>(sp, F_ENV_CLOCK)[b] = clock;
+    if (g.io.msg_count) g.io.msg_count[b] = log_n;
+    if (g.io.err && g.io.err[b] == 0 && s_errkey != ERRKEY_NONE) g.io.err[b] = s_errkey & 15;
+  }
+  if (g.resolve_only) return;
+
+  // ---- per strategic agent: obs / reward / done (env.py:273-292, fsm.py:320-345, stackelberg.py:150-171)
+  const int next_stage = (sp.env_type == PHX_ENV_FSM) ? sp.stage_next[cur_stage] : 0;
+  const uint8_t* obs_mask = sp.obs_mask + (int64_t)list * A;
+  const uint8_t* rew_mask = sp.rew_mask + (int64_t)list * A;
+  float* obs_b = g.io.obs + (int64_t)b * S * D;
+  double* rew_cache = fld<double>(sp, F_ENV_REW_CACHE) + (int64_t)b * S;
+  uint8_t* rew_cache_v = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + (int64_t)b * S;
+  float* obs_cache = fld<float>(sp, F_ENV_OBS_CACHE) + (int64_t)b * S * D;
+  uint8_t* obs_cache_v = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + (int64_t)b * S;
+
+  for (int s = tid; s < S; s += NT) {
+    const int a = sp.strat_idx[s];
+    const int64_t o = (int64_t)b * S + s;
+    uint8_t ov = 0, rv = 0, dv = 0, tm = 0, tr = 0;
+    double rw = 0.0;
+    float ob[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live[a]) {                                             // env.py:274-275
+      dv = 1;
+      if (obs_mask[a]) { dev_encode_obs(sp, b, a, t, ob); ov = 1; }
+      if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, b, a); rv = 1; }
+      else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, b, a); rew_cache_v[s] = 1; }
+      tm = tr = dev_is_done(sp, a, t) ? 1 : 0;                 // env.py:285-286
+      if (tm) { term[s] = 1; trunc[s] = 1; }                   // :288-292
+    }
+    if (term[s]) atomicAdd(&s_nterm, 1);
+    if (trunc[s]) atomicAdd(&s_ntrunc, 1);
+    if (sp.env_type == PHX_ENV_FSM && ov) {                    // self._observations.update, fsm.py:349
+      for (int d = 0; d < D; ++d) obs_cache[s * D + d] = ob[d];
+      obs_cache_v[s] = 1;
+    }
+    for (int d = 0; d < D; ++d) obs_b[s * D + d] = ob[d];
+    g.io.obs_valid[o] = ov; g.io.reward_valid[o] = rv; g.io.done_valid[o] = dv;
+    g.io.terminated[o] = tm; g.io.truncated[o] = tr; g.io.reward[o] = rw;
+  }
+  __syncthreads();
+  const bool all_term = s_nterm == S;                                         // env.py:308-310
+  const bool all_trunc = (t == sp.num_steps) || s_ntrunc == S;               // env.py:312-318
+  const bool terminal = all_term || all_trunc;
+  if (sp.env_type != PHX_ENV_PLAIN) {
+    for (int s = tid; s < S; s += NT) {
+      const int64_t o = (int64_t)b * S + s;
+      const bool observed = g.io.obs_valid[o] != 0;
+      if (sp.env_type == PHX_ENV_FSM) {
+        if (terminal) {                                        // fsm.py:360-375: cached dicts of all agents
+          const uint8_t v = obs_cache_v[s];
+          g.io.obs_valid[o] = v;
+          for (int d = 0; d < D; ++d) obs_b[s * D + d] = v ? obs_cache[s * D + d] : 0.f;
+          g.io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
+          g.io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+        } else if (observed) {                                 // fsm.py:378
+          g.io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
+          g.io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+        }
+      } else {
+        if (terminal) {                                        // stackelberg.py:180-187
+          g.io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
+          g.io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+        } else if (observed && rew_cache_v[s]) {               // stackelberg.py:190-194
+          g.io.reward_valid[o] = 1; g.io.reward[o] = rew_cache[s];
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    *step_p = t;
+    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
+    if (sp.env_type == PHX_ENV_FSM) {                          // fsm.py:355
+      fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = cur_stage; *stage_p = next_stage;
+    }
+    g.io.all_terminated[b] = all_term; g.io.all_truncated[b] = all_trunc;
+  }
+}
+
+// ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask, float* obs,
+                                                       uint8_t* obs_valid) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (mask && !mask[b]) return;
+  const int A = sp.A, S = sp.S, D = sp.D;
+  for (int a = tid; a < A; a += NT) dev_agent_reset(sp, b, a);          // network.py:183-184
+  for (int s = tid; s < S; s += NT) {
+    fld<uint8_t>(sp, F_ENV_TERM)[(int64_t)b * S + s] = 0;               // env.py:223-224
+    fld<uint8_t>(sp, F_ENV_TRUNC)[(int64_t)b * S + s] = 0;
+    if (sp.env_type != PHX_ENV_PLAIN) fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[(int64_t)b * S + s] = 0;
+    if (obs_valid) obs_valid[(int64_t)b * S + s] = 0;
+    if (obs) for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = 0.f;
+  }
+  if (tid == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = 0;                                // env.py:209
+    if (sp.env_type == PHX_ENV_FSM) fld<int32_t>(sp, F_ENV_STAGE)[b] = sp.initial_stage;   // fsm.py:217
+  }
+  __syncthreads();
+  if (!obs) return;
+  for (int k = tid; k < sp.n_reset_obs; k += NT) {                      // env.py:227-237
+    const int a = sp.reset_obs_idx[k], s = sp.strat_rank[a];
+    if (s < 0) continue;
+    float ob[4] = {0.f, 0.f, 0.f, 0.f};
+    dev_encode_obs(sp, b, a, 0, ob);
+    for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = ob[d];
+    if (obs_valid) obs_valid[(int64_t)b * S + s] = 1;
+  }
+}
+
+// ---- launchers (called from phx_api.hip) -----------------------------------------------------
+size_t phx_generic_queue_bytes(int A, int Q, int scan_cap) {
+  return (size_t)Q * (3 * sizeof(DevMsg) + 2 * sizeof(int)) + (size_t)scan_cap * sizeof(int) +
+         (size_t)A * 3 * sizeof(int) + (size_t)((A + 15) & ~15);
+}
+
+hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st) {
+  const size_t bytes = phx_generic_queue_bytes(sp.A, sp.queue_cap, sp.scan_cap);
+  const int big = (sp.A > 64 || sp.queue_cap > 64);
+  if (lds) {
+    if (big) hipLaunchKernelGGL((phx_generic_step_kernel<256, true>), dim3(sp.B), dim3(256), bytes, st, sp, g);
+    else hipLaunchKernelGGL((phx_generic_step_kernel<64, true>), dim3(sp.B), dim3(64), bytes, st, sp, g);
+  } else {
+    hipLaunchKernelGGL((phx_generic_step_kernel<256, false>), dim3(sp.B), dim3(256), 0, st, sp, g);
+  }
+  return hipGetLastError();
+}
+
+hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, float* obs, uint8_t* obs_valid,
+                            hipStream_t st) {
+  hipLaunchKernelGGL((phx_reset_kernel<64>), dim3(sp.B), dim3(64), 0, st, sp, mask, obs, obs_valid);
+  return hipGetLastError();
+}

@@ -1,0 +1,239 @@
+// phx_sc_fused.hip -- fused static-schedule kernels for supply-chain-shaped envs.
+//
+// For a topology made only of FactoryAgent / ShopAgent / CustomerAgent (supply_chain.py:36-150)
+// the message schedule of a step is static: acting phase = one StockRequest per shop and one
+// OrderRequest per customer; round 0 = the factory echoes StockResponses while every shop
+// fills its OrderRequests sequentially against the PRE-delivery stock; round 1 = the shop
+// books the delivery and customers drop their OrderResponses; round 2 is empty.  The whole
+// step is therefore a closed form per shop:
+//     D      = sum of the acting customers' order sizes           (the shop's round-0 inbox)
+//     sales  = min(D, stock0)  (also for stock0 < 0: the first order takes the negative stock)
+//     missed = D - sales ;  stock1 = stock0 - sales
+//     stock2 = min(stock1 + request, 100)
+// so one lane owns one (env, shop): state is read and written exactly once per step with
+// fully coalesced [B][S] accesses, and the only gather -- the K order-size bytes of the
+// shop's inbox -- is staged through LDS from 16-byte coalesced loads of the exo rows.
+// Results are bit-identical to the generic engine (tests/test_gpu_parity.py).
+#include "phx_dev.h"
+
+#define SC_NT 256
+#define SC_STAGE_MAX 32768      // bytes of exo rows staged per block; larger -> direct loads
+
+struct ShopLane {
+  int stock, sales, missed, delivered;
+};
+
+// one shop, one step; returns observation/reward of the post-step state
+__device__ __forceinline__ void sc_shop_step(ShopLane& st, bool has_action, float action, bool any_order,
+                                             int D) {
+  const int stock0 = st.stock;
+  int req = 0;
+  if (has_action) {                                              // decode_action supply_chain.py:136-142
+    const int r = dev_round_half_even(action);
+    const int room = PHX_SHOP_MAX_STOCK - stock0;
+    req = r < room ? r : room;
+  }
+  st.sales = 0; st.missed = 0;                                   // pre_message_resolution :93-96
+  int stock1 = stock0;
+  if (any_order) {                                               // round 0: handle_order_request :105-122
+    const int sales = D < stock0 ? D : stock0;
+    st.sales = sales; st.missed = D - sales; stock1 = stock0 - sales;
+  }
+  if (has_action) {                                              // round 1: handle_stock_response :98-103
+    st.delivered = req;
+    const int ns = stock1 + req;
+    stock1 = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
+  }
+  st.stock = stock1;
+}
+
+__global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, const phx_step_io io,
+                                                            const int stage_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_exo[];
+  const int nS = sp.S, A = sp.A;
+  const int64_t total = (int64_t)sp.B * nS;
+  const int64_t g0 = (int64_t)blockIdx.x * SC_NT;
+  const int64_t g = g0 + threadIdx.x;
+
+  // ---- stage the block's exo rows (the shops' round-0 inboxes) into LDS ----------------------
+  int64_t lds_base = 0;
+  const bool staged = io.exo != nullptr && stage_rows > 0;
+  if (staged) {
+    const int64_t b_first = g0 / nS;
+    const int64_t g_last = (g0 + SC_NT - 1 < total - 1) ? g0 + SC_NT - 1 : total - 1;
+    const int64_t b_last = g_last / nS;
+    const int64_t lo = b_first * sp.n_exo, hi = (b_last + 1) * sp.n_exo;
+    lds_base = lo & ~(int64_t)15;
+    const int64_t hi16 = hi & ~(int64_t)15;
+    for (int64_t off = lds_base + (int64_t)threadIdx.x * 16; off < hi16; off += (int64_t)SC_NT * 16)
+      *(uint4*)(s_exo + (off - lds_base)) = *(const uint4*)(io.exo + off);
+    for (int64_t off = (hi16 > lds_base ? hi16 : lds_base) + threadIdx.x; off < hi; off += SC_NT)
+      s_exo[off - lds_base] = io.exo[off];
+    __syncthreads();
+  }
+  if (g >= total) return;
+  const int b = (int)(g / nS), s = (int)(g - (int64_t)b * nS);
+  const int a_shop = sp.shop_agent[s];
+
+  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
+  const int list = cur_stage;
+  const int t = fld<int32_t>(sp, F_ENV_STEP)[b] + 1;                         // env.py:252
+  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+
+  ShopLane st;
+  st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
+  st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
+  const bool shop_acts = sp.act_mask[(int64_t)list * A + a_shop] != 0;
+  const bool has_action = shop_acts && (io.action_valid == nullptr || io.action_valid[g] != 0);
+  const float action = has_action ? io.actions[g] : 0.0f;
+
+  // D = sum over the shop's inbox of OrderRequest sizes (customers that act in this stage)
+  const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
+  const uint8_t* cact = sp.shop_cust_act + (int64_t)list * sp.n_exo;
+  int D = 0; bool any_order = false;
+  if (io.exo) {
+    const int64_t row = (int64_t)b * sp.n_exo;
+    for (int k = c_lo; k < c_hi; ++k)
+      if (cact[k]) {
+        any_order = true;
+        const int64_t idx = row + sp.shop_cust_exo[k];
+        D += staged ? s_exo[idx - lds_base] : io.exo[idx];
+      }
+  } else {
+    for (int k = c_lo; k < c_hi; ++k) any_order |= cact[k] != 0;
+    if (any_order)
+      D = rng_shop_orders(sp.seed, sp.env_offset + b, tick, s, c_hi - c_lo, cact + c_lo, -1);
+  }
+  sc_shop_step(st, has_action, action, any_order, D);
+
+  fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock;
+  fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
+  fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed;
+  if (has_action) fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
+
+  // ---- obs / reward / done with the PLAIN or FSM masks (env.py:273-292, fsm.py:309-380) -------
+  // ShopAgent never terminates or truncates (agents.py:292-323), so __all__ needs no reduction:
+  const bool all_trunc = (t == sp.num_steps);                                // env.py:312-318
+  float ob[3] = {0.f, 0.f, 0.f};
+  uint8_t ov = 0, rv = 0;
+  double rw = 0.0;
+  if (sp.env_type == PHX_ENV_PLAIN) {
+    shop_obs(st.stock, st.sales, st.missed, sp.param_i[a_shop * PHX_NPI + 1], ob);
+    rw = shop_reward(st.sales, st.stock);
+    ov = 1; rv = 1;
+  } else {
+    double* rc = fld<double>(sp, F_ENV_REW_CACHE) + g;
+    uint8_t* rcv = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + g;
+    float* oc = fld<float>(sp, F_ENV_OBS_CACHE) + g * 3;
+    uint8_t* ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + g;
+    const bool observes = sp.obs_mask[(int64_t)list * A + a_shop] != 0;
+    if (observes) {
+      shop_obs(st.stock, st.sales, st.missed, sp.param_i[a_shop * PHX_NPI + 1], ob);
+      oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; *ocv = 1;                  // fsm.py:349
+    }
+    uint8_t cache_valid = *rcv; double cache = *rc;
+    if (sp.rew_mask[(int64_t)list * A + a_shop]) {                            // fsm.py:334-335,350
+      cache = shop_reward(st.sales, st.stock); cache_valid = 1;
+      *rc = cache; *rcv = 1;
+    }
+    if (all_trunc) {                                                          // fsm.py:360-375
+      ov = *ocv;
+      ob[0] = ov ? oc[0] : 0.f; ob[1] = ov ? oc[1] : 0.f; ob[2] = ov ? oc[2] : 0.f;
+      rv = cache_valid ? 1 : 2; rw = cache_valid ? cache : 0.0;
+    } else if (observes) {                                                    // fsm.py:378
+      ov = 1; rv = cache_valid ? 1 : 2; rw = cache_valid ? cache : 0.0;
+    } else { ob[0] = ob[1] = ob[2] = 0.f; }
+  }
+  io.obs[g * 3 + 0] = ob[0]; io.obs[g * 3 + 1] = ob[1]; io.obs[g * 3 + 2] = ob[2];
+  io.reward[g] = rw;
+  io.obs_valid[g] = ov; io.reward_valid[g] = rv; io.done_valid[g] = 1;
+  io.terminated[g] = 0; io.truncated[g] = 0;
+  if (s == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = t;
+    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
+    if (sp.env_type == PHX_ENV_FSM) {                                         // fsm.py:355
+      fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = cur_stage;
+      fld<int32_t>(sp, F_ENV_STAGE)[b] = sp.stage_next[cur_stage];
+    }
+    io.all_terminated[b] = 0; io.all_truncated[b] = all_trunc;
+  }
+}
+
+// ---- fused rollout: T steps per launch, shop state in registers, only the trajectory
+//      streams to HBM.  PLAIN env; auto-reset at episode end (env.py:185-237 folded in). --------
+__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
+  const int nS = sp.S;
+  const int64_t total = (int64_t)sp.B * nS;
+  const int64_t g = (int64_t)blockIdx.x * SC_NT + threadIdx.x;
+  if (g >= total) return;
+  const int b = (int)(g / nS), s = (int)(g - (int64_t)b * nS);
+  const int a_shop = sp.shop_agent[s];
+  const int norm = sp.param_i[a_shop * PHX_NPI + 1];
+  const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
+  const int K = c_hi - c_lo;
+  const int64_t genv = sp.env_offset + b;
+
+  ShopLane st;
+  st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
+  st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
+  st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g];
+  st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
+  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
+  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  float ob[3] = {0.f, 0.f, 0.f};
+
+  for (int t = 0; t < io.T; ++t) {
+    const int64_t o = (int64_t)t * total + g;
+    const float action = io.actions ? io.actions[o] : rng_action(sp.seed, genv, tick, s);
+    int D = 0;
+    if (io.exo) {
+      const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
+      for (int k = c_lo; k < c_hi; ++k) D += row[sp.shop_cust_exo[k]];
+    } else if (K > 0) {
+      D = rng_shop_orders(sp.seed, genv, tick, s, K, nullptr, -1);
+    }
+    sc_shop_step(st, true, action, K > 0, D);
+    ++step; ++tick;
+    const bool all_trunc = (step == sp.num_steps);
+    shop_obs(st.stock, st.sales, st.missed, norm, ob);
+    const double rw = shop_reward(st.sales, st.stock);
+    io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
+    io.action_out[o] = action;
+    io.reward[o] = (float)rw;
+    io.terminated[o] = 0;
+    io.truncated[o] = all_trunc;
+    if (all_trunc) {                                             // the caller's env.reset(): stock only
+      st.stock = 0; step = 0;                                    // supply_chain.py:149-150
+      shop_obs(st.stock, st.sales, st.missed, norm, ob);         // sales/missed stay stale
+    }
+  }
+  fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock;
+  fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
+  fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed;
+  fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
+  if (io.last_obs) { io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2]; }
+  if (s == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = step;
+    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
+  }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
+  const int64_t total = (int64_t)sp.B * sp.S;
+  const int blocks = (int)((total + SC_NT - 1) / SC_NT);
+  // exo rows touched by one block: at most ceil(256 / S) + 1 envs
+  const int64_t rows = (SC_NT + sp.S - 1) / sp.S + 1;
+  const int64_t bytes = rows * sp.n_exo + 32;
+  const int stage_rows = (io.exo && bytes <= SC_STAGE_MAX) ? (int)rows : 0;
+  hipLaunchKernelGGL(phx_sc_step_kernel, dim3(blocks), dim3(SC_NT), stage_rows ? (size_t)bytes : 0, st,
+                     sp, io, stage_rows);
+  return hipGetLastError();
+}
+
+hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  const int64_t total = (int64_t)sp.B * sp.S;
+  const int blocks = (int)((total + SC_NT - 1) / SC_NT);
+  hipLaunchKernelGGL(phx_sc_rollout_kernel, dim3(blocks), dim3(SC_NT), 0, st, sp, io);
+  return hipGetLastError();
+}

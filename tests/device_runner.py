@@ -1,0 +1,82 @@
+"""Adapter giving the HIP path (phantom_amd.device.DeviceEnv, through the C ABI) the same
+numpy-facing interface as tests/oracle.py's OracleEnv, so one test body drives both."""
+import numpy as np
+import torch
+
+from oracle import LOG_DTYPE
+from phantom_amd.device import DeviceEnv
+
+
+class DeviceRunner:
+    def __init__(self, spec):
+        self.dev = DeviceEnv(spec)
+        self.spec = spec
+        self.B, self.S, self.D, self.n_exo = self.dev.B, self.dev.S, self.dev.D, self.dev.n_exo
+        self.err = np.zeros(self.B, np.int32)
+        self._pending = []
+
+    def _t(self, a, dtype):
+        return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype)).to(self.dev.device)
+
+    def _pull(self):
+        d = self.dev
+        self.obs, self.reward = d.obs.cpu().numpy(), d.reward.cpu().numpy()
+        self.obs_valid, self.reward_valid = d.obs_valid.cpu().numpy(), d.reward_valid.cpu().numpy()
+        self.terminated, self.truncated = d.terminated.cpu().numpy(), d.truncated.cpu().numpy()
+        self.done_valid = d.done_valid.cpu().numpy()
+        self.all_terminated, self.all_truncated = d.all_terminated.cpu().numpy(), d.all_truncated.cpu().numpy()
+        self.err = d.err.cpu().numpy()
+        self.msg_count = d.msg_count.cpu().numpy() if d.msg_count is not None else None
+
+    def reset(self, mask=None):
+        obs, valid = self.dev.reset(mask)
+        self.err = self.dev.err.cpu().numpy()
+        return obs.cpu().numpy(), valid.cpu().numpy()
+
+    def step(self, actions, action_valid=None, exo=None):
+        if actions is None:
+            actions = np.zeros((self.B, max(self.S, 1)), np.float32)
+        self.dev.step(self._t(actions, np.float32), self._t(action_valid, np.uint8),
+                      self._t(exo, np.uint8))
+        self._pull()
+        return self
+
+    def inject(self, messages):
+        self._pending.extend(messages)
+
+    def resolve(self):
+        d = self.dev
+        d.inject(self._pending)
+        self._pending = []
+        d.err.zero_()
+        import ctypes as C
+        lp = d.msg_log.data_ptr() if d.msg_log is not None else None
+        cp = d.msg_count.data_ptr() if d.msg_count is not None else None
+        d._check(d.lib.phx_resolve(d.handle, d.err.data_ptr(), lp, cp, d._stream()), "phx_resolve")
+        self.err = d.err.cpu().numpy()
+        self.msg_count = d.msg_count.cpu().numpy() if d.msg_count is not None else None
+
+    def rollout(self, T, actions=None, exo=None):
+        a = None if actions is None else self._t(actions, np.float32)
+        x = None if exo is None else self._t(exo, np.uint8)
+        tr = self.dev.rollout(T, a, x)
+        self.err = self.dev.err.cpu().numpy()
+        return dict(obs=tr.observations.cpu().numpy(), actions=tr.actions.cpu().numpy(),
+                    rewards=tr.rewards.cpu().numpy(), terminated=tr.terminations.cpu().numpy(),
+                    truncated=tr.truncations.cpu().numpy(), last_obs=tr.last_obs.cpu().numpy())
+
+    def get_i32(self, field):
+        return self.dev.field(field).cpu().numpy().reshape(self.B, -1)
+
+    def set_i32(self, field, arr):
+        self.dev.field(field).copy_(torch.from_numpy(np.ascontiguousarray(arr, np.int32)).reshape(
+            self.dev.field(field).shape))
+
+    def get_f64(self, field):
+        return self.dev.field(field).cpu().numpy().reshape(self.B, -1)
+
+    def log(self, b=0):
+        n = int(self.msg_count[b])
+        assert n <= self.spec.trace_cap
+        raw = self.dev.msg_log[b, :n].cpu().numpy().tobytes()
+        return np.frombuffer(raw, dtype=LOG_DTYPE).copy()

@@ -1,0 +1,240 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against
+  (1) the golden vectors produced by the real reference,
+  (2) the reference's own known-answer tests (kats.py),
+  (3) the CPU oracle on seeded random inputs at moderate sizes,
+  (4) size-independent properties at BASELINE.json's full sizes.
+Integers, routing, stage ids, flags: bit-exact.  Float obs (f32) and rewards (f64): compared by
+bit pattern, i.e. stricter than the 1e-6 relative tolerance north_star allows; the rollout's
+f32-rounded reward is compared at rtol 1e-6."""
+import numpy as np
+import pytest
+
+from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, supply_chain_env)
+from kats import ALL_KATS
+from oracle import OracleEnv
+from test_oracle_vs_goldens import SC_CASES, replay_market, replay_supply_chain
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(spec):
+    from device_runner import DeviceRunner
+    return DeviceRunner(spec)
+
+
+def test_extension_is_loaded_and_no_fallback():
+    import ctypes
+    from phantom_amd import _abi
+    lib = _abi.load_library()
+    assert isinstance(lib, ctypes.CDLL) and lib.phx_abi_version() == 1
+
+
+@pytest.mark.parametrize("kat", ALL_KATS, ids=lambda f: f.__name__)
+def test_device_kat(kat):
+    kat(_dev)
+
+
+@pytest.mark.parametrize("name", SC_CASES)
+def test_generic_engine_supply_chain_matches_reference(name):
+    # tracking on -> the generic engine (with message log) runs
+    replay_supply_chain(golden(name), _dev)
+
+
+@pytest.mark.parametrize("name", SC_CASES)
+def test_fused_kernel_supply_chain_matches_reference(name):
+    g = dict(golden(name).items())
+    g["n_logs"] = np.asarray(0)          # no tracking -> fused static-schedule kernel
+
+    def make(spec):
+        r = _dev(spec)
+        assert r.dev.uses_fused
+        return r
+    replay_supply_chain(g, make)
+
+
+@pytest.mark.parametrize("name", ["stk_small", "stk_full"])
+def test_generic_engine_market_matches_reference(name):
+    replay_market(golden(name), _dev)
+
+
+def _compare_step(o, d, t):
+    for f in ("obs_valid", "reward_valid", "done_valid", "terminated", "truncated", "all_terminated",
+              "all_truncated", "err"):
+        np.testing.assert_array_equal(getattr(d, f), getattr(o, f), err_msg=f"{f} t={t}")
+    np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs), err_msg=f"obs t={t}")
+    np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward), err_msg=f"reward t={t}")
+    for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step"):
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} t={t}")
+
+
+@pytest.mark.parametrize("fsm", [False, True])
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("exo_mode", ["replay", "device_rng"])
+def test_random_differential_vs_oracle(fsm, force_generic, exo_mode):
+    """SC topologies, B=192, 230 steps (two episode ends), partial action masks."""
+    rng = np.random.RandomState(5 + fsm)
+    B, S, K, T = 192, 9, 6, 230
+    env = supply_chain_env(S, [K] * S, 100, B, fsm=fsm, force_generic=force_generic, seed=77,
+                           env_offset=1000)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    assert d.dev.uses_fused == (not force_generic)
+    o.reset(); d.reset()
+    for t in range(T):
+        act = rng.uniform(-20, 130, size=(B, S)).astype(np.float32)
+        act[rng.rand(B, S) < 0.1] = np.float32(rng.randint(0, 50)) + np.float32(0.5)
+        valid = (rng.rand(B, S) < 0.9).astype(np.uint8)
+        exo = rng.randint(0, 5, size=(B, S * K)).astype(np.uint8) if exo_mode == "replay" else None
+        o.step(act, valid, exo); d.step(act, valid, exo)
+        _compare_step(o, d, t)
+        done = (o.all_truncated | o.all_terminated).astype(np.uint8)
+        if done.any():
+            oo, ov = o.reset(done); do, dv = d.reset(done)
+            m = done.astype(bool)
+            np.testing.assert_array_equal(dv[m], ov[m])
+            np.testing.assert_array_equal(f32_bits(do[m]), f32_bits(oo[m]))
+
+
+def test_ragged_masked_reset_and_large_customer_counts():
+    rng = np.random.RandomState(9)
+    ks = [1, 17, 3, 64, 2]
+    B, T = 50, 40
+    env = supply_chain_env(len(ks), ks, 7, B, norm_customers=11)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    for t in range(T):
+        act = rng.uniform(0, 100, size=(B, len(ks))).astype(np.float32)
+        exo = rng.randint(0, 5, size=(B, sum(ks))).astype(np.uint8) if t % 2 else None
+        o.step(act, None, exo); d.step(act, None, exo)
+        _compare_step(o, d, t)
+        mask = ((o.all_truncated > 0) | (rng.rand(B) < 0.05)).astype(np.uint8)   # also mid-episode resets
+        if mask.any():
+            oo, ov = o.reset(mask); do, dv = d.reset(mask)
+            np.testing.assert_array_equal(f32_bits(do[mask > 0]), f32_bits(oo[mask > 0]))
+
+
+@pytest.mark.parametrize("mode", ["replay", "device_rng"])
+def test_rollout_matches_oracle(mode):
+    rng = np.random.RandomState(3)
+    B, S, K, T = 96, 9, 6, 250
+    env = supply_chain_env(S, [K] * S, 100, B, seed=1234, env_offset=7)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    # a few single steps first so the fragment starts mid-episode
+    for t in range(3):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+    if mode == "replay":
+        acts = rng.uniform(-5, 120, (T, B, S)).astype(np.float32)
+        exo = rng.randint(0, 5, (T, B, S * K)).astype(np.uint8)
+    else:
+        acts = exo = None
+    ro, rd = o.rollout(T, acts, exo), d.rollout(T, acts, exo)
+    np.testing.assert_array_equal(f32_bits(rd["obs"]), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(rd["actions"]), f32_bits(ro["actions"]))
+    np.testing.assert_allclose(rd["rewards"], ro["rewards"], rtol=1e-6, atol=0)
+    np.testing.assert_array_equal(f32_bits(rd["rewards"]), f32_bits(ro["rewards"]))
+    np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+    np.testing.assert_array_equal(rd["terminated"], ro["terminated"])
+    np.testing.assert_array_equal(f32_bits(rd["last_obs"]), f32_bits(ro["last_obs"]))
+    assert ro["truncated"].sum() > 0          # at least one episode boundary inside the fragment
+    for f in ("shop.stock", "shop.sales", "shop.missed_sales", "env.step", "env.tick"):
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
+    # stepping continues identically after a rollout
+    a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+    o.step(a, None, None); d.step(a, None, None)
+    _compare_step(o, d, -1)
+
+
+def test_rng_fallback_block_is_exercised():
+    """the masked-rejection draw needs a second Philox block for K > ~25 customers per shop:
+    force that branch and compare with the oracle."""
+    B, ks = 64, [70, 41]
+    env = supply_chain_env(2, ks, 20, B, seed=99)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    for t in range(25):
+        a = np.full((B, 2), 50.0, np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+        _compare_step(o, d, t)
+
+
+# ---- BASELINE.json full sizes: size-independent properties ------------------------------------
+@pytest.mark.parametrize("cfg", [dict(S=9, K=6, B=4096, fsm=False), dict(S=51, K=4, B=8192, fsm=True)],
+                         ids=["SC64_B4096", "SC256_FSM_B8192"])
+def test_full_size_fused_equals_generic_and_invariants(cfg):
+    import torch
+    S, K, B = cfg["S"], cfg["K"], cfg["B"]
+    envf = supply_chain_env(S, [K] * S, 100, B, fsm=cfg["fsm"], seed=5)
+    envg = supply_chain_env(S, [K] * S, 100, B, fsm=cfg["fsm"], seed=5, force_generic=True)
+    f, g = _dev(envf.spec), _dev(envg.spec)
+    assert f.dev.uses_fused and not g.dev.uses_fused
+    f.reset(); g.reset()
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    for t in range(12):
+        act = (torch.rand(B, S, generator=gen) * 100).numpy().astype(np.float32)
+        exo = torch.randint(0, 5, (B, S * K), generator=gen, dtype=torch.uint8).numpy()
+        stock0 = f.get_i32("shop.stock").copy()
+        stage = f.get_i32("env.stage")[:, 0].copy()
+        f.step(act, None, exo); g.step(act, None, exo)
+        _compare_step(g, f, t)
+        stock, sales, missed = f.get_i32("shop.stock"), f.get_i32("shop.sales"), f.get_i32("shop.missed_sales")
+        D = exo.reshape(B, S, K).sum(-1).astype(np.int64)
+        selling = np.ones(B, bool) if not cfg["fsm"] else stage == 1
+        restock = np.ones(B, bool) if not cfg["fsm"] else stage == 0
+        # every order is either sold or missed; sales never exceed the stock held before delivery
+        np.testing.assert_array_equal((sales + missed)[selling], D[selling])
+        assert (sales[selling] <= np.maximum(stock0[selling], 0)).all() and (stock <= 100).all()
+        req = np.minimum(np.rint(act).astype(np.int64), 100 - stock0)
+        exp = np.minimum(stock0 - np.where(selling[:, None], sales, 0) + np.where(restock[:, None], req, 0), 100)
+        np.testing.assert_array_equal(stock, exp)
+    assert (f.err == 0).all()
+
+
+def test_python_surface_matches_reference_b1():
+    """the drop-in dict API at batch_size=1, exogenous draws from the global numpy stream:
+    same np.random.seed -> same trajectory as the reference's SupplyChainEnv (Appendix B)."""
+    import phantom_amd as ph
+    g = golden("sc7_fixed20")
+    env = ph.SupplyChainEnv()
+    np.random.seed(0)
+    obs, infos = env.reset()
+    assert list(obs) == ["SHOP"] and infos == {}
+    np.testing.assert_array_equal(obs["SHOP"], np.zeros(3, np.float32))
+    for t in range(100):
+        step = env.step({"SHOP": np.array([20.0], dtype=np.float32)})
+        np.testing.assert_array_equal(f32_bits(step.observations["SHOP"]), f32_bits(g["obs"][t, 0, 0]))
+        assert step.rewards["SHOP"] == g["reward"][t, 0, 0]
+        assert step.terminations == {"SHOP": False, "__all__": False}
+        assert step.truncations == {"SHOP": False, "__all__": t == 99}
+        assert step.infos == {"SHOP": {}}
+        assert env["SHOP"].stock == g["stock"][t, 0, 0]
+        assert env.current_step == t + 1
+    obs, _ = env.reset()                   # stale `sales` survives the reset (Appendix B)
+    np.testing.assert_array_equal(f32_bits(obs["SHOP"]), f32_bits(g["reset_obs"][100, 0, 0]))
+
+
+def test_python_surface_tracking_and_errors():
+    import phantom_amd as ph
+    resolver = ph.BatchResolver(enable_tracking=True)
+    env = ph.SupplyChainEnv(resolver=resolver)
+    np.random.seed(0)
+    env.reset()
+    env.step({"SHOP": np.array([20.0], dtype=np.float32)})
+    msgs = resolver.tracked_messages
+    assert msgs[0] == ph.Message("SHOP", "WAREHOUSE", ph.StockRequest(20))
+    assert [m.payload.size for m in msgs[1:6]] == [4, 0, 3, 3, 3]          # Appendix B draws
+    assert msgs[6] == ph.Message("WAREHOUSE", "SHOP", ph.StockResponse(20))
+    assert all(m.payload == ph.OrderResponse(0) for m in msgs[7:12]) and len(msgs) == 12
+    # network-level API parity (tests/network/test_network.py:75-99)
+    net = ph.Network([ph.CashboxAgent("mm"), ph.CashboxAgent("inv"), ph.CashboxAgent("inv2")])
+    net.add_connection("mm", "inv")
+    net.send("mm", "inv", ph.CashMessage(100.0))
+    net.resolve()
+    assert net.agents["mm"].total_cash == 25.0 and net.agents["inv"].total_cash == 50.0
+    with pytest.raises(ph.NetworkError):
+        net.send("mm", "inv2", ph.CashMessage(100.0))
+    n2 = ph.Network([ph.ReqRespAgent("A"), ph.ReqRespAgent("B")], ph.BatchResolver(round_limit=0))
+    n2.add_connection("A", "B")
+    n2.send("A", "B", ph.Request(0.0))
+    with pytest.raises(RuntimeError):
+        n2.resolve()
