@@ -144,7 +144,7 @@ typedef struct phx_field {
   int64_t  offset;      /* byte offset in the state blob */
   int32_t  dim0, dim1, dim2;  /* logical shape (dim2 = 1 when unused) */
   int32_t  kind;        /* owning phx_kind, 0 = env-level */
-  char     name[24];
+  char     name[32];
 } phx_field;
 
 /* one message-log record (Resolver.tracked_messages, resolvers.py:35-60) */

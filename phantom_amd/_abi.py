@@ -51,7 +51,7 @@ class PhxSpec(C.Structure):
 class PhxField(C.Structure):
     _fields_ = [("field_id", C.c_int32), ("dtype", C.c_int32), ("offset", C.c_int64),
                 ("dim0", C.c_int32), ("dim1", C.c_int32), ("dim2", C.c_int32),
-                ("kind", C.c_int32), ("name", C.c_char * 24)]
+                ("kind", C.c_int32), ("name", C.c_char * 32)]
 
 
 class _Payload(C.Union):
@@ -97,6 +97,10 @@ def load_library():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback).")
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Import it FIRST so that this
+    # library's NEEDED libamdhip64.so.7 resolves to the already-loaded runtime: two HIP runtimes
+    # in one process do not share devices/streams ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.phx_abi_version.restype = i32

@@ -132,6 +132,7 @@ static int derive(const phx_spec* sp, Derived& d) {
 
   // ---- static supply-chain schedule? (fused kernels) ------------------------------------------
   bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 &&
+            d.kind_count[PHX_KIND_SHOP] <= 256 &&
             !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
             (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS);
   auto edge = [&](int u, int v) { for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k) if (sp->col[k] == v) return true; return false; };

@@ -48,37 +48,43 @@ __device__ __forceinline__ void sc_shop_step(ShopLane& st, bool has_action, floa
 }
 
 __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, const phx_step_io io,
-                                                            const int stage_rows) {
+                                                            const int epb, const int stage_exo) {
+  // A block owns `epb` WHOLE envs (epb * S <= 256 lanes): the per-env words (step, tick, stage)
+  // are read by every lane of the env and rewritten by its shop-0 lane, so readers and writer
+  // must sit in one workgroup with a barrier between the two.
   extern __shared__ __attribute__((aligned(16))) unsigned char s_exo[];
   const int nS = sp.S, A = sp.A;
-  const int64_t total = (int64_t)sp.B * nS;
-  const int64_t g0 = (int64_t)blockIdx.x * SC_NT;
-  const int64_t g = g0 + threadIdx.x;
+  const int64_t b_first = (int64_t)blockIdx.x * epb;
+  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
+  const int lanes = (int)(b_end - b_first) * nS;
+  const bool active = (int)threadIdx.x < lanes;
+  const int64_t g = b_first * nS + threadIdx.x;
 
   // ---- stage the block's exo rows (the shops' round-0 inboxes) into LDS ----------------------
   int64_t lds_base = 0;
-  const bool staged = io.exo != nullptr && stage_rows > 0;
+  const bool staged = io.exo != nullptr && stage_exo;
   if (staged) {
-    const int64_t b_first = g0 / nS;
-    const int64_t g_last = (g0 + SC_NT - 1 < total - 1) ? g0 + SC_NT - 1 : total - 1;
-    const int64_t b_last = g_last / nS;
-    const int64_t lo = b_first * sp.n_exo, hi = (b_last + 1) * sp.n_exo;
+    const int64_t lo = b_first * sp.n_exo, hi = b_end * sp.n_exo;
     lds_base = lo & ~(int64_t)15;
     const int64_t hi16 = hi & ~(int64_t)15;
     for (int64_t off = lds_base + (int64_t)threadIdx.x * 16; off < hi16; off += (int64_t)SC_NT * 16)
       *(uint4*)(s_exo + (off - lds_base)) = *(const uint4*)(io.exo + off);
     for (int64_t off = (hi16 > lds_base ? hi16 : lds_base) + threadIdx.x; off < hi; off += SC_NT)
       s_exo[off - lds_base] = io.exo[off];
-    __syncthreads();
   }
-  if (g >= total) return;
-  const int b = (int)(g / nS), s = (int)(g - (int64_t)b * nS);
+  const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
+  const int s = active ? (int)(threadIdx.x % nS) : 0;
   const int a_shop = sp.shop_agent[s];
+  const int cur_stage0 = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
+  const int step0 = fld<int32_t>(sp, F_ENV_STEP)[b];
+  const uint32_t tick0 = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  __syncthreads();          // exo rows staged; every lane has read the per-env words
+  if (!active) return;
 
-  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
+  const int cur_stage = cur_stage0;
   const int list = cur_stage;
-  const int t = fld<int32_t>(sp, F_ENV_STEP)[b] + 1;                         // env.py:252
-  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  const int t = step0 + 1;                                                   // env.py:252
+  const uint32_t tick = tick0;
 
   ShopLane st;
   st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
@@ -161,12 +167,20 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
 
 // ---- fused rollout: T steps per launch, shop state in registers, only the trajectory
 //      streams to HBM.  PLAIN env; auto-reset at episode end (env.py:185-237 folded in). --------
-__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
+__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp, const phx_rollout_io io,
+                                                               const int epb) {
   const int nS = sp.S;
   const int64_t total = (int64_t)sp.B * nS;
-  const int64_t g = (int64_t)blockIdx.x * SC_NT + threadIdx.x;
-  if (g >= total) return;
-  const int b = (int)(g / nS), s = (int)(g - (int64_t)b * nS);
+  const int64_t b_first = (int64_t)blockIdx.x * epb;
+  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
+  const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
+  const int64_t g = b_first * nS + threadIdx.x;
+  const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
+  const int s = active ? (int)(threadIdx.x % nS) : 0;
+  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
+  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  __syncthreads();          // per-env words are rewritten by the env's shop-0 lane at the end
+  if (!active) return;
   const int a_shop = sp.shop_agent[s];
   const int norm = sp.param_i[a_shop * PHX_NPI + 1];
   const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
@@ -178,8 +192,6 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
   st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
   st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g];
   st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
-  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
-  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
   float ob[3] = {0.f, 0.f, 0.f};
 
   for (int t = 0; t < io.T; ++t) {
@@ -220,20 +232,18 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
 
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
-  const int64_t total = (int64_t)sp.B * sp.S;
-  const int blocks = (int)((total + SC_NT - 1) / SC_NT);
-  // exo rows touched by one block: at most ceil(256 / S) + 1 envs
-  const int64_t rows = (SC_NT + sp.S - 1) / sp.S + 1;
-  const int64_t bytes = rows * sp.n_exo + 32;
-  const int stage_rows = (io.exo && bytes <= SC_STAGE_MAX) ? (int)rows : 0;
-  hipLaunchKernelGGL(phx_sc_step_kernel, dim3(blocks), dim3(SC_NT), stage_rows ? (size_t)bytes : 0, st,
-                     sp, io, stage_rows);
+  const int epb = SC_NT / sp.S;                       // whole envs per block (S <= 256 checked at create)
+  const int blocks = (sp.B + epb - 1) / epb;
+  const int64_t bytes = (int64_t)epb * sp.n_exo + 32;
+  const int stage = (io.exo && bytes <= SC_STAGE_MAX) ? 1 : 0;
+  hipLaunchKernelGGL(phx_sc_step_kernel, dim3(blocks), dim3(SC_NT), stage ? (size_t)bytes : 0, st,
+                     sp, io, epb, stage);
   return hipGetLastError();
 }
 
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
-  const int64_t total = (int64_t)sp.B * sp.S;
-  const int blocks = (int)((total + SC_NT - 1) / SC_NT);
-  hipLaunchKernelGGL(phx_sc_rollout_kernel, dim3(blocks), dim3(SC_NT), 0, st, sp, io);
+  const int epb = SC_NT / sp.S;
+  const int blocks = (sp.B + epb - 1) / epb;
+  hipLaunchKernelGGL(phx_sc_rollout_kernel, dim3(blocks), dim3(SC_NT), 0, st, sp, io, epb);
   return hipGetLastError();
 }
