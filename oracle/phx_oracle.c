@@ -187,9 +187,11 @@ void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 /* np.random.randint(5) draws 3 random bits and rejects values > 4 (masked rejection,
- * SURVEY Appendix B).  The device stream keeps that mapping over Philox words: the K
- * customers of one shop consume successive accepted 3-bit fields (10 per 32-bit word)
- * of blocks ctr = (env_lo, env_hi, tick, shop | blk<<20).                              */
+ * SURVEY Appendix B).  The device stream keeps that mapping over Philox words.  One block
+ * ctr = (env_lo, env_hi, tick, shop | blk<<20) serves one shop for one step: words 0..2 give
+ * 30 3-bit fields, consumed in order by the shop's K customers (accepted fields only; further
+ * blocks blk = 1, 2, ... when 30 fields do not yield K accepted ones); word 3 of block 0 is
+ * the shop's random-policy action.                                                        */
 void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   int got = 0;
@@ -197,20 +199,19 @@ void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K
     uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
                        (uint32_t)shop | (blk << 20)};
     uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
-    for (int j = 0; j < 4 && got < K; ++j)
+    for (int j = 0; j < 3 && got < K; ++j)
       for (int f = 0; f < 10 && got < K; ++f) {
         uint32_t v = (w[j] >> (3 * f)) & 7u;
         if (v <= 4u) out[got++] = (uint8_t)v;
       }
   }
 }
-/* random policy of the rollout: U[0,100) with 24 bits, one Philox word per strategic agent */
-float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int r) {
+/* random policy of the rollout: U[0,100) from the top 24 bits of word 3 of the shop's block 0 */
+float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int shop) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
-                     0x80000000u | (uint32_t)(r >> 2)};
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick, (uint32_t)shop};
   uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
-  return (float)(w[r & 3] >> 8) * (100.0f / 16777216.0f);
+  return (float)(w[3] >> 8) * (100.0f / 16777216.0f);
 }
 
 /* ---- per-kind agent behaviour --------------------------------------------------------- */

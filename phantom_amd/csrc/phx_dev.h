@@ -142,19 +142,22 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Order sizes of the K customers of one shop: the first K accepted 3-bit fields (10 per 32-bit
-// word, values > 4 rejected -- numpy's masked rejection for randint(5)) of the shop's Philox
-// block sequence ctr = (env_lo, env_hi, tick, shop | blk << 20).  Returns the sum over the
-// customers selected by `actmask` (NULL = all) or, with kth >= 0, only customer kth's draw.
+// Device RNG, one Philox block per (env, tick, shop, blk): words 0..2 carry 30 3-bit fields that
+// the shop's K customers consume in order, values > 4 rejected (numpy's masked rejection for
+// randint(5)); blk = 1, 2, ... only when 30 fields do not yield K accepted ones; word 3 of block
+// 0 is the shop's random-policy action.  Returns the sum over the customers selected by
+// `actmask` (NULL = all) or, with kth >= 0, only customer kth's draw; *act_word = word 3.
 __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
-                                               int K, const uint8_t* actmask, int kth) {
+                                               int K, const uint8_t* actmask, int kth,
+                                               uint32_t* act_word = nullptr) {
   int got = 0, sum = 0;
-  for (uint32_t blk = 0; got < K; ++blk) {
+  uint32_t blk = 0;
+  do {
     uint32_t w[4];
     philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
                   (uint32_t)shop | (blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    if (blk == 0 && act_word) *act_word = w[3];
+    for (int j = 0; j < 3 && got < K; ++j) {
       uint32_t x = w[j];
 #pragma unroll
       for (int f = 0; f < 10; ++f) {
@@ -166,16 +169,13 @@ __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint
         }
       }
     }
-  }
+    ++blk;
+  } while (got < K);
   return sum;
 }
 
-__device__ __forceinline__ float rng_action(uint64_t seed, int64_t genv, uint32_t tick, int r) {
-  uint32_t w[4];
-  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick, 0x80000000u | (uint32_t)(r >> 2),
-                (uint32_t)seed, (uint32_t)(seed >> 32), w);
-  const uint32_t u = (r & 3) == 0 ? w[0] : (r & 3) == 1 ? w[1] : (r & 3) == 2 ? w[2] : w[3];
-  return (float)(u >> 8) * (100.0f / 16777216.0f);
+__device__ __forceinline__ float rng_word_to_action(uint32_t w3) {
+  return (float)(w3 >> 8) * (100.0f / 16777216.0f);
 }
 
 // int(round(np.float32(a))) -- round-half-to-even, supply_chain.py:139
@@ -199,6 +199,15 @@ __device__ __forceinline__ void shop_obs(int stock, int sales, int missed, int n
   o[0] = (float)((double)stock / (double)PHX_SHOP_MAX_STOCK);
   o[1] = (float)((double)sales / n);
   o[2] = (float)((double)missed / n);
+}
+
+// Same values from f32 IEEE division: for integers |x| < 2^24 the f32 quotient equals the f64
+// quotient rounded to f32 (p_f64 = 53 >= 2 * 24 + 2, so the double rounding is innocuous;
+// checked exhaustively over the reachable range in tests/test_host_logic.py).
+__device__ __forceinline__ void shop_obs_f32(int stock, int sales, int missed, float norm, float* o) {
+  o[0] = (float)stock / (float)PHX_SHOP_MAX_STOCK;
+  o[1] = (float)sales / norm;
+  o[2] = (float)missed / norm;
 }
 
 // ---- generic per-kind behaviour used by the generic engine ---------------------------------

@@ -15,6 +15,7 @@
 // shop's inbox -- is staged through LDS from 16-byte coalesced loads of the exo rows.
 // Results are bit-identical to the generic engine (tests/test_gpu_parity.py).
 #include "phx_dev.h"
+#include <cstdlib>
 
 #define SC_NT 256
 #define SC_STAGE_MAX 32768      // bytes of exo rows staged per block; larger -> direct loads
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
 
 // ---- fused rollout: T steps per launch, shop state in registers, only the trajectory
 //      streams to HBM.  PLAIN env; auto-reset at episode end (env.py:185-237 folded in). --------
-__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp, const phx_rollout_io io,
+__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_v1_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                const int epb) {
   const int nS = sp.S;
   const int64_t total = (int64_t)sp.B * nS;
@@ -196,14 +197,16 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t o = (int64_t)t * total + g;
-    const float action = io.actions ? io.actions[o] : rng_action(sp.seed, genv, tick, s);
     int D = 0;
+    uint32_t w3 = 0;
     if (io.exo) {
       const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
       for (int k = c_lo; k < c_hi; ++k) D += row[sp.shop_cust_exo[k]];
-    } else if (K > 0) {
-      D = rng_shop_orders(sp.seed, genv, tick, s, K, nullptr, -1);
+      if (!io.actions) rng_shop_orders(sp.seed, genv, tick, s, 0, nullptr, -1, &w3);
+    } else {
+      D = rng_shop_orders(sp.seed, genv, tick, s, K, nullptr, -1, &w3);
     }
+    const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
     sc_shop_step(st, true, action, K > 0, D);
     ++step; ++tick;
     const bool all_trunc = (step == sp.num_steps);
@@ -230,6 +233,138 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
   }
 }
 
+// ---- rollout v2: time-parallel.  The only sequential dependence of an episode is the stock
+// recurrence  stock' = min(stock - min(D, stock) + min(R, 100 - stock), 100)  (a dozen integer
+// ops); everything expensive -- the Philox draws, the IEEE divisions of the observation, the
+// f64 reward, the trajectory stores -- is independent across time steps.  So a block owns G
+// (env, shop) pairs x TC steps, staged in LDS as {R | stock, D, sales}:
+//   phase 1 (all lanes, item = (t, pair)): action + order sum  -> LDS, action_out -> HBM
+//   phase 2 (one lane per pair, sequential over t): the recurrence, in LDS
+//   phase 3 (all lanes, item = (t, pair)): obs / reward / flags -> HBM, rows contiguous in pair
+// Waves take whole time rows (lanes = consecutive pairs), so every trajectory store of a wave
+// covers one contiguous segment of the [T][B][S] arrays.
+__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp, const phx_rollout_io io,
+                                                               const int epb, const int TC) {
+  extern __shared__ __attribute__((aligned(16))) int s_it[];     // [TC][G][3]
+  const int nS = sp.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t total = (int64_t)sp.B * nS;
+  const int64_t b_first = (int64_t)blockIdx.x * epb;
+  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
+  const int G = (int)(b_end - b_first) * nS;
+  const int64_t g_base = b_first * nS;
+
+  // phase-2 lane state: lane `tid` owns pair g_base + tid
+  ShopLane st = {0, 0, 0, 0};
+  int step = 0, p2_K = 0;
+  if (tid < G) {
+    const int64_t g = g_base + tid;
+    st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
+    st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
+    st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g];
+    st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
+    step = fld<int32_t>(sp, F_ENV_STEP)[b_first + tid / nS];
+    const int s2 = tid % nS;
+    p2_K = sp.shop_cust_ptr[s2 + 1] - sp.shop_cust_ptr[s2];
+  }
+
+  for (int t0 = 0; t0 < io.T; t0 += TC) {
+    const int tc = (io.T - t0 < TC) ? io.T - t0 : TC;
+    // ---- phase 1 + 3 item loops: lanes = pairs (64 per chunk), waves = time rows --------------
+    for (int c = 0; c * 64 < G; ++c) {
+      const int gl = c * 64 + lane;
+      if (gl < G) {
+        const int bl = gl / nS, s = gl - bl * nS;
+        const int b = (int)b_first + bl;
+        const int64_t genv = sp.env_offset + b;
+        const uint32_t tick0 = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+        const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
+        for (int tl = wave; tl < tc; tl += SC_NT / 64) {
+          const int t = t0 + tl;
+          const int64_t o = (int64_t)t * total + g_base + gl;
+          int D = 0; uint32_t w3 = 0;
+          if (io.exo) {
+            const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
+            for (int k = c_lo; k < c_hi; ++k) D += row[sp.shop_cust_exo[k]];
+            if (!io.actions) rng_shop_orders(sp.seed, genv, tick0 + t, s, 0, nullptr, -1, &w3);
+          } else {
+            D = rng_shop_orders(sp.seed, genv, tick0 + t, s, c_hi - c_lo, nullptr, -1, &w3);
+          }
+          const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
+          io.action_out[o] = action;
+          int* it = s_it + ((int64_t)tl * G + gl) * 3;
+          it[0] = dev_round_half_even(action); it[1] = D;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: the stock recurrence, one lane per pair ---------------------------------------
+    if (tid < G) {
+      for (int tl = 0; tl < tc; ++tl) {
+        int* it = s_it + ((int64_t)tl * G + tid) * 3;
+        const int R = it[0], D = it[1];
+        const int stock0 = st.stock;
+        const int room = PHX_SHOP_MAX_STOCK - stock0;
+        const int req = R < room ? R : room;                      // supply_chain.py:139
+        int sales = 0, stock1 = stock0;
+        if (p2_K > 0) { sales = D < stock0 ? D : stock0; stock1 = stock0 - sales; }   // :105-122
+        const int ns = stock1 + req;                              // :98-103
+        stock1 = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
+        st.stock = stock1; st.sales = sales; st.missed = (p2_K > 0) ? D - sales : 0; st.delivered = req;
+        it[0] = stock1; it[2] = sales;
+        if (++step == sp.num_steps) { st.stock = 0; step = 0; }   // episode end: env.reset() -> stock = 0
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: observations / rewards / flags ------------------------------------------------
+    for (int c = 0; c * 64 < G; ++c) {
+      const int gl = c * 64 + lane;
+      if (gl < G) {
+        const int bl = gl / nS, s = gl - bl * nS;
+        const int b = (int)b_first + bl;
+        const int a_shop = sp.shop_agent[s];
+        const float norm = (float)sp.param_i[a_shop * PHX_NPI + 1];
+        const int K = sp.shop_cust_ptr[s + 1] - sp.shop_cust_ptr[s];
+        const int step0 = fld<int32_t>(sp, F_ENV_STEP)[b];
+        for (int tl = wave; tl < tc; tl += SC_NT / 64) {
+          const int t = t0 + tl;
+          const int64_t o = (int64_t)t * total + g_base + gl;
+          const int* it = s_it + ((int64_t)tl * G + gl) * 3;
+          const int stock = it[0], D = it[1], sales = it[2];
+          const int missed = (K > 0) ? D - sales : 0;
+          // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
+          // (53 >= 2*24+2: the double rounding is innocuous), see shop_obs_f32
+          float ob[3];
+          shop_obs_f32(stock, sales, missed, norm, ob);
+          io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
+          io.reward[o] = (float)shop_reward(sales, stock);
+          // env step counter after this step (an env stepped past num_steps without reset never truncates)
+          const bool all_trunc = step0 < sp.num_steps && ((step0 + t) % sp.num_steps) + 1 == sp.num_steps;
+          io.terminated[o] = 0;
+          io.truncated[o] = all_trunc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < G) {
+    const int64_t g = g_base + tid;
+    const int s = tid % nS, b = (int)b_first + tid / nS;
+    fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock;
+    fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
+    fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed;
+    fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
+    if (io.last_obs) {
+      float ob[3];
+      shop_obs(st.stock, st.sales, st.missed, sp.param_i[sp.shop_agent[s] * PHX_NPI + 1], ob);
+      io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
+    }
+    if (s == 0) {       // every read of env.step / env.tick above is behind a barrier
+      fld<int32_t>(sp, F_ENV_STEP)[b] = step;
+      fld<int32_t>(sp, F_ENV_TICK)[b] = fld<int32_t>(sp, F_ENV_TICK)[b] + io.T;
+    }
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   const int epb = SC_NT / sp.S;                       // whole envs per block (S <= 256 checked at create)
@@ -242,8 +377,18 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
 }
 
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
-  const int epb = SC_NT / sp.S;
-  const int blocks = (sp.B + epb - 1) / epb;
-  hipLaunchKernelGGL(phx_sc_rollout_kernel, dim3(blocks), dim3(SC_NT), 0, st, sp, io, epb);
+  static const bool use_v1 = getenv("PHX_ROLLOUT_V1") != nullptr;     // A/B against the lane-per-shop loop
+  if (use_v1) {
+    const int epb = SC_NT / sp.S;
+    hipLaunchKernelGGL(phx_sc_rollout_v1_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), 0, st, sp, io, epb);
+    return hipGetLastError();
+  }
+  // ~64 pairs per block (one wave in the sequential phase), TC steps so that the item table
+  // stays around 36 KB -> 4 blocks per CU
+  int epb = 64 / sp.S; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B;
+  const int G = epb * sp.S;
+  int TC = (36 * 1024) / (G * 12); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;
+  const size_t lds = (size_t)G * TC * 12;
+  hipLaunchKernelGGL(phx_sc_rollout_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, TC);
   return hipGetLastError();
 }
