@@ -46,7 +46,7 @@ struct Derived {
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
   bool sc_static = false;
-  std::vector<int32_t> shop_agent, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
+  std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
   std::vector<uint8_t> shop_cust_act;
   int max_cust = 0;
 };
@@ -145,10 +145,10 @@ static int derive(const phx_spec* sp, Derived& d) {
   d.sc_static = sc;
   if (d.kind_count[PHX_KIND_SHOP] > 0) {
     const int nS = d.kind_count[PHX_KIND_SHOP];
-    d.shop_agent.assign(nS, 0);
+    d.shop_agent.assign(nS, 0); d.shop_norm.assign(nS, 1);
     std::vector<std::vector<int>> cust(nS);
     for (int a = 0; a < A; ++a) {
-      if (sp->kind[a] == PHX_KIND_SHOP) d.shop_agent[d.kind_rank[a]] = a;
+      if (sp->kind[a] == PHX_KIND_SHOP) { d.shop_agent[d.kind_rank[a]] = a; d.shop_norm[d.kind_rank[a]] = sp->param_i[a * PHX_NPI + 1]; }
       if (sp->kind[a] == PHX_KIND_CUSTOMER) cust[d.kind_rank[sp->param_i[a * PHX_NPI]]].push_back(a);
     }
     d.shop_cust_ptr.push_back(0);
@@ -291,6 +291,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(reset_obs_idx, der.reset_obs_idx.data(), der.reset_obs_idx.size());
   d.n_reset_obs = (int)der.reset_obs_idx.size();
   UP(shop_agent, der.shop_agent.data(), der.shop_agent.size());
+  UP(shop_norm, der.shop_norm.data(), der.shop_norm.size());
   UP(shop_cust_ptr, der.shop_cust_ptr.data(), der.shop_cust_ptr.size());
   UP(shop_cust_exo, der.shop_cust_exo.data(), der.shop_cust_exo.size());
   UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());

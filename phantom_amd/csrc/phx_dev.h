@@ -70,6 +70,7 @@ struct DevSpec {
   int32_t n_reset_obs;
   // supply-chain static schedule (fused kernels)
   const int32_t* shop_agent;     // [nS] agent index of each shop (kind-rank order)
+  const int32_t* shop_norm;      // [nS] ShopAgent max_sales_per_step (param_i[shop][1])
   const int32_t* shop_cust_ptr;  // [nS+1]
   const int32_t* shop_cust_exo;  // exo rank of each customer of the shop, acting order
   const int32_t* shop_cust_agent;// agent index of each customer
@@ -131,12 +132,12 @@ __device__ __forceinline__ int dev_send_check(const DevSpec& sp, int src, int ds
 // ---- device RNG (the definition is stated in DESIGN.md; the oracle restates it) ---------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  // one 32x32->64 product per multiplier and round (v_mad_u64_u32 gives hi and lo together)
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
@@ -171,6 +172,36 @@ __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint
     }
     ++blk;
   } while (got < K);
+  return sum;
+}
+
+// Same definition, all K customers, sum only -- the fused kernels' fast path.  The ten 3-bit
+// fields of a word are handled at once: acc gets bit 3f set where field f <= 4, the surplus
+// (highest) accepted fields beyond the shop's remaining need are cleared, and the field values
+// are summed bit-plane by bit-plane with popcounts.
+__device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
+                                                  int K, uint32_t* act_word) {
+  int need = K, sum = 0;
+  uint32_t blk = 0;
+  do {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
+                  (uint32_t)shop | (blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    if (blk == 0 && act_word) *act_word = w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (need > 0) {
+        const uint32_t x = w[j];
+        uint32_t acc = ~((x >> 2) & ((x >> 1) | x)) & 0x09249249u;
+        int pc = __popc(acc);
+        while (pc > need) { acc &= ~(0x80000000u >> __clz(acc)); --pc; }
+        const uint32_t xm = x & (acc * 7u);
+        sum += __popc(xm & 0x09249249u) + 2 * __popc(xm & 0x12492492u) + 4 * __popc(xm & 0x24924924u);
+        need -= pc;
+      }
+    }
+    ++blk;
+  } while (need > 0);
   return sum;
 }
 

@@ -107,8 +107,10 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
         D += staged ? s_exo[idx - lds_base] : io.exo[idx];
       }
   } else {
-    for (int k = c_lo; k < c_hi; ++k) any_order |= cact[k] != 0;
-    if (any_order)
+    bool all_order = true;
+    for (int k = c_lo; k < c_hi; ++k) { any_order |= cact[k] != 0; all_order &= cact[k] != 0; }
+    if (all_order) D = rng_shop_order_sum(sp.seed, sp.env_offset + b, tick, s, c_hi - c_lo, nullptr);
+    else if (any_order)
       D = rng_shop_orders(sp.seed, sp.env_offset + b, tick, s, c_hi - c_lo, cact + c_lo, -1);
   }
   sc_shop_step(st, has_action, action, any_order, D);
@@ -243,13 +245,27 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_v1_kernel(const DevSpec 
 //   phase 3 (all lanes, item = (t, pair)): obs / reward / flags -> HBM, rows contiguous in pair
 // Waves take whole time rows (lanes = consecutive pairs), so every trajectory store of a wave
 // covers one contiguous segment of the [T][B][S] arrays.
-__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp, const phx_rollout_io io,
-                                                               const int epb, const int TC) {
+// lean argument block of the rollout kernel (passing the whole DevSpec by value costs ~50
+// spilled SGPRs per wave)
+struct RollArgs {
+  int32_t B, S, n_exo, num_steps, T, epb, TC;
+  uint64_t seed; int64_t env_offset;
+  const int32_t* shop_norm;      // [S] max_sales_per_step of each shop
+  const int32_t* shop_cust_ptr;  // [S+1]
+  const int32_t* shop_cust_exo;
+  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick;
+  phx_rollout_io io;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
   extern __shared__ __attribute__((aligned(16))) int s_it[];     // [TC][G][3]
-  const int nS = sp.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t total = (int64_t)sp.B * nS;
-  const int64_t b_first = (int64_t)blockIdx.x * epb;
-  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
+  const phx_rollout_io& io = a.io;
+  const int nS = a.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TC = a.TC;
+  const int64_t total = (int64_t)a.B * nS;
+  const int64_t b_first = (int64_t)blockIdx.x * a.epb;
+  const int64_t b_end = (b_first + a.epb < a.B) ? b_first + a.epb : a.B;
   const int G = (int)(b_end - b_first) * nS;
   const int64_t g_base = b_first * nS;
 
@@ -258,36 +274,33 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
   int step = 0, p2_K = 0;
   if (tid < G) {
     const int64_t g = g_base + tid;
-    st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
-    st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
-    st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g];
-    st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
-    step = fld<int32_t>(sp, F_ENV_STEP)[b_first + tid / nS];
+    st.stock = a.stock[g]; st.sales = a.sales[g]; st.missed = a.missed[g]; st.delivered = a.delivered[g];
+    step = a.env_step[b_first + tid / nS];
     const int s2 = tid % nS;
-    p2_K = sp.shop_cust_ptr[s2 + 1] - sp.shop_cust_ptr[s2];
+    p2_K = a.shop_cust_ptr[s2 + 1] - a.shop_cust_ptr[s2];
   }
 
-  for (int t0 = 0; t0 < io.T; t0 += TC) {
-    const int tc = (io.T - t0 < TC) ? io.T - t0 : TC;
-    // ---- phase 1 + 3 item loops: lanes = pairs (64 per chunk), waves = time rows --------------
+  for (int t0 = 0; t0 < a.T; t0 += TC) {
+    const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
+    // ---- phase 1: lanes = pairs (64 per chunk), waves = time rows ------------------------------
     for (int c = 0; c * 64 < G; ++c) {
       const int gl = c * 64 + lane;
       if (gl < G) {
         const int bl = gl / nS, s = gl - bl * nS;
         const int b = (int)b_first + bl;
-        const int64_t genv = sp.env_offset + b;
-        const uint32_t tick0 = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-        const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
-        for (int tl = wave; tl < tc; tl += SC_NT / 64) {
+        const int64_t genv = a.env_offset + b;
+        const uint32_t tick0 = (uint32_t)a.env_tick[b];
+        const int c_lo = a.shop_cust_ptr[s], c_hi = a.shop_cust_ptr[s + 1];
+        for (int tl = wave; tl < tc; tl += NT / 64) {
           const int t = t0 + tl;
           const int64_t o = (int64_t)t * total + g_base + gl;
           int D = 0; uint32_t w3 = 0;
           if (io.exo) {
-            const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
-            for (int k = c_lo; k < c_hi; ++k) D += row[sp.shop_cust_exo[k]];
-            if (!io.actions) rng_shop_orders(sp.seed, genv, tick0 + t, s, 0, nullptr, -1, &w3);
+            const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
+            for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
+            if (!io.actions) rng_shop_order_sum(a.seed, genv, tick0 + t, s, 0, &w3);
           } else {
-            D = rng_shop_orders(sp.seed, genv, tick0 + t, s, c_hi - c_lo, nullptr, -1, &w3);
+            D = rng_shop_order_sum(a.seed, genv, tick0 + t, s, c_hi - c_lo, &w3);
           }
           const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
           io.action_out[o] = action;
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
         stock1 = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
         st.stock = stock1; st.sales = sales; st.missed = (p2_K > 0) ? D - sales : 0; st.delivered = req;
         it[0] = stock1; it[2] = sales;
-        if (++step == sp.num_steps) { st.stock = 0; step = 0; }   // episode end: env.reset() -> stock = 0
+        if (++step == a.num_steps) { st.stock = 0; step = 0; }    // episode end: env.reset() -> stock = 0
       }
     }
     __syncthreads();
@@ -321,24 +334,22 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
       if (gl < G) {
         const int bl = gl / nS, s = gl - bl * nS;
         const int b = (int)b_first + bl;
-        const int a_shop = sp.shop_agent[s];
-        const float norm = (float)sp.param_i[a_shop * PHX_NPI + 1];
-        const int K = sp.shop_cust_ptr[s + 1] - sp.shop_cust_ptr[s];
-        const int step0 = fld<int32_t>(sp, F_ENV_STEP)[b];
-        for (int tl = wave; tl < tc; tl += SC_NT / 64) {
+        const float norm = (float)a.shop_norm[s];
+        const int K = a.shop_cust_ptr[s + 1] - a.shop_cust_ptr[s];
+        const int step0 = a.env_step[b];
+        for (int tl = wave; tl < tc; tl += NT / 64) {
           const int t = t0 + tl;
           const int64_t o = (int64_t)t * total + g_base + gl;
           const int* it = s_it + ((int64_t)tl * G + gl) * 3;
           const int stock = it[0], D = it[1], sales = it[2];
           const int missed = (K > 0) ? D - sales : 0;
           // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
-          // (53 >= 2*24+2: the double rounding is innocuous), see shop_obs_f32
           float ob[3];
           shop_obs_f32(stock, sales, missed, norm, ob);
           io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
           io.reward[o] = (float)shop_reward(sales, stock);
           // env step counter after this step (an env stepped past num_steps without reset never truncates)
-          const bool all_trunc = step0 < sp.num_steps && ((step0 + t) % sp.num_steps) + 1 == sp.num_steps;
+          const bool all_trunc = step0 < a.num_steps && ((step0 + t) % a.num_steps) + 1 == a.num_steps;
           io.terminated[o] = 0;
           io.truncated[o] = all_trunc;
         }
@@ -349,18 +360,15 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_kernel(const DevSpec sp,
   if (tid < G) {
     const int64_t g = g_base + tid;
     const int s = tid % nS, b = (int)b_first + tid / nS;
-    fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock;
-    fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
-    fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed;
-    fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
+    a.stock[g] = st.stock; a.sales[g] = st.sales; a.missed[g] = st.missed; a.delivered[g] = st.delivered;
     if (io.last_obs) {
       float ob[3];
-      shop_obs(st.stock, st.sales, st.missed, sp.param_i[sp.shop_agent[s] * PHX_NPI + 1], ob);
+      shop_obs(st.stock, st.sales, st.missed, a.shop_norm[s], ob);
       io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
     }
-    if (s == 0) {       // every read of env.step / env.tick above is behind a barrier
-      fld<int32_t>(sp, F_ENV_STEP)[b] = step;
-      fld<int32_t>(sp, F_ENV_TICK)[b] = fld<int32_t>(sp, F_ENV_TICK)[b] + io.T;
+    if (s == 0) {       // every read of env_step / env_tick above is behind a barrier
+      a.env_step[b] = step;
+      a.env_tick[b] = a.env_tick[b] + a.T;
     }
   }
 }
@@ -384,11 +392,24 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
     return hipGetLastError();
   }
   // ~64 pairs per block (one wave in the sequential phase), TC steps so that the item table
-  // stays around 36 KB -> 4 blocks per CU
+  // stays around 36 KB; 1024-thread blocks put 16 time rows in flight per block
+  RollArgs a;
+  a.B = sp.B; a.S = sp.S; a.n_exo = sp.n_exo; a.num_steps = sp.num_steps; a.T = io.T;
+  a.seed = sp.seed; a.env_offset = sp.env_offset;
+  a.shop_norm = sp.shop_norm; a.shop_cust_ptr = sp.shop_cust_ptr; a.shop_cust_exo = sp.shop_cust_exo;
+  a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
+  a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
+  a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
+  a.io = io;
   int epb = 64 / sp.S; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B;
   const int G = epb * sp.S;
   int TC = (36 * 1024) / (G * 12); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;
+  a.epb = epb; a.TC = TC;
   const size_t lds = (size_t)G * TC * 12;
-  hipLaunchKernelGGL(phx_sc_rollout_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, TC);
+  static const int nt = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 1024;
+  const dim3 grid((sp.B + epb - 1) / epb);
+  if (nt == 256) hipLaunchKernelGGL((phx_sc_rollout_kernel<256>), grid, dim3(256), lds, st, a);
+  else if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_kernel<512>), grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((phx_sc_rollout_kernel<1024>), grid, dim3(1024), lds, st, a);
   return hipGetLastError();
 }

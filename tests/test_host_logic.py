@@ -1,0 +1,181 @@
+"""CPU: host-side logic of the drop-in surface (no GPU, no compute calls through the C ABI):
+Network/FSM construction + validation parity with the reference's tests, the spec compiler,
+the exported symbols of the HIP library, and the pinned definitions (Philox known answers,
+exactness of the f32 observation division, numpy stream equivalence)."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+import phantom_amd as ph
+from phantom_amd import _abi
+from oracle import philox, rng_action, rng_orders
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/phantom_amd.h <-> libphantom_amd.so <-> the ctypes table, without touching a GPU."""
+    header = open(os.path.join(ROOT, "include", "phantom_amd.h")).read()
+    declared = set(re.findall(r"\b(phx_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_abi.EXPORTS)
+    lib = _abi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.phx_abi_version() == _abi.ABI_VERSION
+    assert ctypes.sizeof(_abi.PhxMsgRec) == 16 and ctypes.sizeof(_abi.PhxField) == 64
+
+
+def test_spec_sizes_through_the_abi_without_gpu():
+    lib = _abi.load_library()
+    env = ph.SupplyChainEnv(n_shops=9, customers_per_shop=6, batch_size=4096)
+    cs, keep = env.spec.to_ctypes()
+    assert lib.phx_n_strategic(ctypes.byref(cs)) == 9
+    assert lib.phx_obs_dim(ctypes.byref(cs)) == 3
+    assert lib.phx_n_exo(ctypes.byref(cs)) == 54
+    assert lib.phx_state_nbytes(ctypes.byref(cs)) > 0
+    cs.abi_version = 99
+    assert lib.phx_state_nbytes(ctypes.byref(cs)) == -1
+    assert b"abi_version" in lib.phx_last_error()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = ph.SupplyChainEnv()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        env.reset()
+
+
+def test_supply_chain_spec_matches_reference_layout():
+    env = ph.SupplyChainEnv()                        # supply_chain.py:153-175
+    assert env.agent_ids == ["SHOP", "WAREHOUSE", "CUST1", "CUST2", "CUST3", "CUST4", "CUST5"]
+    assert env.strategic_agent_ids == ["SHOP"] and env.n_agents == 7
+    s = env.spec
+    assert s.kind.tolist() == [2, 1, 3, 3, 3, 3, 3]
+    # nx adjacency order: SHOP -> WAREHOUSE, CUST1..5 ; both directions (network.py:122-123)
+    assert s.col[s.row_ptr[0]:s.row_ptr[1]].tolist() == [1, 2, 3, 4, 5, 6]
+    assert all(s.col[s.row_ptr[a]:s.row_ptr[a + 1]].tolist() == [0] for a in range(1, 7))
+    assert s.param_i[0].tolist()[:2] == [1, 25]      # factory index, NUM_CUSTOMERS * 5
+    assert s.param_i[2:, 1].tolist() == [0, 1, 2, 3, 4]
+    assert s.round_limit == -1 and s.num_steps == 100
+
+
+def test_network_construction_parity():
+    """tests/network/test_network.py:37-47,128-157 of the reference."""
+    net = ph.Network([ph.CashboxAgent("a1"), ph.CashboxAgent("a2")])
+    net.add_connection("a1", "a2")
+    ph.Network([ph.CashboxAgent("a1"), ph.CashboxAgent("a2")], connections=[("a1", "a2")])
+    with pytest.raises(ValueError):
+        ph.Network([ph.CashboxAgent("a1"), ph.CashboxAgent("a1")])
+    with pytest.raises(ValueError):
+        ph.Network([ph.CashboxAgent("a1")], connections=[("a1", "a2")])
+    net2 = ph.Network([ph.CashboxAgent("a"), ph.CashboxAgent("b"), ph.CashboxAgent("c")])
+    net2.add_connections_with_adjmat(["a", "b"], np.array([[0, 1], [1, 0]]))
+    assert net2.has_edge("a", "b") and net2.has_edge("b", "a") and not net2.has_edge("a", "c")
+    for bad, msg in ((np.array([[0, 0, 0], [0, 0, 0]]), "Adjacency matrix must be square."),
+                     (np.array([[0, 0], [1, 0]]), "Adjacency matrix must be symmetric."),
+                     (np.array([[1, 1], [1, 1]]), "Adjacency matrix must be hollow.")):
+        with pytest.raises(ValueError) as e:
+            net2.add_connections_with_adjmat(["a", "b"], bad)
+        assert str(e.value) == msg
+    assert net2.get_agents_with_type(ph.Agent) == net2.agents
+    assert net2.get_agents_without_type(ph.Agent) == {}
+
+
+def test_host_send_checks_parity():
+    """network.py:246-252,297-331; tests/network/test_payload_checks.py of the reference."""
+    net = ph.supply_chain.build_network()
+    with pytest.raises(ph.NetworkError):
+        net.send("CUST1", "WAREHOUSE", ph.OrderRequest(1))         # no edge
+    with pytest.raises(ph.NetworkError):
+        net.send("SHOP", "CUST1", ph.OrderRequest(1))              # wrong sender type
+    with pytest.raises(ph.NetworkError):
+        net.send("CUST1", "SHOP", ph.StockRequest(1))              # wrong sender + receiver
+    with pytest.raises(ph.NetworkError):
+        net.send("CUST1", "SHOP", True)                            # undecorated payload
+    net.send("CUST1", "SHOP", ph.OrderRequest(1))                  # fine: queued for the device
+
+
+def test_fsm_validation_parity():
+    """tests/fsm/test_fsm_validation.py of the reference: same errors at construction."""
+    net = ph.Network([ph.MockStrategicAgent("agent")])
+    with pytest.raises(ph.FSMValidationError):
+        ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[])
+    with pytest.raises(ph.FSMValidationError):
+        ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="X", stages=[
+            ph.FSMStage("A", acting_agents=["agent"], next_stages=["A"])])
+    with pytest.raises(ph.FSMValidationError):
+        ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[
+            ph.FSMStage("A", acting_agents=["agent"], next_stages=["B"])])
+    with pytest.raises(ph.FSMValidationError):
+        ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[
+            ph.FSMStage("A", acting_agents=["agent"], next_stages=[])])
+    with pytest.raises(NotImplementedError):      # python stage handlers cannot run on the device
+        ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[
+            ph.FSMStage("A", acting_agents=["agent"], next_stages=["A"], handler=lambda: "A")])
+    env = ph.FiniteStateMachineEnv(num_steps=3, network=net, initial_stage="A", stages=[
+        ph.FSMStage("A", acting_agents=["agent"], next_stages=["B"]),
+        ph.FSMStage("B", acting_agents=["agent"], rewarded_agents=[], next_stages=["A"])])
+    assert env.is_fsm_deterministic() and env.current_stage == "A"
+    s = env.spec
+    assert s.stage_next.tolist() == [1, 0] and s.stage_rewarded_all.tolist() == [1, 0]
+
+
+def test_stackelberg_validation_parity():
+    net = ph.Network([ph.MockStrategicAgent("l"), ph.MockStrategicAgent("f")])
+    with pytest.raises(AssertionError):
+        ph.StackelbergEnv(3, net, ["l"], ["nope"])
+    with pytest.raises(AssertionError):
+        ph.StackelbergEnv(3, net, ["l"], ["l"])
+    env = ph.StackelbergEnv(3, net, ["l"], ["f"])
+    assert env.spec.leaders.tolist() == [0] and env.spec.followers.tolist() == [1]
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10 pin the device-RNG primitive."""
+    assert [int(x) for x in philox([0, 0, 0, 0], [0, 0])] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [int(x) for x in philox([0xffffffff] * 4, [0xffffffff] * 2)] == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert [int(x) for x in philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                                   [0xa4093822, 0x299f31d0])] == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_device_rng_definition():
+    """orders = accepted 3-bit fields (<= 4) of words 0..2; action = top 24 bits of word 3."""
+    seed, genv, tick, shop = 0x1234567890ABCDEF, 5_000_000_123, 77, 3
+    w = philox([genv & 0xffffffff, genv >> 32, tick, shop], [seed & 0xffffffff, seed >> 32])
+    fields = [(int(w[j]) >> (3 * f)) & 7 for j in range(3) for f in range(10)]
+    acc = [v for v in fields if v <= 4]
+    got = rng_orders(seed, genv, tick, shop, len(acc))
+    assert got.tolist() == acc
+    assert rng_action(seed, genv, tick, shop) == np.float32(int(w[3]) >> 8) * np.float32(100.0 / 16777216.0)
+    many = np.concatenate([rng_orders(1, b, t, 0, 6) for b in range(200) for t in range(20)])
+    assert many.min() == 0 and many.max() == 4
+    assert abs(np.bincount(many, minlength=5) / many.size - 0.2).max() < 0.01
+    # K large enough to need further blocks (blk = 1, 2, ...)
+    big = rng_orders(seed, genv, tick, shop, 100)
+    assert big[:len(acc)].tolist() == acc and big.max() <= 4
+
+
+def test_f32_division_equals_reference_f64_quotient_cast():
+    """encode_observation builds python-float quotients and casts to float32
+    (supply_chain.py:127-134); the rollout kernel divides in f32.  Identical bit patterns."""
+    s = np.arange(-4096, 4097, dtype=np.int64)[:, None]
+    n = np.arange(1, 2049, dtype=np.int64)[None, :]
+    q64 = (s.astype(np.float64) / n.astype(np.float64)).astype(np.float32)
+    q32 = s.astype(np.float32) / n.astype(np.float32)
+    assert (q64.view(np.uint32) == q32.view(np.uint32)).all()
+
+
+def test_numpy_stream_vector_draw_equals_scalar_draws():
+    """PhantomEnv._draw_exo draws one vector per env; the reference's customers draw scalars."""
+    np.random.seed(123)
+    a = [np.random.randint(5) for _ in range(3000)]
+    np.random.seed(123)
+    b = np.concatenate([np.random.randint(5, size=n) for n in (54, 1, 945, 2000)])
+    assert a == b.tolist()
