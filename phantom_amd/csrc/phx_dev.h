@@ -209,11 +209,13 @@ __device__ __forceinline__ float rng_word_to_action(uint32_t w3) {
   return (float)(w3 >> 8) * (100.0f / 16777216.0f);
 }
 
-// int(round(np.float32(a))) -- round-half-to-even, supply_chain.py:139
+// int(round(np.float32(a))) -- round-half-to-even, supply_chain.py:139.  rintf of an f32 value is
+// the same integer the reference's float64 round() produces (every f32 is exactly representable
+// in f64 and the rounded integer is representable in f32); v_rndne_f32 is full rate.
 __device__ __forceinline__ int dev_round_half_even(float a) {
-  double r = rint((double)a);
-  r = r > 1073741824.0 ? 1073741824.0 : r;
-  r = r < -1073741824.0 ? -1073741824.0 : r;
+  float r = rintf(a);
+  r = r > 1073741824.0f ? 1073741824.0f : r;
+  r = r < -1073741824.0f ? -1073741824.0f : r;
   return (int)r;
 }
 

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_v1_kernel(const DevSpec 
 // spilled SGPRs per wave)
 struct RollArgs {
   int32_t B, S, n_exo, num_steps, T, epb, TC;
+  uint32_t mG, mO, mF, mU;       // ceil(2^32 / d) magic numbers: i / d == umulhi(i, m) for i < 2^16
   uint64_t seed; int64_t env_offset;
   const int32_t* shop_norm;      // [S] max_sales_per_step of each shop
   const int32_t* shop_cust_ptr;  // [S+1]
@@ -257,17 +258,54 @@ struct RollArgs {
   phx_rollout_io io;
 };
 
+// ---- rollout v3: time-parallel (see v2 above) + tile-staged, full-width trajectory stores.
+// A block owns G = epb * S (env, shop) pairs (whole envs) and walks the fragment in chunks of
+// TC steps.  Per chunk, LDS holds a tile of TC x G items:
+//   phase 1  (all lanes, flat items)  Philox -> {R, D} + action tile
+//   phase 2  (one lane per pair)      stock recurrence over the TC steps, in LDS
+//   phase 3a (all lanes, flat items)  obs (in place of the item), reward, truncation flag tiles
+//   phase 3b (all lanes)              tiles -> HBM: each tile row is one contiguous, 16-byte
+//                                     aligned segment of the [T][B][S] arrays, written with
+//                                     dwordx4 stores (the same shape a fill kernel uses)
+// Barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// store (s_waitcnt vmcnt(0)) because it is a workgroup-scope release; the tiles below need no
+// global visibility inside the kernel, and draining would expose the HBM write latency at each
+// of the 4 barriers per chunk instead of letting the trajectory stores retire under the next
+// chunk's Philox work.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int s_it[];     // [TC][G][3]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const phx_rollout_io& io = a.io;
-  const int nS = a.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int TC = a.TC;
+  const int nS = a.S, tid = threadIdx.x, TC = a.TC;
   const int64_t total = (int64_t)a.B * nS;
   const int64_t b_first = (int64_t)blockIdx.x * a.epb;
   const int64_t b_end = (b_first + a.epb < a.B) ? b_first + a.epb : a.B;
-  const int G = (int)(b_end - b_first) * nS;
+  const int nb = (int)(b_end - b_first);
+  const int G = nb * nS, Gfull = a.epb * nS;
   const int64_t g_base = b_first * nS;
+
+  // LDS carve (all offsets multiples of 16 bytes)
+  const int items_max = TC * Gfull;
+  int* s_it = (int*)smem;                                  // [TC][G][3]  {R|stock|obs0, D|obs1, sales|obs2}
+  float* s_rew = (float*)(s_it + ((items_max * 3 + 3) & ~3));
+  float* s_act = s_rew + ((items_max + 3) & ~3);
+  uint8_t* s_trunc = (uint8_t*)(s_act + ((items_max + 3) & ~3));
+  uint16_t* s_pair = (uint16_t*)(s_trunc + ((items_max + 15) & ~15));   // [G] shop | env_local << 8
+  int* s_tick0 = (int*)(s_pair + ((Gfull + 7) & ~7));     // [epb]
+  int* s_step0 = s_tick0 + ((a.epb + 3) & ~3);             // [epb]
+  int* s_cptr = s_step0 + ((a.epb + 3) & ~3);              // [S+1]
+  int* s_norm = s_cptr + ((nS + 1 + 3) & ~3);              // [S]
+
+  for (int gl = tid; gl < G; gl += NT) s_pair[gl] = (uint16_t)((gl % nS) | ((gl / nS) << 8));
+  for (int bl = tid; bl < nb; bl += NT) { s_tick0[bl] = a.env_tick[b_first + bl]; s_step0[bl] = a.env_step[b_first + bl]; }
+  for (int k = tid; k <= nS; k += NT) s_cptr[k] = a.shop_cust_ptr[k];
+  for (int k = tid; k < nS; k += NT) s_norm[k] = a.shop_norm[k];
 
   // phase-2 lane state: lane `tid` owns pair g_base + tid
   ShopLane st = {0, 0, 0, 0};
@@ -279,41 +317,44 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
     const int s2 = tid % nS;
     p2_K = a.shop_cust_ptr[s2 + 1] - a.shop_cust_ptr[s2];
   }
+  // full-width copy-out needs every tile row to start and end on a 16-byte boundary
+  const bool wide4 = ((G & 3) == 0) && ((g_base & 3) == 0) && ((total & 3) == 0);
+  const bool wide8 = ((G & 7) == 0) && ((g_base & 7) == 0) && ((total & 7) == 0);
+  lds_barrier();
 
   for (int t0 = 0; t0 < a.T; t0 += TC) {
     const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
-    // ---- phase 1: lanes = pairs (64 per chunk), waves = time rows ------------------------------
-    for (int c = 0; c * 64 < G; ++c) {
-      const int gl = c * 64 + lane;
-      if (gl < G) {
-        const int bl = gl / nS, s = gl - bl * nS;
-        const int b = (int)b_first + bl;
-        const int64_t genv = a.env_offset + b;
-        const uint32_t tick0 = (uint32_t)a.env_tick[b];
-        const int c_lo = a.shop_cust_ptr[s], c_hi = a.shop_cust_ptr[s + 1];
-        for (int tl = wave; tl < tc; tl += NT / 64) {
-          const int t = t0 + tl;
-          const int64_t o = (int64_t)t * total + g_base + gl;
-          int D = 0; uint32_t w3 = 0;
-          if (io.exo) {
-            const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
-            for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
-            if (!io.actions) rng_shop_order_sum(a.seed, genv, tick0 + t, s, 0, &w3);
-          } else {
-            D = rng_shop_order_sum(a.seed, genv, tick0 + t, s, c_hi - c_lo, &w3);
-          }
-          const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
-          io.action_out[o] = action;
-          int* it = s_it + ((int64_t)tl * G + gl) * 3;
-          it[0] = dev_round_half_even(action); it[1] = D;
-        }
+    const int n_items = tc * G;
+    // ---- phase 1 ---------------------------------------------------------------------------------
+    // flat items i = tl * G + gl, thread-strided; (tl, gl) advance incrementally (NT = qG * G + rG)
+    int tl = tid / G, gl = tid - tl * G;
+    const int qG = NT / G, rG = NT - qG * G;
+    for (int i = tid; i < n_items; i += NT) {
+      const int pr = s_pair[gl], s = pr & 255, bl = pr >> 8;
+      const int b = (int)b_first + bl, t = t0 + tl;
+      const int64_t genv = a.env_offset + b;
+      const uint32_t tick = (uint32_t)s_tick0[bl] + (uint32_t)t;
+      const int c_lo = s_cptr[s], c_hi = s_cptr[s + 1];
+      int D = 0; uint32_t w3 = 0;
+      if (io.exo) {
+        const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
+        for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
+        if (!io.actions) rng_shop_order_sum(a.seed, genv, tick, s, 0, &w3);
+      } else {
+        D = rng_shop_order_sum(a.seed, genv, tick, s, c_hi - c_lo, &w3);
       }
+      const float action = io.actions ? io.actions[(int64_t)t * total + g_base + gl] : rng_word_to_action(w3);
+      s_act[i] = action;
+      s_it[3 * i + 0] = dev_round_half_even(action);
+      s_it[3 * i + 1] = D;
+      tl += qG; gl += rG;
+      if (gl >= G) { gl -= G; ++tl; }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 2: the stock recurrence, one lane per pair ---------------------------------------
     if (tid < G) {
       for (int tl = 0; tl < tc; ++tl) {
-        int* it = s_it + ((int64_t)tl * G + tid) * 3;
+        int* it = s_it + (tl * G + tid) * 3;
         const int R = it[0], D = it[1];
         const int stock0 = st.stock;
         const int room = PHX_SHOP_MAX_STOCK - stock0;
@@ -324,38 +365,76 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
         stock1 = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
         st.stock = stock1; st.sales = sales; st.missed = (p2_K > 0) ? D - sales : 0; st.delivered = req;
         it[0] = stock1; it[2] = sales;
-        if (++step == a.num_steps) { st.stock = 0; step = 0; }    // episode end: env.reset() -> stock = 0
-      }
-    }
-    __syncthreads();
-    // ---- phase 3: observations / rewards / flags ------------------------------------------------
-    for (int c = 0; c * 64 < G; ++c) {
-      const int gl = c * 64 + lane;
-      if (gl < G) {
-        const int bl = gl / nS, s = gl - bl * nS;
-        const int b = (int)b_first + bl;
-        const float norm = (float)a.shop_norm[s];
-        const int K = a.shop_cust_ptr[s + 1] - a.shop_cust_ptr[s];
-        const int step0 = a.env_step[b];
-        for (int tl = wave; tl < tc; tl += NT / 64) {
-          const int t = t0 + tl;
-          const int64_t o = (int64_t)t * total + g_base + gl;
-          const int* it = s_it + ((int64_t)tl * G + gl) * 3;
-          const int stock = it[0], D = it[1], sales = it[2];
-          const int missed = (K > 0) ? D - sales : 0;
-          // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
-          float ob[3];
-          shop_obs_f32(stock, sales, missed, norm, ob);
-          io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
-          io.reward[o] = (float)shop_reward(sales, stock);
-          // env step counter after this step (an env stepped past num_steps without reset never truncates)
-          const bool all_trunc = step0 < a.num_steps && ((step0 + t) % a.num_steps) + 1 == a.num_steps;
-          io.terminated[o] = 0;
-          io.truncated[o] = all_trunc;
+        if (++step == a.num_steps) {                              // episode end: truncations["__all__"]
+          st.stock = 0; step = 0;                                 // ... and the caller's env.reset(): stock = 0
+          it[1] = D | (1 << 30);
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    // ---- phase 3a: observations / rewards / flags into the tiles ------------------------------------
+    gl = tid % G;
+    for (int i = tid; i < n_items; i += NT) {
+      const int s = s_pair[gl] & 255;
+      const int stock = s_it[3 * i], Dw = s_it[3 * i + 1], sales = s_it[3 * i + 2];
+      const int D = Dw & 0x3fffffff;
+      const int missed = (s_cptr[s + 1] > s_cptr[s]) ? D - sales : 0;
+      float ob[3];
+      // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
+      shop_obs_f32(stock, sales, missed, (float)s_norm[s], ob);
+      float* of = (float*)s_it + 3 * i;
+      of[0] = ob[0]; of[1] = ob[1]; of[2] = ob[2];
+      s_rew[i] = (float)shop_reward(sales, stock);
+      s_trunc[i] = (uint8_t)((Dw >> 30) & 1);                      // set by phase 2 at episode end
+      gl += rG;
+      if (gl >= G) gl -= G;
+    }
+    lds_barrier();
+    // ---- phase 3b: tiles -> HBM ---------------------------------------------------------------------
+    const int64_t row0 = (int64_t)t0 * total + g_base;           // element offset of tile row 0
+    const int64_t rstride = total;
+    if (wide4) {
+      const int nco = (G * 3) >> 2, ncf = G >> 2;                 // 16-byte chunks per row
+      for (int idx = tid; idx < tc * nco; idx += NT) {
+        const int r = (G == Gfull) ? (int)__umulhi((uint32_t)idx, a.mO) : idx / nco;
+        const int c = idx - r * nco;
+        *(uint4*)(io.obs + (row0 + (int64_t)r * rstride) * 3 + c * 4) = *(const uint4*)(s_it + r * G * 3 + c * 4);
+      }
+      for (int idx = tid; idx < tc * ncf; idx += NT) {
+        const int r = (G == Gfull) ? (int)__umulhi((uint32_t)idx, a.mF) : idx / ncf;
+        const int c = idx - r * ncf;
+        const int64_t o = row0 + (int64_t)r * rstride + c * 4;
+        *(uint4*)(io.reward + o) = *(const uint4*)(s_rew + r * G + c * 4);
+        *(uint4*)(io.action_out + o) = *(const uint4*)(s_act + r * G + c * 4);
+      }
+    } else {
+      for (int i = tid; i < n_items * 3; i += NT) {
+        const int r = i / (G * 3), c = i - r * G * 3;
+        io.obs[(row0 + (int64_t)r * rstride) * 3 + c] = ((const float*)s_it)[i];
+      }
+      for (int i = tid; i < n_items; i += NT) {
+        const int r = i / G, c = i - r * G;
+        const int64_t o = row0 + (int64_t)r * rstride + c;
+        io.reward[o] = s_rew[i]; io.action_out[o] = s_act[i];
+      }
+    }
+    if (wide8) {
+      const int ncu = G >> 3;                                     // 8-byte chunks per row
+      for (int idx = tid; idx < tc * ncu; idx += NT) {
+        const int r = (G == Gfull) ? (int)__umulhi((uint32_t)idx, a.mU) : idx / ncu;
+        const int c = idx - r * ncu;
+        const int64_t o = row0 + (int64_t)r * rstride + c * 8;
+        *(uint2*)(io.truncated + o) = *(const uint2*)(s_trunc + r * G + c * 8);
+        *(uint2*)(io.terminated + o) = make_uint2(0u, 0u);
+      }
+    } else {
+      for (int i = tid; i < n_items; i += NT) {
+        const int r = i / G, c = i - r * G;
+        const int64_t o = row0 + (int64_t)r * rstride + c;
+        io.truncated[o] = s_trunc[i]; io.terminated[o] = 0;
+      }
+    }
+    lds_barrier();
   }
   if (tid < G) {
     const int64_t g = g_base + tid;
@@ -366,9 +445,9 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
       shop_obs(st.stock, st.sales, st.missed, a.shop_norm[s], ob);
       io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
     }
-    if (s == 0) {       // every read of env_step / env_tick above is behind a barrier
+    if (s == 0) {       // env_step / env_tick were read (into LDS / registers) before the first barrier
       a.env_step[b] = step;
-      a.env_tick[b] = a.env_tick[b] + a.T;
+      a.env_tick[b] = s_tick0[tid / nS] + a.T;
     }
   }
 }
@@ -401,12 +480,24 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
   a.io = io;
-  int epb = 64 / sp.S; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B;
+  // whole envs per block: a multiple of 4 (8 when possible) so that G = epb * S makes every tile
+  // row a 16-byte multiple; G around 64..128 pairs; B = 4096, S = 9 -> epb 8, G 72, 512 blocks
+  int epb = 0;
+  for (int cand = 8; cand * sp.S <= 256 && cand <= sp.B; cand += 8) if (cand * sp.S >= 64) { epb = cand; break; }
+  if (!epb) for (int cand = 4; cand * sp.S <= 256 && cand <= sp.B; cand += 4) if (cand * sp.S >= 64) { epb = cand; break; }
+  if (!epb) { epb = 256 / sp.S; if (epb > 8) epb &= ~7; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B; }
   const int G = epb * sp.S;
-  int TC = (36 * 1024) / (G * 12); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;
+  auto magic = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
+  static const int ldskb = getenv("PHX_ROLLOUT_LDSKB") ? atoi(getenv("PHX_ROLLOUT_LDSKB")) : 40;
+  int TC = (ldskb * 1024) / (G * 21); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;
+  while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
+  a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 8);
+  const int items = TC * G;
+  const size_t lds = (size_t)((items * 3 + 3) & ~3) * 4 + (size_t)((items + 3) & ~3) * 8 + (size_t)((items + 15) & ~15) +
+                     (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 8 + (size_t)((sp.S + 4) & ~3) * 4 +
+                     (size_t)((sp.S + 3) & ~3) * 4 + 64;
   a.epb = epb; a.TC = TC;
-  const size_t lds = (size_t)G * TC * 12;
-  static const int nt = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 1024;
+  static const int nt = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 512;
   const dim3 grid((sp.B + epb - 1) / epb);
   if (nt == 256) hipLaunchKernelGGL((phx_sc_rollout_kernel<256>), grid, dim3(256), lds, st, a);
   else if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_kernel<512>), grid, dim3(512), lds, st, a);
