@@ -18,6 +18,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hip
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -45,7 +46,7 @@ struct Derived {
   std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
-  bool sc_static = false;
+  bool sc_static = false, stk_static = false;
   std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
   std::vector<uint8_t> shop_cust_act;
   int max_cust = 0;
@@ -143,6 +144,19 @@ static int derive(const phx_spec* sp, Derived& d) {
     else if (k != PHX_KIND_FACTORY) sc = false;
   }
   d.sc_static = sc;
+  // ---- static Stackelberg-market schedule? (fused kernel) ----------------------------------------
+  bool stk = sp->env_type == PHX_ENV_STACKELBERG && d.kind_count[PHX_KIND_SELLER] > 0 &&
+             !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS)) && sp->trace_cap == 0 &&
+             (sp->round_limit < 0 || sp->round_limit >= 1);
+  for (int a = 0; a < A && stk; ++a) {
+    const int k = sp->kind[a];
+    if (k != PHX_KIND_SELLER && k != PHX_KIND_BUYER) { stk = false; break; }
+    for (int e = sp->row_ptr[a]; e < sp->row_ptr[a + 1] && stk; ++e) {
+      const int v = sp->col[e];                    // bipartite, symmetric adjacency
+      stk = sp->kind[v] == (k == PHX_KIND_SELLER ? PHX_KIND_BUYER : PHX_KIND_SELLER) && edge(v, a);
+    }
+  }
+  d.stk_static = stk;
   if (d.kind_count[PHX_KIND_SHOP] > 0) {
     const int nS = d.kind_count[PHX_KIND_SHOP];
     d.shop_agent.assign(nS, 0); d.shop_norm.assign(nS, 1);
@@ -225,7 +239,7 @@ struct phx_env {
   std::vector<FieldDef> fields;
   std::vector<void*> dev_allocs;
   int device = 0;
-  bool use_fused = false, lds_ok = true;
+  bool use_fused = false, use_stk = false, lds_ok = true;
   DevMsg* inject_dev = nullptr;
   DevMsg inject_host[PHX_MAX_INJECT];
   int n_inject = 0;
@@ -302,6 +316,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.ws_stride = ws_stride;
   e->lds_ok = ws_stride == 0;
   e->use_fused = der.sc_static;
+  e->use_stk = der.stk_static;
   he = hipMalloc((void**)&e->inject_dev, sizeof(DevMsg) * PHX_MAX_INJECT);
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMalloc: %s", hipGetErrorString(he)); }
   // constructor state: zero blob, then Agent.reset() for every agent (env.py:122-124)
@@ -338,7 +353,7 @@ int phx_field_info(const phx_env* e, int index, phx_field* out) {
   return PHX_OK;
 }
 
-int phx_uses_fused(const phx_env* e) { return e && e->use_fused ? 1 : 0; }
+int phx_uses_fused(const phx_env* e) { return e && (e->use_fused || e->use_stk) ? 1 : 0; }
 
 int phx_reset(phx_env* e, const uint8_t* reset_mask, float* obs, uint8_t* obs_valid, void* stream) {
   if (!e) return fail(PHX_EINVAL, "null env");
@@ -369,6 +384,10 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (e->use_fused && e->n_inject == 0) {
     HIPCHK(phx_launch_sc_step(e->d, *io, st));
+    return PHX_OK;
+  }
+  if (e->use_stk && e->n_inject == 0) {
+    HIPCHK(phx_launch_stk_step(e->d, *io, st));
     return PHX_OK;
   }
   GenArgs g; g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0;

@@ -1,0 +1,89 @@
+// phx_epilogue.h -- the tail of PhantomEnv.step shared by the generic engine and the fused
+// Stackelberg kernel: per strategic agent obs / reward / done with the PLAIN, FSM or Stackelberg
+// masks and reward-cache semantics, __all__ flags, clock/stage update.
+//   env.py:273-301 ; fsm.py:309-380 ; stackelberg.py:142-196
+#pragma once
+#include "phx_dev.h"
+
+// One workgroup per env.  `live` = agent has a context this step (NULL: every agent is live).
+// s_nterm / s_ntrunc: zero-initialised LDS counters.  Contains a __syncthreads().
+template <int NT>
+__device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const phx_step_io& io, int b, int t,
+                                                   int list, int cur_stage, uint32_t tick,
+                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc) {
+  const int tid = threadIdx.x;
+  const int A = sp.A, S = sp.S, D = sp.D;
+  uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
+  uint8_t* trunc = fld<uint8_t>(sp, F_ENV_TRUNC) + (int64_t)b * S;
+  const int next_stage = (sp.env_type == PHX_ENV_FSM) ? sp.stage_next[cur_stage] : 0;
+  const uint8_t* obs_mask = sp.obs_mask + (int64_t)list * A;
+  const uint8_t* rew_mask = sp.rew_mask + (int64_t)list * A;
+  float* obs_b = io.obs + (int64_t)b * S * D;
+  double* rew_cache = fld<double>(sp, F_ENV_REW_CACHE) + (int64_t)b * S;
+  uint8_t* rew_cache_v = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + (int64_t)b * S;
+  float* obs_cache = fld<float>(sp, F_ENV_OBS_CACHE) + (int64_t)b * S * D;
+  uint8_t* obs_cache_v = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + (int64_t)b * S;
+
+  for (int s = tid; s < S; s += NT) {                          // env.py:273 / fsm.py:320 / stackelberg.py:150
+    const int a = sp.strat_idx[s];
+    const int64_t o = (int64_t)b * S + s;
+    uint8_t ov = 0, rv = 0, dv = 0, tm = 0, tr = 0;
+    double rw = 0.0;
+    float ob[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!live || live[a]) {                                    // env.py:274-275
+      dv = 1;
+      if (obs_mask[a]) { dev_encode_obs(sp, b, a, t, ob); ov = 1; }
+      if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, b, a); rv = 1; }
+      else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, b, a); rew_cache_v[s] = 1; }
+      tm = tr = dev_is_done(sp, a, t) ? 1 : 0;                 // env.py:285-286
+      if (tm) { term[s] = 1; trunc[s] = 1; }                   // :288-292
+    }
+    if (term[s]) atomicAdd(s_nterm, 1);
+    if (trunc[s]) atomicAdd(s_ntrunc, 1);
+    if (sp.env_type == PHX_ENV_FSM && ov) {                    // self._observations.update, fsm.py:349
+      for (int d = 0; d < D; ++d) obs_cache[s * D + d] = ob[d];
+      obs_cache_v[s] = 1;
+    }
+    for (int d = 0; d < D; ++d) obs_b[s * D + d] = ob[d];
+    io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = dv;
+    io.terminated[o] = tm; io.truncated[o] = tr; io.reward[o] = rw;
+  }
+  __syncthreads();
+  const bool all_term = *s_nterm == S;                                        // env.py:308-310
+  const bool all_trunc = (t == sp.num_steps) || *s_ntrunc == S;              // env.py:312-318
+  const bool terminal = all_term || all_trunc;
+  if (sp.env_type != PHX_ENV_PLAIN) {
+    for (int s = tid; s < S; s += NT) {
+      const int64_t o = (int64_t)b * S + s;
+      const bool observed = io.obs_valid[o] != 0;
+      if (sp.env_type == PHX_ENV_FSM) {
+        if (terminal) {                                        // fsm.py:360-375: cached dicts of all agents
+          const uint8_t v = obs_cache_v[s];
+          io.obs_valid[o] = v;
+          for (int d = 0; d < D; ++d) obs_b[s * D + d] = v ? obs_cache[s * D + d] : 0.f;
+          io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
+          io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+        } else if (observed) {                                 // fsm.py:378
+          io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
+          io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+        }
+      } else {
+        if (terminal) {                                        // stackelberg.py:180-187
+          io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
+          io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+        } else if (observed && rew_cache_v[s]) {               // stackelberg.py:190-194
+          io.reward_valid[o] = 1; io.reward[o] = rew_cache[s];
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = t;
+    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
+    if (sp.env_type == PHX_ENV_FSM) {                          // fsm.py:355
+      fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = cur_stage;
+      fld<int32_t>(sp, F_ENV_STAGE)[b] = next_stage;
+    }
+    io.all_terminated[b] = all_term; io.all_truncated[b] = all_trunc;
+  }
+}

@@ -21,6 +21,7 @@
 // Queues live in LDS (template LDSQ = true); envs whose queue does not fit use a per-env
 // workspace carved from the caller's state blob.
 #include "phx_dev.h"
+#include "phx_epilogue.h"
 
 #define ERRKEY_NONE 0x7fffffff
 
@@ -234,11 +235,12 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, int b, int a, 
 template <int NT, bool LDSQ>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, const GenArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+
   __shared__ int wave_sums[NT / 64];
   __shared__ int s_errkey, s_nterm, s_ntrunc;
 
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int A = sp.A, S = sp.S, D = sp.D, Q = sp.queue_cap;
+  const int A = sp.A, S = sp.S, Q = sp.queue_cap;
 
   char* mem = LDSQ ? smem : ((char*)sp.f[F_WORKSPACE] + (int64_t)b * sp.ws_stride);
   DevMsg* q0 = (DevMsg*)mem;
@@ -387,7 +389,9 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
         const DevMsg m = qc[seg[k]];
         // dropped: receiver not in contexts (resolvers.py:143-144), edge filter (:146-148),
         // or a send that already failed its checks (type 0)
-        if (live[a] && m.type != 0 && dev_has_edge(sp, m.src, m.dst)) {
+        // the receive-side edge filter can only drop something when sends skipped the edge
+        // check (ignore_connection_errors): every queued message already passed has_edge
+        if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, m.src, m.dst))) {
           int code = 0;
           const bool answered = handle_message(sp, b, a, m, clock + P, out, code);
           if (code) set_errkey(&s_errkey, seq_base + P, code);
@@ -426,77 +430,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   }
   if (g.resolve_only) return;
 
-  // ---- per strategic agent: obs / reward / done (env.py:273-292, fsm.py:320-345, stackelberg.py:150-171)
-  const int next_stage = (sp.env_type == PHX_ENV_FSM) ? sp.stage_next[cur_stage] : 0;
-  const uint8_t* obs_mask = sp.obs_mask + (int64_t)list * A;
-  const uint8_t* rew_mask = sp.rew_mask + (int64_t)list * A;
-  float* obs_b = g.io.obs + (int64_t)b * S * D;
-  double* rew_cache = fld<double>(sp, F_ENV_REW_CACHE) + (int64_t)b * S;
-  uint8_t* rew_cache_v = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + (int64_t)b * S;
-  float* obs_cache = fld<float>(sp, F_ENV_OBS_CACHE) + (int64_t)b * S * D;
-  uint8_t* obs_cache_v = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + (int64_t)b * S;
-
-  for (int s = tid; s < S; s += NT) {
-    const int a = sp.strat_idx[s];
-    const int64_t o = (int64_t)b * S + s;
-    uint8_t ov = 0, rv = 0, dv = 0, tm = 0, tr = 0;
-    double rw = 0.0;
-    float ob[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live[a]) {                                             // env.py:274-275
-      dv = 1;
-      if (obs_mask[a]) { dev_encode_obs(sp, b, a, t, ob); ov = 1; }
-      if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, b, a); rv = 1; }
-      else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, b, a); rew_cache_v[s] = 1; }
-      tm = tr = dev_is_done(sp, a, t) ? 1 : 0;                 // env.py:285-286
-      if (tm) { term[s] = 1; trunc[s] = 1; }                   // :288-292
-    }
-    if (term[s]) atomicAdd(&s_nterm, 1);
-    if (trunc[s]) atomicAdd(&s_ntrunc, 1);
-    if (sp.env_type == PHX_ENV_FSM && ov) {                    // self._observations.update, fsm.py:349
-      for (int d = 0; d < D; ++d) obs_cache[s * D + d] = ob[d];
-      obs_cache_v[s] = 1;
-    }
-    for (int d = 0; d < D; ++d) obs_b[s * D + d] = ob[d];
-    g.io.obs_valid[o] = ov; g.io.reward_valid[o] = rv; g.io.done_valid[o] = dv;
-    g.io.terminated[o] = tm; g.io.truncated[o] = tr; g.io.reward[o] = rw;
-  }
-  __syncthreads();
-  const bool all_term = s_nterm == S;                                         // env.py:308-310
-  const bool all_trunc = (t == sp.num_steps) || s_ntrunc == S;               // env.py:312-318
-  const bool terminal = all_term || all_trunc;
-  if (sp.env_type != PHX_ENV_PLAIN) {
-    for (int s = tid; s < S; s += NT) {
-      const int64_t o = (int64_t)b * S + s;
-      const bool observed = g.io.obs_valid[o] != 0;
-      if (sp.env_type == PHX_ENV_FSM) {
-        if (terminal) {                                        // fsm.py:360-375: cached dicts of all agents
-          const uint8_t v = obs_cache_v[s];
-          g.io.obs_valid[o] = v;
-          for (int d = 0; d < D; ++d) obs_b[s * D + d] = v ? obs_cache[s * D + d] : 0.f;
-          g.io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
-          g.io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
-        } else if (observed) {                                 // fsm.py:378
-          g.io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
-          g.io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
-        }
-      } else {
-        if (terminal) {                                        // stackelberg.py:180-187
-          g.io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
-          g.io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
-        } else if (observed && rew_cache_v[s]) {               // stackelberg.py:190-194
-          g.io.reward_valid[o] = 1; g.io.reward[o] = rew_cache[s];
-        }
-      }
-    }
-  }
-  if (tid == 0) {
-    *step_p = t;
-    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
-    if (sp.env_type == PHX_ENV_FSM) {                          // fsm.py:355
-      fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = cur_stage; *stage_p = next_stage;
-    }
-    g.io.all_terminated[b] = all_term; g.io.all_truncated[b] = all_trunc;
-  }
+  strategic_epilogue<NT>(sp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc);
 }
 
 // ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------

@@ -57,6 +57,80 @@ def test_generic_engine_market_matches_reference(name):
     replay_market(golden(name), _dev)
 
 
+@pytest.mark.parametrize("name", ["stk_small", "stk_full"])
+def test_fused_market_kernel_matches_reference(name):
+    def make(spec):
+        r = _dev(spec)
+        assert r.dev.uses_fused
+        return r
+    replay_market(golden(name), make, tracking=False)
+
+
+def test_fused_market_random_differential_vs_oracle():
+    """Stackelberg market 16 sellers x 96 buyers, B=48, 45 steps over 20-step episodes:
+    fused kernel and generic engine against the oracle, ties between sellers included."""
+    rng = np.random.RandomState(21)
+    L, Fw, d, B, T = 16, 96, 4, 48, 45
+    S = L + Fw
+    envs = [market_env(L, Fw, d, 20, B, force_generic=fg) for fg in (False, True)]
+    o = OracleEnv(envs[0].spec)
+    devs = [_dev(e.spec) for e in envs]
+    assert devs[0].dev.uses_fused and not devs[1].dev.uses_fused
+    o.reset(); [x.reset() for x in devs]
+    for t in range(T):
+        step = o.get_i32("env.step")[:, 0] + 1
+        act = np.zeros((B, S), np.float32); valid = np.zeros((B, S), np.uint8)
+        odd = (step % 2 == 1)
+        act[:, :L] = rng.randint(1, 9, size=(B, L)) / 8.0
+        act[:, L:] = (rng.rand(B, Fw) < 0.7)
+        valid[odd, :L] = 1; valid[~odd, L:] = 1
+        valid &= (rng.rand(B, S) < 0.95).astype(np.uint8)          # some agents get no action
+        o.step(act, valid, None)
+        for x in devs:
+            x.step(act, valid, None)
+            for f in ("obs_valid", "reward_valid", "done_valid", "all_truncated", "all_terminated", "err"):
+                np.testing.assert_array_equal(getattr(x, f), getattr(o, f), err_msg=f"{f} t={t}")
+            np.testing.assert_array_equal(f32_bits(x.obs), f32_bits(o.obs), err_msg=f"obs t={t}")
+            np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward), err_msg=f"rew t={t}")
+            for f in ("seller.tx", "buyer.bought"):
+                np.testing.assert_array_equal(x.get_i32(f), o.get_i32(f), err_msg=f)
+            for f in ("seller.price", "seller.revenue", "buyer.paid", "buyer.prices"):
+                np.testing.assert_array_equal(f64_bits(x.get_f64(f)), f64_bits(o.get_f64(f)), err_msg=f)
+        done = o.all_truncated.astype(np.uint8)
+        if done.any():
+            oo, ov = o.reset(done)
+            for x in devs:
+                do, dv = x.reset(done)
+                np.testing.assert_array_equal(dv[done > 0], ov[done > 0])
+                np.testing.assert_array_equal(f32_bits(do[done > 0]), f32_bits(oo[done > 0]))
+
+
+def test_full_size_market_fused_equals_generic():
+    """BASELINE config 5 size (128 leaders / 1024 followers), B=256: fused == generic engine, plus
+    conservation: every Order is booked by exactly one seller."""
+    rng = np.random.RandomState(4)
+    L, Fw, d, B = 128, 1024, 8, 256
+    S = L + Fw
+    f, g = (_dev(market_env(L, Fw, d, 100, B, force_generic=fg).spec) for fg in (False, True))
+    assert f.dev.uses_fused and not g.dev.uses_fused
+    f.reset(); g.reset()
+    for t in range(6):
+        act = np.zeros((B, S), np.float32); valid = np.zeros((B, S), np.uint8)
+        if t % 2 == 0:
+            act[:, :L] = rng.randint(1, 17, size=(B, L)) / 16.0; valid[:, :L] = 1
+        else:
+            act[:, L:] = (rng.rand(B, Fw) < 0.6); valid[:, L:] = 1
+        f.step(act, valid, None); g.step(act, valid, None)
+        np.testing.assert_array_equal(f32_bits(f.obs), f32_bits(g.obs))
+        np.testing.assert_array_equal(f64_bits(f.reward), f64_bits(g.reward))
+        np.testing.assert_array_equal(f.reward_valid, g.reward_valid)
+        np.testing.assert_array_equal(f.get_i32("seller.tx"), g.get_i32("seller.tx"))
+        np.testing.assert_array_equal(f64_bits(f.get_f64("seller.revenue")), f64_bits(g.get_f64("seller.revenue")))
+        if t % 2 == 1:
+            np.testing.assert_array_equal(f.get_i32("seller.tx").sum(1), f.get_i32("buyer.bought").sum(1))
+    assert (f.err == 0).all() and (g.err == 0).all()
+
+
 def _compare_step(o, d, t):
     for f in ("obs_valid", "reward_valid", "done_valid", "terminated", "truncated", "all_terminated",
               "all_truncated", "err"):
