@@ -186,32 +186,35 @@ void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-/* np.random.randint(5) draws 3 random bits and rejects values > 4 (masked rejection,
- * SURVEY Appendix B).  The device stream keeps that mapping over Philox words.  One block
- * ctr = (env_lo, env_hi, tick, shop | blk<<20) serves one shop for one step: words 0..2 give
- * 30 3-bit fields, consumed in order by the shop's K customers (accepted fields only; further
- * blocks blk = 1, 2, ... when 30 fields do not yield K accepted ones); word 3 of block 0 is
- * the shop's random-policy action.                                                        */
-void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out) {
+/* Device-RNG definition (build-owned; replaces the global numpy stream when exo == NULL).
+ * np.random.randint(5) is exactly uniform on {0..4} (numpy draws 3 bits and rejects > 4).  The
+ * device stream is exactly uniform too, by rejection on 16-bit fields: customer k of a shop owns
+ * field j = k % 6 (the six 16-bit halves of words 0..2, low half first) of Philox block
+ *     ctr = (env_lo, env_hi | attempt << 16, tick, shop | (k / 6) << 20),  key = seed;
+ * a field value u is rejected iff u == 65535 (65535 = 5 * 13107 values remain), the order size
+ * is u % 5, and a rejected customer redraws the same field of the block with attempt + 1.
+ * Word 3 of block (k / 6 = 0, attempt 0) gives the shop's random-policy action.            */
+static uint32_t rng_field(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk, int j,
+                          uint32_t attempt, uint32_t* w3) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  int got = 0;
-  for (uint32_t blk = 0; got < K; ++blk) {
-    uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
-                       (uint32_t)shop | (blk << 20)};
-    uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
-    for (int j = 0; j < 3 && got < K; ++j)
-      for (int f = 0; f < 10 && got < K; ++f) {
-        uint32_t v = (w[j] >> (3 * f)) & 7u;
-        if (v <= 4u) out[got++] = (uint8_t)v;
-      }
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick,
+                     (uint32_t)shop | ((uint32_t)blk << 20)};
+  uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
+  if (w3) *w3 = w[3];
+  return (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+}
+void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out) {
+  for (int k = 0; k < K; ++k) {
+    uint32_t u, attempt = 0;
+    do { u = rng_field(seed, genv, tick, shop, k / 6, k % 6, attempt++, NULL); } while (u == 65535u);
+    out[k] = (uint8_t)(u % 5u);
   }
 }
 /* random policy of the rollout: U[0,100) from the top 24 bits of word 3 of the shop's block 0 */
 float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int shop) {
-  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick, (uint32_t)shop};
-  uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
-  return (float)(w[3] >> 8) * (100.0f / 16777216.0f);
+  uint32_t w3;
+  rng_field(seed, genv, tick, shop, 0, 0, 0, &w3);
+  return (float)(w3 >> 8) * (100.0f / 16777216.0f);
 }
 
 /* ---- per-kind agent behaviour --------------------------------------------------------- */

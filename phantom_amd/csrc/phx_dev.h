@@ -143,66 +143,64 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Device RNG, one Philox block per (env, tick, shop, blk): words 0..2 carry 30 3-bit fields that
-// the shop's K customers consume in order, values > 4 rejected (numpy's masked rejection for
-// randint(5)); blk = 1, 2, ... only when 30 fields do not yield K accepted ones; word 3 of block
-// 0 is the shop's random-policy action.  Returns the sum over the customers selected by
-// `actmask` (NULL = all) or, with kth >= 0, only customer kth's draw; *act_word = word 3.
+// Device RNG (definition restated in oracle/phx_oracle.c and DESIGN.md).  Exactly uniform order
+// sizes by rejection on 16-bit fields: customer k of a shop owns field j = k % 6 (the six 16-bit
+// halves of words 0..2, low half first) of Philox block
+//     ctr = (env_lo, env_hi | attempt << 16, tick, shop | (k / 6) << 20), key = seed;
+// u == 65535 is rejected (65535 = 5 * 13107 values remain), the order is u % 5, a rejected
+// customer redraws the same field with attempt + 1.  Word 3 of block (0, attempt 0) is the
+// shop's random-policy action.
+__device__ __forceinline__ void rng_block(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk,
+                                          uint32_t attempt, uint32_t w[4]) {
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick,
+                (uint32_t)shop | ((uint32_t)blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+}
+__device__ __forceinline__ uint32_t rng_mod5(uint32_t u) {          // u < 65536
+  // 24-bit multiplies are full rate; keep every product below 2^31 (HIP's __umul24 is not
+  // reliable above that).  13108 = ceil(2^16 / 5) over-estimates u / 5 by at most 1.
+  const int q = (int)(__umul24(u, 13108u) >> 16);
+  int r = (int)u - q * 5;
+  r = r < 0 ? r + 5 : r;
+  return (uint32_t)r;
+}
+// one customer's draw (generic engine; also the redraw path)
+__device__ __forceinline__ int rng_customer_order(uint64_t seed, int64_t genv, uint32_t tick, int shop, int k,
+                                               uint32_t attempt0) {
+  const int blk = k / 6, j = k - blk * 6;
+  for (uint32_t attempt = attempt0;; ++attempt) {
+    uint32_t w[4];
+    rng_block(seed, genv, tick, shop, blk, attempt, w);
+    const uint32_t wj = j < 2 ? w[0] : (j < 4 ? w[1] : w[2]);
+    const uint32_t u = (wj >> (16 * (j & 1))) & 0xffffu;
+    if (u != 65535u) return (int)rng_mod5(u);
+  }
+}
+// Sum over the shop's K customers (those selected by `actmask`, NULL = all), or with kth >= 0 only
+// customer kth's draw; *act_word = word 3 of block 0.
 __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                int K, const uint8_t* actmask, int kth,
                                                uint32_t* act_word = nullptr) {
-  int got = 0, sum = 0;
-  uint32_t blk = 0;
-  do {
+  if (kth >= 0) return rng_customer_order(seed, genv, tick, shop, kth, 0);
+  int sum = 0;
+  for (int k0 = 0; k0 < K || (k0 == 0 && act_word); k0 += 6) {
     uint32_t w[4];
-    philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
-                  (uint32_t)shop | (blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    if (blk == 0 && act_word) *act_word = w[3];
-    for (int j = 0; j < 3 && got < K; ++j) {
-      uint32_t x = w[j];
+    rng_block(seed, genv, tick, shop, k0 / 6, 0, w);
+    if (k0 == 0 && act_word) *act_word = w[3];
 #pragma unroll
-      for (int f = 0; f < 10; ++f) {
-        const uint32_t v = x & 7u; x >>= 3;
-        if (v <= 4u && got < K) {
-          const bool use = kth >= 0 ? (got == kth) : (actmask == nullptr || actmask[got] != 0);
-          sum += use ? (int)v : 0;
-          ++got;
-        }
+    for (int j = 0; j < 6; ++j) {
+      const int k = k0 + j;
+      if (k < K && (actmask == nullptr || actmask[k] != 0)) {
+        const uint32_t u = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        sum += (u != 65535u) ? (int)rng_mod5(u) : rng_customer_order(seed, genv, tick, shop, k, 1);
       }
     }
-    ++blk;
-  } while (got < K);
+  }
   return sum;
 }
-
-// Same definition, all K customers, sum only -- the fused kernels' fast path.  The ten 3-bit
-// fields of a word are handled at once: acc gets bit 3f set where field f <= 4, the surplus
-// (highest) accepted fields beyond the shop's remaining need are cleared, and the field values
-// are summed bit-plane by bit-plane with popcounts.
+// all K customers, sum only: the fused kernels' fast path (same definition)
 __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                   int K, uint32_t* act_word) {
-  int need = K, sum = 0;
-  uint32_t blk = 0;
-  do {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
-                  (uint32_t)shop | (blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    if (blk == 0 && act_word) *act_word = w[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (need > 0) {
-        const uint32_t x = w[j];
-        uint32_t acc = ~((x >> 2) & ((x >> 1) | x)) & 0x09249249u;
-        int pc = __popc(acc);
-        while (pc > need) { acc &= ~(0x80000000u >> __clz(acc)); --pc; }
-        const uint32_t xm = x & (acc * 7u);
-        sum += __popc(xm & 0x09249249u) + 2 * __popc(xm & 0x12492492u) + 4 * __popc(xm & 0x24924924u);
-        need -= pc;
-      }
-    }
-    ++blk;
-  } while (need > 0);
-  return sum;
+  return rng_shop_orders(seed, genv, tick, shop, K, nullptr, -1, act_word);
 }
 
 __device__ __forceinline__ float rng_word_to_action(uint32_t w3) {

@@ -278,16 +278,19 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int NT>
+// REPLAY: actions and/or exogenous draws come from HBM (parity / replay); false = pure device RNG.
+// WIDE:   every block owns exactly epb envs and every tile row is 16-byte aligned (host-checked),
+//         so the copy-out uses dwordx4 / dwordx2 stores and magic-number row arithmetic only.
+template <int NT, bool REPLAY, bool WIDE>
 __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const phx_rollout_io& io = a.io;
   const int nS = a.S, tid = threadIdx.x, TC = a.TC;
   const int64_t total = (int64_t)a.B * nS;
   const int64_t b_first = (int64_t)blockIdx.x * a.epb;
-  const int64_t b_end = (b_first + a.epb < a.B) ? b_first + a.epb : a.B;
+  const int64_t b_end = (WIDE || b_first + a.epb < a.B) ? b_first + a.epb : a.B;
   const int nb = (int)(b_end - b_first);
-  const int G = nb * nS, Gfull = a.epb * nS;
+  const int Gfull = a.epb * nS, G = WIDE ? Gfull : nb * nS;
   const int64_t g_base = b_first * nS;
 
   // LDS carve (all offsets multiples of 16 bytes)
@@ -318,8 +321,6 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
     p2_K = a.shop_cust_ptr[s2 + 1] - a.shop_cust_ptr[s2];
   }
   // full-width copy-out needs every tile row to start and end on a 16-byte boundary
-  const bool wide4 = ((G & 3) == 0) && ((g_base & 3) == 0) && ((total & 3) == 0);
-  const bool wide8 = ((G & 7) == 0) && ((g_base & 7) == 0) && ((total & 7) == 0);
   lds_barrier();
 
   for (int t0 = 0; t0 < a.T; t0 += TC) {
@@ -336,14 +337,14 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
       const uint32_t tick = (uint32_t)s_tick0[bl] + (uint32_t)t;
       const int c_lo = s_cptr[s], c_hi = s_cptr[s + 1];
       int D = 0; uint32_t w3 = 0;
-      if (io.exo) {
+      if (REPLAY && io.exo) {
         const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
         for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
         if (!io.actions) rng_shop_order_sum(a.seed, genv, tick, s, 0, &w3);
       } else {
         D = rng_shop_order_sum(a.seed, genv, tick, s, c_hi - c_lo, &w3);
       }
-      const float action = io.actions ? io.actions[(int64_t)t * total + g_base + gl] : rng_word_to_action(w3);
+      const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl] : rng_word_to_action(w3);
       s_act[i] = action;
       s_it[3 * i + 0] = dev_round_half_even(action);
       s_it[3 * i + 1] = D;
@@ -393,15 +394,15 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
     // ---- phase 3b: tiles -> HBM ---------------------------------------------------------------------
     const int64_t row0 = (int64_t)t0 * total + g_base;           // element offset of tile row 0
     const int64_t rstride = total;
-    if (wide4) {
+    if (WIDE) {
       const int nco = (G * 3) >> 2, ncf = G >> 2;                 // 16-byte chunks per row
       for (int idx = tid; idx < tc * nco; idx += NT) {
-        const int r = (G == Gfull) ? (int)__umulhi((uint32_t)idx, a.mO) : idx / nco;
+        const int r = (int)__umulhi((uint32_t)idx, a.mO);
         const int c = idx - r * nco;
         *(uint4*)(io.obs + (row0 + (int64_t)r * rstride) * 3 + c * 4) = *(const uint4*)(s_it + r * G * 3 + c * 4);
       }
       for (int idx = tid; idx < tc * ncf; idx += NT) {
-        const int r = (G == Gfull) ? (int)__umulhi((uint32_t)idx, a.mF) : idx / ncf;
+        const int r = (int)__umulhi((uint32_t)idx, a.mF);
         const int c = idx - r * ncf;
         const int64_t o = row0 + (int64_t)r * rstride + c * 4;
         *(uint4*)(io.reward + o) = *(const uint4*)(s_rew + r * G + c * 4);
@@ -418,10 +419,10 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
         io.reward[o] = s_rew[i]; io.action_out[o] = s_act[i];
       }
     }
-    if (wide8) {
+    if (WIDE) {
       const int ncu = G >> 3;                                     // 8-byte chunks per row
       for (int idx = tid; idx < tc * ncu; idx += NT) {
-        const int r = (G == Gfull) ? (int)__umulhi((uint32_t)idx, a.mU) : idx / ncu;
+        const int r = (int)__umulhi((uint32_t)idx, a.mU);
         const int c = idx - r * ncu;
         const int64_t o = row0 + (int64_t)r * rstride + c * 8;
         *(uint2*)(io.truncated + o) = *(const uint2*)(s_trunc + r * G + c * 8);
@@ -497,10 +498,13 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
                      (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 8 + (size_t)((sp.S + 4) & ~3) * 4 +
                      (size_t)((sp.S + 3) & ~3) * 4 + 64;
   a.epb = epb; a.TC = TC;
-  static const int nt = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 512;
   const dim3 grid((sp.B + epb - 1) / epb);
-  if (nt == 256) hipLaunchKernelGGL((phx_sc_rollout_kernel<256>), grid, dim3(256), lds, st, a);
-  else if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_kernel<512>), grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((phx_sc_rollout_kernel<1024>), grid, dim3(1024), lds, st, a);
+  const bool replay = io.actions != nullptr || io.exo != nullptr;
+  const int64_t total = (int64_t)sp.B * sp.S;
+  const bool wide = (sp.B % epb == 0) && (G % 8 == 0) && (total % 8 == 0);
+  if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<512, false, true>), grid, dim3(512), lds, st, a);
+  else if (wide) hipLaunchKernelGGL((phx_sc_rollout_kernel<512, true, true>), grid, dim3(512), lds, st, a);
+  else if (!replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<512, false, false>), grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((phx_sc_rollout_kernel<512, true, false>), grid, dim3(512), lds, st, a);
   return hipGetLastError();
 }

@@ -65,3 +65,15 @@ def log_matrix(recs):
         v = raw.view("<f8")[0] if int(r["type"]) in _abi.FLOAT_PAYLOAD_TYPES else float(raw[0])
         out[k] = (r["sender"], r["receiver"], r["type"], v)
     return out
+
+
+def find_rng_rejection(seed=1, tick=0, shop=0, limit=400000):
+    """first global env index whose block (tick, shop, blk 0, attempt 0) has a rejected
+    (== 65535) 16-bit order field among its six: the rare redraw branch of the device RNG."""
+    from oracle import philox
+    for genv in range(limit):
+        w = philox([genv & 0xffffffff, genv >> 32, tick, shop], [seed & 0xffffffff, seed >> 32])
+        for j in range(6):
+            if (int(w[j >> 1]) >> (16 * (j & 1))) & 0xffff == 65535:
+                return genv, j
+    raise AssertionError("no rejection found")

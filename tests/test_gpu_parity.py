@@ -219,6 +219,40 @@ def test_rollout_matches_oracle(mode):
     _compare_step(o, d, -1)
 
 
+def test_rng_rejection_branch_on_device():
+    """the 1-in-65536 redraw branch of the device RNG: place the batch on a global env index
+    where block (tick 0, shop 0) holds a rejected field; fused, generic and rollout vs oracle."""
+    from helpers import find_rng_rejection
+    genv, j = find_rng_rejection(seed=1)
+    B = 8
+    for force_generic in (False, True):
+        env = supply_chain_env(2, [6, 6], 20, B, seed=1, env_offset=genv - 3, force_generic=force_generic)
+        o, d = OracleEnv(env.spec), _dev(env.spec)
+        o.reset(); d.reset()
+        a = np.full((B, 2), 50.0, np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+        _compare_step(o, d, 0)
+    env = supply_chain_env(2, [6, 6], 20, B, seed=1, env_offset=genv - 3)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    ro, rd = o.rollout(5), d.rollout(5)
+    np.testing.assert_array_equal(f32_bits(rd["obs"]), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(rd["rewards"]), f32_bits(ro["rewards"]))
+
+
+def test_full_size_rollout_matches_oracle():
+    """BASELINE configs[1] at full size: SC64, B=4096, one T=100 fragment, device RNG (22 M draws,
+    a few hundred of them through the redraw branch) -- bit-equal to the oracle."""
+    env = supply_chain_env(9, [6] * 9, 100, 4096, seed=42)
+    o, d = OracleEnv(env.spec, threads=8), _dev(env.spec)
+    o.reset(); d.reset()
+    ro, rd = o.rollout(100), d.rollout(100)
+    for k in ("obs", "actions", "rewards"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+    np.testing.assert_array_equal(d.get_i32("shop.stock"), o.get_i32("shop.stock"))
+
+
 def test_rng_fallback_block_is_exercised():
     """the masked-rejection draw needs a second Philox block for K > ~25 customers per shop:
     force that branch and compare with the oracle."""

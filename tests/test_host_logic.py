@@ -146,20 +146,35 @@ def test_philox_known_answers():
 
 
 def test_device_rng_definition():
-    """orders = accepted 3-bit fields (<= 4) of words 0..2; action = top 24 bits of word 3."""
+    """orders: customer k = 16-bit field k % 6 of block k // 6 (words 0..2), 65535 rejected, u % 5;
+    action = top 24 bits of word 3 of block 0."""
     seed, genv, tick, shop = 0x1234567890ABCDEF, 5_000_000_123, 77, 3
-    w = philox([genv & 0xffffffff, genv >> 32, tick, shop], [seed & 0xffffffff, seed >> 32])
-    fields = [(int(w[j]) >> (3 * f)) & 7 for j in range(3) for f in range(10)]
-    acc = [v for v in fields if v <= 4]
-    got = rng_orders(seed, genv, tick, shop, len(acc))
-    assert got.tolist() == acc
-    assert rng_action(seed, genv, tick, shop) == np.float32(int(w[3]) >> 8) * np.float32(100.0 / 16777216.0)
+
+    def block(blk, attempt=0):
+        return philox([genv & 0xffffffff, (genv >> 32) | (attempt << 16), tick, shop | (blk << 20)],
+                      [seed & 0xffffffff, seed >> 32])
+    K = 20
+    got = rng_orders(seed, genv, tick, shop, K)
+    for k in range(K):
+        w = block(k // 6)
+        u = (int(w[(k % 6) >> 1]) >> (16 * (k & 1 if (k % 6) % 2 == k % 2 else (k % 6) & 1))) & 0xffff
+        u = (int(w[(k % 6) >> 1]) >> (16 * ((k % 6) & 1))) & 0xffff
+        assert u != 65535 and got[k] == u % 5
+    w0 = block(0)
+    assert rng_action(seed, genv, tick, shop) == np.float32(int(w0[3]) >> 8) * np.float32(100.0 / 16777216.0)
     many = np.concatenate([rng_orders(1, b, t, 0, 6) for b in range(200) for t in range(20)])
     assert many.min() == 0 and many.max() == 4
     assert abs(np.bincount(many, minlength=5) / many.size - 0.2).max() < 0.01
-    # K large enough to need further blocks (blk = 1, 2, ...)
-    big = rng_orders(seed, genv, tick, shop, 100)
-    assert big[:len(acc)].tolist() == acc and big.max() <= 4
+
+
+def test_device_rng_rejection_branch():
+    """u == 65535 is rejected and the customer redraws the same field with attempt + 1."""
+    from helpers import find_rng_rejection
+    genv, j = find_rng_rejection(seed=1)
+    w1 = philox([genv & 0xffffffff, (genv >> 32) | (1 << 16), 0, 0], [1, 0])
+    u1 = (int(w1[j >> 1]) >> (16 * (j & 1))) & 0xffff
+    assert u1 != 65535
+    assert rng_orders(1, genv, 0, 0, 6)[j] == u1 % 5
 
 
 def test_f32_division_equals_reference_f64_quotient_cast():
