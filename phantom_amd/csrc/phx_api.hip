@@ -49,6 +49,8 @@ struct Derived {
   bool sc_static = false, stk_static = false;
   std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
   std::vector<uint8_t> shop_cust_act;
+  std::vector<float> sc_tab;
+  int n_tabn = 0, n_quot = 0, rew_smax = -1;
   int max_cust = 0;
 };
 
@@ -170,6 +172,23 @@ static int derive(const phx_spec* sp, Derived& d) {
       for (int a : cust[s]) { d.shop_cust_agent.push_back(a); d.shop_cust_exo.push_back(d.exo_rank[a]); }
       d.shop_cust_ptr.push_back((int)d.shop_cust_agent.size());
       d.max_cust = std::max(d.max_cust, (int)cust[s].size());
+    }
+    // lookup tables of the rollout kernel: the reference's own formulas evaluated on the host
+    //   obs   np.float32(x / n)            supply_chain.py:127-134
+    //   penalty 0.1*stock (f64)            supply_chain.py:147
+    bool uniform = true;
+    for (int s2 = 1; s2 < nS; ++s2) uniform = uniform && d.shop_norm[s2] == d.shop_norm[0];
+    const int n_quot = uniform ? std::min(4 * d.max_cust + 1, 512) : 0;   // valid x/norm entries
+    d.n_tabn = n_quot; d.n_quot = n_quot;
+    d.rew_smax = 0;                                             // penalty table present
+    for (int x = 0; x <= 100; ++x) d.sc_tab.push_back((float)((double)x / 100.0));
+    for (int x = 0; x < d.n_tabn; ++x) d.sc_tab.push_back((float)((double)x / (double)d.shop_norm[0]));
+    if ((d.sc_tab.size() & 1) != 0) d.sc_tab.push_back(0.f);    // 8-byte align the f64 part
+    d.n_tabn = (int)d.sc_tab.size() - 101;                       // padded length of the x/norm part
+    for (int st = 0; st <= 100; ++st) {                         // 0.1 * stock as f64, two floats each
+      volatile double pen = 0.1 * (double)st;
+      double pv = pen; float two[2]; memcpy(two, &pv, 8);
+      d.sc_tab.push_back(two[0]); d.sc_tab.push_back(two[1]);
     }
     d.shop_cust_act.assign((size_t)d.n_lists * std::max(d.n_exo, 1), 0);
     for (int l = 0; l < d.n_lists; ++l)
@@ -310,6 +329,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(shop_cust_exo, der.shop_cust_exo.data(), der.shop_cust_exo.size());
   UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());
   UP(shop_cust_act, der.shop_cust_act.data(), der.shop_cust_act.size());
+  UP(sc_tab, der.sc_tab.data(), der.sc_tab.size());
+  d.n_tabn = der.n_tabn; d.n_quot = der.n_quot; d.rew_smax = der.rew_smax;
 #undef UP
   d.max_cust = der.max_cust;
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;

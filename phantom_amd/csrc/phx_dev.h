@@ -76,6 +76,11 @@ struct DevSpec {
   const int32_t* shop_cust_agent;// agent index of each customer
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
   int32_t max_cust;              // max customers of one shop
+  // host-built lookup tables of the rollout kernel (exactly the values the formulas give):
+  //   [0,101) f32 stock/100 ; [101, 101+n_tabn) f32 x/norm, n_quot valid entries (0 unless
+  //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)
+  const float* sc_tab;
+  int32_t n_tabn, n_quot, rew_smax;
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env
@@ -197,10 +202,31 @@ __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint
   }
   return sum;
 }
-// all K customers, sum only: the fused kernels' fast path (same definition)
+// all K customers, sum only: the fused kernels' fast path (same definition).  u % 5 is computed
+// for all six fields of a block unconditionally (65535 % 5 == 0, so a rejected field adds
+// nothing); the rare redraws are handled in one cold branch per block.
 __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                   int K, uint32_t* act_word) {
-  return rng_shop_orders(seed, genv, tick, shop, K, nullptr, -1, act_word);
+  int sum = 0, k0 = 0;
+  do {
+    uint32_t w[4];
+    rng_block(seed, genv, tick, shop, k0 / 6, 0, w);
+    if (k0 == 0 && act_word) *act_word = w[3];
+    const int n = K - k0;                       // customers served by this block: min(n, 6)
+    uint32_t rej = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const uint32_t u = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
+      const bool take = j < n;
+      sum += take ? (int)rng_mod5(u) : 0;
+      rej |= (take && u == 65535u) ? (1u << j) : 0u;
+    }
+    if (rej)                                   // probability 6 * 2^-16 per block
+      for (int j = 0; j < 6; ++j)
+        if ((rej >> j) & 1u) sum += rng_customer_order(seed, genv, tick, shop, k0 + j, 1);
+    k0 += 6;
+  } while (k0 < K);
+  return sum;
 }
 
 __device__ __forceinline__ float rng_word_to_action(uint32_t w3) {

@@ -16,6 +16,8 @@
 // Results are bit-identical to the generic engine (tests/test_gpu_parity.py).
 #include "phx_dev.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #define SC_NT 256
 #define SC_STAGE_MAX 32768      // bytes of exo rows staged per block; larger -> direct loads
@@ -248,7 +250,9 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_v1_kernel(const DevSpec 
 // lean argument block of the rollout kernel (passing the whole DevSpec by value costs ~50
 // spilled SGPRs per wave)
 struct RollArgs {
-  int32_t B, S, n_exo, num_steps, T, epb, TC;
+  int32_t B, S, n_exo, num_steps, T, epb, TC, n_tabn, n_quot;
+  const float* sc_tab;
+  unsigned long long* timing;    // PHX_TIMING builds only: [blocks][8] cycle sums per phase
   uint32_t mG, mO, mF, mU;       // ceil(2^32 / d) magic numbers: i / d == umulhi(i, m) for i < 2^16
   uint64_t seed; int64_t env_offset;
   const int32_t* shop_norm;      // [S] max_sales_per_step of each shop
@@ -284,6 +288,12 @@ __device__ __forceinline__ void lds_barrier() {
 template <int NT, bool REPLAY, bool WIDE>
 __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PHX_TIMING
+  unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define TICK(k) do {} while (0)
+#endif
   const phx_rollout_io& io = a.io;
   const int nS = a.S, tid = threadIdx.x, TC = a.TC;
   const int64_t total = (int64_t)a.B * nS;
@@ -302,8 +312,14 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
   uint16_t* s_pair = (uint16_t*)(s_trunc + ((items_max + 15) & ~15));   // [G] shop | env_local << 8
   int* s_tick0 = (int*)(s_pair + ((Gfull + 7) & ~7));     // [epb]
   int* s_step0 = s_tick0 + ((a.epb + 3) & ~3);             // [epb]
-  int* s_cptr = s_step0 + ((a.epb + 3) & ~3);              // [S+1]
+  int* s_tend = s_step0 + ((a.epb + 3) & ~3);              // [epb] chunk-local step index that ends the episode, or -1
+  int* s_cptr = s_tend + ((a.epb + 3) & ~3);               // [S+1]
   int* s_norm = s_cptr + ((nS + 1 + 3) & ~3);              // [S]
+  const int n_tab = 101 + a.n_tabn + 202;
+  float* s_tab = (float*)(s_norm + ((nS + 3) & ~3));       // [n_tab] host-built lookup tables
+  const float* s_tabn = s_tab + 101;
+  const double* s_pen = (const double*)(s_tabn + a.n_tabn);   // 0.1 * stock, f64
+  for (int k = tid; k < n_tab; k += NT) s_tab[k] = a.sc_tab[k];
 
   for (int gl = tid; gl < G; gl += NT) s_pair[gl] = (uint16_t)((gl % nS) | ((gl / nS) << 8));
   for (int bl = tid; bl < nb; bl += NT) { s_tick0[bl] = a.env_tick[b_first + bl]; s_step0[bl] = a.env_step[b_first + bl]; }
@@ -323,6 +339,7 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
   // full-width copy-out needs every tile row to start and end on a 16-byte boundary
   lds_barrier();
 
+  TICK(0);
   for (int t0 = 0; t0 < a.T; t0 += TC) {
     const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
     const int n_items = tc * G;
@@ -351,46 +368,72 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
       tl += qG; gl += rG;
       if (gl >= G) { gl -= G; ++tl; }
     }
-    lds_barrier();
+    TICK(1); lds_barrier(); TICK(2);
     // ---- phase 2: the stock recurrence, one lane per pair ---------------------------------------
     if (tid < G) {
-      for (int tl = 0; tl < tc; ++tl) {
-        int* it = s_it + (tl * G + tid) * 3;
-        const int R = it[0], D = it[1];
-        const int stock0 = st.stock;
-        const int room = PHX_SHOP_MAX_STOCK - stock0;
-        const int req = R < room ? R : room;                      // supply_chain.py:139
-        int sales = 0, stock1 = stock0;
-        if (p2_K > 0) { sales = D < stock0 ? D : stock0; stock1 = stock0 - sales; }   // :105-122
-        const int ns = stock1 + req;                              // :98-103
-        stock1 = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
-        st.stock = stock1; st.sales = sales; st.missed = (p2_K > 0) ? D - sales : 0; st.delivered = req;
-        it[0] = stock1; it[2] = sales;
-        if (++step == a.num_steps) {                              // episode end: truncations["__all__"]
-          st.stock = 0; step = 0;                                 // ... and the caller's env.reset(): stock = 0
-          it[1] = D | (1 << 30);
+      // A lone wave issues about one instruction every 4-5 cycles, so this phase costs
+      // (instructions per step) x T: the loop body is kept to two LDS instructions and seven
+      // VALU ops.  stock' = min(max(x - D, 0) + min(R, 100 - x), 100); sales = x - max(x - D, 0).
+      // The episode end (at most one per chunk: TC <= num_steps) is a compare on the local index.
+      const int tend = a.num_steps - 1 - step;
+      if (tid % nS == 0) s_tend[tid / nS] = (tend >= 0 && tend < tc) ? tend : -1;
+      int x = st.stock, sales = st.sales, Dl = 0, req = st.delivered;
+      int* it = s_it + tid * 3;
+      const int istride = G * 3;
+      const bool hasK = p2_K > 0;
+      // dependent chain per step: sub, max, add, min, and  (the reset is an AND with a mask that
+      // does not depend on the stock; shops without customers take the general select)
+#define P2_STEP(R_, D_, tl_, it_, HASK)                                                          \
+      {                                                                                          \
+        Dl = (D_);                                                                               \
+        const int a0 = (HASK) ? max(x - Dl, 0) : (hasK ? max(x - Dl, 0) : x);  /* handle_order_request :105-122 */ \
+        const int keep = ((tl_) == tend) ? 0 : -1;                /* episode end -> env.reset(): stock = 0 */ \
+        req = min((R_), PHX_SHOP_MAX_STOCK - x);                  /* decode_action         :139 */     \
+        sales = x - a0;                                                                          \
+        const int xn = min(a0 + req, PHX_SHOP_MAX_STOCK);         /* handle_stock_response :98-103 */  \
+        (it_)[0] = xn; (it_)[2] = sales;                                                         \
+        x = xn & keep;                                                                           \
+      }
+      int tl = 0;
+      if (__all(hasK)) {
+        for (; tl + 8 <= tc; tl += 8, it += 8 * istride) {         // the 8 reads of a group are issued together
+          int Rv[8], Dv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { Rv[u] = it[u * istride]; Dv[u] = it[u * istride + 1]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) P2_STEP(Rv[u], Dv[u], tl + u, it + u * istride, true)
         }
       }
+      for (; tl < tc; ++tl, it += istride) P2_STEP(it[0], it[1], tl, it, false)
+#undef P2_STEP
+      st.stock = x; st.sales = sales; st.missed = hasK ? Dl - sales : 0; st.delivered = req;
+      step += tc;
+      if (tend >= 0 && tend < tc) step -= a.num_steps;
     }
-    lds_barrier();
+    TICK(3); lds_barrier(); TICK(4);
     // ---- phase 3a: observations / rewards / flags into the tiles ------------------------------------
-    gl = tid % G;
+    tl = tid / G; gl = tid - tl * G;
     for (int i = tid; i < n_items; i += NT) {
-      const int s = s_pair[gl] & 255;
-      const int stock = s_it[3 * i], Dw = s_it[3 * i + 1], sales = s_it[3 * i + 2];
-      const int D = Dw & 0x3fffffff;
+      const int pr = s_pair[gl], s = pr & 255;
+      const int stock = s_it[3 * i], D = s_it[3 * i + 1], sales = s_it[3 * i + 2];
       const int missed = (s_cptr[s + 1] > s_cptr[s]) ? D - sales : 0;
-      float ob[3];
+      // observation / reward from the host-built tables when the operands are in their usual
+      // range; otherwise (negative stock from negative requests, ...) the formulas themselves:
       // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
-      shop_obs_f32(stock, sales, missed, (float)s_norm[s], ob);
+      const float norm = (float)s_norm[s];
+      const bool in100 = (unsigned)stock <= 100u;
       float* of = (float*)s_it + 3 * i;
-      of[0] = ob[0]; of[1] = ob[1]; of[2] = ob[2];
-      s_rew[i] = (float)shop_reward(sales, stock);
-      s_trunc[i] = (uint8_t)((Dw >> 30) & 1);                      // set by phase 2 at episode end
-      gl += rG;
-      if (gl >= G) gl -= G;
+      of[0] = in100 ? s_tab[in100 ? stock : 0] : (float)stock / (float)PHX_SHOP_MAX_STOCK;
+      const bool ins = (unsigned)sales < (unsigned)a.n_quot, inm = (unsigned)missed < (unsigned)a.n_quot;
+      of[1] = ins ? s_tabn[ins ? sales : 0] : (float)sales / norm;
+      of[2] = inm ? s_tabn[inm ? missed : 0] : (float)missed / norm;
+      // reward = sales - 0.1 * stock in f64 (supply_chain.py:147), rounded once to the trajectory's f32
+      s_rew[i] = in100 ? (float)__dsub_rn((double)sales, s_pen[in100 ? stock : 0]) : (float)shop_reward(sales, stock);
+      s_trunc[i] = (uint8_t)(tl == s_tend[pr >> 8]);               // truncations["__all__"], env.py:312-318
+      tl += qG; gl += rG;
+      if (gl >= G) { gl -= G; ++tl; }
     }
-    lds_barrier();
+    TICK(5); lds_barrier();
     // ---- phase 3b: tiles -> HBM ---------------------------------------------------------------------
     const int64_t row0 = (int64_t)t0 * total + g_base;           // element offset of tile row 0
     const int64_t rstride = total;
@@ -435,8 +478,11 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
         io.truncated[o] = s_trunc[i]; io.terminated[o] = 0;
       }
     }
-    lds_barrier();
+    TICK(6); lds_barrier(); TICK(7);
   }
+#ifdef PHX_TIMING
+  if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 8 + q] = tm[q];
+#endif
   if (tid < G) {
     const int64_t g = g_base + tid;
     const int s = tid % nS, b = (int)b_first + tid / nS;
@@ -477,6 +523,15 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   a.B = sp.B; a.S = sp.S; a.n_exo = sp.n_exo; a.num_steps = sp.num_steps; a.T = io.T;
   a.seed = sp.seed; a.env_offset = sp.env_offset;
   a.shop_norm = sp.shop_norm; a.shop_cust_ptr = sp.shop_cust_ptr; a.shop_cust_exo = sp.shop_cust_exo;
+  a.sc_tab = sp.sc_tab; a.n_tabn = sp.n_tabn; a.n_quot = sp.n_quot;
+  a.timing = nullptr;
+#ifdef PHX_TIMING
+  { static unsigned long long* tbuf = nullptr; if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 8 * 8192 * sizeof(unsigned long long)); a.timing = tbuf;
+    if (getenv("PHX_TIMING_DUMP")) { static int calls = 0; if (++calls == 20) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(8 * 8 * 8192); (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+      const int nw = ((sp.B + 7) / 8) * 8; double sum[8] = {0}; double w0[8] = {0}; for (int w = 0; w < nw; ++w) for (int q = 0; q < 8; ++q) { sum[q] += h[(size_t)w * 8 + q]; if (w % 8 == 0) w0[q] += h[(size_t)w * 8 + q]; }
+      fprintf(stderr, "PHX_TIMING avg cycles per wave: setup %.0f | P1 %.0f | bar %.0f | P2 %.0f | bar %.0f | P3a %.0f | P3b(+bar) %.0f | bar %.0f\n", sum[0]/nw, sum[1]/nw, sum[2]/nw, sum[3]/nw, sum[4]/nw, sum[5]/nw, sum[6]/nw, sum[7]/nw);
+      fprintf(stderr, "PHX_TIMING wave0 of each block:      setup %.0f | P1 %.0f | bar %.0f | P2 %.0f | bar %.0f | P3a %.0f | P3b(+bar) %.0f | bar %.0f\n", w0[0]*8/nw, w0[1]*8/nw, w0[2]*8/nw, w0[3]*8/nw, w0[4]*8/nw, w0[5]*8/nw, w0[6]*8/nw, w0[7]*8/nw); } } }
+#endif
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
@@ -492,11 +547,13 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   static const int ldskb = getenv("PHX_ROLLOUT_LDSKB") ? atoi(getenv("PHX_ROLLOUT_LDSKB")) : 40;
   int TC = (ldskb * 1024) / (G * 21); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;
   while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
+  if (TC > 8) TC &= ~7;                                          // groups of 8 steps in the recurrence phase
+  if (sp.num_steps >= 1 && TC > sp.num_steps) TC = sp.num_steps; // at most one episode end per chunk
   a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 8);
   const int items = TC * G;
   const size_t lds = (size_t)((items * 3 + 3) & ~3) * 4 + (size_t)((items + 3) & ~3) * 8 + (size_t)((items + 15) & ~15) +
-                     (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 8 + (size_t)((sp.S + 4) & ~3) * 4 +
-                     (size_t)((sp.S + 3) & ~3) * 4 + 64;
+                     (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
+                     (size_t)((sp.S + 3) & ~3) * 4 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
   a.epb = epb; a.TC = TC;
   const dim3 grid((sp.B + epb - 1) / epb);
   const bool replay = io.actions != nullptr || io.exo != nullptr;
