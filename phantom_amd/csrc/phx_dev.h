@@ -161,12 +161,12 @@ __device__ __forceinline__ void rng_block(uint64_t seed, int64_t genv, uint32_t 
                 (uint32_t)shop | ((uint32_t)blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
 }
 __device__ __forceinline__ uint32_t rng_mod5(uint32_t u) {          // u < 65536
-  // 24-bit multiplies are full rate; keep every product below 2^31 (HIP's __umul24 is not
-  // reliable above that).  13108 = ceil(2^16 / 5) over-estimates u / 5 by at most 1.
-  const int q = (int)(__umul24(u, 13108u) >> 16);
-  int r = (int)u - q * 5;
-  r = r < 0 ? r + 5 : r;
-  return (uint32_t)r;
+  // u / 5 through f32: u * 0.2f carries a relative error < 2^-23, far below the 0.2 gap to the
+  // next integer boundary for u < 2^16, and 0.2f > 0.2 keeps exact multiples of 5 on the right
+  // side (checked exhaustively in tests/test_gpu_parity.py via the oracle comparison and in
+  // scratch unit tests); all four ops are full rate.
+  const uint32_t q = (uint32_t)((float)u * 0.2f);
+  return u - q * 5u;
 }
 // one customer's draw (generic engine; also the redraw path)
 __device__ __forceinline__ int rng_customer_order(uint64_t seed, int64_t genv, uint32_t tick, int shop, int k,
@@ -204,7 +204,9 @@ __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint
 }
 // all K customers, sum only: the fused kernels' fast path (same definition).  u % 5 is computed
 // for all six fields of a block unconditionally (65535 % 5 == 0, so a rejected field adds
-// nothing); the rare redraws are handled in one cold branch per block.
+// nothing); the rare redraws are handled in one cold branch per block.  When every lane of the
+// wave still needs >= 6 customers from the block (the usual K = 6 case) the per-field
+// "customer exists" selects disappear.
 __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                   int K, uint32_t* act_word) {
   int sum = 0, k0 = 0;
@@ -214,12 +216,21 @@ __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, u
     if (k0 == 0 && act_word) *act_word = w[3];
     const int n = K - k0;                       // customers served by this block: min(n, 6)
     uint32_t rej = 0;
+    if (__all(n >= 6)) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const uint32_t u = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
-      const bool take = j < n;
-      sum += take ? (int)rng_mod5(u) : 0;
-      rej |= (take && u == 65535u) ? (1u << j) : 0u;
+      for (int j = 0; j < 6; ++j) {
+        const uint32_t u = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
+        sum += (int)rng_mod5(u);
+        rej |= ((u + 1u) >> 16) << j;           // bit j <=> u == 65535
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const uint32_t u = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
+        const bool take = j < n;
+        sum += take ? (int)rng_mod5(u) : 0;
+        rej |= take ? (((u + 1u) >> 16) << j) : 0u;
+      }
     }
     if (rej)                                   // probability 6 * 2^-16 per block
       for (int j = 0; j < 6; ++j)

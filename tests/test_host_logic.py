@@ -177,6 +177,14 @@ def test_device_rng_rejection_branch():
     assert rng_orders(1, genv, 0, 0, 6)[j] == u1 % 5
 
 
+def test_f32_mod5_formula_is_exact_for_16_bit_fields():
+    """the kernels compute u % 5 as u - 5 * uint(f32(u) * 0.2f): exact for every u < 65536
+    (IEEE f32 multiply, round-to-nearest, truncating conversion -- same on CPU and GPU)."""
+    u = np.arange(65536, dtype=np.uint32)
+    q = (u.astype(np.float32) * np.float32(0.2)).astype(np.uint32)
+    assert (q == u // 5).all() and ((u - q * 5) == u % 5).all()
+
+
 def test_f32_division_equals_reference_f64_quotient_cast():
     """encode_observation builds python-float quotients and casts to float32
     (supply_chain.py:127-134); the rollout kernel divides in f32.  Identical bit patterns."""
