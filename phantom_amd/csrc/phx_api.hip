@@ -376,8 +376,17 @@ int phx_field_info(const phx_env* e, int index, phx_field* out) {
 
 int phx_uses_fused(const phx_env* e) { return e && (e->use_fused || e->use_stk) ? 1 : 0; }
 
+// the handle's device becomes the calling thread's current device (a no-op when it already is)
+static inline hipError_t use_device(const phx_env* e) {
+  int cur = -1;
+  hipError_t r = hipGetDevice(&cur);
+  if (r != hipSuccess) return r;
+  return cur == e->device ? hipSuccess : hipSetDevice(e->device);
+}
+
 int phx_reset(phx_env* e, const uint8_t* reset_mask, float* obs, uint8_t* obs_valid, void* stream) {
   if (!e) return fail(PHX_EINVAL, "null env");
+  HIPCHK(use_device(e));
   HIPCHK(phx_launch_reset(e->d, reset_mask, obs, obs_valid, (hipStream_t)stream));
   return PHX_OK;
 }
@@ -400,6 +409,7 @@ static int upload_inject(phx_env* e, hipStream_t st) {
 
 int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   if (!e) return fail(PHX_EINVAL, "null env");
+  HIPCHK(use_device(e));
   int rc = check_step_io(e, io);
   if (rc != PHX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -434,6 +444,7 @@ int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) {
 int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count, void* stream) {
   if (!e) return fail(PHX_EINVAL, "null env");
   if ((msg_log || msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
+  HIPCHK(use_device(e));
   hipStream_t st = (hipStream_t)stream;
   GenArgs g; memset(&g, 0, sizeof g);
   g.io.err = err; g.io.msg_log = msg_log; g.io.msg_count = msg_count;
@@ -452,6 +463,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EUNSUPPORTED, "phx_rollout needs a plain env with a static supply-chain schedule");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
+  HIPCHK(use_device(e));
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
   return PHX_OK;
 }

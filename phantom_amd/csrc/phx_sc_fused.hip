@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
   uint8_t ov = 0, rv = 0;
   double rw = 0.0;
   if (sp.env_type == PHX_ENV_PLAIN) {
-    shop_obs(st.stock, st.sales, st.missed, sp.param_i[a_shop * PHX_NPI + 1], ob);
+    shop_obs_f32(st.stock, st.sales, st.missed, (float)sp.param_i[a_shop * PHX_NPI + 1], ob);
     rw = shop_reward(st.sales, st.stock);
     ov = 1; rv = 1;
   } else {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
     uint8_t* ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + g;
     const bool observes = sp.obs_mask[(int64_t)list * A + a_shop] != 0;
     if (observes) {
-      shop_obs(st.stock, st.sales, st.missed, sp.param_i[a_shop * PHX_NPI + 1], ob);
+      shop_obs_f32(st.stock, st.sales, st.missed, (float)sp.param_i[a_shop * PHX_NPI + 1], ob);
       oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; *ocv = 1;                  // fsm.py:349
     }
     uint8_t cache_valid = *rcv; double cache = *rc;

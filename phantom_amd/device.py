@@ -109,6 +109,7 @@ class DeviceEnv:
             self.msg_log = z(B, spec.trace_cap, 16, dtype=torch.uint8)
             self.msg_count = z(B, dtype=torch.int32)
         self.topology_version = 0
+        self._step_io = None
 
     # ---- helpers --------------------------------------------------------------------------
     def _err(self) -> str:
@@ -166,32 +167,40 @@ class DeviceEnv:
 
     def step(self, actions, action_valid=None, exo=None) -> StepTensors:
         torch = _torch()
-        io = _abi.PhxStepIO()
+        io = self._step_io
+        if io is None:
+            # the output pointers never change: build the struct once, patch the inputs per call
+            io = self._step_io = _abi.PhxStepIO()
+            io.obs, io.obs_valid = self.obs.data_ptr(), self.obs_valid.data_ptr()
+            io.reward, io.reward_valid = self.reward.data_ptr(), self.reward_valid.data_ptr()
+            io.terminated, io.truncated = self.terminated.data_ptr(), self.truncated.data_ptr()
+            io.done_valid = self.done_valid.data_ptr()
+            io.all_terminated = self.all_terminated.data_ptr()
+            io.all_truncated = self.all_truncated.data_ptr()
+            io.err = self.err.data_ptr()
+            if self.msg_log is not None:
+                io.msg_log, io.msg_count = self.msg_log.data_ptr(), self.msg_count.data_ptr()
+            self._step_io_ref = C.byref(io)
+            self._step_out = StepTensors(self.obs, self.reward, self.terminated, self.truncated,
+                                         self.obs_valid, self.reward_valid, self.done_valid,
+                                         self.all_terminated, self.all_truncated)
         if self.S > 0:
             if actions.dtype != torch.float32 or not actions.is_contiguous() \
-                    or actions.shape != (self.B, self.S):
-                raise ValueError(f"actions must be a contiguous f32 tensor [{self.B}, {self.S}]")
+                    or actions.shape != (self.B, self.S) or actions.device != self.device:
+                raise ValueError(f"actions must be a contiguous f32 tensor [{self.B}, {self.S}] on {self.device}")
             io.actions = actions.data_ptr()
-        if action_valid is not None:
-            io.action_valid = action_valid.data_ptr()
+        io.action_valid = action_valid.data_ptr() if action_valid is not None else None
         if exo is not None:
             if exo.dtype != torch.uint8 or exo.shape != (self.B, self.n_exo) or not exo.is_contiguous():
                 raise ValueError(f"exo must be a contiguous u8 tensor [{self.B}, {self.n_exo}]")
             io.exo = exo.data_ptr()
-        io.obs, io.obs_valid = self.obs.data_ptr(), self.obs_valid.data_ptr()
-        io.reward, io.reward_valid = self.reward.data_ptr(), self.reward_valid.data_ptr()
-        io.terminated, io.truncated = self.terminated.data_ptr(), self.truncated.data_ptr()
-        io.done_valid = self.done_valid.data_ptr()
-        io.all_terminated = self.all_terminated.data_ptr()
-        io.all_truncated = self.all_truncated.data_ptr()
-        io.err = self.err.data_ptr()
-        if self.msg_log is not None:
-            io.msg_log, io.msg_count = self.msg_log.data_ptr(), self.msg_count.data_ptr()
-        with torch.cuda.device(self.device):
-            self._check(self.lib.phx_step(self.handle, C.byref(io), self._stream()), "phx_step")
-        return StepTensors(self.obs, self.reward, self.terminated, self.truncated, self.obs_valid,
-                           self.reward_valid, self.done_valid, self.all_terminated,
-                           self.all_truncated)
+        else:
+            io.exo = None
+        rc = self.lib.phx_step(self.handle, self._step_io_ref,
+                               torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            self._check(rc, "phx_step")
+        return self._step_out
 
     def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
         torch = _torch()
