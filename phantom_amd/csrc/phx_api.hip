@@ -40,7 +40,7 @@ static int kind_obs_dim(int k) {
 
 // ---- derived quantities of a spec (host) ---------------------------------------------------------
 struct Derived {
-  int A = 0, S = 0, D = 1, n_exo = 0, nnz = 0, buyer_nnz = 0, n_lists = 1, scan_cap = 0;
+  int A = 0, S = 0, D = 1, n_exo = 0, nnz = 0, buyer_nnz = 0, buyer_dmax = 0, n_lists = 1, scan_cap = 0;
   int kind_count[PHX_KIND_COUNT] = {0};
   std::vector<int32_t> strat_rank, strat_idx, kind_rank, exo_rank, buyer_off;
   std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
@@ -73,7 +73,7 @@ static int derive(const phx_spec* sp, Derived& d) {
     d.kind_rank[a] = d.kind_count[k]++;
     if (kind_is_strategic(k)) { d.strat_rank[a] = d.S++; d.strat_idx.push_back(a); d.D = std::max(d.D, kind_obs_dim(k)); }
     if (k == PHX_KIND_CUSTOMER) d.exo_rank[a] = d.n_exo++;
-    if (k == PHX_KIND_BUYER) { d.buyer_off[a] = d.buyer_nnz; d.buyer_nnz += sp->row_ptr[a + 1] - sp->row_ptr[a]; }
+    if (k == PHX_KIND_BUYER) { d.buyer_off[a] = d.kind_rank[a]; d.buyer_dmax = std::max(d.buyer_dmax, sp->row_ptr[a + 1] - sp->row_ptr[a]); }
     const int32_t* pi = sp->param_i + a * PHX_NPI;
     if ((k == PHX_KIND_SHOP || k == PHX_KIND_CUSTOMER) && (pi[0] < 0 || pi[0] >= A))
       return fail(PHX_EINVAL, "agent %d: target agent index out of range", a);
@@ -82,6 +82,7 @@ static int derive(const phx_spec* sp, Derived& d) {
     if (k == PHX_KIND_CUSTOMER && sp->kind[pi[0]] != PHX_KIND_SHOP)
       return fail(PHX_EINVAL, "agent %d: CustomerAgent.shop_id is not a ShopAgent", a);
   }
+  d.buyer_nnz = d.buyer_dmax * d.kind_count[PHX_KIND_BUYER];   // slot-major (ELL) price table per env
   // acting lists + masks
   if (sp->env_type == PHX_ENV_PLAIN) {
     d.n_lists = 1; d.act_ptr = {0, A};
@@ -220,7 +221,7 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_SELLER_PRICE, "seller.price", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
     {F_SELLER_REVENUE, "seller.revenue", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
     {F_SELLER_TX, "seller.tx", 0, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
-    {F_BUYER_PRICES, "buyer.prices", 1, PHX_KIND_BUYER, B, d.buyer_nnz, 1, 0},
+    {F_BUYER_PRICES, "buyer.prices", 1, PHX_KIND_BUYER, B, d.buyer_dmax, kc(PHX_KIND_BUYER), 0},
     {F_BUYER_PAID, "buyer.paid", 1, PHX_KIND_BUYER, B, kc(PHX_KIND_BUYER), 1, 0},
     {F_BUYER_BOUGHT, "buyer.bought", 0, PHX_KIND_BUYER, B, kc(PHX_KIND_BUYER), 1, 0},
     {F_CASHBOX_TOTAL, "cashbox.total_cash", 1, PHX_KIND_CASHBOX, B, kc(PHX_KIND_CASHBOX), 1, 0},
@@ -308,7 +309,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.A = der.A; d.S = der.S; d.B = spec->batch; d.D = der.D; d.n_exo = der.n_exo; d.nnz = der.nnz;
   d.num_steps = spec->num_steps; d.round_limit = spec->round_limit; d.env_type = spec->env_type;
   d.flags = spec->flags; d.queue_cap = spec->queue_cap; d.trace_cap = spec->trace_cap; d.scan_cap = der.scan_cap;
-  d.n_lists = der.n_lists; d.initial_stage = spec->initial_stage; d.buyer_nnz = der.buyer_nnz;
+  d.n_lists = der.n_lists; d.initial_stage = spec->initial_stage; d.buyer_nnz = der.buyer_nnz; d.buyer_stride = der.kind_count[PHX_KIND_BUYER];
   d.seed = spec->seed; d.env_offset = spec->env_offset;
   memcpy(d.kind_count, der.kind_count, sizeof d.kind_count);
   const int A = der.A;

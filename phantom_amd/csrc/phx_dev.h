@@ -44,7 +44,8 @@ struct DevSpec {
   int32_t scan_cap;              // >= max(queue_cap, longest acting list + PHX_MAX_INJECT)
   int32_t n_lists;               // acting lists: PLAIN 1, FSM n_stages, STACKELBERG 2
   int32_t initial_stage;
-  int32_t buyer_nnz;             // total price slots of all buyers (per env)
+  int32_t buyer_nnz;             // price slots per env = max buyer degree x number of buyers
+  int32_t buyer_stride;          // buyer.prices is slot-major (ELL): slot k of buyer r at k * stride + r
   uint64_t seed;
   int64_t env_offset;
   int32_t kind_count[PHX_KIND_COUNT];
@@ -58,7 +59,7 @@ struct DevSpec {
   const int32_t* strat_idx;      // [S]
   const int32_t* kind_rank;      // [A]
   const int32_t* exo_rank;       // [A]  -1 unless CUSTOMER
-  const int32_t* buyer_off;      // [A]  first price slot of a BUYER in buyer.prices
+  const int32_t* buyer_off;      // [A]  rank of a BUYER among the buyers (its column in buyer.prices)
   const int32_t* act_ptr;        // [n_lists+1] ordered acting lists
   const int32_t* act_idx;
   const uint8_t* act_mask;       // [n_lists][A] 1 <=> agent is in the acting list
@@ -305,7 +306,7 @@ __device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, int b, int a)
     case PHX_KIND_BUYER: {
       const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
       double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
-      for (int k = 0; k < deg; ++k) pr[k] = 1.0;
+      for (int k = 0; k < deg; ++k) pr[(int64_t)k * sp.buyer_stride] = 1.0;
       fld<double>(sp, F_BUYER_PAID)[r.base] = 0.0;
       fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
       break;
@@ -332,7 +333,7 @@ __device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, int b, int a, 
       const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
       const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
       double mn = pr[0];
-      for (int k = 1; k < deg; ++k) mn = pr[k] < mn ? pr[k] : mn;
+      for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; mn = v < mn ? v : mn; }
       o[0] = (float)mn;
       o[1] = (float)sp.param_f[a * PHX_NPF];
       break;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void act_emit(const DevSpec& sp, int b, int a, bool h
         if (action > 0.5f && deg > 0) {
           const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
           int j = 0; double best = pr[0];
-          for (int k = 1; k < deg; ++k) if (pr[k] < best) { best = pr[k]; j = k; }
+          for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (v < best) { best = v; j = k; } }
           fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 1;
           fld<double>(sp, F_BUYER_PAID)[r.base] = best;
           m.dst = (uint16_t)sp.col[sp.row_ptr[a] + j]; m.type = PHX_MSG_ORDER; m.p.i = 1;
@@ -197,7 +197,7 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, int b, int a, 
       if (m.type == PHX_MSG_PRICE) {
         const int slot = dev_nbr_slot(sp, a, m.src);
         if (slot >= 0)
-          fld<double>(sp, F_BUYER_PRICES)[(int64_t)b * sp.buyer_nnz + sp.buyer_off[a] + slot] = m.p.f;
+          fld<double>(sp, F_BUYER_PRICES)[(int64_t)b * sp.buyer_nnz + sp.buyer_off[a] + (int64_t)slot * sp.buyer_stride] = m.p.f;
         return false;
       }
       break;

@@ -8,7 +8,7 @@
 // all addends of a round are the same f64, so the sequential sum only needs the ORDER COUNT,
 // which the block gets from LDS atomics.  One workgroup per env instance; the 8-byte price
 // slots (buyer.prices f64[B][sum deg], 64 KB per env at 1024 x 8) dominate the traffic and are
-// streamed with lane-contiguous accesses.  Results are bit-identical to the generic engine.
+// stored slot-major (ELL) so that the buyers of a wave read/write slot k at consecutive addresses.  Results are bit-identical to the generic engine.
 #include "phx_dev.h"
 #include "phx_epilogue.h"
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       if (action > 0.5f && deg > 0) {
         const double* pr = prices_b + sp.buyer_off[a];
         int j = 0; double best = pr[0];
-        for (int k = 1; k < deg; ++k) { const double v = pr[k]; if (v < best) { best = v; j = k; } }
+        for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (v < best) { best = v; j = k; } }
         fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 1;
         fld<double>(sp, F_BUYER_PAID)[r.base] = best;
         atomicAdd(&s_count[sp.kind_rank[sp.col[lo + j]]], 1);               // Order(1) -> that seller's inbox
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       double* pr = prices_b + sp.buyer_off[a];
       for (int k = 0; k < deg; ++k) {                                        // handle Price from each neighbour
         const int kr = sp.kind_rank[sp.col[lo + k]];
-        if (s_sent[kr]) pr[k] = s_price[kr];
+        if (s_sent[kr]) pr[(int64_t)k * sp.buyer_stride] = s_price[kr];
       }
     }
   }

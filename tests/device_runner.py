@@ -73,7 +73,17 @@ class DeviceRunner:
             self.dev.field(field).shape))
 
     def get_f64(self, field):
-        return self.dev.field(field).cpu().numpy().reshape(self.B, -1)
+        v = self.dev.field(field).cpu().numpy()
+        if field == "buyer.prices":
+            # device layout is slot-major [B, dmax, n_buyers]; the oracle reports buyers in agent
+            # order with their deg slots each
+            from phantom_amd import _abi
+            sp = self.spec
+            deg = np.diff(sp.row_ptr)
+            buyers = [a for a in range(sp.n_agents) if sp.kind[a] == _abi.KIND_BUYER]
+            cols = [v[:, :deg[a], r] for r, a in enumerate(buyers)]
+            return np.concatenate(cols, axis=1) if cols else v.reshape(self.B, -1)
+        return v.reshape(self.B, -1)
 
     def log(self, b=0):
         n = int(self.msg_count[b])
