@@ -33,6 +33,8 @@ import torch  # noqa: E402
 
 N_SHOPS, CUST_PER_SHOP, NUM_STEPS, BATCH = 9, 6, 100, 4096
 N_AGENTS = 1 + N_SHOPS + N_SHOPS * CUST_PER_SHOP          # 64
+# BASELINE.json configs[1] is the bench line; --config sc256 runs configs[3]'s per-GPU workload
+CONFIGS = {"sc64": (9, 6, 4096), "sc256": (51, 4, 8192)}
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -86,7 +88,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=BATCH, help="envs per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="sc64")
+    ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
     args = ap.parse_args()
@@ -108,7 +111,10 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     import phantom_amd as ph
-    B, S, K, W = args.batch, N_SHOPS, args.steps, args.warmup
+    global N_SHOPS, CUST_PER_SHOP, N_AGENTS
+    N_SHOPS, CUST_PER_SHOP, default_batch = CONFIGS[args.config]
+    N_AGENTS = 1 + N_SHOPS + N_SHOPS * CUST_PER_SHOP
+    B, S, K, W = args.batch or default_batch, N_SHOPS, args.steps, args.warmup
     # one process per GPU owns envs [rank*B, (rank+1)*B); the RNG is keyed by the GLOBAL env
     # index so results do not depend on the number of GPUs.  No collective inside a step.
     env = ph.SupplyChainEnv(n_shops=N_SHOPS, customers_per_shop=CUST_PER_SHOP, num_steps=NUM_STEPS,
@@ -167,17 +173,31 @@ def main():
             traffic = json.load(open(pmc)).get("phx_sc_rollout_kernel", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # achievable write bandwidth of this box for a buffer of the trajectory's size (a plain fill)
+    fill_buf = torch.empty(alg // 4, dtype=torch.float32, device=dev.device)
+    for _ in range(3):
+        fill_buf.fill_(1.0)
+    torch.cuda.synchronize()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record()
+    for _ in range(20):
+        fill_buf.fill_(1.0)
+    f1.record(); torch.cuda.synchronize()
+    fill_gbs = alg / (f0.elapsed_time(f1) / 20 * 1e-3) / 1e9
+    del fill_buf
     roofline = {"bound": "hbm", "kernel": "phx_sc_rollout_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                "launch_ms": launch_ms, "launch": f"T={T} steps x B={B} envs"}
+                "launch_ms": launch_ms, "launch": f"T={T} steps x B={B} envs",
+                "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs}
 
     out = {
         "metric": "agent_steps_per_sec", "value": value, "unit": "agent-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i32", "data": "synthetic",
-        "config": {"workload": "supply-chain SC64 (1 factory + 9 shops + 54 customers = 64 agents), "
+        "config": {"workload": f"supply-chain {args.config.upper()} (1 factory + {N_SHOPS} shops + "
+                               f"{N_SHOPS * CUST_PER_SHOP} customers = {N_AGENTS} agents), "
                                f"batch {B} envs per GPU, random actions U[0,100), device-RNG orders, "
                                "fused on-device rollout T=100 with full trajectory written to HBM",
                    "agents": N_AGENTS, "envs_per_gpu": B, "global_envs": B * world,

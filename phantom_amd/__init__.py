@@ -21,3 +21,5 @@ from .spec import EnvSpec, compile_spec
 from .stackelberg import StackelbergEnv
 from .supply_chain import SupplyChainEnv, SupplyChainFSMEnv
 from .views import AgentView, EnvView, FSMEnvView, View
+from . import metrics, rllib
+from .distributed import all_gather_trajectory, make_sharded_env, shard_batch

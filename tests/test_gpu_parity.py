@@ -346,3 +346,51 @@ def test_python_surface_tracking_and_errors():
     n2.send("A", "B", ph.Request(0.0))
     with pytest.raises(RuntimeError):
         n2.resolve()
+
+
+def test_metrics_and_rllib_adapters():
+    """caller-side contract: SimpleAgentMetric reflection on device state,
+    RLlibEnvWrapper pass-through, BaseEnv-shaped poll/send_actions with lazy per-env views."""
+    import phantom_amd as ph
+    from phantom_amd.metrics import SimpleAgentMetric, logging_helper
+    from phantom_amd.rllib import BatchedBaseEnv, RLlibEnvWrapper
+    g = golden("sc7_fixed20")
+    np.random.seed(0)
+    wrapped = RLlibEnvWrapper(ph.SupplyChainEnv())
+    assert wrapped.get_agent_ids() == {"SHOP"} and wrapped.num_steps == 100      # __getattr__ delegation
+    metrics = {"SHOP/stock": SimpleAgentMetric("SHOP", "stock", "mean"),
+               "SHOP/sales": SimpleAgentMetric("SHOP", "sales", "sum")}
+    values = {}
+    np.random.seed(0)
+    wrapped.reset()
+    for t in range(10):
+        step = wrapped.step({"SHOP": np.array([20.0], np.float32)})
+        logging_helper(wrapped.env, metrics, values)
+        assert step.rewards["SHOP"] == g["reward"][t, 0, 0]
+    assert values["SHOP/stock"] == g["stock"][:10, 0, 0].tolist()
+    assert metrics["SHOP/stock"].reduce(values["SHOP/stock"], "train") == g["stock"][:10, 0, 0].mean()
+    assert metrics["SHOP/sales"].reduce(values["SHOP/sales"], "train") == g["sales"][:10, 0, 0].sum()
+    # batched BaseEnv-shaped driver vs the oracle
+    B, S, K = 6, 3, 2
+    env = supply_chain_env(S, [K] * S, 5, B, seed=3, exogenous="device")
+    o = OracleEnv(env.spec)
+    base = BatchedBaseEnv(env)
+    obs, rew, term, trunc, infos, _ = base.poll()                 # first poll = reset observations
+    oo, _ = o.reset()
+    assert list(obs[2].keys()) == ["SHOP0", "SHOP1", "SHOP2"]
+    np.testing.assert_array_equal(obs[2]["SHOP1"], oo[2, 1])
+    rng = np.random.RandomState(0)
+    for t in range(5):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        base.send_actions(a)
+        obs, rew, term, trunc, infos, _ = base.poll()
+        o.step(a, None, None)
+        for b in (0, B - 1):
+            np.testing.assert_array_equal(obs[b]["SHOP2"], o.obs[b, 2])
+            assert rew[b]["SHOP0"] == o.reward[b, 0]
+            assert trunc[b]["__all__"] == bool(o.all_truncated[b]) and term[b]["SHOP1"] is False
+    assert trunc[0]["__all__"] is True
+    sub = base.get_sub_environments()[4]
+    assert sub.agents["SHOP1"].stock == int(o.get_i32("shop.stock")[4, 1])
+    obs1, _ = base.try_reset(1)
+    assert list(obs1) == [1] and env.current_step.tolist() == [5, 0, 5, 5, 5, 5]
