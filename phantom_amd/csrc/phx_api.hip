@@ -422,7 +422,14 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
     HIPCHK(phx_launch_stk_step(e->d, *io, st));
     return PHX_OK;
   }
-  GenArgs g; g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0;
+  GenArgs g; g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0; g.timing = nullptr;
+#ifdef PHX_TIMING
+  { static unsigned long long* tb = nullptr; static int calls = 0;
+    if (!tb) { (void)hipMalloc((void**)&tb, 16 * 8); (void)hipMemset(tb, 0, 16 * 8); }
+    g.timing = tb;
+    if (getenv("PHX_TIMING_DUMP") && ++calls == 100) { (void)hipDeviceSynchronize(); unsigned long long h[16]; (void)hipMemcpy(h, tb, sizeof h, hipMemcpyDeviceToHost);
+      const double n = 99.0 * e->d.B; fprintf(stderr, "PHX_GTIMING cycles/block:"); for (int q = 0; q < 15; ++q) fprintf(stderr, " %d:%.0f", q, h[q] / n); fprintf(stderr, "\n"); } }
+#endif
   rc = upload_inject(e, st);
   if (rc != PHX_OK) return rc;
   if (e->n_inject) HIPCHK(hipStreamSynchronize(st));   // inject_host is reused right after
@@ -449,7 +456,7 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
   hipStream_t st = (hipStream_t)stream;
   GenArgs g; memset(&g, 0, sizeof g);
   g.io.err = err; g.io.msg_log = msg_log; g.io.msg_count = msg_count;
-  g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 1;
+  g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 1; g.timing = nullptr;
   int rc = upload_inject(e, st);
   if (rc != PHX_OK) return rc;
   if (e->n_inject) HIPCHK(hipStreamSynchronize(st));

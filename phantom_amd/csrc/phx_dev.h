@@ -92,10 +92,33 @@ struct GenArgs {               // arguments of the generic engine kernel
   const DevMsg* inject;         // device copy of host-injected messages (same for every env)
   int32_t n_inject;
   int32_t resolve_only;         // Network.resolve() alone: no clock tick, no acting, no epilogue
+  unsigned long long* timing;   // PHX_TIMING builds only
+  int32_t tab_off;              // byte offset of the LDS-staged topology tables (generic engine)
 };
 
 template <typename T>
 __device__ __forceinline__ T* fld(const DevSpec& sp, int id) { return (T*)sp.f[id]; }
+
+// The static topology tables the message handlers walk in dependent chains.  The generic engine
+// stages them in LDS (every env instance of a launch reads the same few cache lines otherwise);
+// other kernels use the global copies through topo_global().
+struct Topo {
+  const uint8_t* kind;
+  const int32_t* param_i;
+  const double*  param_f;
+  const int32_t* row_ptr;
+  const int32_t* col;
+  const int32_t* strat_rank;
+  const int32_t* kind_rank;
+  const int32_t* exo_rank;
+  const int32_t* buyer_off;
+};
+__device__ __forceinline__ Topo topo_global(const DevSpec& sp) {
+  Topo t;
+  t.kind = sp.kind; t.param_i = sp.param_i; t.param_f = sp.param_f; t.row_ptr = sp.row_ptr; t.col = sp.col;
+  t.strat_rank = sp.strat_rank; t.kind_rank = sp.kind_rank; t.exo_rank = sp.exo_rank; t.buyer_off = sp.buyer_off;
+  return t;
+}
 
 // ---- payload whitelists (message.py:20-42): 0 = any -----------------------------------------
 __device__ __forceinline__ void dev_payload_types(int type, int& sk, int& rk, int& decorated) {
@@ -112,25 +135,25 @@ __device__ __forceinline__ void dev_payload_types(int type, int& sk, int& rk, in
   }
 }
 
-__device__ __forceinline__ int dev_nbr_slot(const DevSpec& sp, int u, int v) {
-  const int lo = sp.row_ptr[u], hi = sp.row_ptr[u + 1];
+__device__ __forceinline__ int dev_nbr_slot(const DevSpec& sp, const Topo& tp, int u, int v) {
+  const int lo = tp.row_ptr[u], hi = tp.row_ptr[u + 1];
   for (int k = lo; k < hi; ++k)
-    if (sp.col[k] == v) return k - lo;
+    if (tp.col[k] == v) return k - lo;
   return -1;
 }
-__device__ __forceinline__ bool dev_has_edge(const DevSpec& sp, int u, int v) {   // network.py:224-231
-  return dev_nbr_slot(sp, u, v) >= 0;
+__device__ __forceinline__ bool dev_has_edge(const DevSpec& sp, const Topo& tp, int u, int v) {   // network.py:224-231
+  return dev_nbr_slot(sp, tp, u, v) >= 0;
 }
 
 // Network.send checks (network.py:246-252, 297-331); returns PHX_ERR_* (0 = deliverable)
-__device__ __forceinline__ int dev_send_check(const DevSpec& sp, int src, int dst, int type) {
-  if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, src, dst)) return PHX_ERR_NETWORK;
+__device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp, int src, int dst, int type) {
+  if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, tp, src, dst)) return PHX_ERR_NETWORK;
   if (!(sp.flags & PHX_F_NO_PAYLOAD_CHECKS)) {
     int sk, rk, dec;
     dev_payload_types(type, sk, rk, dec);
     if (!dec) return PHX_ERR_PAYLOAD;
-    if (sk && sp.kind[src] != sk) return PHX_ERR_PAYLOAD;
-    if (rk && sp.kind[dst] != rk) return PHX_ERR_PAYLOAD;
+    if (sk && tp.kind[src] != sk) return PHX_ERR_PAYLOAD;
+    if (rk && tp.kind[dst] != rk) return PHX_ERR_PAYLOAD;
   }
   return 0;
 }
@@ -285,16 +308,16 @@ struct AgentRef {          // where one agent's state lives for env b
   int64_t base;            // b * kind_count[kind] + kr
 };
 
-__device__ __forceinline__ AgentRef agent_ref(const DevSpec& sp, int b, int a) {
+__device__ __forceinline__ AgentRef agent_ref(const DevSpec& sp, const Topo& tp, int b, int a) {
   AgentRef r;
-  r.a = a; r.kind = sp.kind[a]; r.kr = sp.kind_rank[a];
+  r.a = a; r.kind = tp.kind[a]; r.kr = tp.kind_rank[a];
   r.base = (int64_t)b * sp.kind_count[r.kind] + r.kr;
   return r;
 }
 
 // Agent.reset and subclasses (agents.py:160-175; supply_chain.py:149-150; test_network.py:23-24)
-__device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, int b, int a) {
-  const AgentRef r = agent_ref(sp, b, a);
+__device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, const Topo& tp, int b, int a) {
+  const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
     case PHX_KIND_SHOP: fld<int32_t>(sp, F_SHOP_STOCK)[r.base] = 0; break;
     case PHX_KIND_CASHBOX: fld<double>(sp, F_CASHBOX_TOTAL)[r.base] = 0.0; break;
@@ -304,8 +327,8 @@ __device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, int b, int a)
       fld<int32_t>(sp, F_SELLER_TX)[r.base] = 0;
       break;
     case PHX_KIND_BUYER: {
-      const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
-      double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
+      const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
+      double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + tp.buyer_off[a];
       for (int k = 0; k < deg; ++k) pr[(int64_t)k * sp.buyer_stride] = 1.0;
       fld<double>(sp, F_BUYER_PAID)[r.base] = 0.0;
       fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
@@ -316,26 +339,26 @@ __device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, int b, int a)
 }
 
 // encode_observation of a strategic agent; `step` is ctx.env_view.current_step
-__device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, int b, int a, int step, float* o) {
-  const AgentRef r = agent_ref(sp, b, a);
+__device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, const Topo& tp, int b, int a, int step, float* o) {
+  const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
     case PHX_KIND_SHOP:
       shop_obs(fld<int32_t>(sp, F_SHOP_STOCK)[r.base], fld<int32_t>(sp, F_SHOP_SALES)[r.base],
-               fld<int32_t>(sp, F_SHOP_MISSED)[r.base], sp.param_i[a * PHX_NPI + 1], o);
+               fld<int32_t>(sp, F_SHOP_MISSED)[r.base], tp.param_i[a * PHX_NPI + 1], o);
       break;
     case PHX_KIND_SELLER: {
-      const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
+      const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
       o[0] = (float)((double)fld<int32_t>(sp, F_SELLER_TX)[r.base] / (double)deg);
       o[1] = (float)fld<double>(sp, F_SELLER_PRICE)[r.base];
       break;
     }
     case PHX_KIND_BUYER: {
-      const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
-      const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
+      const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
+      const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + tp.buyer_off[a];
       double mn = pr[0];
       for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; mn = v < mn ? v : mn; }
       o[0] = (float)mn;
-      o[1] = (float)sp.param_f[a * PHX_NPF];
+      o[1] = (float)tp.param_f[a * PHX_NPF];
       break;
     }
     case PHX_KIND_MOCK_STRAT:                                  // tests/__init__.py:49-51
@@ -346,22 +369,22 @@ __device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, int b, int a, 
   }
 }
 
-__device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, int b, int a) {
-  const AgentRef r = agent_ref(sp, b, a);
+__device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, const Topo& tp, int b, int a) {
+  const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
     case PHX_KIND_SHOP:
       return shop_reward(fld<int32_t>(sp, F_SHOP_SALES)[r.base], fld<int32_t>(sp, F_SHOP_STOCK)[r.base]);
     case PHX_KIND_SELLER: return fld<double>(sp, F_SELLER_REVENUE)[r.base];
     case PHX_KIND_BUYER:
       if (fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base])
-        return __dsub_rn(sp.param_f[a * PHX_NPF], fld<double>(sp, F_BUYER_PAID)[r.base]);
+        return __dsub_rn(tp.param_f[a * PHX_NPF], fld<double>(sp, F_BUYER_PAID)[r.base]);
       return 0.0;
     case PHX_KIND_MOCK_STRAT: fld<int32_t>(sp, F_MOCK_REW)[r.base] += 1; return 0.0;
     default: return 0.0;
   }
 }
 
-__device__ __forceinline__ bool dev_is_done(const DevSpec& sp, int a, int step) {
+__device__ __forceinline__ bool dev_is_done(const DevSpec& sp, const Topo& tp, int a, int step) {
   // is_terminated == is_truncated for the only kind that overrides them (tests/__init__.py:61-65)
-  return sp.kind[a] == PHX_KIND_MOCK_STRAT && step == sp.param_i[a * PHX_NPI];
+  return tp.kind[a] == PHX_KIND_MOCK_STRAT && step == tp.param_i[a * PHX_NPI];
 }

@@ -8,7 +8,7 @@
 // One workgroup per env.  `live` = agent has a context this step (NULL: every agent is live).
 // s_nterm / s_ntrunc: zero-initialised LDS counters.  Contains a __syncthreads().
 template <int NT>
-__device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const phx_step_io& io, int b, int t,
+__device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
                                                    int list, int cur_stage, uint32_t tick,
                                                    const uint8_t* live, int* s_nterm, int* s_ntrunc) {
   const int tid = threadIdx.x;
@@ -32,10 +32,10 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const phx_
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
     if (!live || live[a]) {                                    // env.py:274-275
       dv = 1;
-      if (obs_mask[a]) { dev_encode_obs(sp, b, a, t, ob); ov = 1; }
-      if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, b, a); rv = 1; }
-      else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, b, a); rew_cache_v[s] = 1; }
-      tm = tr = dev_is_done(sp, a, t) ? 1 : 0;                 // env.py:285-286
+      if (obs_mask[a]) { dev_encode_obs(sp, tp, b, a, t, ob); ov = 1; }
+      if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, tp, b, a); rv = 1; }
+      else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, tp, b, a); rew_cache_v[s] = 1; }
+      tm = tr = dev_is_done(sp, tp, a, t) ? 1 : 0;                 // env.py:285-286
       if (tm) { term[s] = 1; trunc[s] = 1; }                   // :288-292
     }
     if (term[s]) atomicAdd(s_nterm, 1);

@@ -64,21 +64,21 @@ __device__ __forceinline__ void set_errkey(int* errkey, int seq, int code) {
 }
 
 // ---- acting phase: decode_action (env.py:330-331) / generate_messages (:332-333) -------------
-__device__ __forceinline__ int act_count(const DevSpec& sp, int b, int a, bool has_action, float action) {
-  switch (sp.kind[a]) {
+__device__ __forceinline__ int act_count(const DevSpec& sp, const Topo& tp, int b, int a, bool has_action, float action) {
+  switch (tp.kind[a]) {
     case PHX_KIND_SHOP: return has_action ? 1 : 0;
     case PHX_KIND_CUSTOMER: return 1;
-    case PHX_KIND_SELLER: return has_action ? sp.row_ptr[a + 1] - sp.row_ptr[a] : 0;
-    case PHX_KIND_BUYER: return (has_action && action > 0.5f && sp.row_ptr[a + 1] > sp.row_ptr[a]) ? 1 : 0;
+    case PHX_KIND_SELLER: return has_action ? tp.row_ptr[a + 1] - tp.row_ptr[a] : 0;
+    case PHX_KIND_BUYER: return (has_action && action > 0.5f && tp.row_ptr[a + 1] > tp.row_ptr[a]) ? 1 : 0;
     default: return 0;
   }
 }
 
 template <typename Q>
-__device__ __forceinline__ void act_emit(const DevSpec& sp, int b, int a, bool has_action, float action,
+__device__ __forceinline__ void act_emit(const DevSpec& sp, const Topo& tp, int b, int a, bool has_action, float action,
                                          const uint8_t* exo_b, uint32_t tick, Q* out) {
-  const AgentRef r = agent_ref(sp, b, a);
-  const int32_t* pi = sp.param_i + a * PHX_NPI;
+  const AgentRef r = agent_ref(sp, tp, b, a);
+  const int32_t* pi = tp.param_i + a * PHX_NPI;
   DevMsg m;
   m.src = (uint16_t)a; m.pad = 0;
   switch (r.kind) {
@@ -92,8 +92,8 @@ __device__ __forceinline__ void act_emit(const DevSpec& sp, int b, int a, bool h
       break;
     case PHX_KIND_CUSTOMER: {                                  // supply_chain.py:61-67
       int order;
-      if (exo_b) order = exo_b[sp.exo_rank[a]];
-      else order = rng_shop_orders(sp.seed, sp.env_offset + b, tick, sp.kind_rank[pi[0]], pi[1] + 1,
+      if (exo_b) order = exo_b[tp.exo_rank[a]];
+      else order = rng_shop_orders(sp.seed, sp.env_offset + b, tick, tp.kind_rank[pi[0]], pi[1] + 1,
                                    nullptr, pi[1]);
       m.dst = (uint16_t)pi[0]; m.type = PHX_MSG_ORDER_REQUEST; m.p.i = order;
       out[0] = m;
@@ -104,20 +104,20 @@ __device__ __forceinline__ void act_emit(const DevSpec& sp, int b, int a, bool h
         const double price = (double)action;
         fld<double>(sp, F_SELLER_PRICE)[r.base] = price;
         m.type = PHX_MSG_PRICE; m.p.f = price;
-        const int lo = sp.row_ptr[a], hi = sp.row_ptr[a + 1];
-        for (int k = lo; k < hi; ++k) { m.dst = (uint16_t)sp.col[k]; out[k - lo] = m; }
+        const int lo = tp.row_ptr[a], hi = tp.row_ptr[a + 1];
+        for (int k = lo; k < hi; ++k) { m.dst = (uint16_t)tp.col[k]; out[k - lo] = m; }
       }
       break;
     case PHX_KIND_BUYER:
       if (has_action) {
-        const int deg = sp.row_ptr[a + 1] - sp.row_ptr[a];
+        const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
         if (action > 0.5f && deg > 0) {
-          const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + sp.buyer_off[a];
+          const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + tp.buyer_off[a];
           int j = 0; double best = pr[0];
           for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (v < best) { best = v; j = k; } }
           fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 1;
           fld<double>(sp, F_BUYER_PAID)[r.base] = best;
-          m.dst = (uint16_t)sp.col[sp.row_ptr[a] + j]; m.type = PHX_MSG_ORDER; m.p.i = 1;
+          m.dst = (uint16_t)tp.col[tp.row_ptr[a] + j]; m.type = PHX_MSG_ORDER; m.p.i = 1;
           out[0] = m;
         } else {
           fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
@@ -132,8 +132,8 @@ __device__ __forceinline__ void act_emit(const DevSpec& sp, int b, int a, bool h
   }
 }
 
-__device__ __forceinline__ void pre_resolution(const DevSpec& sp, int b, int a, int step) {
-  const AgentRef r = agent_ref(sp, b, a);
+__device__ __forceinline__ void pre_resolution(const DevSpec& sp, const Topo& tp, int b, int a, int step) {
+  const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
     case PHX_KIND_SHOP:                                        // supply_chain.py:93-96
       fld<int32_t>(sp, F_SHOP_SALES)[r.base] = 0;
@@ -151,10 +151,10 @@ __device__ __forceinline__ void pre_resolution(const DevSpec& sp, int b, int a, 
 
 // Agent.handle_message (agents.py:122-155): returns true and fills `resp` (dst/type/payload)
 // when the handler answers; sets `code` to PHX_ERR_UNKNOWN_MSG for an unhandled payload type.
-__device__ __forceinline__ bool handle_message(const DevSpec& sp, int b, int a, const DevMsg& m,
+__device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp, int b, int a, const DevMsg& m,
                                                int clock, DevMsg& resp, int& code) {
-  const AgentRef r = agent_ref(sp, b, a);
-  const int32_t* pi = sp.param_i + a * PHX_NPI;
+  const AgentRef r = agent_ref(sp, tp, b, a);
+  const int32_t* pi = tp.param_i + a * PHX_NPI;
   resp.src = (uint16_t)a; resp.dst = m.src; resp.pad = 0; resp.type = 0;
   switch (r.kind) {
     case PHX_KIND_FACTORY:
@@ -195,9 +195,9 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, int b, int a, 
       break;
     case PHX_KIND_BUYER:
       if (m.type == PHX_MSG_PRICE) {
-        const int slot = dev_nbr_slot(sp, a, m.src);
+        const int slot = dev_nbr_slot(sp, tp, a, m.src);
         if (slot >= 0)
-          fld<double>(sp, F_BUYER_PRICES)[(int64_t)b * sp.buyer_nnz + sp.buyer_off[a] + (int64_t)slot * sp.buyer_stride] = m.p.f;
+          fld<double>(sp, F_BUYER_PRICES)[(int64_t)b * sp.buyer_nnz + tp.buyer_off[a] + (int64_t)slot * sp.buyer_stride] = m.p.f;
         return false;
       }
       break;
@@ -232,12 +232,18 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, int b, int a, 
   return false;
 }
 
-template <int NT, bool LDSQ>
+template <int NT, bool LDSQ, bool TABLDS>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, const GenArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   __shared__ int wave_sums[NT / 64];
   __shared__ int s_errkey, s_nterm, s_ntrunc;
+#ifdef PHX_TIMING
+  unsigned long long gtm[16] = {0}, gprev = __builtin_readcyclecounter();
+#define GTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
+#else
+#define GTICK(k) do {} while (0)
+#endif
 
   const int b = blockIdx.x, tid = threadIdx.x;
   const int A = sp.A, S = sp.S, Q = sp.queue_cap;
@@ -253,6 +259,29 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   int* first = cnt + A;
   int* goff = first + A;
   uint8_t* live = (uint8_t*)(goff + A);
+
+  // static topology tables: LDS copies behind the queues (TABLDS) or the global arrays
+  Topo tp = topo_global(sp);
+  if (TABLDS) {
+    char* tb = smem + g.tab_off;
+    const int nnz = sp.nnz;
+    int32_t* t_row = (int32_t*)tb;            tb += ((A + 1) * 4 + 15) & ~15;
+    int32_t* t_col = (int32_t*)tb;            tb += (nnz * 4 + 15) & ~15;
+    int32_t* t_pi = (int32_t*)tb;             tb += (A * PHX_NPI * 4 + 15) & ~15;
+    int32_t* t_sr = (int32_t*)tb;             tb += (A * 4 + 15) & ~15;
+    int32_t* t_kr = (int32_t*)tb;             tb += (A * 4 + 15) & ~15;
+    int32_t* t_xr = (int32_t*)tb;             tb += (A * 4 + 15) & ~15;
+    uint8_t* t_kind = (uint8_t*)tb;
+    for (int k = threadIdx.x; k <= A; k += NT) t_row[k] = sp.row_ptr[k];
+    for (int k = threadIdx.x; k < nnz; k += NT) t_col[k] = sp.col[k];
+    for (int k = threadIdx.x; k < A * PHX_NPI; k += NT) t_pi[k] = sp.param_i[k];
+    for (int k = threadIdx.x; k < A; k += NT) {
+      t_sr[k] = sp.strat_rank[k]; t_kr[k] = sp.kind_rank[k]; t_xr[k] = sp.exo_rank[k]; t_kind[k] = sp.kind[k];
+    }
+    tp.row_ptr = t_row; tp.col = t_col; tp.param_i = t_pi; tp.strat_rank = t_sr; tp.kind_rank = t_kr;
+    tp.exo_rank = t_xr; tp.kind = t_kind;
+    __syncthreads();
+  }
 
   int32_t* step_p = fld<int32_t>(sp, F_ENV_STEP) + b;
   int32_t* stage_p = fld<int32_t>(sp, F_ENV_STAGE) + b;
@@ -271,10 +300,11 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   if (tid == 0) { s_errkey = ERRKEY_NONE; s_nterm = 0; s_ntrunc = 0; }
   // _make_ctxs (env.py:338-348): contexts only for agents that are not done
   for (int a = tid; a < A; a += NT) {
-    const int s = sp.strat_rank[a];
+    const int s = tp.strat_rank[a];
     live[a] = (g.resolve_only || s < 0) ? 1 : !(term[s] | trunc[s]);
   }
   __syncthreads();
+  GTICK(0);
 
   // ---- round-0 queue: host-injected sends, then the acting agents in list order -------------
   const int n_act = full ? sp.act_ptr[list + 1] - sp.act_ptr[list] : 0;
@@ -289,19 +319,20 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     int c = 0;
     if (it < g.n_inject) {
       const DevMsg m = g.inject[it];
-      const int code = dev_send_check(sp, m.src, m.dst, m.type);
+      const int code = dev_send_check(sp, tp, m.src, m.dst, m.type);
       if (code) set_errkey(&s_errkey, it, code); else c = 1;
     } else {
       const int a = act_list[it - g.n_inject];
       if (live[a]) {                                           // env.py:324-325
-        const int s = sp.strat_rank[a];
+        const int s = tp.strat_rank[a];
         const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);        // aid in actions, env.py:330
-        c = act_count(sp, b, a, has, has ? actions_b[s] : 0.0f);
+        c = act_count(sp, tp, b, a, has, has ? actions_b[s] : 0.0f);
       }
     }
     scanbuf[it] = c;
   }
   __syncthreads();
+  GTICK(1);
   int n = block_exscan<NT>(scanbuf, n_items, wave_sums);
   if (n > Q) { if (tid == 0) set_errkey(&s_errkey, n_items, PHX_ERR_QUEUE_FULL); n = 0; }
   else {
@@ -309,31 +340,33 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
       const int off = scanbuf[it];
       if (it < g.n_inject) {
         const DevMsg m = g.inject[it];
-        if (dev_send_check(sp, m.src, m.dst, m.type) == 0) q0[off] = m;
+        if (dev_send_check(sp, tp, m.src, m.dst, m.type) == 0) q0[off] = m;
       } else {
         const int a = act_list[it - g.n_inject];
         if (live[a]) {
-          const int s = sp.strat_rank[a];
+          const int s = tp.strat_rank[a];
           const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);
           // decode_action's state mutation happens exactly once, here; an agent that sends
           // nothing writes nothing
-          act_emit(sp, b, a, has, has ? actions_b[s] : 0.0f, exo_b, tick, q0 + off);
+          act_emit(sp, tp, b, a, has, has ? actions_b[s] : 0.0f, exo_b, tick, q0 + off);
         }
       }
     }
   }
   __syncthreads();
+  GTICK(2);
   // acting-phase sends are checked like any Network.send (static topologies always pass)
   for (int i = tid; i < n; i += NT) {
     const DevMsg m = q0[i];
-    const int code = dev_send_check(sp, m.src, m.dst, m.type);
+    const int code = dev_send_check(sp, tp, m.src, m.dst, m.type);
     if (code) { set_errkey(&s_errkey, g.n_inject + i, code); q0[i].type = 0; }
   }
   __syncthreads();
+  GTICK(3);
 
   // pre_message_resolution for every live agent (env.py:170-173)
   if (full)
-    for (int a = tid; a < A; a += NT) if (live[a]) pre_resolution(sp, b, a, t);
+    for (int a = tid; a < A; a += NT) if (live[a]) pre_resolution(sp, tp, b, a, t);
 
   phx_msg_rec* log_b = g.io.msg_log ? g.io.msg_log + (int64_t)b * sp.trace_cap : nullptr;
   if (log_b)                                                    // Resolver.push tracking, resolvers.py:41-42
@@ -346,6 +379,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   int seq_base = n_items;          // error ordering key continues after the acting items
   int clock = clock0;
   __syncthreads();
+  GTICK(4);
 
   // ---- BatchResolver.resolve round loop (resolvers.py:128-163) ---------------------------------
   DevMsg* qc = q0; DevMsg* qn = q1;
@@ -353,26 +387,31 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   while (n > 0 && (sp.round_limit < 0 || round < sp.round_limit)) {
     for (int a = tid; a < A; a += NT) { cnt[a] = 0; first[a] = 0x7fffffff; }
     __syncthreads();
+    GTICK(5);
     for (int i = tid; i < n; i += NT) {
       const int d = qc[i].dst;
       slot[i] = atomicAdd(&cnt[d], 1);
       atomicMin(&first[d], i);
     }
     __syncthreads();
+    GTICK(6);
     // receivers in dict (first-arrival) order -> inbox offsets
     for (int i = tid; i < n; i += NT) {
       const int d = qc[i].dst;
       scanbuf[i] = (first[d] == i) ? cnt[d] : 0;
     }
     __syncthreads();
+    GTICK(7);
     block_exscan<NT>(scanbuf, n, wave_sums);
     for (int i = tid; i < n; i += NT) {
       const int d = qc[i].dst;
       if (first[d] == i) goff[d] = scanbuf[i];
     }
     __syncthreads();
+    GTICK(8);
     for (int i = tid; i < n; i += NT) order[goff[qc[i].dst] + slot[i]] = i;
     __syncthreads();
+    GTICK(9);
     // one lane per receiver: batch in send order, handled one message at a time (agents.py:96-120)
     for (int a = tid; a < A; a += NT) {
       const int c = cnt[a];
@@ -391,12 +430,12 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
         // or a send that already failed its checks (type 0)
         // the receive-side edge filter can only drop something when sends skipped the edge
         // check (ignore_connection_errors): every queued message already passed has_edge
-        if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, m.src, m.dst))) {
+        if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
           int code = 0;
-          const bool answered = handle_message(sp, b, a, m, clock + P, out, code);
+          const bool answered = handle_message(sp, tp, b, a, m, clock + P, out, code);
           if (code) set_errkey(&s_errkey, seq_base + P, code);
           if (answered) {                                       // network.send(receiver, sub_receiver, payload) :156-158
-            const int sc = dev_send_check(sp, out.src, out.dst, out.type);
+            const int sc = dev_send_check(sp, tp, out.src, out.dst, out.type);
             if (sc) { set_errkey(&s_errkey, seq_base + P, sc); out.type = 0; }
           } else out.type = 0;
         }
@@ -405,6 +444,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
       }
     }
     __syncthreads();
+    GTICK(10);
     const int n_next = block_exscan<NT>(scanbuf, n, wave_sums);
     for (int P = tid; P < n; P += NT)
       if (resp[P].type != 0) {
@@ -416,12 +456,14 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
         }
       }
     __syncthreads();
+    GTICK(11);
     log_n += n_next; seq_base += n; clock += n;
     n = n_next; ++round;
     DevMsg* tq = qc; qc = qn; qn = tq;
   }
   if (n > 0 && tid == 0) set_errkey(&s_errkey, seq_base + 1, PHX_ERR_ROUND_LIMIT);   // resolvers.py:160-163
   __syncthreads();
+  GTICK(12);
 
   if (tid == 0) {
     fld<int32_t>(sp, F_ENV_CLOCK)[b] = clock;
@@ -430,7 +472,12 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   }
   if (g.resolve_only) return;
 
-  strategic_epilogue<NT>(sp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc);
+  GTICK(13);
+  strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc);
+  GTICK(14);
+#ifdef PHX_TIMING
+  if (g.timing && threadIdx.x == 0) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
+#endif
 }
 
 // ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------
@@ -440,7 +487,8 @@ __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const u
   const int b = blockIdx.x, tid = threadIdx.x;
   if (mask && !mask[b]) return;
   const int A = sp.A, S = sp.S, D = sp.D;
-  for (int a = tid; a < A; a += NT) dev_agent_reset(sp, b, a);          // network.py:183-184
+  const Topo tp = topo_global(sp);
+  for (int a = tid; a < A; a += NT) dev_agent_reset(sp, tp, b, a);          // network.py:183-184
   for (int s = tid; s < S; s += NT) {
     fld<uint8_t>(sp, F_ENV_TERM)[(int64_t)b * S + s] = 0;               // env.py:223-224
     fld<uint8_t>(sp, F_ENV_TRUNC)[(int64_t)b * S + s] = 0;
@@ -455,10 +503,10 @@ __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const u
   __syncthreads();
   if (!obs) return;
   for (int k = tid; k < sp.n_reset_obs; k += NT) {                      // env.py:227-237
-    const int a = sp.reset_obs_idx[k], s = sp.strat_rank[a];
+    const int a = sp.reset_obs_idx[k], s = tp.strat_rank[a];
     if (s < 0) continue;
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
-    dev_encode_obs(sp, b, a, 0, ob);
+    dev_encode_obs(sp, tp, b, a, 0, ob);
     for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = ob[d];
     if (obs_valid) obs_valid[(int64_t)b * S + s] = 1;
   }
@@ -470,14 +518,29 @@ size_t phx_generic_queue_bytes(int A, int Q, int scan_cap) {
          (size_t)A * 3 * sizeof(int) + (size_t)((A + 15) & ~15);
 }
 
-hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st) {
-  const size_t bytes = phx_generic_queue_bytes(sp.A, sp.queue_cap, sp.scan_cap);
+size_t phx_generic_table_bytes(int A, int nnz) {
+  return (size_t)(((A + 1) * 4 + 15) & ~15) + (size_t)((nnz * 4 + 15) & ~15) + (size_t)((A * PHX_NPI * 4 + 15) & ~15) +
+         3 * (size_t)((A * 4 + 15) & ~15) + (size_t)((A + 15) & ~15);
+}
+
+hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
+  GenArgs g = g_;
+  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.queue_cap, sp.scan_cap) + 15) & ~(size_t)15;
+  const size_t tab = phx_generic_table_bytes(sp.A, sp.nnz);
+  const bool tablds = lds && tab <= 24 * 1024 && bytes + tab <= 60 * 1024;
+  g.tab_off = (int32_t)bytes;
+  if (tablds) bytes += tab;
   const int big = (sp.A > 64 || sp.queue_cap > 64);
   if (lds) {
-    if (big) hipLaunchKernelGGL((phx_generic_step_kernel<256, true>), dim3(sp.B), dim3(256), bytes, st, sp, g);
-    else hipLaunchKernelGGL((phx_generic_step_kernel<64, true>), dim3(sp.B), dim3(64), bytes, st, sp, g);
+    if (tablds) {
+      if (big) hipLaunchKernelGGL((phx_generic_step_kernel<256, true, true>), dim3(sp.B), dim3(256), bytes, st, sp, g);
+      else hipLaunchKernelGGL((phx_generic_step_kernel<64, true, true>), dim3(sp.B), dim3(64), bytes, st, sp, g);
+    } else {
+      if (big) hipLaunchKernelGGL((phx_generic_step_kernel<256, true, false>), dim3(sp.B), dim3(256), bytes, st, sp, g);
+      else hipLaunchKernelGGL((phx_generic_step_kernel<64, true, false>), dim3(sp.B), dim3(64), bytes, st, sp, g);
+    }
   } else {
-    hipLaunchKernelGGL((phx_generic_step_kernel<256, false>), dim3(sp.B), dim3(256), 0, st, sp, g);
+    hipLaunchKernelGGL((phx_generic_step_kernel<256, false, false>), dim3(sp.B), dim3(256), 0, st, sp, g);
   }
   return hipGetLastError();
 }

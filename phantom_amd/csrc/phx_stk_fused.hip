@@ -19,6 +19,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   __shared__ int s_nterm, s_ntrunc;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int A = sp.A, S = sp.S;
+  const Topo tp = topo_global(sp);
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
   double* s_price = (double*)smem;                       // [nSell] price posted this step
   int* s_count = (int*)(s_price + nSell);                // [nSell] orders received this step
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     const bool has = actions_b && (!av_b || av_b[s]);                        // aid in actions
     if (!has) continue;
     const float action = actions_b[s];
-    const AgentRef r = agent_ref(sp, b, a);
+    const AgentRef r = agent_ref(sp, tp, b, a);
     if (r.kind == PHX_KIND_SELLER) {
       const double price = (double)action;
       fld<double>(sp, F_SELLER_PRICE)[r.base] = price;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   __syncthreads();
   // ---- pre_message_resolution + the single round -------------------------------------------------
   for (int a = tid; a < A; a += STK_NT) {
-    const AgentRef r = agent_ref(sp, b, a);
+    const AgentRef r = agent_ref(sp, tp, b, a);
     if (r.kind == PHX_KIND_SELLER) {
       double rev = fld<double>(sp, F_SELLER_REVENUE)[r.base];
       int tx = fld<int32_t>(sp, F_SELLER_TX)[r.base];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     }
   }
   __syncthreads();
-  strategic_epilogue<STK_NT>(sp, io, b, t, list, 0, tick, nullptr, &s_nterm, &s_ntrunc);
+  strategic_epilogue<STK_NT>(sp, tp, io, b, t, list, 0, tick, nullptr, &s_nterm, &s_ntrunc);
 }
 
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
