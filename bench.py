@@ -103,7 +103,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the PhantomEnv.step() path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PHX_BENCH_FORCE_DIST"):
+        # one process per GPU over RCCL (backend "nccl" on ROCm); also taken with a single rank
+        # under torchrun so that the collective path can be exercised on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -168,7 +170,7 @@ def main():
     achieved = alg / (launch_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.config == "sc64" and B == BATCH:
         try:
             traffic = json.load(open(pmc)).get("phx_sc_rollout_kernel", {}).get("hbm_bytes_per_launch")
         except Exception:
@@ -241,16 +243,15 @@ def main():
 
     # ---- rollout collection exchange (BASELINE config 4's RCCL all-gather), outside `value` ------
     if dist is not None:
+        from phantom_amd.distributed import all_gather_trajectory
         payload = [traj.observations, traj.actions, traj.rewards, traj.terminations, traj.truncations]
-        outs = [torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device) for x in payload]
-        for x, o in zip(payload, outs):
-            dist.all_gather_into_tensor(o, x)
+        outs = all_gather_trajectory(payload)                  # allocates [world, T, B, ...] once
         sync_barrier()
         t0 = time.perf_counter()
-        for x, o in zip(payload, outs):
-            dist.all_gather_into_tensor(o, x)
+        all_gather_trajectory(payload, out=outs)
         sync_barrier()
         ag = time.perf_counter() - t0
+        assert torch.equal(outs[0][rank], payload[0])            # own shard lands in its slot
         nbytes = sum(x.numel() * x.element_size() for x in payload)
         out["rollout_allgather"] = {"ms": ag * 1e3, "bytes_per_rank": nbytes,
                                     "recv_GBps_per_rank": nbytes * (world - 1) / ag / 1e9,

@@ -170,73 +170,6 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
   }
 }
 
-// ---- fused rollout: T steps per launch, shop state in registers, only the trajectory
-//      streams to HBM.  PLAIN env; auto-reset at episode end (env.py:185-237 folded in). --------
-__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_v1_kernel(const DevSpec sp, const phx_rollout_io io,
-                                                               const int epb) {
-  const int nS = sp.S;
-  const int64_t total = (int64_t)sp.B * nS;
-  const int64_t b_first = (int64_t)blockIdx.x * epb;
-  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
-  const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
-  const int64_t g = b_first * nS + threadIdx.x;
-  const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
-  const int s = active ? (int)(threadIdx.x % nS) : 0;
-  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
-  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-  __syncthreads();          // per-env words are rewritten by the env's shop-0 lane at the end
-  if (!active) return;
-  const int a_shop = sp.shop_agent[s];
-  const int norm = sp.param_i[a_shop * PHX_NPI + 1];
-  const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
-  const int K = c_hi - c_lo;
-  const int64_t genv = sp.env_offset + b;
-
-  ShopLane st;
-  st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
-  st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
-  st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g];
-  st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
-  float ob[3] = {0.f, 0.f, 0.f};
-
-  for (int t = 0; t < io.T; ++t) {
-    const int64_t o = (int64_t)t * total + g;
-    int D = 0;
-    uint32_t w3 = 0;
-    if (io.exo) {
-      const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
-      for (int k = c_lo; k < c_hi; ++k) D += row[sp.shop_cust_exo[k]];
-      if (!io.actions) rng_shop_orders(sp.seed, genv, tick, s, 0, nullptr, -1, &w3);
-    } else {
-      D = rng_shop_orders(sp.seed, genv, tick, s, K, nullptr, -1, &w3);
-    }
-    const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
-    sc_shop_step(st, true, action, K > 0, D);
-    ++step; ++tick;
-    const bool all_trunc = (step == sp.num_steps);
-    shop_obs(st.stock, st.sales, st.missed, norm, ob);
-    const double rw = shop_reward(st.sales, st.stock);
-    io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
-    io.action_out[o] = action;
-    io.reward[o] = (float)rw;
-    io.terminated[o] = 0;
-    io.truncated[o] = all_trunc;
-    if (all_trunc) {                                             // the caller's env.reset(): stock only
-      st.stock = 0; step = 0;                                    // supply_chain.py:149-150
-      shop_obs(st.stock, st.sales, st.missed, norm, ob);         // sales/missed stay stale
-    }
-  }
-  fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock;
-  fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
-  fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed;
-  fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
-  if (io.last_obs) { io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2]; }
-  if (s == 0) {
-    fld<int32_t>(sp, F_ENV_STEP)[b] = step;
-    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
-  }
-}
-
 // ---- rollout v2: time-parallel.  The only sequential dependence of an episode is the stock
 // recurrence  stock' = min(stock - min(D, stock) + min(R, 100 - stock), 100)  (a dozen integer
 // ops); everything expensive -- the Philox draws, the IEEE divisions of the observation, the
@@ -511,12 +444,6 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
 }
 
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
-  static const bool use_v1 = getenv("PHX_ROLLOUT_V1") != nullptr;     // A/B against the lane-per-shop loop
-  if (use_v1) {
-    const int epb = SC_NT / sp.S;
-    hipLaunchKernelGGL(phx_sc_rollout_v1_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), 0, st, sp, io, epb);
-    return hipGetLastError();
-  }
   // ~64 pairs per block (one wave in the sequential phase), TC steps so that the item table
   // stays around 36 KB; 1024-thread blocks put 16 time rows in flight per block
   RollArgs a;

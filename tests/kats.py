@@ -248,7 +248,23 @@ def kat_payload_whitelist(make_runner):
     assert run.err[0] == _abi.ERR_PAYLOAD
 
 
-ALL_KATS = [kat_tracking, kat_call_response, kat_ordering, kat_round_limit,
+def kat_ignore_connection_errors(make_runner):
+    """Network(ignore_connection_errors=True): a send along a missing edge is queued (and
+    tracked) but the receiver's batch filter drops it (network.py:246-249, resolvers.py:146-148)."""
+    net = ph.Network([ph.ForwarderAgent("A"), ph.ForwarderAgent("B", target="C"), ph.HalverAgent("C")],
+                     ph.BatchResolver(enable_tracking=True), ignore_connection_errors=True,
+                     enforce_msg_payload_checks=False)
+    net.add_connection("A", "B")
+    run = make_runner(_net_spec(net))
+    run.inject([Message("A", "B", ph.Request(0.0))])
+    run.resolve()
+    assert run.err[0] == 0
+    log = log_matrix(run.log(0))
+    # A->B Request, then B's forward to C along the missing edge: pushed, never handled
+    assert log[:, :3].tolist() == [[0, 1, _abi.MSG_REQUEST], [1, 2, _abi.MSG_PING]]
+
+
+ALL_KATS = [kat_ignore_connection_errors, kat_tracking, kat_call_response, kat_ordering, kat_round_limit,
             kat_invalid_response_connection, kat_unknown_message_type, kat_env_step,
             kat_fsm_odd_even_two_agents, kat_fsm_odd_even_one_agent, kat_fsm_one_state,
             kat_stackelberg, kat_payload_whitelist]

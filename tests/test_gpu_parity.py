@@ -394,3 +394,33 @@ def test_metrics_and_rllib_adapters():
     assert sub.agents["SHOP1"].stock == int(o.get_i32("shop.stock")[4, 1])
     obs1, _ = base.try_reset(1)
     assert list(obs1) == [1] and env.current_step.tolist() == [5, 0, 5, 5, 5, 5]
+
+
+@pytest.mark.parametrize("S,K,B,T,num_steps", [
+    (51, 4, 18, 130, 100),      # SC256 topology: 204-pair blocks, B not a multiple of the block's env count
+    (9, 6, 13, 75, 30),         # tail block + several episode ends per fragment
+    (1, 5, 300, 40, 7),         # the shipped SC7 shape, many envs per block, num_steps < chunk length
+    (3, 2, 64, 33, 100),        # tiny shops
+    (64, 1, 8, 20, 10),         # one block-row wider than a wave
+])
+def test_rollout_shapes_match_oracle(S, K, B, T, num_steps):
+    """every launch geometry of the rollout kernel (wide / narrow copy-out, tail blocks, replay and
+    device-RNG variants) against the oracle."""
+    rng = np.random.RandomState(S * 1000 + B)
+    for mode in ("device_rng", "replay"):
+        env = supply_chain_env(S, [K] * S, num_steps, B, seed=5, env_offset=123)
+        o, d = OracleEnv(env.spec), _dev(env.spec)
+        o.reset(); d.reset()
+        acts = exo = None
+        if mode == "replay":
+            acts = rng.uniform(-10, 130, (T, B, S)).astype(np.float32)
+            exo = rng.randint(0, 5, (T, B, S * K)).astype(np.uint8)
+        ro, rd = o.rollout(T, acts, exo), d.rollout(T, acts, exo)
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"{k} {mode}")
+        np.testing.assert_array_equal(rd["truncated"], ro["truncated"], err_msg=mode)
+        np.testing.assert_array_equal(rd["terminated"], ro["terminated"])
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} {mode}")
+        ro2, rd2 = o.rollout(5, None, None), d.rollout(5, None, None)       # fragments chain
+        np.testing.assert_array_equal(f32_bits(rd2["obs"]), f32_bits(ro2["obs"]))
