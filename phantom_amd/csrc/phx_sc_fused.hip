@@ -219,7 +219,7 @@ __device__ __forceinline__ void lds_barrier() {
 // WIDE:   every block owns exactly epb envs and every tile row is 16-byte aligned (host-checked),
 //         so the copy-out uses dwordx4 / dwordx2 stores and magic-number row arithmetic only.
 template <int NT, bool REPLAY, bool WIDE>
-__global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
+__global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(const RollArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PHX_TIMING
   unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -396,13 +396,13 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_kernel(const RollArgs a) {
       }
     }
     if (WIDE) {
-      const int ncu = G >> 3;                                     // 8-byte chunks per row
+      const int ncu = G >> 2;                                     // 4-byte chunks per row
       for (int idx = tid; idx < tc * ncu; idx += NT) {
         const int r = (int)__umulhi((uint32_t)idx, a.mU);
         const int c = idx - r * ncu;
-        const int64_t o = row0 + (int64_t)r * rstride + c * 8;
-        *(uint2*)(io.truncated + o) = *(const uint2*)(s_trunc + r * G + c * 8);
-        *(uint2*)(io.terminated + o) = make_uint2(0u, 0u);
+        const int64_t o = row0 + (int64_t)r * rstride + c * 4;
+        *(uint32_t*)(io.truncated + o) = *(const uint32_t*)(s_trunc + r * G + c * 4);
+        *(uint32_t*)(io.terminated + o) = 0u;
       }
     } else {
       for (int i = tid; i < n_items; i += NT) {
@@ -476,7 +476,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
   if (TC > 8) TC &= ~7;                                          // groups of 8 steps in the recurrence phase
   if (sp.num_steps >= 1 && TC > sp.num_steps) TC = sp.num_steps; // at most one episode end per chunk
-  a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 8);
+  a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 4);
   const int items = TC * G;
   const size_t lds = (size_t)((items * 3 + 3) & ~3) * 4 + (size_t)((items + 3) & ~3) * 8 + (size_t)((items + 15) & ~15) +
                      (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
@@ -485,10 +485,16 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   const dim3 grid((sp.B + epb - 1) / epb);
   const bool replay = io.actions != nullptr || io.exo != nullptr;
   const int64_t total = (int64_t)sp.B * sp.S;
-  const bool wide = (sp.B % epb == 0) && (G % 8 == 0) && (total % 8 == 0);
-  if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<512, false, true>), grid, dim3(512), lds, st, a);
-  else if (wide) hipLaunchKernelGGL((phx_sc_rollout_kernel<512, true, true>), grid, dim3(512), lds, st, a);
-  else if (!replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<512, false, false>), grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((phx_sc_rollout_kernel<512, true, false>), grid, dim3(512), lds, st, a);
+  const bool wide = (sp.B % epb == 0) && (G % 4 == 0) && (total % 4 == 0);
+  static const int nt = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 512;
+#define PHX_LAUNCH_ROLLOUT(NT_)                                                                              \
+  do {                                                                                                        \
+    if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, true>), grid, dim3(NT_), lds, st, a);  \
+    else if (wide) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, true, true>), grid, dim3(NT_), lds, st, a);         \
+    else if (!replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, false>), grid, dim3(NT_), lds, st, a);    \
+    else hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, true, false>), grid, dim3(NT_), lds, st, a);                  \
+  } while (0)
+  if (nt == 1024) PHX_LAUNCH_ROLLOUT(1024); else if (nt == 256) PHX_LAUNCH_ROLLOUT(256); else PHX_LAUNCH_ROLLOUT(512);
+#undef PHX_LAUNCH_ROLLOUT
   return hipGetLastError();
 }
