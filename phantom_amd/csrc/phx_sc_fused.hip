@@ -50,7 +50,8 @@ __device__ __forceinline__ void sc_shop_step(ShopLane& st, bool has_action, floa
   st.stock = stock1;
 }
 
-__global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, const phx_step_io io,
+template <int NT>
+__global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const phx_step_io io,
                                                             const int epb, const int stage_exo) {
   // A block owns `epb` WHOLE envs (epb * S <= 256 lanes): the per-env words (step, tick, stage)
   // are read by every lane of the env and rewritten by its shop-0 lane, so readers and writer
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_step_kernel(const DevSpec sp, co
     const int64_t lo = b_first * sp.n_exo, hi = b_end * sp.n_exo;
     lds_base = lo & ~(int64_t)15;
     const int64_t hi16 = hi & ~(int64_t)15;
-    for (int64_t off = lds_base + (int64_t)threadIdx.x * 16; off < hi16; off += (int64_t)SC_NT * 16)
+    for (int64_t off = lds_base + (int64_t)threadIdx.x * 16; off < hi16; off += (int64_t)NT * 16)
       *(uint4*)(s_exo + (off - lds_base)) = *(const uint4*)(io.exo + off);
-    for (int64_t off = (hi16 > lds_base ? hi16 : lds_base) + threadIdx.x; off < hi; off += SC_NT)
+    for (int64_t off = (hi16 > lds_base ? hi16 : lds_base) + threadIdx.x; off < hi; off += NT)
       s_exo[off - lds_base] = io.exo[off];
   }
   const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
@@ -434,12 +435,19 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
 
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
-  const int epb = SC_NT / sp.S;                       // whole envs per block (S <= 256 checked at create)
+  // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
+  // same (the per-launch mode is bound by the host's launch cadence); PHX_STEP_NT overrides.
+  int nt = 256;
+  static const int force_nt = getenv("PHX_STEP_NT") ? atoi(getenv("PHX_STEP_NT")) : 0;
+  if (force_nt == 64 || force_nt == 128 || force_nt == 256) nt = force_nt < sp.S ? 256 : force_nt;
+  const int epb = nt / sp.S;
   const int blocks = (sp.B + epb - 1) / epb;
   const int64_t bytes = (int64_t)epb * sp.n_exo + 32;
   const int stage = (io.exo && bytes <= SC_STAGE_MAX) ? 1 : 0;
-  hipLaunchKernelGGL(phx_sc_step_kernel, dim3(blocks), dim3(SC_NT), stage ? (size_t)bytes : 0, st,
-                     sp, io, epb, stage);
+  const size_t lds = stage ? (size_t)bytes : 0;
+  if (nt == 64) hipLaunchKernelGGL((phx_sc_step_kernel<64>), dim3(blocks), dim3(64), lds, st, sp, io, epb, stage);
+  else if (nt == 128) hipLaunchKernelGGL((phx_sc_step_kernel<128>), dim3(blocks), dim3(128), lds, st, sp, io, epb, stage);
+  else hipLaunchKernelGGL((phx_sc_step_kernel<256>), dim3(blocks), dim3(256), lds, st, sp, io, epb, stage);
   return hipGetLastError();
 }
 
