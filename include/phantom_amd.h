@@ -185,6 +185,8 @@ typedef struct phx_rollout_io {
   float*    reward;            /* [T][B][S]     f64 reward rounded to f32                   */
   uint8_t*  terminated;        /* [T][B][S]                                                 */
   uint8_t*  truncated;         /* [T][B][S]     per-agent flag OR'ed with __all__ truncation */
+  uint8_t*  obs_valid;         /* [T][B][S] or NULL: 1 <=> aid in step.observations (FSM envs) */
+  uint8_t*  reward_valid;      /* [T][B][S] or NULL: 0 absent, 1 value, 2 None (FSM envs)      */
   float*    last_obs;          /* [B][S][D]     observation the next fragment starts from   */
   int32_t*  err;               /* [B]                                                       */
 } phx_rollout_io;
@@ -225,7 +227,7 @@ int  phx_inject(phx_env* env, const phx_msg_rec* host_msgs, int n);
 int  phx_resolve(phx_env* env, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count,
                  void* stream);
 
-/* T fused steps (supply-chain static schedule only; PHX_EUNSUPPORTED otherwise)            */
+/* T fused steps (supply-chain static schedule, plain or FSM env; PHX_EUNSUPPORTED otherwise) */
 int  phx_rollout(phx_env* env, const phx_rollout_io* io, void* stream);
 
 #ifdef __cplusplus

@@ -865,6 +865,8 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
       io->reward[base + s] = (float)rw[s];
       io->terminated[base + s] = (uint8_t)(u8[2 * S + s] | at);
       io->truncated[base + s] = (uint8_t)(u8[3 * S + s] | au);
+      if (io->obs_valid) io->obs_valid[base + s] = u8[s];
+      if (io->reward_valid) io->reward_valid[base + s] = u8[S + s];
     }
     if (at || au) env_reset_one(E, e, o, u8);                         /* caller's env.reset() */
   }

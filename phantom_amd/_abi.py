@@ -72,8 +72,8 @@ class PhxStepIO(C.Structure):
 
 class PhxRolloutIO(C.Structure):
     _fields_ = [("T", C.c_int32)] + [(n, C.c_void_p) for n in (
-        "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "last_obs",
-        "err")]
+        "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
+        "reward_valid", "last_obs", "err")]
 
 
 assert C.sizeof(PhxMsgRec) == 16

@@ -19,6 +19,7 @@ hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, float* obs, 
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
+hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -467,11 +468,14 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
-  if (!e->use_fused || e->d.env_type != PHX_ENV_PLAIN)
-    return fail(PHX_EUNSUPPORTED, "phx_rollout needs a plain env with a static supply-chain schedule");
+  if (!e->use_fused)
+    return fail(PHX_EUNSUPPORTED, "phx_rollout needs a plain or FSM env with a static supply-chain schedule");
+  if (e->d.env_type == PHX_ENV_FSM && (!io->obs_valid || !io->reward_valid))
+    return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
   HIPCHK(use_device(e));
+  if (e->d.env_type == PHX_ENV_FSM) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
   return PHX_OK;
 }

@@ -433,6 +433,112 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
   }
 }
 
+// ---- FSM rollout: T steps per launch for FiniteStateMachineEnv supply chains (BASELINE config 3).
+// One lane owns one (env, shop) and walks the steps in order: the stage masks (who acts, who
+// observes, who is rewarded -- fsm.py:276-345), the reward cache with emit-on-observe and the
+// terminal dump of the cached dicts (fsm.py:349-378) are all sequential in time, so this kernel
+// keeps the lane-per-pair loop and relies on the batch for parallelism (SC256 x B = 8192 gives
+// 6 500 waves).  Per-(stage, shop) mask bits are staged in LDS once per block.
+__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec sp, const phx_rollout_io io,
+                                                                  const int epb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_fl[];   // [n_lists][S]
+  const int nS = sp.S, A = sp.A, nL = sp.n_lists;
+  for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) {
+    const int l = idx / nS, s = idx - l * nS, a_shop = sp.shop_agent[s];
+    const uint8_t* cact = sp.shop_cust_act + (int64_t)l * sp.n_exo;
+    bool any = false, all = true;
+    for (int k = sp.shop_cust_ptr[s]; k < sp.shop_cust_ptr[s + 1]; ++k) { any |= cact[k] != 0; all &= cact[k] != 0; }
+    s_fl[idx] = (uint8_t)((sp.act_mask[(int64_t)l * A + a_shop] ? 1 : 0) | (any ? 2 : 0) | ((any && all) ? 4 : 0) |
+                          (sp.obs_mask[(int64_t)l * A + a_shop] ? 8 : 0) | (sp.rew_mask[(int64_t)l * A + a_shop] ? 16 : 0));
+  }
+  const int64_t total = (int64_t)sp.B * nS;
+  const int64_t b_first = (int64_t)blockIdx.x * epb;
+  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
+  const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
+  const int64_t g = b_first * nS + threadIdx.x;
+  const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
+  const int s = active ? (int)(threadIdx.x % nS) : 0;
+  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
+  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  int stage = fld<int32_t>(sp, F_ENV_STAGE)[b];
+  int prev_stage = fld<int32_t>(sp, F_ENV_PREV_STAGE)[b];
+  __syncthreads();          // mask bits staged; per-env words read before their shop-0 lane rewrites them
+  if (!active) return;
+
+  const int a_shop = sp.shop_agent[s];
+  const float norm = (float)sp.param_i[a_shop * PHX_NPI + 1];
+  const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1], K = c_hi - c_lo;
+  const int64_t genv = sp.env_offset + b;
+  ShopLane st;
+  st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g]; st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
+  st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g]; st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
+  double rc = fld<double>(sp, F_ENV_REW_CACHE)[g];                           // self._rewards[aid]
+  uint8_t rcv = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g];
+  float oc[3] = {fld<float>(sp, F_ENV_OBS_CACHE)[g * 3], fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 1],
+                 fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 2]};               // self._observations[aid]
+  uint8_t ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g];
+  float lo[3] = {0.f, 0.f, 0.f};
+
+  for (int t = 0; t < io.T; ++t) {
+    const int64_t o = (int64_t)t * total + g;
+    const int fl = s_fl[stage * nS + s];
+    const bool has_action = (fl & 1) != 0, any_order = (fl & 2) != 0;
+    const uint8_t* cact = sp.shop_cust_act + (int64_t)stage * sp.n_exo;
+    int D = 0; uint32_t w3 = 0;
+    if (io.exo) {
+      const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
+      if (any_order) for (int k = c_lo; k < c_hi; ++k) if (cact[k]) D += row[sp.shop_cust_exo[k]];
+      if (!io.actions) rng_shop_order_sum(sp.seed, genv, tick, s, 0, &w3);
+    } else if (fl & 4) {
+      D = rng_shop_order_sum(sp.seed, genv, tick, s, K, &w3);
+    } else if (any_order) {
+      D = rng_shop_orders(sp.seed, genv, tick, s, K, cact + c_lo, -1, &w3);
+    } else if (!io.actions) {
+      rng_shop_order_sum(sp.seed, genv, tick, s, 0, &w3);
+    }
+    const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
+    sc_shop_step(st, has_action, action, any_order, D);
+    ++step; ++tick;
+    const bool all_trunc = (step == sp.num_steps);                           // env.py:312-318
+    float ob[3] = {0.f, 0.f, 0.f};
+    uint8_t ov = 0, rv = 0; double rw = 0.0;
+    const bool observes = (fl & 8) != 0;
+    if (observes) {                                                          // fsm.py:328-332,349
+      shop_obs_f32(st.stock, st.sales, st.missed, norm, ob);
+      oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; ocv = 1;
+    }
+    if (fl & 16) { rc = shop_reward(st.sales, st.stock); rcv = 1; }         // fsm.py:334-335,350
+    if (all_trunc) {                                                         // fsm.py:360-375
+      ov = ocv; ob[0] = ocv ? oc[0] : 0.f; ob[1] = ocv ? oc[1] : 0.f; ob[2] = ocv ? oc[2] : 0.f;
+      rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
+    } else if (observes) {                                                   // fsm.py:378
+      ov = 1; rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
+    }
+    io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
+    io.action_out[o] = action;
+    io.reward[o] = (float)rw;
+    io.terminated[o] = 0; io.truncated[o] = all_trunc;
+    io.obs_valid[o] = ov; io.reward_valid[o] = rv;
+    lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2];
+    prev_stage = stage; stage = sp.stage_next[stage];                        // fsm.py:355
+    if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
+      st.stock = 0; step = 0; stage = sp.initial_stage; rcv = 0;
+      lo[0] = lo[1] = lo[2] = 0.f;
+      if (s_fl[sp.initial_stage * nS + s] & 1) shop_obs_f32(st.stock, st.sales, st.missed, norm, lo);
+    }
+  }
+  fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock; fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
+  fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed; fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
+  fld<double>(sp, F_ENV_REW_CACHE)[g] = rc; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g] = rcv;
+  fld<float>(sp, F_ENV_OBS_CACHE)[g * 3] = oc[0]; fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 1] = oc[1];
+  fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 2] = oc[2]; fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g] = ocv;
+  if (io.last_obs) { io.last_obs[g * 3] = lo[0]; io.last_obs[g * 3 + 1] = lo[1]; io.last_obs[g * 3 + 2] = lo[2]; }
+  if (s == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
+    fld<int32_t>(sp, F_ENV_STAGE)[b] = stage; fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = prev_stage;
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
@@ -448,6 +554,13 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
   if (nt == 64) hipLaunchKernelGGL((phx_sc_step_kernel<64>), dim3(blocks), dim3(64), lds, st, sp, io, epb, stage);
   else if (nt == 128) hipLaunchKernelGGL((phx_sc_step_kernel<128>), dim3(blocks), dim3(128), lds, st, sp, io, epb, stage);
   else hipLaunchKernelGGL((phx_sc_step_kernel<256>), dim3(blocks), dim3(256), lds, st, sp, io, epb, stage);
+  return hipGetLastError();
+}
+
+hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  const int epb = SC_NT / sp.S;
+  hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
+                     (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb);
   return hipGetLastError();
 }
 

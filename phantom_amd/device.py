@@ -44,6 +44,8 @@ class Trajectory(NamedTuple):
     terminations: "object"   # u8  [T, B, S]
     truncations: "object"    # u8  [T, B, S]
     last_obs: "object"       # f32 [B, S, D]
+    obs_valid: "object" = None      # u8 [T, B, S]  (FSM envs: key present in step.observations)
+    reward_valid: "object" = None   # u8 [T, B, S]  (FSM envs: 0 absent / 1 value / 2 None)
 
 
 class DeviceError(RuntimeError):
@@ -207,9 +209,12 @@ class DeviceEnv:
         B, S, D = self.B, self.S, self.D
         if out is None:
             e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=self.device)
+            fsm = self.spec.env_type != _abi.ENV_PLAIN
             out = Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
                              e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
-                             e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32))
+                             e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),
+                             e(T, B, S, dtype=torch.uint8) if fsm else None,
+                             e(T, B, S, dtype=torch.uint8) if fsm else None)
         io = _abi.PhxRolloutIO()
         io.T = T
         if actions is not None:
@@ -222,6 +227,8 @@ class DeviceEnv:
                                             out.rewards.data_ptr())
         io.terminated, io.truncated = out.terminations.data_ptr(), out.truncations.data_ptr()
         io.last_obs = out.last_obs.data_ptr()
+        if out.obs_valid is not None:
+            io.obs_valid, io.reward_valid = out.obs_valid.data_ptr(), out.reward_valid.data_ptr()
         io.err = self.err.data_ptr()
         with torch.cuda.device(self.device):
             self._check(self.lib.phx_rollout(self.handle, C.byref(io), self._stream()), "phx_rollout")

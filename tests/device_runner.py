@@ -63,7 +63,9 @@ class DeviceRunner:
         self.err = self.dev.err.cpu().numpy()
         return dict(obs=tr.observations.cpu().numpy(), actions=tr.actions.cpu().numpy(),
                     rewards=tr.rewards.cpu().numpy(), terminated=tr.terminations.cpu().numpy(),
-                    truncated=tr.truncations.cpu().numpy(), last_obs=tr.last_obs.cpu().numpy())
+                    truncated=tr.truncations.cpu().numpy(), last_obs=tr.last_obs.cpu().numpy(),
+                    obs_valid=None if tr.obs_valid is None else tr.obs_valid.cpu().numpy(),
+                    reward_valid=None if tr.reward_valid is None else tr.reward_valid.cpu().numpy())
 
     def get_i32(self, field):
         return self.dev.field(field).cpu().numpy().reshape(self.B, -1)

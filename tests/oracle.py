@@ -148,7 +148,8 @@ class OracleEnv:
         B, S, D = self.B, self.S, self.D
         out = dict(obs=np.zeros((T, B, S, D), np.float32), actions=np.zeros((T, B, S), np.float32),
                    rewards=np.zeros((T, B, S), np.float32), terminated=np.zeros((T, B, S), np.uint8),
-                   truncated=np.zeros((T, B, S), np.uint8), last_obs=np.zeros((B, S, D), np.float32))
+                   truncated=np.zeros((T, B, S), np.uint8), last_obs=np.zeros((B, S, D), np.float32),
+                   obs_valid=np.zeros((T, B, S), np.uint8), reward_valid=np.zeros((T, B, S), np.uint8))
         io = _abi.PhxRolloutIO()
         io.T = T
         self._a = np.ascontiguousarray(actions, np.float32) if actions is not None else None
@@ -156,6 +157,7 @@ class OracleEnv:
         io.actions, io.exo = _p(self._a), _p(self._x)
         io.obs, io.action_out, io.reward = _p(out["obs"]), _p(out["actions"]), _p(out["rewards"])
         io.terminated, io.truncated = _p(out["terminated"]), _p(out["truncated"])
+        io.obs_valid, io.reward_valid = _p(out["obs_valid"]), _p(out["reward_valid"])
         io.last_obs, io.err = _p(out["last_obs"]), _p(self.err)
         self.L.phxo_rollout(self.h, C.byref(io))
         return out

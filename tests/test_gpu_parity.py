@@ -424,3 +424,32 @@ def test_rollout_shapes_match_oracle(S, K, B, T, num_steps):
             np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} {mode}")
         ro2, rd2 = o.rollout(5, None, None), d.rollout(5, None, None)       # fragments chain
         np.testing.assert_array_equal(f32_bits(rd2["obs"]), f32_bits(ro2["obs"]))
+
+
+@pytest.mark.parametrize("S,K,B,T,num_steps", [(2, 3, 5, 40, 6), (9, 6, 40, 130, 100), (51, 4, 12, 60, 25)])
+def test_fsm_rollout_matches_oracle(S, K, B, T, num_steps):
+    """FiniteStateMachineEnv rollouts (RESTOCK -> SELL -> RESTOCK ...): stage masks, reward cache with
+    emit-on-observe, terminal dump of the cached dicts, auto-reset -- fused kernel vs oracle."""
+    rng = np.random.RandomState(S + B)
+    for mode in ("device_rng", "replay"):
+        env = supply_chain_env(S, [K] * S, num_steps, B, fsm=True, seed=8, env_offset=31)
+        o, d = OracleEnv(env.spec), _dev(env.spec)
+        assert d.dev.uses_fused
+        o.reset(); d.reset()
+        a0 = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a0, None, None); d.step(a0, None, None)             # start the fragment in stage SELL
+        acts = exo = None
+        if mode == "replay":
+            acts = rng.uniform(-10, 130, (T, B, S)).astype(np.float32)
+            exo = rng.randint(0, 5, (T, B, S * K)).astype(np.uint8)
+        ro, rd = o.rollout(T, acts, exo), d.rollout(T, acts, exo)
+        for k in ("obs_valid", "reward_valid", "truncated", "terminated"):
+            np.testing.assert_array_equal(rd[k], ro[k], err_msg=f"{k} {mode}")
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"{k} {mode}")
+        assert (ro["obs_valid"] == 0).any() and (ro["obs_valid"] == 1).any() and ro["truncated"].any()
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "env.step", "env.tick", "env.stage", "env.prev_stage"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} {mode}")
+        a1 = rng.uniform(0, 100, (B, S)).astype(np.float32)         # per-step launches continue identically
+        o.step(a1, None, None); d.step(a1, None, None)
+        _compare_step(o, d, -1)

@@ -49,6 +49,22 @@ def main():
     sc("SC64 B=4096 plain", 9, 6, 4096, False, True)
     sc("SC256 B=8192 FSM", 51, 4, 8192, True, False)
     sc("SC256 B=8192 FSM", 51, 4, 8192, True, True)
+    # config 3 as a fused FSM rollout (T = 100 steps per launch)
+    S, K, B = 51, 4, 8192
+    env = supply_chain_env(S, [K] * S, 100, B, fsm=True, seed=1, exogenous="device")
+    d = env._device(); env.reset()
+    traj = d.rollout(100)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        d.rollout(100, out=traj)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 1000 * 1e3
+    out.append(dict(config="SC256 B=8192 FSM rollout T=100", engine="fused", agents=256, batch=B,
+                    us_per_step_events=us, us_per_step_wall=us, agent_steps_per_s=256 * B / (us * 1e-6)))
+    print(json.dumps(out[-1]), flush=True)
+    del traj, d, env
     B = 512 if quick else 4096
     env = market_env(128, 1024, 8, 100, B)
     d = env._device(); env.reset()
