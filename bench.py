@@ -256,6 +256,20 @@ def main():
         out["rollout_allgather"] = {"ms": ag * 1e3, "bytes_per_rank": nbytes,
                                     "recv_GBps_per_rank": nbytes * (world - 1) / ag / 1e9,
                                     "note": "one T=100 fragment, RCCL all_gather; not in `value`"}
+        # produce + collect, pipelined: chunk c is gathered on a side stream while chunk c+1 rolls out
+        from phantom_amd.distributed import device_env_collector
+        col = device_env_collector(dev, T)                     # chunking by bytes (auto_chunk)
+        col.collect(); sync_barrier()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            col.collect()
+        sync_barrier()
+        pc = (time.perf_counter() - t0) / reps
+        out["rollout_allgather"]["pipelined_rollout_plus_gather_ms"] = pc * 1e3
+        out["rollout_allgather"]["pipelined_agent_steps_per_sec"] = N_AGENTS * B * world * T / pc
+        out["rollout_allgather"]["pipeline"] = (f"{col.n_chunks} chunk(s) of {col.chunk} steps, "
+                                                 "2 staging buffers, gather on a side stream")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

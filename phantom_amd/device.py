@@ -204,17 +204,23 @@ class DeviceEnv:
             self._check(rc, "phx_step")
         return self._step_out
 
+    def alloc_trajectory(self, T: int) -> Trajectory:
+        """Uninitialised device buffers for a T-step fragment (time-major)."""
+        torch = _torch()
+        B, S, D = self.B, self.S, self.D
+        e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=self.device)
+        fsm = self.spec.env_type != _abi.ENV_PLAIN
+        return Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
+                          e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
+                          e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),
+                          e(T, B, S, dtype=torch.uint8) if fsm else None,
+                          e(T, B, S, dtype=torch.uint8) if fsm else None)
+
     def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
         torch = _torch()
         B, S, D = self.B, self.S, self.D
         if out is None:
-            e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=self.device)
-            fsm = self.spec.env_type != _abi.ENV_PLAIN
-            out = Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
-                             e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
-                             e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),
-                             e(T, B, S, dtype=torch.uint8) if fsm else None,
-                             e(T, B, S, dtype=torch.uint8) if fsm else None)
+            out = self.alloc_trajectory(T)
         io = _abi.PhxRolloutIO()
         io.T = T
         if actions is not None:

@@ -66,5 +66,106 @@ def all_gather_trajectory(traj, group=None, out=None):
     return tuple(outs)
 
 
+class RolloutCollector:
+    """Rollout collection pipelined against rollout production (BASELINE config 4).
+
+    A T-step fragment is produced in chunks of ``chunk`` steps; while chunk c+1 is being
+    produced on the caller's stream, chunk c is all-gathered on a side stream out of one of
+    ``n_buffers`` staging buffers, so that on xGMI the exchange hides behind the rollout kernel
+    (or the other way round) instead of adding to it.  ``produce(t0, tc, bufs)`` must enqueue,
+    on the current stream, the work that fills ``bufs`` (tensors [chunk, B_local, ...]) with
+    steps [t0, t0 + tc) of this rank's fragment -- for a DeviceEnv that is one phx_rollout of
+    ``tc`` steps continuing from the resident state.
+
+    Result: a tuple of tensors [n_chunks, world, chunk, B_local, ...]; global env
+    = shard * B_local + local env, global step = c * chunk + step-in-chunk.  Chunk-major output
+    keeps every all-gather a single contiguous all_gather_into_tensor (no repacking pass).
+    On a CPU device (gloo tests) the same schedule runs without streams.
+    """
+
+    def __init__(self, produce, like, T: int, chunk: int, group=None, n_buffers: int = 2):
+        import torch
+        import torch.distributed as dist
+        if T % chunk:
+            raise ValueError(f"T={T} must be a multiple of chunk={chunk}")
+        self.produce, self.T, self.chunk, self.group = produce, T, chunk, group
+        self.n_chunks = T // chunk
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = like[0].device
+        mk = lambda x, lead: torch.empty(lead + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        self.bufs = [tuple(mk(x, (chunk,)) for x in like) for _ in range(n_buffers)]
+        self.out = tuple(mk(x, (self.n_chunks, self.world, chunk)) for x in like)
+        self.cuda = self.device.type == "cuda"
+        if self.cuda:
+            self.side = torch.cuda.Stream(self.device)
+            self.free = [torch.cuda.Event() for _ in range(n_buffers)]
+            self.ready = [torch.cuda.Event() for _ in range(n_buffers)]
+
+    def _gather(self, c, bufs):
+        import torch.distributed as dist
+        for o, x in zip(self.out, bufs):
+            if self.world == 1:
+                o[c, 0].copy_(x, non_blocking=True)
+            else:
+                dist.all_gather_into_tensor(o[c].view((self.world * self.chunk,) + tuple(x.shape[1:])),
+                                            x, group=self.group)
+
+    def collect(self):
+        """Run one fragment; returns ``self.out`` (valid on the caller's stream on return)."""
+        import torch
+        if not self.cuda:
+            for c in range(self.n_chunks):
+                bufs = self.bufs[c % len(self.bufs)]
+                self.produce(c * self.chunk, self.chunk, bufs)
+                self._gather(c, bufs)
+            return self.out
+        main = torch.cuda.current_stream(self.device)
+        for c in range(self.n_chunks):
+            k = c % len(self.bufs)
+            if c >= len(self.bufs):
+                main.wait_event(self.free[k])          # gather of chunk c - n_buffers has read buffer k
+            self.produce(c * self.chunk, self.chunk, self.bufs[k])
+            self.ready[k].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready[k])
+                self._gather(c, self.bufs[k])
+                self.free[k].record(self.side)
+        main.wait_stream(self.side)
+        return self.out
+
+
+def auto_chunk(T: int, bytes_per_step: int, min_chunk_bytes: int = 128 << 20) -> int:
+    """Smallest divisor of T whose chunk carries at least ``min_chunk_bytes`` per rank (else T):
+    below ~100 MB a chunk's gather is launch-latency bound and pipelining costs more than it
+    hides (measured: SC64 B=4096, 81 MB fragment: 0.37 ms in 5 chunks vs 0.13 ms in one)."""
+    for c in range(1, T + 1):
+        if T % c == 0 and c * bytes_per_step >= min_chunk_bytes:
+            return c
+    return T
+
+
+def device_env_collector(dev, T: int, chunk: Optional[int] = None, group=None,
+                         n_buffers: int = 2) -> RolloutCollector:
+    """RolloutCollector over a DeviceEnv: each chunk is one phx_rollout of ``chunk`` steps
+    (default: auto_chunk on the fragment's bytes per step)."""
+    from .device import Trajectory
+    if chunk is None:
+        one = dev.alloc_trajectory(1)
+        per_step = sum(x.numel() * x.element_size() for x in one
+                       if x is not None and x is not one.last_obs)
+        chunk = auto_chunk(T, per_step)
+    probe = dev.alloc_trajectory(chunk)             # shapes/dtypes only; nothing is launched
+    fields = [x for x in (probe.observations, probe.actions, probe.rewards, probe.terminations,
+                          probe.truncations, probe.obs_valid, probe.reward_valid) if x is not None]
+    has_masks = probe.obs_valid is not None
+
+    def produce(t0, tc, bufs):
+        masks = (bufs[5], bufs[6]) if has_masks else (None, None)
+        dev.rollout(tc, out=Trajectory(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], probe.last_obs, *masks))
+
+    return RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers)
+
+
 def global_env_index(shard_index: int, local_env: int, local_batch: int) -> int:
     return shard_index * local_batch + local_env

@@ -35,6 +35,24 @@ def _worker(rank, world, port, tmp):
     assert gathered[0].shape == (world, T, sh.local_batch, S, 3)
     if rank == 0:
         np.savez(os.path.join(tmp, "gathered.npz"), **{f"a{k}": g.numpy() for k, g in enumerate(gathered)})
+    # pipelined collection: the same fragment produced and gathered in chunks of 10 steps
+    from phantom_amd.distributed import RolloutCollector
+    o2 = OracleEnv(env.spec)
+    o2.reset()
+    names = ("obs", "actions", "rewards", "terminated", "truncated")
+
+    def produce(t0, tc, bufs):
+        rr = o2.rollout(tc)                 # continues from the resident state
+        for b, k in zip(bufs, names):
+            b.copy_(torch.from_numpy(rr[k]))
+
+    col = RolloutCollector(produce, traj, T, 10)
+    chunks = col.collect()
+    assert chunks[0].shape == (3, world, 10, sh.local_batch, S, 3)
+    for g, ch in zip(gathered, chunks):
+        # [C, W, tc, ...] -> [W, C*tc, ...]
+        glued = torch.cat([ch[c] for c in range(ch.shape[0])], dim=1)
+        assert torch.equal(glued, g)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -453,3 +453,27 @@ def test_fsm_rollout_matches_oracle(S, K, B, T, num_steps):
         a1 = rng.uniform(0, 100, (B, S)).astype(np.float32)         # per-step launches continue identically
         o.step(a1, None, None); d.step(a1, None, None)
         _compare_step(o, d, -1)
+
+
+@pytest.mark.parametrize("fsm", [False, True])
+def test_pipelined_collector_equals_one_shot_rollout(fsm):
+    """distributed.RolloutCollector on one GPU (world 1): a fragment produced in chunks on the
+    main stream and collected on the side stream equals the one-shot phx_rollout and the oracle."""
+    import torch
+    from phantom_amd.distributed import device_env_collector
+    S, K, B, T, chunk = 9, 6, 64, 120, 24
+    env = supply_chain_env(S, [K] * S, 50, B, fsm=fsm, seed=5, env_offset=7)
+    o, d1, d2 = OracleEnv(env.spec), _dev(env.spec), _dev(env.spec)
+    o.reset(); d1.reset(); d2.reset()
+    ro = o.rollout(T, None, None)
+    col = device_env_collector(d2.dev, T, chunk, n_buffers=2)
+    out = col.collect()
+    torch.cuda.synchronize()
+    names = ["obs", "actions", "rewards", "terminated", "truncated"] + (["obs_valid", "reward_valid"] if fsm else [])
+    assert out[0].shape == (T // chunk, 1, chunk, B, S, 3)
+    for name, x in zip(names, out):
+        got = x[:, 0].reshape((T,) + tuple(x.shape[3:])).cpu().numpy()
+        want = ro[name]
+        if got.dtype == np.float32:
+            got, want = f32_bits(got), f32_bits(want)
+        np.testing.assert_array_equal(got, want, err_msg=name)

@@ -202,3 +202,10 @@ def test_numpy_stream_vector_draw_equals_scalar_draws():
     np.random.seed(123)
     b = np.concatenate([np.random.randint(5, size=n) for n in (54, 1, 945, 2000)])
     assert a == b.tolist()
+
+
+def test_auto_chunk_picks_divisors_by_bytes():
+    from phantom_amd.distributed import auto_chunk
+    assert auto_chunk(100, 811_008) == 100                  # SC64 B=4096: 81 MB fragment -> one chunk
+    assert auto_chunk(100, 9_191_424) == 20                 # SC256 B=8192: 9.2 MB/step -> 20-step chunks
+    assert auto_chunk(7, 1 << 30) == 1
