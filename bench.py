@@ -232,9 +232,28 @@ def main():
         torch.cuda.synchronize()
         kms = float(np.median([a.elapsed_time(b_) for a, b_ in evs]))
         alg_s = algorithmic_bytes_step(B, S, CUST_PER_SHOP, device_rng=True)
+        # the same per-step launches captured once into a hipGraph (100 steps per replay)
+        graph_us = None
+        try:
+            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                for i in range(100):
+                    dev.step(acts[i])
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(10):
+                g.replay()
+            torch.cuda.synchronize()
+            graph_us = (time.perf_counter() - tg) / 1000 * 1e6
+        except Exception as e:                                   # report, do not hide
+            graph_us = f"capture failed: {e}"
         out["per_step"] = {"value": N_AGENTS * B * world * ksteps / dt, "unit": "agent-steps/s",
                            "steps": ksteps, "ms_per_step_wall": dt / ksteps * 1e3,
                            "event_ms_per_launch": kms,
+                           "hipgraph_us_per_step": graph_us,
                            "roofline": {"bound": "hbm", "kernel": "phx_sc_step_kernel",
                                         "achieved": alg_s / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": alg_s / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -477,3 +477,32 @@ def test_pipelined_collector_equals_one_shot_rollout(fsm):
         if got.dtype == np.float32:
             got, want = f32_bits(got), f32_bits(want)
         np.testing.assert_array_equal(got, want, err_msg=name)
+
+
+def test_step_launches_are_graph_capturable():
+    """phx_step is stream-ordered with no allocation or sync inside, so a block of steps can be
+    captured into a hipGraph on torch's capture stream and replayed; results equal eager launches."""
+    import torch
+    S, K, B, N = 9, 6, 256, 30
+    envs = [supply_chain_env(S, [K] * S, 12, B, seed=3) for _ in range(2)]
+    de, dg = _dev(envs[0].spec).dev, _dev(envs[1].spec).dev
+    de.reset(); dg.reset()
+    acts = torch.rand(N, B, S, device=de.device) * 100.0
+    log_e, log_g = (torch.zeros(N, B, S, 3, device=de.device) for _ in range(2))
+    rew_e, rew_g = (torch.zeros(N, B, S, dtype=torch.float64, device=de.device) for _ in range(2))
+    for i in range(N):
+        o = de.step(acts[i]); log_e[i].copy_(o.observations); rew_e[i].copy_(o.rewards)
+        if i % 12 == 11:
+            de.reset()
+    g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        for i in range(N):
+            o = dg.step(acts[i]); log_g[i].copy_(o.observations); rew_g[i].copy_(o.rewards)
+            if i % 12 == 11:
+                dg.reset()
+    log_g.zero_(); torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(log_e, log_g) and torch.equal(rew_e, rew_g)
+    for f in ("shop.stock", "shop.sales", "env.step", "env.tick"):
+        assert torch.equal(de.field(f), dg.field(f)), f
