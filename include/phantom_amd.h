@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 1
+#define PHX_ABI_VERSION 2
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -53,7 +53,10 @@ typedef enum phx_kind {
   PHX_KIND_NONE       = 0,
   /* examples/environments/supply_chain/supply_chain.py */
   PHX_KIND_FACTORY    = 1,  /* FactoryAgent  :36-45                                        */
-  PHX_KIND_SHOP       = 2,  /* ShopAgent     :70-150   pi0=factory, pi1=max_sales_per_step */
+  PHX_KIND_SHOP       = 2,  /* ShopAgent     :70-150   pi0=factory, pi1=max_sales_per_step;
+                               with a type (type_src != PHX_TYPE_NONE) it is tutorial 2's shop,
+                               docs/user/tutorial2.rst:244-307: reward = sales - w * stock,
+                               obs[3] = w / pf1, w = Supertype.excess_stock_weight (pf0 if constant) */
   PHX_KIND_CUSTOMER   = 3,  /* CustomerAgent :48-67    pi0=shop                            */
   /* build-authored Stackelberg market, run on ph.StackelbergEnv     */
   PHX_KIND_SELLER     = 4,  /* leader:   price setter                                      */
@@ -87,6 +90,16 @@ typedef enum phx_msg_type {
 
 #define PHX_NPI 4   /* int32 params per agent  */
 #define PHX_NPF 2   /* double params per agent */
+
+/* ---- Supertypes / Samplers (supertype.py:16-30, utils/samplers.py:47-271, env.py:80-124,211-216)
+ * Every distinct Sampler object of the env + agent supertypes (env._samplers order) is one
+ * column of the per-env state field "env.sampler"; env.reset() resamples every column once
+ * (env.py:211-212), agents sharing a Sampler see the same value (supertype.py:23-24).         */
+#define PHX_SAMPLER_HOST    0  /* any Sampler: the caller passes the sampled values to phx_reset */
+#define PHX_SAMPLER_UNIFORM 1  /* UniformFloatSampler samplers.py:120-147: low + (high-low)*u,
+                                  optional clip; drawn on the device when no values are passed  */
+#define PHX_TYPE_NONE  -2      /* type_src: the agent has no device-consumed type field         */
+#define PHX_TYPE_CONST -1      /* type_src: constant supertype field = param_f[a][0]            */
 
 /* env flavours */
 #define PHX_ENV_PLAIN       0  /* PhantomEnv            env.py  */
@@ -132,6 +145,12 @@ typedef struct phx_spec {
   /* device RNG (used when exo == NULL): Philox4x32-10, key = (seed, env_offset + b)        */
   uint64_t seed;
   int64_t  env_offset;          /* global index of local env 0 (multi-GPU sharding)          */
+  /* Supertypes / Samplers (ABI 2); n_samplers == 0 and type_src == NULL when unused          */
+  int32_t n_samplers;
+  const int32_t* sampler_kind;  /* [n_samplers] PHX_SAMPLER_*                                */
+  const double*  sampler_param; /* [n_samplers][4] low, high, clip_low, clip_high (NaN = None) */
+  const int32_t* type_src;      /* [A] or NULL: sampler column feeding the agent's type field,
+                                   PHX_TYPE_CONST or PHX_TYPE_NONE                           */
 } phx_spec;
 
 typedef struct phx_env phx_env;   /* opaque */
@@ -213,9 +232,12 @@ int  phx_field_info(const phx_env* env, int index, phx_field* out);
 int  phx_uses_fused(const phx_env* env);
 
 /* PhantomEnv.reset (env.py:185-237 / fsm.py:195-251 / stackelberg.py:53-109) for every env
- * with reset_mask[b] != 0 (NULL = all).  Writes the initial observations.                 */
-int  phx_reset(phx_env* env, const uint8_t* reset_mask, float* obs, uint8_t* obs_valid,
-               void* stream);
+ * with reset_mask[b] != 0 (NULL = all).  Writes the initial observations.
+ * sampler_values: device f64 [B][n_samplers], the values `sampler.sample()` returned for each
+ * env (env.py:211-212), or NULL: UNIFORM samplers are then drawn from the device Philox
+ * stream (ctr = (env, episode, 0x80000000 | column)), HOST samplers keep their value.      */
+int  phx_reset(phx_env* env, const uint8_t* reset_mask, const double* sampler_values, float* obs,
+               uint8_t* obs_valid, void* stream);
 
 /* one PhantomEnv.step for all B envs */
 int  phx_step(phx_env* env, const phx_step_io* io, void* stream);
@@ -227,7 +249,8 @@ int  phx_inject(phx_env* env, const phx_msg_rec* host_msgs, int n);
 int  phx_resolve(phx_env* env, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count,
                  void* stream);
 
-/* T fused steps (supply-chain static schedule, plain or FSM env; PHX_EUNSUPPORTED otherwise) */
+/* T fused steps (supply-chain static schedule, plain or FSM env; PHX_EUNSUPPORTED otherwise,
+ * and for envs with PHX_SAMPLER_HOST samplers: the auto-reset resamples on the device)      */
 int  phx_rollout(phx_env* env, const phx_rollout_io* io, void* stream);
 
 #ifdef __cplusplus

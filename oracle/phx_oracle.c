@@ -60,6 +60,8 @@ typedef struct {
   int32_t step;           /* PhantomEnv._current_step env.py:63 */
   int32_t stage, prev_stage;   /* fsm.py:126-127 */
   uint32_t tick;          /* device-RNG draw counter (never reset) */
+  double* sampler;        /* [n_samplers] Sampler._value of every sampler of env._samplers  samplers.py:60-66 */
+  int32_t episode;        /* number of env.reset() calls so far (device-RNG counter of the samplers) */
   int32_t clock;          /* handle_message invocation counter (stands in for time.time()) */
   uint8_t* term;          /* [S] PhantomEnv._terminations env.py:71 */
   uint8_t* trunc;         /* [S] PhantomEnv._truncations  env.py:72 */
@@ -174,6 +176,17 @@ static void network_send(const phxo_env* E, oenv* e, int src, int dst, int type,
 static omsg mk_i(int64_t v) { omsg m; memset(&m, 0, sizeof m); m.p.i = v; return m; }
 static omsg mk_f(double v)  { omsg m; memset(&m, 0, sizeof m); m.p.f = v; return m; }
 
+/* ---- Supertypes / Samplers ---------------------------------------------------------------
+ * agent.type.<field> of a managed supertype is the env-owned Sampler's current value
+ * (supertype.py:23-24: `field.value` when `_managed`), i.e. column type_src[a] of e->sampler,
+ * or the constant the supertype was built with (param_f[a][0]).                            */
+static int type_src_of(const phxo_env* E, int a) { return E->s.type_src ? E->s.type_src[a] : PHX_TYPE_NONE; }
+static int agent_is_typed(const phxo_env* E, int a) { return type_src_of(E, a) != PHX_TYPE_NONE; }
+static double agent_type_value(const phxo_env* E, const oenv* e, int a) {
+  const int src = type_src_of(E, a);
+  return src >= 0 ? e->sampler[src] : E->s.param_f[a * PHX_NPF + 0];
+}
+
 /* ---- device-RNG definition (build-owned; replaces the global np.random stream) -------- */
 void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
@@ -215,6 +228,34 @@ float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int shop) {
   uint32_t w3;
   rng_field(seed, genv, tick, shop, 0, 0, 0, &w3);
   return (float)(w3 >> 8) * (100.0f / 16777216.0f);
+}
+
+/* Device draw of UniformFloatSampler column j at the env's `episode`-th reset (build-owned
+ * definition, replaces np.random.uniform of samplers.py:141): Philox block
+ *     ctr = (env_lo, env_hi, episode, 0x80000000 | j), key = seed,
+ * u = ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53 (numpy's 53-bit double), value = low + (high - low) * u
+ * with product and sum rounded separately, then np.clip (samplers.py:143-144).             */
+double phxo_rng_uniform(uint64_t seed, int64_t genv, uint32_t episode, int j, const double prm[4]) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, 0x80000000u | (uint32_t)j};
+  uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
+  const double u = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
+  volatile double scaled = (prm[1] - prm[0]) * u;              /* volatile: no fma contraction */
+  double v = prm[0] + scaled;
+  if (prm[2] == prm[2] && v < prm[2]) v = prm[2];
+  if (prm[3] == prm[3] && v > prm[3]) v = prm[3];
+  return v;
+}
+
+/* env.reset(): `for sampler in self._samplers: sampler.sample()`  env.py:211-212 */
+static void env_sample(const phxo_env* E, oenv* e, int b, const double* values) {
+  for (int j = 0; j < E->s.n_samplers; ++j) {
+    if (values) e->sampler[j] = values[j];
+    else if (E->s.sampler_kind[j] == PHX_SAMPLER_UNIFORM)
+      e->sampler[j] = phxo_rng_uniform(E->s.seed, E->s.env_offset + b, (uint32_t)e->episode, j,
+                                       E->s.sampler_param + 4 * j);
+  }
+  e->episode += 1;
 }
 
 /* ---- per-kind agent behaviour --------------------------------------------------------- */
@@ -401,6 +442,8 @@ static void agent_encode_obs(const phxo_env* E, const oenv* e, int a, float* o) 
       o[0] = (float)((double)st->i[0] / (double)SHOP_MAX_STOCK);
       o[1] = (float)((double)st->i[1] / max_sales_per_step);
       o[2] = (float)((double)st->i[2] / max_sales_per_step);
+      if (agent_is_typed(E, a))                               /* docs/user/tutorial2.rst:283-294 */
+        o[3] = (float)(agent_type_value(E, e, a) / E->s.param_f[a * PHX_NPF + 1]);
       break;
     }
     case PHX_KIND_SELLER: {
@@ -429,7 +472,9 @@ static double agent_compute_reward(const phxo_env* E, oenv* e, int a) {
   ostate* st = &e->ag[a];
   switch (E->s.kind[a]) {
     case PHX_KIND_SHOP: {                                     /* supply_chain.py:144-147 */
-      volatile double penalty = 0.1 * (double)st->i[0];       /* volatile: no fma contraction */
+      /* typed shop: self.type.excess_stock_weight * self.stock  docs/user/tutorial2.rst:270-273 */
+      const double w = agent_is_typed(E, a) ? agent_type_value(E, e, a) : 0.1;
+      volatile double penalty = w * (double)st->i[0];         /* volatile: no fma contraction */
       return (double)st->i[1] - penalty;
     }
     case PHX_KIND_SELLER: return st->f[1];
@@ -490,9 +535,11 @@ static int env_is_truncated(const phxo_env* E, const oenv* e) {
   return (e->step == E->s.num_steps) || n == E->S;
 }
 
-static void env_reset_one(const phxo_env* E, oenv* e, float* obs, uint8_t* obs_valid) {
+static void env_reset_one(const phxo_env* E, oenv* e, int b, const double* sampler_values,
+                          float* obs, uint8_t* obs_valid) {
   /* PhantomEnv.reset env.py:185-237; fsm.py:195-251; stackelberg.py:53-109 */
   e->step = 0;
+  env_sample(E, e, b, sampler_values);                                /* env.py:211-212 */
   if (E->s.env_type == PHX_ENV_FSM) e->stage = E->s.initial_stage;    /* fsm.py:217 */
   inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]); e->cur = 0; /* network.reset -> resolver.reset */
   for (int a = 0; a < E->A; ++a) agent_reset(E, e, a);                /* network.py:183-184 */
@@ -711,6 +758,9 @@ phxo_env* phxo_create(const phx_spec* sp) {
     E->s.leaders = (const int32_t*)dup_arr(sp->leaders, sizeof(int32_t) * (sp->n_leaders ? sp->n_leaders : 1));
     E->s.followers = (const int32_t*)dup_arr(sp->followers, sizeof(int32_t) * (sp->n_followers ? sp->n_followers : 1));
   }
+  E->s.sampler_kind = (const int32_t*)dup_arr(sp->sampler_kind, sizeof(int32_t) * sp->n_samplers);
+  E->s.sampler_param = (const double*)dup_arr(sp->sampler_param, sizeof(double) * 4 * sp->n_samplers);
+  E->s.type_src = (const int32_t*)dup_arr(sp->type_src, sizeof(int32_t) * A);
   E->strat_rank = (int*)calloc(A, sizeof(int));
   E->kind_rank = (int*)calloc(A, sizeof(int));
   E->exo_rank = (int*)calloc(A, sizeof(int));
@@ -723,6 +773,7 @@ phxo_env* phxo_create(const phx_spec* sp) {
     if (is_strategic_kind(k)) {                                       /* isinstance(a, StrategicAgent) env.py:151-159 */
       E->strat_rank[a] = S; E->strat_idx[S++] = a;
       if (obs_dim_of_kind(k) > D) D = obs_dim_of_kind(k);
+      if (k == PHX_KIND_SHOP && sp->type_src && sp->type_src[a] != PHX_TYPE_NONE && D < 4) D = 4;
     } else E->strat_rank[a] = -1;
     E->exo_rank[a] = (k == PHX_KIND_CUSTOMER) ? nx++ : -1;
   }
@@ -741,6 +792,8 @@ phxo_env* phxo_create(const phx_spec* sp) {
     if (!inbox_alloc(E, &e->box[0]) || !inbox_alloc(E, &e->box[1])) return NULL;
     inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]);
     e->stage = sp->initial_stage; e->prev_stage = -1;
+    e->sampler = (double*)calloc(sp->n_samplers > 0 ? sp->n_samplers : 1, sizeof(double));
+    env_sample(E, e, b, NULL);                                        /* env.py:118-119 */
     for (int a = 0; a < A; ++a) agent_reset(E, e, a);                 /* env.py:122-124 */
   }
   return E;
@@ -751,7 +804,7 @@ void phxo_destroy(phxo_env* E) {
   for (int b = 0; b < E->B; ++b) {
     oenv* e = &E->env[b];
     free(e->ag); free(e->vecpool); free(e->term); free(e->trunc); free(e->rew_cache);
-    free(e->rew_cache_valid); free(e->obs_cache); free(e->obs_cache_valid);
+    free(e->rew_cache_valid); free(e->obs_cache); free(e->obs_cache_valid); free(e->sampler);
     for (int k = 0; k < 2; ++k) {
       free(e->box[k].pool); free(e->box[k].next); free(e->box[k].order);
       free(e->box[k].head); free(e->box[k].tail);
@@ -761,6 +814,7 @@ void phxo_destroy(phxo_env* E) {
   free(E->injected);
   free((void*)E->s.kind); free((void*)E->s.param_i); free((void*)E->s.param_f);
   free((void*)E->s.row_ptr); free((void*)E->s.col);
+  free((void*)E->s.sampler_kind); free((void*)E->s.sampler_param); free((void*)E->s.type_src);
   if (E->s.env_type == PHX_ENV_FSM) {
     free((void*)E->s.stage_act_ptr); free((void*)E->s.stage_act_idx);
     free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next);
@@ -774,13 +828,14 @@ int phxo_n_strategic(const phxo_env* E) { return E->S; }
 int phxo_n_exo(const phxo_env* E) { return E->n_exo; }
 
 /* ---- batch entry points ---------------------------------------------------------------------- */
-void phxo_reset(phxo_env* E, const uint8_t* mask, float* obs, uint8_t* obs_valid) {
+void phxo_reset(phxo_env* E, const uint8_t* mask, const double* sampler_values, float* obs,
+                uint8_t* obs_valid) {
   const int S = E->S, D = E->D;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int b = 0; b < E->B; ++b) {
     if (mask && !mask[b]) continue;
-    env_reset_one(E, &E->env[b], obs ? obs + (size_t)b * S * D : NULL,
-                  obs_valid ? obs_valid + (size_t)b * S : NULL);
+    env_reset_one(E, &E->env[b], b, sampler_values ? sampler_values + (size_t)b * E->s.n_samplers : NULL,
+                  obs ? obs + (size_t)b * S * D : NULL, obs_valid ? obs_valid + (size_t)b * S : NULL);
   }
 }
 
@@ -868,7 +923,7 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
       if (io->obs_valid) io->obs_valid[base + s] = u8[s];
       if (io->reward_valid) io->reward_valid[base + s] = u8[S + s];
     }
-    if (at || au) env_reset_one(E, e, o, u8);                         /* caller's env.reset() */
+    if (at || au) env_reset_one(E, e, b, NULL, o, u8);                /* caller's env.reset() */
   }
   if (io->last_obs) memcpy(io->last_obs + (size_t)b * S * D, o, sizeof(float) * S * D);
   if (io->err) io->err[b] = e->err;
@@ -904,6 +959,7 @@ int64_t phxo_get_i32(const phxo_env* E, const char* field, int32_t* out) {
   if (!strcmp(field, "env.stage")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].stage; return E->B; }
   if (!strcmp(field, "env.prev_stage")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].prev_stage; return E->B; }
   if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) out[b] = (int32_t)E->env[b].tick; return E->B; }
+  if (!strcmp(field, "env.episode")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].episode; return E->B; }
   const ofield* f = find_field(field);
   if (!f || f->is_f) return -1;
   int n = E->kind_count[f->kind];
@@ -914,6 +970,7 @@ int64_t phxo_get_i32(const phxo_env* E, const char* field, int32_t* out) {
 }
 int64_t phxo_set_i32(phxo_env* E, const char* field, const int32_t* in) {
   if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) E->env[b].tick = (uint32_t)in[b]; return E->B; }
+  if (!strcmp(field, "env.episode")) { for (int b = 0; b < E->B; ++b) E->env[b].episode = in[b]; return E->B; }
   const ofield* f = find_field(field);
   if (!f || f->is_f) return -1;
   int n = E->kind_count[f->kind];
@@ -931,6 +988,11 @@ int64_t phxo_get_f64(const phxo_env* E, const char* field, double* out) {
         if (E->s.kind[a] == PHX_KIND_BUYER)
           for (int k = 0; k < E->s.row_ptr[a + 1] - E->s.row_ptr[a]; ++k) out[w++] = E->env[b].ag[a].vec[k];
     return (int64_t)w;
+  }
+  if (!strcmp(field, "env.sampler")) {
+    for (int b = 0; b < E->B; ++b)
+      for (int j = 0; j < E->s.n_samplers; ++j) out[(size_t)b * E->s.n_samplers + j] = E->env[b].sampler[j];
+    return (int64_t)E->B * E->s.n_samplers;
   }
   const ofield* f = find_field(field);
   if (!f || !f->is_f) return -1;

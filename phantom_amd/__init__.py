@@ -9,7 +9,7 @@ __version__ = "0.1.0"
 from . import _abi
 from .agents import (Agent, BuyerAgent, CashboxAgent, CustomerAgent, FactoryAgent,
                      ForwarderAgent, HalverAgent, MockAgent, MockStrategicAgent, ReqRespAgent,
-                     SellerAgent, ShopAgent, StrategicAgent, msg_handler)
+                     SellerAgent, ShopAgent, StrategicAgent, TypedShopAgent, msg_handler)
 from .env import PhantomEnv
 from .fsm import (FiniteStateMachineEnv, FSMRuntimeError, FSMStage, FSMValidationError)
 from .message import (AgentID, CashMessage, HalveMessage, Message, MsgPayload, Order,
@@ -20,6 +20,10 @@ from .resolvers import BatchResolver, Resolver
 from .spec import EnvSpec, compile_spec
 from .stackelberg import StackelbergEnv
 from .supply_chain import SupplyChainEnv, SupplyChainFSMEnv
+from .supertype import Supertype
+from . import samplers
+from .samplers import (LambdaSampler, NormalArraySampler, NormalSampler, Sampler,
+                       UniformArraySampler, UniformFloatSampler, UniformIntSampler)
 from .views import AgentView, EnvView, FSMEnvView, View
 from . import metrics, rllib
 from .distributed import all_gather_trajectory, make_sharded_env, shard_batch

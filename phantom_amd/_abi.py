@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NPI, NPF = 4, 2
 
 # phx_kind
@@ -23,6 +23,8 @@ OBS_DIM = {KIND_SHOP: 3, KIND_SELLER: 2, KIND_BUYER: 2, KIND_MOCK_STRAT: 1}
 FLOAT_PAYLOAD_TYPES = (MSG_PRICE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE)
 
 ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
+SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
+TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC = 1, 2, 4
 
 ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL = range(6)
@@ -45,6 +47,8 @@ class PhxSpec(C.Structure):
         ("n_leaders", C.c_int32), ("n_followers", C.c_int32),
         ("leaders", C.c_void_p), ("followers", C.c_void_p),
         ("seed", C.c_uint64), ("env_offset", C.c_int64),
+        ("n_samplers", C.c_int32), ("sampler_kind", C.c_void_p), ("sampler_param", C.c_void_p),
+        ("type_src", C.c_void_p),
     ]
 
 
@@ -121,7 +125,7 @@ def load_library():
     lib.phx_uses_fused.restype = i32
     lib.phx_uses_fused.argtypes = [vp]
     lib.phx_reset.restype = i32
-    lib.phx_reset.argtypes = [vp, vp, vp, vp, vp]
+    lib.phx_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.phx_step.restype = i32
     lib.phx_step.argtypes = [vp, C.POINTER(PhxStepIO), vp]
     lib.phx_inject.restype = i32

@@ -7,9 +7,11 @@ classes (``ShopAgent.stock`` ...) live in device memory, one value per env insta
 read back lazily through attribute access (so ``env["SHOP"].stock`` and
 ``SimpleAgentMetric("SHOP", "stock")``-style reflection keep working, metrics.py:230-231).
 """
+from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 from . import _abi
+from .supertype import Supertype as _Supertype
 from .message import AgentID
 from .views import AgentView
 
@@ -20,14 +22,25 @@ class Agent:
     device_kind = _abi.KIND_MOCK_AGENT
     #: python attribute name -> device state field
     state_fields: Dict[str, str] = {}
+    #: name of the Supertype field the device handlers of this kind consume (None: host-only type)
+    device_type_field: Optional[str] = None
 
     def __init__(self, agent_id: AgentID, supertype=None) -> None:
-        if supertype is not None:
-            raise NotImplementedError("Supertypes are reset-time host features outside the "
-                                      "device hot path (SURVEY.md 8f-3)")
         self._id = agent_id
-        self.supertype = None
+        self.supertype = supertype
         self._env = None          # bound by PhantomEnv / Network device binding
+
+    @property
+    def type(self):
+        """agents.py:160-175: the supertype with every Sampler replaced by the value drawn at the
+        last reset (per env instance: a python value for batch_size 1, an array [B] otherwise)."""
+        st = self.supertype
+        if st is None:
+            if not hasattr(self, "Supertype"):
+                raise AttributeError("type")
+            st = self.Supertype()
+        env = self.__dict__.get("_env")
+        return st.sample() if env is None else env._resolve_type(st)
 
     @property
     def id(self) -> AgentID:
@@ -40,7 +53,7 @@ class Agent:
         """(int params, float params) compiled into phx_spec.param_i / param_f."""
         return (), ()
 
-    def reset(self) -> None:      # agents.py:160-175 (supertype sampling is out of scope)
+    def reset(self) -> None:      # agents.py:160-175: `type` is resolved lazily, see above
         return None
 
     def __getattr__(self, name):
@@ -142,6 +155,29 @@ class ShopAgent(StrategicAgent):
         return (index_of(self.factory_id), self.num_customers * CUSTOMER_MAX_ORDER_SIZE), ()
 
 
+MAX_EXCESS_STOCK_WEIGHT = 0.2    # docs/user/tutorial2.rst:246
+
+
+class TypedShopAgent(ShopAgent):
+    """Tutorial 2's ShopAgent (docs/user/tutorial2.rst:244-307): a Supertype with one field,
+    ``excess_stock_weight``; reward = sales - type.excess_stock_weight * stock and the
+    observation gains type.excess_stock_weight / MAX_EXCESS_STOCK_WEIGHT as a 4th entry."""
+    device_type_field = "excess_stock_weight"
+
+    @dataclass
+    class Supertype(_Supertype):
+        excess_stock_weight: float = 0.1
+
+    def __init__(self, agent_id: str, factory_id: str, num_customers: int = 5, supertype=None):
+        super().__init__(agent_id, factory_id, num_customers)
+        self.supertype = supertype
+        self.observation_space = Box(0.0, 1.0, (4,))
+
+    def device_params(self, index_of):
+        pi, _ = super().device_params(index_of)
+        return pi, (0.1, MAX_EXCESS_STOCK_WEIGHT)     # pf0 (constant weight) is set by compile_spec
+
+
 # --------------------------------------------------------------------------------------
 # Stackelberg market (build-authored agents; golden vectors come from running the same
 # behaviour, written against ph.StrategicAgent, on the reference's StackelbergEnv)
@@ -213,8 +249,12 @@ class MockStrategicAgent(StrategicAgent):
                     "decode_action_count": "mock.decode_action_count",
                     "compute_reward_count": "mock.compute_reward_count"}
 
-    def __init__(self, agent_id: AgentID, num_steps: Optional[int] = None):
-        super().__init__(agent_id)
+    @dataclass
+    class Supertype(_Supertype):            # tests/__init__.py:34-36
+        type_value: float = 0.0
+
+    def __init__(self, agent_id: AgentID, num_steps: Optional[int] = None, supertype=None):
+        super().__init__(agent_id, supertype=supertype)
         self.num_steps = num_steps
         self.action_space = Box(0, 1, (1,))
         self.observation_space = Box(0, 1, (1,))

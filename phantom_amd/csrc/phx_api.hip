@@ -15,7 +15,7 @@
 
 size_t phx_generic_queue_bytes(int A, int Q, int scan_cap);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
-hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, float* obs, uint8_t* obs_valid, hipStream_t st);
+hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
@@ -53,6 +53,10 @@ struct Derived {
   std::vector<float> sc_tab;
   int n_tabn = 0, n_quot = 0, rew_smax = -1;
   int max_cust = 0;
+  // supertypes
+  bool any_typed = false, device_sampling = false;
+  std::vector<int32_t> type_src, shop_type_src;
+  std::vector<double> shop_type_prm;
 };
 
 static int derive(const phx_spec* sp, Derived& d) {
@@ -63,6 +67,25 @@ static int derive(const phx_spec* sp, Derived& d) {
   if (!sp->kind || !sp->param_i || !sp->param_f || !sp->row_ptr || !sp->col) return fail(PHX_EINVAL, "null table");
   if (sp->queue_cap <= 0) return fail(PHX_EINVAL, "queue_cap must be positive");
   const int A = sp->n_agents;
+  if (sp->n_samplers < 0 || (sp->n_samplers > 0 && (!sp->sampler_kind || !sp->sampler_param)))
+    return fail(PHX_EINVAL, "sampler tables missing");
+  d.device_sampling = sp->n_samplers > 0;
+  for (int j = 0; j < sp->n_samplers; ++j) {
+    if (sp->sampler_kind[j] != PHX_SAMPLER_HOST && sp->sampler_kind[j] != PHX_SAMPLER_UNIFORM)
+      return fail(PHX_EINVAL, "sampler %d: unknown kind %d", j, sp->sampler_kind[j]);
+    if (sp->sampler_kind[j] == PHX_SAMPLER_UNIFORM && !(sp->sampler_param[4 * j + 1] >= sp->sampler_param[4 * j]))
+      return fail(PHX_EINVAL, "sampler %d: high < low", j);                       // samplers.py:134
+    d.device_sampling = d.device_sampling && sp->sampler_kind[j] == PHX_SAMPLER_UNIFORM;
+  }
+  d.type_src.assign(A, PHX_TYPE_NONE);
+  for (int a = 0; a < A && sp->type_src; ++a) {
+    const int src = sp->type_src[a];
+    if (src == PHX_TYPE_NONE) continue;
+    if (src < PHX_TYPE_NONE || src >= sp->n_samplers) return fail(PHX_EINVAL, "agent %d: type_src out of range", a);
+    if (sp->kind[a] != PHX_KIND_SHOP) return fail(PHX_EUNSUPPORTED, "agent %d: only ShopAgent consumes a type field on the device", a);
+    if (!(sp->param_f[a * PHX_NPF + 1] != 0.0)) return fail(PHX_EINVAL, "agent %d: type normaliser (pf1) is zero", a);
+    d.type_src[a] = src; d.any_typed = true;
+  }
   d.A = A; d.nnz = sp->row_ptr[A];
   if (sp->row_ptr[0] != 0) return fail(PHX_EINVAL, "row_ptr[0] != 0");
   for (int a = 0; a < A; ++a) if (sp->row_ptr[a + 1] < sp->row_ptr[a]) return fail(PHX_EINVAL, "row_ptr not monotone");
@@ -72,7 +95,8 @@ static int derive(const phx_spec* sp, Derived& d) {
     const int k = sp->kind[a];
     if (k <= 0 || k >= PHX_KIND_COUNT) return fail(PHX_EINVAL, "agent %d: unknown kind %d", a, k);
     d.kind_rank[a] = d.kind_count[k]++;
-    if (kind_is_strategic(k)) { d.strat_rank[a] = d.S++; d.strat_idx.push_back(a); d.D = std::max(d.D, kind_obs_dim(k)); }
+    if (kind_is_strategic(k)) { d.strat_rank[a] = d.S++; d.strat_idx.push_back(a);
+      d.D = std::max(d.D, kind_obs_dim(k) + (k == PHX_KIND_SHOP && d.type_src[a] != PHX_TYPE_NONE ? 1 : 0)); }
     if (k == PHX_KIND_CUSTOMER) d.exo_rank[a] = d.n_exo++;
     if (k == PHX_KIND_BUYER) { d.buyer_off[a] = d.kind_rank[a]; d.buyer_dmax = std::max(d.buyer_dmax, sp->row_ptr[a + 1] - sp->row_ptr[a]); }
     const int32_t* pi = sp->param_i + a * PHX_NPI;
@@ -164,9 +188,12 @@ static int derive(const phx_spec* sp, Derived& d) {
   if (d.kind_count[PHX_KIND_SHOP] > 0) {
     const int nS = d.kind_count[PHX_KIND_SHOP];
     d.shop_agent.assign(nS, 0); d.shop_norm.assign(nS, 1);
+    d.shop_type_src.assign(nS, PHX_TYPE_NONE); d.shop_type_prm.assign((size_t)2 * nS, 0.0);
     std::vector<std::vector<int>> cust(nS);
     for (int a = 0; a < A; ++a) {
-      if (sp->kind[a] == PHX_KIND_SHOP) { d.shop_agent[d.kind_rank[a]] = a; d.shop_norm[d.kind_rank[a]] = sp->param_i[a * PHX_NPI + 1]; }
+      if (sp->kind[a] == PHX_KIND_SHOP) { d.shop_agent[d.kind_rank[a]] = a; d.shop_norm[d.kind_rank[a]] = sp->param_i[a * PHX_NPI + 1];
+        d.shop_type_src[d.kind_rank[a]] = d.type_src[a];
+        d.shop_type_prm[2 * d.kind_rank[a]] = sp->param_f[a * PHX_NPF]; d.shop_type_prm[2 * d.kind_rank[a] + 1] = sp->param_f[a * PHX_NPF + 1]; }
       if (sp->kind[a] == PHX_KIND_CUSTOMER) cust[d.kind_rank[sp->param_i[a * PHX_NPI]]].push_back(a);
     }
     d.shop_cust_ptr.push_back(0);
@@ -215,6 +242,7 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_ENV_TERM, "env.term", 2, 0, B, S, 1, 0}, {F_ENV_TRUNC, "env.trunc", 2, 0, B, S, 1, 0},
     {F_ENV_REW_CACHE, "env.rew_cache", 1, 0, B, S, 1, 0}, {F_ENV_REW_CACHE_VALID, "env.rew_cache_valid", 2, 0, B, S, 1, 0},
     {F_ENV_OBS_CACHE, "env.obs_cache", 3, 0, B, S, d.D, 0}, {F_ENV_OBS_CACHE_VALID, "env.obs_cache_valid", 2, 0, B, S, 1, 0},
+    {F_ENV_SAMPLER, "env.sampler", 1, 0, B, sp->n_samplers, 1, 0}, {F_ENV_EPISODE, "env.episode", 0, 0, B, sp->n_samplers > 0 ? 1 : 0, 1, 0},
     {F_SHOP_STOCK, "shop.stock", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_SALES, "shop.sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_MISSED, "shop.missed_sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
@@ -332,6 +360,11 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());
   UP(shop_cust_act, der.shop_cust_act.data(), der.shop_cust_act.size());
   UP(sc_tab, der.sc_tab.data(), der.sc_tab.size());
+  UP(sampler_kind, spec->sampler_kind, spec->n_samplers); UP(sampler_param, spec->sampler_param, 4 * spec->n_samplers);
+  UP(type_src, der.type_src.data(), A);
+  UP(shop_type_src, der.shop_type_src.data(), der.shop_type_src.size());
+  UP(shop_type_prm, der.shop_type_prm.data(), der.shop_type_prm.size());
+  d.n_samplers = spec->n_samplers; d.any_typed = der.any_typed ? 1 : 0; d.device_sampling = der.device_sampling ? 1 : 0;
   d.n_tabn = der.n_tabn; d.n_quot = der.n_quot; d.rew_smax = der.rew_smax;
 #undef UP
   d.max_cust = der.max_cust;
@@ -350,7 +383,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     (void)hipMemcpy(d.f[F_ENV_STAGE], st.data(), st.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d.f[F_ENV_PREV_STAGE], pv.data(), pv.size() * 4, hipMemcpyHostToDevice);
   }
-  he = phx_launch_reset(d, nullptr, nullptr, nullptr, 0);
+  he = phx_launch_reset(d, nullptr, nullptr, nullptr, nullptr, 0);   // also the constructor's first sampler draw, env.py:118-119
   if (he == hipSuccess) he = hipDeviceSynchronize();
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "initial reset: %s", hipGetErrorString(he)); }
   *out = e;
@@ -386,10 +419,12 @@ static inline hipError_t use_device(const phx_env* e) {
   return cur == e->device ? hipSuccess : hipSetDevice(e->device);
 }
 
-int phx_reset(phx_env* e, const uint8_t* reset_mask, float* obs, uint8_t* obs_valid, void* stream) {
+int phx_reset(phx_env* e, const uint8_t* reset_mask, const double* sampler_values, float* obs, uint8_t* obs_valid,
+              void* stream) {
   if (!e) return fail(PHX_EINVAL, "null env");
+  if (sampler_values && e->d.n_samplers == 0) return fail(PHX_EINVAL, "sampler_values given but the spec has no samplers");
   HIPCHK(use_device(e));
-  HIPCHK(phx_launch_reset(e->d, reset_mask, obs, obs_valid, (hipStream_t)stream));
+  HIPCHK(phx_launch_reset(e->d, reset_mask, sampler_values, obs, obs_valid, (hipStream_t)stream));
   return PHX_OK;
 }
 
@@ -474,8 +509,11 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
+  if (e->d.n_samplers > 0 && !e->d.device_sampling)
+    return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   HIPCHK(use_device(e));
-  if (e->d.env_type == PHX_ENV_FSM) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
+  // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
+  if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
   return PHX_OK;
 }

@@ -25,7 +25,7 @@ static_assert(sizeof(DevMsg) == 16, "DevMsg must be 16 bytes");
 enum {
   F_ENV_STEP = 0, F_ENV_STAGE, F_ENV_PREV_STAGE, F_ENV_TICK, F_ENV_CLOCK,
   F_ENV_TERM, F_ENV_TRUNC, F_ENV_REW_CACHE, F_ENV_REW_CACHE_VALID, F_ENV_OBS_CACHE,
-  F_ENV_OBS_CACHE_VALID,
+  F_ENV_OBS_CACHE_VALID, F_ENV_SAMPLER, F_ENV_EPISODE,
   F_SHOP_STOCK, F_SHOP_SALES, F_SHOP_MISSED, F_SHOP_DELIVERED,
   F_SELLER_PRICE, F_SELLER_REVENUE, F_SELLER_TX,
   F_BUYER_PRICES, F_BUYER_PAID, F_BUYER_BOUGHT,
@@ -82,6 +82,15 @@ struct DevSpec {
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)
   const float* sc_tab;
   int32_t n_tabn, n_quot, rew_smax;
+  // Supertypes / Samplers (supertype.py:16-30, utils/samplers.py, env.py:211-216)
+  int32_t n_samplers;            // columns of env.sampler
+  int32_t any_typed;             // some shop consumes a type field (obs dim 4, weighted penalty)
+  int32_t device_sampling;       // every sampler is PHX_SAMPLER_UNIFORM (rollouts can auto-reset)
+  const int32_t* sampler_kind;   // [n_samplers]
+  const double*  sampler_param;  // [n_samplers][4] low, high, clip_low, clip_high (NaN = None)
+  const int32_t* type_src;       // [A] sampler column, PHX_TYPE_CONST or PHX_TYPE_NONE
+  const int32_t* shop_type_src;  // [nS] the same per shop (kind-rank order)
+  const double*  shop_type_prm;  // [nS][2] constant weight, obs normaliser (param_f of the shop)
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env
@@ -264,6 +273,35 @@ __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, u
   return sum;
 }
 
+// UniformFloatSampler column j at the env's `episode`-th reset (definition restated in
+// oracle/phx_oracle.c: phxo_rng_uniform): ctr = (env_lo, env_hi, episode, 0x80000000 | j);
+// u = ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53; low + (high - low) * u rounded per operation; np.clip.
+__device__ __forceinline__ double rng_uniform(uint64_t seed, int64_t genv, uint32_t episode, int j,
+                                              const double* prm) {
+  uint32_t w[4];
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, 0x80000000u | (uint32_t)j,
+                (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const double u = __dmul_rn(__dadd_rn(__dmul_rn((double)(w[0] >> 5), 67108864.0), (double)(w[1] >> 6)),
+                             1.0 / 9007199254740992.0);
+  double v = __dadd_rn(prm[0], __dmul_rn(__dsub_rn(prm[1], prm[0]), u));
+  if (prm[2] == prm[2] && v < prm[2]) v = prm[2];
+  if (prm[3] == prm[3] && v > prm[3]) v = prm[3];
+  return v;
+}
+// env.reset(): `for sampler in self._samplers: sampler.sample()` (env.py:211-212) for column j
+__device__ __forceinline__ double dev_sample_column(const DevSpec& sp, int b, int j, uint32_t episode,
+                                                    const double* values, double current) {
+  if (values) return values[(int64_t)b * sp.n_samplers + j];
+  if (sp.sampler_kind[j] == PHX_SAMPLER_UNIFORM)
+    return rng_uniform(sp.seed, sp.env_offset + b, episode, j, sp.sampler_param + 4 * j);
+  return current;
+}
+// agent.type.<field> of a shop: the managed Sampler's current value or the constant
+__device__ __forceinline__ double shop_type_value(const DevSpec& sp, int b, int s) {
+  const int src = sp.shop_type_src[s];
+  return src >= 0 ? fld<double>(sp, F_ENV_SAMPLER)[(int64_t)b * sp.n_samplers + src] : sp.shop_type_prm[2 * s];
+}
+
 __device__ __forceinline__ float rng_word_to_action(uint32_t w3) {
   return (float)(w3 >> 8) * (100.0f / 16777216.0f);
 }
@@ -283,6 +321,10 @@ __device__ __forceinline__ int dev_round_half_even(float a) {
 __device__ __forceinline__ double shop_reward(int sales, int stock) {
   const double penalty = __dmul_rn(0.1, (double)stock);
   return __dsub_rn((double)sales, penalty);
+}
+// tutorial 2's shop: sales - type.excess_stock_weight * stock  (docs/user/tutorial2.rst:270-273)
+__device__ __forceinline__ double shop_reward_w(int sales, int stock, double w) {
+  return __dsub_rn((double)sales, __dmul_rn(w, (double)stock));
 }
 
 // ShopAgent.encode_observation (supply_chain.py:124-134): python-float quotient cast to f32
@@ -345,6 +387,8 @@ __device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, const Topo& tp
     case PHX_KIND_SHOP:
       shop_obs(fld<int32_t>(sp, F_SHOP_STOCK)[r.base], fld<int32_t>(sp, F_SHOP_SALES)[r.base],
                fld<int32_t>(sp, F_SHOP_MISSED)[r.base], tp.param_i[a * PHX_NPI + 1], o);
+      if (sp.any_typed && sp.shop_type_src[r.kr] != PHX_TYPE_NONE)          // tutorial2.rst:283-294
+        o[3] = (float)(shop_type_value(sp, b, r.kr) / sp.shop_type_prm[2 * r.kr + 1]);
       break;
     case PHX_KIND_SELLER: {
       const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
@@ -373,6 +417,9 @@ __device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, const To
   const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
     case PHX_KIND_SHOP:
+      if (sp.any_typed && sp.shop_type_src[r.kr] != PHX_TYPE_NONE)
+        return shop_reward_w(fld<int32_t>(sp, F_SHOP_SALES)[r.base], fld<int32_t>(sp, F_SHOP_STOCK)[r.base],
+                             shop_type_value(sp, b, r.kr));
       return shop_reward(fld<int32_t>(sp, F_SHOP_SALES)[r.base], fld<int32_t>(sp, F_SHOP_STOCK)[r.base]);
     case PHX_KIND_SELLER: return fld<double>(sp, F_SELLER_REVENUE)[r.base];
     case PHX_KIND_BUYER:

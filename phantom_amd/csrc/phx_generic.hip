@@ -482,12 +482,20 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
 
 // ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------
 template <int NT>
-__global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask, float* obs,
+__global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask,
+                                                       const double* sampler_values, float* obs,
                                                        uint8_t* obs_valid) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (mask && !mask[b]) return;
   const int A = sp.A, S = sp.S, D = sp.D;
   const Topo tp = topo_global(sp);
+  if (sp.n_samplers > 0) {                                              // env.py:211-212
+    const uint32_t ep = (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b];
+    double* sv = fld<double>(sp, F_ENV_SAMPLER) + (int64_t)b * sp.n_samplers;
+    for (int j = tid; j < sp.n_samplers; j += NT) sv[j] = dev_sample_column(sp, b, j, ep, sampler_values, sv[j]);
+    __syncthreads();
+    if (tid == 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)(ep + 1);
+  }
   for (int a = tid; a < A; a += NT) dev_agent_reset(sp, tp, b, a);          // network.py:183-184
   for (int s = tid; s < S; s += NT) {
     fld<uint8_t>(sp, F_ENV_TERM)[(int64_t)b * S + s] = 0;               // env.py:223-224
@@ -545,8 +553,8 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   return hipGetLastError();
 }
 
-hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, float* obs, uint8_t* obs_valid,
-                            hipStream_t st) {
-  hipLaunchKernelGGL((phx_reset_kernel<64>), dim3(sp.B), dim3(64), 0, st, sp, mask, obs, obs_valid);
+hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, float* obs,
+                            uint8_t* obs_valid, hipStream_t st) {
+  hipLaunchKernelGGL((phx_reset_kernel<64>), dim3(sp.B), dim3(64), 0, st, sp, mask, sampler_values, obs, obs_valid);
   return hipGetLastError();
 }

@@ -126,37 +126,47 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   // ---- obs / reward / done with the PLAIN or FSM masks (env.py:273-292, fsm.py:309-380) -------
   // ShopAgent never terminates or truncates (agents.py:292-323), so __all__ needs no reduction:
   const bool all_trunc = (t == sp.num_steps);                                // env.py:312-318
-  float ob[3] = {0.f, 0.f, 0.f};
+  // tutorial 2's typed shop (docs/user/tutorial2.rst:244-307): weighted penalty + 4th observation
+  const int OD = sp.D;
+  const bool typed = sp.any_typed && sp.shop_type_src[s] != PHX_TYPE_NONE;
+  const double tw = typed ? shop_type_value(sp, b, s) : 0.0;
+  const float tobs = typed ? (float)(tw / sp.shop_type_prm[2 * s + 1]) : 0.f;
+  float ob[4] = {0.f, 0.f, 0.f, 0.f};
   uint8_t ov = 0, rv = 0;
   double rw = 0.0;
   if (sp.env_type == PHX_ENV_PLAIN) {
     shop_obs_f32(st.stock, st.sales, st.missed, (float)sp.param_i[a_shop * PHX_NPI + 1], ob);
-    rw = shop_reward(st.sales, st.stock);
+    ob[3] = tobs;
+    rw = typed ? shop_reward_w(st.sales, st.stock, tw) : shop_reward(st.sales, st.stock);
     ov = 1; rv = 1;
   } else {
     double* rc = fld<double>(sp, F_ENV_REW_CACHE) + g;
     uint8_t* rcv = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + g;
-    float* oc = fld<float>(sp, F_ENV_OBS_CACHE) + g * 3;
+    float* oc = fld<float>(sp, F_ENV_OBS_CACHE) + g * OD;
     uint8_t* ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + g;
     const bool observes = sp.obs_mask[(int64_t)list * A + a_shop] != 0;
     if (observes) {
       shop_obs_f32(st.stock, st.sales, st.missed, (float)sp.param_i[a_shop * PHX_NPI + 1], ob);
+      ob[3] = tobs;
       oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; *ocv = 1;                  // fsm.py:349
+      if (OD == 4) oc[3] = ob[3];
     }
     uint8_t cache_valid = *rcv; double cache = *rc;
     if (sp.rew_mask[(int64_t)list * A + a_shop]) {                            // fsm.py:334-335,350
-      cache = shop_reward(st.sales, st.stock); cache_valid = 1;
+      cache = typed ? shop_reward_w(st.sales, st.stock, tw) : shop_reward(st.sales, st.stock); cache_valid = 1;
       *rc = cache; *rcv = 1;
     }
     if (all_trunc) {                                                          // fsm.py:360-375
       ov = *ocv;
       ob[0] = ov ? oc[0] : 0.f; ob[1] = ov ? oc[1] : 0.f; ob[2] = ov ? oc[2] : 0.f;
+      ob[3] = (ov && OD == 4) ? oc[3] : 0.f;
       rv = cache_valid ? 1 : 2; rw = cache_valid ? cache : 0.0;
     } else if (observes) {                                                    // fsm.py:378
       ov = 1; rv = cache_valid ? 1 : 2; rw = cache_valid ? cache : 0.0;
-    } else { ob[0] = ob[1] = ob[2] = 0.f; }
+    } else { ob[0] = ob[1] = ob[2] = ob[3] = 0.f; }
   }
-  io.obs[g * 3 + 0] = ob[0]; io.obs[g * 3 + 1] = ob[1]; io.obs[g * 3 + 2] = ob[2];
+  if (OD == 4) *(float4*)(io.obs + g * 4) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+  else { io.obs[g * 3 + 0] = ob[0]; io.obs[g * 3 + 1] = ob[1]; io.obs[g * 3 + 2] = ob[2]; }
   io.reward[g] = rw;
   io.obs_valid[g] = ov; io.reward_valid[g] = rv; io.done_valid[g] = 1;
   io.terminated[g] = 0; io.truncated[g] = 0;
@@ -433,7 +443,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
   }
 }
 
-// ---- FSM rollout: T steps per launch for FiniteStateMachineEnv supply chains (BASELINE config 3).
+// ---- FSM rollout: T steps per launch for FiniteStateMachineEnv supply chains (BASELINE config 3)
+// and for envs with typed shops (tutorial 2; a plain env is the one-stage special case).
 // One lane owns one (env, shop) and walks the steps in order: the stage masks (who acts, who
 // observes, who is rewarded -- fsm.py:276-345), the reward cache with emit-on-observe and the
 // terminal dump of the cached dicts (fsm.py:349-378) are all sequential in time, so this kernel
@@ -474,10 +485,20 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g]; st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
   double rc = fld<double>(sp, F_ENV_REW_CACHE)[g];                           // self._rewards[aid]
   uint8_t rcv = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g];
-  float oc[3] = {fld<float>(sp, F_ENV_OBS_CACHE)[g * 3], fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 1],
-                 fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 2]};               // self._observations[aid]
+  const int OD = sp.D;            // observation length (D below is the demand)
+  float oc[4] = {fld<float>(sp, F_ENV_OBS_CACHE)[g * OD], fld<float>(sp, F_ENV_OBS_CACHE)[g * OD + 1],
+                 fld<float>(sp, F_ENV_OBS_CACHE)[g * OD + 2],
+                 OD == 4 ? fld<float>(sp, F_ENV_OBS_CACHE)[g * OD + 3] : 0.f};   // self._observations[aid]
   uint8_t ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g];
-  float lo[3] = {0.f, 0.f, 0.f};
+  float lo[4] = {0.f, 0.f, 0.f, 0.f};
+  // typed shop: weight and 4th observation from the sampler column, redrawn at every auto-reset
+  const int tsrc = sp.any_typed ? sp.shop_type_src[s] : PHX_TYPE_NONE;
+  const bool typed = tsrc != PHX_TYPE_NONE;
+  double tw = typed ? shop_type_value(sp, b, s) : 0.0;
+  const double tnorm = typed ? sp.shop_type_prm[2 * s + 1] : 1.0;
+  float tobs = typed ? (float)(tw / tnorm) : 0.f;
+  uint32_t episode = sp.n_samplers > 0 ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
+  int n_resets = 0;
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t o = (int64_t)t * total + g;
@@ -500,42 +521,56 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     sc_shop_step(st, has_action, action, any_order, D);
     ++step; ++tick;
     const bool all_trunc = (step == sp.num_steps);                           // env.py:312-318
-    float ob[3] = {0.f, 0.f, 0.f};
+    float ob[4] = {0.f, 0.f, 0.f, 0.f};
     uint8_t ov = 0, rv = 0; double rw = 0.0;
     const bool observes = (fl & 8) != 0;
     if (observes) {                                                          // fsm.py:328-332,349
       shop_obs_f32(st.stock, st.sales, st.missed, norm, ob);
-      oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; ocv = 1;
+      ob[3] = tobs;
+      oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; oc[3] = ob[3]; ocv = 1;
     }
-    if (fl & 16) { rc = shop_reward(st.sales, st.stock); rcv = 1; }         // fsm.py:334-335,350
+    if (fl & 16) { rc = typed ? shop_reward_w(st.sales, st.stock, tw) : shop_reward(st.sales, st.stock); rcv = 1; }   // fsm.py:334-335,350
     if (all_trunc) {                                                         // fsm.py:360-375
-      ov = ocv; ob[0] = ocv ? oc[0] : 0.f; ob[1] = ocv ? oc[1] : 0.f; ob[2] = ocv ? oc[2] : 0.f;
+      ov = ocv; ob[0] = ocv ? oc[0] : 0.f; ob[1] = ocv ? oc[1] : 0.f; ob[2] = ocv ? oc[2] : 0.f; ob[3] = ocv ? oc[3] : 0.f;
       rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
     } else if (observes) {                                                   // fsm.py:378
       ov = 1; rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
     }
-    io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2];
+    if (OD == 4) *(float4*)(io.obs + o * 4) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+    else { io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2]; }
     io.action_out[o] = action;
     io.reward[o] = (float)rw;
     io.terminated[o] = 0; io.truncated[o] = all_trunc;
-    io.obs_valid[o] = ov; io.reward_valid[o] = rv;
-    lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2];
+    if (io.obs_valid) io.obs_valid[o] = ov;
+    if (io.reward_valid) io.reward_valid[o] = rv;
+    lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2]; lo[3] = ob[3];
     prev_stage = stage; stage = sp.stage_next[stage];                        // fsm.py:355
     if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
       st.stock = 0; step = 0; stage = sp.initial_stage; rcv = 0;
-      lo[0] = lo[1] = lo[2] = 0.f;
-      if (s_fl[sp.initial_stage * nS + s] & 1) shop_obs_f32(st.stock, st.sales, st.missed, norm, lo);
+      if (tsrc >= 0) {                                                       // env.py:211-212, agents.py:167-168
+        tw = rng_uniform(sp.seed, genv, episode, tsrc, sp.sampler_param + 4 * tsrc);
+        tobs = (float)(tw / tnorm);
+      }
+      ++episode; ++n_resets;
+      lo[0] = lo[1] = lo[2] = lo[3] = 0.f;
+      if (s_fl[sp.initial_stage * nS + s] & 1) { shop_obs_f32(st.stock, st.sales, st.missed, norm, lo); lo[3] = tobs; }
     }
   }
   fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock; fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
   fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed; fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
   fld<double>(sp, F_ENV_REW_CACHE)[g] = rc; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g] = rcv;
-  fld<float>(sp, F_ENV_OBS_CACHE)[g * 3] = oc[0]; fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 1] = oc[1];
-  fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 2] = oc[2]; fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g] = ocv;
-  if (io.last_obs) { io.last_obs[g * 3] = lo[0]; io.last_obs[g * 3 + 1] = lo[1]; io.last_obs[g * 3 + 2] = lo[2]; }
+  for (int d = 0; d < OD; ++d) fld<float>(sp, F_ENV_OBS_CACHE)[g * OD + d] = oc[d];
+  fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g] = ocv;
+  if (io.last_obs) for (int d = 0; d < OD; ++d) io.last_obs[g * OD + d] = lo[d];
   if (s == 0) {
     fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
-    fld<int32_t>(sp, F_ENV_STAGE)[b] = stage; fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = prev_stage;
+    if (sp.env_type == PHX_ENV_FSM) { fld<int32_t>(sp, F_ENV_STAGE)[b] = stage; fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = prev_stage; }
+    if (sp.n_samplers > 0 && n_resets > 0) {      // every column as drawn at the last auto-reset
+      fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)episode;
+      for (int j = 0; j < sp.n_samplers; ++j)
+        fld<double>(sp, F_ENV_SAMPLER)[(int64_t)b * sp.n_samplers + j] =
+            rng_uniform(sp.seed, genv, episode - 1u, j, sp.sampler_param + 4 * j);
+    }
   }
 }
 

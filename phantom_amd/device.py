@@ -149,9 +149,16 @@ class DeviceEnv:
         return v[0].item() if self.B == 1 else v
 
     # ---- entry points ---------------------------------------------------------------------
-    def reset(self, mask=None):
+    def reset(self, mask=None, sampler_values=None):
+        """``sampler_values``: f64 [B, n_samplers] (host array or device tensor) = what
+        `sampler.sample()` returned for each env (env.py:211-212); None -> device-drawn."""
         torch = _torch()
-        mp = None
+        mp = vp = None
+        if sampler_values is not None:
+            self._sampler_values = torch.as_tensor(sampler_values, dtype=torch.float64).to(
+                self.device).contiguous()
+            assert self._sampler_values.shape == (self.B, self.spec.n_samplers)
+            vp = self._sampler_values.data_ptr()
         if mask is not None:
             mask = torch.as_tensor(mask, dtype=torch.uint8, device=self.device).contiguous()
             mp = mask.data_ptr()
@@ -159,7 +166,7 @@ class DeviceEnv:
         else:
             self.err.zero_()
         with torch.cuda.device(self.device):
-            self._check(self.lib.phx_reset(self.handle, mp, self.obs.data_ptr(),
+            self._check(self.lib.phx_reset(self.handle, mp, vp, self.obs.data_ptr(),
                                            self.obs_valid.data_ptr(), self._stream()), "phx_reset")
         return self.obs, self.obs_valid
 

@@ -33,9 +33,6 @@ class PhantomEnv:
                  agent_supertypes=None, *, batch_size: int = 1, device=None, seed: int = 0,
                  env_offset: int = 0, exogenous: Optional[str] = None,
                  force_generic: bool = False) -> None:
-        if env_supertype is not None or agent_supertypes is not None:
-            raise NotImplementedError("Supertypes are reset-time host features outside the "
-                                      "device hot path (SURVEY.md 8f-3)")
         self.network = network or Network()
         self.num_steps = num_steps
         self.batch_size = int(batch_size)
@@ -55,12 +52,84 @@ class PhantomEnv:
         self.network._owner = self
         for a in self.network.agents.values():
             a._env = self
+        self._init_supertypes(env_supertype, agent_supertypes)
+
+    # ---- Supertypes / Samplers (env.py:80-124) ------------------------------------------------
+    def _init_supertypes(self, env_supertype, agent_supertypes):
+        from .samplers import Sampler, UniformFloatSampler
+        self._samplers: List = []          # distinct Sampler objects, env supertype first
+
+        def adopt(st):
+            st._managed = True             # the env samples, the supertype reads .value
+            for v in st.__dict__.values():
+                if isinstance(v, Sampler) and not any(v is s for s in self._samplers):
+                    self._samplers.append(v)
+
+        if env_supertype is not None:
+            if isinstance(env_supertype, dict):
+                env_supertype = self.Supertype(**env_supertype)
+            adopt(env_supertype)
+            self.env_supertype = env_supertype
+        if agent_supertypes is not None:
+            for aid, st in agent_supertypes.items():
+                if isinstance(st, dict):
+                    st = self.agents[aid].Supertype(**st)
+                adopt(st)
+                self.network.agents[aid].supertype = st
+        #: every sampler is drawn by the device Philox stream (no host round trip at reset,
+        #: fused rollouts can auto-reset): needs exogenous="device" and only UniformFloatSamplers
+        self._device_sampling = bool(self._samplers) and self.exogenous == "device" and all(
+            isinstance(s, UniformFloatSampler) for s in self._samplers)
+        # values drawn on the host, one row per env instance (None while the device samples)
+        self._sampled = None
+        if self._samplers and not self._device_sampling:
+            self._sampled = np.empty((self.batch_size, len(self._samplers)), dtype=object)
+            self._host_sample(None)        # "Generate initial sampled values", env.py:118-119
+
+    def _host_sample(self, mask):
+        """`for sampler in self._samplers: sampler.sample()` (env.py:211-212) once per env
+        instance being reset, env by env -- the order a list of reference envs would consume
+        the global numpy stream in.  Returns the f64 matrix handed to phx_reset."""
+        if self._sampled is None:
+            return None
+        for b in range(self.batch_size):
+            if mask is None or mask[b]:
+                for j, sm in enumerate(self._samplers):
+                    self._sampled[b, j] = sm.sample()
+        vals = np.zeros(self._sampled.shape, dtype=np.float64)
+        for idx, v in np.ndenumerate(self._sampled):
+            try:
+                vals[idx] = float(v)
+            except (TypeError, ValueError):
+                vals[idx] = np.nan         # array-valued samplers have no device consumer
+        return vals
+
+    def _resolve_type(self, st):
+        """the *type* of a managed supertype: Samplers replaced by their per-env values."""
+        from .samplers import Sampler
+        out = {}
+        for name in st.__dataclass_fields__:
+            v = getattr(st, name)
+            if isinstance(v, Sampler):
+                j = [k for k, sm in enumerate(self._samplers) if sm is v]
+                if not j:
+                    out[name] = v.value
+                elif self._sampled is not None:
+                    col = self._sampled[:, j[0]]
+                    out[name] = col[0] if self.batch_size == 1 else np.asarray(list(col))
+                else:
+                    col = self._device().field("env.sampler")[:, j[0]].cpu().numpy()
+                    out[name] = float(col[0]) if self.batch_size == 1 else col
+            else:
+                out[name] = v
+        return st.__class__(**out)
 
     # ---- spec / device (lazy, so that construction and validation work without a GPU) -------
     def _compile(self) -> EnvSpec:
         return compile_spec(self.network, self.num_steps, self.batch_size, self._env_type,
                             seed=self._seed, env_offset=self._env_offset,
-                            force_generic=self._force_generic)
+                            force_generic=self._force_generic, samplers=self._samplers,
+                            device_sampling=self._device_sampling)
 
     @property
     def spec(self) -> EnvSpec:
@@ -170,15 +239,17 @@ class PhantomEnv:
         """env.py:185-237.  ``seed`` is accepted and ignored exactly as in the reference, where
         it only seeds ``self.np_random`` which nothing consumes."""
         dev = self._device()
-        obs, valid = dev.reset(mask)
+        obs, valid = dev.reset(mask, self._host_sample(mask))
         self._host_reset(mask)
+        if self.env_supertype is not None:                   # env.py:214-215
+            self.env_type = self._resolve_type(self.env_supertype)
         return self._obs_dict(obs.cpu().numpy(), valid.cpu().numpy()), {}
 
     def _obs_dict(self, obs: np.ndarray, valid: np.ndarray) -> Dict[AgentID, Any]:
         out = {}
         spec = self.spec
         for s, a in enumerate(spec.strategic_idx):
-            d = _abi.OBS_DIM[int(spec.kind[a])]
+            d = spec.agent_obs_dim(a)
             if self.batch_size == 1:
                 if valid[0, s]:
                     out[spec.agent_ids[a]] = obs[0, s, :d].copy()
@@ -256,7 +327,7 @@ class PhantomEnv:
         observations, rewards, terminations, truncations, infos = {}, {}, {}, {}, {}
         for s, a in enumerate(spec.strategic_idx):
             aid = spec.agent_ids[a]
-            d = _abi.OBS_DIM[int(spec.kind[a])]
+            d = spec.agent_obs_dim(a)
             if B == 1:
                 if ov[0, s]:
                     observations[aid] = obs[0, s, :d].copy()

@@ -42,6 +42,10 @@ class EnvSpec:
     # Stackelberg
     leaders: Optional[np.ndarray] = None
     followers: Optional[np.ndarray] = None
+    # Supertypes / Samplers: one column per distinct Sampler of env._samplers (env.py:80-119)
+    sampler_kind: Optional[np.ndarray] = None     # i32 [n_samplers]
+    sampler_param: Optional[np.ndarray] = None    # f64 [n_samplers, 4]
+    type_src: Optional[np.ndarray] = None         # i32 [A]
 
     # ---- derived ------------------------------------------------------------------------
     @property
@@ -61,8 +65,20 @@ class EnvSpec:
         return int(len(self.strategic_idx))
 
     @property
+    def n_samplers(self) -> int:
+        return 0 if self.sampler_kind is None else int(len(self.sampler_kind))
+
+    def agent_obs_dim(self, a: int) -> int:
+        """observation length of strategic agent index ``a`` (a typed shop appends its type)."""
+        d = _abi.OBS_DIM[int(self.kind[a])]
+        if self.type_src is not None and int(self.kind[a]) == _abi.KIND_SHOP \
+                and int(self.type_src[a]) != _abi.TYPE_NONE:
+            d += 1
+        return d
+
+    @property
     def obs_dim(self) -> int:
-        d = [_abi.OBS_DIM[k] for k in self.kind.tolist() if k in _abi.OBS_DIM]
+        d = [self.agent_obs_dim(a) for a, k in enumerate(self.kind.tolist()) if k in _abi.OBS_DIM]
         return max(d) if d else 1
 
     @property
@@ -117,6 +133,10 @@ class EnvSpec:
         s.followers = ptr(self.followers, np.int32)
         s.seed = self.seed & 0xFFFFFFFFFFFFFFFF
         s.env_offset = self.env_offset
+        s.n_samplers = self.n_samplers
+        s.sampler_kind = ptr(self.sampler_kind, np.int32) if self.n_samplers else None
+        s.sampler_param = ptr(self.sampler_param, np.float64) if self.n_samplers else None
+        s.type_src = ptr(self.type_src, np.int32)
         return s, keep
 
 
@@ -133,7 +153,8 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                  stages: Optional[Sequence] = None, initial_stage=None,
                  leaders: Optional[Sequence] = None, followers: Optional[Sequence] = None,
                  seed: int = 0, env_offset: int = 0, force_generic: bool = False,
-                 extra_queue: int = 16) -> EnvSpec:
+                 extra_queue: int = 16, samplers: Optional[Sequence] = None,
+                 device_sampling: bool = False) -> EnvSpec:
     from .agents import Agent, StrategicAgent
     agent_ids = list(network.agents.keys())
     A = len(agent_ids)
@@ -225,4 +246,33 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
     elif env_type == _abi.ENV_STACKELBERG:
         spec.leaders = np.asarray([index_of(a) for a in leaders], dtype=np.int32)
         spec.followers = np.asarray([index_of(a) for a in followers], dtype=np.int32)
+
+    # ---- Supertypes: the device-consumed type field of each agent (agents.py:160-175) ----------
+    from .samplers import Sampler, UniformFloatSampler
+    samplers = list(samplers or [])
+    if samplers:
+        spec.sampler_kind = np.asarray(
+            [_abi.SAMPLER_UNIFORM if device_sampling and isinstance(sm, UniformFloatSampler)
+             else _abi.SAMPLER_HOST for sm in samplers], dtype=np.int32)
+        spec.sampler_param = np.asarray(
+            [sm.device_params() if isinstance(sm, UniformFloatSampler) else (np.nan,) * 4
+             for sm in samplers], dtype=np.float64).reshape(len(samplers), 4)
+    type_src = np.full(A, _abi.TYPE_NONE, dtype=np.int32)
+    for a, aid in enumerate(agent_ids):
+        agent = network.agents[aid]
+        fname = getattr(agent, "device_type_field", None)
+        if fname is None:
+            continue
+        st = agent.supertype if agent.supertype is not None else agent.Supertype()   # agents.py:167-171
+        v = getattr(st, fname)
+        if isinstance(v, Sampler):
+            col = [j for j, sm in enumerate(samplers) if sm is v]
+            if not col:
+                raise ValueError(f"agent '{aid}': Sampler of '{fname}' is not managed by the env")
+            type_src[a] = col[0]
+        else:
+            type_src[a] = _abi.TYPE_CONST
+            spec.param_f[a, 0] = float(v)
+    if (type_src != _abi.TYPE_NONE).any():
+        spec.type_src = type_src
     return spec

@@ -8,7 +8,7 @@ arguments build the synthetic benchmark topologies of BASELINE.json (SC64 = 1 fa
 from typing import List, Optional, Sequence
 
 from .agents import (CUSTOMER_MAX_ORDER_SIZE, SHOP_MAX_STOCK, CustomerAgent, FactoryAgent,
-                     ShopAgent)
+                     ShopAgent, TypedShopAgent)
 from .env import PhantomEnv
 from .fsm import FiniteStateMachineEnv, FSMStage
 from .message import OrderRequest, OrderResponse, StockRequest, StockResponse  # noqa: F401
@@ -18,9 +18,11 @@ NUM_EPISODE_STEPS = 100      # supply_chain.py:9
 NUM_CUSTOMERS = 5            # supply_chain.py:11
 
 
-def build_network(n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS, resolver=None) -> Network:
+def build_network(n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS, resolver=None,
+                  typed: bool = False) -> Network:
     """Supply-chain topology.  ``customers_per_shop`` may be an int or a per-shop sequence
-    (ragged).  With the defaults the ids are those of the shipped example."""
+    (ragged).  With the defaults the ids are those of the shipped example.  ``typed`` builds
+    tutorial 2's shops (TypedShopAgent: Supertype.excess_stock_weight)."""
     ks: Sequence[int] = ([customers_per_shop] * n_shops if isinstance(customers_per_shop, int)
                          else list(customers_per_shop))
     assert len(ks) == n_shops
@@ -31,7 +33,8 @@ def build_network(n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS, resolver=N
         factory_id = "WAREHOUSE"
         shop_ids = [f"SHOP{i}" for i in range(n_shops)]
         cust_ids = [[f"CUST{i}_{j}" for j in range(ks[i])] for i in range(n_shops)]
-    shops = [ShopAgent(sid, factory_id=factory_id, num_customers=ks[i])
+    shop_cls = TypedShopAgent if typed else ShopAgent
+    shops = [shop_cls(sid, factory_id=factory_id, num_customers=ks[i])
              for i, sid in enumerate(shop_ids)]
     customers = [CustomerAgent(cid, shop_id=shop_ids[i]) for i in range(n_shops) for cid in cust_ids[i]]
     network = Network(shops + [FactoryAgent(factory_id)] + customers, resolver=resolver)
@@ -44,8 +47,9 @@ def build_network(n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS, resolver=N
 
 class SupplyChainEnv(PhantomEnv):
     def __init__(self, n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS,
-                 num_steps: int = NUM_EPISODE_STEPS, resolver=None, **device_kwargs):
-        network = build_network(n_shops, customers_per_shop, resolver)
+                 num_steps: int = NUM_EPISODE_STEPS, resolver=None, typed: bool = False,
+                 **device_kwargs):
+        network = build_network(n_shops, customers_per_shop, resolver, typed)
         super().__init__(num_steps=num_steps, network=network, **device_kwargs)
 
 
@@ -54,8 +58,9 @@ class SupplyChainFSMEnv(FiniteStateMachineEnv):
     rewarded=[]} -> RESTOCK, handler-less."""
 
     def __init__(self, n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS,
-                 num_steps: int = NUM_EPISODE_STEPS, resolver=None, **device_kwargs):
-        network = build_network(n_shops, customers_per_shop, resolver)
+                 num_steps: int = NUM_EPISODE_STEPS, resolver=None, typed: bool = False,
+                 **device_kwargs):
+        network = build_network(n_shops, customers_per_shop, resolver, typed)
         shops = [a.id for a in network.agents.values() if isinstance(a, ShopAgent)]
         customers = [a.id for a in network.agents.values() if isinstance(a, CustomerAgent)]
         stages = [

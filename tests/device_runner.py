@@ -28,8 +28,8 @@ class DeviceRunner:
         self.err = d.err.cpu().numpy()
         self.msg_count = d.msg_count.cpu().numpy() if d.msg_count is not None else None
 
-    def reset(self, mask=None):
-        obs, valid = self.dev.reset(mask)
+    def reset(self, mask=None, sampler_values=None):
+        obs, valid = self.dev.reset(mask, sampler_values)
         self.err = self.dev.err.cpu().numpy()
         return obs.cpu().numpy(), valid.cpu().numpy()
 

@@ -61,9 +61,43 @@ def log_array(msgs, index):
 # ------------------------------------------------------------------------------------------
 # supply chain
 # ------------------------------------------------------------------------------------------
-def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=False, fsm=False):
+MAX_EXCESS_STOCK_WEIGHT = 0.2                 # docs/user/tutorial2.rst:246
+
+
+def make_typed_shop_class():
+    """Tutorial 2's ShopAgent (docs/user/tutorial2.rst:244-307): a Supertype with one field,
+    `excess_stock_weight`, that scales the stock penalty and is appended to the observation.
+    User-level subclass of the reference's ShopAgent; the env / samplers executing it are the
+    reference's."""
+    from dataclasses import dataclass
+
+    class ShopAgent(sc.ShopAgent):     # same class name: the payload whitelists match on it (network.py:311-331)
+        @dataclass                     # (the tutorial's frozen=True cannot subclass the non-frozen base)
+        class Supertype(ph.Supertype):
+            excess_stock_weight: float = 0.1
+
+        def encode_observation(self, ctx):
+            max_sales_per_step = sc.NUM_CUSTOMERS * sc.CUSTOMER_MAX_ORDER_SIZE
+            return np.array([self.stock / sc.SHOP_MAX_STOCK, self.sales / max_sales_per_step,
+                             self.missed_sales / max_sales_per_step,
+                             self.type.excess_stock_weight / MAX_EXCESS_STOCK_WEIGHT], dtype=np.float32)
+
+        def compute_reward(self, ctx):
+            return self.sales - self.type.excess_stock_weight * self.stock
+
+        def reset(self):
+            ph.StrategicAgent.reset(self)      # self.type = supertype.sample()  (agents.py:160-175)
+            self.stock = 0
+
+    return ShopAgent
+
+
+def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=False, fsm=False,
+                           typed=None):
     """same ids / agent order / connection order as phantom_amd.supply_chain.build_network,
-    built from the reference's own agent classes."""
+    built from the reference's own agent classes.  ``typed`` = (samplers, per_shop) with
+    samplers = [(low, high, clip_low, clip_high)], per_shop[i] = ("sampler", j) | ("const", v) |
+    None (no supertype passed -> Supertype() defaults, agents.py:169-171)."""
     sc.NUM_CUSTOMERS = norm_customers            # read at call time, supply_chain.py:125
     if n_shops == 1:
         shop_ids, cust_ids = ["SHOP"], [[f"CUST{i + 1}" for i in range(ks[0])]]
@@ -71,7 +105,15 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
         shop_ids = [f"SHOP{i}" for i in range(n_shops)]
         cust_ids = [[f"CUST{i}_{j}" for j in range(ks[i])] for i in range(n_shops)]
     factory_id = "WAREHOUSE"
-    shops = [sc.ShopAgent(s, factory_id=factory_id) for s in shop_ids]
+    ShopCls = make_typed_shop_class() if typed else sc.ShopAgent
+    shops = [ShopCls(s, factory_id=factory_id) for s in shop_ids]
+    kw = {}
+    if typed:
+        from phantom.utils.samplers import UniformFloatSampler
+        sam = [UniformFloatSampler(lo, hi, clo, chi) for lo, hi, clo, chi in typed[0]]
+        kw["agent_supertypes"] = {
+            sid: ShopCls.Supertype(excess_stock_weight=(sam[t[1]] if t[0] == "sampler" else t[1]))
+            for sid, t in zip(shop_ids, typed[1]) if t is not None}
     customers = [sc.CustomerAgent(c, shop_id=shop_ids[i]) for i in range(n_shops) for c in cust_ids[i]]
     net = ph.Network(shops + [sc.FactoryAgent(factory_id)] + customers,
                      resolver=ph.resolvers.BatchResolver(enable_tracking=tracking))
@@ -86,14 +128,16 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
             stages=[ph.FSMStage("RESTOCK", acting_agents=shop_ids, rewarded_agents=shop_ids,
                                 next_stages=["SELL"]),
                     ph.FSMStage("SELL", acting_agents=flat_c, rewarded_agents=[],
-                                next_stages=["RESTOCK"])])
+                                next_stages=["RESTOCK"])], **kw)
     else:
-        env = ph.PhantomEnv(num_steps=num_steps, network=net)
+        env = ph.PhantomEnv(num_steps=num_steps, network=net, **kw)
+    if typed:
+        env._golden_samplers = sam
     return env, shop_ids, [c for cs in cust_ids for c in cs]
 
 
 def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_customers=None,
-                     fsm=False, log_steps=0, use_shipped_env=False):
+                     fsm=False, log_steps=0, use_shipped_env=False, typed=None):
     """B = len(seeds) independent reference envs, each alone on the global numpy stream."""
     B, S = len(seeds), n_shops
     n_exo = sum(ks)
@@ -102,13 +146,17 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
          (("actions", np.float32), ("stock", np.int32), ("sales", np.int32), ("missed", np.int32),
           ("reward", np.float64), ("reward_valid", np.uint8), ("obs_valid", np.uint8),
           ("terminated", np.uint8), ("truncated", np.uint8), ("done_valid", np.uint8))}
-    A["obs"] = np.zeros((T, B, S, 3), np.float32)
+    D = 4 if typed else 3
+    A["obs"] = np.zeros((T, B, S, D), np.float32)
+    if typed:
+        A["type_w"] = np.zeros((T, B, S), np.float64)                 # agent.type.excess_stock_weight
+        A["sampler_values"] = np.zeros((T, B, len(typed[0])), np.float64)   # Sampler.value after reset
     A["exo"] = np.zeros((T, B, n_exo), np.uint8)
     A["exo_valid"] = np.zeros((T, B), np.uint8)
     A["all_terminated"] = np.zeros((T, B), np.uint8)
     A["all_truncated"] = np.zeros((T, B), np.uint8)
     A["reset_before"] = np.zeros((T, B), np.uint8)
-    A["reset_obs"] = np.zeros((T, B, S, 3), np.float32)
+    A["reset_obs"] = np.zeros((T, B, S, D), np.float32)
     A["reset_obs_valid"] = np.zeros((T, B, S), np.uint8)
     A["stage"] = np.zeros((T, B), np.int32)
     logs = []
@@ -119,10 +167,12 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
             env.network.resolver.enable_tracking = log_steps > 0
             shop_ids, cust_ids = ["SHOP"], [f"CUST{i + 1}" for i in range(5)]
         else:
+            np.random.seed(seed)                   # the constructor already samples (env.py:118-119)
             env, shop_ids, cust_ids = build_ref_supply_chain(n_shops, ks, num_steps, norm_customers,
-                                                             tracking=log_steps > 0, fsm=fsm)
+                                                             tracking=log_steps > 0, fsm=fsm, typed=typed)
         index = {aid: i for i, aid in enumerate(env.agent_ids)}
-        np.random.seed(seed)
+        if not typed:
+            np.random.seed(seed)
         need_reset = True
         for t in range(T):
             if need_reset:
@@ -133,6 +183,10 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
                         A["reset_obs"][t, b, s] = obs[sid]
                         A["reset_obs_valid"][t, b, s] = 1
                 need_reset = False
+            if typed:
+                A["sampler_values"][t, b] = [sm.value for sm in env._golden_samplers]
+                for s, sid in enumerate(shop_ids):
+                    A["type_w"][t, b, s] = env.agents[sid].type.excess_stock_weight
             if fsm:
                 A["stage"][t, b] = ["RESTOCK", "SELL"].index(env.current_stage)
             acts = {}
@@ -171,6 +225,16 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
                 need_reset = True
     meta = dict(n_shops=n_shops, ks=np.asarray(ks), num_steps=num_steps, T=T,
                 seeds=np.asarray(seeds), norm_customers=norm_customers, fsm=int(fsm))
+    if typed:
+        nan = float("nan")
+        meta["sampler_params"] = np.asarray([[lo, hi, nan if clo is None else clo, nan if chi is None else chi]
+                                             for lo, hi, clo, chi in typed[0]], np.float64)
+        # per shop: source sampler index, -1 constant, -2 default Supertype(); and the constant
+        meta["type_src"] = np.asarray([(-2 if t is None else (t[1] if t[0] == "sampler" else -1))
+                                       for t in typed[1]], np.int32)
+        meta["type_const"] = np.asarray([(0.1 if t is None else (t[1] if t[0] == "const" else 0.1))
+                                         for t in typed[1]], np.float64)
+        meta["max_weight"] = np.asarray(MAX_EXCESS_STOCK_WEIGHT)
     for k, lg in enumerate(logs):
         A[f"log{k}"] = lg
     A["n_logs"] = np.asarray(len(logs))
@@ -360,6 +424,14 @@ def main():
     # Appendix B FSM case: S=2, K=3, num_steps=6, actions 10+t
     run_supply_chain("sc_fsm_small", 2, [3, 3], 6, 14, [0], lambda t, b, s: 10.0 + (t % 6) + 1,
                      fsm=True, log_steps=2)
+    # tutorial 2 (docs/user/tutorial2.rst:244-307): ShopAgent.Supertype.excess_stock_weight fed by
+    # shared / clipped UniformFloatSamplers, a constant and the dataclass default; plain and FSM env
+    typed = ([(0.0, 0.2, None, None), (0.05, 0.15, 0.07, 0.13)],
+             [("sampler", 0), ("sampler", 0), ("sampler", 1), ("const", 0.15), None])
+    run_supply_chain("sc_typed", 5, [2, 3, 1, 2, 2], 6, 26, [21, 22, 23], act_mixed, norm_customers=3,
+                     typed=typed)
+    run_supply_chain("sc_typed_fsm", 5, [2, 3, 1, 2, 2], 6, 26, [31, 32], act_mixed, norm_customers=3,
+                     typed=typed, fsm=True)
     # config 5: Stackelberg market, small and full size
     run_market("stk_small", 8, 32, 4, 7, 16, seed=11)
     run_market("stk_full", 128, 1024, 8, 100, 6, seed=12)

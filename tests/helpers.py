@@ -27,7 +27,24 @@ def supply_chain_env(n_shops, ks, num_steps, batch, fsm=False, norm_customers=No
     return env
 
 
+def typed_supertypes(g):
+    """agent_supertypes of a typed golden (tests/golden/gen_goldens.py `typed`): shared
+    UniformFloatSamplers, constants, and shops left on the Supertype() defaults."""
+    nan = lambda v: None if np.isnan(v) else float(v)
+    sam = [ph.UniformFloatSampler(float(p[0]), float(p[1]), nan(p[2]), nan(p[3]))
+           for p in g["sampler_params"]]
+    out = {}
+    for i, src in enumerate(g["type_src"].tolist()):
+        if src >= 0:
+            out[f"SHOP{i}"] = ph.TypedShopAgent.Supertype(excess_stock_weight=sam[src])
+        elif src == -1:
+            out[f"SHOP{i}"] = ph.TypedShopAgent.Supertype(excess_stock_weight=float(g["type_const"][i]))
+    return out
+
+
 def env_from_golden(g, batch=None, tracking=False, **kw):
+    if "type_src" in g:
+        kw.update(typed=True, agent_supertypes=typed_supertypes(g))
     return supply_chain_env(int(g["n_shops"]), g["ks"], int(g["num_steps"]),
                             batch or len(g["seeds"]), fsm=bool(g["fsm"]),
                             norm_customers=int(g["norm_customers"]), tracking=tracking, **kw)

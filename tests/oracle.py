@@ -43,7 +43,9 @@ def lib():
         for n in ("phxo_obs_dim", "phxo_n_strategic", "phxo_n_exo"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [vp]
-        L.phxo_reset.argtypes = [vp, vp, vp, vp]
+        L.phxo_reset.argtypes = [vp, vp, vp, vp, vp]
+        L.phxo_rng_uniform.restype = C.c_double
+        L.phxo_rng_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_int, vp]
         L.phxo_step.argtypes = [vp, C.POINTER(_abi.PhxStepIO)]
         L.phxo_inject.argtypes = [vp, C.POINTER(_abi.PhxMsgRec), C.c_int]
         L.phxo_resolve.argtypes = [vp, vp, vp, vp]
@@ -103,13 +105,16 @@ class OracleEnv:
     def set_threads(self, n):
         self.L.phxo_set_threads(n)
 
-    def reset(self, mask=None):
+    def reset(self, mask=None, sampler_values=None):
+        if sampler_values is not None:
+            sampler_values = np.ascontiguousarray(sampler_values, np.float64)
+            assert sampler_values.shape == (self.B, self.spec.n_samplers)
         if mask is not None:
             mask = np.ascontiguousarray(mask, np.uint8)
             self.err[mask.astype(bool)] = 0
         else:
             self.err[:] = 0
-        self.L.phxo_reset(self.h, _p(mask), _p(self.obs), _p(self.obs_valid))
+        self.L.phxo_reset(self.h, _p(mask), _p(sampler_values), _p(self.obs), _p(self.obs_valid))
         return self.obs.copy(), self.obs_valid.copy()
 
     def step(self, actions, action_valid=None, exo=None):
@@ -173,7 +178,7 @@ class OracleEnv:
         assert self.L.phxo_set_i32(self.h, field.encode(), _p(arr)) >= 0
 
     def get_f64(self, field):
-        buf = np.zeros(self.B * max(self.spec.n_agents, len(self.spec.col), 1), np.float64)
+        buf = np.zeros(self.B * max(self.spec.n_agents, len(self.spec.col), self.spec.n_samplers, 1), np.float64)
         n = self.L.phxo_get_f64(self.h, field.encode(), _p(buf))
         assert n >= 0, field
         return buf[:n].reshape(self.B, -1).copy()

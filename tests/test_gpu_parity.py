@@ -9,6 +9,8 @@ f32-rounded reward is compared at rtol 1e-6."""
 import numpy as np
 import pytest
 
+import phantom_amd as ph
+
 from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, supply_chain_env)
 from kats import ALL_KATS
 from oracle import OracleEnv
@@ -26,7 +28,7 @@ def test_extension_is_loaded_and_no_fallback():
     import ctypes
     from phantom_amd import _abi
     lib = _abi.load_library()
-    assert isinstance(lib, ctypes.CDLL) and lib.phx_abi_version() == 1
+    assert isinstance(lib, ctypes.CDLL) and lib.phx_abi_version() == _abi.ABI_VERSION
 
 
 @pytest.mark.parametrize("kat", ALL_KATS, ids=lambda f: f.__name__)
@@ -506,3 +508,123 @@ def test_step_launches_are_graph_capturable():
     assert torch.equal(log_e, log_g) and torch.equal(rew_e, rew_g)
     for f in ("shop.stock", "shop.sales", "env.step", "env.tick"):
         assert torch.equal(de.field(f), dg.field(f)), f
+
+
+def _typed_env(S, ks, num_steps, B, fsm, force_generic, device_sampling, seed=13, env_offset=40):
+    """tutorial-2 shops: shops 0/1 share a sampler, shop 2 has a clipped one, shop 3 a constant,
+    the rest stay on the Supertype() default."""
+    s0, s1 = ph.UniformFloatSampler(0.0, 0.2), ph.UniformFloatSampler(0.05, 0.15, 0.07, 0.13)
+    sup = {"SHOP0": ph.TypedShopAgent.Supertype(s0), "SHOP1": ph.TypedShopAgent.Supertype(s0),
+           "SHOP2": ph.TypedShopAgent.Supertype(s1), "SHOP3": ph.TypedShopAgent.Supertype(0.15)}
+    return supply_chain_env(S, ks, num_steps, B, fsm=fsm, force_generic=force_generic, typed=True,
+                            agent_supertypes=sup, seed=seed, env_offset=env_offset,
+                            exogenous="device" if device_sampling else "numpy")
+
+
+@pytest.mark.parametrize("fsm", [False, True])
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("device_sampling", [False, True])
+def test_typed_shops_differential_vs_oracle(fsm, force_generic, device_sampling):
+    """Supertypes on the device (tutorial 2): per-env sampled excess_stock_weight in the reward and
+    as 4th observation; sampler values fed by the host or drawn by the device Philox stream."""
+    import phantom_amd as ph_
+    rng = np.random.RandomState(17 + fsm)
+    S, ks, B, T = 6, [2, 3, 1, 2, 6, 4], 70, 45
+    env = _typed_env(S, ks, 10, B, fsm, force_generic, device_sampling)
+    spec = env.spec
+    assert spec.n_samplers == 2 and spec.obs_dim == 4
+    assert (spec.sampler_kind == (ph_._abi.SAMPLER_UNIFORM if device_sampling else ph_._abi.SAMPLER_HOST)).all()
+    o, d = OracleEnv(spec), _dev(spec)
+    assert d.dev.uses_fused == (not force_generic) and d.D == 4
+
+    def reset(mask=None):
+        vals = None if device_sampling else rng.uniform(0.0, 0.2, (B, 2))
+        (oo, ov), (do, dv) = o.reset(mask, vals), d.reset(mask, vals)
+        m = slice(None) if mask is None else mask.astype(bool)
+        np.testing.assert_array_equal(dv[m], ov[m])
+        np.testing.assert_array_equal(f32_bits(do[m]), f32_bits(oo[m]))
+        np.testing.assert_array_equal(f64_bits(d.get_f64("env.sampler")), f64_bits(o.get_f64("env.sampler")))
+        np.testing.assert_array_equal(d.get_i32("env.episode"), o.get_i32("env.episode"))
+
+    np.testing.assert_array_equal(f64_bits(d.get_f64("env.sampler")), f64_bits(o.get_f64("env.sampler")))
+    reset()
+    for t in range(T):
+        act = rng.uniform(-20, 130, size=(B, S)).astype(np.float32)
+        exo = rng.randint(0, 5, size=(B, sum(ks))).astype(np.uint8) if t % 3 else None
+        o.step(act, None, exo); d.step(act, None, exo)
+        _compare_step(o, d, t)
+        done = ((o.all_truncated > 0) | (rng.rand(B) < 0.03)).astype(np.uint8)
+        if done.any():
+            reset(done)
+    assert len(np.unique(o.get_f64("env.sampler")[:, 0])) > B // 2     # per-env values differ
+    assert (o.obs[:, :, 3][o.obs_valid > 0] > 0).all()
+    if device_sampling and not force_generic:
+        # fused rollout with auto-reset: the device redraws every sampler at each episode boundary
+        for mode in ("device_rng", "replay"):
+            acts = exo = None
+            if mode == "replay":
+                acts = rng.uniform(-10, 130, (33, B, S)).astype(np.float32)
+                exo = rng.randint(0, 5, (33, B, sum(ks))).astype(np.uint8)
+            ro, rd = o.rollout(33, acts, exo), d.rollout(33, acts, exo)
+            for k in ("truncated", "terminated") + (("obs_valid", "reward_valid") if fsm else ()):
+                np.testing.assert_array_equal(rd[k], ro[k], err_msg=f"{k} {mode}")
+            for k in ("obs", "actions", "rewards", "last_obs"):
+                np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"{k} {mode}")
+            assert ro["truncated"].sum() >= 3 * B * S
+            np.testing.assert_array_equal(f64_bits(d.get_f64("env.sampler")), f64_bits(o.get_f64("env.sampler")))
+            for f in ("shop.stock", "shop.sales", "env.step", "env.tick", "env.episode"):
+                np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} {mode}")
+        act = rng.uniform(0, 100, size=(B, S)).astype(np.float32)
+        o.step(act, None, None); d.step(act, None, None)
+        _compare_step(o, d, -1)
+    elif not force_generic:
+        with pytest.raises(Exception, match="PHX_SAMPLER_UNIFORM"):
+            d.rollout(5)
+
+
+def test_python_surface_supertypes_match_reference_tests():
+    """tests/test_supertypes_env.py:11-44,86-104 through the Python surface (B = 1): samplers are
+    drawn once at construction and once per reset; agents sharing nothing see their own values."""
+    import phantom_amd as ph_
+
+    class MockSampler(ph_.Sampler):                      # tests/__init__.py:9-15
+        def __init__(self, value):
+            self._value = value
+
+        def sample(self):
+            self._value += 1
+            return self._value
+
+    agents = [ph_.MockStrategicAgent("a1"), ph_.MockStrategicAgent("a2")]
+    net = ph_.Network(agents)
+    s1, s2 = MockSampler(0), MockSampler(10)
+    sup = {"a1": ph_.MockStrategicAgent.Supertype(type_value=s1), "a2": {"type_value": s2}}
+    env = ph_.PhantomEnv(1, net, agent_supertypes=sup)
+    assert env._samplers == [s1, s2]
+    assert env.agents["a1"].supertype == sup["a1"]
+    assert env.agents["a1"].type == ph_.MockStrategicAgent.Supertype(1)
+    assert env.agents["a2"].type == ph_.MockStrategicAgent.Supertype(11)
+    env.reset()
+    assert env.agents["a1"].type == ph_.MockStrategicAgent.Supertype(2)
+    assert env.agents["a2"].type == ph_.MockStrategicAgent.Supertype(12)
+    np.testing.assert_array_equal(env._device().field("env.sampler").cpu().numpy(), [[2.0, 12.0]])
+
+    # tutorial 2 through the dict API, numpy stream (B = 1) vs the reference golden
+    from helpers import typed_supertypes
+    g = golden("sc_typed")
+    np.random.seed(int(g["seeds"][0]))
+    env = supply_chain_env(int(g["n_shops"]), g["ks"], int(g["num_steps"]), 1, typed=True,
+                           norm_customers=int(g["norm_customers"]), agent_supertypes=typed_supertypes(g))
+    shops = [f"SHOP{i}" for i in range(int(g["n_shops"]))]
+    for t in range(int(g["T"])):
+        if g["reset_before"][t, 0]:
+            obs, _ = env.reset()
+            for i, sid in enumerate(shops):
+                np.testing.assert_array_equal(f32_bits(obs[sid]), f32_bits(g["reset_obs"][t, 0, i]))
+                assert env[sid].type.excess_stock_weight == g["type_w"][t, 0, i]
+        step = env.step({sid: np.array([g["actions"][t, 0, i]], np.float32) for i, sid in enumerate(shops)})
+        for i, sid in enumerate(shops):
+            assert step.observations[sid].shape == (4,)
+            np.testing.assert_array_equal(f32_bits(step.observations[sid]), f32_bits(g["obs"][t, 0, i]))
+            assert step.rewards[sid] == g["reward"][t, 0, i]
+        assert step.truncations["__all__"] == bool(g["all_truncated"][t, 0])

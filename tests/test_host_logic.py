@@ -209,3 +209,71 @@ def test_auto_chunk_picks_divisors_by_bytes():
     assert auto_chunk(100, 811_008) == 100                  # SC64 B=4096: 81 MB fragment -> one chunk
     assert auto_chunk(100, 9_191_424) == 20                 # SC256 B=8192: 9.2 MB/step -> 20-step chunks
     assert auto_chunk(7, 1 << 30) == 1
+
+
+def test_supertype_and_sampler_semantics():
+    """tests/test_supertype.py:12-37 and utils/samplers.py: sample() replaces Samplers by drawn
+    values; a managed supertype reads Sampler.value instead of drawing (supertype.py:23-26)."""
+    from dataclasses import dataclass
+
+    class MockSampler(ph.Sampler):
+        def __init__(self, value):
+            self._value = value
+
+        def sample(self):
+            self._value += 1
+            return self._value
+
+    @dataclass
+    class TestSupertype(ph.Supertype):
+        a: float
+        b: float
+
+    assert TestSupertype(1.0, "string").sample().__dict__ == {"a": 1.0, "b": "string"}
+    s2 = TestSupertype(MockSampler(0), "string")
+    assert s2.sample().__dict__ == {"a": 1, "b": "string"}
+    s2._managed = True
+    assert s2.sample().a == 1 and s2.sample().a == 1          # no further draws once managed
+    np.random.seed(3)
+    u = ph.UniformFloatSampler(0.05, 0.15, 0.07, 0.13)
+    np.random.seed(3)
+    expect = np.clip(np.random.uniform(0.05, 0.15), 0.07, 0.13)
+    np.random.seed(3)
+    assert u.sample() == expect and u.value == expect and u <= 0.13 and u >= 0.07
+    assert u == u and not (u == ph.UniformFloatSampler())     # identity against other samplers
+
+
+def test_compile_spec_sampler_tables_and_device_uniform_definition():
+    import oracle
+    s0, s1 = ph.UniformFloatSampler(0.0, 0.2), ph.UniformFloatSampler(0.05, 0.15, 0.07, 0.13)
+    sup = {"SHOP0": ph.TypedShopAgent.Supertype(s0), "SHOP1": ph.TypedShopAgent.Supertype(s0),
+           "SHOP2": ph.TypedShopAgent.Supertype(s1), "SHOP3": {"excess_stock_weight": 0.15}}
+    env = ph.SupplyChainEnv(n_shops=5, customers_per_shop=2, num_steps=4, batch_size=3, typed=True,
+                            agent_supertypes=sup, exogenous="device", seed=9, env_offset=5)
+    spec = env.spec
+    assert env._samplers == [s0, s1] and env._device_sampling
+    assert spec.obs_dim == 4 and spec.n_samplers == 2
+    np.testing.assert_array_equal(spec.sampler_kind, [_abi.SAMPLER_UNIFORM] * 2)
+    np.testing.assert_array_equal(spec.sampler_param[0, :2], [0.0, 0.2])
+    assert np.isnan(spec.sampler_param[0, 2:]).all()
+    np.testing.assert_array_equal(spec.sampler_param[1], [0.05, 0.15, 0.07, 0.13])
+    np.testing.assert_array_equal(spec.type_src[:5], [0, 0, 1, _abi.TYPE_CONST, _abi.TYPE_CONST])
+    np.testing.assert_array_equal(spec.param_f[:5, 0], [0.1, 0.1, 0.1, 0.15, 0.1])
+    assert (spec.type_src[5:] == _abi.TYPE_NONE).all()
+    # host sampling with the numpy stream when exogenous="numpy" (B = 1 parity mode)
+    env1 = ph.SupplyChainEnv(n_shops=2, customers_per_shop=2, typed=True,
+                             agent_supertypes={"SHOP0": ph.TypedShopAgent.Supertype(ph.UniformFloatSampler())})
+    assert not env1._device_sampling and (env1.spec.sampler_kind == _abi.SAMPLER_HOST).all()
+    # the device draw (oracle restatement) against an independent numpy evaluation of its definition
+    o = oracle.OracleEnv(spec)
+    vals = o.get_f64("env.sampler")
+    for b in range(3):
+        for j, (lo, hi, clo, chi) in enumerate([(0.0, 0.2, None, None), (0.05, 0.15, 0.07, 0.13)]):
+            genv = 5 + b
+            w = oracle.philox([genv, 0, 0, 0x80000000 | j], [9, 0])          # episode 0 = constructor
+            u = (float(int(w[0]) >> 5) * 67108864.0 + float(int(w[1]) >> 6)) / 9007199254740992.0
+            v = lo + (hi - lo) * u
+            v = v if clo is None else min(max(v, clo), chi)
+            assert vals[b, j] == v
+    o.reset()
+    assert (o.get_i32("env.episode") == 2).all() and not np.array_equal(o.get_f64("env.sampler"), vals)

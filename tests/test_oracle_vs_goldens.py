@@ -7,18 +7,25 @@ import pytest
 from helpers import (env_from_golden, f32_bits, f64_bits, golden, log_matrix, market_env)
 from oracle import OracleEnv
 
-SC_CASES = ["sc7_fixed20", "sc7_mixed", "sc64", "sc_ragged", "sc256_fsm", "sc_fsm_small"]
+SC_CASES = ["sc7_fixed20", "sc7_mixed", "sc64", "sc_ragged", "sc256_fsm", "sc_fsm_small",
+            "sc_typed", "sc_typed_fsm"]
 
 
 def replay_supply_chain(g, make_runner):
     """drive a runner (oracle or device adapter) with the golden inputs and compare outputs."""
     T, B = int(g["T"]), len(g["seeds"])
+    typed = "type_src" in g
     env = env_from_golden(g, tracking=int(g["n_logs"]) > 0)
     run = make_runner(env.spec)
+    assert run.D == (4 if typed else 3)
     for t in range(T):
         rb = g["reset_before"][t]
         if rb.any():
-            obs, valid = run.reset(rb)
+            # typed goldens: the values the reference's Samplers returned at this reset
+            obs, valid = run.reset(rb, g["sampler_values"][t]) if typed else run.reset(rb)
+            if typed:
+                np.testing.assert_array_equal(f64_bits(run.get_f64("env.sampler")[rb.astype(bool)]),
+                                              f64_bits(g["sampler_values"][t][rb.astype(bool)]))
             m = rb.astype(bool)
             np.testing.assert_array_equal(valid[m], g["reset_obs_valid"][t][m])
             sel = g["reset_obs_valid"][t].astype(bool) & m[:, None]
