@@ -230,6 +230,11 @@ int  phx_n_fields(const phx_env* env);
 int  phx_field_info(const phx_env* env, int index, phx_field* out);
 /* 1 when step/rollout run a fused static-schedule kernel, 0 for the generic engine        */
 int  phx_uses_fused(const phx_env* env);
+/* Brings lazily maintained state fields up to date before the caller reads them: the fused
+ * Stackelberg kernel keeps BuyerAgent.prices (one f64 per buyer and neighbour) in its
+ * compressed form "last price posted by each seller" (seller.posted) and materialises the
+ * buyer.prices field only here.  A no-op for every other field / engine.                  */
+int  phx_sync_fields(phx_env* env, void* stream);
 
 /* PhantomEnv.reset (env.py:185-237 / fsm.py:195-251 / stackelberg.py:53-109) for every env
  * with reset_mask[b] != 0 (NULL = all).  Writes the initial observations.

@@ -88,7 +88,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libphantom_amd.so")
 
 EXPORTS = ("phx_abi_version", "phx_last_error", "phx_state_nbytes", "phx_obs_dim",
            "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",
-           "phx_field_info", "phx_uses_fused", "phx_reset", "phx_step", "phx_inject",
+           "phx_field_info", "phx_uses_fused", "phx_sync_fields", "phx_reset", "phx_step", "phx_inject",
            "phx_resolve", "phx_rollout")
 
 
@@ -124,6 +124,8 @@ def load_library():
     lib.phx_field_info.argtypes = [vp, i32, C.POINTER(PhxField)]
     lib.phx_uses_fused.restype = i32
     lib.phx_uses_fused.argtypes = [vp]
+    lib.phx_sync_fields.restype = i32
+    lib.phx_sync_fields.argtypes = [vp, vp]
     lib.phx_reset.restype = i32
     lib.phx_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.phx_step.restype = i32

@@ -19,6 +19,7 @@ hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
+hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st);
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 
 static thread_local char g_err[512] = "";
@@ -53,6 +54,9 @@ struct Derived {
   std::vector<float> sc_tab;
   int n_tabn = 0, n_quot = 0, rew_smax = -1;
   int max_cust = 0;
+  std::vector<uint16_t> stk_nbr;
+  std::vector<uint32_t> stk_rec;
+  std::vector<uint8_t> stk_flags;
   // supertypes
   bool any_typed = false, device_sampling = false;
   std::vector<int32_t> type_src, shop_type_src;
@@ -184,7 +188,24 @@ static int derive(const phx_spec* sp, Derived& d) {
       stk = sp->kind[v] == (k == PHX_KIND_SELLER ? PHX_KIND_BUYER : PHX_KIND_SELLER) && edge(v, a);
     }
   }
-  d.stk_static = stk;
+  d.stk_static = stk && d.kind_count[PHX_KIND_SELLER] < 65535 && d.kind_count[PHX_KIND_BUYER] < 65536 && d.buyer_dmax < 256 && d.S == A && d.D == 2;
+  if (d.stk_static) {                       // slot-major neighbour table of the buyers (seller ranks)
+    const int nB = d.kind_count[PHX_KIND_BUYER];
+    d.stk_nbr.assign((size_t)std::max(d.buyer_dmax, 1) * std::max(nB, 1), 0xFFFF);
+    for (int a = 0; a < A; ++a)
+      if (sp->kind[a] == PHX_KIND_BUYER)
+        for (int e = sp->row_ptr[a]; e < sp->row_ptr[a + 1]; ++e)
+          d.stk_nbr[(size_t)(e - sp->row_ptr[a]) * nB + d.kind_rank[a]] = (uint16_t)d.kind_rank[sp->col[e]];
+    d.stk_rec.assign(A, 0); d.stk_flags.assign((size_t)2 * A, 0);
+    for (int a = 0; a < A; ++a) {
+      // buyers: deg <= buyer_dmax < 256; a seller's degree (its obs divisor) is read from row_ptr
+      const int deg = sp->row_ptr[a + 1] - sp->row_ptr[a];
+      d.stk_rec[a] = (uint32_t)sp->kind[a] | ((uint32_t)std::min(deg, 255) << 8) | ((uint32_t)d.kind_rank[a] << 16);
+      for (int l = 0; l < 2; ++l)
+        d.stk_flags[(size_t)l * A + a] = (uint8_t)((d.act_mask[(size_t)l * A + a] ? 1 : 0) | (d.obs_mask[(size_t)l * A + a] ? 2 : 0) |
+                                                   (d.rew_mask[(size_t)l * A + a] ? 4 : 0));
+    }
+  }
   if (d.kind_count[PHX_KIND_SHOP] > 0) {
     const int nS = d.kind_count[PHX_KIND_SHOP];
     d.shop_agent.assign(nS, 0); d.shop_norm.assign(nS, 1);
@@ -250,6 +271,7 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_SELLER_PRICE, "seller.price", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
     {F_SELLER_REVENUE, "seller.revenue", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
     {F_SELLER_TX, "seller.tx", 0, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
+    {F_SELLER_POSTED, "seller.posted", 1, PHX_KIND_SELLER, B, kc(PHX_KIND_SELLER), 1, 0},
     {F_BUYER_PRICES, "buyer.prices", 1, PHX_KIND_BUYER, B, d.buyer_dmax, kc(PHX_KIND_BUYER), 0},
     {F_BUYER_PAID, "buyer.paid", 1, PHX_KIND_BUYER, B, kc(PHX_KIND_BUYER), 1, 0},
     {F_BUYER_BOUGHT, "buyer.bought", 0, PHX_KIND_BUYER, B, kc(PHX_KIND_BUYER), 1, 0},
@@ -289,6 +311,7 @@ struct phx_env {
   std::vector<void*> dev_allocs;
   int device = 0;
   bool use_fused = false, use_stk = false, lds_ok = true;
+  bool prices_compressed = false;   // buyer.prices is represented by seller.posted (fused Stackelberg kernel)
   DevMsg* inject_dev = nullptr;
   DevMsg inject_host[PHX_MAX_INJECT];
   int n_inject = 0;
@@ -360,6 +383,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());
   UP(shop_cust_act, der.shop_cust_act.data(), der.shop_cust_act.size());
   UP(sc_tab, der.sc_tab.data(), der.sc_tab.size());
+  UP(stk_nbr, der.stk_nbr.data(), der.stk_nbr.size());
+  UP(stk_rec, der.stk_rec.data(), der.stk_rec.size()); UP(stk_flags, der.stk_flags.data(), der.stk_flags.size());
   UP(sampler_kind, spec->sampler_kind, spec->n_samplers); UP(sampler_param, spec->sampler_param, 4 * spec->n_samplers);
   UP(type_src, der.type_src.data(), A);
   UP(shop_type_src, der.shop_type_src.data(), der.shop_type_src.size());
@@ -373,6 +398,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   e->lds_ok = ws_stride == 0;
   e->use_fused = der.sc_static;
   e->use_stk = der.stk_static;
+  e->prices_compressed = der.stk_static;
   he = hipMalloc((void**)&e->inject_dev, sizeof(DevMsg) * PHX_MAX_INJECT);
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMalloc: %s", hipGetErrorString(he)); }
   // constructor state: zero blob, then Agent.reset() for every agent (env.py:122-124)
@@ -411,12 +437,21 @@ int phx_field_info(const phx_env* e, int index, phx_field* out) {
 
 int phx_uses_fused(const phx_env* e) { return e && (e->use_fused || e->use_stk) ? 1 : 0; }
 
+
 // the handle's device becomes the calling thread's current device (a no-op when it already is)
 static inline hipError_t use_device(const phx_env* e) {
   int cur = -1;
   hipError_t r = hipGetDevice(&cur);
   if (r != hipSuccess) return r;
   return cur == e->device ? hipSuccess : hipSetDevice(e->device);
+}
+
+int phx_sync_fields(phx_env* e, void* stream) {
+  if (!e) return fail(PHX_EINVAL, "null env");
+  if (!e->prices_compressed) return PHX_OK;
+  HIPCHK(use_device(e));
+  HIPCHK(phx_launch_stk_materialise(e->d, (hipStream_t)stream));
+  return PHX_OK;
 }
 
 int phx_reset(phx_env* e, const uint8_t* reset_mask, const double* sampler_values, float* obs, uint8_t* obs_valid,
@@ -458,6 +493,10 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
     HIPCHK(phx_launch_stk_step(e->d, *io, st));
     return PHX_OK;
   }
+  if (e->prices_compressed) {       // host-injected messages can address a single price slot: materialise
+    HIPCHK(phx_launch_stk_materialise(e->d, st));   // the table and stay on the generic engine from here on
+    e->prices_compressed = false; e->use_stk = false;
+  }
   GenArgs g; g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0; g.timing = nullptr;
 #ifdef PHX_TIMING
   { static unsigned long long* tb = nullptr; static int calls = 0;
@@ -490,6 +529,10 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
   if ((msg_log || msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
   HIPCHK(use_device(e));
   hipStream_t st = (hipStream_t)stream;
+  if (e->prices_compressed) {
+    HIPCHK(phx_launch_stk_materialise(e->d, st));
+    e->prices_compressed = false; e->use_stk = false;
+  }
   GenArgs g; memset(&g, 0, sizeof g);
   g.io.err = err; g.io.msg_log = msg_log; g.io.msg_count = msg_count;
   g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 1; g.timing = nullptr;

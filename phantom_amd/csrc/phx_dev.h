@@ -27,7 +27,7 @@ enum {
   F_ENV_TERM, F_ENV_TRUNC, F_ENV_REW_CACHE, F_ENV_REW_CACHE_VALID, F_ENV_OBS_CACHE,
   F_ENV_OBS_CACHE_VALID, F_ENV_SAMPLER, F_ENV_EPISODE,
   F_SHOP_STOCK, F_SHOP_SALES, F_SHOP_MISSED, F_SHOP_DELIVERED,
-  F_SELLER_PRICE, F_SELLER_REVENUE, F_SELLER_TX,
+  F_SELLER_PRICE, F_SELLER_REVENUE, F_SELLER_TX, F_SELLER_POSTED,
   F_BUYER_PRICES, F_BUYER_PAID, F_BUYER_BOUGHT,
   F_CASHBOX_TOTAL,
   F_REQRESP_REQ, F_REQRESP_RES,
@@ -82,6 +82,10 @@ struct DevSpec {
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)
   const float* sc_tab;
   int32_t n_tabn, n_quot, rew_smax;
+  // Stackelberg market static schedule (fused kernel): neighbour table of the buyers, slot-major
+  const uint16_t* stk_nbr;       // [buyer_dmax][nBuyers] seller rank of neighbour k, 0xFFFF = none
+  const uint32_t* stk_rec;       // [A] kind | deg << 8 | kind_rank << 16
+  const uint8_t*  stk_flags;     // [2][A] 1 acts, 2 observes, 4 rewarded in list 0 (leaders' step) / 1
   // Supertypes / Samplers (supertype.py:16-30, utils/samplers.py, env.py:211-216)
   int32_t n_samplers;            // columns of env.sampler
   int32_t any_typed;             // some shop consumes a type field (obs dim 4, weighted penalty)
@@ -367,6 +371,7 @@ __device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, const Topo& t
       fld<double>(sp, F_SELLER_PRICE)[r.base] = 0.0;
       fld<double>(sp, F_SELLER_REVENUE)[r.base] = 0.0;
       fld<int32_t>(sp, F_SELLER_TX)[r.base] = 0;
+      fld<double>(sp, F_SELLER_POSTED)[r.base] = 1.0;      // what every neighbour's price slot holds after reset
       break;
     case PHX_KIND_BUYER: {
       const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];

@@ -7,10 +7,12 @@
 
 // One workgroup per env.  `live` = agent has a context this step (NULL: every agent is live).
 // s_nterm / s_ntrunc: zero-initialised LDS counters.  Contains a __syncthreads().
-template <int NT>
+// `encode_obs(a, t, ob)` is the agent's encode_observation; the fused Stackelberg kernel passes one
+// that reads the buyers' prices from its LDS copy of seller.posted.
+template <int NT, typename ObsFn>
 __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
                                                    int list, int cur_stage, uint32_t tick,
-                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc) {
+                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc, ObsFn encode_obs) {
   const int tid = threadIdx.x;
   const int A = sp.A, S = sp.S, D = sp.D;
   uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
@@ -32,7 +34,7 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
     if (!live || live[a]) {                                    // env.py:274-275
       dv = 1;
-      if (obs_mask[a]) { dev_encode_obs(sp, tp, b, a, t, ob); ov = 1; }
+      if (obs_mask[a]) { encode_obs(a, t, ob); ov = 1; }
       if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, tp, b, a); rv = 1; }
       else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, tp, b, a); rew_cache_v[s] = 1; }
       tm = tr = dev_is_done(sp, tp, a, t) ? 1 : 0;                 // env.py:285-286
@@ -86,4 +88,12 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
     }
     io.all_terminated[b] = all_term; io.all_truncated[b] = all_trunc;
   }
+}
+
+template <int NT>
+__device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
+                                                   int list, int cur_stage, uint32_t tick,
+                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc) {
+  strategic_epilogue<NT>(sp, tp, io, b, t, list, cur_stage, tick, live, s_nterm, s_ntrunc,
+                         [&](int a, int tt, float* ob) { dev_encode_obs(sp, tp, b, a, tt, ob); });
 }

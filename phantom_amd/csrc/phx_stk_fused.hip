@@ -7,95 +7,161 @@
 // (first minimum in neighbour order); a seller books revenue += price * vol once per order --
 // all addends of a round are the same f64, so the sequential sum only needs the ORDER COUNT,
 // which the block gets from LDS atomics.  One workgroup per env instance; the 8-byte price
-// slots (buyer.prices f64[B][sum deg], 64 KB per env at 1024 x 8) dominate the traffic and are
-// stored slot-major (ELL) so that the buyers of a wave read/write slot k at consecutive addresses.  Results are bit-identical to the generic engine.
+// slots of the buyers are kept in compressed per-seller form (below).  Results are bit-identical to
+// the generic engine.
+#include <algorithm>
+
 #include "phx_dev.h"
-#include "phx_epilogue.h"
 
 #define STK_NT 256
 
+// BuyerAgent.prices in compressed form.  Every Price a seller posts goes to ALL of its neighbours
+// in the same round (decode_action returns one message per ctx.neighbour_ids entry) and the
+// topology is static, so the slot a buyer keeps for neighbour l always holds "the last price l
+// posted since the reset, else 1.0": one f64 per SELLER (seller.posted, 1 KB per env at 128
+// sellers) instead of one per (buyer, neighbour) (64 KB per env at 1024 x 8).  The kernel keeps
+// the per-seller array in LDS; buyers gather from it through the slot-major neighbour table
+// stk_nbr.  phx_sync_fields / the first host-injected message materialise buyer.prices.
 __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, const phx_step_io io) {
+  // Static per-agent record stk_rec[a] = kind | deg << 8 | kind_rank << 16 and per-list flag byte
+  // stk_flags[list][a] (1 acts, 2 observes, 4 rewarded) replace the kind / kind_rank / row_ptr /
+  // mask lookups: one dependent level between the record and the agent's state instead of four.
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_nterm, s_ntrunc;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int A = sp.A, S = sp.S;
-  const Topo tp = topo_global(sp);
-  const int nSell = sp.kind_count[PHX_KIND_SELLER];
-  double* s_price = (double*)smem;                       // [nSell] price posted this step
-  int* s_count = (int*)(s_price + nSell);                // [nSell] orders received this step
+  const int A = sp.A;                                    // every agent of this schedule is strategic: s == a
+  const int nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER];
+  double* s_posted = (double*)smem;                      // [nSell] price every neighbour currently holds
+  double* s_price = s_posted + nSell;                    // [nSell] seller.price
+  double* s_rev = s_price + nSell;                       // [nSell] seller.revenue
+  int* s_tx = (int*)(s_rev + nSell);                     // [nSell] seller.tx
+  int* s_count = s_tx + nSell;                           // [nSell] orders received this step
   uint8_t* s_sent = (uint8_t*)(s_count + nSell);         // [nSell] seller broadcast a Price this step
 
   const int t = fld<int32_t>(sp, F_ENV_STEP)[b] + 1;                         // env.py:252
   const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
   const int list = (t & 1) ? 0 : 1;                                          // stackelberg.py:133-137
-  const uint8_t* act_mask = sp.act_mask + (int64_t)list * A;
-  const float* actions_b = io.actions ? io.actions + (int64_t)b * S : nullptr;
-  const uint8_t* av_b = io.action_valid ? io.action_valid + (int64_t)b * S : nullptr;
-  double* prices_b = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz;
+  const uint8_t* flags = sp.stk_flags + (int64_t)list * A;
+  const float* actions_b = io.actions ? io.actions + (int64_t)b * A : nullptr;
+  const uint8_t* av_b = io.action_valid ? io.action_valid + (int64_t)b * A : nullptr;
+  const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy;
+  double* posted_b = fld<double>(sp, F_SELLER_POSTED) + sbase;
 
-  if (tid == 0) { s_nterm = 0; s_ntrunc = 0; }
-  for (int k = tid; k < nSell; k += STK_NT) { s_count[k] = 0; s_sent[k] = 0; }
+  for (int k = tid; k < nSell; k += STK_NT) {
+    s_posted[k] = posted_b[k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
+    s_rev[k] = fld<double>(sp, F_SELLER_REVENUE)[sbase + k]; s_tx[k] = fld<int32_t>(sp, F_SELLER_TX)[sbase + k];
+    s_count[k] = 0; s_sent[k] = 0;
+  }
   __syncthreads();
 
-  // ---- acting phase (_handle_acting_agents, env.py:320-336): decode_action of every acting agent
+  // ---- acting phase (_handle_acting_agents, env.py:320-336): decode_action of every acting agent.
+  //      Sellers only record the new price (the Price messages land after the acting phase:
+  //      buyers acting in the same step still see the old slots).
   for (int a = tid; a < A; a += STK_NT) {
-    if (!act_mask[a]) continue;
-    const int s = sp.strat_rank[a];
-    const bool has = actions_b && (!av_b || av_b[s]);                        // aid in actions
-    if (!has) continue;
-    const float action = actions_b[s];
-    const AgentRef r = agent_ref(sp, tp, b, a);
-    if (r.kind == PHX_KIND_SELLER) {
-      const double price = (double)action;
-      fld<double>(sp, F_SELLER_PRICE)[r.base] = price;
-      s_price[r.kr] = price; s_sent[r.kr] = 1;
+    if (!(flags[a] & 1)) continue;
+    if (!(actions_b && (!av_b || av_b[a]))) continue;                        // aid in actions
+    const float action = actions_b[a];
+    const uint32_t rec = sp.stk_rec[a];
+    const int kr = (int)(rec >> 16), deg = (int)((rec >> 8) & 255u);
+    if ((rec & 255u) == PHX_KIND_SELLER) {
+      s_price[kr] = (double)action; s_sent[kr] = 1;
     } else {                                                                 // BUYER
-      const int lo = sp.row_ptr[a], deg = sp.row_ptr[a + 1] - lo;
+      int bought = 0; double paid = 0.0;
       if (action > 0.5f && deg > 0) {
-        const double* pr = prices_b + sp.buyer_off[a];
-        int j = 0; double best = pr[0];
-        for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (v < best) { best = v; j = k; } }
-        fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 1;
-        fld<double>(sp, F_BUYER_PAID)[r.base] = best;
-        atomicAdd(&s_count[sp.kind_rank[sp.col[lo + j]]], 1);               // Order(1) -> that seller's inbox
-      } else {
-        fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
-        fld<double>(sp, F_BUYER_PAID)[r.base] = 0.0;
+        const uint16_t* nb = sp.stk_nbr + kr;
+        int jr = nb[0]; double best = s_posted[jr];                           // first minimum in neighbour order
+        for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
+        bought = 1; paid = best;
+        atomicAdd(&s_count[jr], 1);                                          // Order(1) -> that seller's inbox
       }
+      fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr] = bought;
+      fld<double>(sp, F_BUYER_PAID)[bbase + kr] = paid;
     }
   }
   __syncthreads();
-  // ---- pre_message_resolution + the single round -------------------------------------------------
+  // ---- pre_message_resolution + the single round: sellers book their orders (one add per Order,
+  //      in inbox order: all addends are the same f64); this step's Price messages land in every
+  //      neighbour's slot, i.e. the seller's posted price changes -----------------------------------
+  for (int kr = tid; kr < nSell; kr += STK_NT) {
+    double rev = s_rev[kr]; int tx = s_tx[kr];
+    if ((t & 1) == 0) { rev = 0.0; tx = 0; }                                 // start of a buying round
+    const int n = s_count[kr];
+    if (n > 0) {
+      const double amount = __dmul_rn(s_price[kr], 1.0);                     // price * vol, vol = 1
+      for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+      tx += n;
+    }
+    s_rev[kr] = rev; s_tx[kr] = tx;
+    fld<double>(sp, F_SELLER_REVENUE)[sbase + kr] = rev;
+    fld<int32_t>(sp, F_SELLER_TX)[sbase + kr] = tx;
+    if (s_sent[kr]) { fld<double>(sp, F_SELLER_PRICE)[sbase + kr] = s_price[kr]; s_posted[kr] = s_price[kr]; posted_b[kr] = s_price[kr]; }
+  }
+  __syncthreads();
+  // ---- obs / reward / done in ONE pass (stackelberg.py:142-196).  Neither kind terminates or
+  //      truncates (agents.py:292-323), so "terminal" is the step count alone (env.py:312-318).
+  const bool terminal = (t == sp.num_steps);
+  double* rew_cache = fld<double>(sp, F_ENV_REW_CACHE) + (int64_t)b * A;
+  uint8_t* rew_cache_v = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + (int64_t)b * A;
   for (int a = tid; a < A; a += STK_NT) {
-    const AgentRef r = agent_ref(sp, tp, b, a);
-    if (r.kind == PHX_KIND_SELLER) {
-      double rev = fld<double>(sp, F_SELLER_REVENUE)[r.base];
-      int tx = fld<int32_t>(sp, F_SELLER_TX)[r.base];
-      if ((t & 1) == 0) { rev = 0.0; tx = 0; }                               // start of a buying round
-      const int n = s_count[r.kr];
-      if (n > 0) {
-        const double amount = __dmul_rn(fld<double>(sp, F_SELLER_PRICE)[r.base], 1.0);   // price * vol, vol = 1
-        for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);             // one add per Order, inbox order
-        tx += n;
-      }
-      fld<double>(sp, F_SELLER_REVENUE)[r.base] = rev;
-      fld<int32_t>(sp, F_SELLER_TX)[r.base] = tx;
-    } else {
-      const int lo = sp.row_ptr[a], deg = sp.row_ptr[a + 1] - lo;
-      double* pr = prices_b + sp.buyer_off[a];
-      for (int k = 0; k < deg; ++k) {                                        // handle Price from each neighbour
-        const int kr = sp.kind_rank[sp.col[lo + k]];
-        if (s_sent[kr]) pr[(int64_t)k * sp.buyer_stride] = s_price[kr];
+    const int64_t o = (int64_t)b * A + a;
+    const int fl = flags[a];
+    const uint32_t rec = sp.stk_rec[a];
+    const int kr = (int)(rec >> 16), deg = (int)((rec >> 8) & 255u);
+    const bool seller = (rec & 255u) == PHX_KIND_SELLER;
+    float ob0 = 0.f, ob1 = 0.f; uint8_t ov = 0;
+    if (fl & 2) {                                                            // encode_observation
+      ov = 1;
+      if (seller) { ob0 = (float)((double)s_tx[kr] / (double)(sp.row_ptr[a + 1] - sp.row_ptr[a])); ob1 = (float)s_price[kr]; }
+      else {
+        const uint16_t* nb = sp.stk_nbr + kr;
+        double mn = s_posted[nb[0]];                                         // min over the price slots
+        for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
+        ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
       }
     }
+    uint8_t cv = rew_cache_v[a]; double cache = rew_cache[a];
+    if (fl & 4) {                                                            // compute_reward -> self._rewards
+      if (seller) cache = s_rev[kr];
+      else cache = fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr]
+                       ? __dsub_rn(sp.param_f[a * PHX_NPF], fld<double>(sp, F_BUYER_PAID)[bbase + kr]) : 0.0;
+      cv = 1; rew_cache[a] = cache; rew_cache_v[a] = 1;
+    }
+    uint8_t rv = 0; double rw = 0.0;
+    if (terminal) { rv = cv ? 1 : 2; rw = cv ? cache : 0.0; }                // stackelberg.py:180-187
+    else if (ov && cv) { rv = 1; rw = cache; }                               // stackelberg.py:190-194
+    *(float2*)(io.obs + o * 2) = make_float2(ob0, ob1);
+    io.reward[o] = rw;
+    io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = 1;
+    io.terminated[o] = 0; io.truncated[o] = 0;
   }
-  __syncthreads();
-  strategic_epilogue<STK_NT>(sp, tp, io, b, t, list, 0, tick, nullptr, &s_nterm, &s_ntrunc);
+  if (tid == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = t;
+    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
+    io.all_terminated[b] = 0; io.all_truncated[b] = terminal;
+  }
+}
+
+// buyer.prices[b][k][r] = seller.posted[b][neighbour k of buyer r]
+__global__ __launch_bounds__(256) void phx_stk_materialise_kernel(const DevSpec sp) {
+  const int nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER];
+  const int64_t n = (int64_t)sp.B * sp.buyer_nnz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / sp.buyer_nnz; const int slot = (int)(i - b * sp.buyer_nnz);
+    const int l = sp.stk_nbr[slot];
+    if (l != 0xFFFF) fld<double>(sp, F_BUYER_PRICES)[i] = fld<double>(sp, F_SELLER_POSTED)[b * nSell + l];
+  }
+  (void)nBuy;
 }
 
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
-  const size_t lds = (size_t)nSell * (8 + 4 + 1) + 16;
+  const size_t lds = (size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 16;
   hipLaunchKernelGGL(phx_stk_step_kernel, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
+  return hipGetLastError();
+}
+
+hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st) {
+  const int64_t n = (int64_t)sp.B * sp.buyer_nnz;
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
+  if (n > 0) hipLaunchKernelGGL(phx_stk_materialise_kernel, dim3(blocks), dim3(256), 0, st, sp);
   return hipGetLastError();
 }

@@ -81,7 +81,7 @@ class DeviceEnv:
         if rc != 0:
             raise DeviceError(f"phx_create failed ({rc}): " + self._err())
         self.handle = handle
-        self.uses_fused = bool(self.lib.phx_uses_fused(handle))
+
         self._kind_rank = spec.kind_rank()
         self._fields: Dict[str, "object"] = {}
         dt = {0: torch.int32, 1: torch.float64, 2: torch.uint8, 3: torch.float32}
@@ -135,8 +135,17 @@ class DeviceEnv:
         except Exception:
             pass
 
+    @property
+    def uses_fused(self) -> bool:
+        """a fused static-schedule kernel serves step/rollout (can turn False: a host-injected
+        message moves a fused Stackelberg env onto the generic engine for good)."""
+        return bool(self.lib.phx_uses_fused(self.handle))
+
     def field(self, name: str):
-        """torch view [B, n] into the state blob (zero-copy)."""
+        """torch view [B, n] into the state blob (zero-copy).  ``buyer.prices`` is kept in
+        compressed per-seller form by the fused Stackelberg kernel and materialised here."""
+        if name == "buyer.prices":
+            self._check(self.lib.phx_sync_fields(self.handle, self._stream()), "phx_sync_fields")
         return self._fields[name]
 
     def field_names(self) -> List[str]:

@@ -11,7 +11,8 @@ import pytest
 
 import phantom_amd as ph
 
-from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, supply_chain_env)
+from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, market_topology,
+                     supply_chain_env)
 from kats import ALL_KATS
 from oracle import OracleEnv
 from test_oracle_vs_goldens import SC_CASES, replay_market, replay_supply_chain
@@ -628,3 +629,48 @@ def test_python_surface_supertypes_match_reference_tests():
             np.testing.assert_array_equal(f32_bits(step.observations[sid]), f32_bits(g["obs"][t, 0, i]))
             assert step.rewards[sid] == g["reward"][t, 0, i]
         assert step.truncations["__all__"] == bool(g["all_truncated"][t, 0])
+
+
+def test_market_compressed_prices_materialise_on_inject():
+    """The fused market kernel keeps BuyerAgent.prices as one value per seller; a host-injected
+    Price to a single buyer breaks that form: the table is materialised and the env continues on
+    the generic engine -- same results as the oracle throughout."""
+    from phantom_amd.message import Message
+    rng = np.random.RandomState(8)
+    L, Fw, d, B = 8, 32, 4, 6
+    S = L + Fw
+    env = market_env(L, Fw, d, 50, B)
+    o, x = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); x.reset()
+
+    nb0 = market_topology(L, Fw, d)[0][1]                       # second neighbour of buyer B0
+
+    def step(t, mute_seller=None, force_buy=False):
+        act = np.zeros((B, S), np.float32); valid = np.zeros((B, S), np.uint8)
+        odd = (o.get_i32("env.step")[:, 0] + 1) % 2 == 1
+        act[:, :L] = rng.randint(1, 9, size=(B, L)) / 8.0
+        act[:, L:] = (rng.rand(B, Fw) < 0.7)
+        if force_buy:
+            act[:, L] = 1.0
+        valid[odd, :L] = 1; valid[~odd, L:] = 1
+        if mute_seller is not None:
+            valid[:, mute_seller] = 0
+        o.step(act, valid, None); x.step(act, valid, None)
+        for f in ("obs_valid", "reward_valid", "err"):
+            np.testing.assert_array_equal(getattr(x, f), getattr(o, f), err_msg=f"{f} t={t}")
+        np.testing.assert_array_equal(f32_bits(x.obs), f32_bits(o.obs), err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward), err_msg=f"rew t={t}")
+
+    for t in range(4):
+        step(t)
+    assert x.dev.uses_fused
+    np.testing.assert_array_equal(f64_bits(x.get_f64("buyer.prices")), f64_bits(o.get_f64("buyer.prices")))
+    msg = [Message(f"S{nb0}", "B0", ph.Price(0.015625))]
+    o.inject(msg); x.dev.inject(msg)
+    step(4, mute_seller=nb0)                 # leaders' step: only the injected Price reaches B0's slot
+    assert not x.dev.uses_fused
+    step(5, force_buy=True)                  # followers' step: B0 buys at the injected price
+    assert (o.get_f64("buyer.paid")[:, 0] == 0.015625).all()
+    for t in range(6, 10):
+        step(t)
+    np.testing.assert_array_equal(f64_bits(x.get_f64("buyer.prices")), f64_bits(o.get_f64("buyer.prices")))
