@@ -201,33 +201,42 @@ void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 }
 /* Device-RNG definition (build-owned; replaces the global numpy stream when exo == NULL).
  * np.random.randint(5) is exactly uniform on {0..4} (numpy draws 3 bits and rejects > 4).  The
- * device stream is exactly uniform too, by rejection on 16-bit fields: customer k of a shop owns
- * field j = k % 6 (the six 16-bit halves of words 0..2, low half first) of Philox block
- *     ctr = (env_lo, env_hi | attempt << 16, tick, shop | (k / 6) << 20),  key = seed;
- * a field value u is rejected iff u == 65535 (65535 = 5 * 13107 values remain), the order size
- * is u % 5, and a rejected customer redraws the same field of the block with attempt + 1.
- * Word 3 of block (k / 6 = 0, attempt 0) gives the shop's random-policy action.            */
-static uint32_t rng_field(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk, int j,
-                          uint32_t attempt, uint32_t* w3) {
+ * device stream is exactly uniform too.  One Philox4x32-10 block
+ *     ctr = (env_lo, env_hi | attempt << 16, tick >> 1, shop | blk << 20),  key = seed
+ * serves two consecutive ticks of a shop.  With p = tick & 1, block 0 holds the order word of
+ * customers 0..5 in word 2p and the shop's random-policy action in word 2p + 1; customers
+ * 6g .. 6g+5 (g >= 1) own word x % 4 of block 1 + x / 4 with x = 2 (g - 1) + p.  An order word u
+ * is rejected iff low32(u * 5^6) < 2^32 mod 5^6 = 14171 (then redrawn at the same position with
+ * attempt + 1); otherwise y = (u * 5^6) >> 32 is uniform on [0, 5^6) and customer j of the group
+ * orders base-5 digit j of y.                                                                */
+static uint32_t rng_word(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk, int word,
+                         uint32_t attempt) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick,
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 1,
                      (uint32_t)shop | ((uint32_t)blk << 20)};
   uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
-  if (w3) *w3 = w[3];
-  return (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+  return w[word];
+}
+static uint32_t rng_group_y(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g) {
+  const int p = (int)(tick & 1u);
+  int blk = 0, word = 2 * p;
+  if (g > 0) { int x = 2 * (g - 1) + p; blk = 1 + x / 4; word = x % 4; }
+  for (uint32_t attempt = 0;; ++attempt) {
+    uint64_t m = (uint64_t)rng_word(seed, genv, tick, shop, blk, word, attempt) * 15625u;
+    if ((uint32_t)m >= 14171u) return (uint32_t)(m >> 32);
+  }
 }
 void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out) {
   for (int k = 0; k < K; ++k) {
-    uint32_t u, attempt = 0;
-    do { u = rng_field(seed, genv, tick, shop, k / 6, k % 6, attempt++, NULL); } while (u == 65535u);
-    out[k] = (uint8_t)(u % 5u);
+    uint32_t y = rng_group_y(seed, genv, tick, shop, k / 6);
+    for (int j = 0; j < k % 6; ++j) y /= 5u;
+    out[k] = (uint8_t)(y % 5u);
   }
 }
-/* random policy of the rollout: U[0,100) from the top 24 bits of word 3 of the shop's block 0 */
+/* random policy of the rollout: U[0,100) from the top 24 bits of the shop's action word */
 float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int shop) {
-  uint32_t w3;
-  rng_field(seed, genv, tick, shop, 0, 0, 0, &w3);
-  return (float)(w3 >> 8) * (100.0f / 16777216.0f);
+  uint32_t w = rng_word(seed, genv, tick, shop, 0, 2 * (int)(tick & 1u) + 1, 0);
+  return (float)(w >> 8) * (100.0f / 16777216.0f);
 }
 
 /* Device draw of UniformFloatSampler column j at the env's `episode`-th reset (build-owned

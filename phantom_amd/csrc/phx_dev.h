@@ -185,95 +185,107 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Device RNG (definition restated in oracle/phx_oracle.c and DESIGN.md).  Exactly uniform order
-// sizes by rejection on 16-bit fields: customer k of a shop owns field j = k % 6 (the six 16-bit
-// halves of words 0..2, low half first) of Philox block
-//     ctr = (env_lo, env_hi | attempt << 16, tick, shop | (k / 6) << 20), key = seed;
-// u == 65535 is rejected (65535 = 5 * 13107 values remain), the order is u % 5, a rejected
-// customer redraws the same field with attempt + 1.  Word 3 of block (0, attempt 0) is the
-// shop's random-policy action.
+// Device RNG (definition restated in oracle/phx_oracle.c and DESIGN.md).  One Philox block
+//     ctr = (env_lo, env_hi | attempt << 16, tick >> 1, shop | blk << 20), key = seed
+// serves TWO consecutive ticks of a shop.  With p = tick & 1, block 0 holds
+//     word 2p     the order word of customers 0..5        word 2p + 1   the random-policy action
+// and customers 6g .. 6g+5 (g >= 1) own word x % 4 of block 1 + x / 4, x = 2 (g - 1) + p.
+// An order word u yields SIX exactly uniform order sizes: y = (u * 5^6) >> 32 is uniform on
+// [0, 5^6) once the words with low32(u * 5^6) < 2^32 mod 5^6 = 14171 are rejected (Lemire; a
+// rejected word is redrawn at the same position with attempt + 1, probability 3.3e-6), and
+// customer j of the group takes base-5 digit j of y.  The action is U[0,100) from the top 24 bits.
+#define PHX_RNG_P6   15625u
+#define PHX_RNG_REJ  14171u
 __device__ __forceinline__ void rng_block(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk,
                                           uint32_t attempt, uint32_t w[4]) {
-  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick,
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 1,
                 (uint32_t)shop | ((uint32_t)blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
 }
-__device__ __forceinline__ uint32_t rng_mod5(uint32_t u) {          // u < 65536
-  // u / 5 through f32: u * 0.2f carries a relative error < 2^-23, far below the 0.2 gap to the
-  // next integer boundary for u < 2^16, and 0.2f > 0.2 keeps exact multiples of 5 on the right
-  // side (checked exhaustively in tests/test_gpu_parity.py via the oracle comparison and in
-  // scratch unit tests); all four ops are full rate.
-  const uint32_t q = (uint32_t)((float)u * 0.2f);
-  return u - q * 5u;
+// u -> y, false when the word is rejected
+__device__ __forceinline__ bool rng_word_to_y(uint32_t u, uint32_t& y) {
+  const uint64_t m = (uint64_t)u * PHX_RNG_P6;
+  y = (uint32_t)(m >> 32);
+  return (uint32_t)m >= PHX_RNG_REJ;
 }
-// one customer's draw (generic engine; also the redraw path)
-__device__ __forceinline__ int rng_customer_order(uint64_t seed, int64_t genv, uint32_t tick, int shop, int k,
-                                               uint32_t attempt0) {
-  const int blk = k / 6, j = k - blk * 6;
+__device__ __forceinline__ void rng_group_pos(int g, uint32_t tick, int& blk, int& word) {
+  const int p = (int)(tick & 1u);
+  if (g == 0) { blk = 0; word = 2 * p; }
+  else { const int x = 2 * (g - 1) + p; blk = 1 + (x >> 2); word = x & 3; }
+}
+// y of customer group g, starting at `attempt0` (the cold / generic path: one Philox call per try)
+__device__ __forceinline__ uint32_t rng_group_y(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g,
+                                                uint32_t attempt0) {
+  int blk, word; rng_group_pos(g, tick, blk, word);
   for (uint32_t attempt = attempt0;; ++attempt) {
-    uint32_t w[4];
+    uint32_t w[4], y;
     rng_block(seed, genv, tick, shop, blk, attempt, w);
-    const uint32_t wj = j < 2 ? w[0] : (j < 4 ? w[1] : w[2]);
-    const uint32_t u = (wj >> (16 * (j & 1))) & 0xffffu;
-    if (u != 65535u) return (int)rng_mod5(u);
+    const uint32_t u = word == 0 ? w[0] : (word == 1 ? w[1] : (word == 2 ? w[2] : w[3]));
+    if (rng_word_to_y(u, y)) return y;
   }
 }
-// Sum over the shop's K customers (those selected by `actmask`, NULL = all), or with kth >= 0 only
-// customer kth's draw; *act_word = word 3 of block 0.
-__device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
-                                               int K, const uint8_t* actmask, int kth,
-                                               uint32_t* act_word = nullptr) {
-  if (kth >= 0) return rng_customer_order(seed, genv, tick, shop, kth, 0);
+// x / 5 for x < 2^16 through f32: x * 0.2f carries a relative error < 2^-23, far below the 0.2 gap
+// to the next integer boundary, and 0.2f > 0.2 keeps exact multiples on the right side; the same
+// holds for 0.04f .. 0.00032f on [0, 5^6) (all checked exhaustively in tests/test_host_logic.py).
+__device__ __forceinline__ uint32_t rng_div5(uint32_t x) { return (uint32_t)((float)x * 0.2f); }
+// sum of the six base-5 digits of y < 5^6:  y - 4 * (y/5 + y/25 + y/125 + y/625 + y/3125)
+__device__ __forceinline__ int rng_digit_sum6(uint32_t y) {
+  const float yf = (float)y;
+  const uint32_t q = (uint32_t)(yf * 0.2f) + (uint32_t)(yf * 0.04f) + (uint32_t)(yf * 0.008f) +
+                     (uint32_t)(yf * 0.0016f) + (uint32_t)(yf * 0.00032f);
+  return (int)(y - (q << 2));
+}
+// sum of digits j in [0, n) selected by mask (NULL = all); n <= 6
+__device__ __forceinline__ int rng_digit_sum(uint32_t y, int n, const uint8_t* actmask) {
   int sum = 0;
-  for (int k0 = 0; k0 < K || (k0 == 0 && act_word); k0 += 6) {
-    uint32_t w[4];
-    rng_block(seed, genv, tick, shop, k0 / 6, 0, w);
-    if (k0 == 0 && act_word) *act_word = w[3];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int k = k0 + j;
-      if (k < K && (actmask == nullptr || actmask[k] != 0)) {
-        const uint32_t u = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-        sum += (u != 65535u) ? (int)rng_mod5(u) : rng_customer_order(seed, genv, tick, shop, k, 1);
-      }
-    }
+  for (int j = 0; j < n; ++j) {
+    const uint32_t q = rng_div5(y);
+    if (actmask == nullptr || actmask[j] != 0) sum += (int)(y - 5u * q);
+    y = q;
   }
   return sum;
 }
-// all K customers, sum only: the fused kernels' fast path (same definition).  u % 5 is computed
-// for all six fields of a block unconditionally (65535 % 5 == 0, so a rejected field adds
-// nothing); the rare redraws are handled in one cold branch per block.  When every lane of the
-// wave still needs >= 6 customers from the block (the usual K = 6 case) the per-field
-// "customer exists" selects disappear.
+// one customer's draw (generic engine)
+__device__ __forceinline__ int rng_customer_order(uint64_t seed, int64_t genv, uint32_t tick, int shop, int k) {
+  const int g = k / 6, j = k - g * 6;
+  uint32_t y = rng_group_y(seed, genv, tick, shop, g, 0);
+  for (int i = 0; i < j; ++i) y = rng_div5(y);
+  return (int)(y - 5u * rng_div5(y));
+}
+// Sum over the shop's K customers (those selected by `actmask`, NULL = all), or with kth >= 0 only
+// customer kth's draw; *act_word = the shop's action word of this tick.
+__device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
+                                               int K, const uint8_t* actmask, int kth,
+                                               uint32_t* act_word = nullptr) {
+  if (kth >= 0) return rng_customer_order(seed, genv, tick, shop, kth);
+  const int p = (int)(tick & 1u);
+  uint32_t w[4];
+  rng_block(seed, genv, tick, shop, 0, 0, w);
+  if (act_word) *act_word = p ? w[3] : w[1];
+  int sum = 0;
+  for (int g = 0; 6 * g < K; ++g) {
+    const int n = K - 6 * g < 6 ? K - 6 * g : 6;
+    uint32_t y;
+    if (g != 0 || !rng_word_to_y(p ? w[2] : w[0], y)) y = rng_group_y(seed, genv, tick, shop, g, g == 0 ? 1 : 0);
+    sum += rng_digit_sum(y, n, actmask ? actmask + 6 * g : nullptr);
+  }
+  return sum;
+}
+// all K customers, sum only: the fused kernels' fast path (same definition).  When every lane of
+// the wave has a full group the digit sum is the closed form above.
 __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                   int K, uint32_t* act_word) {
-  int sum = 0, k0 = 0;
-  do {
-    uint32_t w[4];
-    rng_block(seed, genv, tick, shop, k0 / 6, 0, w);
-    if (k0 == 0 && act_word) *act_word = w[3];
-    const int n = K - k0;                       // customers served by this block: min(n, 6)
-    uint32_t rej = 0;
-    if (__all(n >= 6)) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const uint32_t u = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
-        sum += (int)rng_mod5(u);
-        rej |= ((u + 1u) >> 16) << j;           // bit j <=> u == 65535
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const uint32_t u = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
-        const bool take = j < n;
-        sum += take ? (int)rng_mod5(u) : 0;
-        rej |= take ? (((u + 1u) >> 16) << j) : 0u;
-      }
-    }
-    if (rej)                                   // probability 6 * 2^-16 per block
-      for (int j = 0; j < 6; ++j)
-        if ((rej >> j) & 1u) sum += rng_customer_order(seed, genv, tick, shop, k0 + j, 1);
-    k0 += 6;
-  } while (k0 < K);
+  const int p = (int)(tick & 1u);
+  uint32_t w[4];
+  rng_block(seed, genv, tick, shop, 0, 0, w);
+  if (act_word) *act_word = p ? w[3] : w[1];
+  if (K <= 0) return 0;
+  uint32_t y;
+  if (!rng_word_to_y(p ? w[2] : w[0], y)) y = rng_group_y(seed, genv, tick, shop, 0, 1);   // probability 3.3e-6
+  int sum = __all(K >= 6) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, nullptr);
+  for (int g = 1; 6 * g < K; ++g) {
+    const int n = K - 6 * g < 6 ? K - 6 * g : 6;
+    sum += rng_digit_sum(rng_group_y(seed, genv, tick, shop, g, 0), n, nullptr);
+  }
   return sum;
 }
 

@@ -288,29 +288,51 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
     const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
     const int n_items = tc * G;
     // ---- phase 1 ---------------------------------------------------------------------------------
-    // flat items i = tl * G + gl, thread-strided; (tl, gl) advance incrementally (NT = qG * G + rG)
-    int tl = tid / G, gl = tid - tl * G;
+    // One Philox block serves the two ticks (2q, 2q + 1) of a shop, so the flat work items are
+    // (row pair jr, pair gl): rows tla = 2 jr - e and tla + 1 of the chunk, where e is the parity
+    // of the env's tick at chunk row 0.  Thread-strided; (jr, gl) advance incrementally.
+    const int npr = (tc >> 1) + 1;
+    const int n_work = npr * G;
+    int jr = tid / G, gl = tid - jr * G;
     const int qG = NT / G, rG = NT - qG * G;
-    for (int i = tid; i < n_items; i += NT) {
+    for (int iw = tid; iw < n_work; iw += NT) {
       const int pr = s_pair[gl], s = pr & 255, bl = pr >> 8;
-      const int b = (int)b_first + bl, t = t0 + tl;
+      const int b = (int)b_first + bl;
       const int64_t genv = a.env_offset + b;
-      const uint32_t tick = (uint32_t)s_tick0[bl] + (uint32_t)t;
-      const int c_lo = s_cptr[s], c_hi = s_cptr[s + 1];
-      int D = 0; uint32_t w3 = 0;
-      if (REPLAY && io.exo) {
-        const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
-        for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
-        if (!io.actions) rng_shop_order_sum(a.seed, genv, tick, s, 0, &w3);
-      } else {
-        D = rng_shop_order_sum(a.seed, genv, tick, s, c_hi - c_lo, &w3);
+      const uint32_t tick_base = (uint32_t)s_tick0[bl] + (uint32_t)t0;
+      const int e = (int)(tick_base & 1u);
+      const int tla = 2 * jr - e;
+      const bool va = tla >= 0 && tla < tc, vb = tla + 1 < tc;
+      if (va || vb) {
+        const uint32_t tick_a = tick_base + (uint32_t)tla;           // even
+        const int c_lo = s_cptr[s], c_hi = s_cptr[s + 1], K = c_hi - c_lo;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (!(REPLAY && io.exo && io.actions)) rng_block(a.seed, genv, tick_a, s, 0, 0, w);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int tl = tla + h;
+          if (!(h ? vb : va)) continue;
+          const int t = t0 + tl, i = tl * G + gl;
+          int D = 0;
+          if (REPLAY && io.exo) {
+            const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
+            for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
+          } else if (K > 0) {
+            uint32_t y;
+            if (!rng_word_to_y(w[2 * h], y)) y = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1);   // 3.3e-6
+            D = __all(K >= 6) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, nullptr);
+            for (int g = 1; 6 * g < K; ++g)
+              D += rng_digit_sum(rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, g, 0), K - 6 * g < 6 ? K - 6 * g : 6, nullptr);
+          }
+          const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl]
+                                                      : rng_word_to_action(w[2 * h + 1]);
+          s_act[i] = action;
+          s_it[3 * i + 0] = dev_round_half_even(action);
+          s_it[3 * i + 1] = D;
+        }
       }
-      const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl] : rng_word_to_action(w3);
-      s_act[i] = action;
-      s_it[3 * i + 0] = dev_round_half_even(action);
-      s_it[3 * i + 1] = D;
-      tl += qG; gl += rG;
-      if (gl >= G) { gl -= G; ++tl; }
+      jr += qG; gl += rG;
+      if (gl >= G) { gl -= G; ++jr; }
     }
     TICK(1); lds_barrier(); TICK(2);
     // ---- phase 2: the stock recurrence, one lane per pair ---------------------------------------
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
     }
     TICK(3); lds_barrier(); TICK(4);
     // ---- phase 3a: observations / rewards / flags into the tiles ------------------------------------
-    tl = tid / G; gl = tid - tl * G;
+    int tl = tid / G; gl = tid - tl * G;
     for (int i = tid; i < n_items; i += NT) {
       const int pr = s_pair[gl], s = pr & 255;
       const int stock = s_it[3 * i], D = s_it[3 * i + 1], sales = s_it[3 * i + 2];

@@ -84,13 +84,27 @@ def log_matrix(recs):
     return out
 
 
-def find_rng_rejection(seed=1, tick=0, shop=0, limit=400000):
-    """first global env index whose block (tick, shop, blk 0, attempt 0) has a rejected
-    (== 65535) 16-bit order field among its six: the rare redraw branch of the device RNG."""
-    from oracle import philox
-    for genv in range(limit):
-        w = philox([genv & 0xffffffff, genv >> 32, tick, shop], [seed & 0xffffffff, seed >> 32])
-        for j in range(6):
-            if (int(w[j >> 1]) >> (16 * (j & 1))) & 0xffff == 65535:
-                return genv, j
+def philox_np(c0, c1, c2, c3, k0, k1):
+    """vectorised Philox4x32-10 (numpy uint64 arithmetic); pinned to oracle.philox in the tests."""
+    c0, c1, c2, c3 = (np.asarray(c, np.uint64) & np.uint64(0xffffffff) for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c0, c1, c2, c3
+
+
+def find_rng_rejection(seed=1, tick=0, shop=0, limit=4_000_000):
+    """first global env index whose order word of (tick, shop), customers 0..5, is rejected
+    (low32(u * 5^6) < 14171, probability 3.3e-6): the rare redraw branch of the device RNG."""
+    step = 1 << 18
+    for lo in range(0, limit, step):
+        genv = np.arange(lo, lo + step, dtype=np.uint64)
+        w = philox_np(genv, 0, tick >> 1, shop, seed & 0xffffffff, seed >> 32)
+        u = w[2 * (tick & 1)]
+        rej = ((u * np.uint64(15625)) & np.uint64(0xffffffff)) < np.uint64(14171)
+        if rej.any():
+            return int(genv[np.flatnonzero(rej)[0]])
     raise AssertionError("no rejection found")

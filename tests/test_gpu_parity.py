@@ -223,10 +223,10 @@ def test_rollout_matches_oracle(mode):
 
 
 def test_rng_rejection_branch_on_device():
-    """the 1-in-65536 redraw branch of the device RNG: place the batch on a global env index
-    where block (tick 0, shop 0) holds a rejected field; fused, generic and rollout vs oracle."""
+    """the 3.3e-6 redraw branch of the device RNG: place the batch on a global env index where
+    the order word of (tick 0, shop 0) is rejected; fused, generic and rollout vs oracle."""
     from helpers import find_rng_rejection
-    genv, j = find_rng_rejection(seed=1)
+    genv = find_rng_rejection(seed=1)
     B = 8
     for force_generic in (False, True):
         env = supply_chain_env(2, [6, 6], 20, B, seed=1, env_offset=genv - 3, force_generic=force_generic)
@@ -244,8 +244,8 @@ def test_rng_rejection_branch_on_device():
 
 
 def test_full_size_rollout_matches_oracle():
-    """BASELINE configs[1] at full size: SC64, B=4096, one T=100 fragment, device RNG (22 M draws,
-    a few hundred of them through the redraw branch) -- bit-equal to the oracle."""
+    """BASELINE configs[1] at full size: SC64, B=4096, one T=100 fragment, device RNG (3.7 M order
+    words, about a dozen of them through the redraw branch) -- bit-equal to the oracle."""
     env = supply_chain_env(9, [6] * 9, 100, 4096, seed=42)
     o, d = OracleEnv(env.spec, threads=8), _dev(env.spec)
     o.reset(); d.reset()
@@ -257,8 +257,8 @@ def test_full_size_rollout_matches_oracle():
 
 
 def test_rng_fallback_block_is_exercised():
-    """the masked-rejection draw needs a second Philox block for K > ~25 customers per shop:
-    force that branch and compare with the oracle."""
+    """more than 6 customers per shop: further order words in blocks 1, 2, ... (ragged last group);
+    compare with the oracle."""
     B, ks = 64, [70, 41]
     env = supply_chain_env(2, ks, 20, B, seed=99)
     o, d = OracleEnv(env.spec), _dev(env.spec)

@@ -146,43 +146,69 @@ def test_philox_known_answers():
 
 
 def test_device_rng_definition():
-    """orders: customer k = 16-bit field k % 6 of block k // 6 (words 0..2), 65535 rejected, u % 5;
-    action = top 24 bits of word 3 of block 0."""
-    seed, genv, tick, shop = 0x1234567890ABCDEF, 5_000_000_123, 77, 3
-
-    def block(blk, attempt=0):
-        return philox([genv & 0xffffffff, (genv >> 32) | (attempt << 16), tick, shop | (blk << 20)],
-                      [seed & 0xffffffff, seed >> 32])
+    """one Philox block per (shop, tick pair): word 2p = order word of customers 0..5, word 2p+1 =
+    action (p = tick & 1); customers 6g.. own word x % 4 of block 1 + x // 4, x = 2(g-1)+p;
+    y = (u * 5^6) >> 32 (rejected iff low32 < 14171), customer j = base-5 digit j of y."""
+    seed, genv, shop = 0x1234567890ABCDEF, 5_000_000_123, 3
     K = 20
-    got = rng_orders(seed, genv, tick, shop, K)
-    for k in range(K):
-        w = block(k // 6)
-        u = (int(w[(k % 6) >> 1]) >> (16 * (k & 1 if (k % 6) % 2 == k % 2 else (k % 6) & 1))) & 0xffff
-        u = (int(w[(k % 6) >> 1]) >> (16 * ((k % 6) & 1))) & 0xffff
-        assert u != 65535 and got[k] == u % 5
-    w0 = block(0)
-    assert rng_action(seed, genv, tick, shop) == np.float32(int(w0[3]) >> 8) * np.float32(100.0 / 16777216.0)
+    for tick in (76, 77):
+        p = tick & 1
+
+        def word(blk, w, attempt=0):
+            return int(philox([genv & 0xffffffff, (genv >> 32) | (attempt << 16), tick >> 1, shop | (blk << 20)],
+                              [seed & 0xffffffff, seed >> 32])[w])
+        got = rng_orders(seed, genv, tick, shop, K)
+        for k in range(K):
+            g, j = divmod(k, 6)
+            blk, w = (0, 2 * p) if g == 0 else (1 + (2 * (g - 1) + p) // 4, (2 * (g - 1) + p) % 4)
+            m = word(blk, w) * 15625
+            assert (m & 0xffffffff) >= 14171
+            assert got[k] == ((m >> 32) // 5 ** j) % 5
+        assert rng_action(seed, genv, tick, shop) == np.float32(word(0, 2 * p + 1) >> 8) * np.float32(100.0 / 16777216.0)
     many = np.concatenate([rng_orders(1, b, t, 0, 6) for b in range(200) for t in range(20)])
     assert many.min() == 0 and many.max() == 4
     assert abs(np.bincount(many, minlength=5) / many.size - 0.2).max() < 0.01
+    # the six digits of one word are independent: all 5^2 pairs of (customer 0, customer 5) occur
+    pairs = many.reshape(-1, 6)[:, [0, 5]]
+    assert len({(int(a), int(b)) for a, b in pairs}) == 25
 
 
 def test_device_rng_rejection_branch():
-    """u == 65535 is rejected and the customer redraws the same field with attempt + 1."""
-    from helpers import find_rng_rejection
-    genv, j = find_rng_rejection(seed=1)
-    w1 = philox([genv & 0xffffffff, (genv >> 32) | (1 << 16), 0, 0], [1, 0])
-    u1 = (int(w1[j >> 1]) >> (16 * (j & 1))) & 0xffff
-    assert u1 != 65535
-    assert rng_orders(1, genv, 0, 0, 6)[j] == u1 % 5
+    """a rejected order word is redrawn at the same position with attempt + 1."""
+    from helpers import find_rng_rejection, philox_np
+    w = philox_np(np.arange(5), 7, 3, 2, 11, 13)                  # the numpy Philox is the oracle's
+    for b in range(5):
+        assert [int(x[b]) for x in w] == [int(v) for v in philox([b, 7, 3, 2], [11, 13])]
+    genv = find_rng_rejection(seed=1)
+    u0 = int(philox([genv & 0xffffffff, genv >> 32, 0, 0], [1, 0])[0])
+    assert ((u0 * 15625) & 0xffffffff) < 14171
+    u1 = int(philox([genv & 0xffffffff, (genv >> 32) | (1 << 16), 0, 0], [1, 0])[0])
+    y = (u1 * 15625) >> 32
+    assert ((u1 * 15625) & 0xffffffff) >= 14171
+    assert list(rng_orders(1, genv, 0, 0, 6)) == [(y // 5 ** j) % 5 for j in range(6)]
 
 
-def test_f32_mod5_formula_is_exact_for_16_bit_fields():
-    """the kernels compute u % 5 as u - 5 * uint(f32(u) * 0.2f): exact for every u < 65536
-    (IEEE f32 multiply, round-to-nearest, truncating conversion -- same on CPU and GPU)."""
+def test_f32_digit_formulas_are_exact():
+    """the kernels take base-5 digits through f32: x // 5 == uint(f32(x) * 0.2f) for x < 2^16 and
+    y // 5^i == uint(f32(y) * f32(5^-i)) for y < 5^6 (IEEE multiply, truncating conversion -- the
+    same on CPU and GPU), so digit sums are y - 4 * sum_i y // 5^i; Lemire's map is exactly uniform."""
     u = np.arange(65536, dtype=np.uint32)
     q = (u.astype(np.float32) * np.float32(0.2)).astype(np.uint32)
     assert (q == u // 5).all() and ((u - q * 5) == u % 5).all()
+    y = np.arange(15625, dtype=np.uint32)
+    tot = np.zeros_like(y)
+    for i, c in enumerate([0.2, 0.04, 0.008, 0.0016, 0.00032]):
+        qi = (y.astype(np.float32) * np.float32(c)).astype(np.uint32)
+        assert (qi == y // 5 ** (i + 1)).all()
+        tot += qi
+    digits = sum((y // 5 ** j) % 5 for j in range(6))
+    assert ((y - 4 * tot) == digits).all()
+    assert 2 ** 32 % 15625 == 14171
+    # every y is hit by exactly floor(2^32 / 5^6) accepted words: check on a coarse residue sample
+    us = np.arange(0, 2 ** 32, 9973, dtype=np.uint64)
+    m = us * np.uint64(15625)
+    acc = (m & np.uint64(0xffffffff)) >= np.uint64(14171)
+    assert ((m >> np.uint64(32))[acc] < 15625).all() and abs(acc.mean() - (1 - 14171 / 2 ** 32)) < 1e-4
 
 
 def test_f32_division_equals_reference_f64_quotient_cast():
