@@ -251,42 +251,39 @@ __device__ __forceinline__ int rng_customer_order(uint64_t seed, int64_t genv, u
   for (int i = 0; i < j; ++i) y = rng_div5(y);
   return (int)(y - 5u * rng_div5(y));
 }
+// order sum of a shop's K customers (those selected by `actmask`, NULL = all) given block 0 of
+// its tick pair (w); further groups and the rare redraw fetch their own blocks
+__device__ __forceinline__ int rng_orders_from_block(const uint32_t w[4], uint64_t seed, int64_t genv, uint32_t tick,
+                                                     int shop, int K, const uint8_t* actmask) {
+  if (K <= 0) return 0;
+  uint32_t y;
+  if (!rng_word_to_y((tick & 1u) ? w[2] : w[0], y)) y = rng_group_y(seed, genv, tick, shop, 0, 1);   // probability 3.3e-6
+  int sum = (actmask == nullptr && __all(K >= 6)) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, actmask);
+  for (int g = 1; 6 * g < K; ++g)
+    sum += rng_digit_sum(rng_group_y(seed, genv, tick, shop, g, 0), K - 6 * g < 6 ? K - 6 * g : 6,
+                         actmask ? actmask + 6 * g : nullptr);
+  return sum;
+}
 // Sum over the shop's K customers (those selected by `actmask`, NULL = all), or with kth >= 0 only
 // customer kth's draw; *act_word = the shop's action word of this tick.
 __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                int K, const uint8_t* actmask, int kth,
                                                uint32_t* act_word = nullptr) {
   if (kth >= 0) return rng_customer_order(seed, genv, tick, shop, kth);
-  const int p = (int)(tick & 1u);
   uint32_t w[4];
   rng_block(seed, genv, tick, shop, 0, 0, w);
-  if (act_word) *act_word = p ? w[3] : w[1];
-  int sum = 0;
-  for (int g = 0; 6 * g < K; ++g) {
-    const int n = K - 6 * g < 6 ? K - 6 * g : 6;
-    uint32_t y;
-    if (g != 0 || !rng_word_to_y(p ? w[2] : w[0], y)) y = rng_group_y(seed, genv, tick, shop, g, g == 0 ? 1 : 0);
-    sum += rng_digit_sum(y, n, actmask ? actmask + 6 * g : nullptr);
-  }
-  return sum;
+  if (act_word) *act_word = (tick & 1u) ? w[3] : w[1];
+  return rng_orders_from_block(w, seed, genv, tick, shop, K, actmask);
 }
-// all K customers, sum only: the fused kernels' fast path (same definition).  When every lane of
-// the wave has a full group the digit sum is the closed form above.
+// all K customers, sum only (same definition)
 __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                   int K, uint32_t* act_word) {
-  const int p = (int)(tick & 1u);
-  uint32_t w[4];
-  rng_block(seed, genv, tick, shop, 0, 0, w);
-  if (act_word) *act_word = p ? w[3] : w[1];
-  if (K <= 0) return 0;
-  uint32_t y;
-  if (!rng_word_to_y(p ? w[2] : w[0], y)) y = rng_group_y(seed, genv, tick, shop, 0, 1);   // probability 3.3e-6
-  int sum = __all(K >= 6) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, nullptr);
-  for (int g = 1; 6 * g < K; ++g) {
-    const int n = K - 6 * g < 6 ? K - 6 * g : 6;
-    sum += rng_digit_sum(rng_group_y(seed, genv, tick, shop, g, 0), n, nullptr);
-  }
-  return sum;
+  return rng_shop_orders(seed, genv, tick, shop, K, nullptr, -1, act_word);
+}
+// block 0 of a shop's tick pair, kept across the two ticks by kernels that walk time in order
+struct RngPairCache { uint32_t w[4]; uint32_t q; };
+__device__ __forceinline__ void rng_pair_block(RngPairCache& c, uint64_t seed, int64_t genv, uint32_t tick, int shop) {
+  if ((tick >> 1) != c.q) { rng_block(seed, genv, tick, shop, 0, 0, c.w); c.q = tick >> 1; }
 }
 
 // UniformFloatSampler column j at the env's `episode`-th reset (definition restated in

@@ -230,7 +230,11 @@ __device__ __forceinline__ void lds_barrier() {
 // WIDE:   every block owns exactly epb envs and every tile row is 16-byte aligned (host-checked),
 //         so the copy-out uses dwordx4 / dwordx2 stores and magic-number row arithmetic only.
 template <int NT, bool REPLAY, bool WIDE>
-__global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(const RollArgs a) {
+__global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 6 : 4))) void phx_sc_rollout_kernel(const RollArgs a) {
+  // Software pipeline over chunks of TC steps.  Phase 1 (Philox draws) of chunk c + 1 does not
+  // depend on the stock recurrence, so it runs on waves P1W.. while waves 0..P2W-1 walk the
+  // recurrence (phase 2) of chunk c; item tiles {R|stock, D, sales} and the action tile are
+  // double-buffered in LDS.  Per chunk:   [P2(c) || P1(c+1)]  bar  P3(c)  bar
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PHX_TIMING
   unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -249,11 +253,10 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
 
   // LDS carve (all offsets multiples of 16 bytes)
   const int items_max = TC * Gfull;
-  int* s_it = (int*)smem;                                  // [TC][G][3]  {R|stock|obs0, D|obs1, sales|obs2}
-  float* s_rew = (float*)(s_it + ((items_max * 3 + 3) & ~3));
-  float* s_act = s_rew + ((items_max + 3) & ~3);
-  uint8_t* s_trunc = (uint8_t*)(s_act + ((items_max + 3) & ~3));
-  uint16_t* s_pair = (uint16_t*)(s_trunc + ((items_max + 15) & ~15));   // [G] shop | env_local << 8
+  const int it_words = (items_max * 3 + 3) & ~3, it1 = (items_max + 3) & ~3;
+  int* s_it0 = (int*)smem;                                 // 2 x [TC][G][3]
+  float* s_act0 = (float*)(s_it0 + 2 * it_words);          // 2 x [TC][G]
+  uint16_t* s_pair = (uint16_t*)(s_act0 + 2 * it1);        // [G] shop | env_local << 8
   int* s_tick0 = (int*)(s_pair + ((Gfull + 7) & ~7));     // [epb]
   int* s_step0 = s_tick0 + ((a.epb + 3) & ~3);             // [epb]
   int* s_tend = s_step0 + ((a.epb + 3) & ~3);              // [epb] chunk-local step index that ends the episode, or -1
@@ -280,22 +283,27 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
     const int s2 = tid % nS;
     p2_K = a.shop_cust_ptr[s2 + 1] - a.shop_cust_ptr[s2];
   }
-  // full-width copy-out needs every tile row to start and end on a 16-byte boundary
+  // thread roles in the overlapped phase: the waves that hold a recurrence lane do phase 2, the
+  // others phase 1 (when no wave is left over, everybody does phase 1 after phase 2)
+  const int p2_threads = ((G + 63) >> 6) << 6;
+  const int p1_first = (p2_threads + 64 <= NT) ? p2_threads : 0;
   lds_barrier();
-
   TICK(0);
-  for (int t0 = 0; t0 < a.T; t0 += TC) {
-    const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
-    const int n_items = tc * G;
-    // ---- phase 1 ---------------------------------------------------------------------------------
-    // One Philox block serves the two ticks (2q, 2q + 1) of a shop, so the flat work items are
-    // (row pair jr, pair gl): rows tla = 2 jr - e and tla + 1 of the chunk, where e is the parity
-    // of the env's tick at chunk row 0.  Thread-strided; (jr, gl) advance incrementally.
+
+  // ---- phase 1 of the chunk starting at step t0 (tc rows) into buffer `buf`, by threads
+  //      [first, NT).  One Philox block serves the two ticks (2q, 2q + 1) of a shop, so the flat
+  //      work items are (row pair jr, pair gl): rows tla = 2 jr - e and tla + 1 of the chunk, e =
+  //      parity of the env's tick at chunk row 0.  Thread-strided; (jr, gl) advance incrementally.
+  auto phase1 = [&](int t0, int tc, int buf, int first) {
+    if (tid < first) return;
+    int* s_it = s_it0 + buf * it_words;
+    float* s_act = s_act0 + buf * it1;
+    const int nw = NT - first, wt = tid - first;
     const int npr = (tc >> 1) + 1;
     const int n_work = npr * G;
-    int jr = tid / G, gl = tid - jr * G;
-    const int qG = NT / G, rG = NT - qG * G;
-    for (int iw = tid; iw < n_work; iw += NT) {
+    int jr = wt / G, gl = wt - jr * G;
+    const int qG = nw / G, rG = nw - qG * G;
+    for (int iw = wt; iw < n_work; iw += nw) {
       const int pr = s_pair[gl], s = pr & 255, bl = pr >> 8;
       const int b = (int)b_first + bl;
       const int64_t genv = a.env_offset + b;
@@ -334,7 +342,17 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
       jr += qG; gl += rG;
       if (gl >= G) { gl -= G; ++jr; }
     }
-    TICK(1); lds_barrier(); TICK(2);
+  };
+
+  phase1(0, a.T < TC ? a.T : TC, 0, 0);
+  TICK(1); lds_barrier(); TICK(2);
+  int buf = 0;
+  for (int t0 = 0; t0 < a.T; t0 += TC, buf ^= 1) {
+    const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
+    const int n_items = tc * G;
+    int* s_it = s_it0 + buf * it_words;
+    const float* s_act = s_act0 + buf * it1;
+    const int t1 = t0 + TC, tc1 = (a.T - t1 < TC) ? a.T - t1 : TC;     // next chunk
     // ---- phase 2: the stock recurrence, one lane per pair ---------------------------------------
     if (tid < G) {
       // A lone wave issues about one instruction every 4-5 cycles, so this phase costs
@@ -376,72 +394,67 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 4) void phx_sc_rollout_kernel(
       step += tc;
       if (tend >= 0 && tend < tc) step -= a.num_steps;
     }
-    TICK(3); lds_barrier(); TICK(4);
-    // ---- phase 3a: observations / rewards / flags into the tiles ------------------------------------
-    int tl = tid / G; gl = tid - tl * G;
-    for (int i = tid; i < n_items; i += NT) {
-      const int pr = s_pair[gl], s = pr & 255;
-      const int stock = s_it[3 * i], D = s_it[3 * i + 1], sales = s_it[3 * i + 2];
+    TICK(3);
+    // ---- phase 1 of the NEXT chunk, overlapped with the recurrence above -------------------------
+    if (t1 < a.T) phase1(t1, tc1, buf ^ 1, p1_first);
+    TICK(1); lds_barrier(); TICK(4);
+    // ---- phase 3: observations / rewards / flags straight to HBM ------------------------------------
+    // WIDE: a work unit is 4 consecutive pairs of one tile row: 12 observation floats, 4 rewards,
+    // 4 actions and 4 + 4 flag bytes, i.e. whole 16-byte (4-byte for the flags) segments of the
+    // [T][B][S] arrays, computed in registers from the {stock, D, sales} tile and written with
+    // dwordx4 stores -- no staging of the outputs in LDS and no second pass.
+    const int64_t row0 = (int64_t)t0 * total + g_base;           // element offset of tile row 0
+    const int64_t rstride = total;
+    auto item_out = [&](int stock, int D, int sales, int s, float* ob, float& rew) {
       const int missed = (s_cptr[s + 1] > s_cptr[s]) ? D - sales : 0;
       // observation / reward from the host-built tables when the operands are in their usual
       // range; otherwise (negative stock from negative requests, ...) the formulas themselves:
       // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
       const float norm = (float)s_norm[s];
       const bool in100 = (unsigned)stock <= 100u;
-      float* of = (float*)s_it + 3 * i;
-      of[0] = in100 ? s_tab[in100 ? stock : 0] : (float)stock / (float)PHX_SHOP_MAX_STOCK;
+      ob[0] = in100 ? s_tab[in100 ? stock : 0] : (float)stock / (float)PHX_SHOP_MAX_STOCK;
       const bool ins = (unsigned)sales < (unsigned)a.n_quot, inm = (unsigned)missed < (unsigned)a.n_quot;
-      of[1] = ins ? s_tabn[ins ? sales : 0] : (float)sales / norm;
-      of[2] = inm ? s_tabn[inm ? missed : 0] : (float)missed / norm;
+      ob[1] = ins ? s_tabn[ins ? sales : 0] : (float)sales / norm;
+      ob[2] = inm ? s_tabn[inm ? missed : 0] : (float)missed / norm;
       // reward = sales - 0.1 * stock in f64 (supply_chain.py:147), rounded once to the trajectory's f32
-      s_rew[i] = in100 ? (float)__dsub_rn((double)sales, s_pen[in100 ? stock : 0]) : (float)shop_reward(sales, stock);
-      s_trunc[i] = (uint8_t)(tl == s_tend[pr >> 8]);               // truncations["__all__"], env.py:312-318
-      tl += qG; gl += rG;
-      if (gl >= G) { gl -= G; ++tl; }
-    }
-    TICK(5); lds_barrier();
-    // ---- phase 3b: tiles -> HBM ---------------------------------------------------------------------
-    const int64_t row0 = (int64_t)t0 * total + g_base;           // element offset of tile row 0
-    const int64_t rstride = total;
+      rew = in100 ? (float)__dsub_rn((double)sales, s_pen[in100 ? stock : 0]) : (float)shop_reward(sales, stock);
+    };
     if (WIDE) {
-      const int nco = (G * 3) >> 2, ncf = G >> 2;                 // 16-byte chunks per row
-      for (int idx = tid; idx < tc * nco; idx += NT) {
-        const int r = (int)__umulhi((uint32_t)idx, a.mO);
-        const int c = idx - r * nco;
-        *(uint4*)(io.obs + (row0 + (int64_t)r * rstride) * 3 + c * 4) = *(const uint4*)(s_it + r * G * 3 + c * 4);
-      }
-      for (int idx = tid; idx < tc * ncf; idx += NT) {
-        const int r = (int)__umulhi((uint32_t)idx, a.mF);
-        const int c = idx - r * ncf;
-        const int64_t o = row0 + (int64_t)r * rstride + c * 4;
-        *(uint4*)(io.reward + o) = *(const uint4*)(s_rew + r * G + c * 4);
-        *(uint4*)(io.action_out + o) = *(const uint4*)(s_act + r * G + c * 4);
+      const int G4 = G >> 2;
+      for (int u = tid; u < tc * G4; u += NT) {
+        const int r = (int)__umulhi((uint32_t)u, a.mF);          // u / G4
+        const int c4 = u - r * G4, gl0 = c4 << 2, i0 = r * G + gl0;
+        const uint4 v0 = *(const uint4*)(s_it + 3 * i0), v1 = *(const uint4*)(s_it + 3 * i0 + 4), v2 = *(const uint4*)(s_it + 3 * i0 + 8);
+        const uint2 pp = *(const uint2*)(s_pair + gl0);
+        const int p0 = pp.x & 0xffff, p1 = pp.x >> 16, p2 = pp.y & 0xffff, p3 = pp.y >> 16;
+        float o[12], rw[4];
+        item_out((int)v0.x, (int)v0.y, (int)v0.z, p0 & 255, o + 0, rw[0]);
+        item_out((int)v0.w, (int)v1.x, (int)v1.y, p1 & 255, o + 3, rw[1]);
+        item_out((int)v1.z, (int)v1.w, (int)v2.x, p2 & 255, o + 6, rw[2]);
+        item_out((int)v2.y, (int)v2.z, (int)v2.w, p3 & 255, o + 9, rw[3]);
+        const uint32_t tr = (uint32_t)(r == s_tend[p0 >> 8]) | ((uint32_t)(r == s_tend[p1 >> 8]) << 8) |
+                            ((uint32_t)(r == s_tend[p2 >> 8]) << 16) | ((uint32_t)(r == s_tend[p3 >> 8]) << 24);   // truncations["__all__"], env.py:312-318
+        const int64_t e0 = row0 + (int64_t)r * rstride + gl0;
+        float4* po = (float4*)(io.obs + e0 * 3);
+        po[0] = make_float4(o[0], o[1], o[2], o[3]); po[1] = make_float4(o[4], o[5], o[6], o[7]); po[2] = make_float4(o[8], o[9], o[10], o[11]);
+        *(float4*)(io.reward + e0) = make_float4(rw[0], rw[1], rw[2], rw[3]);
+        *(float4*)(io.action_out + e0) = *(const float4*)(s_act + i0);
+        *(uint32_t*)(io.truncated + e0) = tr;
+        *(uint32_t*)(io.terminated + e0) = 0u;
       }
     } else {
-      for (int i = tid; i < n_items * 3; i += NT) {
-        const int r = i / (G * 3), c = i - r * G * 3;
-        io.obs[(row0 + (int64_t)r * rstride) * 3 + c] = ((const float*)s_it)[i];
-      }
+      int tl = tid / G, gl = tid - tl * G;
+      const int qG = NT / G, rG = NT - qG * G;
       for (int i = tid; i < n_items; i += NT) {
-        const int r = i / G, c = i - r * G;
-        const int64_t o = row0 + (int64_t)r * rstride + c;
-        io.reward[o] = s_rew[i]; io.action_out[o] = s_act[i];
-      }
-    }
-    if (WIDE) {
-      const int ncu = G >> 2;                                     // 4-byte chunks per row
-      for (int idx = tid; idx < tc * ncu; idx += NT) {
-        const int r = (int)__umulhi((uint32_t)idx, a.mU);
-        const int c = idx - r * ncu;
-        const int64_t o = row0 + (int64_t)r * rstride + c * 4;
-        *(uint32_t*)(io.truncated + o) = *(const uint32_t*)(s_trunc + r * G + c * 4);
-        *(uint32_t*)(io.terminated + o) = 0u;
-      }
-    } else {
-      for (int i = tid; i < n_items; i += NT) {
-        const int r = i / G, c = i - r * G;
-        const int64_t o = row0 + (int64_t)r * rstride + c;
-        io.truncated[o] = s_trunc[i]; io.terminated[o] = 0;
+        const int pr = s_pair[gl];
+        float o[3], rw;
+        item_out(s_it[3 * i], s_it[3 * i + 1], s_it[3 * i + 2], pr & 255, o, rw);
+        const int64_t e0 = row0 + (int64_t)tl * rstride + gl;
+        io.obs[e0 * 3] = o[0]; io.obs[e0 * 3 + 1] = o[1]; io.obs[e0 * 3 + 2] = o[2];
+        io.reward[e0] = rw; io.action_out[e0] = s_act[i];
+        io.truncated[e0] = (uint8_t)(tl == s_tend[pr >> 8]); io.terminated[e0] = 0;
+        tl += qG; gl += rG;
+        if (gl >= G) { gl -= G; ++tl; }
       }
     }
     TICK(6); lds_barrier(); TICK(7);
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   float tobs = typed ? (float)(tw / tnorm) : 0.f;
   uint32_t episode = sp.n_samplers > 0 ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
   int n_resets = 0;
+  RngPairCache rc_rng; rc_rng.q = 0xffffffffu;
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t o = (int64_t)t * total + g;
@@ -528,16 +542,16 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     const bool has_action = (fl & 1) != 0, any_order = (fl & 2) != 0;
     const uint8_t* cact = sp.shop_cust_act + (int64_t)stage * sp.n_exo;
     int D = 0; uint32_t w3 = 0;
+    const bool need_orders = !io.exo && any_order;
+    if (need_orders || !io.actions) {                      // one Philox block per two ticks
+      rng_pair_block(rc_rng, sp.seed, genv, tick, s);
+      w3 = (tick & 1u) ? rc_rng.w[3] : rc_rng.w[1];
+    }
     if (io.exo) {
       const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
       if (any_order) for (int k = c_lo; k < c_hi; ++k) if (cact[k]) D += row[sp.shop_cust_exo[k]];
-      if (!io.actions) rng_shop_order_sum(sp.seed, genv, tick, s, 0, &w3);
-    } else if (fl & 4) {
-      D = rng_shop_order_sum(sp.seed, genv, tick, s, K, &w3);
     } else if (any_order) {
-      D = rng_shop_orders(sp.seed, genv, tick, s, K, cact + c_lo, -1, &w3);
-    } else if (!io.actions) {
-      rng_shop_order_sum(sp.seed, genv, tick, s, 0, &w3);
+      D = rng_orders_from_block(rc_rng.w, sp.seed, genv, tick, s, K, (fl & 4) ? nullptr : cact + c_lo);
     }
     const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
     sc_shop_step(st, has_action, action, any_order, D);
@@ -622,8 +636,8 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
 }
 
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
-  // ~64 pairs per block (one wave in the sequential phase), TC steps so that the item table
-  // stays around 36 KB; 1024-thread blocks put 16 time rows in flight per block
+  // ~32..64 pairs per block (one wave in the sequential phase), TC steps so that the two item
+  // tiles stay around 34 KB
   RollArgs a;
   a.B = sp.B; a.S = sp.S; a.n_exo = sp.n_exo; a.num_steps = sp.num_steps; a.T = io.T;
   a.seed = sp.seed; a.env_offset = sp.env_offset;
@@ -641,22 +655,28 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
   a.io = io;
-  // whole envs per block: a multiple of 4 (8 when possible) so that G = epb * S makes every tile
-  // row a 16-byte multiple; G around 64..128 pairs; B = 4096, S = 9 -> epb 8, G 72, 512 blocks
+  // whole envs per block: a multiple of 4 so that G = epb * S makes every tile row a 16-byte
+  // multiple; B = 4096, S = 9 -> epb 4, G 36, 1024 blocks of 256 threads
   int epb = 0;
-  for (int cand = 8; cand * sp.S <= 256 && cand <= sp.B; cand += 8) if (cand * sp.S >= 64) { epb = cand; break; }
-  if (!epb) for (int cand = 4; cand * sp.S <= 256 && cand <= sp.B; cand += 4) if (cand * sp.S >= 64) { epb = cand; break; }
-  if (!epb) { epb = 256 / sp.S; if (epb > 8) epb &= ~7; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B; }
+  static const int force_epb = getenv("PHX_ROLLOUT_EPB") ? atoi(getenv("PHX_ROLLOUT_EPB")) : 0;
+  if (force_epb > 0 && force_epb * sp.S <= 256 && force_epb <= sp.B) epb = force_epb;
+  // measured best on SC64 and SC256 up to ~100 k pairs: 256-thread blocks owning ~32..64 pairs;
+  // beyond that (the chip is full either way) 512-thread blocks with twice the pairs win by ~5 %
+  const bool big = (int64_t)sp.B * sp.S >= 131072 && 8 * sp.S <= 256;
+  if (!epb && big) epb = 8;
+  if (!epb) for (int cand = 4; cand * sp.S <= 256 && cand <= sp.B; cand += 4) if (cand * sp.S >= 32) { epb = cand; break; }
+  if (!epb) { epb = 256 / sp.S; if (epb > 4) epb &= ~3; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B; }
   const int G = epb * sp.S;
   auto magic = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
-  static const int ldskb = getenv("PHX_ROLLOUT_LDSKB") ? atoi(getenv("PHX_ROLLOUT_LDSKB")) : 40;
-  int TC = (ldskb * 1024) / (G * 21); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;
+  static const int ldskb_env = getenv("PHX_ROLLOUT_LDSKB") ? atoi(getenv("PHX_ROLLOUT_LDSKB")) : 0;
+  const int ldskb = ldskb_env ? ldskb_env : (big ? 44 : 34);
+  int TC = (ldskb * 1024) / (G * 32); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;   // 32 B of LDS per item (double-buffered tiles)
   while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
   if (TC > 8) TC &= ~7;                                          // groups of 8 steps in the recurrence phase
   if (sp.num_steps >= 1 && TC > sp.num_steps) TC = sp.num_steps; // at most one episode end per chunk
   a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 4);
   const int items = TC * G;
-  const size_t lds = (size_t)((items * 3 + 3) & ~3) * 4 + (size_t)((items + 3) & ~3) * 8 + (size_t)((items + 15) & ~15) +
+  const size_t lds = (size_t)((items * 3 + 3) & ~3) * 4 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
                      (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
                      (size_t)((sp.S + 3) & ~3) * 4 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
   a.epb = epb; a.TC = TC;
@@ -664,7 +684,8 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   const bool replay = io.actions != nullptr || io.exo != nullptr;
   const int64_t total = (int64_t)sp.B * sp.S;
   const bool wide = (sp.B % epb == 0) && (G % 4 == 0) && (total % 4 == 0);
-  static const int nt = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 512;
+  static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
+  const int nt = nt_env ? nt_env : (big ? 512 : 256);
 #define PHX_LAUNCH_ROLLOUT(NT_)                                                                              \
   do {                                                                                                        \
     if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, true>), grid, dim3(NT_), lds, st, a);  \
@@ -672,7 +693,8 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
     else if (!replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, false>), grid, dim3(NT_), lds, st, a);    \
     else hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, true, false>), grid, dim3(NT_), lds, st, a);                  \
   } while (0)
-  if (nt == 1024) PHX_LAUNCH_ROLLOUT(1024); else if (nt == 256) PHX_LAUNCH_ROLLOUT(256); else PHX_LAUNCH_ROLLOUT(512);
+  if (nt == 1024) PHX_LAUNCH_ROLLOUT(1024); else if (nt == 768) PHX_LAUNCH_ROLLOUT(768); else if (nt == 384) PHX_LAUNCH_ROLLOUT(384);
+  else if (nt == 512) PHX_LAUNCH_ROLLOUT(512); else PHX_LAUNCH_ROLLOUT(256);
 #undef PHX_LAUNCH_ROLLOUT
   return hipGetLastError();
 }
