@@ -151,6 +151,13 @@ typedef struct phx_spec {
   const double*  sampler_param; /* [n_samplers][4] low, high, clip_low, clip_high (NaN = None) */
   const int32_t* type_src;      /* [A] or NULL: sampler column feeding the agent's type field,
                                    PHX_TYPE_CONST or PHX_TYPE_NONE                           */
+  /* StochasticNetwork (network.py:340-453): row_ptr/col then describe the BASE connections
+   * (network.py:383-394, neighbours in base-connection order); every reset keeps connection i
+   * of each env with probability conn_rate[i] (resample_connectivity, network.py:438-452); the
+   * surviving subset is the per-env state field "net.conn_on".  n_conn == 0: static Network.  */
+  int32_t n_conn;
+  const double*  conn_rate;     /* [n_conn]                                                  */
+  const int32_t* col_conn;      /* [nnz] base connection of each CSR entry (both directions)  */
 } phx_spec;
 
 typedef struct phx_env phx_env;   /* opaque */
@@ -240,9 +247,12 @@ int  phx_sync_fields(phx_env* env, void* stream);
  * with reset_mask[b] != 0 (NULL = all).  Writes the initial observations.
  * sampler_values: device f64 [B][n_samplers], the values `sampler.sample()` returned for each
  * env (env.py:211-212), or NULL: UNIFORM samplers are then drawn from the device Philox
- * stream (ctr = (env, episode, 0x80000000 | column)), HOST samplers keep their value.      */
-int  phx_reset(phx_env* env, const uint8_t* reset_mask, const double* sampler_values, float* obs,
-               uint8_t* obs_valid, void* stream);
+ * stream (ctr = (env, episode, 0x80000000 | column)), HOST samplers keep their value.
+ * conn_on: device u8 [B][n_conn], the outcome of `np.random.random() < rate` per base connection
+ * and env (network.py:444-447), or NULL: drawn on the device (ctr = (env, episode,
+ * 0x40000000 | connection / 2), u < rate).                                                  */
+int  phx_reset(phx_env* env, const uint8_t* reset_mask, const double* sampler_values,
+               const uint8_t* conn_on, float* obs, uint8_t* obs_valid, void* stream);
 
 /* one PhantomEnv.step for all B envs */
 int  phx_step(phx_env* env, const phx_step_io* io, void* stream);

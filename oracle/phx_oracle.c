@@ -61,6 +61,7 @@ typedef struct {
   int32_t stage, prev_stage;   /* fsm.py:126-127 */
   uint32_t tick;          /* device-RNG draw counter (never reset) */
   double* sampler;        /* [n_samplers] Sampler._value of every sampler of env._samplers  samplers.py:60-66 */
+  uint8_t* conn_on;       /* [n_conn] StochasticNetwork: base connection is in self.graph  network.py:438-447 */
   int32_t episode;        /* number of env.reset() calls so far (device-RNG counter of the samplers) */
   int32_t clock;          /* handle_message invocation counter (stands in for time.time()) */
   uint8_t* term;          /* [S] PhantomEnv._terminations env.py:71 */
@@ -119,9 +120,13 @@ static void payload_types(int type, int* sender_kind, int* receiver_kind, int* d
   }
 }
 
-static int has_edge(const phxo_env* E, int u, int v) {        /* network.py:224-231 */
+/* CSR entry k is an edge of this env's graph (always, for a static Network) */
+static int edge_on(const phxo_env* E, const oenv* e, int k) {
+  return E->s.n_conn == 0 || e->conn_on[E->s.col_conn[k]];
+}
+static int has_edge(const phxo_env* E, const oenv* e, int u, int v) {   /* network.py:224-231 */
   for (int k = E->s.row_ptr[u]; k < E->s.row_ptr[u + 1]; ++k)
-    if (E->s.col[k] == v) return 1;
+    if (E->s.col[k] == v && edge_on(E, e, k)) return 1;
   return 0;
 }
 static int nbr_slot(const phxo_env* E, int u, int v) {        /* index of v in ctx.neighbour_ids of u */
@@ -160,7 +165,7 @@ static void resolver_push(const phxo_env* E, oenv* e, const omsg* m) {
 
 /* Network.send  network.py:233-254 (+ _enforce_payload_checks :297-331) */
 static void network_send(const phxo_env* E, oenv* e, int src, int dst, int type, omsg payload) {
-  if (!(E->s.flags & PHX_F_IGNORE_CONN_ERRORS) && !has_edge(E, src, dst)) {
+  if (!(E->s.flags & PHX_F_IGNORE_CONN_ERRORS) && !has_edge(E, e, src, dst)) {
     set_err(e, PHX_ERR_NETWORK); return;                      /* raise NetworkError :246-249 */
   }
   if (!(E->s.flags & PHX_F_NO_PAYLOAD_CHECKS)) {
@@ -256,14 +261,30 @@ double phxo_rng_uniform(uint64_t seed, int64_t genv, uint32_t episode, int j, co
   return v;
 }
 
-/* env.reset(): `for sampler in self._samplers: sampler.sample()`  env.py:211-212 */
-static void env_sample(const phxo_env* E, oenv* e, int b, const double* values) {
+/* Device draw of `np.random.random() < rate` for base connection i (network.py:444-447;
+ * build-owned definition): Philox block ctr = (env_lo, env_hi, episode, 0x40000000 | i / 2),
+ * u from words (2 (i % 2), 2 (i % 2) + 1) as above.                                          */
+int phxo_rng_connection(uint64_t seed, int64_t genv, uint32_t episode, int i, double rate) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, 0x40000000u | (uint32_t)(i >> 1)};
+  uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
+  const int h = 2 * (i & 1);
+  const double u = ((double)(w[h] >> 5) * 67108864.0 + (double)(w[h + 1] >> 6)) / 9007199254740992.0;
+  return u < rate;
+}
+
+/* env.reset(): `for sampler in self._samplers: sampler.sample()`  env.py:211-212, then
+ * network.reset() -> StochasticNetwork.resample_connectivity()      env.py:218, network.py:449-452 */
+static void env_sample(const phxo_env* E, oenv* e, int b, const double* values, const uint8_t* conn) {
   for (int j = 0; j < E->s.n_samplers; ++j) {
     if (values) e->sampler[j] = values[j];
     else if (E->s.sampler_kind[j] == PHX_SAMPLER_UNIFORM)
       e->sampler[j] = phxo_rng_uniform(E->s.seed, E->s.env_offset + b, (uint32_t)e->episode, j,
                                        E->s.sampler_param + 4 * j);
   }
+  for (int i = 0; i < E->s.n_conn; ++i)
+    e->conn_on[i] = conn ? (conn[i] != 0)
+                         : (uint8_t)phxo_rng_connection(E->s.seed, E->s.env_offset + b, (uint32_t)e->episode, i, E->s.conn_rate[i]);
   e->episode += 1;
 }
 
@@ -324,15 +345,16 @@ static void agent_act(const phxo_env* E, oenv* e, int b, int a, int has_action, 
       if (has_action) {
         st->f[0] = (double)action;                            /* self.price = float(action[0]) */
         for (int k = E->s.row_ptr[a]; k < E->s.row_ptr[a + 1]; ++k)   /* ctx.neighbour_ids order */
-          network_send(E, e, a, E->s.col[k], PHX_MSG_PRICE, mk_f(st->f[0]));
+          if (edge_on(E, e, k)) network_send(E, e, a, E->s.col[k], PHX_MSG_PRICE, mk_f(st->f[0]));
       }
       break;
     case PHX_KIND_BUYER:
       if (has_action) {
         int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
-        if (action > 0.5f && deg > 0) {
-          int j = 0;                                          /* first minimum */
-          for (int k = 1; k < deg; ++k) if (st->vec[k] < st->vec[j]) j = k;
+        int j = -1;                                           /* first minimum over the current neighbours */
+        for (int k = 0; k < deg; ++k)
+          if (edge_on(E, e, E->s.row_ptr[a] + k) && (j < 0 || st->vec[k] < st->vec[j])) j = k;
+        if (action > 0.5f && j >= 0) {
           st->i[0] = 1; st->f[0] = st->vec[j];
           network_send(E, e, a, E->s.col[E->s.row_ptr[a] + j], PHX_MSG_ORDER, mk_i(1));
         } else { st->i[0] = 0; st->f[0] = 0.0; }
@@ -456,15 +478,17 @@ static void agent_encode_obs(const phxo_env* E, const oenv* e, int a, float* o) 
       break;
     }
     case PHX_KIND_SELLER: {
-      int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
-      o[0] = (float)((double)st->i[0] / (double)deg);
+      int deg = 0;                                            /* len(ctx.neighbour_ids) */
+      for (int k = E->s.row_ptr[a]; k < E->s.row_ptr[a + 1]; ++k) deg += edge_on(E, e, k);
+      o[0] = deg ? (float)((double)st->i[0] / (double)deg) : 0.0f;
       o[1] = (float)st->f[0];
       break;
     }
     case PHX_KIND_BUYER: {
-      int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
-      double mn = st->vec[0];
-      for (int k = 1; k < deg; ++k) if (st->vec[k] < mn) mn = st->vec[k];
+      int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a], any = 0;
+      double mn = 1.0;                                        /* min(prices.values(), default=1.0) */
+      for (int k = 0; k < deg; ++k)
+        if (edge_on(E, e, E->s.row_ptr[a] + k) && (!any || st->vec[k] < mn)) { mn = st->vec[k]; any = 1; }
       o[0] = (float)mn;
       o[1] = (float)E->s.param_f[a * PHX_NPF + 0];
       break;
@@ -525,7 +549,7 @@ static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
         int clock = e->clock++;
         if (!live[receiver]) continue;                                /* :143-144 */
         const omsg* m = &proc->pool[id];
-        if (!has_edge(E, m->src, m->dst)) continue;                   /* :146-148 */
+        if (!has_edge(E, e, m->src, m->dst)) continue;                /* :146-148 */
         agent_handle_message(E, e, receiver, m, clock);               /* handle_batch agents.py:96-120 */
       }
     }
@@ -545,10 +569,10 @@ static int env_is_truncated(const phxo_env* E, const oenv* e) {
 }
 
 static void env_reset_one(const phxo_env* E, oenv* e, int b, const double* sampler_values,
-                          float* obs, uint8_t* obs_valid) {
+                          const uint8_t* conn, float* obs, uint8_t* obs_valid) {
   /* PhantomEnv.reset env.py:185-237; fsm.py:195-251; stackelberg.py:53-109 */
   e->step = 0;
-  env_sample(E, e, b, sampler_values);                                /* env.py:211-212 */
+  env_sample(E, e, b, sampler_values, conn);                          /* env.py:211-218 */
   if (E->s.env_type == PHX_ENV_FSM) e->stage = E->s.initial_stage;    /* fsm.py:217 */
   inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]); e->cur = 0; /* network.reset -> resolver.reset */
   for (int a = 0; a < E->A; ++a) agent_reset(E, e, a);                /* network.py:183-184 */
@@ -770,6 +794,8 @@ phxo_env* phxo_create(const phx_spec* sp) {
   E->s.sampler_kind = (const int32_t*)dup_arr(sp->sampler_kind, sizeof(int32_t) * sp->n_samplers);
   E->s.sampler_param = (const double*)dup_arr(sp->sampler_param, sizeof(double) * 4 * sp->n_samplers);
   E->s.type_src = (const int32_t*)dup_arr(sp->type_src, sizeof(int32_t) * A);
+  E->s.conn_rate = (const double*)dup_arr(sp->conn_rate, sizeof(double) * sp->n_conn);
+  E->s.col_conn = (const int32_t*)dup_arr(sp->col_conn, sizeof(int32_t) * (sp->n_conn ? E->nnz : 0));
   E->strat_rank = (int*)calloc(A, sizeof(int));
   E->kind_rank = (int*)calloc(A, sizeof(int));
   E->exo_rank = (int*)calloc(A, sizeof(int));
@@ -802,7 +828,8 @@ phxo_env* phxo_create(const phx_spec* sp) {
     inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]);
     e->stage = sp->initial_stage; e->prev_stage = -1;
     e->sampler = (double*)calloc(sp->n_samplers > 0 ? sp->n_samplers : 1, sizeof(double));
-    env_sample(E, e, b, NULL);                                        /* env.py:118-119 */
+    e->conn_on = (uint8_t*)calloc(sp->n_conn > 0 ? sp->n_conn : 1, 1);
+    env_sample(E, e, b, NULL, NULL);                                  /* env.py:118-119; add_connection network.py:389-391 */
     for (int a = 0; a < A; ++a) agent_reset(E, e, a);                 /* env.py:122-124 */
   }
   return E;
@@ -813,7 +840,7 @@ void phxo_destroy(phxo_env* E) {
   for (int b = 0; b < E->B; ++b) {
     oenv* e = &E->env[b];
     free(e->ag); free(e->vecpool); free(e->term); free(e->trunc); free(e->rew_cache);
-    free(e->rew_cache_valid); free(e->obs_cache); free(e->obs_cache_valid); free(e->sampler);
+    free(e->rew_cache_valid); free(e->obs_cache); free(e->obs_cache_valid); free(e->sampler); free(e->conn_on);
     for (int k = 0; k < 2; ++k) {
       free(e->box[k].pool); free(e->box[k].next); free(e->box[k].order);
       free(e->box[k].head); free(e->box[k].tail);
@@ -824,6 +851,7 @@ void phxo_destroy(phxo_env* E) {
   free((void*)E->s.kind); free((void*)E->s.param_i); free((void*)E->s.param_f);
   free((void*)E->s.row_ptr); free((void*)E->s.col);
   free((void*)E->s.sampler_kind); free((void*)E->s.sampler_param); free((void*)E->s.type_src);
+  free((void*)E->s.conn_rate); free((void*)E->s.col_conn);
   if (E->s.env_type == PHX_ENV_FSM) {
     free((void*)E->s.stage_act_ptr); free((void*)E->s.stage_act_idx);
     free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next);
@@ -837,14 +865,14 @@ int phxo_n_strategic(const phxo_env* E) { return E->S; }
 int phxo_n_exo(const phxo_env* E) { return E->n_exo; }
 
 /* ---- batch entry points ---------------------------------------------------------------------- */
-void phxo_reset(phxo_env* E, const uint8_t* mask, const double* sampler_values, float* obs,
-                uint8_t* obs_valid) {
+void phxo_reset(phxo_env* E, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_on,
+                float* obs, uint8_t* obs_valid) {
   const int S = E->S, D = E->D;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int b = 0; b < E->B; ++b) {
     if (mask && !mask[b]) continue;
     env_reset_one(E, &E->env[b], b, sampler_values ? sampler_values + (size_t)b * E->s.n_samplers : NULL,
-                  obs ? obs + (size_t)b * S * D : NULL, obs_valid ? obs_valid + (size_t)b * S : NULL);
+                  conn_on ? conn_on + (size_t)b * E->s.n_conn : NULL, obs ? obs + (size_t)b * S * D : NULL, obs_valid ? obs_valid + (size_t)b * S : NULL);
   }
 }
 
@@ -932,7 +960,7 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
       if (io->obs_valid) io->obs_valid[base + s] = u8[s];
       if (io->reward_valid) io->reward_valid[base + s] = u8[S + s];
     }
-    if (at || au) env_reset_one(E, e, b, NULL, o, u8);                /* caller's env.reset() */
+    if (at || au) env_reset_one(E, e, b, NULL, NULL, o, u8);          /* caller's env.reset() */
   }
   if (io->last_obs) memcpy(io->last_obs + (size_t)b * S * D, o, sizeof(float) * S * D);
   if (io->err) io->err[b] = e->err;
@@ -976,6 +1004,11 @@ int64_t phxo_get_i32(const phxo_env* E, const char* field, int32_t* out) {
     for (int a = 0; a < E->A; ++a)
       if (E->s.kind[a] == f->kind) out[(size_t)b * n + E->kind_rank[a]] = E->env[b].ag[a].i[f->slot];
   return (int64_t)E->B * n;
+}
+int64_t phxo_get_u8(const phxo_env* E, const char* field, uint8_t* out) {
+  if (strcmp(field, "net.conn_on")) return -1;
+  for (int b = 0; b < E->B; ++b) memcpy(out + (size_t)b * E->s.n_conn, E->env[b].conn_on, E->s.n_conn);
+  return (int64_t)E->B * E->s.n_conn;
 }
 int64_t phxo_set_i32(phxo_env* E, const char* field, const int32_t* in) {
   if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) E->env[b].tick = (uint32_t)in[b]; return E->B; }

@@ -34,8 +34,8 @@ int  phxo_n_strategic(const phxo_env* e);
 int  phxo_n_exo(const phxo_env* e);
 
 /* all pointers are HOST pointers; layouts identical to the device ABI */
-void phxo_reset(phxo_env* e, const uint8_t* reset_mask, const double* sampler_values, float* obs,
-                uint8_t* obs_valid);
+void phxo_reset(phxo_env* e, const uint8_t* reset_mask, const double* sampler_values,
+                const uint8_t* conn_on, float* obs, uint8_t* obs_valid);
 void phxo_step(phxo_env* e, const phx_step_io* io);
 void phxo_inject(phxo_env* e, const phx_msg_rec* msgs, int n);
 void phxo_resolve(phxo_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count);
@@ -53,6 +53,8 @@ void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out);
 float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int strat_rank);
 double phxo_rng_uniform(uint64_t seed, int64_t genv, uint32_t episode, int column, const double prm[4]);
+int phxo_rng_connection(uint64_t seed, int64_t genv, uint32_t episode, int conn, double rate);
+int64_t phxo_get_u8(const phxo_env* e, const char* field, uint8_t* out);
 
 #ifdef __cplusplus
 }

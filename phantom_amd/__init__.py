@@ -15,7 +15,7 @@ from .fsm import (FiniteStateMachineEnv, FSMRuntimeError, FSMStage, FSMValidatio
 from .message import (AgentID, CashMessage, HalveMessage, Message, MsgPayload, Order,
                       OrderRequest, OrderResponse, Price, Request, Response, StockRequest,
                       StockResponse, msg_payload)
-from .network import Network, NetworkError
+from .network import Network, NetworkError, StochasticNetwork
 from .resolvers import BatchResolver, Resolver
 from .spec import EnvSpec, compile_spec
 from .stackelberg import StackelbergEnv

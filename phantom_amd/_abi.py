@@ -49,6 +49,7 @@ class PhxSpec(C.Structure):
         ("seed", C.c_uint64), ("env_offset", C.c_int64),
         ("n_samplers", C.c_int32), ("sampler_kind", C.c_void_p), ("sampler_param", C.c_void_p),
         ("type_src", C.c_void_p),
+        ("n_conn", C.c_int32), ("conn_rate", C.c_void_p), ("col_conn", C.c_void_p),
     ]
 
 
@@ -127,7 +128,7 @@ def load_library():
     lib.phx_sync_fields.restype = i32
     lib.phx_sync_fields.argtypes = [vp, vp]
     lib.phx_reset.restype = i32
-    lib.phx_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.phx_reset.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.phx_step.restype = i32
     lib.phx_step.argtypes = [vp, C.POINTER(PhxStepIO), vp]
     lib.phx_inject.restype = i32

@@ -15,7 +15,7 @@
 
 size_t phx_generic_queue_bytes(int A, int Q, int scan_cap);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
-hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, float* obs, uint8_t* obs_valid, hipStream_t st);
+hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
@@ -49,6 +49,7 @@ struct Derived {
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
   bool sc_static = false, stk_static = false;
+  bool dynamic_graph = false;      // StochasticNetwork with some rate < 1: edges differ per env
   std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
   std::vector<uint8_t> shop_cust_act;
   std::vector<float> sc_tab;
@@ -81,6 +82,15 @@ static int derive(const phx_spec* sp, Derived& d) {
       return fail(PHX_EINVAL, "sampler %d: high < low", j);                       // samplers.py:134
     d.device_sampling = d.device_sampling && sp->sampler_kind[j] == PHX_SAMPLER_UNIFORM;
   }
+  if (sp->n_conn < 0 || (sp->n_conn > 0 && (!sp->conn_rate || !sp->col_conn))) return fail(PHX_EINVAL, "StochasticNetwork tables missing");
+  bool all_on = true;
+  for (int i = 0; i < sp->n_conn; ++i) {
+    if (!(sp->conn_rate[i] >= 0.0)) return fail(PHX_EINVAL, "connection %d: bad rate", i);
+    all_on = all_on && sp->conn_rate[i] >= 1.0;
+  }
+  for (int k = 0; k < (sp->n_conn > 0 ? sp->row_ptr[A] : 0); ++k)
+    if (sp->col_conn[k] < 0 || sp->col_conn[k] >= sp->n_conn) return fail(PHX_EINVAL, "col_conn out of range");
+  d.dynamic_graph = sp->n_conn > 0 && !all_on;
   d.type_src.assign(A, PHX_TYPE_NONE);
   for (int a = 0; a < A && sp->type_src; ++a) {
     const int src = sp->type_src[a];
@@ -167,7 +177,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 &&
             d.kind_count[PHX_KIND_SHOP] <= 256 &&
             !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
-            (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS);
+            (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS) && !d.dynamic_graph;
   auto edge = [&](int u, int v) { for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k) if (sp->col[k] == v) return true; return false; };
   for (int a = 0; a < A && sc; ++a) {
     const int k = sp->kind[a]; const int32_t* pi = sp->param_i + a * PHX_NPI;
@@ -179,7 +189,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   // ---- static Stackelberg-market schedule? (fused kernel) ----------------------------------------
   bool stk = sp->env_type == PHX_ENV_STACKELBERG && d.kind_count[PHX_KIND_SELLER] > 0 &&
              !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS)) && sp->trace_cap == 0 &&
-             (sp->round_limit < 0 || sp->round_limit >= 1);
+             (sp->round_limit < 0 || sp->round_limit >= 1) && !d.dynamic_graph;
   for (int a = 0; a < A && stk; ++a) {
     const int k = sp->kind[a];
     if (k != PHX_KIND_SELLER && k != PHX_KIND_BUYER) { stk = false; break; }
@@ -263,7 +273,8 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_ENV_TERM, "env.term", 2, 0, B, S, 1, 0}, {F_ENV_TRUNC, "env.trunc", 2, 0, B, S, 1, 0},
     {F_ENV_REW_CACHE, "env.rew_cache", 1, 0, B, S, 1, 0}, {F_ENV_REW_CACHE_VALID, "env.rew_cache_valid", 2, 0, B, S, 1, 0},
     {F_ENV_OBS_CACHE, "env.obs_cache", 3, 0, B, S, d.D, 0}, {F_ENV_OBS_CACHE_VALID, "env.obs_cache_valid", 2, 0, B, S, 1, 0},
-    {F_ENV_SAMPLER, "env.sampler", 1, 0, B, sp->n_samplers, 1, 0}, {F_ENV_EPISODE, "env.episode", 0, 0, B, sp->n_samplers > 0 ? 1 : 0, 1, 0},
+    {F_ENV_SAMPLER, "env.sampler", 1, 0, B, sp->n_samplers, 1, 0}, {F_ENV_EPISODE, "env.episode", 0, 0, B, (sp->n_samplers > 0 || sp->n_conn > 0) ? 1 : 0, 1, 0},
+    {F_NET_CONN_ON, "net.conn_on", 2, 0, B, sp->n_conn, 1, 0},
     {F_SHOP_STOCK, "shop.stock", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_SALES, "shop.sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_MISSED, "shop.missed_sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
@@ -383,6 +394,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());
   UP(shop_cust_act, der.shop_cust_act.data(), der.shop_cust_act.size());
   UP(sc_tab, der.sc_tab.data(), der.sc_tab.size());
+  UP(conn_rate, spec->conn_rate, spec->n_conn); UP(col_conn, spec->col_conn, spec->n_conn > 0 ? der.nnz : 0);
+  d.n_conn = spec->n_conn;
   UP(stk_nbr, der.stk_nbr.data(), der.stk_nbr.size());
   UP(stk_rec, der.stk_rec.data(), der.stk_rec.size()); UP(stk_flags, der.stk_flags.data(), der.stk_flags.size());
   UP(sampler_kind, spec->sampler_kind, spec->n_samplers); UP(sampler_param, spec->sampler_param, 4 * spec->n_samplers);
@@ -409,7 +422,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     (void)hipMemcpy(d.f[F_ENV_STAGE], st.data(), st.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d.f[F_ENV_PREV_STAGE], pv.data(), pv.size() * 4, hipMemcpyHostToDevice);
   }
-  he = phx_launch_reset(d, nullptr, nullptr, nullptr, nullptr, 0);   // also the constructor's first sampler draw, env.py:118-119
+  he = phx_launch_reset(d, nullptr, nullptr, nullptr, nullptr, nullptr, 0);   // also the constructor's first draws, env.py:118-119, network.py:389
   if (he == hipSuccess) he = hipDeviceSynchronize();
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "initial reset: %s", hipGetErrorString(he)); }
   *out = e;
@@ -454,12 +467,13 @@ int phx_sync_fields(phx_env* e, void* stream) {
   return PHX_OK;
 }
 
-int phx_reset(phx_env* e, const uint8_t* reset_mask, const double* sampler_values, float* obs, uint8_t* obs_valid,
-              void* stream) {
+int phx_reset(phx_env* e, const uint8_t* reset_mask, const double* sampler_values, const uint8_t* conn_on, float* obs,
+              uint8_t* obs_valid, void* stream) {
   if (!e) return fail(PHX_EINVAL, "null env");
   if (sampler_values && e->d.n_samplers == 0) return fail(PHX_EINVAL, "sampler_values given but the spec has no samplers");
+  if (conn_on && e->d.n_conn == 0) return fail(PHX_EINVAL, "conn_on given but the spec is not a StochasticNetwork");
   HIPCHK(use_device(e));
-  HIPCHK(phx_launch_reset(e->d, reset_mask, sampler_values, obs, obs_valid, (hipStream_t)stream));
+  HIPCHK(phx_launch_reset(e->d, reset_mask, sampler_values, conn_on, obs, obs_valid, (hipStream_t)stream));
   return PHX_OK;
 }
 

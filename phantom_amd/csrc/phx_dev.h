@@ -25,7 +25,7 @@ static_assert(sizeof(DevMsg) == 16, "DevMsg must be 16 bytes");
 enum {
   F_ENV_STEP = 0, F_ENV_STAGE, F_ENV_PREV_STAGE, F_ENV_TICK, F_ENV_CLOCK,
   F_ENV_TERM, F_ENV_TRUNC, F_ENV_REW_CACHE, F_ENV_REW_CACHE_VALID, F_ENV_OBS_CACHE,
-  F_ENV_OBS_CACHE_VALID, F_ENV_SAMPLER, F_ENV_EPISODE,
+  F_ENV_OBS_CACHE_VALID, F_ENV_SAMPLER, F_ENV_EPISODE, F_NET_CONN_ON,
   F_SHOP_STOCK, F_SHOP_SALES, F_SHOP_MISSED, F_SHOP_DELIVERED,
   F_SELLER_PRICE, F_SELLER_REVENUE, F_SELLER_TX, F_SELLER_POSTED,
   F_BUYER_PRICES, F_BUYER_PAID, F_BUYER_BOUGHT,
@@ -86,6 +86,10 @@ struct DevSpec {
   const uint16_t* stk_nbr;       // [buyer_dmax][nBuyers] seller rank of neighbour k, 0xFFFF = none
   const uint32_t* stk_rec;       // [A] kind | deg << 8 | kind_rank << 16
   const uint8_t*  stk_flags;     // [2][A] 1 acts, 2 observes, 4 rewarded in list 0 (leaders' step) / 1
+  // StochasticNetwork (network.py:340-453): per-env on/off byte per base connection
+  int32_t n_conn;
+  const double*  conn_rate;      // [n_conn]
+  const int32_t* col_conn;       // [nnz] base connection of each CSR entry
   // Supertypes / Samplers (supertype.py:16-30, utils/samplers.py, env.py:211-216)
   int32_t n_samplers;            // columns of env.sampler
   int32_t any_typed;             // some shop consumes a type field (obs dim 4, weighted penalty)
@@ -125,9 +129,16 @@ struct Topo {
   const int32_t* kind_rank;
   const int32_t* exo_rank;
   const int32_t* buyer_off;
+  const int32_t* col_conn;       // StochasticNetwork: base connection of each CSR entry, else NULL
+  const uint8_t* conn_on;        // this env's row of net.conn_on (set by the kernel), else NULL
 };
+// CSR entry k is an edge of this env's graph (always, for a static Network)
+__device__ __forceinline__ bool edge_on(const Topo& tp, int k) {
+  return tp.conn_on == nullptr || tp.conn_on[tp.col_conn[k]] != 0;
+}
 __device__ __forceinline__ Topo topo_global(const DevSpec& sp) {
   Topo t;
+  t.col_conn = sp.col_conn; t.conn_on = nullptr;
   t.kind = sp.kind; t.param_i = sp.param_i; t.param_f = sp.param_f; t.row_ptr = sp.row_ptr; t.col = sp.col;
   t.strat_rank = sp.strat_rank; t.kind_rank = sp.kind_rank; t.exo_rank = sp.exo_rank; t.buyer_off = sp.buyer_off;
   return t;
@@ -155,9 +166,17 @@ __device__ __forceinline__ int dev_nbr_slot(const DevSpec& sp, const Topo& tp, i
   return -1;
 }
 __device__ __forceinline__ bool dev_has_edge(const DevSpec& sp, const Topo& tp, int u, int v) {   // network.py:224-231
-  return dev_nbr_slot(sp, tp, u, v) >= 0;
+  const int lo = tp.row_ptr[u], hi = tp.row_ptr[u + 1];
+  for (int k = lo; k < hi; ++k)
+    if (tp.col[k] == v && edge_on(tp, k)) return true;
+  return false;
 }
-
+// topo_global + this env's connectivity row
+__device__ __forceinline__ Topo topo_env(const DevSpec& sp, int b) {
+  Topo t = topo_global(sp);
+  if (sp.n_conn > 0) t.conn_on = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
+  return t;
+}
 // Network.send checks (network.py:246-252, 297-331); returns PHX_ERR_* (0 = deliverable)
 __device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp, int src, int dst, int type) {
   if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, tp, src, dst)) return PHX_ERR_NETWORK;
@@ -301,6 +320,18 @@ __device__ __forceinline__ double rng_uniform(uint64_t seed, int64_t genv, uint3
   if (prm[3] == prm[3] && v > prm[3]) v = prm[3];
   return v;
 }
+// `np.random.random() < rate` for base connection i at the env's `episode`-th reset (definition
+// restated in oracle/phx_oracle.c: phxo_rng_connection)
+__device__ __forceinline__ bool rng_connection(uint64_t seed, int64_t genv, uint32_t episode, int i, double rate) {
+  uint32_t w[4];
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), episode, 0x40000000u | (uint32_t)(i >> 1),
+                (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const uint32_t wa = (i & 1) ? w[2] : w[0], wb = (i & 1) ? w[3] : w[1];
+  const double u = __dmul_rn(__dadd_rn(__dmul_rn((double)(wa >> 5), 67108864.0), (double)(wb >> 6)),
+                             1.0 / 9007199254740992.0);
+  return u < rate;
+}
+
 // env.reset(): `for sampler in self._samplers: sampler.sample()` (env.py:211-212) for column j
 __device__ __forceinline__ double dev_sample_column(const DevSpec& sp, int b, int j, uint32_t episode,
                                                     const double* values, double current) {
@@ -405,16 +436,18 @@ __device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, const Topo& tp
         o[3] = (float)(shop_type_value(sp, b, r.kr) / sp.shop_type_prm[2 * r.kr + 1]);
       break;
     case PHX_KIND_SELLER: {
-      const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
-      o[0] = (float)((double)fld<int32_t>(sp, F_SELLER_TX)[r.base] / (double)deg);
+      int deg = 0;                                             // len(ctx.neighbour_ids)
+      for (int k = tp.row_ptr[a]; k < tp.row_ptr[a + 1]; ++k) deg += edge_on(tp, k) ? 1 : 0;
+      o[0] = deg ? (float)((double)fld<int32_t>(sp, F_SELLER_TX)[r.base] / (double)deg) : 0.f;
       o[1] = (float)fld<double>(sp, F_SELLER_PRICE)[r.base];
       break;
     }
     case PHX_KIND_BUYER: {
-      const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
+      const int lo = tp.row_ptr[a], deg = tp.row_ptr[a + 1] - lo;
       const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + tp.buyer_off[a];
-      double mn = pr[0];
-      for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; mn = v < mn ? v : mn; }
+      double mn = 1.0; bool any = false;                       // min(prices.values(), default=1.0)
+      for (int k = 0; k < deg; ++k)
+        if (edge_on(tp, lo + k)) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (!any || v < mn) { mn = v; any = true; } }
       o[0] = (float)mn;
       o[1] = (float)tp.param_f[a * PHX_NPF];
       break;

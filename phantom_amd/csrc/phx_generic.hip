@@ -68,8 +68,18 @@ __device__ __forceinline__ int act_count(const DevSpec& sp, const Topo& tp, int 
   switch (tp.kind[a]) {
     case PHX_KIND_SHOP: return has_action ? 1 : 0;
     case PHX_KIND_CUSTOMER: return 1;
-    case PHX_KIND_SELLER: return has_action ? tp.row_ptr[a + 1] - tp.row_ptr[a] : 0;
-    case PHX_KIND_BUYER: return (has_action && action > 0.5f && tp.row_ptr[a + 1] > tp.row_ptr[a]) ? 1 : 0;
+    case PHX_KIND_SELLER: {
+      if (!has_action) return 0;
+      if (tp.conn_on == nullptr) return tp.row_ptr[a + 1] - tp.row_ptr[a];
+      int n = 0;
+      for (int k = tp.row_ptr[a]; k < tp.row_ptr[a + 1]; ++k) n += edge_on(tp, k) ? 1 : 0;
+      return n;
+    }
+    case PHX_KIND_BUYER: {
+      if (!(has_action && action > 0.5f)) return 0;
+      for (int k = tp.row_ptr[a]; k < tp.row_ptr[a + 1]; ++k) if (edge_on(tp, k)) return 1;
+      return 0;
+    }
     default: return 0;
   }
 }
@@ -105,16 +115,18 @@ __device__ __forceinline__ void act_emit(const DevSpec& sp, const Topo& tp, int 
         fld<double>(sp, F_SELLER_PRICE)[r.base] = price;
         m.type = PHX_MSG_PRICE; m.p.f = price;
         const int lo = tp.row_ptr[a], hi = tp.row_ptr[a + 1];
-        for (int k = lo; k < hi; ++k) { m.dst = (uint16_t)tp.col[k]; out[k - lo] = m; }
+        int n = 0;
+        for (int k = lo; k < hi; ++k) if (edge_on(tp, k)) { m.dst = (uint16_t)tp.col[k]; out[n++] = m; }
       }
       break;
     case PHX_KIND_BUYER:
       if (has_action) {
-        const int deg = tp.row_ptr[a + 1] - tp.row_ptr[a];
-        if (action > 0.5f && deg > 0) {
-          const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + tp.buyer_off[a];
-          int j = 0; double best = pr[0];
-          for (int k = 1; k < deg; ++k) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (v < best) { best = v; j = k; } }
+        const int lo = tp.row_ptr[a], deg = tp.row_ptr[a + 1] - lo;
+        const double* pr = fld<double>(sp, F_BUYER_PRICES) + (int64_t)b * sp.buyer_nnz + tp.buyer_off[a];
+        int j = -1; double best = 0.0;                         // first minimum over the current neighbours
+        for (int k = 0; k < deg; ++k)
+          if (edge_on(tp, lo + k)) { const double v = pr[(int64_t)k * sp.buyer_stride]; if (j < 0 || v < best) { best = v; j = k; } }
+        if (action > 0.5f && j >= 0) {
           fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 1;
           fld<double>(sp, F_BUYER_PAID)[r.base] = best;
           m.dst = (uint16_t)tp.col[tp.row_ptr[a] + j]; m.type = PHX_MSG_ORDER; m.p.i = 1;
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   uint8_t* live = (uint8_t*)(goff + A);
 
   // static topology tables: LDS copies behind the queues (TABLDS) or the global arrays
-  Topo tp = topo_global(sp);
+  Topo tp = topo_env(sp, b);
   if (TABLDS) {
     char* tb = smem + g.tab_off;
     const int nnz = sp.nnz;
@@ -483,16 +495,24 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
 // ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------
 template <int NT>
 __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask,
-                                                       const double* sampler_values, float* obs,
-                                                       uint8_t* obs_valid) {
+                                                       const double* sampler_values, const uint8_t* conn_values,
+                                                       float* obs, uint8_t* obs_valid) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (mask && !mask[b]) return;
   const int A = sp.A, S = sp.S, D = sp.D;
-  const Topo tp = topo_global(sp);
-  if (sp.n_samplers > 0) {                                              // env.py:211-212
+  const Topo tp = topo_env(sp, b);
+  if (sp.n_samplers > 0 || sp.n_conn > 0) {                             // env.py:211-218
     const uint32_t ep = (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b];
-    double* sv = fld<double>(sp, F_ENV_SAMPLER) + (int64_t)b * sp.n_samplers;
-    for (int j = tid; j < sp.n_samplers; j += NT) sv[j] = dev_sample_column(sp, b, j, ep, sampler_values, sv[j]);
+    if (sp.n_samplers > 0) {
+      double* sv = fld<double>(sp, F_ENV_SAMPLER) + (int64_t)b * sp.n_samplers;
+      for (int j = tid; j < sp.n_samplers; j += NT) sv[j] = dev_sample_column(sp, b, j, ep, sampler_values, sv[j]);
+    }
+    if (sp.n_conn > 0) {                                                // resample_connectivity network.py:438-447
+      uint8_t* cv = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
+      for (int i = tid; i < sp.n_conn; i += NT)
+        cv[i] = conn_values ? (conn_values[(int64_t)b * sp.n_conn + i] != 0)
+                            : (uint8_t)rng_connection(sp.seed, sp.env_offset + b, ep, i, sp.conn_rate[i]);
+    }
     __syncthreads();
     if (tid == 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)(ep + 1);
   }
@@ -553,8 +573,8 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   return hipGetLastError();
 }
 
-hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, float* obs,
-                            uint8_t* obs_valid, hipStream_t st) {
-  hipLaunchKernelGGL((phx_reset_kernel<64>), dim3(sp.B), dim3(64), 0, st, sp, mask, sampler_values, obs, obs_valid);
+hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values,
+                            const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st) {
+  hipLaunchKernelGGL((phx_reset_kernel<64>), dim3(sp.B), dim3(64), 0, st, sp, mask, sampler_values, conn_values, obs, obs_valid);
   return hipGetLastError();
 }

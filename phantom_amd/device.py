@@ -158,11 +158,16 @@ class DeviceEnv:
         return v[0].item() if self.B == 1 else v
 
     # ---- entry points ---------------------------------------------------------------------
-    def reset(self, mask=None, sampler_values=None):
+    def reset(self, mask=None, sampler_values=None, conn_on=None):
         """``sampler_values``: f64 [B, n_samplers] (host array or device tensor) = what
-        `sampler.sample()` returned for each env (env.py:211-212); None -> device-drawn."""
+        `sampler.sample()` returned for each env (env.py:211-212); ``conn_on``: u8 [B, n_conn] =
+        the StochasticNetwork draws (network.py:444-447); None -> device-drawn."""
         torch = _torch()
-        mp = vp = None
+        mp = vp = cp = None
+        if conn_on is not None:
+            self._conn_on = torch.as_tensor(conn_on, dtype=torch.uint8).to(self.device).contiguous()
+            assert self._conn_on.shape == (self.B, self.spec.n_conn)
+            cp = self._conn_on.data_ptr()
         if sampler_values is not None:
             self._sampler_values = torch.as_tensor(sampler_values, dtype=torch.float64).to(
                 self.device).contiguous()
@@ -175,7 +180,7 @@ class DeviceEnv:
         else:
             self.err.zero_()
         with torch.cuda.device(self.device):
-            self._check(self.lib.phx_reset(self.handle, mp, vp, self.obs.data_ptr(),
+            self._check(self.lib.phx_reset(self.handle, mp, vp, cp, self.obs.data_ptr(),
                                            self.obs_valid.data_ptr(), self._stream()), "phx_reset")
         return self.obs, self.obs_valid
 

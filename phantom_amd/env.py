@@ -86,16 +86,42 @@ class PhantomEnv:
             self._sampled = np.empty((self.batch_size, len(self._samplers)), dtype=object)
             self._host_sample(None)        # "Generate initial sampled values", env.py:118-119
 
+    def _host_draws(self, mask):
+        """The reset-time draws a reference env takes from the global numpy stream, env instance by
+        env instance (the order a list of reference envs reset one after the other consumes it):
+        `for sampler in self._samplers: sampler.sample()` (env.py:211-212), then
+        StochasticNetwork.resample_connectivity (env.py:218 -> network.py:438-447).
+        Returns (sampler values f64 [B, n] | None, connectivity u8 [B, n_conn] | None) for phx_reset;
+        None = that part is drawn by the device."""
+        net = self.network
+        host_conn = hasattr(net, "draw_connectivity") and self.exogenous != "device"
+        conn = np.zeros((self.batch_size, len(net._base_connections)), np.uint8) if host_conn else None
+        if self._sampled is None and conn is None:
+            return None, None
+        for b in range(self.batch_size):
+            if mask is None or mask[b]:
+                if self._sampled is not None:
+                    for j, sm in enumerate(self._samplers):
+                        self._sampled[b, j] = sm.sample()
+                if conn is not None:
+                    conn[b] = net.draw_connectivity()
+        if conn is not None and (mask is None or mask[0]):
+            net._apply_connectivity(conn[0])       # the host graph mirrors env instance 0
+        return self._sampler_matrix(), conn
+
     def _host_sample(self, mask):
-        """`for sampler in self._samplers: sampler.sample()` (env.py:211-212) once per env
-        instance being reset, env by env -- the order a list of reference envs would consume
-        the global numpy stream in.  Returns the f64 matrix handed to phx_reset."""
+        """sampler part of _host_draws alone (the constructor's first draw, env.py:118-119)."""
         if self._sampled is None:
             return None
         for b in range(self.batch_size):
             if mask is None or mask[b]:
                 for j, sm in enumerate(self._samplers):
                     self._sampled[b, j] = sm.sample()
+        return self._sampler_matrix()
+
+    def _sampler_matrix(self):
+        if self._sampled is None:
+            return None
         vals = np.zeros(self._sampled.shape, dtype=np.float64)
         for idx, v in np.ndenumerate(self._sampled):
             try:
@@ -239,7 +265,8 @@ class PhantomEnv:
         """env.py:185-237.  ``seed`` is accepted and ignored exactly as in the reference, where
         it only seeds ``self.np_random`` which nothing consumes."""
         dev = self._device()
-        obs, valid = dev.reset(mask, self._host_sample(mask))
+        sampler_values, conn_on = self._host_draws(mask)
+        obs, valid = dev.reset(mask, sampler_values, conn_on)
         self._host_reset(mask)
         if self.env_supertype is not None:                   # env.py:214-215
             self.env_type = self._resolve_type(self.env_supertype)

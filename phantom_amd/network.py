@@ -169,3 +169,72 @@ class Network:
                 f"Message payload of type '{payload.__class__.__name__}' cannot be received by "
                 f"agent with type '{receiver.__class__.__name__:}' (expected one of "
                 f"{payload._receiver_types})")
+
+
+class StochasticNetwork(Network):
+    """network.py:340-453: every connection carries a connectivity ``rate``; the graph is resampled
+    at each reset (``resample_connectivity``).  The host object keeps the reference's behaviour for
+    its own ``graph`` (one numpy draw per base connection, in order, at ``add_connection`` and at
+    every ``resample_connectivity``); the device keeps one on/off byte per base connection and env
+    instance (state field ``net.conn_on``), fed by the host's draws or drawn by the device RNG."""
+
+    def __init__(self, agents=None, resolver=None, connections=None,
+                 ignore_connection_errors: bool = False, enforce_msg_payload_checks: bool = True) -> None:
+        self._base_connections: List[Tuple[AgentID, AgentID, float]] = []
+        super().__init__(agents, resolver, connections, ignore_connection_errors,
+                         enforce_msg_payload_checks)
+
+    def add_connection(self, u: AgentID, v: AgentID, rate: float = 1.0) -> None:
+        if u not in self.agents:
+            raise ValueError(f"Agent with ID = '{u}' does not exist.")
+        if v not in self.agents:
+            raise ValueError(f"Agent with ID = '{v}' does not exist.")
+        if any({u, v} == {a, b} for a, b, _ in self._base_connections):
+            raise NotImplementedError(f"connection ({u}, {v}) is defined twice")
+        if np.random.random() < rate:                       # network.py:389-391
+            self._succ[u].setdefault(v, None)
+            self._succ[v].setdefault(u, None)
+        self._base_connections.append((u, v, float(rate)))
+        self._topology_version += 1
+
+    def add_connections_from(self, ebunch) -> None:         # network.py:395-423
+        for connection in ebunch:
+            if len(connection) == 2:
+                self.add_connection(connection[0], connection[1])
+            elif len(connection) == 3:
+                self.add_connection(connection[0], connection[1], connection[2])
+            else:
+                raise ValueError(f"Ill-formatted connection tuple {connection}.")
+
+    def add_connections_between(self, us, vs, rate: float = 1.0) -> None:   # network.py:425-436
+        for u, v in product(us, vs):
+            self.add_connection(u, v, rate)
+
+    def base_neighbors(self, agent_id: AgentID) -> List[Tuple[AgentID, int]]:
+        """(neighbour, base connection index) in base-connection order: the adjacency order of ANY
+        resampled graph is a subsequence of it (network.py:441-447 re-adds edges in that order)."""
+        out = []
+        for i, (u, v, _) in enumerate(self._base_connections):
+            if u == agent_id:
+                out.append((v, i))
+            elif v == agent_id:
+                out.append((u, i))
+        return out
+
+    def draw_connectivity(self) -> np.ndarray:
+        """one `np.random.random() < rate` per base connection, in order (network.py:444-445)."""
+        return np.asarray([np.random.random() < r for _, _, r in self._base_connections], dtype=np.uint8)
+
+    def _apply_connectivity(self, on: np.ndarray) -> None:
+        self._succ = {aid: {} for aid in self.agents}
+        for (u, v, _), keep in zip(self._base_connections, on):
+            if keep:
+                self._succ[u].setdefault(v, None)
+                self._succ[v].setdefault(u, None)
+
+    def resample_connectivity(self) -> None:                # network.py:438-447
+        self._apply_connectivity(self.draw_connectivity())
+
+    def reset(self) -> None:                                # network.py:449-452
+        self.resample_connectivity()
+        Network.reset(self)

@@ -46,6 +46,9 @@ class EnvSpec:
     sampler_kind: Optional[np.ndarray] = None     # i32 [n_samplers]
     sampler_param: Optional[np.ndarray] = None    # f64 [n_samplers, 4]
     type_src: Optional[np.ndarray] = None         # i32 [A]
+    # StochasticNetwork: base connections (row_ptr/col then describe the base graph)
+    conn_rate: Optional[np.ndarray] = None        # f64 [n_conn]
+    col_conn: Optional[np.ndarray] = None         # i32 [nnz]
 
     # ---- derived ------------------------------------------------------------------------
     @property
@@ -67,6 +70,10 @@ class EnvSpec:
     @property
     def n_samplers(self) -> int:
         return 0 if self.sampler_kind is None else int(len(self.sampler_kind))
+
+    @property
+    def n_conn(self) -> int:
+        return 0 if self.conn_rate is None else int(len(self.conn_rate))
 
     def agent_obs_dim(self, a: int) -> int:
         """observation length of strategic agent index ``a`` (a typed shop appends its type)."""
@@ -137,6 +144,9 @@ class EnvSpec:
         s.sampler_kind = ptr(self.sampler_kind, np.int32) if self.n_samplers else None
         s.sampler_param = ptr(self.sampler_param, np.float64) if self.n_samplers else None
         s.type_src = ptr(self.type_src, np.int32)
+        s.n_conn = self.n_conn
+        s.conn_rate = ptr(self.conn_rate, np.float64) if self.n_conn else None
+        s.col_conn = ptr(self.col_conn, np.int32) if self.n_conn else None
         return s, keep
 
 
@@ -195,9 +205,14 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
 
     row_ptr = np.zeros(A + 1, dtype=np.int32)
     col: List[int] = []
+    col_conn: List[int] = []
+    stochastic = hasattr(network, "base_neighbors")           # StochasticNetwork: the base graph
     for a, aid in enumerate(agent_ids):
-        nb = network.neighbors(aid)
-        col.extend(index[n] for n in nb)
+        if stochastic:
+            for n, i in network.base_neighbors(aid):
+                col.append(index[n]); col_conn.append(i)
+        else:
+            col.extend(index[n] for n in network.neighbors(aid))
         row_ptr[a + 1] = len(col)
     col_arr = np.asarray(col, dtype=np.int32)
 
@@ -246,6 +261,10 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
     elif env_type == _abi.ENV_STACKELBERG:
         spec.leaders = np.asarray([index_of(a) for a in leaders], dtype=np.int32)
         spec.followers = np.asarray([index_of(a) for a in followers], dtype=np.int32)
+
+    if stochastic:
+        spec.conn_rate = np.asarray([r for _, _, r in network._base_connections], dtype=np.float64)
+        spec.col_conn = np.asarray(col_conn, dtype=np.int32)
 
     # ---- Supertypes: the device-consumed type field of each agent (agents.py:160-175) ----------
     from .samplers import Sampler, UniformFloatSampler

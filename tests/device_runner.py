@@ -28,8 +28,8 @@ class DeviceRunner:
         self.err = d.err.cpu().numpy()
         self.msg_count = d.msg_count.cpu().numpy() if d.msg_count is not None else None
 
-    def reset(self, mask=None, sampler_values=None):
-        obs, valid = self.dev.reset(mask, sampler_values)
+    def reset(self, mask=None, sampler_values=None, conn_on=None):
+        obs, valid = self.dev.reset(mask, sampler_values, conn_on)
         self.err = self.dev.err.cpu().numpy()
         return obs.cpu().numpy(), valid.cpu().numpy()
 
@@ -73,6 +73,9 @@ class DeviceRunner:
     def set_i32(self, field, arr):
         self.dev.field(field).copy_(torch.from_numpy(np.ascontiguousarray(arr, np.int32)).reshape(
             self.dev.field(field).shape))
+
+    def get_u8(self, field):
+        return self.dev.field(field).cpu().numpy().reshape(self.B, -1)
 
     def get_f64(self, field):
         v = self.dev.field(field).cpu().numpy()

@@ -277,7 +277,8 @@ class SellerAgent(ph.StrategicAgent):
         self.tx += message.payload.vol
 
     def encode_observation(self, ctx):
-        return np.array([self.tx / len(ctx.neighbour_ids), self.price], dtype=np.float32)
+        n = len(ctx.neighbour_ids)             # can be 0 on a StochasticNetwork
+        return np.array([self.tx / n if n else 0.0, self.price], dtype=np.float32)
 
     def compute_reward(self, ctx):
         return self.revenue
@@ -314,7 +315,7 @@ class BuyerAgent(ph.StrategicAgent):
         return []
 
     def encode_observation(self, ctx):
-        return np.array([min(self._prices(ctx).values()), self.value], dtype=np.float32)
+        return np.array([min(self._prices(ctx).values(), default=1.0), self.value], dtype=np.float32)
 
     def compute_reward(self, ctx):
         return self.value - self.paid if self.bought else 0.0
@@ -325,15 +326,24 @@ def market_topology(L, Fw, d):
     return [[(f * d + j * 17) % L for j in range(d)] for f in range(Fw)]
 
 
-def run_market(name, L, Fw, d, num_steps, T, seed):
+def run_market(name, L, Fw, d, num_steps, T, seed, rates=None):
+    """``rates``: per-connection connectivity of a ph.StochasticNetwork (network.py:340-453), cycled
+    over the base connections; None -> static ph.Network."""
     leaders = [f"S{i}" for i in range(L)]
     followers = [f"B{i}" for i in range(Fw)]
     values = [((f % 7) + 1) / 8.0 for f in range(Fw)]
     agents = [SellerAgent(s) for s in leaders] + [BuyerAgent(b, values[f]) for f, b in enumerate(followers)]
-    net = ph.Network(agents, resolver=ph.resolvers.BatchResolver(enable_tracking=True))
-    for f, nb in enumerate(market_topology(L, Fw, d)):
-        for l in nb:
-            net.add_connection(followers[f], leaders[l])
+    base = [(followers[f], leaders[l]) for f, nb in enumerate(market_topology(L, Fw, d)) for l in nb]
+    if rates is None:
+        net = ph.Network(agents, resolver=ph.resolvers.BatchResolver(enable_tracking=True))
+        for u, v in base:
+            net.add_connection(u, v)
+    else:
+        np.random.seed(seed)                       # add_connection draws (network.py:389)
+        net = ph.StochasticNetwork(agents, resolver=ph.resolvers.BatchResolver(enable_tracking=True))
+        conn_rate = [rates[i % len(rates)] for i in range(len(base))]
+        for (u, v), r in zip(base, conn_rate):
+            net.add_connection(u, v, r)
     env = ph.StackelbergEnv(num_steps, net, leaders, followers)
     ids = leaders + followers
     index = {aid: i for i, aid in enumerate(ids)}
@@ -348,6 +358,9 @@ def run_market(name, L, Fw, d, num_steps, T, seed):
              seller_price=np.zeros((T, L)), seller_revenue=np.zeros((T, L)),
              seller_tx=np.zeros((T, L), np.int32), buyer_bought=np.zeros((T, Fw), np.int32),
              buyer_paid=np.zeros((T, Fw)), n_msgs=np.zeros(T, np.int32))
+    if rates is not None:
+        A["conn_rate"] = np.asarray(conn_rate)
+        A["conn_on"] = np.zeros((T, len(base)), np.uint8)     # base connection is in the graph after this reset
     logs = {}
     need_reset = True
     for t in range(T):
@@ -358,6 +371,8 @@ def run_market(name, L, Fw, d, num_steps, T, seed):
                 A["reset_obs"][t, index[aid]] = o
                 A["reset_obs_valid"][t, index[aid]] = 1
             need_reset = False
+            if rates is not None:
+                A["conn_on"][t] = [net.graph.has_edge(u, v) for u, v in base]
         odd = (env.current_step + 1) % 2 == 1
         acts = {}
         # prices on a coarse grid so that ties between sellers occur (tie -> first neighbour)
@@ -435,6 +450,8 @@ def main():
     # config 5: Stackelberg market, small and full size
     run_market("stk_small", 8, 32, 4, 7, 16, seed=11)
     run_market("stk_full", 128, 1024, 8, 100, 6, seed=12)
+    # the same market on a StochasticNetwork: connectivity resampled at every reset
+    run_market("stk_stochastic", 6, 20, 3, 5, 23, seed=13, rates=[0.7, 0.35, 1.0, 0.0, 0.5])
 
 
 if __name__ == "__main__":

@@ -54,15 +54,23 @@ def market_topology(L, Fw, d):
     return [[(f * d + j * 17) % L for j in range(d)] for f in range(Fw)]
 
 
-def market_env(L, Fw, d, num_steps, batch, tracking=False, **kw):
+def market_env(L, Fw, d, num_steps, batch, tracking=False, rates=None, **kw):
+    """``rates``: per-connection connectivity of a StochasticNetwork, cycled over the base
+    connections (tests/golden/gen_goldens.py run_market); None -> static Network."""
     leaders = [f"S{i}" for i in range(L)]
     followers = [f"B{i}" for i in range(Fw)]
     agents = [ph.SellerAgent(s) for s in leaders] + \
              [ph.BuyerAgent(b, ((f % 7) + 1) / 8.0) for f, b in enumerate(followers)]
-    net = ph.Network(agents, resolver=ph.BatchResolver(enable_tracking=tracking))
-    for f, nb in enumerate(market_topology(L, Fw, d)):
-        for l in nb:
-            net.add_connection(followers[f], leaders[l])
+    resolver = ph.BatchResolver(enable_tracking=tracking)
+    base = [(followers[f], leaders[l]) for f, nb in enumerate(market_topology(L, Fw, d)) for l in nb]
+    if rates is None:
+        net = ph.Network(agents, resolver=resolver)
+        for u, v in base:
+            net.add_connection(u, v)
+    else:
+        net = ph.StochasticNetwork(agents, resolver=resolver)
+        for i, (u, v) in enumerate(base):
+            net.add_connection(u, v, rates[i % len(rates)])
     return ph.StackelbergEnv(num_steps, net, leaders, followers, batch_size=batch, **kw)
 
 

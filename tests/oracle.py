@@ -43,7 +43,9 @@ def lib():
         for n in ("phxo_obs_dim", "phxo_n_strategic", "phxo_n_exo"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [vp]
-        L.phxo_reset.argtypes = [vp, vp, vp, vp, vp]
+        L.phxo_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.phxo_get_u8.restype = C.c_int64
+        L.phxo_get_u8.argtypes = [vp, C.c_char_p, vp]
         L.phxo_rng_uniform.restype = C.c_double
         L.phxo_rng_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_int, vp]
         L.phxo_step.argtypes = [vp, C.POINTER(_abi.PhxStepIO)]
@@ -105,7 +107,10 @@ class OracleEnv:
     def set_threads(self, n):
         self.L.phxo_set_threads(n)
 
-    def reset(self, mask=None, sampler_values=None):
+    def reset(self, mask=None, sampler_values=None, conn_on=None):
+        if conn_on is not None:
+            conn_on = np.ascontiguousarray(conn_on, np.uint8)
+            assert conn_on.shape == (self.B, self.spec.n_conn)
         if sampler_values is not None:
             sampler_values = np.ascontiguousarray(sampler_values, np.float64)
             assert sampler_values.shape == (self.B, self.spec.n_samplers)
@@ -114,7 +119,7 @@ class OracleEnv:
             self.err[mask.astype(bool)] = 0
         else:
             self.err[:] = 0
-        self.L.phxo_reset(self.h, _p(mask), _p(sampler_values), _p(self.obs), _p(self.obs_valid))
+        self.L.phxo_reset(self.h, _p(mask), _p(sampler_values), _p(conn_on), _p(self.obs), _p(self.obs_valid))
         return self.obs.copy(), self.obs_valid.copy()
 
     def step(self, actions, action_valid=None, exo=None):
@@ -176,6 +181,12 @@ class OracleEnv:
     def set_i32(self, field, arr):
         arr = np.ascontiguousarray(arr, np.int32)
         assert self.L.phxo_set_i32(self.h, field.encode(), _p(arr)) >= 0
+
+    def get_u8(self, field):
+        buf = np.zeros(self.B * max(self.spec.n_conn, 1), np.uint8)
+        n = self.L.phxo_get_u8(self.h, field.encode(), _p(buf))
+        assert n >= 0, field
+        return buf[:n].reshape(self.B, -1).copy()
 
     def get_f64(self, field):
         buf = np.zeros(self.B * max(self.spec.n_agents, len(self.spec.col), self.spec.n_samplers, 1), np.float64)

@@ -15,7 +15,7 @@ from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, ma
                      supply_chain_env)
 from kats import ALL_KATS
 from oracle import OracleEnv
-from test_oracle_vs_goldens import SC_CASES, replay_market, replay_supply_chain
+from test_oracle_vs_goldens import MARKET_CASES, SC_CASES, replay_market, replay_supply_chain
 
 pytestmark = pytest.mark.gpu
 
@@ -55,7 +55,7 @@ def test_fused_kernel_supply_chain_matches_reference(name):
     replay_supply_chain(g, make)
 
 
-@pytest.mark.parametrize("name", ["stk_small", "stk_full"])
+@pytest.mark.parametrize("name", MARKET_CASES)
 def test_generic_engine_market_matches_reference(name):
     replay_market(golden(name), _dev)
 
@@ -674,3 +674,75 @@ def test_market_compressed_prices_materialise_on_inject():
     for t in range(6, 10):
         step(t)
     np.testing.assert_array_equal(f64_bits(x.get_f64("buyer.prices")), f64_bits(o.get_f64("buyer.prices")))
+
+
+@pytest.mark.parametrize("device_draw", [False, True])
+def test_stochastic_network_differential_vs_oracle(device_draw):
+    """StochasticNetwork (network.py:340-453): per-env connectivity resampled at every reset, fed by
+    the host or drawn by the device Philox stream; market kinds iterate / check the per-env graph."""
+    rng = np.random.RandomState(31)
+    L, Fw, d, B, T = 6, 24, 3, 40, 36
+    S = L + Fw
+    np.random.seed(5)
+    env = market_env(L, Fw, d, 9, B, rates=[0.8, 0.3, 1.0, 0.0, 0.55], seed=21, env_offset=100)
+    spec = env.spec
+    assert spec.n_conn == Fw * d and len(spec.col_conn) == 2 * spec.n_conn
+    o, x = OracleEnv(spec), _dev(spec)
+    assert not x.dev.uses_fused
+    np.testing.assert_array_equal(x.get_u8("net.conn_on"), o.get_u8("net.conn_on"))   # constructor draw
+
+    def reset(mask=None):
+        conn = None if device_draw else (rng.rand(B, spec.n_conn) < spec.conn_rate).astype(np.uint8)
+        (oo, ov), (do, dv) = o.reset(mask, None, conn), x.reset(mask, None, conn)
+        m = slice(None) if mask is None else mask.astype(bool)
+        np.testing.assert_array_equal(dv[m], ov[m])
+        np.testing.assert_array_equal(f32_bits(do[m]), f32_bits(oo[m]))
+        np.testing.assert_array_equal(x.get_u8("net.conn_on"), o.get_u8("net.conn_on"))
+        np.testing.assert_array_equal(x.get_i32("env.episode"), o.get_i32("env.episode"))
+
+    reset()
+    on = o.get_u8("net.conn_on")
+    assert 0.3 < on.mean() < 0.7 and (on[:, 2::5] == 1).all() and (on[:, 3::5] == 0).all()
+    assert len({tuple(r) for r in on}) > B // 2                   # the envs have different graphs
+    for t in range(T):
+        act = np.zeros((B, S), np.float32); valid = np.zeros((B, S), np.uint8)
+        odd = (o.get_i32("env.step")[:, 0] + 1) % 2 == 1
+        act[:, :L] = rng.randint(1, 9, size=(B, L)) / 8.0
+        act[:, L:] = (rng.rand(B, Fw) < 0.7)
+        valid[odd, :L] = 1; valid[~odd, L:] = 1
+        o.step(act, valid, None); x.step(act, valid, None)
+        for f in ("obs_valid", "reward_valid", "done_valid", "all_truncated", "err"):
+            np.testing.assert_array_equal(getattr(x, f), getattr(o, f), err_msg=f"{f} t={t}")
+        assert (o.err == 0).all()
+        np.testing.assert_array_equal(f32_bits(x.obs), f32_bits(o.obs), err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward), err_msg=f"rew t={t}")
+        for f in ("seller.tx", "buyer.bought"):
+            np.testing.assert_array_equal(x.get_i32(f), o.get_i32(f), err_msg=f)
+        done = o.all_truncated.astype(np.uint8)
+        if done.any():
+            reset(done)
+
+
+def test_stochastic_network_reference_kats():
+    """tests/network/test_stochastic_network.py:13-58 through the Python surface: rate 1 keeps the
+    edge, rate 0 never creates it, before and after resample_connectivity()."""
+    for rate, how in [(1.0, "one"), (0.0, "one"), (0.0, "from"), (0.0, "between")]:
+        net = ph.StochasticNetwork([ph.Agent("A"), ph.Agent("B")], ph.BatchResolver(2))
+        if how == "one":
+            net.add_connection("A", "B", rate)
+        elif how == "from":
+            net.add_connections_from([("A", "B", rate)])
+        else:
+            net.add_connections_between(["A"], ["B"], rate=rate)
+        for _ in range(2):
+            assert net.has_edge("A", "B") == (rate == 1.0) and net.has_edge("B", "A") == (rate == 1.0)
+            net.resample_connectivity()
+    # a missing edge is a NetworkError inside the step: PHX_ERR_NETWORK on the device
+    import phantom_amd as ph_
+    env = market_env(2, 4, 2, 4, 3, rates=[0.0], exogenous="device")
+    d = env._device()
+    env.reset()
+    assert (d.field("net.conn_on").cpu().numpy() == 0).all()
+    out = env.step_tensors(__import__("torch").ones(3, 6, device=d.device))
+    assert (d.err.cpu().numpy() == 0).all()                      # nobody has a neighbour: nothing is sent
+    assert (out.observations.cpu().numpy()[:, 2:, 0] == 1.0).all()   # buyers: min over no prices -> 1.0

@@ -303,3 +303,54 @@ def test_compile_spec_sampler_tables_and_device_uniform_definition():
             assert vals[b, j] == v
     o.reset()
     assert (o.get_i32("env.episode") == 2).all() and not np.array_equal(o.get_f64("env.sampler"), vals)
+
+
+def test_stochastic_network_host_semantics_and_spec_tables():
+    """tests/network/test_stochastic_network.py:13-58 on the host object, the numpy-stream order of
+    the draws, and the base-graph CSR handed to the device."""
+    for rate, how in [(1.0, "one"), (0.0, "one"), (0.0, "from"), (0.0, "between")]:
+        net = ph.StochasticNetwork([ph.Agent("A"), ph.Agent("B")], ph.BatchResolver(2))
+        if how == "one":
+            net.add_connection("A", "B", rate)
+        elif how == "from":
+            net.add_connections_from([("A", "B", rate)])
+        else:
+            net.add_connections_between(["A"], ["B"], rate=rate)
+        for _ in range(2):
+            assert net.has_edge("A", "B") == (rate == 1.0) and net.has_edge("B", "A") == (rate == 1.0)
+            net.resample_connectivity()
+    with pytest.raises(ValueError):
+        ph.StochasticNetwork([ph.Agent("A")]).add_connections_from([("A",)])
+    # one np.random.random() per base connection, in order, at add_connection and at each resample
+    agents = [ph.SellerAgent("S0"), ph.SellerAgent("S1"), ph.BuyerAgent("B0", 0.5), ph.BuyerAgent("B1", 0.5)]
+    rates = [0.5, 0.25, 0.75, 1.0]
+    pairs = [("B0", "S0"), ("B0", "S1"), ("B1", "S1"), ("B1", "S0")]
+    np.random.seed(4)
+    net = ph.StochasticNetwork(agents)
+    for (u, v), r in zip(pairs, rates):
+        net.add_connection(u, v, r)
+    np.random.seed(4)
+    expect = [np.random.random() < r for r in rates]
+    assert [net.has_edge(u, v) for u, v in pairs] == expect
+    state = np.random.get_state()
+    expect2 = [np.random.random() < r for r in rates]
+    np.random.set_state(state)
+    net.resample_connectivity()
+    assert [net.has_edge(u, v) for u, v in pairs] == expect2
+    env = ph.StackelbergEnv(4, net, ["S0", "S1"], ["B0", "B1"], batch_size=2)
+    spec = env.spec
+    np.testing.assert_array_equal(spec.conn_rate, rates)
+    # base CSR: S0: (B0 c0, B1 c3); S1: (B0 c1, B1 c2); B0: (S0 c0, S1 c1); B1: (S1 c2, S0 c3)
+    np.testing.assert_array_equal(spec.row_ptr, [0, 2, 4, 6, 8])
+    np.testing.assert_array_equal(spec.col, [2, 3, 2, 3, 0, 1, 1, 0])
+    np.testing.assert_array_equal(spec.col_conn, [0, 3, 1, 2, 0, 1, 2, 3])
+    # device draw definition (oracle restatement) vs an independent evaluation
+    import oracle
+    o = oracle.OracleEnv(spec)
+    on = o.get_u8("net.conn_on")
+    for b in range(2):
+        for i, r in enumerate(rates):
+            w = oracle.philox([b, 0, 0, 0x40000000 | (i >> 1)], [0, 0])
+            h = 2 * (i & 1)
+            u = (float(int(w[h]) >> 5) * 67108864.0 + float(int(w[h + 1]) >> 6)) / 9007199254740992.0
+            assert on[b, i] == (u < r)

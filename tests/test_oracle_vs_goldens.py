@@ -60,11 +60,18 @@ def test_oracle_supply_chain_matches_reference(name):
 
 def replay_market(g, make_runner, tracking=True):
     L, Fw, d, T = int(g["L"]), int(g["Fw"]), int(g["d"]), int(g["T"])
-    env = market_env(L, Fw, d, int(g["num_steps"]), 1, tracking=tracking)
+    stochastic = "conn_rate" in g
+    rates = [0.7, 0.35, 1.0, 0.0, 0.5] if stochastic else None            # gen_goldens.py main()
+    env = market_env(L, Fw, d, int(g["num_steps"]), 1, tracking=tracking, rates=rates)
+    if stochastic:
+        np.testing.assert_array_equal(env.spec.conn_rate, g["conn_rate"])
     run = make_runner(env.spec)
     for t in range(T):
         if g["reset_before"][t]:
-            obs, valid = run.reset()
+            # stochastic golden: the connectivity the reference's StochasticNetwork drew at this reset
+            obs, valid = run.reset(None, None, g["conn_on"][t][None]) if stochastic else run.reset()
+            if stochastic:
+                np.testing.assert_array_equal(run.get_u8("net.conn_on")[0], g["conn_on"][t])
             np.testing.assert_array_equal(valid[0], g["reset_obs_valid"][t])
             sel = g["reset_obs_valid"][t].astype(bool)
             np.testing.assert_array_equal(f32_bits(obs[0][sel]), f32_bits(g["reset_obs"][t][sel]))
@@ -89,6 +96,9 @@ def replay_market(g, make_runner, tracking=True):
             np.testing.assert_array_equal(log_matrix(run.log(0)), g[f"log{t}"], err_msg=f"log t={t}")
 
 
-@pytest.mark.parametrize("name", ["stk_small", "stk_full"])
+MARKET_CASES = ["stk_small", "stk_full", "stk_stochastic"]
+
+
+@pytest.mark.parametrize("name", MARKET_CASES)
 def test_oracle_market_matches_reference(name):
     replay_market(golden(name), lambda spec: OracleEnv(spec))
