@@ -152,8 +152,9 @@ def main():
     sync_barrier()
     t0 = time.perf_counter()
     run(K)
-    sync_barrier()
+    torch.cuda.synchronize()                 # this rank's K steps are done ...
     elapsed = time.perf_counter() - t0
+    sync_barrier()                           # ... all ranks are; the job's time is the MAX over ranks
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

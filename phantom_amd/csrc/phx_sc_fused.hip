@@ -253,8 +253,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
 
   // LDS carve (all offsets multiples of 16 bytes)
   const int items_max = TC * Gfull;
-  const int it_words = (items_max * 3 + 3) & ~3, it1 = (items_max + 3) & ~3;
-  int* s_it0 = (int*)smem;                                 // 2 x [TC][G][3]
+  const int it1 = (items_max + 3) & ~3, it_words = 3 * it1;
+  int* s_it0 = (int*)smem;                                 // 2 x 3 planes [TC][G]: R | stock, D, sales
   float* s_act0 = (float*)(s_it0 + 2 * it_words);          // 2 x [TC][G]
   uint16_t* s_pair = (uint16_t*)(s_act0 + 2 * it1);        // [G] shop | env_local << 8
   int* s_tick0 = (int*)(s_pair + ((Gfull + 7) & ~7));     // [epb]
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
           const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl]
                                                       : rng_word_to_action(w[2 * h + 1]);
           s_act[i] = action;
-          s_it[3 * i + 0] = dev_round_half_even(action);
-          s_it[3 * i + 1] = D;
+          s_it[i] = dev_round_half_even(action);
+          s_it[it1 + i] = D;
         }
       }
       jr += qG; gl += rG;
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       const int tend = a.num_steps - 1 - step;
       if (tid % nS == 0) s_tend[tid / nS] = (tend >= 0 && tend < tc) ? tend : -1;
       int x = st.stock, sales = st.sales, Dl = 0, req = st.delivered;
-      int* it = s_it + tid * 3;
-      const int istride = G * 3;
+      int* it = s_it + tid;
+      const int istride = G;
       const bool hasK = p2_K > 0;
       // dependent chain per step: sub, max, add, min, and  (the reset is an AND with a mask that
       // does not depend on the stock; shops without customers take the general select)
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
         req = min((R_), PHX_SHOP_MAX_STOCK - x);                  /* decode_action         :139 */     \
         sales = x - a0;                                                                          \
         const int xn = min(a0 + req, PHX_SHOP_MAX_STOCK);         /* handle_stock_response :98-103 */  \
-        (it_)[0] = xn; (it_)[2] = sales;                                                         \
+        (it_)[0] = xn; (it_)[2 * it1] = sales;                                                   \
         x = xn & keep;                                                                           \
       }
       int tl = 0;
@@ -383,12 +383,12 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
         for (; tl + 8 <= tc; tl += 8, it += 8 * istride) {         // the 8 reads of a group are issued together
           int Rv[8], Dv[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { Rv[u] = it[u * istride]; Dv[u] = it[u * istride + 1]; }
+          for (int u = 0; u < 8; ++u) { Rv[u] = it[u * istride]; Dv[u] = it[u * istride + it1]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) P2_STEP(Rv[u], Dv[u], tl + u, it + u * istride, true)
         }
       }
-      for (; tl < tc; ++tl, it += istride) P2_STEP(it[0], it[1], tl, it, false)
+      for (; tl < tc; ++tl, it += istride) P2_STEP(it[0], it[it1], tl, it, false)
 #undef P2_STEP
       st.stock = x; st.sales = sales; st.missed = hasK ? Dl - sales : 0; st.delivered = req;
       step += tc;
@@ -424,14 +424,14 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       for (int u = tid; u < tc * G4; u += NT) {
         const int r = (int)__umulhi((uint32_t)u, a.mF);          // u / G4
         const int c4 = u - r * G4, gl0 = c4 << 2, i0 = r * G + gl0;
-        const uint4 v0 = *(const uint4*)(s_it + 3 * i0), v1 = *(const uint4*)(s_it + 3 * i0 + 4), v2 = *(const uint4*)(s_it + 3 * i0 + 8);
+        const uint4 vs = *(const uint4*)(s_it + i0), vd = *(const uint4*)(s_it + it1 + i0), vl = *(const uint4*)(s_it + 2 * it1 + i0);
         const uint2 pp = *(const uint2*)(s_pair + gl0);
         const int p0 = pp.x & 0xffff, p1 = pp.x >> 16, p2 = pp.y & 0xffff, p3 = pp.y >> 16;
         float o[12], rw[4];
-        item_out((int)v0.x, (int)v0.y, (int)v0.z, p0 & 255, o + 0, rw[0]);
-        item_out((int)v0.w, (int)v1.x, (int)v1.y, p1 & 255, o + 3, rw[1]);
-        item_out((int)v1.z, (int)v1.w, (int)v2.x, p2 & 255, o + 6, rw[2]);
-        item_out((int)v2.y, (int)v2.z, (int)v2.w, p3 & 255, o + 9, rw[3]);
+        item_out((int)vs.x, (int)vd.x, (int)vl.x, p0 & 255, o + 0, rw[0]);
+        item_out((int)vs.y, (int)vd.y, (int)vl.y, p1 & 255, o + 3, rw[1]);
+        item_out((int)vs.z, (int)vd.z, (int)vl.z, p2 & 255, o + 6, rw[2]);
+        item_out((int)vs.w, (int)vd.w, (int)vl.w, p3 & 255, o + 9, rw[3]);
         const uint32_t tr = (uint32_t)(r == s_tend[p0 >> 8]) | ((uint32_t)(r == s_tend[p1 >> 8]) << 8) |
                             ((uint32_t)(r == s_tend[p2 >> 8]) << 16) | ((uint32_t)(r == s_tend[p3 >> 8]) << 24);   // truncations["__all__"], env.py:312-318
         const int64_t e0 = row0 + (int64_t)r * rstride + gl0;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       for (int i = tid; i < n_items; i += NT) {
         const int pr = s_pair[gl];
         float o[3], rw;
-        item_out(s_it[3 * i], s_it[3 * i + 1], s_it[3 * i + 2], pr & 255, o, rw);
+        item_out(s_it[i], s_it[it1 + i], s_it[2 * it1 + i], pr & 255, o, rw);
         const int64_t e0 = row0 + (int64_t)tl * rstride + gl;
         io.obs[e0 * 3] = o[0]; io.obs[e0 * 3 + 1] = o[1]; io.obs[e0 * 3 + 2] = o[2];
         io.reward[e0] = rw; io.action_out[e0] = s_act[i];
@@ -676,7 +676,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   if (sp.num_steps >= 1 && TC > sp.num_steps) TC = sp.num_steps; // at most one episode end per chunk
   a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 4);
   const int items = TC * G;
-  const size_t lds = (size_t)((items * 3 + 3) & ~3) * 4 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
+  const size_t lds = (size_t)((items + 3) & ~3) * 4 * 3 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
                      (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
                      (size_t)((sp.S + 3) & ~3) * 4 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
   a.epb = epb; a.TC = TC;
