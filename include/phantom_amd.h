@@ -264,7 +264,8 @@ int  phx_inject(phx_env* env, const phx_msg_rec* host_msgs, int n);
 int  phx_resolve(phx_env* env, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count,
                  void* stream);
 
-/* T fused steps (supply-chain static schedule, plain or FSM env; PHX_EUNSUPPORTED otherwise,
+/* T fused steps (static supply-chain schedule on a plain or FSM env, or the static Stackelberg
+ * market; PHX_EUNSUPPORTED otherwise,
  * and for envs with PHX_SAMPLER_HOST samplers: the auto-reset resamples on the device)      */
 int  phx_rollout(phx_env* env, const phx_rollout_io* io, void* stream);
 

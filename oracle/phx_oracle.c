@@ -933,6 +933,17 @@ void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
   E->n_injected = 0;
 }
 
+/* random policy of a rollout (build-owned): the strategic agent's action word of this tick (word
+ * 2p + 1 of its block 0, see the device-RNG definition) mapped onto the kind's action space:
+ * ShopAgent U[0,100) (Box(0, SHOP_MAX_STOCK)), Seller price U[0,1), Buyer buy/skip with p = 1/2. */
+static float policy_action(const phxo_env* E, const oenv* e, int b, int s) {
+  const int kind = E->s.kind[E->strat_idx[s]];
+  const uint32_t w = rng_word(E->s.seed, E->s.env_offset + b, e->tick, s, 0, 2 * (int)(e->tick & 1u) + 1, 0);
+  if (kind == PHX_KIND_SELLER) return (float)(w >> 8) * (1.0f / 16777216.0f);
+  if (kind == PHX_KIND_BUYER) return (w >> 31) ? 1.0f : 0.0f;
+  return (float)(w >> 8) * (100.0f / 16777216.0f);
+}
+
 /* rollout = the list-of-envs loop of utils/rllib/rollout.py:361-363, with the caller's
  * reset-after-num_steps folded in (auto-reset at the end of the terminal step).          */
 static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
@@ -944,9 +955,19 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
   uint8_t* u8 = (uint8_t*)alloca(5 * (S ? S : 1));
   e->log = NULL; e->err = io->err ? io->err[b] : 0;
   for (int t = 0; t < T; ++t) {
-    for (int s = 0; s < S; ++s)
-      act[s] = io->actions ? io->actions[((size_t)t * B + b) * S + s]
-                           : phxo_rng_action(E->s.seed, E->s.env_offset + b, e->tick, s);
+    for (int s = 0; s < S; ++s) {
+      const int a = E->strat_idx[s];
+      if (E->s.env_type == PHX_ENV_STACKELBERG) {
+        /* only the side that acts this step takes an action (stackelberg.py:133-137); the
+         * trajectory records 0 for the other side */
+        const int odd = ((e->step + 1) & 1);
+        const int acts = odd ? in_list(E->s.leaders, E->s.n_leaders, a) : in_list(E->s.followers, E->s.n_followers, a);
+        act[s] = !acts ? 0.0f : io->actions ? io->actions[((size_t)t * B + b) * S + s]
+                                            : policy_action(E, e, b, s);
+      } else {
+        act[s] = io->actions ? io->actions[((size_t)t * B + b) * S + s] : policy_action(E, e, b, s);
+      }
+    }
     uint8_t at = 0, au = 0;
     env_step_one(E, e, b, act, NULL, io->exo ? io->exo + ((size_t)t * B + b) * E->n_exo : NULL,
                  o, u8, rw, u8 + S, u8 + 2 * S, u8 + 3 * S, u8 + 4 * S, &at, &au);

@@ -20,6 +20,8 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st);
+hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+size_t phx_stk_rollout_lds(const DevSpec& sp);
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 
 static thread_local char g_err[512] = "";
@@ -560,15 +562,20 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
-  if (!e->use_fused)
-    return fail(PHX_EUNSUPPORTED, "phx_rollout needs a plain or FSM env with a static supply-chain schedule");
-  if (e->d.env_type == PHX_ENV_FSM && (!io->obs_valid || !io->reward_valid))
-    return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");
+  if (!e->use_fused && !(e->use_stk && e->prices_compressed))
+    return fail(PHX_EUNSUPPORTED, "phx_rollout needs a static supply-chain schedule (plain or FSM env) or a static Stackelberg market");
+  if (e->d.env_type != PHX_ENV_PLAIN && (!io->obs_valid || !io->reward_valid))
+    return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   HIPCHK(use_device(e));
+  if (e->use_stk) {
+    if (io->exo) return fail(PHX_EINVAL, "the market has no exogenous draws");
+    if (phx_stk_rollout_lds(e->d) > 60 * 1024) return fail(PHX_EUNSUPPORTED, "market too large for the LDS-resident rollout");
+    HIPCHK(phx_launch_stk_rollout(e->d, *io, (hipStream_t)stream)); return PHX_OK;
+  }
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));

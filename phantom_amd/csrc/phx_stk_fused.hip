@@ -14,6 +14,9 @@
 #include "phx_dev.h"
 
 #define STK_NT 256
+#ifndef STKR_NT
+#define STKR_NT 512    // rollout kernel: one block per env, ~2 agents per lane at 128 x 1024
+#endif
 
 // BuyerAgent.prices in compressed form.  Every Price a seller posts goes to ALL of its neighbours
 // in the same round (decode_action returns one message per ctx.neighbour_ids entry) and the
@@ -138,6 +141,174 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
     io.all_terminated[b] = 0; io.all_truncated[b] = terminal;
   }
+}
+
+// ---- T fused steps of the market (phx_rollout): the env's whole mutable state -- per seller
+// posted / price / revenue / tx, per buyer bought / paid, the per-agent reward cache -- lives in
+// LDS for the fragment; HBM sees the trajectory rows only.  Random policy (actions == NULL): the
+// acting agent's action word (word 2p + 1 of block 0 of its tick pair, the stream the supply
+// chain uses) mapped onto its action space: seller price U[0,1), buyer buy/skip with p = 1/2.
+// Auto-reset at the end of the terminal step (the caller's env.reset(), stackelberg.py:53-109).
+__global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int A = sp.A, B = sp.B;
+  const int nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER];
+  double* s_posted = (double*)smem;
+  double* s_price = s_posted + nSell;
+  double* s_rev = s_price + nSell;
+  double* s_cache = s_rev + nSell;                       // [A] self._rewards
+  double* s_paid = s_cache + A;                          // [nBuy]
+  int* s_tx = (int*)(s_paid + nBuy);
+  int* s_count = s_tx + nSell;
+  float* s_act = (float*)(s_count + nSell);              // [A] action taken this step (0: did not act)
+  uint8_t* s_sent = (uint8_t*)(s_act + A);
+  uint8_t* s_cv = s_sent + nSell;                        // [A] reward cache valid
+  uint8_t* s_bought = s_cv + A;                          // [nBuy]
+  const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy, abase = (int64_t)b * A;
+  const int64_t genv = sp.env_offset + b;
+
+  for (int k = tid; k < nSell; k += STKR_NT) {
+    s_posted[k] = fld<double>(sp, F_SELLER_POSTED)[sbase + k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
+    s_rev[k] = fld<double>(sp, F_SELLER_REVENUE)[sbase + k]; s_tx[k] = fld<int32_t>(sp, F_SELLER_TX)[sbase + k];
+  }
+  for (int k = tid; k < nBuy; k += STKR_NT) {
+    s_paid[k] = fld<double>(sp, F_BUYER_PAID)[bbase + k]; s_bought[k] = (uint8_t)fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + k];
+  }
+  for (int a = tid; a < A; a += STKR_NT) {
+    s_cache[a] = fld<double>(sp, F_ENV_REW_CACHE)[abase + a]; s_cv[a] = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[abase + a];
+  }
+  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
+  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  __syncthreads();
+
+  for (int t = 0; t < io.T; ++t) {
+    const int tt = step + 1;                                                 // env.py:252
+    const int list = (tt & 1) ? 0 : 1;                                       // stackelberg.py:133-137
+    const uint8_t* flags = sp.stk_flags + (int64_t)list * A;
+    const int64_t row = ((int64_t)t * B + b) * A;
+    for (int k = tid; k < nSell; k += STKR_NT) { s_count[k] = 0; s_sent[k] = 0; }
+    __syncthreads();
+    // ---- acting phase ---------------------------------------------------------------------------
+    for (int a = tid; a < A; a += STKR_NT) {
+      float action = 0.f;
+      if (flags[a] & 1) {
+        const uint32_t rec = sp.stk_rec[a];
+        const int kr = (int)(rec >> 16), deg = (int)((rec >> 8) & 255u);
+        const bool seller = (rec & 255u) == PHX_KIND_SELLER;
+        if (io.actions) action = io.actions[row + a];
+        else {
+          uint32_t w[4];
+          rng_block(sp.seed, genv, tick, a, 0, 0, w);
+          const uint32_t aw = (tick & 1u) ? w[3] : w[1];
+          action = seller ? (float)(aw >> 8) * (1.0f / 16777216.0f) : ((aw >> 31) ? 1.0f : 0.0f);
+        }
+        if (seller) { s_price[kr] = (double)action; s_sent[kr] = 1; }
+        else {
+          int bought = 0; double paid = 0.0;
+          if (action > 0.5f && deg > 0) {
+            const uint16_t* nb = sp.stk_nbr + kr;
+            int jr = nb[0]; double best = s_posted[jr];
+            for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
+            bought = 1; paid = best;
+            atomicAdd(&s_count[jr], 1);
+          }
+          s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;
+        }
+      }
+      s_act[a] = action;
+    }
+    __syncthreads();
+    // ---- pre_message_resolution + the single round --------------------------------------------------
+    for (int kr = tid; kr < nSell; kr += STKR_NT) {
+      double rev = s_rev[kr]; int tx = s_tx[kr];
+      if ((tt & 1) == 0) { rev = 0.0; tx = 0; }
+      const int n = s_count[kr];
+      if (n > 0) {
+        const double amount = __dmul_rn(s_price[kr], 1.0);
+        for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+        tx += n;
+      }
+      s_rev[kr] = rev; s_tx[kr] = tx;
+      if (s_sent[kr]) s_posted[kr] = s_price[kr];
+    }
+    __syncthreads();
+    // ---- obs / reward / flags -> trajectory row (stackelberg.py:142-196) -----------------------------
+    const bool terminal = (tt == sp.num_steps);
+    const bool last = (t == io.T - 1);
+    auto agent_out = [&](int a, float& ob0, float& ob1, float& rwf, uint8_t& ov, uint8_t& rv) {
+      const int fl = flags[a];
+      const uint32_t rec = sp.stk_rec[a];
+      const int kr = (int)(rec >> 16), deg = (int)((rec >> 8) & 255u);
+      const bool seller = (rec & 255u) == PHX_KIND_SELLER;
+      ob0 = 0.f; ob1 = 0.f; ov = 0;
+      if (fl & 2) {
+        ov = 1;
+        if (seller) { ob0 = (float)((double)s_tx[kr] / (double)(sp.row_ptr[a + 1] - sp.row_ptr[a])); ob1 = (float)s_price[kr]; }
+        else {
+          const uint16_t* nb = sp.stk_nbr + kr;
+          double mn = s_posted[nb[0]];
+          for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
+          ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
+        }
+      }
+      uint8_t cv = s_cv[a]; double cache = s_cache[a];
+      if (fl & 4) {
+        cache = seller ? s_rev[kr] : (s_bought[kr] ? __dsub_rn(sp.param_f[a * PHX_NPF], s_paid[kr]) : 0.0);
+        cv = 1; s_cache[a] = cache; s_cv[a] = 1;
+      }
+      rv = 0; double rw = 0.0;
+      if (terminal) { rv = cv ? 1 : 2; rw = cv ? cache : 0.0; }
+      else if (ov && cv) { rv = 1; rw = cache; }
+      rwf = (float)rw;
+    };
+    // (one agent per lane and iteration: packing four agents per lane for 16-byte stores was 30 %
+    //  slower -- the phase is bound by the dependent LDS lookups per agent, not by the stores)
+    for (int a = tid; a < A; a += STKR_NT) {
+      float ob0, ob1, rwf; uint8_t ov, rv;
+      agent_out(a, ob0, ob1, rwf, ov, rv);
+      const int64_t o = row + a;
+      *(float2*)(io.obs + o * 2) = make_float2(ob0, ob1);
+      io.action_out[o] = s_act[a];
+      io.reward[o] = rwf;
+      io.terminated[o] = 0; io.truncated[o] = terminal;
+      io.obs_valid[o] = ov; io.reward_valid[o] = rv;
+      if (last && io.last_obs) {
+        if (terminal) { ob0 = 0.f; ob1 = 0.f; }
+        *(float2*)(io.last_obs + (abase + a) * 2) = make_float2(ob0, ob1);
+      }
+    }
+    step = tt; ++tick;
+    __syncthreads();
+    if (terminal) {                                                          // the caller's env.reset()
+      for (int k = tid; k < nSell; k += STKR_NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
+      for (int k = tid; k < nBuy; k += STKR_NT) { s_paid[k] = 0.0; s_bought[k] = 0; }
+      for (int a = tid; a < A; a += STKR_NT) s_cv[a] = 0;
+      step = 0;
+      __syncthreads();
+    }
+  }
+  for (int k = tid; k < nSell; k += STKR_NT) {
+    fld<double>(sp, F_SELLER_POSTED)[sbase + k] = s_posted[k]; fld<double>(sp, F_SELLER_PRICE)[sbase + k] = s_price[k];
+    fld<double>(sp, F_SELLER_REVENUE)[sbase + k] = s_rev[k]; fld<int32_t>(sp, F_SELLER_TX)[sbase + k] = s_tx[k];
+  }
+  for (int k = tid; k < nBuy; k += STKR_NT) {
+    fld<double>(sp, F_BUYER_PAID)[bbase + k] = s_paid[k]; fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + k] = s_bought[k];
+  }
+  for (int a = tid; a < A; a += STKR_NT) {
+    fld<double>(sp, F_ENV_REW_CACHE)[abase + a] = s_cache[a]; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[abase + a] = s_cv[a];
+  }
+  if (tid == 0) { fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick; }
+}
+
+size_t phx_stk_rollout_lds(const DevSpec& sp) {
+  const size_t nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER], A = sp.A;
+  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell + A) + nSell + A + nBuy + 32;
+}
+
+hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  hipLaunchKernelGGL(phx_stk_rollout_kernel, dim3(sp.B), dim3(STKR_NT), phx_stk_rollout_lds(sp), st, sp, io);
+  return hipGetLastError();
 }
 
 // buyer.prices[b][k][r] = seller.posted[b][neighbour k of buyer r]

@@ -746,3 +746,41 @@ def test_stochastic_network_reference_kats():
     out = env.step_tensors(__import__("torch").ones(3, 6, device=d.device))
     assert (d.err.cpu().numpy() == 0).all()                      # nobody has a neighbour: nothing is sent
     assert (out.observations.cpu().numpy()[:, 2:, 0] == 1.0).all()   # buyers: min over no prices -> 1.0
+
+
+@pytest.mark.parametrize("L,Fw,d,B,T,num_steps", [(8, 32, 4, 10, 45, 12), (128, 1024, 8, 6, 14, 9), (5, 7, 2, 3, 30, 7)])
+def test_market_rollout_matches_oracle(L, Fw, d, B, T, num_steps):
+    """phx_rollout on the Stackelberg market: T fused steps with the whole env state in LDS, random
+    policy (seller price U[0,1), buyer buy/skip) or replayed actions, auto-reset -- vs the oracle."""
+    rng = np.random.RandomState(L + T)
+    S = L + Fw
+    for mode in ("device_rng", "replay"):
+        env = market_env(L, Fw, d, num_steps, B, seed=17, env_offset=5)
+        o, x = OracleEnv(env.spec), _dev(env.spec)
+        assert x.dev.uses_fused
+        o.reset(); x.reset()
+        a0 = np.zeros((B, S), np.float32); a0[:, :L] = rng.randint(1, 9, (B, L)) / 8.0
+        v0 = np.zeros((B, S), np.uint8); v0[:, :L] = 1
+        o.step(a0, v0, None); x.step(a0, v0, None)               # the fragment starts on a followers' step
+        acts = None
+        if mode == "replay":
+            acts = np.where(rng.rand(T, B, S) < 0.5, rng.randint(1, 9, (T, B, S)) / 8.0, 1.0).astype(np.float32)
+        ro, rd = o.rollout(T, acts, None), x.rollout(T, acts, None)
+        for k in ("obs_valid", "reward_valid", "truncated", "terminated"):
+            np.testing.assert_array_equal(rd[k], ro[k], err_msg=f"{k} {mode}")
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"{k} {mode}")
+        assert ro["truncated"].any() and (ro["reward_valid"] == 1).any() and (ro["rewards"] != 0).any()
+        for f in ("seller.tx", "buyer.bought", "env.step", "env.tick"):
+            np.testing.assert_array_equal(x.get_i32(f), o.get_i32(f), err_msg=f"{f} {mode}")
+        for f in ("seller.price", "seller.revenue", "buyer.paid", "buyer.prices"):
+            np.testing.assert_array_equal(f64_bits(x.get_f64(f)), f64_bits(o.get_f64(f)), err_msg=f"{f} {mode}")
+        # per-step launches continue identically after the fragment
+        odd = (o.get_i32("env.step")[:, 0] + 1) % 2 == 1
+        a1 = np.zeros((B, S), np.float32); v1 = np.zeros((B, S), np.uint8)
+        a1[:, :L] = 0.25; a1[:, L:] = 1.0
+        v1[odd, :L] = 1; v1[~odd, L:] = 1
+        o.step(a1, v1, None); x.step(a1, v1, None)
+        np.testing.assert_array_equal(f32_bits(x.obs), f32_bits(o.obs))
+        np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward))
+        np.testing.assert_array_equal(x.reward_valid, o.reward_valid)

@@ -77,6 +77,22 @@ def main():
                     us_per_step_events=us, us_per_step_wall=wall, agent_steps_per_s=S * B / (us * 1e-6)))
     print(json.dumps(out[-1]), flush=True)
 
+    # config 5 as a fused rollout (T = 50 steps per launch, whole env state in LDS)
+    T = 50
+    traj = d.rollout(T)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        d.rollout(T, out=traj)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / (4 * T) * 1e3
+    nbytes = sum(x.numel() * x.element_size() for x in traj if x is not None and x is not traj.last_obs)
+    out.append(dict(config=f"STK 128x1024 B={B} rollout T={T}", engine="fused", agents=S, batch=B,
+                    us_per_step_events=us, us_per_step_wall=us, agent_steps_per_s=S * B / (us * 1e-6),
+                    trajectory_GBps=nbytes / T / (us * 1e-6) / 1e9))
+    print(json.dumps(out[-1]), flush=True)
+
 
 if __name__ == "__main__":
     main()
