@@ -20,6 +20,8 @@
 //     compacts the responses into the next round's queue = the order network.send was called.
 // Queues live in LDS (template LDSQ = true); envs whose queue does not fit use a per-env
 // workspace carved from the caller's state blob.
+#include <cstdlib>
+
 #include "phx_dev.h"
 #include "phx_epilogue.h"
 
@@ -558,18 +560,18 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   const bool tablds = lds && tab <= 24 * 1024 && bytes + tab <= 60 * 1024;
   g.tab_off = (int32_t)bytes;
   if (tablds) bytes += tab;
-  const int big = (sp.A > 64 || sp.queue_cap > 64);
-  if (lds) {
-    if (tablds) {
-      if (big) hipLaunchKernelGGL((phx_generic_step_kernel<256, true, true>), dim3(sp.B), dim3(256), bytes, st, sp, g);
-      else hipLaunchKernelGGL((phx_generic_step_kernel<64, true, true>), dim3(sp.B), dim3(64), bytes, st, sp, g);
-    } else {
-      if (big) hipLaunchKernelGGL((phx_generic_step_kernel<256, true, false>), dim3(sp.B), dim3(256), bytes, st, sp, g);
-      else hipLaunchKernelGGL((phx_generic_step_kernel<64, true, false>), dim3(sp.B), dim3(64), bytes, st, sp, g);
-    }
-  } else {
-    hipLaunchKernelGGL((phx_generic_step_kernel<256, false, false>), dim3(sp.B), dim3(256), 0, st, sp, g);
-  }
+  // threads per env: one wave while the agents fit it (the barriers of a single-wave workgroup are
+  // free and a CU holds sixteen of them), two waves for wider envs.  Measured at 64 / 128 / 256:
+  // SC64 B=4096 40 / 63 / 94 us per step, SC256-FSM B=8192 819 / 727 / 743 us.  (Keeping the env's
+  // agent state in LDS for the step was measured too: no gain, the wave is instruction-bound --
+  // about 6 000 instructions and 90 memory operations per env-step at SC64.)
+  static const int nt_env = getenv("PHX_GENERIC_NT") ? atoi(getenv("PHX_GENERIC_NT")) : 0;
+  int nt = nt_env ? nt_env : (sp.A <= 64 ? 64 : 128);
+#define PHX_LAUNCH_GENERIC(NT_, L_, T_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_>), dim3(sp.B), dim3(NT_), bytes, st, sp, g)
+  if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
+  else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, true); else PHX_LAUNCH_GENERIC(256, true, true); }
+  else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, false); else PHX_LAUNCH_GENERIC(256, true, false); }
+#undef PHX_LAUNCH_GENERIC
   return hipGetLastError();
 }
 
