@@ -784,3 +784,19 @@ def test_market_rollout_matches_oracle(L, Fw, d, B, T, num_steps):
         np.testing.assert_array_equal(f32_bits(x.obs), f32_bits(o.obs))
         np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward))
         np.testing.assert_array_equal(x.reward_valid, o.reward_valid)
+
+
+def test_rollout_with_per_env_tick_parities():
+    """one Philox block serves a tick PAIR; envs of one workgroup whose tick counters differ in parity
+    (possible after per-env state surgery) pair their rows differently -- still the oracle's stream."""
+    B, S, K, T = 24, 9, 6, 37
+    env = supply_chain_env(S, [K] * S, 10, B, seed=6, env_offset=11)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    ticks = (np.arange(B, dtype=np.int32) * 7 + 3) % 23            # mixed parities inside every block
+    o.set_i32("env.tick", ticks); d.set_i32("env.tick", ticks.reshape(B, 1))
+    ro, rd = o.rollout(T, None, None), d.rollout(T, None, None)
+    for k in ("obs", "actions", "rewards", "last_obs"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+    np.testing.assert_array_equal(d.get_i32("env.tick")[:, 0], ticks + T)
