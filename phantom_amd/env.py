@@ -309,8 +309,12 @@ class PhantomEnv:
         dev = self._device().device
         return torch.from_numpy(act).to(dev), torch.from_numpy(valid).to(dev)
 
-    def step(self, actions: Mapping[AgentID, Any]) -> "PhantomEnv.Step":
-        """env.py:239-303 for every env instance of the batch, in one kernel launch."""
+    def step(self, actions: Mapping[AgentID, Any]):
+        """env.py:239-303 for every env instance of the batch, in one kernel launch.  A Mapping
+        returns the reference's ``Step`` of dicts; a device tensor f32 [B, S] (strategic agents in
+        agent order) takes the tensor-native path and returns ``StepTensors`` (see step_tensors)."""
+        if not isinstance(actions, Mapping) and hasattr(actions, "data_ptr"):
+            return self.step_tensors(actions)
         dev = self._device()
         act, valid = self._actions_tensor(actions)
         exo = self._draw_exo()

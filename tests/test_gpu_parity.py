@@ -743,7 +743,7 @@ def test_stochastic_network_reference_kats():
     d = env._device()
     env.reset()
     assert (d.field("net.conn_on").cpu().numpy() == 0).all()
-    out = env.step_tensors(__import__("torch").ones(3, 6, device=d.device))
+    out = env.step(__import__("torch").ones(3, 6, device=d.device))      # tensor in -> StepTensors out
     assert (d.err.cpu().numpy() == 0).all()                      # nobody has a neighbour: nothing is sent
     assert (out.observations.cpu().numpy()[:, 2:, 0] == 1.0).all()   # buyers: min over no prices -> 1.0
 
