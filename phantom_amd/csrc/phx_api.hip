@@ -570,6 +570,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EINVAL, "bad rollout io");
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
+  if (e->use_fused && e->d.max_cust >= 65535) return fail(PHX_EUNSUPPORTED, "phx_rollout: at most 65534 customers per shop");
   HIPCHK(use_device(e));
   if (e->use_stk) {
     if (io->exo) return fail(PHX_EINVAL, "the market has no exogenous draws");

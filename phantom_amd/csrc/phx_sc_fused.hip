@@ -254,10 +254,10 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   // LDS carve (all offsets multiples of 16 bytes)
   const int items_max = TC * Gfull;
   const int it1 = (items_max + 3) & ~3, it_words = 3 * it1;
-  int* s_it0 = (int*)smem;                                 // 2 x 3 planes [TC][G]: R | stock, D, sales
+  int* s_it0 = (int*)smem;                                 // 2 x 3 planes [TC][G]: R | stock, D | missed, sales
   float* s_act0 = (float*)(s_it0 + 2 * it_words);          // 2 x [TC][G]
-  uint16_t* s_pair = (uint16_t*)(s_act0 + 2 * it1);        // [G] shop | env_local << 8
-  int* s_tick0 = (int*)(s_pair + ((Gfull + 7) & ~7));     // [epb]
+  uint32_t* s_pair = (uint32_t*)(s_act0 + 2 * it1);        // [G] shop | env_local << 8 | customers << 16
+  int* s_tick0 = (int*)(s_pair + ((Gfull + 3) & ~3));     // [epb]
   int* s_step0 = s_tick0 + ((a.epb + 3) & ~3);             // [epb]
   int* s_tend = s_step0 + ((a.epb + 3) & ~3);              // [epb] chunk-local step index that ends the episode, or -1
   int* s_cptr = s_tend + ((a.epb + 3) & ~3);               // [S+1]
@@ -268,7 +268,10 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   const double* s_pen = (const double*)(s_tabn + a.n_tabn);   // 0.1 * stock, f64
   for (int k = tid; k < n_tab; k += NT) s_tab[k] = a.sc_tab[k];
 
-  for (int gl = tid; gl < G; gl += NT) s_pair[gl] = (uint16_t)((gl % nS) | ((gl / nS) << 8));
+  for (int gl = tid; gl < G; gl += NT) {
+    const int s2 = gl % nS, kk = a.shop_cust_ptr[s2 + 1] - a.shop_cust_ptr[s2];
+    s_pair[gl] = (uint32_t)s2 | ((uint32_t)(gl / nS) << 8) | ((uint32_t)(kk < 65535 ? kk : 65535) << 16);
+  }
   for (int bl = tid; bl < nb; bl += NT) { s_tick0[bl] = a.env_tick[b_first + bl]; s_step0[bl] = a.env_step[b_first + bl]; }
   for (int k = tid; k <= nS; k += NT) s_cptr[k] = a.shop_cust_ptr[k];
   for (int k = tid; k < nS; k += NT) s_norm[k] = a.shop_norm[k];
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
     int jr = wt / G, gl = wt - jr * G;
     const int qG = nw / G, rG = nw - qG * G;
     for (int iw = wt; iw < n_work; iw += nw) {
-      const int pr = s_pair[gl], s = pr & 255, bl = pr >> 8;
+      const uint32_t pr = s_pair[gl];
+      const int s = (int)(pr & 255u), bl = (int)((pr >> 8) & 255u);
       const int b = (int)b_first + bl;
       const int64_t genv = a.env_offset + b;
       const uint32_t tick_base = (uint32_t)s_tick0[bl] + (uint32_t)t0;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       const bool va = tla >= 0 && tla < tc, vb = tla + 1 < tc;
       if (va || vb) {
         const uint32_t tick_a = tick_base + (uint32_t)tla;           // even
-        const int c_lo = s_cptr[s], c_hi = s_cptr[s + 1], K = c_hi - c_lo;
+        const int K = (int)(pr >> 16);
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         if (!(REPLAY && io.exo && io.actions)) rng_block(a.seed, genv, tick_a, s, 0, 0, w);
 #pragma unroll
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
           int D = 0;
           if (REPLAY && io.exo) {
             const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
-            for (int k = c_lo; k < c_hi; ++k) D += row[a.shop_cust_exo[k]];
+            for (int k = s_cptr[s]; k < s_cptr[s + 1]; ++k) D += row[a.shop_cust_exo[k]];
           } else if (K > 0) {
             uint32_t y;
             if (!rng_word_to_y(w[2 * h], y)) y = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1);   // 3.3e-6
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
         req = min((R_), PHX_SHOP_MAX_STOCK - x);                  /* decode_action         :139 */     \
         sales = x - a0;                                                                          \
         const int xn = min(a0 + req, PHX_SHOP_MAX_STOCK);         /* handle_stock_response :98-103 */  \
-        (it_)[0] = xn; (it_)[2 * it1] = sales;                                                   \
+        (it_)[0] = xn; (it_)[it1] = (HASK || hasK) ? Dl - sales : 0; (it_)[2 * it1] = sales;       \
         x = xn & keep;                                                                           \
       }
       int tl = 0;
@@ -405,19 +409,24 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
     // dwordx4 stores -- no staging of the outputs in LDS and no second pass.
     const int64_t row0 = (int64_t)t0 * total + g_base;           // element offset of tile row 0
     const int64_t rstride = total;
-    auto item_out = [&](int stock, int D, int sales, int s, float* ob, float& rew) {
-      const int missed = (s_cptr[s + 1] > s_cptr[s]) ? D - sales : 0;
-      // observation / reward from the host-built tables when the operands are in their usual
-      // range; otherwise (negative stock from negative requests, ...) the formulas themselves:
-      // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24
-      const float norm = (float)s_norm[s];
+    auto item_out = [&](int stock, int missed, int sales, int s, float* ob, float& rew) {
+      // observation / reward from the host-built tables (= the reference's formulas evaluated on
+      // the host) when the operands are in their usual range; otherwise (negative stock from
+      // negative requests, ...) the formulas themselves: f32 IEEE division == the reference's f64
+      // quotient cast to f32 for |ints| < 2^24
       const bool in100 = (unsigned)stock <= 100u;
-      ob[0] = in100 ? s_tab[in100 ? stock : 0] : (float)stock / (float)PHX_SHOP_MAX_STOCK;
       const bool ins = (unsigned)sales < (unsigned)a.n_quot, inm = (unsigned)missed < (unsigned)a.n_quot;
-      ob[1] = ins ? s_tabn[ins ? sales : 0] : (float)sales / norm;
-      ob[2] = inm ? s_tabn[inm ? missed : 0] : (float)missed / norm;
-      // reward = sales - 0.1 * stock in f64 (supply_chain.py:147), rounded once to the trajectory's f32
-      rew = in100 ? (float)__dsub_rn((double)sales, s_pen[in100 ? stock : 0]) : (float)shop_reward(sales, stock);
+      if (in100 && ins && inm) {
+        ob[0] = s_tab[stock]; ob[1] = s_tabn[sales]; ob[2] = s_tabn[missed];
+        // reward = sales - 0.1 * stock in f64 (supply_chain.py:147), rounded once to the trajectory's f32
+        rew = (float)__dsub_rn((double)sales, s_pen[stock]);
+      } else {
+        const float norm = (float)s_norm[s];
+        ob[0] = in100 ? s_tab[in100 ? stock : 0] : (float)stock / (float)PHX_SHOP_MAX_STOCK;
+        ob[1] = ins ? s_tabn[ins ? sales : 0] : (float)sales / norm;
+        ob[2] = inm ? s_tabn[inm ? missed : 0] : (float)missed / norm;
+        rew = in100 ? (float)__dsub_rn((double)sales, s_pen[in100 ? stock : 0]) : (float)shop_reward(sales, stock);
+      }
     };
     if (WIDE) {
       const int G4 = G >> 2;
@@ -425,8 +434,8 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
         const int r = (int)__umulhi((uint32_t)u, a.mF);          // u / G4
         const int c4 = u - r * G4, gl0 = c4 << 2, i0 = r * G + gl0;
         const uint4 vs = *(const uint4*)(s_it + i0), vd = *(const uint4*)(s_it + it1 + i0), vl = *(const uint4*)(s_it + 2 * it1 + i0);
-        const uint2 pp = *(const uint2*)(s_pair + gl0);
-        const int p0 = pp.x & 0xffff, p1 = pp.x >> 16, p2 = pp.y & 0xffff, p3 = pp.y >> 16;
+        const uint4 pp = *(const uint4*)(s_pair + gl0);
+        const int p0 = (int)(pp.x & 0xffffu), p1 = (int)(pp.y & 0xffffu), p2 = (int)(pp.z & 0xffffu), p3 = (int)(pp.w & 0xffffu);
         float o[12], rw[4];
         item_out((int)vs.x, (int)vd.x, (int)vl.x, p0 & 255, o + 0, rw[0]);
         item_out((int)vs.y, (int)vd.y, (int)vl.y, p1 & 255, o + 3, rw[1]);
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       int tl = tid / G, gl = tid - tl * G;
       const int qG = NT / G, rG = NT - qG * G;
       for (int i = tid; i < n_items; i += NT) {
-        const int pr = s_pair[gl];
+        const int pr = (int)(s_pair[gl] & 0xffffu);
         float o[3], rw;
         item_out(s_it[i], s_it[it1 + i], s_it[2 * it1 + i], pr & 255, o, rw);
         const int64_t e0 = row0 + (int64_t)tl * rstride + gl;
@@ -677,7 +686,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 4);
   const int items = TC * G;
   const size_t lds = (size_t)((items + 3) & ~3) * 4 * 3 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
-                     (size_t)((G + 7) & ~7) * 2 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
+                     (size_t)((G + 3) & ~3) * 4 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
                      (size_t)((sp.S + 3) & ~3) * 4 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
   a.epb = epb; a.TC = TC;
   const dim3 grid((sp.B + epb - 1) / epb);
