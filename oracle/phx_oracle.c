@@ -207,41 +207,41 @@ void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 /* Device-RNG definition (build-owned; replaces the global numpy stream when exo == NULL).
  * np.random.randint(5) is exactly uniform on {0..4} (numpy draws 3 bits and rejects > 4).  The
  * device stream is exactly uniform too.  One Philox4x32-10 block
- *     ctr = (env_lo, env_hi | attempt << 16, tick >> 1, shop | blk << 20),  key = seed
- * serves two consecutive ticks of a shop.  With p = tick & 1, block 0 holds the order word of
- * customers 0..5 in word 2p and the shop's random-policy action in word 2p + 1; customers
- * 6g .. 6g+5 (g >= 1) own word x % 4 of block 1 + x / 4 with x = 2 (g - 1) + p.  An order word u
- * is rejected iff low32(u * 5^6) < 2^32 mod 5^6 = 14171 (then redrawn at the same position with
- * attempt + 1); otherwise y = (u * 5^6) >> 32 is uniform on [0, 5^6) and customer j of the group
- * orders base-5 digit j of y.                                                                */
-static uint32_t rng_word(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk, int word,
-                         uint32_t attempt) {
+ *     ctr = (env_lo, env_hi | attempt << 16, tick >> 2, shop | g << 20),  key = seed
+ * serves four consecutive ticks of customer group g (customers 6g .. 6g+5) of a shop; tick t owns
+ * word t & 3.  With m = u * 5^6, a word u is rejected iff low32(m) < 2^32 mod 5^6 = 14171 (then
+ * redrawn at the same position with attempt + 1); every y = m >> 32 in [0, 5^6) is hit by exactly
+ * 274877 consecutive accepted words, so y and the rank j = (low32(m) - 14171) / 5^6 of the word
+ * among them are independent and exactly uniform.  Customer i of the group orders base-5 digit i
+ * of y; group 0's j is the shop's random-policy action, j * (100 / 274877).                     */
+static uint32_t rng_word(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g, uint32_t attempt) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 1,
-                     (uint32_t)shop | ((uint32_t)blk << 20)};
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 2,
+                     (uint32_t)shop | ((uint32_t)g << 20)};
   uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
-  return w[word];
+  return w[tick & 3u];
 }
-static uint32_t rng_group_y(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g) {
-  const int p = (int)(tick & 1u);
-  int blk = 0, word = 2 * p;
-  if (g > 0) { int x = 2 * (g - 1) + p; blk = 1 + x / 4; word = x % 4; }
+static uint32_t rng_group_y(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g, uint32_t* j) {
   for (uint32_t attempt = 0;; ++attempt) {
-    uint64_t m = (uint64_t)rng_word(seed, genv, tick, shop, blk, word, attempt) * 15625u;
-    if ((uint32_t)m >= 14171u) return (uint32_t)(m >> 32);
+    uint64_t m = (uint64_t)rng_word(seed, genv, tick, shop, g, attempt) * 15625u;
+    uint32_t l = (uint32_t)m;
+    if (l >= 14171u) { if (j) *j = (l - 14171u) / 15625u; return (uint32_t)(m >> 32); }
   }
 }
 void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out) {
   for (int k = 0; k < K; ++k) {
-    uint32_t y = rng_group_y(seed, genv, tick, shop, k / 6);
-    for (int j = 0; j < k % 6; ++j) y /= 5u;
+    uint32_t y = rng_group_y(seed, genv, tick, shop, k / 6, NULL);
+    for (int i = 0; i < k % 6; ++i) y /= 5u;
     out[k] = (uint8_t)(y % 5u);
   }
 }
-/* random policy of the rollout: U[0,100) from the top 24 bits of the shop's action word */
+/* rank j of the agent's word of this tick */
+uint32_t phxo_rng_rank(uint64_t seed, int64_t genv, uint32_t tick, int agent) {
+  uint32_t j; rng_group_y(seed, genv, tick, agent, 0, &j); return j;
+}
+/* random policy of the rollout for a shop: U[0,100) */
 float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int shop) {
-  uint32_t w = rng_word(seed, genv, tick, shop, 0, 2 * (int)(tick & 1u) + 1, 0);
-  return (float)(w >> 8) * (100.0f / 16777216.0f);
+  return (float)phxo_rng_rank(seed, genv, tick, shop) * (100.0f / 274877.0f);
 }
 
 /* Device draw of UniformFloatSampler column j at the env's `episode`-th reset (build-owned
@@ -933,15 +933,16 @@ void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
   E->n_injected = 0;
 }
 
-/* random policy of a rollout (build-owned): the strategic agent's action word of this tick (word
- * 2p + 1 of its block 0, see the device-RNG definition) mapped onto the kind's action space:
- * ShopAgent U[0,100) (Box(0, SHOP_MAX_STOCK)), Seller price U[0,1), Buyer buy/skip with p = 1/2. */
+/* random policy of a rollout (build-owned): the strategic agent's word of this tick (see the
+ * device-RNG definition: its rank j in [0, 274877)) mapped onto the kind's action
+ * space: ShopAgent j * 100 / 274877 (Box(0, SHOP_MAX_STOCK)), Seller price j / 274877, Buyer buys
+ * iff j < 137438 (p = 1/2).                                                                          */
 static float policy_action(const phxo_env* E, const oenv* e, int b, int s) {
   const int kind = E->s.kind[E->strat_idx[s]];
-  const uint32_t w = rng_word(E->s.seed, E->s.env_offset + b, e->tick, s, 0, 2 * (int)(e->tick & 1u) + 1, 0);
-  if (kind == PHX_KIND_SELLER) return (float)(w >> 8) * (1.0f / 16777216.0f);
-  if (kind == PHX_KIND_BUYER) return (w >> 31) ? 1.0f : 0.0f;
-  return (float)(w >> 8) * (100.0f / 16777216.0f);
+  const uint32_t j = phxo_rng_rank(E->s.seed, E->s.env_offset + b, e->tick, s);
+  if (kind == PHX_KIND_SELLER) return (float)j * (1.0f / 274877.0f);
+  if (kind == PHX_KIND_BUYER) return j < 137438u ? 1.0f : 0.0f;
+  return (float)j * (100.0f / 274877.0f);
 }
 
 /* rollout = the list-of-envs loop of utils/rllib/rollout.py:361-363, with the caller's

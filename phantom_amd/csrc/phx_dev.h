@@ -205,43 +205,45 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // Device RNG (definition restated in oracle/phx_oracle.c and DESIGN.md).  One Philox block
-//     ctr = (env_lo, env_hi | attempt << 16, tick >> 1, shop | blk << 20), key = seed
-// serves TWO consecutive ticks of a shop.  With p = tick & 1, block 0 holds
-//     word 2p     the order word of customers 0..5        word 2p + 1   the random-policy action
-// and customers 6g .. 6g+5 (g >= 1) own word x % 4 of block 1 + x / 4, x = 2 (g - 1) + p.
-// An order word u yields SIX exactly uniform order sizes: y = (u * 5^6) >> 32 is uniform on
-// [0, 5^6) once the words with low32(u * 5^6) < 2^32 mod 5^6 = 14171 are rejected (Lemire; a
-// rejected word is redrawn at the same position with attempt + 1, probability 3.3e-6), and
-// customer j of the group takes base-5 digit j of y.  The action is U[0,100) from the top 24 bits.
+//     ctr = (env_lo, env_hi | attempt << 16, tick >> 2, shop | g << 20), key = seed
+// serves FOUR consecutive ticks of customer group g (customers 6g .. 6g+5) of a shop: tick t owns
+// word t & 3.  One 32-bit word u yields six exactly uniform order sizes AND (group 0) the shop's
+// random-policy action: with m = u * 5^6, the words with low32(m) < 2^32 mod 5^6 = 14171 are
+// rejected (Lemire; redrawn at the same position with attempt + 1, probability 3.3e-6); every
+// y = m >> 32 in [0, 5^6) is then hit by exactly 274877 consecutive words, so y and the word's
+// rank j = (low32(m) - 14171) / 5^6 in [0, 274877) are independent and exactly uniform.  Customer
+// i of the group orders base-5 digit i of y; the action is j * (100 / 274877) in [0, 100).
 #define PHX_RNG_P6   15625u
 #define PHX_RNG_REJ  14171u
-__device__ __forceinline__ void rng_block(uint64_t seed, int64_t genv, uint32_t tick, int shop, int blk,
+#define PHX_RNG_NJ   274877u
+__device__ __forceinline__ void rng_block(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g,
                                           uint32_t attempt, uint32_t w[4]) {
-  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 1,
-                (uint32_t)shop | ((uint32_t)blk << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 2,
+                (uint32_t)shop | ((uint32_t)g << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
 }
-// u -> y, false when the word is rejected
-__device__ __forceinline__ bool rng_word_to_y(uint32_t u, uint32_t& y) {
+// u -> (y, j), false when the word is rejected.  (x / 5^6 == umulhi(x, 2251799814) >> 13 for every
+// 32-bit x: ceil(2^45 / 5^6) with error 4918 <= 2^13.)
+__device__ __forceinline__ bool rng_split(uint32_t u, uint32_t& y, uint32_t& j) {
   const uint64_t m = (uint64_t)u * PHX_RNG_P6;
+  const uint32_t l = (uint32_t)m;
   y = (uint32_t)(m >> 32);
-  return (uint32_t)m >= PHX_RNG_REJ;
+  j = __umulhi(l - PHX_RNG_REJ, 2251799814u) >> 13;
+  return l >= PHX_RNG_REJ;
 }
-__device__ __forceinline__ void rng_group_pos(int g, uint32_t tick, int& blk, int& word) {
-  const int p = (int)(tick & 1u);
-  if (g == 0) { blk = 0; word = 2 * p; }
-  else { const int x = 2 * (g - 1) + p; blk = 1 + (x >> 2); word = x & 3; }
+__device__ __forceinline__ uint32_t rng_pick(const uint32_t w[4], uint32_t tick) {
+  const uint32_t k = tick & 3u;
+  return k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
 }
-// y of customer group g, starting at `attempt0` (the cold / generic path: one Philox call per try)
+// (y, j) of customer group g, starting at `attempt0` (the cold / generic path: one Philox call per try)
 __device__ __forceinline__ uint32_t rng_group_y(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g,
-                                                uint32_t attempt0) {
-  int blk, word; rng_group_pos(g, tick, blk, word);
+                                                uint32_t attempt0, uint32_t* jout = nullptr) {
   for (uint32_t attempt = attempt0;; ++attempt) {
-    uint32_t w[4], y;
-    rng_block(seed, genv, tick, shop, blk, attempt, w);
-    const uint32_t u = word == 0 ? w[0] : (word == 1 ? w[1] : (word == 2 ? w[2] : w[3]));
-    if (rng_word_to_y(u, y)) return y;
+    uint32_t w[4], y, j;
+    rng_block(seed, genv, tick, shop, g, attempt, w);
+    if (rng_split(rng_pick(w, tick), y, j)) { if (jout) *jout = j; return y; }
   }
 }
+__device__ __forceinline__ float rng_j_to_action(uint32_t j) { return (float)j * (100.0f / 274877.0f); }
 // x / 5 for x < 2^16 through f32: x * 0.2f carries a relative error < 2^-23, far below the 0.2 gap
 // to the next integer boundary, and 0.2f > 0.2 keeps exact multiples on the right side; the same
 // holds for 0.04f .. 0.00032f on [0, 5^6) (all checked exhaustively in tests/test_host_logic.py).
@@ -253,30 +255,32 @@ __device__ __forceinline__ int rng_digit_sum6(uint32_t y) {
                      (uint32_t)(yf * 0.0016f) + (uint32_t)(yf * 0.00032f);
   return (int)(y - (q << 2));
 }
-// sum of digits j in [0, n) selected by mask (NULL = all); n <= 6
+// sum of digits i in [0, n) selected by mask (NULL = all); n <= 6
 __device__ __forceinline__ int rng_digit_sum(uint32_t y, int n, const uint8_t* actmask) {
   int sum = 0;
-  for (int j = 0; j < n; ++j) {
+  for (int i = 0; i < n; ++i) {
     const uint32_t q = rng_div5(y);
-    if (actmask == nullptr || actmask[j] != 0) sum += (int)(y - 5u * q);
+    if (actmask == nullptr || actmask[i] != 0) sum += (int)(y - 5u * q);
     y = q;
   }
   return sum;
 }
 // one customer's draw (generic engine)
 __device__ __forceinline__ int rng_customer_order(uint64_t seed, int64_t genv, uint32_t tick, int shop, int k) {
-  const int g = k / 6, j = k - g * 6;
+  const int g = k / 6, i = k - g * 6;
   uint32_t y = rng_group_y(seed, genv, tick, shop, g, 0);
-  for (int i = 0; i < j; ++i) y = rng_div5(y);
+  for (int q = 0; q < i; ++q) y = rng_div5(y);
   return (int)(y - 5u * rng_div5(y));
 }
-// order sum of a shop's K customers (those selected by `actmask`, NULL = all) given block 0 of
-// its tick pair (w); further groups and the rare redraw fetch their own blocks
+// order sum of a shop's K customers (those selected by `actmask`, NULL = all) given group 0's block of
+// its tick quad (w); *act_j = the action rank of this tick.  Further groups and the rare redraw
+// fetch their own blocks.
 __device__ __forceinline__ int rng_orders_from_block(const uint32_t w[4], uint64_t seed, int64_t genv, uint32_t tick,
-                                                     int shop, int K, const uint8_t* actmask) {
+                                                     int shop, int K, const uint8_t* actmask, uint32_t* act_j) {
+  uint32_t y, j;
+  if (!rng_split(rng_pick(w, tick), y, j)) y = rng_group_y(seed, genv, tick, shop, 0, 1, &j);   // probability 3.3e-6
+  if (act_j) *act_j = j;
   if (K <= 0) return 0;
-  uint32_t y;
-  if (!rng_word_to_y((tick & 1u) ? w[2] : w[0], y)) y = rng_group_y(seed, genv, tick, shop, 0, 1);   // probability 3.3e-6
   int sum = (actmask == nullptr && __all(K >= 6)) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, actmask);
   for (int g = 1; 6 * g < K; ++g)
     sum += rng_digit_sum(rng_group_y(seed, genv, tick, shop, g, 0), K - 6 * g < 6 ? K - 6 * g : 6,
@@ -284,25 +288,24 @@ __device__ __forceinline__ int rng_orders_from_block(const uint32_t w[4], uint64
   return sum;
 }
 // Sum over the shop's K customers (those selected by `actmask`, NULL = all), or with kth >= 0 only
-// customer kth's draw; *act_word = the shop's action word of this tick.
+// customer kth's draw; *act_j = the shop's action rank of this tick.
 __device__ __forceinline__ int rng_shop_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop,
                                                int K, const uint8_t* actmask, int kth,
-                                               uint32_t* act_word = nullptr) {
+                                               uint32_t* act_j = nullptr) {
   if (kth >= 0) return rng_customer_order(seed, genv, tick, shop, kth);
   uint32_t w[4];
   rng_block(seed, genv, tick, shop, 0, 0, w);
-  if (act_word) *act_word = (tick & 1u) ? w[3] : w[1];
-  return rng_orders_from_block(w, seed, genv, tick, shop, K, actmask);
+  return rng_orders_from_block(w, seed, genv, tick, shop, K, actmask, act_j);
 }
 // all K customers, sum only (same definition)
 __device__ __forceinline__ int rng_shop_order_sum(uint64_t seed, int64_t genv, uint32_t tick, int shop,
-                                                  int K, uint32_t* act_word) {
-  return rng_shop_orders(seed, genv, tick, shop, K, nullptr, -1, act_word);
+                                                  int K, uint32_t* act_j) {
+  return rng_shop_orders(seed, genv, tick, shop, K, nullptr, -1, act_j);
 }
-// block 0 of a shop's tick pair, kept across the two ticks by kernels that walk time in order
-struct RngPairCache { uint32_t w[4]; uint32_t q; };
-__device__ __forceinline__ void rng_pair_block(RngPairCache& c, uint64_t seed, int64_t genv, uint32_t tick, int shop) {
-  if ((tick >> 1) != c.q) { rng_block(seed, genv, tick, shop, 0, 0, c.w); c.q = tick >> 1; }
+// group 0's block of a shop's tick quad, kept across the four ticks by kernels that walk time in order
+struct RngQuadCache { uint32_t w[4]; uint32_t q; };
+__device__ __forceinline__ void rng_quad_block(RngQuadCache& c, uint64_t seed, int64_t genv, uint32_t tick, int shop) {
+  if ((tick >> 2) != c.q) { rng_block(seed, genv, tick, shop, 0, 0, c.w); c.q = tick >> 2; }
 }
 
 // UniformFloatSampler column j at the env's `episode`-th reset (definition restated in
@@ -344,10 +347,6 @@ __device__ __forceinline__ double dev_sample_column(const DevSpec& sp, int b, in
 __device__ __forceinline__ double shop_type_value(const DevSpec& sp, int b, int s) {
   const int src = sp.shop_type_src[s];
   return src >= 0 ? fld<double>(sp, F_ENV_SAMPLER)[(int64_t)b * sp.n_samplers + src] : sp.shop_type_prm[2 * s];
-}
-
-__device__ __forceinline__ float rng_word_to_action(uint32_t w3) {
-  return (float)(w3 >> 8) * (100.0f / 16777216.0f);
 }
 
 // int(round(np.float32(a))) -- round-half-to-even, supply_chain.py:139.  rintf of an f32 value is

@@ -230,7 +230,7 @@ __device__ __forceinline__ void lds_barrier() {
 // WIDE:   every block owns exactly epb envs and every tile row is 16-byte aligned (host-checked),
 //         so the copy-out uses dwordx4 / dwordx2 stores and magic-number row arithmetic only.
 template <int NT, bool REPLAY, bool WIDE>
-__global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 6 : 4))) void phx_sc_rollout_kernel(const RollArgs a) {
+__global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 6 : (NT == 320 ? 5 : 4)))) void phx_sc_rollout_kernel(const RollArgs a) {
   // Software pipeline over chunks of TC steps.  Phase 1 (Philox draws) of chunk c + 1 does not
   // depend on the stock recurrence, so it runs on waves P1W.. while waves 0..P2W-1 walk the
   // recurrence (phase 2) of chunk c; item tiles {R|stock, D, sales} and the action tile are
@@ -294,15 +294,15 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   TICK(0);
 
   // ---- phase 1 of the chunk starting at step t0 (tc rows) into buffer `buf`, by threads
-  //      [first, NT).  One Philox block serves the two ticks (2q, 2q + 1) of a shop, so the flat
-  //      work items are (row pair jr, pair gl): rows tla = 2 jr - e and tla + 1 of the chunk, e =
-  //      parity of the env's tick at chunk row 0.  Thread-strided; (jr, gl) advance incrementally.
+  //      [first, NT).  One Philox block serves the four ticks (4q .. 4q + 3) of a shop, so the flat
+  //      work items are (row quad jr, pair gl): rows tla = 4 jr - e .. tla + 3 of the chunk, e =
+  //      the env's tick at chunk row 0 modulo 4.  Thread-strided; (jr, gl) advance incrementally.
   auto phase1 = [&](int t0, int tc, int buf, int first) {
     if (tid < first) return;
     int* s_it = s_it0 + buf * it_words;
     float* s_act = s_act0 + buf * it1;
     const int nw = NT - first, wt = tid - first;
-    const int npr = (tc >> 1) + 1;
+    const int npr = ((tc + 3) >> 2) + 1;
     const int n_work = npr * G;
     int jr = wt / G, gl = wt - jr * G;
     const int qG = nw / G, rG = nw - qG * G;
@@ -312,32 +312,31 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       const int b = (int)b_first + bl;
       const int64_t genv = a.env_offset + b;
       const uint32_t tick_base = (uint32_t)s_tick0[bl] + (uint32_t)t0;
-      const int e = (int)(tick_base & 1u);
-      const int tla = 2 * jr - e;
-      const bool va = tla >= 0 && tla < tc, vb = tla + 1 < tc;
-      if (va || vb) {
-        const uint32_t tick_a = tick_base + (uint32_t)tla;           // even
+      const int e = (int)(tick_base & 3u);
+      const int tla = 4 * jr - e;
+      if (tla + 3 >= 0 && tla < tc) {
+        const uint32_t tick_a = tick_base + (uint32_t)tla;           // multiple of 4
         const int K = (int)(pr >> 16);
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         if (!(REPLAY && io.exo && io.actions)) rng_block(a.seed, genv, tick_a, s, 0, 0, w);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 4; ++h) {
           const int tl = tla + h;
-          if (!(h ? vb : va)) continue;
+          if (tl < 0 || tl >= tc) continue;
           const int t = t0 + tl, i = tl * G + gl;
-          int D = 0;
+          int D = 0; uint32_t y = 0, aj = 0;
+          if (!(REPLAY && io.exo && io.actions) && !rng_split(w[h], y, aj))
+            y = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj);                    // 3.3e-6
           if (REPLAY && io.exo) {
             const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
             for (int k = s_cptr[s]; k < s_cptr[s + 1]; ++k) D += row[a.shop_cust_exo[k]];
           } else if (K > 0) {
-            uint32_t y;
-            if (!rng_word_to_y(w[2 * h], y)) y = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1);   // 3.3e-6
             D = __all(K >= 6) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, nullptr);
             for (int g = 1; 6 * g < K; ++g)
               D += rng_digit_sum(rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, g, 0), K - 6 * g < 6 ? K - 6 * g : 6, nullptr);
           }
           const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl]
-                                                      : rng_word_to_action(w[2 * h + 1]);
+                                                      : rng_j_to_action(aj);
           s_act[i] = action;
           s_it[i] = dev_round_half_even(action);
           s_it[it1 + i] = D;
@@ -543,26 +542,26 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   float tobs = typed ? (float)(tw / tnorm) : 0.f;
   uint32_t episode = sp.n_samplers > 0 ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
   int n_resets = 0;
-  RngPairCache rc_rng; rc_rng.q = 0xffffffffu;
+  RngQuadCache rc_rng; rc_rng.q = 0xffffffffu;
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t o = (int64_t)t * total + g;
     const int fl = s_fl[stage * nS + s];
     const bool has_action = (fl & 1) != 0, any_order = (fl & 2) != 0;
     const uint8_t* cact = sp.shop_cust_act + (int64_t)stage * sp.n_exo;
-    int D = 0; uint32_t w3 = 0;
+    int D = 0; uint32_t aj = 0;
     const bool need_orders = !io.exo && any_order;
-    if (need_orders || !io.actions) {                      // one Philox block per two ticks
-      rng_pair_block(rc_rng, sp.seed, genv, tick, s);
-      w3 = (tick & 1u) ? rc_rng.w[3] : rc_rng.w[1];
+    if (need_orders || !io.actions) {                      // one Philox block per four ticks
+      rng_quad_block(rc_rng, sp.seed, genv, tick, s);
+      const int Dr = rng_orders_from_block(rc_rng.w, sp.seed, genv, tick, s, need_orders ? K : 0,
+                                           (fl & 4) ? nullptr : cact + c_lo, &aj);
+      if (need_orders) D = Dr;
     }
     if (io.exo) {
       const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
       if (any_order) for (int k = c_lo; k < c_hi; ++k) if (cact[k]) D += row[sp.shop_cust_exo[k]];
-    } else if (any_order) {
-      D = rng_orders_from_block(rc_rng.w, sp.seed, genv, tick, s, K, (fl & 4) ? nullptr : cact + c_lo);
     }
-    const float action = io.actions ? io.actions[o] : rng_word_to_action(w3);
+    const float action = io.actions ? io.actions[o] : rng_j_to_action(aj);
     sc_shop_step(st, has_action, action, any_order, D);
     ++step; ++tick;
     const bool all_trunc = (step == sp.num_steps);                           // env.py:312-318
@@ -694,7 +693,16 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   const int64_t total = (int64_t)sp.B * sp.S;
   const bool wide = (sp.B % epb == 0) && (G % 4 == 0) && (total % 4 == 0);
   static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
-  const int nt = nt_env ? nt_env : (big ? 512 : 256);
+  // block size: the waves that hold a recurrence lane + enough waves to take phase 1 (one work item
+  // per row quad and pair) in a single pass, when that fits 512 threads
+  int nt = 256;
+  {
+    const int p2w = (G + 63) / 64, p1w = ((((TC + 3) >> 2) + 1) * G + 63) / 64;
+    const int want = 64 * (p2w + p1w);
+    if (want <= 256) nt = 256; else if (want <= 320) nt = 320; else if (want <= 384) nt = 384; else if (want <= 512) nt = 512;
+    else nt = big ? 512 : 256;
+  }
+  if (nt_env) nt = nt_env;
 #define PHX_LAUNCH_ROLLOUT(NT_)                                                                              \
   do {                                                                                                        \
     if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, true>), grid, dim3(NT_), lds, st, a);  \
@@ -703,6 +711,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
     else hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, true, false>), grid, dim3(NT_), lds, st, a);                  \
   } while (0)
   if (nt == 1024) PHX_LAUNCH_ROLLOUT(1024); else if (nt == 768) PHX_LAUNCH_ROLLOUT(768); else if (nt == 384) PHX_LAUNCH_ROLLOUT(384);
+  else if (nt == 320) PHX_LAUNCH_ROLLOUT(320);
   else if (nt == 512) PHX_LAUNCH_ROLLOUT(512); else PHX_LAUNCH_ROLLOUT(256);
 #undef PHX_LAUNCH_ROLLOUT
   return hipGetLastError();

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
 // ---- T fused steps of the market (phx_rollout): the env's whole mutable state -- per seller
 // posted / price / revenue / tx, per buyer bought / paid, the per-agent reward cache -- lives in
 // LDS for the fragment; HBM sees the trajectory rows only.  Random policy (actions == NULL): the
-// acting agent's action word (word 2p + 1 of block 0 of its tick pair, the stream the supply
-// chain uses) mapped onto its action space: seller price U[0,1), buyer buy/skip with p = 1/2.
+// acting agent's word of the tick (the stream the supply chain uses; its rank j in [0, 274877))
+// mapped onto its action space: seller price j / 274877, buyer buys iff j < 137438 (p = 1/2).
 // Auto-reset at the end of the terminal step (the caller's env.reset(), stackelberg.py:53-109).
 __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -198,10 +198,9 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
         const bool seller = (rec & 255u) == PHX_KIND_SELLER;
         if (io.actions) action = io.actions[row + a];
         else {
-          uint32_t w[4];
-          rng_block(sp.seed, genv, tick, a, 0, 0, w);
-          const uint32_t aw = (tick & 1u) ? w[3] : w[1];
-          action = seller ? (float)(aw >> 8) * (1.0f / 16777216.0f) : ((aw >> 31) ? 1.0f : 0.0f);
+          uint32_t aj;
+          rng_group_y(sp.seed, genv, tick, a, 0, 0, &aj);          // the agent's word of this tick: rank j
+          action = seller ? (float)aj * (1.0f / 274877.0f) : (aj < 137438u ? 1.0f : 0.0f);
         }
         if (seller) { s_price[kr] = (double)action; s_sent[kr] = 1; }
         else {

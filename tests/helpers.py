@@ -110,8 +110,8 @@ def find_rng_rejection(seed=1, tick=0, shop=0, limit=4_000_000):
     step = 1 << 18
     for lo in range(0, limit, step):
         genv = np.arange(lo, lo + step, dtype=np.uint64)
-        w = philox_np(genv, 0, tick >> 1, shop, seed & 0xffffffff, seed >> 32)
-        u = w[2 * (tick & 1)]
+        w = philox_np(genv, 0, tick >> 2, shop, seed & 0xffffffff, seed >> 32)
+        u = w[tick & 3]
         rej = ((u * np.uint64(15625)) & np.uint64(0xffffffff)) < np.uint64(14171)
         if rej.any():
             return int(genv[np.flatnonzero(rej)[0]])

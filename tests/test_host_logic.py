@@ -146,35 +146,52 @@ def test_philox_known_answers():
 
 
 def test_device_rng_definition():
-    """one Philox block per (shop, tick pair): word 2p = order word of customers 0..5, word 2p+1 =
-    action (p = tick & 1); customers 6g.. own word x % 4 of block 1 + x // 4, x = 2(g-1)+p;
-    y = (u * 5^6) >> 32 (rejected iff low32 < 14171), customer j = base-5 digit j of y."""
+    """one Philox block per (shop, customer group g, tick quad): tick t owns word t & 3; m = u * 5^6,
+    rejected iff low32(m) < 14171, y = m >> 32 gives six base-5 digits (customers 6g .. 6g+5), the
+    word's rank j = (low32(m) - 14171) // 5^6 gives the action j * 100 / 274877."""
     seed, genv, shop = 0x1234567890ABCDEF, 5_000_000_123, 3
     K = 20
-    for tick in (76, 77):
-        p = tick & 1
-
-        def word(blk, w, attempt=0):
-            return int(philox([genv & 0xffffffff, (genv >> 32) | (attempt << 16), tick >> 1, shop | (blk << 20)],
-                              [seed & 0xffffffff, seed >> 32])[w])
+    for tick in (76, 77, 78, 79, 80):
+        def word(g, attempt=0):
+            return int(philox([genv & 0xffffffff, (genv >> 32) | (attempt << 16), tick >> 2, shop | (g << 20)],
+                              [seed & 0xffffffff, seed >> 32])[tick & 3])
         got = rng_orders(seed, genv, tick, shop, K)
         for k in range(K):
-            g, j = divmod(k, 6)
-            blk, w = (0, 2 * p) if g == 0 else (1 + (2 * (g - 1) + p) // 4, (2 * (g - 1) + p) % 4)
-            m = word(blk, w) * 15625
+            g, i = divmod(k, 6)
+            m = word(g) * 15625
             assert (m & 0xffffffff) >= 14171
-            assert got[k] == ((m >> 32) // 5 ** j) % 5
-        assert rng_action(seed, genv, tick, shop) == np.float32(word(0, 2 * p + 1) >> 8) * np.float32(100.0 / 16777216.0)
+            assert got[k] == ((m >> 32) // 5 ** i) % 5
+        m0 = word(0) * 15625
+        j = ((m0 & 0xffffffff) - 14171) // 15625
+        assert 0 <= j < 274877
+        assert rng_action(seed, genv, tick, shop) == np.float32(j) * np.float32(100.0 / 274877.0)
     many = np.concatenate([rng_orders(1, b, t, 0, 6) for b in range(200) for t in range(20)])
     assert many.min() == 0 and many.max() == 4
     assert abs(np.bincount(many, minlength=5) / many.size - 0.2).max() < 0.01
     # the six digits of one word are independent: all 5^2 pairs of (customer 0, customer 5) occur
     pairs = many.reshape(-1, 6)[:, [0, 5]]
     assert len({(int(a), int(b)) for a, b in pairs}) == 25
+    acts = np.array([rng_action(1, b, t, 0) for b in range(100) for t in range(20)])
+    assert 0.0 <= acts.min() and acts.max() < 100.0 and abs(acts.mean() - 50.0) < 2.0
+    # (y, j) is a bijection with the accepted words: exhaustively for the words of three y buckets
+    for y in (0, 7777, 15624):
+        u0 = -(-(y << 32) // 15625)                                  # first word mapping to y
+        us = np.arange(max(u0 - 3, 0), min(u0 + 274877 + 4, 2 ** 32), dtype=np.uint64)
+        m = us * np.uint64(15625)
+        sel = (m >> np.uint64(32)) == np.uint64(y)
+        low = (m & np.uint64(0xffffffff))[sel]
+        acc = low >= np.uint64(14171)
+        jj = ((low[acc] - np.uint64(14171)) // np.uint64(15625)).astype(np.int64)
+        assert acc.sum() == 274877 and np.array_equal(jj, np.arange(274877))
+        # the kernels divide by 5^6 with a multiply-high: x // 15625 == (x * 2251799814) >> 45
+        x = (low[acc] - np.uint64(14171)).astype(object)
+        assert all(int(v) * 2251799814 >> 45 == int(v) // 15625 for v in x[::997])
+    xs = np.array([0, 1, 15624, 15625, 15626, 2 ** 32 - 14172, 2 ** 32 - 1], dtype=object)
+    assert all(int(v) * 2251799814 >> 45 == int(v) // 15625 for v in xs)
 
 
 def test_device_rng_rejection_branch():
-    """a rejected order word is redrawn at the same position with attempt + 1."""
+    """a rejected word is redrawn at the same position with attempt + 1."""
     from helpers import find_rng_rejection, philox_np
     w = philox_np(np.arange(5), 7, 3, 2, 11, 13)                  # the numpy Philox is the oracle's
     for b in range(5):
@@ -185,7 +202,8 @@ def test_device_rng_rejection_branch():
     u1 = int(philox([genv & 0xffffffff, (genv >> 32) | (1 << 16), 0, 0], [1, 0])[0])
     y = (u1 * 15625) >> 32
     assert ((u1 * 15625) & 0xffffffff) >= 14171
-    assert list(rng_orders(1, genv, 0, 0, 6)) == [(y // 5 ** j) % 5 for j in range(6)]
+    assert list(rng_orders(1, genv, 0, 0, 6)) == [(y // 5 ** i) % 5 for i in range(6)]
+    assert rng_action(1, genv, 0, 0) == np.float32((((u1 * 15625) & 0xffffffff) - 14171) // 15625) * np.float32(100.0 / 274877.0)
 
 
 def test_f32_digit_formulas_are_exact():
