@@ -181,16 +181,15 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   }
 }
 
-// ---- rollout v2: time-parallel.  The only sequential dependence of an episode is the stock
+// ---- rollout: time-parallel.  The only sequential dependence of an episode is the stock
 // recurrence  stock' = min(stock - min(D, stock) + min(R, 100 - stock), 100)  (a dozen integer
-// ops); everything expensive -- the Philox draws, the IEEE divisions of the observation, the
-// f64 reward, the trajectory stores -- is independent across time steps.  So a block owns G
-// (env, shop) pairs x TC steps, staged in LDS as {R | stock, D, sales}:
-//   phase 1 (all lanes, item = (t, pair)): action + order sum  -> LDS, action_out -> HBM
-//   phase 2 (one lane per pair, sequential over t): the recurrence, in LDS
-//   phase 3 (all lanes, item = (t, pair)): obs / reward / flags -> HBM, rows contiguous in pair
-// Waves take whole time rows (lanes = consecutive pairs), so every trajectory store of a wave
-// covers one contiguous segment of the [T][B][S] arrays.
+// ops); everything expensive -- the Philox draws, the divisions of the observation, the f64
+// reward, the trajectory stores -- is independent across time steps.  A block owns G = epb * S
+// (env, shop) pairs (whole envs) and walks the fragment in chunks of TC steps; LDS holds the
+// chunk's item tiles as three planes [TC][G]: {R | stock, D | missed, sales} plus an action tile:
+//   phase 1 (worker waves, item = (row quad, pair)): Philox -> R, D, action    (next chunk)
+//   phase 2 (one lane per pair, sequential over t):  the recurrence, in LDS    (this chunk, overlapped)
+//   phase 3 (all lanes, item = (row, 4 pairs)):      obs / reward / flags -> HBM, 16-byte stores
 // lean argument block of the rollout kernel (passing the whole DevSpec by value costs ~50
 // spilled SGPRs per wave)
 struct RollArgs {
@@ -206,20 +205,10 @@ struct RollArgs {
   phx_rollout_io io;
 };
 
-// ---- rollout v3: time-parallel (see v2 above) + tile-staged, full-width trajectory stores.
-// A block owns G = epb * S (env, shop) pairs (whole envs) and walks the fragment in chunks of
-// TC steps.  Per chunk, LDS holds a tile of TC x G items:
-//   phase 1  (all lanes, flat items)  Philox -> {R, D} + action tile
-//   phase 2  (one lane per pair)      stock recurrence over the TC steps, in LDS
-//   phase 3a (all lanes, flat items)  obs (in place of the item), reward, truncation flag tiles
-//   phase 3b (all lanes)              tiles -> HBM: each tile row is one contiguous, 16-byte
-//                                     aligned segment of the [T][B][S] arrays, written with
-//                                     dwordx4 stores (the same shape a fill kernel uses)
 // Barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
 // store (s_waitcnt vmcnt(0)) because it is a workgroup-scope release; the tiles below need no
 // global visibility inside the kernel, and draining would expose the HBM write latency at each
-// of the 4 barriers per chunk instead of letting the trajectory stores retire under the next
-// chunk's Philox work.
+// barrier instead of letting the trajectory stores retire under the next chunk's Philox work.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -228,7 +217,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // REPLAY: actions and/or exogenous draws come from HBM (parity / replay); false = pure device RNG.
 // WIDE:   every block owns exactly epb envs and every tile row is 16-byte aligned (host-checked),
-//         so the copy-out uses dwordx4 / dwordx2 stores and magic-number row arithmetic only.
+//         so the output phase writes whole 16-byte segments with magic-number row arithmetic only.
 template <int NT, bool REPLAY, bool WIDE>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 6 : (NT == 320 ? 5 : 4)))) void phx_sc_rollout_kernel(const RollArgs a) {
   // Software pipeline over chunks of TC steps.  Phase 1 (Philox draws) of chunk c + 1 does not
