@@ -79,7 +79,8 @@ class RolloutCollector:
 
     Result: a tuple of tensors [n_chunks, world, chunk, B_local, ...]; global env
     = shard * B_local + local env, global step = c * chunk + step-in-chunk.  Chunk-major output
-    keeps every all-gather a single contiguous all_gather_into_tensor (no repacking pass).
+    keeps every all-gather a single contiguous all_gather_into_tensor (no repacking pass); all the
+    arrays of a chunk share one flat staging buffer, so a chunk is ONE collective.
     On a CPU device (gloo tests) the same schedule runs without streams.
     """
 
@@ -93,32 +94,46 @@ class RolloutCollector:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = like[0].device
-        mk = lambda x, lead: torch.empty(lead + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        self.bufs = [tuple(mk(x, (chunk,)) for x in like) for _ in range(n_buffers)]
-        self.out = tuple(mk(x, (self.n_chunks, self.world, chunk)) for x in like)
+        # every field of a chunk lives in ONE flat staging buffer (256-byte aligned sections), so a
+        # chunk is a single all_gather_into_tensor whatever the number of trajectory arrays
+        shapes = [(chunk,) + tuple(x.shape[1:]) for x in like]
+        nbytes = [int(torch.tensor(sh).prod()) * x.element_size() for sh, x in zip(shapes, like)]
+        offs, total = [], 0
+        for n in nbytes:
+            offs.append(total)
+            total += (n + 255) & ~255
+        self.nbytes = total
+
+        def views(flat, lead):
+            # flat: uint8 [..., total] -> one typed view [..., chunk, B_local, ...] per field
+            return tuple(flat[..., o:o + n].view(x.dtype).unflatten(-1, sh)
+                         for o, n, sh, x in zip(offs, nbytes, shapes, like))
+
+        self._flat = [torch.empty(total, dtype=torch.uint8, device=self.device) for _ in range(n_buffers)]
+        self.bufs = [views(f, ()) for f in self._flat]
+        self._out_flat = torch.empty((self.n_chunks, self.world, total), dtype=torch.uint8, device=self.device)
+        self.out = views(self._out_flat, (self.n_chunks, self.world))
         self.cuda = self.device.type == "cuda"
         if self.cuda:
             self.side = torch.cuda.Stream(self.device)
             self.free = [torch.cuda.Event() for _ in range(n_buffers)]
             self.ready = [torch.cuda.Event() for _ in range(n_buffers)]
 
-    def _gather(self, c, bufs):
+    def _gather(self, c, k):
         import torch.distributed as dist
-        for o, x in zip(self.out, bufs):
-            if self.world == 1:
-                o[c, 0].copy_(x, non_blocking=True)
-            else:
-                dist.all_gather_into_tensor(o[c].view((self.world * self.chunk,) + tuple(x.shape[1:])),
-                                            x, group=self.group)
+        if self.world == 1:
+            self._out_flat[c, 0].copy_(self._flat[k], non_blocking=True)
+        else:
+            dist.all_gather_into_tensor(self._out_flat[c].view(-1), self._flat[k], group=self.group)
 
     def collect(self):
         """Run one fragment; returns ``self.out`` (valid on the caller's stream on return)."""
         import torch
         if not self.cuda:
             for c in range(self.n_chunks):
-                bufs = self.bufs[c % len(self.bufs)]
-                self.produce(c * self.chunk, self.chunk, bufs)
-                self._gather(c, bufs)
+                k = c % len(self.bufs)
+                self.produce(c * self.chunk, self.chunk, self.bufs[k])
+                self._gather(c, k)
             return self.out
         main = torch.cuda.current_stream(self.device)
         for c in range(self.n_chunks):
@@ -129,7 +144,7 @@ class RolloutCollector:
             self.ready[k].record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ready[k])
-                self._gather(c, self.bufs[k])
+                self._gather(c, k)
                 self.free[k].record(self.side)
         main.wait_stream(self.side)
         return self.out
