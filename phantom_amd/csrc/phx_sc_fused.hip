@@ -196,7 +196,7 @@ struct RollArgs {
   int32_t B, S, n_exo, num_steps, T, epb, TC, n_tabn, n_quot;
   const float* sc_tab;
   unsigned long long* timing;    // PHX_TIMING builds only: [blocks][8] cycle sums per phase
-  uint32_t mG, mO, mF, mU;       // ceil(2^32 / d) magic numbers: i / d == umulhi(i, m) for i < 2^16
+  uint32_t mF;                   // ceil(2^32 / (G / 4)): i / (G / 4) == umulhi(i, mF) for i < 2^16 (G > 4)
   uint64_t seed; int64_t env_offset;
   const int32_t* shop_norm;      // [S] max_sales_per_step of each shop
   const int32_t* shop_cust_ptr;  // [S+1]
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
     if (WIDE) {
       const int G4 = G >> 2;
       for (int u = tid; u < tc * G4; u += NT) {
-        const int r = (int)__umulhi((uint32_t)u, a.mF);          // u / G4
+        const int r = G4 == 1 ? u : (int)__umulhi((uint32_t)u, a.mF);   // u / G4 (the magic of 1 does not fit 32 bits)
         const int c4 = u - r * G4, gl0 = c4 << 2, i0 = r * G + gl0;
         const uint4 vs = *(const uint4*)(s_it + i0), vd = *(const uint4*)(s_it + it1 + i0), vl = *(const uint4*)(s_it + 2 * it1 + i0);
         const uint4 pp = *(const uint4*)(s_pair + gl0);
@@ -671,7 +671,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
   if (TC > 8) TC &= ~7;                                          // groups of 8 steps in the recurrence phase
   if (sp.num_steps >= 1 && TC > sp.num_steps) TC = sp.num_steps; // at most one episode end per chunk
-  a.mG = magic(G); a.mO = magic(G * 3 / 4); a.mF = magic(G / 4); a.mU = magic(G / 4);
+  a.mF = magic(G / 4);
   const int items = TC * G;
   const size_t lds = (size_t)((items + 3) & ~3) * 4 * 3 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
                      (size_t)((G + 3) & ~3) * 4 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +

@@ -113,10 +113,10 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     float ob0 = 0.f, ob1 = 0.f; uint8_t ov = 0;
     if (fl & 2) {                                                            // encode_observation
       ov = 1;
-      if (seller) { ob0 = (float)((double)s_tx[kr] / (double)(sp.row_ptr[a + 1] - sp.row_ptr[a])); ob1 = (float)s_price[kr]; }
+      if (seller) { const int sd = sp.row_ptr[a + 1] - sp.row_ptr[a]; ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr]; }
       else {
         const uint16_t* nb = sp.stk_nbr + kr;
-        double mn = s_posted[nb[0]];                                         // min over the price slots
+        double mn = deg > 0 ? s_posted[nb[0]] : 1.0;                         // min over the price slots (none: 1.0)
         for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
         ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
       }
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
       ob0 = 0.f; ob1 = 0.f; ov = 0;
       if (fl & 2) {
         ov = 1;
-        if (seller) { ob0 = (float)((double)s_tx[kr] / (double)(sp.row_ptr[a + 1] - sp.row_ptr[a])); ob1 = (float)s_price[kr]; }
+        if (seller) { const int sd = sp.row_ptr[a + 1] - sp.row_ptr[a]; ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr]; }
         else {
           const uint16_t* nb = sp.stk_nbr + kr;
-          double mn = s_posted[nb[0]];
+          double mn = deg > 0 ? s_posted[nb[0]] : 1.0;
           for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
           ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
         }

@@ -1,0 +1,160 @@
+"""Random differential cases: the HIP path vs the CPU oracle over random supply-chain and market
+topologies (agent order, factories, ragged customers, FSM stage tables, typed shops, stochastic
+networks, tracking, masked resets, rollouts).  Used by test_gpu_fuzz.py; `python tests/fuzz_cases.py
+N [first]` runs a longer campaign on a GPU box."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+import phantom_amd as ph
+from oracle import OracleEnv
+from device_runner import DeviceRunner
+from helpers import f32_bits, f64_bits
+
+def cmp(o, d, tag):
+    for f in ("obs_valid", "reward_valid", "done_valid", "terminated", "truncated", "all_terminated", "all_truncated", "err"):
+        assert np.array_equal(getattr(d, f), getattr(o, f)), (tag, f)
+    assert np.array_equal(f32_bits(d.obs), f32_bits(o.obs)), (tag, "obs")
+    assert np.array_equal(f64_bits(d.reward), f64_bits(o.reward)), (tag, "reward")
+
+def sc_case(rng, case):
+    big = rng.rand() < 0.15
+    nF = rng.randint(1, 4); S = rng.randint(1, 60 if big else 12)
+    ks = [int(rng.randint(0, 71 if (big and rng.rand() < 0.3) else 9)) for _ in range(S)]
+    fsm = rng.rand() < 0.4; typed = rng.rand() < 0.3
+    B = int(rng.randint(1, 300 if big else 70)); num_steps = int(rng.randint(1, 30 if big else 9)); T = int(rng.randint(3, 30))
+    force_generic = rng.rand() < 0.4; tracking = force_generic and rng.rand() < 0.5
+    factories = [ph.FactoryAgent(f"F{i}") for i in range(nF)]
+    shop_cls = ph.TypedShopAgent if typed else ph.ShopAgent
+    shops = [shop_cls(f"SHOP{i}", factory_id=f"F{rng.randint(nF)}", num_customers=max(ks[i], 1)) for i in range(S)]
+    custs = [ph.CustomerAgent(f"C{i}_{j}", shop_id=f"SHOP{i}") for i in range(S) for j in range(ks[i])]
+    agents = shops + factories + custs
+    order = rng.permutation(len(agents))
+    agents = [agents[i] for i in order]                       # arbitrary agent order
+    net = ph.Network(agents, resolver=ph.BatchResolver(enable_tracking=tracking))
+    for s in shops: net.add_connection(s.id, s.factory_id)
+    for c in custs: net.add_connection(c.id, c.shop_id)
+    kw = dict(batch_size=B, seed=int(rng.randint(1 << 30)), env_offset=int(rng.randint(1 << 20)), force_generic=force_generic)
+    sup = None
+    host_fed = False
+    if typed:
+        sm = ph.UniformFloatSampler(0.0, 0.2)
+        sm2 = ph.UniformFloatSampler(0.02, 0.18, 0.05, 0.15)
+        sup = {s.id: ph.TypedShopAgent.Supertype(sm if rng.rand() < 0.4 else (sm2 if rng.rand() < 0.3 else float(rng.rand() * 0.2)))
+               for s in shops if rng.rand() < 0.8}
+        host_fed = rng.rand() < 0.4                      # sampler values passed to phx_reset instead of device-drawn
+        kw["exogenous"] = "numpy" if host_fed else "device"
+    if fsm:
+        stages = [ph.FSMStage("A", acting_agents=[s.id for s in shops], rewarded_agents=[s.id for s in shops if rng.rand() < 0.7], next_stages=["B"]),
+                  ph.FSMStage("B", acting_agents=[c.id for c in custs if rng.rand() < 0.8] + [s.id for s in shops if rng.rand() < 0.2],
+                              rewarded_agents=None if rng.rand() < 0.3 else [s.id for s in shops if rng.rand() < 0.5], next_stages=["A"])]
+        env = ph.FiniteStateMachineEnv(num_steps, net, initial_stage="A", stages=stages, agent_supertypes=sup, **kw)
+    else:
+        env = ph.PhantomEnv(num_steps, net, agent_supertypes=sup, **kw)
+    spec = env.spec
+    o, d = OracleEnv(spec), DeviceRunner(spec)
+
+    def reset(mask=None):
+        vals = rng.uniform(0.0, 0.2, (B, spec.n_samplers)) if (host_fed and spec.n_samplers) else None
+        (oo, ov), (do, dv) = o.reset(mask, vals), d.reset(mask, vals)
+        m = slice(None) if mask is None else mask.astype(bool)
+        assert np.array_equal(dv[m], ov[m]) and np.array_equal(f32_bits(do[m]), f32_bits(oo[m])), (case, "reset")
+
+    reset()
+    if rng.rand() < 0.3:                                  # per-env tick surgery: mixed tick phases
+        ticks = rng.randint(0, 50, B).astype(np.int32)
+        o.set_i32("env.tick", ticks); d.set_i32("env.tick", ticks.reshape(B, 1))
+    Ss = spec.n_strategic; nx = spec.n_exo
+    for t in range(T):
+        act = rng.uniform(-20, 130, (B, Ss)).astype(np.float32)
+        valid = (rng.rand(B, Ss) < 0.9).astype(np.uint8) if rng.rand() < 0.5 else None
+        exo = rng.randint(0, 5, (B, nx)).astype(np.uint8) if (nx and rng.rand() < 0.5) else None
+        o.step(act, valid, exo); d.step(act, valid, exo)
+        cmp(o, d, (case, t))
+        if tracking:
+            assert np.array_equal(d.msg_count, o.msg_count), (case, t, "msg_count")
+            b0 = int(rng.randint(B))
+            assert np.array_equal(d.log(b0), o.log(b0)), (case, t, "log")
+        done = ((o.all_truncated > 0) | (rng.rand(B) < 0.05)).astype(np.uint8)
+        if done.any():
+            reset(done)
+    if d.dev.uses_fused and rng.rand() < 0.7 and not (host_fed and spec.n_samplers):
+        Tr = int(rng.randint(1, 150 if big else 40))
+        replay = rng.rand() < 0.4
+        acts = rng.uniform(-10, 130, (Tr, B, Ss)).astype(np.float32) if replay else None
+        exo = rng.randint(0, 5, (Tr, B, nx)).astype(np.uint8) if (replay and nx) else None
+        ro, rd = o.rollout(Tr, acts, exo), d.rollout(Tr, acts, exo)
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            assert np.array_equal(f32_bits(rd[k]), f32_bits(ro[k])), (case, "rollout", k)
+        for k in ("truncated", "terminated") + (("obs_valid", "reward_valid") if fsm else ()):
+            assert np.array_equal(rd[k], ro[k]), (case, "rollout", k)
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "env.step", "env.tick"):
+            assert np.array_equal(d.get_i32(f), o.get_i32(f)), (case, "after rollout", f)
+    return f"S={S} ks={ks} nF={nF} fsm={fsm} typed={typed} B={B} ns={num_steps} generic={force_generic} fused={d.dev.uses_fused}"
+
+def stk_case(rng, case):
+    L = int(rng.randint(1, 10)); Fw = int(rng.randint(1, 40)); B = int(rng.randint(1, 30))
+    num_steps = int(rng.randint(1, 11)); T = int(rng.randint(3, 25))
+    stochastic = rng.rand() < 0.4; force_generic = rng.rand() < 0.3
+    sellers = [ph.SellerAgent(f"S{i}") for i in range(L)]
+    buyers = [ph.BuyerAgent(f"B{i}", float(rng.randint(1, 9)) / 8.0) for i in range(Fw)]
+    agents = sellers + buyers
+    agents = [agents[i] for i in rng.permutation(len(agents))]
+    pairs = [(b.id, s.id) for b in buyers for s in sellers if rng.rand() < min(1.0, 3.0 / L)]
+    if stochastic:
+        net = ph.StochasticNetwork(agents)
+        for u, v in pairs: net.add_connection(u, v, float(rng.choice([0.0, 0.3, 0.8, 1.0])))
+    else:
+        net = ph.Network(agents)
+        for u, v in pairs: net.add_connection(u, v)
+    leaders = [s.id for s in sellers]; followers = [b.id for b in buyers]
+    env = ph.StackelbergEnv(num_steps, net, leaders, followers, batch_size=B, seed=int(rng.randint(1 << 30)),
+                            env_offset=int(rng.randint(1 << 20)), force_generic=force_generic, exogenous="device")
+    spec = env.spec
+    o, d = OracleEnv(spec), DeviceRunner(spec)
+    o.reset(); d.reset()
+    S = spec.n_strategic
+    for t in range(T):
+        act = np.where(rng.rand(B, S) < 0.5, rng.randint(1, 9, (B, S)) / 8.0, 1.0).astype(np.float32)
+        valid = (rng.rand(B, S) < 0.9).astype(np.uint8)
+        o.step(act, valid, None); d.step(act, valid, None)
+        cmp(o, d, (case, t))
+        done = ((o.all_truncated > 0) | (rng.rand(B) < 0.05)).astype(np.uint8)
+        if done.any():
+            (oo, ov), (do, dv) = o.reset(done), d.reset(done)
+            m = done.astype(bool)
+            assert np.array_equal(dv[m], ov[m]) and np.array_equal(f32_bits(do[m]), f32_bits(oo[m])), (case, t, "reset")
+    if d.dev.uses_fused and rng.rand() < 0.7:
+        Tr = int(rng.randint(1, 30))
+        ro, rd = o.rollout(Tr, None, None), d.rollout(Tr, None, None)
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            assert np.array_equal(f32_bits(rd[k]), f32_bits(ro[k])), (case, "rollout", k)
+        for k in ("truncated", "obs_valid", "reward_valid"):
+            assert np.array_equal(rd[k], ro[k]), (case, "rollout", k)
+    for f in ("seller.price", "seller.revenue", "buyer.paid"):
+        if spec.n_strategic: assert np.array_equal(f64_bits(d.get_f64(f)), f64_bits(o.get_f64(f))), (case, f)
+    return f"L={L} Fw={Fw} B={B} edges={len(pairs)} stochastic={stochastic} generic={force_generic} fused={d.dev.uses_fused}"
+
+
+
+def run_case(case):
+    rng = np.random.RandomState(case)
+    np.random.seed(case)
+    return (stk_case if case % 3 == 2 else sc_case)(rng, case)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    for case in range(first, first + n):
+        try:
+            desc = run_case(case)
+        except AssertionError as e:
+            print("FAIL case", case, e.args, flush=True)
+            raise
+        if case % 20 == 0:
+            print("ok", case, desc, flush=True)
+    print("fuzz done", n)

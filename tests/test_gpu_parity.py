@@ -800,3 +800,37 @@ def test_rollout_with_per_env_tick_parities():
         np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
     np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
     np.testing.assert_array_equal(d.get_i32("env.tick")[:, 0], ticks + T)
+
+
+def test_fuzz_regressions():
+    """cases found by the random differential fuzz (scratch/fuzz.py): (1) buyers / sellers without
+    any neighbour in the fused market kernels, (2) a rollout whose workgroup owns only 4 pairs."""
+    # (1) isolated agents: min over no prices is 1.0, tx / len(neighbours) is 0
+    agents = [ph.SellerAgent("S0"), ph.SellerAgent("S1"), ph.BuyerAgent("B0", 0.5), ph.BuyerAgent("B1", 0.75),
+              ph.BuyerAgent("B2", 0.25)]
+    net = ph.Network(agents)
+    net.add_connection("B0", "S0"); net.add_connection("B1", "S0")          # S1 and B2 are isolated
+    env = ph.StackelbergEnv(6, net, ["S0", "S1"], ["B0", "B1", "B2"], batch_size=5, seed=3)
+    o, x = OracleEnv(env.spec), _dev(env.spec)
+    assert x.dev.uses_fused
+    o.reset(); x.reset()
+    rng = np.random.RandomState(2)
+    for t in range(8):
+        act = rng.randint(1, 9, (5, 5)).astype(np.float32) / 8.0
+        act[:, 2:] = 1.0
+        o.step(act, None, None); x.step(act, None, None)
+        np.testing.assert_array_equal(f32_bits(x.obs), f32_bits(o.obs), err_msg=f"t={t}")
+        np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward))
+        if o.all_truncated.any():
+            o.reset(); x.reset()
+    ro, rd = o.rollout(9), x.rollout(9)
+    np.testing.assert_array_equal(f32_bits(rd["obs"]), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(rd["rewards"]), f32_bits(ro["rewards"]))
+    # (2) B = 2 envs x 2 shops: one workgroup of 4 pairs
+    env = supply_chain_env(2, [2, 3], 6, 2, seed=4)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    ro, rd = o.rollout(31), d.rollout(31)
+    for k in ("obs", "actions", "rewards", "last_obs"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
