@@ -140,9 +140,58 @@ def stk_case(rng, case):
 
 
 
+def net_case(rng, case):
+    """message-passing kinds of the reference's own network tests on random graphs: injected sends,
+    Network.resolve alone; routing order, round limit, edge / payload / handler errors, tracking."""
+    from phantom_amd.message import Message
+    from phantom_amd.spec import compile_spec
+    n = int(rng.randint(2, 9))
+    ids = [f"N{i}" for i in range(n)]
+    agents = []
+    for i, aid in enumerate(ids):
+        k = rng.randint(5)
+        if k == 0: agents.append(ph.HalverAgent(aid))
+        elif k == 1: agents.append(ph.CashboxAgent(aid))
+        elif k == 2: agents.append(ph.ReqRespAgent(aid))
+        elif k == 3: agents.append(ph.ForwarderAgent(aid, target=(ids[rng.randint(n)] if rng.rand() < 0.7 else None)))
+        else: agents.append(ph.MockAgent(aid))
+    rl = None if rng.rand() < 0.4 else int(rng.randint(0, 7))
+    net = ph.Network(agents, ph.BatchResolver(enable_tracking=True, round_limit=rl),
+                     ignore_connection_errors=bool(rng.rand() < 0.25), enforce_msg_payload_checks=bool(rng.rand() < 0.8))
+    for i in range(n):
+        for j in range(i + 1, n):
+            if rng.rand() < 0.45: net.add_connection(ids[i], ids[j])
+    B = int(rng.randint(1, 4))
+    spec = compile_spec(net, num_steps=0, batch_size=B)
+    o, d = OracleEnv(spec), DeviceRunner(spec)
+    for rep in range(int(rng.randint(1, 4))):
+        msgs = []
+        for _ in range(int(rng.randint(1, 9))):
+            u, v = ids[rng.randint(n)], ids[rng.randint(n)]
+            t = rng.randint(4)
+            pay = (ph.HalveMessage(int(rng.randint(0, 40))) if t == 0 else ph.CashMessage(float(rng.randint(0, 400))) if t == 1
+                   else ph.Request(float(rng.randint(0, 100))) if t == 2 else ph.Response(float(rng.randint(0, 100))))
+            msgs.append(Message(u, v, pay))
+        o.inject(msgs); d.inject(msgs)
+        o.resolve(); d.resolve()
+        assert np.array_equal(d.err, o.err), (case, rep, "err", d.err, o.err)
+        if (o.err == 0).all():
+            assert np.array_equal(d.msg_count, o.msg_count), (case, rep, "msg_count")
+            assert np.array_equal(d.log(0), o.log(0)), (case, rep, "log")
+            for f in ("cashbox.total_cash",):
+                if spec.kind.tolist().count(7): assert np.array_equal(f64_bits(d.get_f64(f)), f64_bits(o.get_f64(f))), (case, rep, f)
+            for f in ("reqresp.req_time", "reqresp.res_time"):
+                if spec.kind.tolist().count(8): assert np.array_equal(d.get_i32(f), o.get_i32(f)), (case, rep, f)
+        else:
+            o.reset(); d.reset()
+    return f"net n={n} rl={rl} flags={spec.flags} B={B}"
+
+
 def run_case(case):
     rng = np.random.RandomState(case)
     np.random.seed(case)
+    if case % 5 == 4:
+        return net_case(rng, case)
     return (stk_case if case % 3 == 2 else sc_case)(rng, case)
 
 
