@@ -280,6 +280,10 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   const int p2_threads = ((G + 63) >> 6) << 6;
   const int p1_first = (p2_threads + 64 <= NT) ? p2_threads : 0;
   lds_barrier();
+  // row quads per chunk: one more when the chunk starts are not quad-aligned for every env (some
+  // tick counter, or the chunk length, is not a multiple of 4)
+  int quad_extra = (TC & 3) != 0;
+  for (int bl = 0; bl < nb; ++bl) quad_extra |= (s_tick0[bl] & 3) != 0;
   TICK(0);
 
   // ---- phase 1 of the chunk starting at step t0 (tc rows) into buffer `buf`, by threads
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
     int* s_it = s_it0 + buf * it_words;
     float* s_act = s_act0 + buf * it1;
     const int nw = NT - first, wt = tid - first;
-    const int npr = ((tc + 3) >> 2) + 1;
+    const int npr = ((tc + 3) >> 2) + quad_extra;
     const int n_work = npr * G;
     int jr = wt / G, gl = wt - jr * G;
     const int qG = nw / G, rG = nw - qG * G;
@@ -666,11 +670,22 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   const int G = epb * sp.S;
   auto magic = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
   static const int ldskb_env = getenv("PHX_ROLLOUT_LDSKB") ? atoi(getenv("PHX_ROLLOUT_LDSKB")) : 0;
-  const int ldskb = ldskb_env ? ldskb_env : (big ? 44 : 34);
+  const int ldskb = ldskb_env ? ldskb_env : (big ? 44 : 30);
   int TC = (ldskb * 1024) / (G * 32); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;   // 32 B of LDS per item (double-buffered tiles)
   while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
-  if (TC > 8) TC &= ~7;                                          // groups of 8 steps in the recurrence phase
   if (sp.num_steps >= 1 && TC > sp.num_steps) TC = sp.num_steps; // at most one episode end per chunk
+  if (TC >= 8) {
+    // Both parallel phases have TC * G / 4 work items per chunk (draws: one per row quad and pair,
+    // outputs: one per row and 4 pairs).  Among the multiples of 4 that fit, take the chunk length
+    // that fills whole waves best (a mostly empty last pass costs as much as a full one).
+    int best = TC & ~3; double best_fill = 0.0;
+    for (int cand = TC & ~3; cand >= 8 && cand * 2 > TC; cand -= 4) {
+      const int work = cand * G / 4;
+      const double fill = (double)work / (double)(((work + 63) / 64) * 64);
+      if (fill > best_fill + 0.02) { best_fill = fill; best = cand; }
+    }
+    TC = best;
+  }
   a.mF = magic(G / 4);
   const int items = TC * G;
   const size_t lds = (size_t)((items + 3) & ~3) * 4 * 3 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
@@ -686,7 +701,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   // per row quad and pair) in a single pass, when that fits 512 threads
   int nt = 256;
   {
-    const int p2w = (G + 63) / 64, p1w = ((((TC + 3) >> 2) + 1) * G + 63) / 64;
+    const int p2w = (G + 63) / 64, p1w = (((TC + 3) >> 2) * G + 63) / 64;      // quad-aligned ticks: one pass
     const int want = 64 * (p2w + p1w);
     if (want <= 256) nt = 256; else if (want <= 320) nt = 320; else if (want <= 384) nt = 384; else if (want <= 512) nt = 512;
     else nt = big ? 512 : 256;
