@@ -251,11 +251,13 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   int* s_tend = s_step0 + ((a.epb + 3) & ~3);              // [epb] chunk-local step index that ends the episode, or -1
   int* s_cptr = s_tend + ((a.epb + 3) & ~3);               // [S+1]
   int* s_norm = s_cptr + ((nS + 1 + 3) & ~3);              // [S]
+  uint8_t* s_ds3 = (uint8_t*)(s_norm + ((nS + 3) & ~3));   // [125] base-5 digit sum of k < 5^3
   const int n_tab = 101 + a.n_tabn + 202;
-  float* s_tab = (float*)(s_norm + ((nS + 3) & ~3));       // [n_tab] host-built lookup tables
+  float* s_tab = (float*)(s_ds3 + 128);                    // [n_tab] host-built lookup tables
   const float* s_tabn = s_tab + 101;
   const double* s_pen = (const double*)(s_tabn + a.n_tabn);   // 0.1 * stock, f64
   for (int k = tid; k < n_tab; k += NT) s_tab[k] = a.sc_tab[k];
+  for (int k = tid; k < 125; k += NT) s_ds3[k] = (uint8_t)(k % 5 + (k / 5) % 5 + k / 25);
 
   for (int gl = tid; gl < G; gl += NT) {
     const int s2 = gl % nS, kk = a.shop_cust_ptr[s2 + 1] - a.shop_cust_ptr[s2];
@@ -324,14 +326,21 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
             const uint8_t* row = io.exo + ((int64_t)t * a.B + b) * a.n_exo;
             for (int k = s_cptr[s]; k < s_cptr[s + 1]; ++k) D += row[a.shop_cust_exo[k]];
           } else if (K > 0) {
-            D = __all(K >= 6) ? rng_digit_sum6(y) : rng_digit_sum(y, K < 6 ? K : 6, nullptr);
+            if (__all(K >= 6)) {
+              // digit sum of y < 5^6 from the 125-entry table: y = 125 hi + lo (y / 125 through f32 is exact)
+              const uint32_t hi = (uint32_t)((float)y * 0.008f);
+              D = (int)s_ds3[hi] + (int)s_ds3[y - 125u * hi];
+            } else {
+              D = rng_digit_sum(y, K < 6 ? K : 6, nullptr);
+            }
             for (int g = 1; 6 * g < K; ++g)
               D += rng_digit_sum(rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, g, 0), K - 6 * g < 6 ? K - 6 * g : 6, nullptr);
           }
           const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl]
                                                       : rng_j_to_action(aj);
           s_act[i] = action;
-          s_it[i] = dev_round_half_even(action);
+          // the random-policy action lies in [0, 100): no saturation needed before the conversion
+          s_it[i] = (REPLAY && io.actions) ? dev_round_half_even(action) : (int)rintf(action);
           s_it[it1 + i] = D;
         }
       }
@@ -690,7 +699,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   const int items = TC * G;
   const size_t lds = (size_t)((items + 3) & ~3) * 4 * 3 * 2 + (size_t)((items + 3) & ~3) * 4 * 2 +
                      (size_t)((G + 3) & ~3) * 4 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
-                     (size_t)((sp.S + 3) & ~3) * 4 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
+                     (size_t)((sp.S + 3) & ~3) * 4 + 128 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
   a.epb = epb; a.TC = TC;
   const dim3 grid((sp.B + epb - 1) / epb);
   const bool replay = io.actions != nullptr || io.exo != nullptr;
