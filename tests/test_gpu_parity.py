@@ -834,3 +834,54 @@ def test_fuzz_regressions():
     for k in ("obs", "actions", "rewards", "last_obs"):
         np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
     np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+
+
+def test_env_supertype_and_dict_vs_tensor_api():
+    """tests/test_supertypes_env.py:86-135 (env supertype: sampled in the constructor and at every
+    reset, env_type is None before the first reset) and the dict API against the tensor API."""
+    import torch
+    from dataclasses import dataclass
+
+    class MockSampler(ph.Sampler):
+        def __init__(self, value):
+            self._value = value
+
+        def sample(self):
+            self._value += 1
+            return self._value
+
+    class MockEnv(ph.PhantomEnv):
+        @dataclass
+        class Supertype(ph.Supertype):
+            type_value: float = 0.0
+
+        def __init__(self, **kw):
+            super().__init__(num_steps=5, network=ph.Network([ph.MockStrategicAgent("a1")]), **kw)
+
+    s1 = MockSampler(0)
+    env = MockEnv(env_supertype=MockEnv.Supertype(type_value=s1))
+    assert env._samplers == [s1] and env.env_type is None
+    env.reset()
+    assert env.env_type == MockEnv.Supertype(2)
+    env2 = MockEnv(env_supertype={"type_value": MockSampler(0)})
+    env2.reset()
+    assert env2.env_type == MockEnv.Supertype(2)
+    with pytest.raises(Exception):
+        MockEnv(env_supertype={"xxx": 0.0})
+
+    # dict API == tensor API (B = 3): same kernel launches, the dicts are views of the tensors
+    rng = np.random.RandomState(1)
+    ea = ph.SupplyChainEnv(n_shops=3, customers_per_shop=[2, 3, 1], num_steps=4, batch_size=3, seed=5, exogenous="device")
+    eb = ph.SupplyChainEnv(n_shops=3, customers_per_shop=[2, 3, 1], num_steps=4, batch_size=3, seed=5, exogenous="device")
+    oa, _ = ea.reset(); eb.reset()
+    for t in range(9):
+        act = rng.uniform(0, 100, (3, 3)).astype(np.float32)
+        sa = ea.step({f"SHOP{i}": act[:, i] for i in range(3)})
+        sb = eb.step(torch.from_numpy(act).to(eb._device().device))
+        obs_b, rew_b = sb.observations.cpu().numpy(), sb.rewards.cpu().numpy()
+        for i in range(3):
+            np.testing.assert_array_equal(sa.observations[f"SHOP{i}"], obs_b[:, i])
+            np.testing.assert_array_equal(sa.rewards[f"SHOP{i}"], rew_b[:, i])
+        assert bool(np.all(sa.truncations["__all__"])) == bool(sb.all_truncated.cpu().numpy().all())
+        if np.all(sa.truncations["__all__"]):
+            ea.reset(); eb.reset()
