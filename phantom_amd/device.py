@@ -95,16 +95,22 @@ class DeviceEnv:
             self._fields[f.name.decode()] = view.view(*shape)
         B, S, D = self.B, max(self.S, 1), self.D
         z = lambda *s, dtype: torch.zeros(*s, dtype=dtype, device=self.device)
-        self.obs = z(B, S, D, dtype=torch.float32)
-        self.reward = z(B, S, dtype=torch.float64)
-        self.obs_valid = z(B, S, dtype=torch.uint8)
-        self.reward_valid = z(B, S, dtype=torch.uint8)
-        self.terminated = z(B, S, dtype=torch.uint8)
-        self.truncated = z(B, S, dtype=torch.uint8)
-        self.done_valid = z(B, S, dtype=torch.uint8)
-        self.all_terminated = z(B, dtype=torch.uint8)
-        self.all_truncated = z(B, dtype=torch.uint8)
-        self.err = z(B, dtype=torch.int32)
+        # the step outputs are 256-byte aligned sections of ONE device buffer, so that the dict API
+        # (PhantomEnv.step) brings them to the host with a single copy (pull_step)
+        layout = [("obs", (B, S, D), torch.float32), ("reward", (B, S), torch.float64),
+                  ("obs_valid", (B, S), torch.uint8), ("reward_valid", (B, S), torch.uint8),
+                  ("terminated", (B, S), torch.uint8), ("truncated", (B, S), torch.uint8),
+                  ("done_valid", (B, S), torch.uint8), ("all_terminated", (B,), torch.uint8),
+                  ("all_truncated", (B,), torch.uint8), ("err", (B,), torch.int32)]
+        self._out_layout, total = [], 0
+        for name, shape, dtype in layout:
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            self._out_layout.append((name, shape, dtype, total, n))
+            total += (n + 255) & ~255
+        self._out_flat = z(total, dtype=torch.uint8)
+        self._out_host = None
+        for name, shape, dtype, off, n in self._out_layout:
+            setattr(self, name, self._out_flat[off:off + n].view(dtype).view(*shape))
         self.ones_valid = None
         self.msg_log = self.msg_count = None
         if spec.trace_cap > 0:
@@ -225,6 +231,17 @@ class DeviceEnv:
             self._check(rc, "phx_step")
         return self._step_out
 
+    def pull_step(self) -> Dict[str, "object"]:
+        """numpy views of the last step's outputs (and err), fetched with ONE device-to-host copy."""
+        torch = _torch()
+        if self._out_host is None:
+            self._out_host = torch.empty(self._out_flat.shape, dtype=torch.uint8, pin_memory=True)
+        self._out_host.copy_(self._out_flat, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        h = self._out_host.numpy()
+        return {name: h[off:off + n].view(np.dtype(str(dtype).replace("torch.", ""))).reshape(shape)
+                for name, shape, dtype, off, n in self._out_layout}
+
     def alloc_trajectory(self, T: int) -> Trajectory:
         """Uninitialised device buffers for a T-step fragment (time-major)."""
         torch = _torch()
@@ -313,9 +330,10 @@ class DeviceEnv:
                                record_to_payload(int(r["type"]), raw_i, raw_f)))
         return out
 
-    def raise_errors(self, network=None):
+    def raise_errors(self, network=None, err=None):
         """Re-raise per-env soft error codes as the exceptions the reference raises in step()."""
-        err = self.err.cpu().numpy()
+        if err is None:
+            err = self.err.cpu().numpy()
         bad = np.flatnonzero(err)
         if bad.size == 0:
             return

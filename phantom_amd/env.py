@@ -318,12 +318,13 @@ class PhantomEnv:
         dev = self._device()
         act, valid = self._actions_tensor(actions)
         exo = self._draw_exo()
-        out = dev.step(act, valid, exo)
+        dev.step(act, valid, exo)
         self._host_advance()
-        dev.raise_errors(self.network)
+        h = dev.pull_step()                                # one device-to-host copy for all outputs
+        dev.raise_errors(self.network, err=h["err"])
         if self.network.resolver.enable_tracking:
             self.network.resolver._tracked_messages.extend(dev.read_log(0))
-        return self._step_dicts(out)
+        return self._step_dicts(h)
 
     def step_tensors(self, actions, action_valid=None, exo=None, check_errors: bool = False):
         """Tensor-native step: ``actions`` f32 [B, S] on the env's device; returns StepTensors
@@ -345,16 +346,14 @@ class PhantomEnv:
         self._h_step = (self._h_step + T) % max(self.num_steps, 1)
         return traj
 
-    def _step_dicts(self, out) -> "PhantomEnv.Step":
+    def _step_dicts(self, h) -> "PhantomEnv.Step":
+        """``h``: DeviceEnv.pull_step() of the step just taken."""
         spec = self.spec
         B = self.batch_size
-        obs = out.observations.cpu().numpy()
-        rew = out.rewards.cpu().numpy()
-        term = out.terminations.cpu().numpy().astype(bool)
-        trunc = out.truncations.cpu().numpy().astype(bool)
-        ov, rv, dv = (out.obs_valid.cpu().numpy(), out.reward_valid.cpu().numpy(),
-                      out.done_valid.cpu().numpy())
-        at, au = out.all_terminated.cpu().numpy().astype(bool), out.all_truncated.cpu().numpy().astype(bool)
+        obs, rew = h["obs"], h["reward"]
+        term, trunc = h["terminated"].astype(bool), h["truncated"].astype(bool)
+        ov, rv, dv = h["obs_valid"], h["reward_valid"], h["done_valid"]
+        at, au = h["all_terminated"].astype(bool), h["all_truncated"].astype(bool)
         observations, rewards, terminations, truncations, infos = {}, {}, {}, {}, {}
         for s, a in enumerate(spec.strategic_idx):
             aid = spec.agent_ids[a]
