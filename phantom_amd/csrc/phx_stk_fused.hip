@@ -273,7 +273,15 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
       io.terminated[o] = 0; io.truncated[o] = terminal;
       io.obs_valid[o] = ov; io.reward_valid[o] = rv;
       if (last && io.last_obs) {
-        if (terminal) { ob0 = 0.f; ob1 = 0.f; }
+        // the observation the next fragment starts from: after a terminal step, the reset's (the
+        // leaders observe their reset state, stackelberg.py:95-109: a seller sees tx / deg = 0 and
+        // price 0, a buyer among the leaders no prices yet -> 1.0, and its value)
+        if (terminal) {
+          const bool lead_buyer = (sp.stk_flags[a] & 1) != 0 &&           // acts on the leaders' step
+                                  (sp.stk_rec[a] & 255u) != PHX_KIND_SELLER;
+          ob0 = lead_buyer ? 1.0f : 0.f;
+          ob1 = lead_buyer ? (float)sp.param_f[a * PHX_NPF] : 0.f;
+        }
         *(float2*)(io.last_obs + (abase + a) * 2) = make_float2(ob0, ob1);
       }
     }

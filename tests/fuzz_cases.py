@@ -48,10 +48,16 @@ def sc_case(rng, case):
         host_fed = rng.rand() < 0.4                      # sampler values passed to phx_reset instead of device-drawn
         kw["exogenous"] = "numpy" if host_fed else "device"
     if fsm:
-        stages = [ph.FSMStage("A", acting_agents=[s.id for s in shops], rewarded_agents=[s.id for s in shops if rng.rand() < 0.7], next_stages=["B"]),
-                  ph.FSMStage("B", acting_agents=[c.id for c in custs if rng.rand() < 0.8] + [s.id for s in shops if rng.rand() < 0.2],
-                              rewarded_agents=None if rng.rand() < 0.3 else [s.id for s in shops if rng.rand() < 0.5], next_stages=["A"])]
-        env = ph.FiniteStateMachineEnv(num_steps, net, initial_stage="A", stages=stages, agent_supertypes=sup, **kw)
+        n_st = int(rng.randint(2, 5))                          # 2..4 stages in a cycle, random tables
+        names = [chr(ord("A") + i) for i in range(n_st)]
+        stages = []
+        for i, nm in enumerate(names):
+            acting = [c.id for c in custs if rng.rand() < 0.6] + [s.id for s in shops if rng.rand() < 0.5]
+            acting = [acting[j] for j in rng.permutation(len(acting))]
+            rewarded = None if rng.rand() < 0.3 else [s.id for s in shops if rng.rand() < 0.5]
+            stages.append(ph.FSMStage(nm, acting_agents=acting, rewarded_agents=rewarded, next_stages=[names[(i + 1) % n_st]]))
+        env = ph.FiniteStateMachineEnv(num_steps, net, initial_stage=names[int(rng.randint(n_st))], stages=stages,
+                                       agent_supertypes=sup, **kw)
     else:
         env = ph.PhantomEnv(num_steps, net, agent_supertypes=sup, **kw)
     spec = env.spec
@@ -110,7 +116,15 @@ def stk_case(rng, case):
     else:
         net = ph.Network(agents)
         for u, v in pairs: net.add_connection(u, v)
-    leaders = [s.id for s in sellers]; followers = [b.id for b in buyers]
+    if rng.rand() < 0.6:
+        leaders = [s.id for s in sellers]; followers = [b.id for b in buyers]
+    else:                                                  # arbitrary lists: any agent on either side, or on none
+        leaders, followers = [], []
+        for ag in [agents[i] for i in rng.permutation(len(agents))]:
+            r = rng.rand()
+            p_lead = 0.7 if isinstance(ag, ph.SellerAgent) else 0.2
+            if r < 0.1: continue
+            (leaders if rng.rand() < p_lead else followers).append(ag.id)
     env = ph.StackelbergEnv(num_steps, net, leaders, followers, batch_size=B, seed=int(rng.randint(1 << 30)),
                             env_offset=int(rng.randint(1 << 20)), force_generic=force_generic, exogenous="device")
     spec = env.spec
