@@ -64,19 +64,22 @@ def supply_chain_case(rng, case):
         sup_r = {s: RShop.Supertype(excess_stock_weight=v) for s, v in consts.items()}
         sup_m = {s: ph.TypedShopAgent.Supertype(excess_stock_weight=v) for s, v in consts.items()}
     if fsm:
-        def stage_lists():
-            a1 = [shops[i] for i in rng.permutation(S) if rng.rand() < 0.9]
-            a2 = [c for c in (custs[i] for i in rng.permutation(len(custs))) if rng.rand() < 0.85] + [s for s in shops if rng.rand() < 0.2]
-            r1 = None if rng.rand() < 0.3 else [s for s in shops if rng.rand() < 0.6]
-            r2 = None if rng.rand() < 0.3 else [s for s in shops if rng.rand() < 0.6]
-            return a1, a2, r1, r2
-        a1, a2, r1, r2 = stage_lists()
-        renv = rph.FiniteStateMachineEnv(num_steps=num_steps, network=rnet, initial_stage="A", agent_supertypes=sup_r,
-                                         stages=[rph.FSMStage("A", acting_agents=a1, rewarded_agents=r1, next_stages=["B"]),
-                                                 rph.FSMStage("B", acting_agents=a2, rewarded_agents=r2, next_stages=["A"])])
-        menv = ph.FiniteStateMachineEnv(num_steps, mnet, initial_stage="A", agent_supertypes=sup_m,
-                                        stages=[ph.FSMStage("A", acting_agents=a1, rewarded_agents=r1, next_stages=["B"]),
-                                                ph.FSMStage("B", acting_agents=a2, rewarded_agents=r2, next_stages=["A"])])
+        n_st = int(rng.randint(2, 5))                          # 2..4 stages in a cycle, random tables
+        snames = [chr(ord("A") + i) for i in range(n_st)]
+        tabs = []
+        for i in range(n_st):
+            acting = [c for c in custs if rng.rand() < 0.6] + [s for s in shops if rng.rand() < 0.5]
+            acting = [acting[j] for j in rng.permutation(len(acting))]
+            rewarded = None if rng.rand() < 0.3 else [s for s in shops if rng.rand() < 0.5]
+            tabs.append((acting, rewarded))
+        init = snames[int(rng.randint(n_st))]
+        renv = rph.FiniteStateMachineEnv(num_steps=num_steps, network=rnet, initial_stage=init, agent_supertypes=sup_r,
+                                         stages=[rph.FSMStage(nm, acting_agents=a_, rewarded_agents=r_, next_stages=[snames[(i + 1) % n_st]])
+                                                 for i, (nm, (a_, r_)) in enumerate(zip(snames, tabs))])
+        menv = ph.FiniteStateMachineEnv(num_steps, mnet, initial_stage=init, agent_supertypes=sup_m,
+                                        stages=[ph.FSMStage(nm, acting_agents=a_, rewarded_agents=r_, next_stages=[snames[(i + 1) % n_st]])
+                                                for i, (nm, (a_, r_)) in enumerate(zip(snames, tabs))])
+        acting_of = {nm: a_ for nm, (a_, r_) in zip(snames, tabs)}
     else:
         renv = rph.PhantomEnv(num_steps=num_steps, network=rnet, agent_supertypes=sup_r)
         menv = ph.PhantomEnv(num_steps, mnet, agent_supertypes=sup_m)
@@ -104,7 +107,7 @@ def supply_chain_case(rng, case):
             st = renv.step(acts)
         # the customers that drew, in consumption order = acting order
         if fsm:
-            acting = [c for c in (a1 if renv.previous_stage == "A" else a2) if str(c).startswith("C")]
+            acting = [c for c in acting_of[renv.previous_stage] if str(c).startswith("C")]
         else:
             acting = [c for c in spec.agent_ids if str(c).startswith("C")]
         exo = np.zeros((1, max(spec.n_exo, 1)), np.uint8)
@@ -160,8 +163,16 @@ def market_case(rng, case):
         rnet, mnet = rph.Network(r_agents), ph.Network(m_agents)
         for u, v in pairs:
             rnet.add_connection(u, v); mnet.add_connection(u, v)
-    leaders = [f"S{i}" for i in rng.permutation(L)]
-    followers = [f"B{i}" for i in rng.permutation(Fw)]
+    if rng.rand() < 0.5:
+        leaders = [f"S{i}" for i in rng.permutation(L)]
+        followers = [f"B{i}" for i in rng.permutation(Fw)]
+    else:                                                  # arbitrary lists: any agent on either side, or on none
+        leaders, followers = [], []
+        allids = [f"S{i}" for i in range(L)] + [f"B{i}" for i in range(Fw)]
+        for aid_ in [allids[i] for i in rng.permutation(len(allids))]:
+            if rng.rand() < 0.1:
+                continue
+            (leaders if rng.rand() < (0.7 if aid_.startswith("S") else 0.2) else followers).append(aid_)
     renv = rph.StackelbergEnv(num_steps, rnet, leaders, followers)
     menv = ph.StackelbergEnv(num_steps, mnet, leaders, followers)
     spec = menv.spec
