@@ -21,6 +21,9 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st);
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+hipError_t phx_launch_gen_policy(const DevSpec& sp, int t, const float* actions_in, float* actions, float* action_out, hipStream_t st);
+hipError_t phx_launch_gen_collect(const DevSpec& sp, int t, const phx_step_io& step, const phx_rollout_io& io, uint8_t* done, hipStream_t st);
+hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st);
 size_t phx_stk_rollout_lds(const DevSpec& sp);
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 
@@ -260,6 +263,19 @@ static int derive(const phx_spec* sp, Derived& d) {
   return PHX_OK;
 }
 
+// ---- scratch of the launch-loop rollout: the outputs of one phx_step for the whole batch ----------------
+struct GenScratch { int64_t obs, reward, obs_valid, reward_valid, terminated, truncated, done_valid, all_term, all_trunc, done, actions, total; };
+static GenScratch gen_scratch(int64_t B, int64_t S, int64_t D) {
+  GenScratch g; int64_t off = 0;
+  auto take = [&](int64_t bytes) { const int64_t o = off; off += (bytes + 255) & ~(int64_t)255; return o; };
+  g.obs = take(B * S * D * 4); g.reward = take(B * S * 8);
+  g.obs_valid = take(B * S); g.reward_valid = take(B * S); g.terminated = take(B * S); g.truncated = take(B * S);
+  g.done_valid = take(B * S); g.all_term = take(B); g.all_trunc = take(B); g.done = take(B); g.actions = take(B * S * 4);
+  g.total = off;
+  return g;
+}
+static int64_t gen_rollout_scratch_bytes(int64_t B, int64_t S, int64_t D) { return gen_scratch(B, S, D).total; }
+
 // ---- state blob layout ------------------------------------------------------------------------------
 struct FieldDef { int id; const char* name; int dtype; int kind; int64_t dim0, dim1, dim2; int64_t offset; };
 
@@ -312,6 +328,13 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     FieldDef w = {F_WORKSPACE, "workspace", 2, 0, B, *ws_stride, 1, off};
     off += B * *ws_stride;
     out.push_back(w);
+  }
+  // step-shaped scratch of the launch-loop rollout (envs without a fused rollout kernel)
+  if (!d.sc_static && !d.stk_static) {
+    const int64_t n = gen_rollout_scratch_bytes(B, S, d.D);
+    FieldDef r = {F_ROLLOUT_SCRATCH, "rollout.scratch", 2, 0, 1, n, 1, off};
+    off += n;
+    out.push_back(r);
   }
   return std::max<int64_t>(off, 256);
 }
@@ -562,8 +585,6 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
-  if (!e->use_fused && !(e->use_stk && e->prices_compressed))
-    return fail(PHX_EUNSUPPORTED, "phx_rollout needs a static supply-chain schedule (plain or FSM env) or a static Stackelberg market");
   if (e->d.env_type != PHX_ENV_PLAIN && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
@@ -572,6 +593,36 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   if (e->use_fused && e->d.max_cust >= 65535) return fail(PHX_EUNSUPPORTED, "phx_rollout: at most 65534 customers per shop");
   HIPCHK(use_device(e));
+  if (!e->use_fused && !(e->use_stk && e->prices_compressed)) {
+    // Launch loop for every other env (any topology of the device kinds, tracking off): per step a
+    // policy kernel, the generic engine, a collect kernel and the masked auto-reset, all stream
+    // ordered, the step-shaped intermediates in the blob's rollout.scratch field.
+    if (!e->d.f[F_ROLLOUT_SCRATCH]) return fail(PHX_EUNSUPPORTED, "phx_rollout: this env switched engines after creation");
+    if (e->n_inject) return fail(PHX_EINVAL, "phx_rollout with injected messages pending");
+    hipStream_t st = (hipStream_t)stream;
+    const GenScratch gs = gen_scratch(e->d.B, std::max(e->d.S, 1), e->d.D);
+    char* base = (char*)e->d.f[F_ROLLOUT_SCRATCH];
+    phx_step_io sio; memset(&sio, 0, sizeof sio);
+    sio.actions = (const float*)(base + gs.actions);
+    sio.obs = (float*)(base + gs.obs); sio.obs_valid = (uint8_t*)(base + gs.obs_valid);
+    sio.reward = (double*)(base + gs.reward); sio.reward_valid = (uint8_t*)(base + gs.reward_valid);
+    sio.terminated = (uint8_t*)(base + gs.terminated); sio.truncated = (uint8_t*)(base + gs.truncated);
+    sio.done_valid = (uint8_t*)(base + gs.done_valid);
+    sio.all_terminated = (uint8_t*)(base + gs.all_term); sio.all_truncated = (uint8_t*)(base + gs.all_trunc);
+    sio.err = io->err;
+    uint8_t* done = (uint8_t*)(base + gs.done);
+    GenArgs g; g.io = sio; g.inject = e->inject_dev; g.n_inject = 0; g.resolve_only = 0; g.timing = nullptr;
+    for (int t = 0; t < io->T; ++t) {
+      sio.exo = io->exo ? io->exo + (int64_t)t * e->d.B * e->d.n_exo : nullptr;
+      g.io = sio;
+      HIPCHK(phx_launch_gen_policy(e->d, t, io->actions, (float*)(base + gs.actions), io->action_out, st));
+      HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
+      HIPCHK(phx_launch_gen_collect(e->d, t, sio, *io, done, st));
+      HIPCHK(phx_launch_reset(e->d, done, nullptr, nullptr, sio.obs, sio.obs_valid, st));     // the caller's env.reset()
+    }
+    if (io->last_obs) HIPCHK(phx_launch_gen_last_obs(e->d, sio.obs, io->last_obs, st));
+    return PHX_OK;
+  }
   if (e->use_stk) {
     if (io->exo) return fail(PHX_EINVAL, "the market has no exogenous draws");
     if (phx_stk_rollout_lds(e->d) > 60 * 1024) return fail(PHX_EUNSUPPORTED, "market too large for the LDS-resident rollout");

@@ -32,7 +32,7 @@ enum {
   F_CASHBOX_TOTAL,
   F_REQRESP_REQ, F_REQRESP_RES,
   F_MOCK_ENC, F_MOCK_DEC, F_MOCK_REW,
-  F_WORKSPACE,
+  F_WORKSPACE, F_ROLLOUT_SCRATCH,
   F_COUNT
 };
 

@@ -580,3 +580,69 @@ hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double
   hipLaunchKernelGGL((phx_reset_kernel<64>), dim3(sp.B), dim3(64), 0, st, sp, mask, sampler_values, conn_values, obs, obs_valid);
   return hipGetLastError();
 }
+
+// ---- launch-loop rollout for envs without a fused rollout kernel (phx_api.hip: phx_rollout) ------------
+// random policy = the strategic agent's word of the tick (rank j, see the device-RNG definition):
+// ShopAgent / mock agents j * 100 / 274877, Seller price j / 274877, Buyer buys iff j < 137438; on a
+// Stackelberg env only the side that acts takes (and records) an action.
+__global__ void phx_gen_policy_kernel(const DevSpec sp, const int t, const float* actions_in, float* actions,
+                                      float* action_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)sp.B * sp.S) return;
+  const int b = (int)(i / sp.S), s = (int)(i - (int64_t)b * sp.S);
+  const int a = sp.strat_idx[s], kind = sp.kind[a];
+  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  bool acts = true;
+  if (sp.env_type == PHX_ENV_STACKELBERG) {
+    const int list = ((fld<int32_t>(sp, F_ENV_STEP)[b] + 1) & 1) ? 0 : 1;
+    acts = sp.act_mask[(int64_t)list * sp.A + a] != 0;
+  }
+  float action = 0.f;
+  if (acts) {
+    if (actions_in) action = actions_in[(int64_t)t * sp.B * sp.S + i];
+    else {
+      uint32_t j;
+      rng_group_y(sp.seed, sp.env_offset + b, tick, s, 0, 0, &j);
+      action = kind == PHX_KIND_SELLER ? (float)j * (1.0f / 274877.0f)
+             : kind == PHX_KIND_BUYER ? (j < 137438u ? 1.0f : 0.0f) : rng_j_to_action(j);
+    }
+  }
+  actions[i] = action;
+  action_out[(int64_t)t * sp.B * sp.S + i] = action;
+}
+// one step's outputs -> trajectory row t; done[b] = the env's episode ended (the caller would reset)
+__global__ void phx_gen_collect_kernel(const DevSpec sp, const int t, const phx_step_io step, const phx_rollout_io io,
+                                       uint8_t* done) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)sp.B * sp.S) return;
+  const int b = (int)(i / sp.S);
+  const int64_t o = (int64_t)t * sp.B * sp.S + i;
+  const uint8_t at = step.all_terminated[b], au = step.all_truncated[b];
+  for (int d = 0; d < sp.D; ++d) io.obs[o * sp.D + d] = step.obs[i * sp.D + d];
+  io.reward[o] = (float)step.reward[i];
+  io.terminated[o] = (uint8_t)(step.terminated[i] | at);
+  io.truncated[o] = (uint8_t)(step.truncated[i] | au);
+  if (io.obs_valid) io.obs_valid[o] = step.obs_valid[i];
+  if (io.reward_valid) io.reward_valid[o] = step.reward_valid[i];
+  if (i - (int64_t)b * sp.S == 0) done[b] = (uint8_t)(at | au);
+}
+__global__ void phx_gen_last_obs_kernel(const int64_t n, const float* obs, float* last_obs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) last_obs[i] = obs[i];
+}
+
+hipError_t phx_launch_gen_policy(const DevSpec& sp, int t, const float* actions_in, float* actions, float* action_out, hipStream_t st) {
+  const int64_t n = (int64_t)sp.B * sp.S;
+  if (n > 0) hipLaunchKernelGGL(phx_gen_policy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp, t, actions_in, actions, action_out);
+  return hipGetLastError();
+}
+hipError_t phx_launch_gen_collect(const DevSpec& sp, int t, const phx_step_io& step, const phx_rollout_io& io, uint8_t* done, hipStream_t st) {
+  const int64_t n = (int64_t)sp.B * sp.S;
+  if (n > 0) hipLaunchKernelGGL(phx_gen_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp, t, step, io, done);
+  return hipGetLastError();
+}
+hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st) {
+  const int64_t n = (int64_t)sp.B * sp.S * sp.D;
+  if (n > 0) hipLaunchKernelGGL(phx_gen_last_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, obs, last_obs);
+  return hipGetLastError();
+}

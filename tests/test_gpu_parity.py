@@ -885,3 +885,32 @@ def test_env_supertype_and_dict_vs_tensor_api():
         assert bool(np.all(sa.truncations["__all__"])) == bool(sb.all_truncated.cpu().numpy().all())
         if np.all(sa.truncations["__all__"]):
             ea.reset(); eb.reset()
+
+
+def test_launch_loop_rollout_for_generic_engine_envs():
+    """phx_rollout on envs without a fused rollout kernel (stochastic market; supply chain forced onto
+    the generic engine): the stream-ordered launch loop vs the oracle, incl. auto-reset redraws."""
+    env = market_env(5, 14, 3, 6, 9, rates=[0.8, 0.3, 1.0, 0.0, 0.55], seed=4, env_offset=2, exogenous="device")
+    o, x = OracleEnv(env.spec), _dev(env.spec)
+    assert not x.dev.uses_fused
+    o.reset(); x.reset()
+    ro, rd = o.rollout(20), x.rollout(20)
+    for k in ("obs_valid", "reward_valid", "truncated", "terminated"):
+        np.testing.assert_array_equal(rd[k], ro[k], err_msg=k)
+    for k in ("obs", "actions", "rewards", "last_obs"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    np.testing.assert_array_equal(x.get_u8("net.conn_on"), o.get_u8("net.conn_on"))     # redrawn 3 times
+    assert ro["truncated"].sum() > 0
+    env = supply_chain_env(4, [2, 7, 0, 3], 5, 11, force_generic=True, seed=9, norm_customers=3)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-10, 120, (17, 11, 4)).astype(np.float32)
+    exo = rng.randint(0, 5, (17, 11, 12)).astype(np.uint8)
+    for a_, x_ in ((None, None), (acts, exo)):
+        ro, rd = o.rollout(17, a_, x_), d.rollout(17, a_, x_)
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+        np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+    for f in ("shop.stock", "shop.sales", "env.step", "env.tick"):
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
