@@ -343,8 +343,12 @@ class PhantomEnv:
         """T fused steps on the device with auto-reset at episode end (the loop of
         utils/rllib/rollout.py:300-363 in one launch).  Returns a device Trajectory."""
         traj = self._device().rollout(T, actions, exo, out)
-        self._h_step = (self._h_step + T) % max(self.num_steps, 1)
+        self._sync_host_state()
         return traj
+
+    def _sync_host_state(self):
+        """host mirrors of the env clock (current_step, FSM stages) re-read from the device state."""
+        self._h_step = self._device().field("env.step")[:, 0].cpu().numpy().astype(np.int64)
 
     def _step_dicts(self, h) -> "PhantomEnv.Step":
         """``h``: DeviceEnv.pull_step() of the step just taken."""

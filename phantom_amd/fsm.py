@@ -132,6 +132,12 @@ class FiniteStateMachineEnv(PhantomEnv):
         self._h_step[sel] = 0
         self._h_stage[sel] = self._stage_index[self._initial_stage]      # fsm.py:217
 
+    def _sync_host_state(self):
+        super()._sync_host_state()
+        dev = self._device()
+        self._h_stage = dev.field("env.stage")[:, 0].cpu().numpy().astype(np.int64)
+        self.previous_stage_idx = dev.field("env.prev_stage")[:, 0].cpu().numpy().astype(np.int64)
+
     def _host_advance(self):
         self._h_step += 1
         nxt = np.asarray([self._stage_index[s.next_stages[0]] for s in self._stage_list])

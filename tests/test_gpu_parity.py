@@ -914,3 +914,16 @@ def test_launch_loop_rollout_for_generic_engine_envs():
         np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
     for f in ("shop.stock", "shop.sales", "env.step", "env.tick"):
         np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
+
+
+def test_host_clock_mirrors_after_rollout():
+    """env.current_step / current_stage / previous_stage follow the device state after env.rollout()."""
+    env = ph.SupplyChainFSMEnv(n_shops=2, customers_per_shop=2, num_steps=6, batch_size=3, seed=1, exogenous="device")
+    env.reset()
+    env.rollout(9)                                  # 6 steps + auto-reset + 3 steps: stage SELL after an odd count
+    assert list(env.current_step) == [3, 3, 3]
+    assert env.current_stage == ["SELL"] * 3 and env.previous_stage == ["RESTOCK"] * 3
+    import torch
+    out = env.step(torch.zeros(3, 2, device=env._device().device))
+    assert list(env.current_step) == [4, 4, 4] and env.current_stage == ["RESTOCK"] * 3
+    assert int(out.obs_valid.sum()) == 6            # shops observe on the SELL -> RESTOCK transition
