@@ -130,7 +130,8 @@ class BatchedBaseEnv:
             mask = np.zeros(self.env.batch_size, dtype=np.uint8)
             mask[env_id] = 1
         dev = self.env._device()
-        obs, valid = dev.reset(mask)
+        sampler_values, conn_on = self.env._host_draws(mask)       # env.py:211-218 (None: device-drawn)
+        obs, valid = dev.reset(mask, sampler_values, conn_on)
         self.env._host_reset(mask)
         o, v = obs.cpu().numpy(), valid.cpu().numpy()
         rows = {b: _EnvRow(self._ids, o, v, b) for b in
@@ -151,14 +152,15 @@ class BatchedBaseEnv:
             empty = {b: {} for b in range(B)}
             return rows, empty, {b: {"__all__": False} for b in range(B)}, \
                 {b: {"__all__": False} for b in range(B)}, infos, {}
-        out = self._pending
         self._pending = None
         B = self.env.batch_size
-        obs, ov = out.observations.cpu().numpy(), out.obs_valid.cpu().numpy()
-        rew, rv = out.rewards.cpu().numpy(), out.reward_valid.cpu().numpy() == 1
-        term, trunc = out.terminations.cpu().numpy().astype(bool), out.truncations.cpu().numpy().astype(bool)
-        dv = out.done_valid.cpu().numpy()
-        at, au = out.all_terminated.cpu().numpy().astype(bool), out.all_truncated.cpu().numpy().astype(bool)
+        h = self.env._device().pull_step()                         # one device-to-host copy; copies: the
+        h = {k: v.copy() for k, v in h.items()}                    # rows outlive the next step
+        obs, ov = h["obs"], h["obs_valid"]
+        rew, rv = h["reward"], h["reward_valid"] == 1
+        term, trunc = h["terminated"].astype(bool), h["truncated"].astype(bool)
+        dv = h["done_valid"]
+        at, au = h["all_terminated"].astype(bool), h["all_truncated"].astype(bool)
         obs_d = {b: _EnvRow(self._ids, obs, ov, b) for b in range(B)}
         rew_d = {b: _EnvRow(self._ids, rew, rv, b, scalar=True) for b in range(B)}
         term_d = {b: _EnvRow(self._ids, term, dv, b, {"__all__": bool(at[b])}, scalar=True) for b in range(B)}
