@@ -83,6 +83,62 @@ def cpu_baseline(budget_s=12.0):
             "single_core_value": single, "host_cpu_count": cores}
 
 
+def other_configs(device):
+    """per-step time of BASELINE.json's configs 3, 4 (one GPU's share) and 5 -- not part of `value`."""
+    import phantom_amd as ph
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import market_env
+    res = []
+
+    def timed(fn, n):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3                    # seconds per call
+
+    def add(name, agents, B, steps_per_call, sec, mode):
+        res.append({"config": name, "mode": mode, "agents": agents, "envs": B,
+                    "us_per_step": sec / steps_per_call * 1e6,
+                    "agent_steps_per_sec": agents * B * steps_per_call / sec})
+
+    # config 3: SC256 (1 + 51 + 204 agents), 2-stage FSM, B = 8192
+    env = ph.SupplyChainFSMEnv(n_shops=51, customers_per_shop=4, num_steps=100, batch_size=8192, seed=42,
+                               exogenous="device", device=device)
+    env.reset(); dev = env._device()
+    tr = dev.rollout(100)
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 3), "fused FSM rollout T=100")
+    acts = torch.rand(8192, 51, device=dev.device) * 100.0
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 1, timed(lambda: dev.step(acts), 100), "one launch per step")
+    del env, dev, tr, acts; torch.cuda.empty_cache()
+    # config 4, one GPU's share: SC256 plain, B = 8192 per GPU, rollout T = 100
+    env = ph.SupplyChainEnv(n_shops=51, customers_per_shop=4, num_steps=100, batch_size=8192, seed=42,
+                            exogenous="device", device=device)
+    env.reset(); dev = env._device()
+    tr = dev.rollout(100)
+    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 3), "fused rollout T=100")
+    del env, dev, tr; torch.cuda.empty_cache()
+    # config 5: Stackelberg market 128 leaders / 1024 followers, B = 4096
+    env = market_env(128, 1024, 8, 100, 4096, exogenous="device", device=device)
+    env.reset(); dev = env._device()
+    S = 1152
+    valid = [torch.zeros(4096, S, dtype=torch.uint8, device=dev.device) for _ in range(2)]
+    valid[0][:, :128] = 1; valid[1][:, 128:] = 1
+    acts = torch.rand(4096, S, device=dev.device)
+    k = [0]
+
+    def one():
+        dev.step(acts, valid[k[0] & 1]); k[0] += 1
+    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 1, timed(one, 40), "one launch per step")
+    tr = dev.rollout(20)
+    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 20, timed(lambda: dev.rollout(20, out=tr), 2), "fused rollout T=20")
+    del env, dev, tr
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,7 +272,7 @@ def main():
         acts = torch.rand(ksteps, B, S, device=dev.device) * 100.0
         env.reset()
         for i in range(20):
-            dev.step(acts[i])
+            dev.step(acts[i % ksteps])
         sync_barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter(); e0.record()
@@ -240,7 +297,7 @@ def main():
             torch.cuda.synchronize()
             with torch.cuda.graph(g, stream=side):
                 for i in range(100):
-                    dev.step(acts[i])
+                    dev.step(acts[i % ksteps])
             for _ in range(3):
                 g.replay()
             torch.cuda.synchronize()
@@ -290,6 +347,12 @@ def main():
         out["rollout_allgather"]["pipelined_agent_steps_per_sec"] = N_AGENTS * B * world * T / pc
         out["rollout_allgather"]["pipeline"] = (f"{col.n_chunks} chunk(s) of {col.chunk} steps, "
                                                  "2 staging buffers, gather on a side stream")
+
+    # ---- BASELINE.json configs 3-5 on this GPU (parity-test cases; reported for orientation only) ------
+    if rank == 0 and world == 1 and args.config == "sc64" and not args.no_other_configs:
+        del traj
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(f"cuda:{local_rank}")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
