@@ -76,6 +76,9 @@ static int derive(const phx_spec* sp, Derived& d) {
   if (sp->batch <= 0) return fail(PHX_EINVAL, "batch must be positive");
   if (!sp->kind || !sp->param_i || !sp->param_f || !sp->row_ptr || !sp->col) return fail(PHX_EINVAL, "null table");
   if (sp->queue_cap <= 0) return fail(PHX_EINVAL, "queue_cap must be positive");
+  // the device RNG counter carries the global env index in 48 bits (bits 48.. hold the redraw attempt)
+  if (sp->env_offset < 0 || sp->env_offset + (int64_t)sp->batch > ((int64_t)1 << 48))
+    return fail(PHX_EINVAL, "env_offset + batch must stay below 2^48");
   const int A = sp->n_agents;
   if (sp->n_samplers < 0 || (sp->n_samplers > 0 && (!sp->sampler_kind || !sp->sampler_param)))
     return fail(PHX_EINVAL, "sampler tables missing");
