@@ -58,11 +58,27 @@ def supply_chain_case(rng, case):
     shops = [f"SHOP{i}" for i in range(S)]
     custs = [f"C{i}_{j}" for i in range(S) for j in range(ks[i])]
     sup_r = sup_m = None
-    consts = {}
+    r_samplers, m_samplers = [], []
     if typed:
-        consts = {s: float(rng.randint(0, 21)) / 100.0 for s in shops if rng.rand() < 0.7}
-        sup_r = {s: RShop.Supertype(excess_stock_weight=v) for s, v in consts.items()}
-        sup_m = {s: ph.TypedShopAgent.Supertype(excess_stock_weight=v) for s, v in consts.items()}
+        from phantom.utils.samplers import UniformFloatSampler as RUniform
+        n_sm = int(rng.randint(0, 3))
+        prm = [(float(rng.uniform(0, 0.1)), float(rng.uniform(0.1, 0.2)), None if rng.rand() < 0.5 else 0.04,
+                None if rng.rand() < 0.5 else 0.16) for _ in range(n_sm)]
+        r_samplers = [RUniform(*q) for q in prm]
+        m_samplers = [ph.UniformFloatSampler(*q) for q in prm]
+        sup_r, sup_m = {}, {}
+        for s in shops:
+            r = rng.rand()
+            if r < 0.25:
+                continue                                     # no supertype passed: Supertype() defaults
+            if r < 0.6 and n_sm:
+                j = int(rng.randint(n_sm))
+                sup_r[s] = RShop.Supertype(excess_stock_weight=r_samplers[j])
+                sup_m[s] = ph.TypedShopAgent.Supertype(excess_stock_weight=m_samplers[j])
+            else:
+                v = float(rng.randint(0, 21)) / 100.0
+                sup_r[s] = RShop.Supertype(excess_stock_weight=v)
+                sup_m[s] = ph.TypedShopAgent.Supertype(excess_stock_weight=v)
     if fsm:
         n_st = int(rng.randint(2, 5))                          # 2..4 stages in a cycle, random tables
         snames = [chr(ord("A") + i) for i in range(n_st)]
@@ -93,7 +109,11 @@ def supply_chain_case(rng, case):
     for t in range(T):
         if need_reset:
             robs, _ = renv.reset()
-            oobs, ovalid = o.reset()
+            # the values the reference's samplers drew at this reset, in env._samplers order
+            vals = np.asarray([[sm.value for sm in renv._samplers]], np.float64) if spec.n_samplers else None
+            if spec.n_samplers:
+                assert len(renv._samplers) == spec.n_samplers
+            oobs, ovalid = o.reset(None, vals)
             assert {k for k in robs} == {spec.strategic_ids[s] for s in range(Ss) if ovalid[0, s]}, (case, t, "reset keys")
             for k, v in robs.items():
                 assert np.array_equal(f32_bits(v), f32_bits(oobs[0, sidx[k], :len(v)])), (case, t, "reset obs", k)
