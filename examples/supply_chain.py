@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""The supply-chain example of the reference (examples/environments/supply_chain/supply_chain.py)
+on the MI355X path, three ways.  Needs a GPU and the built library
+(python -c "import __graft_entry__ as g; g.build()").
+
+    python examples/supply_chain.py
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import phantom_amd as ph
+
+# 1. drop-in: one env instance, the reference's dict API, the global numpy stream for the customers
+np.random.seed(0)
+env = ph.SupplyChainEnv()                       # 1 factory, 1 shop, 5 customers, 100 steps
+obs, _ = env.reset()
+total = 0.0
+for t in range(env.num_steps):
+    step = env.step({"SHOP": np.array([20.0], dtype=np.float32)})
+    total += step.rewards["SHOP"]
+print(f"B=1 dict API: episode return {total:.2f}, final stock {env['SHOP'].stock}, done {step.truncations['__all__']}")
+
+# 2. batched: 4096 envs of the 64-agent benchmark topology, tensors stay on the GPU
+env = ph.SupplyChainEnv(n_shops=9, customers_per_shop=6, batch_size=4096, seed=42, exogenous="device")
+env.reset()
+actions = torch.full((4096, 9), 30.0, device=env._device().device)
+out = env.step(actions)                         # StepTensors: device views, no host sync
+print("B=4096 tensor API: mean reward", float(out.rewards.mean()))
+
+# 3. fused rollout: one episode of all 4096 envs per launch, trajectory [T, B, S, ...] on the GPU
+traj = env.rollout(100)                         # random policy; pass actions=[T, B, S] to replay a policy
+print("rollout:", tuple(traj.observations.shape), "mean reward", float(traj.rewards.mean()),
+      "episode ends", int(traj.truncations[:, :, 0].sum()))
+
+# 4. tutorial 2: per-env sampled reward weights (Supertype / Sampler), drawn on the device
+weights = ph.UniformFloatSampler(0.0, 0.2)
+env = ph.SupplyChainEnv(n_shops=3, customers_per_shop=4, batch_size=1024, typed=True, exogenous="device",
+                        agent_supertypes={f"SHOP{i}": ph.TypedShopAgent.Supertype(weights) for i in range(3)})
+env.reset()
+print("typed shops: obs dim", env.spec.obs_dim, "weights of env 0..3", env["SHOP0"].type.excess_stock_weight[:4])
