@@ -312,6 +312,15 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       if (tla + 3 >= 0 && tla < tc) {
         const uint32_t tick_a = tick_base + (uint32_t)tla;           // multiple of 4
         const int K = (int)(pr >> 16);
+        // replayed actions: the quad's four loads are issued before the Philox block hides them
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        if (REPLAY && io.actions) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int tl = tla + h;
+            if (tl >= 0 && tl < tc) av[h] = io.actions[(int64_t)(t0 + tl) * total + g_base + gl];
+          }
+        }
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         if (!(REPLAY && io.exo && io.actions)) rng_block(a.seed, genv, tick_a, s, 0, 0, w);
 #pragma unroll
@@ -336,8 +345,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
             for (int g = 1; 6 * g < K; ++g)
               D += rng_digit_sum(rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, g, 0), K - 6 * g < 6 ? K - 6 * g : 6, nullptr);
           }
-          const float action = (REPLAY && io.actions) ? io.actions[(int64_t)t * total + g_base + gl]
-                                                      : rng_j_to_action(aj);
+          const float action = (REPLAY && io.actions) ? av[h] : rng_j_to_action(aj);
           s_act[i] = action;
           // the random-policy action lies in [0, 100): no saturation needed before the conversion
           s_it[i] = (REPLAY && io.actions) ? dev_round_half_even(action) : (int)rintf(action);
