@@ -47,6 +47,9 @@ extern "C" {
 #define PHX_ERR_UNKNOWN_MSG 3 /* ValueError: no handler for payload type  agents.py:140-143  */
 #define PHX_ERR_ROUND_LIMIT 4 /* RuntimeError: msgs left after round_limit resolvers.py:160  */
 #define PHX_ERR_QUEUE_FULL  5 /* build-specific: per-round message capacity exceeded         */
+/* BatchResolver(round_limit=None) loops until no message is left (resolvers.py:129-131), i.e. forever
+ * on a message cycle; this build stops after PHX_MAX_ROUNDS rounds with PHX_ERR_ROUND_LIMIT.        */
+#define PHX_MAX_ROUNDS 4096
 
 /* ---- agent kinds (closed set) -------------------------------------------------------- */
 typedef enum phx_kind {

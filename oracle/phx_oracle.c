@@ -536,6 +536,7 @@ static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
   e->round = 0;
   for (int i = 0;; ++i) {
     if (E->s.round_limit >= 0 && i >= E->s.round_limit) break;        /* range(round_limit) :129-131 */
+    if (i >= PHX_MAX_ROUNDS) break;                                   /* itertools.count(): build-specific safety cap */
     oinbox* proc = &e->box[e->cur];
     if (proc->n_recv == 0) break;                                     /* :134-135 */
     e->cur ^= 1;                                                      /* self.messages = defaultdict(list) :139-140 */

@@ -28,6 +28,7 @@ TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC = 1, 2, 4
 
 ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL = range(6)
+MAX_ROUNDS = 4096            # PHX_MAX_ROUNDS: cap on BatchResolver(round_limit=None) rounds
 
 _u8p, _i32p, _f32p, _f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),
                              C.POINTER(C.c_double))

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   // ---- BatchResolver.resolve round loop (resolvers.py:128-163) ---------------------------------
   DevMsg* qc = q0; DevMsg* qn = q1;
   int round = 0;
-  while (n > 0 && (sp.round_limit < 0 || round < sp.round_limit)) {
+  while (n > 0 && (sp.round_limit < 0 || round < sp.round_limit) && round < PHX_MAX_ROUNDS) {
     for (int a = tid; a < A; a += NT) { cnt[a] = 0; first[a] = 0x7fffffff; }
     __syncthreads();
     GTICK(5);

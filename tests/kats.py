@@ -264,7 +264,21 @@ def kat_ignore_connection_errors(make_runner):
     assert log[:, :3].tolist() == [[0, 1, _abi.MSG_REQUEST], [1, 2, _abi.MSG_PING]]
 
 
-ALL_KATS = [kat_ignore_connection_errors, kat_tracking, kat_call_response, kat_ordering, kat_round_limit,
+def kat_message_cycle(make_runner):
+    """build-specific: BatchResolver(round_limit=None) on a message cycle never returns in the
+    reference (resolvers.py:129-131, itertools.count()); this build stops after
+    PHX_MAX_ROUNDS rounds and reports ERR_ROUND_LIMIT, on the oracle and on the device alike."""
+    net = ph.Network([ph.ForwarderAgent("A", target="B"), ph.ForwarderAgent("B", target="A")],
+                     ph.BatchResolver(enable_tracking=True), enforce_msg_payload_checks=False)
+    net.add_connection("A", "B")
+    run = make_runner(_net_spec(net, batch=2))
+    run.inject([Message("A", "B", ph.Request(0.0))])
+    run.resolve()
+    assert (run.err == _abi.ERR_ROUND_LIMIT).all()
+    assert (run.msg_count == _abi.MAX_ROUNDS + 1).all()
+
+
+ALL_KATS = [kat_message_cycle, kat_ignore_connection_errors, kat_tracking, kat_call_response, kat_ordering, kat_round_limit,
             kat_invalid_response_connection, kat_unknown_message_type, kat_env_step,
             kat_fsm_odd_even_two_agents, kat_fsm_odd_even_one_agent, kat_fsm_one_state,
             kat_stackelberg, kat_payload_whitelist]
