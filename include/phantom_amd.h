@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 2
+#define PHX_ABI_VERSION 3
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -47,6 +47,7 @@ extern "C" {
 #define PHX_ERR_UNKNOWN_MSG 3 /* ValueError: no handler for payload type  agents.py:140-143  */
 #define PHX_ERR_ROUND_LIMIT 4 /* RuntimeError: msgs left after round_limit resolvers.py:160  */
 #define PHX_ERR_QUEUE_FULL  5 /* build-specific: per-round message capacity exceeded         */
+#define PHX_ERR_CONTEXT     6 /* KeyError: ctx[agent_id] of a non-neighbour  context.py:36-37  */
 /* BatchResolver(round_limit=None) loops until no message is left (resolvers.py:129-131), i.e. forever
  * on a message cycle; this build stops after PHX_MAX_ROUNDS rounds with PHX_ERR_ROUND_LIMIT.        */
 #define PHX_MAX_ROUNDS 4096
@@ -71,7 +72,17 @@ typedef enum phx_kind {
   PHX_KIND_FORWARDER  = 9,  /* tests/network/test_resolver.py:89-96  _TestAgent2 pi0=target*/
   PHX_KIND_MOCK_STRAT = 10, /* tests/__init__.py:32-65 MockStrategicAgent  pi0=num_steps   */
   PHX_KIND_MOCK_AGENT = 11, /* tests/__init__.py:25-29 MockAgent (no handlers)             */
-  PHX_KIND_COUNT      = 12
+  /* examples/environments/digital_ads_market/digital_ads_market.py (a custom
+   * handle_batch reduction -- the auction -- on a StochasticNetwork FSM env)               */
+  PHX_KIND_PUBLISHER  = 12, /* PublisherAgent  :140-196  pi0=exchange, pi1=click-draw slots per step;
+                               pf[(user-1)*4 + theme] = P(click | user, theme)   :151-154        */
+  PHX_KIND_ADVERTISER = 13, /* AdvertiserAgent :199-374  pi0=exchange, pi1=theme index (0..3),
+                               pi2=1 if Supertype.budget is a strong np.float64 (a clipped
+                               UniformFloatSampler, samplers.py:144-145) else 0 (python float);
+                               budget = the agent's type field (sampler column or pf0)          */
+  PHX_KIND_ADEXCHANGE = 14, /* AdExchangeAgent :377-516  pi0=publisher, pi1=0 first / 1 second price;
+                               advertiser_ids = its ADVERTISER base neighbours in CSR order     */
+  PHX_KIND_COUNT      = 15
 } phx_kind;
 
 /* ---- message payload types ------------------------------------------------------------ */
@@ -88,11 +99,24 @@ typedef enum phx_msg_type {
   PHX_MSG_REQUEST        = 9, /* f64 cash   any->any   test_resolver.py:14-16                    */
   PHX_MSG_RESPONSE       = 10,/* f64 cash   any->any   test_resolver.py:19-21                    */
   PHX_MSG_PING           = 11,/* (bool)     undecorated payload, test_resolver.py:94             */
-  PHX_MSG_COUNT          = 12
+  /* digital_ads_market.py payloads; `aux` = phx_msg_rec.round's sibling field in the queues  */
+  PHX_MSG_IMPRESSION_REQ = 12,/* i user_id (timestamp unused)  any->any  :28-53                   */
+  PHX_MSG_BID            = 13,/* f bid, aux = theme | user_id<<4 | tag<<8   :56-72                */
+  PHX_MSG_AUCTION_RESULT = 14,/* f cost (winning_bid unused by its handler), aux = tag<<8  :75-88 */
+  PHX_MSG_ADS            = 15,/* i advertiser index, aux = theme | user_id<<4   :91-107          */
+  PHX_MSG_IMPRESSION_RES = 16,/* i clicked   :110-121                                            */
+  PHX_MSG_COUNT          = 17
 } phx_msg_type;
 
+/* numpy scalar kind of a float that travels through the ads market (NEP 50 promotion, numpy>=2):
+ * python float (weak) < np.float32 < np.float64; a binary op yields the larger tag and is
+ * computed in f32 iff that tag is F32 (python floats are cast to f32 first).                   */
+#define PHX_TAG_PYF 0
+#define PHX_TAG_F32 1
+#define PHX_TAG_F64 2
+
 #define PHX_NPI 4   /* int32 params per agent  */
-#define PHX_NPF 2   /* double params per agent */
+#define PHX_NPF 8   /* double params per agent */
 
 /* ---- Supertypes / Samplers (supertype.py:16-30, utils/samplers.py:47-271, env.py:80-124,211-216)
  * Every distinct Sampler object of the env + agent supertypes (env._samplers order) is one
@@ -178,7 +202,7 @@ typedef struct phx_field {
 
 /* one message-log record (Resolver.tracked_messages, resolvers.py:35-60) */
 typedef struct phx_msg_rec {
-  uint16_t sender, receiver, type, round;
+  uint16_t sender, receiver, type, round;   /* phx_inject input: `round` = aux bits of the payload */
   union { int64_t i; double f; } payload;
 } phx_msg_rec;
 

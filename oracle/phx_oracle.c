@@ -35,11 +35,12 @@ int phxo_max_threads(void) {
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
   int src, dst, type;
+  int aux;                /* small extra payload fields (theme | user_id << 4 | tag << 8) */
   union { int64_t i; double f; } p;
 } omsg;
 
 typedef struct {          /* python attributes of one agent object */
-  int32_t i[4];
+  int32_t i[16];
   double f[2];
   double* vec;            /* BuyerAgent.prices[deg] */
 } ostate;
@@ -64,6 +65,8 @@ typedef struct {
   uint8_t* conn_on;       /* [n_conn] StochasticNetwork: base connection is in self.graph  network.py:438-447 */
   int32_t episode;        /* number of env.reset() calls so far (device-RNG counter of the samplers) */
   int32_t clock;          /* handle_message invocation counter (stands in for time.time()) */
+  const uint8_t* exo_b;   /* this step's exogenous draws (NULL -> device RNG) */
+  int64_t genv;           /* global env index (device-RNG counter) */
   uint8_t* term;          /* [S] PhantomEnv._terminations env.py:71 */
   uint8_t* trunc;         /* [S] PhantomEnv._truncations  env.py:72 */
   double* rew_cache;      /* [S] FSM/Stackelberg _rewards */
@@ -93,7 +96,7 @@ struct phxo_env {
 
 static int is_strategic_kind(int k) {
   return k == PHX_KIND_SHOP || k == PHX_KIND_SELLER || k == PHX_KIND_BUYER ||
-         k == PHX_KIND_MOCK_STRAT;
+         k == PHX_KIND_MOCK_STRAT || k == PHX_KIND_ADVERTISER;
 }
 static int obs_dim_of_kind(int k) {
   switch (k) {
@@ -101,6 +104,7 @@ static int obs_dim_of_kind(int k) {
     case PHX_KIND_SELLER: return 2;
     case PHX_KIND_BUYER: return 2;
     case PHX_KIND_MOCK_STRAT: return 1;
+    case PHX_KIND_ADVERTISER: return 3;
     default: return 0;
   }
 }
@@ -288,6 +292,53 @@ static void env_sample(const phxo_env* E, oenv* e, int b, const double* values, 
   e->episode += 1;
 }
 
+/* ---- numpy scalar promotion of the ads market's floats (NEP 50, numpy >= 2) ----------------
+ * digital_ads_market.py mixes np.float32 (action[0]), python floats (a constant or unclipped
+ * Supertype.budget, the literal 0.0 cost) and np.float64 (a clipped sampler's budget).  A binary
+ * op yields the larger of the two tags PYF < F32 < F64 and is evaluated in float32 iff that tag
+ * is F32 -- the weak python float is cast to float32 first.                                   */
+typedef struct { double v; int tag; } tval;
+static tval tv(double v, int tag) { tval t; t.v = v; t.tag = tag; return t; }
+static int t_tag(tval a, tval b) { return a.tag > b.tag ? a.tag : b.tag; }
+static tval t_mul(tval a, tval b) {
+  int tag = t_tag(a, b);
+  if (tag == PHX_TAG_F32) { volatile float r = (float)a.v * (float)b.v; return tv((double)r, tag); }
+  return tv(a.v * b.v, tag);
+}
+static tval t_sub(tval a, tval b) {
+  int tag = t_tag(a, b);
+  if (tag == PHX_TAG_F32) { volatile float r = (float)a.v - (float)b.v; return tv((double)r, tag); }
+  return tv(a.v - b.v, tag);
+}
+static tval t_div(tval a, tval b) {
+  int tag = t_tag(a, b);
+  if (tag == PHX_TAG_F32) { volatile float r = (float)a.v / (float)b.v; return tv((double)r, tag); }
+  return tv(a.v / b.v, tag);
+}
+static int t_lt(tval a, tval b) {
+  if (t_tag(a, b) == PHX_TAG_F32) return (float)a.v < (float)b.v;
+  return a.v < b.v;
+}
+/* AdvertiserAgent attribute slots in ostate */
+enum { ADV_LEFT_TAG = 0, ADV_BID_TAG = 1, ADV_CLICKS = 2, ADV_WINS = 3, ADV_USER = 4,
+       ADV_TOT_CLICKS = 5, ADV_TOT_REQUESTS = 8, ADV_TOT_WINS = 11 };   /* totals: [user 0,1,2] */
+static tval adv_budget(const phxo_env* E, const oenv* e, int a) {       /* self.type.budget */
+  return tv(agent_type_value(E, e, a), E->s.param_i[a * PHX_NPI + 2] ? PHX_TAG_F64 : PHX_TAG_PYF);
+}
+
+/* Device draws of the PublisherAgent when exo == NULL (build-owned; replace np.random.choice([1, 2])
+ * digital_ads_market.py:52 and np.random.binomial(1, p) :193-195): Philox block
+ *     ctr = (env_lo, env_hi, tick, 0x20000000 | k << 16 | agent), key = seed,
+ * k = 0: user_id = 1 + (w0 & 1);  k >= 1 (k-th Ads of the step): clicked = (w0 >> 8) * 2^-24 < p. */
+int phxo_rng_publisher(uint64_t seed, int64_t genv, uint32_t tick, int agent, int k, double p) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick,
+                     0x20000000u | ((uint32_t)k << 16) | (uint32_t)agent};
+  uint32_t w[4]; phxo_philox4x32_10(ctr, key, w);
+  if (k == 0) return 1 + (int)(w[0] & 1u);
+  return (double)(w[0] >> 8) * (1.0 / 16777216.0) < p;
+}
+
 /* ---- per-kind agent behaviour --------------------------------------------------------- */
 
 /* Agent.reset / subclasses: agents.py:160-175 */
@@ -301,6 +352,13 @@ static void agent_reset(const phxo_env* E, oenv* e, int a) {
       int deg = E->s.row_ptr[a + 1] - E->s.row_ptr[a];
       for (int k = 0; k < deg; ++k) st->vec[k] = 1.0;
       st->f[0] = 0.0; st->i[0] = 0; break;
+    }
+    case PHX_KIND_ADVERTISER: {                               /* digital_ads_market.py:353-374 */
+      tval budget = adv_budget(E, e, a);
+      st->f[0] = budget.v; st->i[ADV_LEFT_TAG] = budget.tag;  /* self.left = self.type.budget */
+      st->f[1] = 0.0; st->i[ADV_BID_TAG] = PHX_TAG_PYF;       /* self.bid = 0.0 */
+      for (int k = ADV_CLICKS; k < 14; ++k) st->i[k] = 0;     /* step_*, _current_user_id, total_* */
+      break;
     }
     default: break;
   }
@@ -363,6 +421,25 @@ static void agent_act(const phxo_env* E, oenv* e, int b, int a, int has_action, 
     case PHX_KIND_MOCK_STRAT:
       if (has_action) st->i[1] += 1;                          /* decode_action_count tests/__init__.py:53-55 */
       break;
+    case PHX_KIND_PUBLISHER: {                                /* digital_ads_market.py:164-165, :48-53 */
+      int user = exo_b ? exo_b[E->exo_rank[a]]
+                       : phxo_rng_publisher(E->s.seed, E->s.env_offset + b, e->tick, a, 0, 0.0);
+      network_send(E, e, a, pi[0], PHX_MSG_IMPRESSION_REQ, mk_i(user));
+      break;
+    }
+    case PHX_KIND_ADVERTISER:
+      if (has_action) {                                       /* digital_ads_market.py:318-333 */
+        tval left = tv(st->f[0], st->i[ADV_LEFT_TAG]);
+        tval bid = t_mul(tv((double)action, PHX_TAG_F32), adv_budget(E, e, a));
+        if (t_lt(left, bid)) bid = left;                      /* min(action[0] * budget, self.left) */
+        st->f[1] = bid.v; st->i[ADV_BID_TAG] = bid.tag;
+        if (bid.v > 0.0) {
+          omsg m = mk_f(bid.v);
+          m.aux = pi[1] | (st->i[ADV_USER] << 4) | (bid.tag << 8);
+          network_send(E, e, a, pi[0], PHX_MSG_BID, m);
+        }
+      }
+      break;
     default: break;                                           /* generate_messages -> [] */
   }
 }
@@ -374,6 +451,8 @@ static void agent_pre_resolution(const phxo_env* E, oenv* e, int a) {
     case PHX_KIND_SELLER:
       if (e->step % 2 == 0) { st->f[1] = 0.0; st->i[0] = 0; } /* revenue, tx of the buying round */
       break;
+    case PHX_KIND_ADVERTISER: st->i[ADV_CLICKS] = 0; st->i[ADV_WINS] = 0; break;   /* digital_ads_market.py:241-247 */
+    case PHX_KIND_PUBLISHER: st->i[0] = 0; break;             /* build bookkeeping: Ads handled this step */
     default: break;
   }
 }
@@ -456,6 +535,50 @@ static void agent_handle_message(const phxo_env* E, oenv* e, int a, const omsg* 
       }
       if (m->type == PHX_MSG_RESPONSE) { st->i[1] = clock; return; }   /* :39-45 */
       break;
+    case PHX_KIND_PUBLISHER:
+      if (m->type == PHX_MSG_ADS) {                           /* digital_ads_market.py:167-196 */
+        const int theme = m->aux & 15, user = (m->aux >> 4) & 15;
+        if (user < 1 || user > 2 || theme > 3) { set_err(e, PHX_ERR_CONTEXT); return; }   /* dict KeyError :194 */
+        const double p = E->s.param_f[a * PHX_NPF + (user - 1) * 4 + theme];
+        const int k = ++st->i[0];                             /* k-th click draw of this step */
+        int clicked;
+        if (e->exo_b) {
+          if (k > pi[1]) { set_err(e, PHX_ERR_QUEUE_FULL); return; }
+          clicked = e->exo_b[E->exo_rank[a] + k];
+        } else clicked = phxo_rng_publisher(E->s.seed, e->genv, e->tick, a, k, p);
+        network_send(E, e, a, (int)m->p.i, PHX_MSG_IMPRESSION_RES, mk_i(clicked));
+        return;
+      }
+      break;
+    case PHX_KIND_ADVERTISER:
+      if (m->type == PHX_MSG_IMPRESSION_REQ) {                /* digital_ads_market.py:249-271 */
+        st->i[ADV_USER] = (int)m->p.i;
+        if (!has_edge(E, e, a, pi[0])) { set_err(e, PHX_ERR_CONTEXT); return; }   /* ctx[self.exchange_id] :261 */
+        if (m->p.i >= 0 && m->p.i <= 2) st->i[ADV_TOT_REQUESTS + m->p.i] += 1;
+        return;
+      }
+      if (m->type == PHX_MSG_AUCTION_RESULT) {                /* :273-282 */
+        const int won = m->p.f != 0.0;
+        st->i[ADV_WINS] += won;
+        st->i[ADV_TOT_WINS + st->i[ADV_USER]] += won;
+        tval left = t_sub(tv(st->f[0], st->i[ADV_LEFT_TAG]), tv(m->p.f, (m->aux >> 8) & 3));
+        st->f[0] = left.v; st->i[ADV_LEFT_TAG] = left.tag;
+        return;
+      }
+      if (m->type == PHX_MSG_IMPRESSION_RES) {                /* :284-292 */
+        st->i[ADV_CLICKS] += (int)m->p.i;
+        st->i[ADV_TOT_CLICKS + st->i[ADV_USER]] += (int)m->p.i;
+        return;
+      }
+      break;
+    case PHX_KIND_ADEXCHANGE:
+      if (m->type == PHX_MSG_IMPRESSION_REQ) {                /* :415-427: forward to self.advertiser_ids */
+        for (int k = E->s.row_ptr[a]; k < E->s.row_ptr[a + 1]; ++k)
+          if (E->s.kind[E->s.col[k]] == PHX_KIND_ADVERTISER)
+            network_send(E, e, a, E->s.col[k], PHX_MSG_IMPRESSION_REQ, mk_i(m->p.i));
+        return;
+      }
+      break;
     case PHX_KIND_FORWARDER:                                  /* overrides handle_message test_resolver.py:93-96 */
       if (pi[0] >= 0) network_send(E, e, a, pi[0], PHX_MSG_PING, mk_i(1));
       return;
@@ -464,7 +587,8 @@ static void agent_handle_message(const phxo_env* E, oenv* e, int a, const omsg* 
   set_err(e, PHX_ERR_UNKNOWN_MSG);                            /* raise ValueError agents.py:140-143 */
 }
 
-static void agent_encode_obs(const phxo_env* E, const oenv* e, int a, float* o) {
+/* returns 0 where encode_observation returns None (the caller then omits the agent, env.py:279-280) */
+static int agent_encode_obs(const phxo_env* E, const oenv* e, int a, float* o) {
   const ostate* st = &e->ag[a];
   const int32_t* pi = &E->s.param_i[a * PHX_NPI];
   switch (E->s.kind[a]) {
@@ -497,8 +621,17 @@ static void agent_encode_obs(const phxo_env* E, const oenv* e, int a, float* o) 
       ((ostate*)st)->i[0] += 1;                               /* encode_obs_count */
       o[0] = (float)((double)e->step / (double)E->s.num_steps);   /* views.py:33-34, env.py:168 */
       break;
+    case PHX_KIND_ADVERTISER: {                               /* digital_ads_market.py:294-316 */
+      if (st->i[ADV_USER] == 0) return 0;                     /* `if self._current_user_id != 0` else None */
+      tval budget = adv_budget(E, e, a);
+      o[0] = (float)budget.v;                                 /* "type": np.array([budget], float32) supertype.py:68-69 */
+      o[1] = (float)t_div(tv(st->f[0], st->i[ADV_LEFT_TAG]), budget).v;   /* "budget_left" (an f64 array there) */
+      o[2] = (float)(st->i[ADV_USER] - 1);                    /* "user_id" */
+      break;
+    }
     default: break;
   }
+  return 1;
 }
 
 static double agent_compute_reward(const phxo_env* E, oenv* e, int a) {
@@ -515,18 +648,57 @@ static double agent_compute_reward(const phxo_env* E, oenv* e, int a) {
       if (st->i[0]) return E->s.param_f[a * PHX_NPF + 0] - st->f[0];
       return 0.0;
     case PHX_KIND_MOCK_STRAT: st->i[2] += 1; return 0.0;      /* tests/__init__.py:57-59 */
+    case PHX_KIND_ADVERTISER:                                 /* digital_ads_market.py:335-343, risk_aversion = 0:
+                                                                 1.0 * step_clicks + (0.0 * left) / budget       */
+      return (double)st->i[ADV_CLICKS];
     default: return 0.0;
   }
 }
 static int agent_is_terminated(const phxo_env* E, const oenv* e, int a) {
   if (E->s.kind[a] == PHX_KIND_MOCK_STRAT)                    /* tests/__init__.py:61-62 */
     return e->step == E->s.param_i[a * PHX_NPI + 0];
+  if (E->s.kind[a] == PHX_KIND_ADVERTISER)                    /* digital_ads_market.py:345-349 */
+    return e->ag[a].f[0] <= 0.0;
   return 0;                                                   /* agents.py:292-307 */
 }
 static int agent_is_truncated(const phxo_env* E, const oenv* e, int a) {
   if (E->s.kind[a] == PHX_KIND_MOCK_STRAT)                    /* tests/__init__.py:64-65 */
     return e->step == E->s.param_i[a * PHX_NPI + 0];
   return 0;                                                   /* agents.py:309-323 */
+}
+
+/* AdExchangeAgent.handle_batch + auction  digital_ads_market.py:429-516: every Bid of the batch is
+ * held back, the other messages are handled one by one, then ONE auction runs over the bids:
+ * sorted(bids, key=bid, reverse=True) is stable, so the winner is the first maximal bid in arrival
+ * order and sorted_bids[1] the first maximal one among the rest.                                  */
+static void adexchange_handle_batch(const phxo_env* E, oenv* e, int a, const oinbox* proc, const uint8_t* ok,
+                                    int clock0) {
+  int nb = 0, w = -1, w2 = -1, k = 0;
+  for (int id = proc->head[a]; id >= 0; id = proc->next[id], ++k) {
+    if (!ok[id]) continue;
+    const omsg* m = &proc->pool[id];
+    if (m->type == PHX_MSG_BID) { nb++; continue; }
+    agent_handle_message(E, e, a, m, clock0 + k);
+  }
+  if (!nb) return;
+#define BIDV(id) tv(proc->pool[id].p.f, (proc->pool[id].aux >> 8) & 3)
+  for (int id = proc->head[a]; id >= 0; id = proc->next[id])
+    if (ok[id] && proc->pool[id].type == PHX_MSG_BID && (w < 0 || t_lt(BIDV(w), BIDV(id)))) w = id;
+  for (int id = proc->head[a]; id >= 0; id = proc->next[id])
+    if (ok[id] && proc->pool[id].type == PHX_MSG_BID && id != w && (w2 < 0 || t_lt(BIDV(w2), BIDV(id)))) w2 = id;
+  const int second = E->s.param_i[a * PHX_NPI + 1];
+  const omsg* win = &proc->pool[w];
+  const omsg* costm = (second && w2 >= 0) ? &proc->pool[w2] : win;    /* :498-516 */
+  omsg ads = mk_i(win->src); ads.aux = win->aux & 0xff;               /* Ads(advertiser_id, theme, user_id) :472-482 */
+  network_send(E, e, a, E->s.param_i[a * PHX_NPI + 0], PHX_MSG_ADS, ads);
+  for (int id = proc->head[a]; id >= 0; id = proc->next[id]) {        /* :484-492 */
+    if (!ok[id] || proc->pool[id].type != PHX_MSG_BID) continue;
+    omsg r;
+    if (proc->pool[id].src == win->src) { r = mk_f(costm->p.f); r.aux = costm->aux & 0x300; }
+    else { r = mk_f(0.0); r.aux = PHX_TAG_PYF << 8; }
+    network_send(E, e, a, proc->pool[id].src, PHX_MSG_AUCTION_RESULT, r);
+  }
+#undef BIDV
 }
 
 /* ---- resolver ---------------------------------------------------------------------------- */
@@ -544,6 +716,16 @@ static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
     e->round = i + 1;
     for (int r = 0; r < proc->n_recv; ++r) {                          /* dict order :142 */
       int receiver = proc->order[r];
+      if (E->s.kind[receiver] == PHX_KIND_ADEXCHANGE) {               /* overrides handle_batch */
+        uint8_t* ok = (uint8_t*)alloca(proc->n > 0 ? proc->n : 1);
+        const int clock0 = e->clock;
+        for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) {
+          e->clock++;
+          ok[id] = live[receiver] && has_edge(E, e, proc->pool[id].src, proc->pool[id].dst);
+        }
+        if (live[receiver]) adexchange_handle_batch(E, e, receiver, proc, ok, clock0);
+        continue;
+      }
       for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) {
         /* logical time = position of the message in the processing order, counting every
          * queued message whether it is handled or dropped (stands in for time.time()) */
@@ -586,23 +768,23 @@ static void env_reset_one(const phxo_env* E, oenv* e, int b, const double* sampl
   if (!obs) return;
   if (E->s.env_type == PHX_ENV_PLAIN) {                               /* env.py:227-237 */
     for (int s = 0; s < E->S; ++s) {
-      agent_encode_obs(E, e, E->strat_idx[s], obs + s * E->D);
-      if (obs_valid) obs_valid[s] = 1;
+      int v = agent_encode_obs(E, e, E->strat_idx[s], obs + s * E->D);
+      if (obs_valid) obs_valid[s] = (uint8_t)v;                       /* `if v is not None` env.py:237 */
     }
   } else if (E->s.env_type == PHX_ENV_FSM) {                          /* fsm.py:237-251 */
     int st = e->stage;
     for (int k = E->s.stage_act_ptr[st]; k < E->s.stage_act_ptr[st + 1]; ++k) {
       int a = E->s.stage_act_idx[k], s = E->strat_rank[a];
       if (s < 0) continue;
-      agent_encode_obs(E, e, a, obs + s * E->D);
-      if (obs_valid) obs_valid[s] = 1;
+      int v = agent_encode_obs(E, e, a, obs + s * E->D);
+      if (obs_valid) obs_valid[s] = (uint8_t)v;
     }
   } else {                                                            /* stackelberg.py:95-109 */
     for (int k = 0; k < E->s.n_leaders; ++k) {
       int a = E->s.leaders[k], s = E->strat_rank[a];
       if (s < 0) continue;
-      agent_encode_obs(E, e, a, obs + s * E->D);
-      if (obs_valid) obs_valid[s] = 1;
+      int v = agent_encode_obs(E, e, a, obs + s * E->D);
+      if (obs_valid) obs_valid[s] = (uint8_t)v;
     }
   }
 }
@@ -620,6 +802,7 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
                          uint8_t* all_term, uint8_t* all_trunc) {
   const int A = E->A, S = E->S, D = E->D;
   e->step += 1;                                                       /* env.py:252 */
+  e->exo_b = exo_b;
 
   /* _make_ctxs env.py:338-348: contexts exist for agents that are not done */
   uint8_t* live = (uint8_t*)alloca(A);
@@ -685,13 +868,13 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
       do_obs = in_list(next_act_list, n_next_act, a);                 /* stackelberg.py:156 */
       do_rew = in_list(act_list, n_act, a);                           /* :162 */
     }
-    if (do_obs) {
-      agent_encode_obs(E, e, a, obs + s * D);                         /* obs is never None for these kinds */
-      observed[s] = 1;
-    }
+    if (do_obs)                                                       /* `if obs is not None` env.py:279-280 */
+      observed[s] = (uint8_t)agent_encode_obs(E, e, a, obs + s * D);
     if (E->s.env_type == PHX_ENV_PLAIN) {
-      reward[s] = agent_compute_reward(E, e, a);                      /* env.py:283 */
-      reward_valid[s] = 1;
+      if (observed[s]) {
+        reward[s] = agent_compute_reward(E, e, a);                    /* env.py:283 */
+        reward_valid[s] = 1;
+      }
     } else if (do_rew) {
       e->rew_cache[s] = agent_compute_reward(E, e, a);                /* fsm.py:335,350 / stackelberg.py:163 */
       e->rew_cache_valid[s] = 1;
@@ -811,7 +994,10 @@ phxo_env* phxo_create(const phx_spec* sp) {
       if (obs_dim_of_kind(k) > D) D = obs_dim_of_kind(k);
       if (k == PHX_KIND_SHOP && sp->type_src && sp->type_src[a] != PHX_TYPE_NONE && D < 4) D = 4;
     } else E->strat_rank[a] = -1;
-    E->exo_rank[a] = (k == PHX_KIND_CUSTOMER) ? nx++ : -1;
+    /* exogenous draws per step: a customer's order; a publisher's user id + pi1 click draws */
+    if (k == PHX_KIND_CUSTOMER) E->exo_rank[a] = nx++;
+    else if (k == PHX_KIND_PUBLISHER) { E->exo_rank[a] = nx; nx += 1 + sp->param_i[a * PHX_NPI + 1]; }
+    else E->exo_rank[a] = -1;
   }
   E->S = S; E->D = D > 0 ? D : 1; E->n_exo = nx;
   E->env = (oenv*)calloc(E->B, sizeof(oenv));
@@ -827,7 +1013,7 @@ phxo_env* phxo_create(const phx_spec* sp) {
     e->obs_cache_valid = (uint8_t*)calloc(S ? S : 1, 1);
     if (!inbox_alloc(E, &e->box[0]) || !inbox_alloc(E, &e->box[1])) return NULL;
     inbox_clear(E, &e->box[0]); inbox_clear(E, &e->box[1]);
-    e->stage = sp->initial_stage; e->prev_stage = -1;
+    e->stage = sp->initial_stage; e->prev_stage = -1; e->genv = sp->env_offset + b;
     e->sampler = (double*)calloc(sp->n_samplers > 0 ? sp->n_samplers : 1, sizeof(double));
     e->conn_on = (uint8_t*)calloc(sp->n_conn > 0 ? sp->n_conn : 1, 1);
     env_sample(E, e, b, NULL, NULL);                                  /* env.py:118-119; add_connection network.py:389-391 */
@@ -889,6 +1075,7 @@ void phxo_inject(phxo_env* E, const phx_msg_rec* msgs, int n) {
   for (int k = 0; k < n; ++k) {
     omsg m; memset(&m, 0, sizeof m);
     m.src = msgs[k].sender; m.dst = msgs[k].receiver; m.type = msgs[k].type; m.p.i = msgs[k].payload.i;
+    m.aux = msgs[k].round;                                            /* on input `round` carries the aux bits */
     E->injected[E->n_injected++] = m;
   }
 }
@@ -924,7 +1111,7 @@ void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
     oenv* e = &E->env[b];
     e->log = msg_log ? msg_log + (size_t)b * E->s.trace_cap : NULL;
     e->log_cap = E->s.trace_cap; e->log_n = 0; e->round = 0;
-    e->err = err ? err[b] : 0;
+    e->err = err ? err[b] : 0; e->exo_b = NULL;
     apply_injected(E, e);
     batch_resolve(E, e, live);
     if (err) err[b] = e->err;
@@ -941,7 +1128,7 @@ void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
 static float policy_action(const phxo_env* E, const oenv* e, int b, int s) {
   const int kind = E->s.kind[E->strat_idx[s]];
   const uint32_t j = phxo_rng_rank(E->s.seed, E->s.env_offset + b, e->tick, s);
-  if (kind == PHX_KIND_SELLER) return (float)j * (1.0f / 274877.0f);
+  if (kind == PHX_KIND_SELLER || kind == PHX_KIND_ADVERTISER) return (float)j * (1.0f / 274877.0f);
   if (kind == PHX_KIND_BUYER) return j < 137438u ? 1.0f : 0.0f;
   return (float)j * (100.0f / 274877.0f);
 }
@@ -1003,6 +1190,10 @@ static const ofield FIELDS[] = {
   {"seller.revenue", PHX_KIND_SELLER, 1, 1},
   {"buyer.bought", PHX_KIND_BUYER, 0, 0}, {"buyer.paid", PHX_KIND_BUYER, 1, 0},
   {"cashbox.total_cash", PHX_KIND_CASHBOX, 1, 0},
+  {"adv.left", PHX_KIND_ADVERTISER, 1, 0}, {"adv.bid", PHX_KIND_ADVERTISER, 1, 1},
+  {"adv.left_tag", PHX_KIND_ADVERTISER, 0, ADV_LEFT_TAG}, {"adv.bid_tag", PHX_KIND_ADVERTISER, 0, ADV_BID_TAG},
+  {"adv.step_clicks", PHX_KIND_ADVERTISER, 0, ADV_CLICKS}, {"adv.step_wins", PHX_KIND_ADVERTISER, 0, ADV_WINS},
+  {"adv.user", PHX_KIND_ADVERTISER, 0, ADV_USER},
   {"reqresp.req_time", PHX_KIND_REQRESP, 0, 0}, {"reqresp.res_time", PHX_KIND_REQRESP, 0, 1},
   {"mock.encode_obs_count", PHX_KIND_MOCK_STRAT, 0, 0},
   {"mock.decode_action_count", PHX_KIND_MOCK_STRAT, 0, 1},
@@ -1020,6 +1211,16 @@ int64_t phxo_get_i32(const phxo_env* E, const char* field, int32_t* out) {
   if (!strcmp(field, "env.prev_stage")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].prev_stage; return E->B; }
   if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) out[b] = (int32_t)E->env[b].tick; return E->B; }
   if (!strcmp(field, "env.episode")) { for (int b = 0; b < E->B; ++b) out[b] = E->env[b].episode; return E->B; }
+  int tot = !strcmp(field, "adv.total_clicks") ? ADV_TOT_CLICKS : !strcmp(field, "adv.total_requests") ? ADV_TOT_REQUESTS
+          : !strcmp(field, "adv.total_wins") ? ADV_TOT_WINS : -1;
+  if (tot >= 0) {                                                     /* defaultdict(int) keyed by user id: [B][n][3] */
+    int n = E->kind_count[PHX_KIND_ADVERTISER];
+    for (int b = 0; b < E->B; ++b)
+      for (int a = 0; a < E->A; ++a)
+        if (E->s.kind[a] == PHX_KIND_ADVERTISER)
+          for (int u = 0; u < 3; ++u) out[((size_t)b * n + E->kind_rank[a]) * 3 + u] = E->env[b].ag[a].i[tot + u];
+    return (int64_t)E->B * n * 3;
+  }
   const ofield* f = find_field(field);
   if (!f || f->is_f) return -1;
   int n = E->kind_count[f->kind];

@@ -53,6 +53,7 @@ void phxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 void phxo_rng_orders(uint64_t seed, int64_t genv, uint32_t tick, int shop, int K, uint8_t* out);
 float phxo_rng_action(uint64_t seed, int64_t genv, uint32_t tick, int strat_rank);
 uint32_t phxo_rng_rank(uint64_t seed, int64_t genv, uint32_t tick, int agent);
+int phxo_rng_publisher(uint64_t seed, int64_t genv, uint32_t tick, int agent, int k, double p);
 double phxo_rng_uniform(uint64_t seed, int64_t genv, uint32_t episode, int column, const double prm[4]);
 int phxo_rng_connection(uint64_t seed, int64_t genv, uint32_t episode, int conn, double rate);
 int64_t phxo_get_u8(const phxo_env* e, const char* field, uint8_t* out);

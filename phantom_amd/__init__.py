@@ -21,6 +21,8 @@ from .spec import EnvSpec, compile_spec
 from .stackelberg import StackelbergEnv
 from .supply_chain import SupplyChainEnv, SupplyChainFSMEnv
 from .supertype import Supertype
+from .ads_market import AdExchangeAgent, AdvertiserAgent, DigitalAdsEnv, PublisherAgent
+from .message import Ads, AuctionResult, Bid, ImpressionRequest, ImpressionResult
 from . import samplers
 from .samplers import (LambdaSampler, NormalArraySampler, NormalSampler, Sampler,
                        UniformArraySampler, UniformFloatSampler, UniformIntSampler)

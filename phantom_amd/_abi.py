@@ -5,29 +5,34 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 2
-NPI, NPF = 4, 2
+ABI_VERSION = 3
+NPI, NPF = 4, 8
 
 # phx_kind
 KIND_FACTORY, KIND_SHOP, KIND_CUSTOMER, KIND_SELLER, KIND_BUYER = 1, 2, 3, 4, 5
 KIND_HALVER, KIND_CASHBOX, KIND_REQRESP, KIND_FORWARDER = 6, 7, 8, 9
 KIND_MOCK_STRAT, KIND_MOCK_AGENT = 10, 11
+KIND_PUBLISHER, KIND_ADVERTISER, KIND_ADEXCHANGE = 12, 13, 14
 KIND_NAMES = {1: "factory", 2: "shop", 3: "customer", 4: "seller", 5: "buyer", 6: "halver",
-              7: "cashbox", 8: "reqresp", 9: "forwarder", 10: "mock", 11: "mock_agent"}
-STRATEGIC_KINDS = (KIND_SHOP, KIND_SELLER, KIND_BUYER, KIND_MOCK_STRAT)
-OBS_DIM = {KIND_SHOP: 3, KIND_SELLER: 2, KIND_BUYER: 2, KIND_MOCK_STRAT: 1}
+              7: "cashbox", 8: "reqresp", 9: "forwarder", 10: "mock", 11: "mock_agent",
+              12: "pub", 13: "adv", 14: "adx"}
+STRATEGIC_KINDS = (KIND_SHOP, KIND_SELLER, KIND_BUYER, KIND_MOCK_STRAT, KIND_ADVERTISER)
+OBS_DIM = {KIND_SHOP: 3, KIND_SELLER: 2, KIND_BUYER: 2, KIND_MOCK_STRAT: 1, KIND_ADVERTISER: 3}
 
 # phx_msg_type
 (MSG_STOCK_REQUEST, MSG_STOCK_RESPONSE, MSG_ORDER_REQUEST, MSG_ORDER_RESPONSE, MSG_PRICE,
  MSG_ORDER, MSG_HALVE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE, MSG_PING) = range(1, 12)
-FLOAT_PAYLOAD_TYPES = (MSG_PRICE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE)
+(MSG_IMPRESSION_REQ, MSG_BID, MSG_AUCTION_RESULT, MSG_ADS, MSG_IMPRESSION_RES) = range(12, 17)
+FLOAT_PAYLOAD_TYPES = (MSG_PRICE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE, MSG_BID, MSG_AUCTION_RESULT)
+TAG_PYF, TAG_F32, TAG_F64 = 0, 1, 2      # PHX_TAG_*: numpy scalar kind of an ads-market float
 
 ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC = 1, 2, 4
 
-ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL = range(6)
+(ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL,
+ ERR_CONTEXT) = range(7)
 MAX_ROUNDS = 4096            # PHX_MAX_ROUNDS: cap on BatchResolver(round_limit=None) rounds
 
 _u8p, _i32p, _f32p, _f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),

@@ -38,11 +38,12 @@ static int fail(int code, const char* fmt, ...) {
 static const int GENERIC_LDS_LIMIT = 60 * 1024;
 
 static bool kind_is_strategic(int k) {
-  return k == PHX_KIND_SHOP || k == PHX_KIND_SELLER || k == PHX_KIND_BUYER || k == PHX_KIND_MOCK_STRAT;
+  return k == PHX_KIND_SHOP || k == PHX_KIND_SELLER || k == PHX_KIND_BUYER || k == PHX_KIND_MOCK_STRAT ||
+         k == PHX_KIND_ADVERTISER;
 }
 static int kind_obs_dim(int k) {
   switch (k) { case PHX_KIND_SHOP: return 3; case PHX_KIND_SELLER: case PHX_KIND_BUYER: return 2;
-               case PHX_KIND_MOCK_STRAT: return 1; default: return 0; }
+               case PHX_KIND_MOCK_STRAT: return 1; case PHX_KIND_ADVERTISER: return 3; default: return 0; }
 }
 
 // ---- derived quantities of a spec (host) ---------------------------------------------------------
@@ -104,9 +105,10 @@ static int derive(const phx_spec* sp, Derived& d) {
     const int src = sp->type_src[a];
     if (src == PHX_TYPE_NONE) continue;
     if (src < PHX_TYPE_NONE || src >= sp->n_samplers) return fail(PHX_EINVAL, "agent %d: type_src out of range", a);
-    if (sp->kind[a] != PHX_KIND_SHOP) return fail(PHX_EUNSUPPORTED, "agent %d: only ShopAgent consumes a type field on the device", a);
-    if (!(sp->param_f[a * PHX_NPF + 1] != 0.0)) return fail(PHX_EINVAL, "agent %d: type normaliser (pf1) is zero", a);
-    d.type_src[a] = src; d.any_typed = true;
+    if (sp->kind[a] != PHX_KIND_SHOP && sp->kind[a] != PHX_KIND_ADVERTISER)
+      return fail(PHX_EUNSUPPORTED, "agent %d: only ShopAgent / AdvertiserAgent consume a type field on the device", a);
+    if (sp->kind[a] == PHX_KIND_SHOP && !(sp->param_f[a * PHX_NPF + 1] != 0.0)) return fail(PHX_EINVAL, "agent %d: type normaliser (pf1) is zero", a);
+    d.type_src[a] = src; d.any_typed = d.any_typed || sp->kind[a] == PHX_KIND_SHOP;
   }
   d.A = A; d.nnz = sp->row_ptr[A];
   if (sp->row_ptr[0] != 0) return fail(PHX_EINVAL, "row_ptr[0] != 0");
@@ -120,12 +122,20 @@ static int derive(const phx_spec* sp, Derived& d) {
     if (kind_is_strategic(k)) { d.strat_rank[a] = d.S++; d.strat_idx.push_back(a);
       d.D = std::max(d.D, kind_obs_dim(k) + (k == PHX_KIND_SHOP && d.type_src[a] != PHX_TYPE_NONE ? 1 : 0)); }
     if (k == PHX_KIND_CUSTOMER) d.exo_rank[a] = d.n_exo++;
+    if (k == PHX_KIND_PUBLISHER) {                              // user id + pi1 click draws per step
+      if (sp->param_i[a * PHX_NPI + 1] < 0 || sp->param_i[a * PHX_NPI + 1] > 4095) return fail(PHX_EINVAL, "agent %d: click draws per step out of range", a);
+      d.exo_rank[a] = d.n_exo; d.n_exo += 1 + sp->param_i[a * PHX_NPI + 1];
+    }
     if (k == PHX_KIND_BUYER) { d.buyer_off[a] = d.kind_rank[a]; d.buyer_dmax = std::max(d.buyer_dmax, sp->row_ptr[a + 1] - sp->row_ptr[a]); }
     const int32_t* pi = sp->param_i + a * PHX_NPI;
     if ((k == PHX_KIND_SHOP || k == PHX_KIND_CUSTOMER) && (pi[0] < 0 || pi[0] >= A))
       return fail(PHX_EINVAL, "agent %d: target agent index out of range", a);
     if (k == PHX_KIND_SHOP && pi[1] <= 0) return fail(PHX_EINVAL, "agent %d: ShopAgent max_sales_per_step must be > 0", a);
     if (k == PHX_KIND_FORWARDER && pi[0] >= A) return fail(PHX_EINVAL, "agent %d: forward target out of range", a);
+    if ((k == PHX_KIND_PUBLISHER || k == PHX_KIND_ADVERTISER || k == PHX_KIND_ADEXCHANGE) && (pi[0] < 0 || pi[0] >= A))
+      return fail(PHX_EINVAL, "agent %d: exchange / publisher index out of range", a);
+    if (k == PHX_KIND_ADVERTISER && (pi[1] < 0 || pi[1] > 3)) return fail(PHX_EINVAL, "agent %d: theme index must be 0..3", a);
+    if (k == PHX_KIND_ADVERTISER && d.type_src[a] == PHX_TYPE_NONE) return fail(PHX_EINVAL, "agent %d: AdvertiserAgent needs a budget (type_src)", a);
     if (k == PHX_KIND_CUSTOMER && sp->kind[pi[0]] != PHX_KIND_SHOP)
       return fail(PHX_EINVAL, "agent %d: CustomerAgent.shop_id is not a ShopAgent", a);
   }
@@ -313,6 +323,17 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_MOCK_ENC, "mock.encode_obs_count", 0, PHX_KIND_MOCK_STRAT, B, kc(PHX_KIND_MOCK_STRAT), 1, 0},
     {F_MOCK_DEC, "mock.decode_action_count", 0, PHX_KIND_MOCK_STRAT, B, kc(PHX_KIND_MOCK_STRAT), 1, 0},
     {F_MOCK_REW, "mock.compute_reward_count", 0, PHX_KIND_MOCK_STRAT, B, kc(PHX_KIND_MOCK_STRAT), 1, 0},
+    {F_ADV_LEFT, "adv.left", 1, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_BID, "adv.bid", 1, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_LEFT_TAG, "adv.left_tag", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_BID_TAG, "adv.bid_tag", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_CLICKS, "adv.step_clicks", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_WINS, "adv.step_wins", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_USER, "adv.user", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 1, 0},
+    {F_ADV_TOT_CLICKS, "adv.total_clicks", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 3, 0},
+    {F_ADV_TOT_REQUESTS, "adv.total_requests", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 3, 0},
+    {F_ADV_TOT_WINS, "adv.total_wins", 0, PHX_KIND_ADVERTISER, B, kc(PHX_KIND_ADVERTISER), 3, 0},
+    {F_PUB_ADS_SEEN, "pub.ads_seen", 0, PHX_KIND_PUBLISHER, B, kc(PHX_KIND_PUBLISHER), 1, 0},
   };
   int64_t off = 0;
   out.clear();
@@ -560,7 +581,7 @@ int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) {
   if (e->n_inject + n > PHX_MAX_INJECT) return fail(PHX_ECAPACITY, "at most %d injected messages per resolve", PHX_MAX_INJECT);
   for (int k = 0; k < n; ++k) {
     if (msgs[k].sender >= e->d.A || msgs[k].receiver >= e->d.A) return fail(PHX_EINVAL, "agent index out of range");
-    DevMsg m; m.src = msgs[k].sender; m.dst = msgs[k].receiver; m.type = msgs[k].type; m.pad = 0; m.p.i = msgs[k].payload.i;
+    DevMsg m; m.src = msgs[k].sender; m.dst = msgs[k].receiver; m.type = msgs[k].type; m.pad = msgs[k].round; m.p.i = msgs[k].payload.i;
     e->inject_host[e->n_inject++] = m;
   }
   return PHX_OK;

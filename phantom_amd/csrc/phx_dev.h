@@ -32,6 +32,8 @@ enum {
   F_CASHBOX_TOTAL,
   F_REQRESP_REQ, F_REQRESP_RES,
   F_MOCK_ENC, F_MOCK_DEC, F_MOCK_REW,
+  F_ADV_LEFT, F_ADV_BID, F_ADV_LEFT_TAG, F_ADV_BID_TAG, F_ADV_CLICKS, F_ADV_WINS, F_ADV_USER,
+  F_ADV_TOT_CLICKS, F_ADV_TOT_REQUESTS, F_ADV_TOT_WINS, F_PUB_ADS_SEEN,
   F_WORKSPACE, F_ROLLOUT_SCRATCH,
   F_COUNT
 };
@@ -58,7 +60,7 @@ struct DevSpec {
   const int32_t* strat_rank;     // [A]  -1 for non-strategic
   const int32_t* strat_idx;      // [S]
   const int32_t* kind_rank;      // [A]
-  const int32_t* exo_rank;       // [A]  -1 unless CUSTOMER
+  const int32_t* exo_rank;       // [A]  first exo column of a CUSTOMER / PUBLISHER, else -1
   const int32_t* buyer_off;      // [A]  rank of a BUYER among the buyers (its column in buyer.prices)
   const int32_t* act_ptr;        // [n_lists+1] ordered acting lists
   const int32_t* act_idx;
@@ -387,6 +389,34 @@ __device__ __forceinline__ void shop_obs_f32(int stock, int sales, int missed, f
   o[2] = (float)missed / norm;
 }
 
+// ---- numpy scalar promotion of the ads market's floats (NEP 50; see the oracle's restatement) ----
+struct TVal { double v; int tag; };
+__device__ __forceinline__ TVal tv(double v, int tag) { TVal t; t.v = v; t.tag = tag; return t; }
+__device__ __forceinline__ int t_tag(const TVal& a, const TVal& b) { return a.tag > b.tag ? a.tag : b.tag; }
+__device__ __forceinline__ TVal t_mul(const TVal& a, const TVal& b) {
+  const int tag = t_tag(a, b);
+  return tag == PHX_TAG_F32 ? tv((double)__fmul_rn((float)a.v, (float)b.v), tag) : tv(__dmul_rn(a.v, b.v), tag);
+}
+__device__ __forceinline__ TVal t_sub(const TVal& a, const TVal& b) {
+  const int tag = t_tag(a, b);
+  return tag == PHX_TAG_F32 ? tv((double)__fsub_rn((float)a.v, (float)b.v), tag) : tv(__dsub_rn(a.v, b.v), tag);
+}
+__device__ __forceinline__ TVal t_div(const TVal& a, const TVal& b) {
+  const int tag = t_tag(a, b);
+  return tag == PHX_TAG_F32 ? tv((double)__fdiv_rn((float)a.v, (float)b.v), tag) : tv(__ddiv_rn(a.v, b.v), tag);
+}
+__device__ __forceinline__ bool t_lt(const TVal& a, const TVal& b) {
+  return t_tag(a, b) == PHX_TAG_F32 ? (float)a.v < (float)b.v : a.v < b.v;
+}
+// PublisherAgent draws when exo == NULL: k = 0 user id in {1, 2}; k >= 1 the k-th click of the step
+__device__ __forceinline__ int rng_publisher(uint64_t seed, int64_t genv, uint32_t tick, int agent, int k, double p) {
+  uint32_t w[4];
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), tick, 0x20000000u | ((uint32_t)k << 16) | (uint32_t)agent,
+                (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  if (k == 0) return 1 + (int)(w[0] & 1u);
+  return (double)(w[0] >> 8) * (1.0 / 16777216.0) < p ? 1 : 0;
+}
+
 // ---- generic per-kind behaviour used by the generic engine ---------------------------------
 struct AgentRef {          // where one agent's state lives for env b
   int a, kind, kr;         // agent index, kind, rank within kind
@@ -398,6 +428,12 @@ __device__ __forceinline__ AgentRef agent_ref(const DevSpec& sp, const Topo& tp,
   r.a = a; r.kind = tp.kind[a]; r.kr = tp.kind_rank[a];
   r.base = (int64_t)b * sp.kind_count[r.kind] + r.kr;
   return r;
+}
+// AdvertiserAgent: self.type.budget with its numpy kind (pi2: strong np.float64 / python float)
+__device__ __forceinline__ TVal adv_budget(const DevSpec& sp, const Topo& tp, int b, int a) {
+  const int src = sp.type_src[a];
+  const double v = src >= 0 ? fld<double>(sp, F_ENV_SAMPLER)[(int64_t)b * sp.n_samplers + src] : sp.param_f[a * PHX_NPF];
+  return tv(v, tp.param_i[a * PHX_NPI + 2] ? PHX_TAG_F64 : PHX_TAG_PYF);
 }
 
 // Agent.reset and subclasses (agents.py:160-175; supply_chain.py:149-150; test_network.py:23-24)
@@ -420,12 +456,26 @@ __device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, const Topo& t
       fld<int32_t>(sp, F_BUYER_BOUGHT)[r.base] = 0;
       break;
     }
+    case PHX_KIND_ADVERTISER: {                                // digital_ads_market.py:353-374
+      const TVal budget = adv_budget(sp, tp, b, a);
+      fld<double>(sp, F_ADV_LEFT)[r.base] = budget.v; fld<int32_t>(sp, F_ADV_LEFT_TAG)[r.base] = budget.tag;
+      fld<double>(sp, F_ADV_BID)[r.base] = 0.0; fld<int32_t>(sp, F_ADV_BID_TAG)[r.base] = PHX_TAG_PYF;
+      fld<int32_t>(sp, F_ADV_CLICKS)[r.base] = 0; fld<int32_t>(sp, F_ADV_WINS)[r.base] = 0;
+      fld<int32_t>(sp, F_ADV_USER)[r.base] = 0;
+      for (int u = 0; u < 3; ++u) {
+        fld<int32_t>(sp, F_ADV_TOT_CLICKS)[r.base * 3 + u] = 0;
+        fld<int32_t>(sp, F_ADV_TOT_REQUESTS)[r.base * 3 + u] = 0;
+        fld<int32_t>(sp, F_ADV_TOT_WINS)[r.base * 3 + u] = 0;
+      }
+      break;
+    }
     default: break;
   }
 }
 
-// encode_observation of a strategic agent; `step` is ctx.env_view.current_step
-__device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, const Topo& tp, int b, int a, int step, float* o) {
+// encode_observation of a strategic agent; `step` is ctx.env_view.current_step.  false where the
+// reference returns None (the agent is then left out of the observations, env.py:279-280)
+__device__ __forceinline__ bool dev_encode_obs(const DevSpec& sp, const Topo& tp, int b, int a, int step, float* o) {
   const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
     case PHX_KIND_SHOP:
@@ -455,8 +505,18 @@ __device__ __forceinline__ void dev_encode_obs(const DevSpec& sp, const Topo& tp
       fld<int32_t>(sp, F_MOCK_ENC)[r.base] += 1;
       o[0] = (float)((double)step / (double)sp.num_steps);
       break;
+    case PHX_KIND_ADVERTISER: {                                // digital_ads_market.py:294-316
+      const int user = fld<int32_t>(sp, F_ADV_USER)[r.base];
+      if (user == 0) return false;
+      const TVal budget = adv_budget(sp, tp, b, a);
+      o[0] = (float)budget.v;
+      o[1] = (float)t_div(tv(fld<double>(sp, F_ADV_LEFT)[r.base], fld<int32_t>(sp, F_ADV_LEFT_TAG)[r.base]), budget).v;
+      o[2] = (float)(user - 1);
+      break;
+    }
     default: break;
   }
+  return true;
 }
 
 __device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, const Topo& tp, int b, int a) {
@@ -473,11 +533,17 @@ __device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, const To
         return __dsub_rn(tp.param_f[a * PHX_NPF], fld<double>(sp, F_BUYER_PAID)[r.base]);
       return 0.0;
     case PHX_KIND_MOCK_STRAT: fld<int32_t>(sp, F_MOCK_REW)[r.base] += 1; return 0.0;
+    case PHX_KIND_ADVERTISER: return (double)fld<int32_t>(sp, F_ADV_CLICKS)[r.base];   // :335-343, risk_aversion 0
     default: return 0.0;
   }
 }
 
-__device__ __forceinline__ bool dev_is_done(const DevSpec& sp, const Topo& tp, int a, int step) {
-  // is_terminated == is_truncated for the only kind that overrides them (tests/__init__.py:61-65)
-  return tp.kind[a] == PHX_KIND_MOCK_STRAT && step == tp.param_i[a * PHX_NPI];
+__device__ __forceinline__ bool dev_is_terminated(const DevSpec& sp, const Topo& tp, int b, int a, int step) {
+  if (tp.kind[a] == PHX_KIND_MOCK_STRAT) return step == tp.param_i[a * PHX_NPI];          // tests/__init__.py:61-62
+  if (tp.kind[a] == PHX_KIND_ADVERTISER)                                                   // digital_ads_market.py:345-349
+    return fld<double>(sp, F_ADV_LEFT)[(int64_t)b * sp.kind_count[PHX_KIND_ADVERTISER] + tp.kind_rank[a]] <= 0.0;
+  return false;
+}
+__device__ __forceinline__ bool dev_is_truncated(const DevSpec& sp, const Topo& tp, int a, int step) {
+  return tp.kind[a] == PHX_KIND_MOCK_STRAT && step == tp.param_i[a * PHX_NPI];            // tests/__init__.py:64-65
 }

@@ -34,11 +34,13 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
     if (!live || live[a]) {                                    // env.py:274-275
       dv = 1;
-      if (obs_mask[a]) { encode_obs(a, t, ob); ov = 1; }
-      if (sp.env_type == PHX_ENV_PLAIN) { rw = dev_compute_reward(sp, tp, b, a); rv = 1; }
+      if (obs_mask[a]) ov = encode_obs(a, t, ob) ? 1 : 0;      // `if obs is not None` env.py:279-280
+      if (sp.env_type == PHX_ENV_PLAIN) { if (ov) { rw = dev_compute_reward(sp, tp, b, a); rv = 1; } }   // env.py:283
       else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, tp, b, a); rew_cache_v[s] = 1; }
-      tm = tr = dev_is_done(sp, tp, a, t) ? 1 : 0;                 // env.py:285-286
-      if (tm) { term[s] = 1; trunc[s] = 1; }                   // :288-292
+      tm = dev_is_terminated(sp, tp, b, a, t) ? 1 : 0;         // env.py:285-286
+      tr = dev_is_truncated(sp, tp, a, t) ? 1 : 0;
+      if (tm) term[s] = 1;                                     // :288-292
+      if (tr) trunc[s] = 1;
     }
     if (term[s]) atomicAdd(s_nterm, 1);
     if (trunc[s]) atomicAdd(s_ntrunc, 1);
@@ -95,5 +97,5 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
                                                    int list, int cur_stage, uint32_t tick,
                                                    const uint8_t* live, int* s_nterm, int* s_ntrunc) {
   strategic_epilogue<NT>(sp, tp, io, b, t, list, cur_stage, tick, live, s_nterm, s_ntrunc,
-                         [&](int a, int tt, float* ob) { dev_encode_obs(sp, tp, b, a, tt, ob); });
+                         [&](int a, int tt, float* ob) { return dev_encode_obs(sp, tp, b, a, tt, ob); });
 }

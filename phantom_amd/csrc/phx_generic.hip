@@ -82,6 +82,15 @@ __device__ __forceinline__ int act_count(const DevSpec& sp, const Topo& tp, int 
       for (int k = tp.row_ptr[a]; k < tp.row_ptr[a + 1]; ++k) if (edge_on(tp, k)) return 1;
       return 0;
     }
+    case PHX_KIND_PUBLISHER: return 1;
+    case PHX_KIND_ADVERTISER: {                                // a bid is sent iff it is > 0 (digital_ads_market.py:328)
+      if (!has_action) return 0;
+      const int64_t base = (int64_t)b * sp.kind_count[PHX_KIND_ADVERTISER] + tp.kind_rank[a];
+      const TVal left = tv(fld<double>(sp, F_ADV_LEFT)[base], fld<int32_t>(sp, F_ADV_LEFT_TAG)[base]);
+      TVal bid = t_mul(tv((double)action, PHX_TAG_F32), adv_budget(sp, tp, b, a));
+      if (t_lt(left, bid)) bid = left;
+      return bid.v > 0.0 ? 1 : 0;
+    }
     default: return 0;
   }
 }
@@ -142,6 +151,25 @@ __device__ __forceinline__ void act_emit(const DevSpec& sp, const Topo& tp, int 
     case PHX_KIND_MOCK_STRAT:
       if (has_action) fld<int32_t>(sp, F_MOCK_DEC)[r.base] += 1;     // tests/__init__.py:53-55
       break;
+    case PHX_KIND_PUBLISHER: {                                 // digital_ads_market.py:164-165, :48-53
+      const int user = exo_b ? exo_b[tp.exo_rank[a]] : rng_publisher(sp.seed, sp.env_offset + b, tick, a, 0, 0.0);
+      m.dst = (uint16_t)pi[0]; m.type = PHX_MSG_IMPRESSION_REQ; m.p.i = user;
+      out[0] = m;
+      break;
+    }
+    case PHX_KIND_ADVERTISER:
+      if (has_action) {                                        // digital_ads_market.py:318-333
+        const TVal left = tv(fld<double>(sp, F_ADV_LEFT)[r.base], fld<int32_t>(sp, F_ADV_LEFT_TAG)[r.base]);
+        TVal bid = t_mul(tv((double)action, PHX_TAG_F32), adv_budget(sp, tp, b, a));
+        if (t_lt(left, bid)) bid = left;                       // min(action[0] * budget, self.left)
+        fld<double>(sp, F_ADV_BID)[r.base] = bid.v; fld<int32_t>(sp, F_ADV_BID_TAG)[r.base] = bid.tag;
+        if (bid.v > 0.0) {
+          m.dst = (uint16_t)pi[0]; m.type = PHX_MSG_BID; m.p.f = bid.v;
+          m.pad = (uint16_t)(pi[1] | (fld<int32_t>(sp, F_ADV_USER)[r.base] << 4) | (bid.tag << 8));
+          out[0] = m;
+        }
+      }
+      break;
     default: break;
   }
 }
@@ -159,6 +187,10 @@ __device__ __forceinline__ void pre_resolution(const DevSpec& sp, const Topo& tp
         fld<int32_t>(sp, F_SELLER_TX)[r.base] = 0;
       }
       break;
+    case PHX_KIND_ADVERTISER:                                  // digital_ads_market.py:241-247
+      fld<int32_t>(sp, F_ADV_CLICKS)[r.base] = 0; fld<int32_t>(sp, F_ADV_WINS)[r.base] = 0;
+      break;
+    case PHX_KIND_PUBLISHER: fld<int32_t>(sp, F_PUB_ADS_SEEN)[r.base] = 0; break;
     default: break;
   }
 }
@@ -166,7 +198,7 @@ __device__ __forceinline__ void pre_resolution(const DevSpec& sp, const Topo& tp
 // Agent.handle_message (agents.py:122-155): returns true and fills `resp` (dst/type/payload)
 // when the handler answers; sets `code` to PHX_ERR_UNKNOWN_MSG for an unhandled payload type.
 __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp, int b, int a, const DevMsg& m,
-                                               int clock, DevMsg& resp, int& code) {
+                                               int clock, const uint8_t* exo_b, uint32_t tick, DevMsg& resp, int& code) {
   const AgentRef r = agent_ref(sp, tp, b, a);
   const int32_t* pi = tp.param_i + a * PHX_NPI;
   resp.src = (uint16_t)a; resp.dst = m.src; resp.pad = 0; resp.type = 0;
@@ -240,10 +272,123 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp
     case PHX_KIND_FORWARDER:                                   // test_resolver.py:93-96
       if (pi[0] >= 0) { resp.dst = (uint16_t)pi[0]; resp.type = PHX_MSG_PING; resp.p.i = 1; return true; }
       return false;
+    case PHX_KIND_PUBLISHER:
+      if (m.type == PHX_MSG_ADS) {                             // digital_ads_market.py:167-196
+        const int theme = m.pad & 15, user = (m.pad >> 4) & 15;
+        if (user < 1 || user > 2 || theme > 3) { code = PHX_ERR_CONTEXT; return false; }   // dict KeyError :194
+        const double p = sp.param_f[a * PHX_NPF + (user - 1) * 4 + theme];
+        const int k = ++fld<int32_t>(sp, F_PUB_ADS_SEEN)[r.base];
+        int clicked;
+        if (exo_b) {
+          if (k > pi[1]) { code = PHX_ERR_QUEUE_FULL; return false; }
+          clicked = exo_b[tp.exo_rank[a] + k];
+        } else clicked = rng_publisher(sp.seed, sp.env_offset + b, tick, a, k, p);
+        resp.dst = (uint16_t)m.p.i; resp.type = PHX_MSG_IMPRESSION_RES; resp.p.i = clicked; return true;
+      }
+      break;
+    case PHX_KIND_ADVERTISER:
+      if (m.type == PHX_MSG_IMPRESSION_REQ) {                  // :249-271
+        fld<int32_t>(sp, F_ADV_USER)[r.base] = (int32_t)m.p.i;
+        if (!dev_has_edge(sp, tp, a, pi[0])) { code = PHX_ERR_CONTEXT; return false; }     // ctx[self.exchange_id] :261
+        if (m.p.i >= 0 && m.p.i <= 2) fld<int32_t>(sp, F_ADV_TOT_REQUESTS)[r.base * 3 + m.p.i] += 1;
+        return false;
+      }
+      if (m.type == PHX_MSG_AUCTION_RESULT) {                  // :273-282
+        const int won = m.p.f != 0.0 ? 1 : 0;
+        fld<int32_t>(sp, F_ADV_WINS)[r.base] += won;
+        fld<int32_t>(sp, F_ADV_TOT_WINS)[r.base * 3 + fld<int32_t>(sp, F_ADV_USER)[r.base]] += won;
+        const TVal left = t_sub(tv(fld<double>(sp, F_ADV_LEFT)[r.base], fld<int32_t>(sp, F_ADV_LEFT_TAG)[r.base]),
+                                tv(m.p.f, (m.pad >> 8) & 3));
+        fld<double>(sp, F_ADV_LEFT)[r.base] = left.v; fld<int32_t>(sp, F_ADV_LEFT_TAG)[r.base] = left.tag;
+        return false;
+      }
+      if (m.type == PHX_MSG_IMPRESSION_RES) {                  // :284-292
+        fld<int32_t>(sp, F_ADV_CLICKS)[r.base] += (int32_t)m.p.i;
+        fld<int32_t>(sp, F_ADV_TOT_CLICKS)[r.base * 3 + fld<int32_t>(sp, F_ADV_USER)[r.base]] += (int32_t)m.p.i;
+        return false;
+      }
+      break;
     default: break;
   }
   code = PHX_ERR_UNKNOWN_MSG;                                  // agents.py:140-143
   return false;
+}
+
+// ---- AdExchangeAgent.handle_batch (digital_ads_market.py:429-516): an inbox REDUCTION ---------------
+// The exchange's lane walks its batch twice.  Pass `emit == false` counts what each position sends
+// (an ImpressionRequest fans out to every AdvertiserAgent neighbour, :427; the auction's Ads +
+// AuctionResults are booked on the batch's last position, after everything handle_message sent,
+// :443-449) and reports errors; after the block scan, pass `emit == true` writes the same messages at
+// their queue offsets.  The exchange keeps no state, so both passes see the same batch.
+//   ok(k)  : message k of the batch is delivered (receiver live, edge present, send succeeded)
+template <typename OkFn>
+__device__ __forceinline__ void adexchange_batch(const DevSpec& sp, const Topo& tp, int a, const DevMsg* qc, const int* seg,
+                                                 int c, OkFn ok, bool emit, int* counts, const int* offs, DevMsg* qn,
+                                                 int* errkey, int seq0) {
+  const int32_t* pi = tp.param_i + a * PHX_NPI;
+  int nb = 0, w = -1, w2 = -1, last_own = 0;
+  for (int k = 0; k < c; ++k) {
+    if (!emit) counts[k] = 0;
+    if (!ok(k)) continue;
+    const DevMsg m = qc[seg[k]];
+    if (m.type == PHX_MSG_BID) {
+      ++nb;
+      if (w < 0 || t_lt(tv(qc[seg[w]].p.f, (qc[seg[w]].pad >> 8) & 3), tv(m.p.f, (m.pad >> 8) & 3))) w = k;
+      continue;
+    }
+    if (m.type != PHX_MSG_IMPRESSION_REQ) {                    // no handler: ValueError agents.py:140-143
+      if (!emit) set_errkey(errkey, seq0 + k, PHX_ERR_UNKNOWN_MSG);
+      continue;
+    }
+    int n = 0;
+    for (int e = tp.row_ptr[a]; e < tp.row_ptr[a + 1]; ++e) {
+      const int dst = tp.col[e];
+      if (tp.kind[dst] != PHX_KIND_ADVERTISER) continue;
+      const int sc = dev_send_check(sp, tp, a, dst, PHX_MSG_IMPRESSION_REQ);
+      if (sc) { if (!emit) set_errkey(errkey, seq0 + k, sc); continue; }
+      if (emit) {
+        DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)dst; o.type = PHX_MSG_IMPRESSION_REQ; o.pad = 0; o.p.i = m.p.i;
+        qn[offs[k] + n] = o;
+      }
+      ++n;
+    }
+    if (!emit) counts[k] = n;
+    if (k == c - 1) last_own = n;
+  }
+  if (!nb) return;
+  for (int k = 0; k < c; ++k) {                                // sorted_bids[1]: first maximum among the rest
+    if (k == w || !ok(k) || qc[seg[k]].type != PHX_MSG_BID) continue;
+    if (w2 < 0 || t_lt(tv(qc[seg[w2]].p.f, (qc[seg[w2]].pad >> 8) & 3), tv(qc[seg[k]].p.f, (qc[seg[k]].pad >> 8) & 3))) w2 = k;
+  }
+  const DevMsg win = qc[seg[w]];
+  const DevMsg costm = (pi[1] && w2 >= 0) ? qc[seg[w2]] : win;          // second / first price :498-516
+  int n = last_own;                                            // the auction's sends follow the last position's own
+  int off = emit ? offs[c - 1] + last_own : 0;
+  {                                                            // Ads(advertiser_id, theme, user_id) :472-482
+    const int sc = dev_send_check(sp, tp, a, pi[0], PHX_MSG_ADS);
+    if (sc) { if (!emit) set_errkey(errkey, seq0 + c - 1, sc); }
+    else {
+      if (emit) {
+        DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)pi[0]; o.type = PHX_MSG_ADS; o.pad = win.pad & 0xff; o.p.i = win.src;
+        qn[off] = o;
+      }
+      ++off; ++n;
+    }
+  }
+  for (int k = 0; k < c; ++k) {                                // AuctionResult to every bidder, bid order :484-492
+    if (!ok(k) || qc[seg[k]].type != PHX_MSG_BID) continue;
+    const int dst = qc[seg[k]].src;
+    const int sc = dev_send_check(sp, tp, a, dst, PHX_MSG_AUCTION_RESULT);
+    if (sc) { if (!emit) set_errkey(errkey, seq0 + c - 1, sc); continue; }
+    if (emit) {
+      DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)dst; o.type = PHX_MSG_AUCTION_RESULT;
+      if (dst == win.src) { o.pad = costm.pad & 0x300; o.p.f = costm.p.f; }
+      else { o.pad = PHX_TAG_PYF << 8; o.p.f = 0.0; }
+      qn[off] = o;
+    }
+    ++off; ++n;
+  }
+  if (!emit) counts[c - 1] = n;
 }
 
 template <int NT, bool LDSQ, bool TABLDS>
@@ -436,6 +581,14 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
         while (y >= 0 && seg[y] > v) { seg[y + 1] = seg[y]; --y; }
         seg[y + 1] = v;
       }
+      if (tp.kind[a] == PHX_KIND_ADEXCHANGE) {                  // overrides handle_batch: count now, emit after the scan
+        for (int k = 0; k < c; ++k) resp[goff[a] + k].type = 0;
+        adexchange_batch(sp, tp, a, qc, seg, c,
+                         [&](int k) { const DevMsg m = qc[seg[k]];
+                                      return live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst)); },
+                         false, scanbuf + goff[a], nullptr, nullptr, &s_errkey, seq_base + goff[a]);
+        continue;
+      }
       for (int k = 0; k < c; ++k) {
         const int P = goff[a] + k;
         DevMsg out; out.type = 0;
@@ -446,7 +599,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
         // check (ignore_connection_errors): every queued message already passed has_edge
         if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
           int code = 0;
-          const bool answered = handle_message(sp, tp, b, a, m, clock + P, out, code);
+          const bool answered = handle_message(sp, tp, b, a, m, clock + P, exo_b, tick, out, code);
           if (code) set_errkey(&s_errkey, seq_base + P, code);
           if (answered) {                                       // network.send(receiver, sub_receiver, payload) :156-158
             const int sc = dev_send_check(sp, tp, out.src, out.dst, out.type);
@@ -459,16 +612,27 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     }
     __syncthreads();
     GTICK(10);
-    const int n_next = block_exscan<NT>(scanbuf, n, wave_sums);
-    for (int P = tid; P < n; P += NT)
-      if (resp[P].type != 0) {
-        const int off = scanbuf[P];
-        qn[off] = resp[P];
-        if (log_b && log_n + off < sp.trace_cap) {
-          phx_msg_rec r; r.sender = resp[P].src; r.receiver = resp[P].dst; r.type = resp[P].type;
-          r.round = (uint16_t)(round + 1); r.payload.i = resp[P].p.i; log_b[log_n + off] = r;
-        }
+    int n_next = block_exscan<NT>(scanbuf, n, wave_sums);
+    if (n_next > Q) { if (tid == 0) set_errkey(&s_errkey, seq_base + n, PHX_ERR_QUEUE_FULL); n_next = 0; }
+    else {
+      for (int P = tid; P < n; P += NT)
+        if (resp[P].type != 0) qn[scanbuf[P]] = resp[P];
+      if (sp.kind_count[PHX_KIND_ADEXCHANGE] > 0)
+        for (int a = tid; a < A; a += NT)
+          if (cnt[a] > 0 && tp.kind[a] == PHX_KIND_ADEXCHANGE)
+            adexchange_batch(sp, tp, a, qc, order + goff[a], cnt[a],
+                             [&](int k) { const DevMsg m = qc[order[goff[a] + k]];
+                                          return live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst)); },
+                             true, nullptr, scanbuf + goff[a], qn, &s_errkey, seq_base + goff[a]);
+      if (log_b) {
+        __syncthreads();
+        for (int i = tid; i < n_next; i += NT)
+          if (log_n + i < sp.trace_cap) {
+            phx_msg_rec r; r.sender = qn[i].src; r.receiver = qn[i].dst; r.type = qn[i].type;
+            r.round = (uint16_t)(round + 1); r.payload.i = qn[i].p.i; log_b[log_n + i] = r;
+          }
       }
+    }
     __syncthreads();
     GTICK(11);
     log_n += n_next; seq_base += n; clock += n;
@@ -536,9 +700,9 @@ __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const u
     const int a = sp.reset_obs_idx[k], s = tp.strat_rank[a];
     if (s < 0) continue;
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
-    dev_encode_obs(sp, tp, b, a, 0, ob);
-    for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = ob[d];
-    if (obs_valid) obs_valid[(int64_t)b * S + s] = 1;
+    const bool v = dev_encode_obs(sp, tp, b, a, 0, ob);              // `if v is not None` env.py:237
+    for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = v ? ob[d] : 0.f;
+    if (obs_valid) obs_valid[(int64_t)b * S + s] = v ? 1 : 0;
   }
 }
 
@@ -603,7 +767,7 @@ __global__ void phx_gen_policy_kernel(const DevSpec sp, const int t, const float
     else {
       uint32_t j;
       rng_group_y(sp.seed, sp.env_offset + b, tick, s, 0, 0, &j);
-      action = kind == PHX_KIND_SELLER ? (float)j * (1.0f / 274877.0f)
+      action = (kind == PHX_KIND_SELLER || kind == PHX_KIND_ADVERTISER) ? (float)j * (1.0f / 274877.0f)
              : kind == PHX_KIND_BUYER ? (j < 137438u ? 1.0f : 0.0f) : rng_j_to_action(j);
     }
   }

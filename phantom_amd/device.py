@@ -161,6 +161,8 @@ class DeviceEnv:
         a = self.spec.index_of(agent.id)
         col = int(self._kind_rank[a])
         v = self._fields[field_name][:, col].cpu().numpy()
+        if v.ndim > 1:                      # a per-agent vector (adv.total_*: counts keyed by user id)
+            return v[0] if self.B == 1 else v
         return v[0].item() if self.B == 1 else v
 
     # ---- entry points ---------------------------------------------------------------------

@@ -239,6 +239,9 @@ class PhantomEnv:
         spec = self.spec
         if spec.n_exo == 0 or self.exogenous != "numpy":
             return None
+        if (spec.kind == _abi.KIND_PUBLISHER).any():
+            raise NotImplementedError("PublisherAgent's np.random.binomial(1, p) depends on the auction's "
+                                      "outcome and cannot be pre-drawn on the host: use exogenous='device'")
         if not hasattr(self, "_customers_all"):
             self._customers_all = [a for a in range(spec.n_agents)
                                    if spec.kind[a] == _abi.KIND_CUSTOMER]
@@ -279,11 +282,16 @@ class PhantomEnv:
             d = spec.agent_obs_dim(a)
             if self.batch_size == 1:
                 if valid[0, s]:
-                    out[spec.agent_ids[a]] = obs[0, s, :d].copy()
+                    out[spec.agent_ids[a]] = self._format_obs(a, obs[0, s, :d].copy())
             elif valid[:, s].any():
                 self._require_uniform(valid[:, s])
                 out[spec.agent_ids[a]] = obs[:, s, :d].copy()
         return out
+
+    def _format_obs(self, a: int, row: np.ndarray):
+        """kinds whose reference observation is not a flat Box rebuild it from the device row."""
+        fmt = getattr(self.network.agents[self.spec.agent_ids[a]], "format_observation", None)
+        return row if fmt is None else fmt(row)
 
     @staticmethod
     def _require_uniform(col: np.ndarray):
@@ -364,7 +372,7 @@ class PhantomEnv:
             d = spec.agent_obs_dim(a)
             if B == 1:
                 if ov[0, s]:
-                    observations[aid] = obs[0, s, :d].copy()
+                    observations[aid] = self._format_obs(a, obs[0, s, :d].copy())
                     infos[aid] = {}
                 if rv[0, s] == 1:
                     rewards[aid] = float(rew[0, s])

@@ -103,6 +103,39 @@ class Response:                # tests/network/test_resolver.py:19-21
     cash: float
 
 
+# digital_ads_market.py:28-121.  On the device the small fields ride in the record's aux bits
+# (theme | user_id << 4 | tag << 8); only the 8-byte value is logged.
+@_device_payload(_abi.MSG_IMPRESSION_REQ, "user_id")
+class ImpressionRequest:
+    user_id: int
+    timestamp: float = 0.0
+
+
+@_device_payload(_abi.MSG_BID, "bid")
+class Bid:
+    bid: float
+    theme: Any = 0
+    user_id: int = 0
+
+
+@_device_payload(_abi.MSG_AUCTION_RESULT, "cost")
+class AuctionResult:
+    cost: float
+    winning_bid: float = 0.0
+
+
+@_device_payload(_abi.MSG_ADS, "advertiser_id")
+class Ads:
+    advertiser_id: Any
+    theme: Any = 0
+    user_id: int = 0
+
+
+@_device_payload(_abi.MSG_IMPRESSION_RES, "clicked")
+class ImpressionResult:
+    clicked: bool
+
+
 def payload_to_record(payload):
     """(type id, is_float, value) of a payload instance; TypeError if it has no device type."""
     t = getattr(type(payload), "_msg_type", None)

@@ -90,7 +90,20 @@ class EnvSpec:
 
     @property
     def n_exo(self) -> int:
-        return int((self.kind == _abi.KIND_CUSTOMER).sum())
+        """exogenous draws per step: one per CustomerAgent, 1 + pi1 per PublisherAgent."""
+        pubs = self.kind == _abi.KIND_PUBLISHER
+        return int((self.kind == _abi.KIND_CUSTOMER).sum() + pubs.sum() + self.param_i[pubs, 1].sum())
+
+    def exo_slot(self) -> np.ndarray:
+        """first exo column of each agent (-1: none), agent order (phx_api.hip derive())."""
+        out, n = np.full(self.n_agents, -1, dtype=np.int64), 0
+        for a in range(self.n_agents):
+            k = int(self.kind[a])
+            if k == _abi.KIND_CUSTOMER:
+                out[a] = n; n += 1
+            elif k == _abi.KIND_PUBLISHER:
+                out[a] = n; n += 1 + int(self.param_i[a, 1])
+        return out
 
     def kind_rank(self) -> np.ndarray:
         """rank of each agent among the agents of its own kind (state column)."""
@@ -152,8 +165,11 @@ class EnvSpec:
 
 def _max_emissions(kind: int, deg: int) -> int:
     """upper bound of messages one acting agent of this kind sends in the acting phase."""
-    if kind in (_abi.KIND_SHOP, _abi.KIND_CUSTOMER, _abi.KIND_BUYER):
+    if kind in (_abi.KIND_SHOP, _abi.KIND_CUSTOMER, _abi.KIND_BUYER, _abi.KIND_PUBLISHER,
+                _abi.KIND_ADVERTISER):
         return 1
+    if kind == _abi.KIND_ADEXCHANGE:      # not acting, but one round of it emits up to deg + 1 messages
+        return deg + 1
     if kind == _abi.KIND_SELLER:
         return deg
     return 0
@@ -193,6 +209,8 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         pi, pf = agent.device_params(index_of)
         param_i[a, :len(pi)] = pi
         param_f[a, :len(pf)] = pf
+        if hasattr(agent, "check_topology"):
+            agent.check_topology(network)
 
     # CustomerAgent.pi1 = index among the customers of its shop, in agent order (keys the
     # device RNG stream so that results do not depend on how lanes are mapped)
@@ -292,6 +310,14 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         else:
             type_src[a] = _abi.TYPE_CONST
             spec.param_f[a, 0] = float(v)
+        if int(kind[a]) == _abi.KIND_ADVERTISER:
+            # numpy kind of type.budget (NEP 50): np.clip makes a clipped UniformFloatSampler return
+            # np.float64 (samplers.py:143-145); np.random.uniform alone returns a python float
+            if isinstance(v, UniformFloatSampler):
+                strong = v.clip_low is not None or v.clip_high is not None
+            else:
+                strong = isinstance(v.value if isinstance(v, Sampler) else v, np.floating)
+            spec.param_i[a, 2] = int(strong)
     if (type_src != _abi.TYPE_NONE).any():
         spec.type_src = type_src
     return spec

@@ -74,6 +74,32 @@ def market_env(L, Fw, d, num_steps, batch, tracking=False, rates=None, **kw):
     return ph.StackelbergEnv(num_steps, net, leaders, followers, batch_size=batch, **kw)
 
 
+ADS_THEMES = ("sport", "travel", "science", "tech")
+
+
+def ads_env_from_golden(g, batch=1, tracking=True, **kw):
+    """the DigitalAdsEnv of a tests/golden/ads_*.npz case (gen_goldens_ads.py run_ads)."""
+    themes = [ADS_THEMES[i] for i in g["themes"]]
+    counts = {}
+    for th in themes:
+        counts[th] = counts.get(th, 0) + 1
+    samplers = [ph.UniformFloatSampler(p[0], p[1], None if np.isnan(p[2]) else p[2],
+                                       None if np.isnan(p[3]) else p[3]) for p in g["sampler_params"]]
+    st = {}
+    for i, col in enumerate(g["sampler_cols"]):
+        st[f"ADV_{i + 1}"] = ph.AdvertiserAgent.Supertype(
+            budget=samplers[col] if col >= 0 else float(g["const_budgets"][i]))
+    rates = (1.0, 1.0, 1.0)
+    if "conn_rate" in g:
+        r, n = g["conn_rate"], len(themes)
+        rates = (float(r[0]), float(r[1]), float(r[1 + n]))
+    env = ph.DigitalAdsEnv(num_steps=int(g["num_steps"]), num_agents_theme=counts, agent_supertypes=st,
+                           strategy="second" if int(g["second"]) else "first", connection_rates=rates,
+                           batch_size=batch, **kw)
+    env.network.resolver.enable_tracking = tracking
+    return env
+
+
 def f32_bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 

@@ -173,7 +173,7 @@ class OracleEnv:
         return out
 
     def get_i32(self, field):
-        buf = np.zeros(self.B * max(self.spec.n_agents, 1), np.int32)
+        buf = np.zeros(self.B * max(self.spec.n_agents, 1) * 3, np.int32)
         n = self.L.phxo_get_i32(self.h, field.encode(), _p(buf))
         assert n >= 0, field
         return buf[:n].reshape(self.B, -1).copy()

@@ -15,7 +15,8 @@ from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, ma
                      supply_chain_env)
 from kats import ALL_KATS
 from oracle import OracleEnv
-from test_oracle_vs_goldens import MARKET_CASES, SC_CASES, replay_market, replay_supply_chain
+from test_oracle_vs_goldens import (ADS_CASES, MARKET_CASES, SC_CASES, replay_ads, replay_market,
+                                    replay_supply_chain)
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +59,13 @@ def test_fused_kernel_supply_chain_matches_reference(name):
 @pytest.mark.parametrize("name", MARKET_CASES)
 def test_generic_engine_market_matches_reference(name):
     replay_market(golden(name), _dev)
+
+
+@pytest.mark.parametrize("name", ADS_CASES)
+def test_generic_engine_ads_market_matches_reference(name):
+    """digital_ads_market.py on the device: the exchange's handle_batch auction as an inbox reduction,
+    the publisher's draws as exogenous inputs, NEP-50 tagged float arithmetic, None observations."""
+    replay_ads(golden(name), _dev)
 
 
 @pytest.mark.parametrize("name", ["stk_small", "stk_full"])

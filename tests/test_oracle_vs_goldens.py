@@ -4,8 +4,9 @@ rewards are compared by BIT PATTERN as well (stricter than the 1e-6 the task all
 import numpy as np
 import pytest
 
-from helpers import (env_from_golden, f32_bits, f64_bits, golden, log_matrix, market_env)
+from helpers import (ads_env_from_golden, env_from_golden, f32_bits, f64_bits, golden, log_matrix, market_env)
 from oracle import OracleEnv
+from phantom_amd import _abi
 
 SC_CASES = ["sc7_fixed20", "sc7_mixed", "sc64", "sc_ragged", "sc256_fsm", "sc_fsm_small",
             "sc_typed", "sc_typed_fsm"]
@@ -102,3 +103,58 @@ MARKET_CASES = ["stk_small", "stk_full", "stk_stochastic"]
 @pytest.mark.parametrize("name", MARKET_CASES)
 def test_oracle_market_matches_reference(name):
     replay_market(golden(name), lambda spec: OracleEnv(spec))
+
+
+def replay_ads(g, make_runner):
+    """the digital-ads market (gen_goldens_ads.py): exchange auction, publisher draws, tagged floats."""
+    T = int(g["T"])
+    env = ads_env_from_golden(g)
+    spec = env.spec
+    np.testing.assert_array_equal(spec.param_f[spec.kind == _abi.KIND_PUBLISHER][0], g["click_table"].ravel())
+    run = make_runner(spec)
+    assert run.D == 3 and run.n_exo == 2
+    stochastic = "conn_rate" in g
+    n_s = spec.n_samplers
+    for t in range(T):
+        if g["reset_before"][t]:
+            sv = g["sampler_values"][t][None, :n_s] if n_s else None
+            conn = g["conn_on"][t][None] if stochastic else None
+            _, valid = run.reset(None, sv, conn)
+            np.testing.assert_array_equal(valid[0], g["reset_obs_valid"][t])
+        assert int(run.get_i32("env.stage")[0, 0]) == int(g["stage"][t])
+        run.step(g["actions"][t][None], g["action_valid"][t][None], g["exo"][t][None])
+        assert (run.err == 0).all(), (t, run.err)
+        msg = f"t={t}"
+        np.testing.assert_array_equal(run.get_i32("adv.user")[0], g["user"][t], err_msg=msg)
+        np.testing.assert_array_equal(run.get_i32("adv.left_tag")[0], g["left_tag"][t], err_msg=msg)
+        np.testing.assert_array_equal(f64_bits(run.get_f64("adv.left")[0]), f64_bits(g["left"][t]), err_msg=msg)
+        np.testing.assert_array_equal(run.get_i32("adv.bid_tag")[0], g["bid_tag"][t], err_msg=msg)
+        np.testing.assert_array_equal(f64_bits(run.get_f64("adv.bid")[0]), f64_bits(g["bid"][t]), err_msg=msg)
+        np.testing.assert_array_equal(run.get_i32("adv.step_clicks")[0], g["step_clicks"][t], err_msg=msg)
+        np.testing.assert_array_equal(run.get_i32("adv.step_wins")[0], g["step_wins"][t], err_msg=msg)
+        for f in ("total_clicks", "total_requests", "total_wins"):
+            np.testing.assert_array_equal(run.get_i32("adv." + f)[0].reshape(-1, 3), g[f][t], err_msg=f"{f} {msg}")
+        np.testing.assert_array_equal(run.obs_valid[0], g["obs_valid"][t], err_msg=msg)
+        np.testing.assert_array_equal(run.reward_valid[0], g["reward_valid"][t], err_msg=msg)
+        np.testing.assert_array_equal(run.done_valid[0], g["done_valid"][t], err_msg=msg)
+        ov = g["obs_valid"][t].astype(bool)
+        # the device row is f32: budget is f32 in the reference too, budget_left its f64 rounded to f32
+        np.testing.assert_array_equal(f32_bits(run.obs[0][ov]), f32_bits(g["obs"][t][ov].astype(np.float32)), err_msg=msg)
+        rv = g["reward_valid"][t] == 1
+        np.testing.assert_array_equal(f64_bits(run.reward[0][rv]), f64_bits(g["reward"][t][rv]), err_msg=msg)
+        dv = g["done_valid"][t].astype(bool)
+        np.testing.assert_array_equal(run.terminated[0][dv], g["terminated"][t][dv], err_msg=msg)
+        np.testing.assert_array_equal(run.truncated[0][dv], g["truncated"][t][dv], err_msg=msg)
+        np.testing.assert_array_equal(run.all_terminated[0], g["all_terminated"][t])
+        np.testing.assert_array_equal(run.all_truncated[0], g["all_truncated"][t])
+        assert int(run.msg_count[0]) == int(g["n_msgs"][t]), msg
+        if t < 6:
+            np.testing.assert_array_equal(log_matrix(run.log(0)), g[f"log{t}"], err_msg=f"log {msg}")
+
+
+ADS_CASES = ["ads_first", "ads_second", "ads_sampled", "ads_stochastic"]
+
+
+@pytest.mark.parametrize("name", ADS_CASES)
+def test_oracle_ads_market_matches_reference(name):
+    replay_ads(golden(name), lambda spec: OracleEnv(spec))
