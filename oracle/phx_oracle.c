@@ -1170,7 +1170,11 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
       if (io->obs_valid) io->obs_valid[base + s] = u8[s];
       if (io->reward_valid) io->reward_valid[base + s] = u8[S + s];
     }
-    if (at || au) env_reset_one(E, e, b, NULL, NULL, o, u8);          /* caller's env.reset() */
+    if (at || au) {                                                   /* caller's env.reset() */
+      const int32_t first_err = e->err;                               /* io->err reports the rollout's first error */
+      env_reset_one(E, e, b, NULL, NULL, o, u8);
+      e->err = first_err;
+    }
   }
   if (io->last_obs) memcpy(io->last_obs + (size_t)b * S * D, o, sizeof(float) * S * D);
   if (io->err) io->err[b] = e->err;

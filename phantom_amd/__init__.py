@@ -27,5 +27,5 @@ from . import samplers
 from .samplers import (LambdaSampler, NormalArraySampler, NormalSampler, Sampler,
                        UniformArraySampler, UniformFloatSampler, UniformIntSampler)
 from .views import AgentView, EnvView, FSMEnvView, View
-from . import metrics, rllib
+from . import ads_market, metrics, rllib
 from .distributed import all_gather_trajectory, make_sharded_env, shard_batch

@@ -249,7 +249,8 @@ class DeviceEnv:
         torch = _torch()
         B, S, D = self.B, self.S, self.D
         e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=self.device)
-        fsm = self.spec.env_type != _abi.ENV_PLAIN
+        # validity masks: stage-masked envs, and kinds whose encode_observation can return None
+        fsm = self.spec.env_type != _abi.ENV_PLAIN or bool((self.spec.kind == _abi.KIND_ADVERTISER).any())
         return Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
                           e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
                           e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),

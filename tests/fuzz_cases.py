@@ -211,9 +211,107 @@ def net_case(rng, case):
     return f"net n={n} rl={rl} flags={spec.flags} B={B}"
 
 
+def ads_case(rng, case):
+    """digital-ads market on random topologies: several publisher / exchange pairs, advertisers spread
+    over the exchanges, random connectivity rates, first / second price, constant and sampled budgets,
+    plain env (requests and bids meet in one batch) or the two-stage FSM, exogenous or device draws."""
+    P = int(rng.randint(1, 3)); N = int(rng.randint(1, 14)); B = int(rng.randint(1, 40))
+    num_steps = int(rng.randint(2, 14)); T = int(rng.randint(4, 30))
+    themes = [ph.ads_market.THEMES[i] for i in rng.randint(0, 4, N)]
+    adx_of = rng.randint(0, P, N)
+    pubs = [ph.PublisherAgent(f"PUB{p}", exchange_id=f"ADX{p}", click_draws_per_step=int(rng.randint(1, 3)),
+                              user_click_proba={u: {t: float(rng.choice([0.0, 0.25, 0.5, 1.0])) for t in ph.ads_market.THEMES}
+                                                for u in (1, 2)}) for p in range(P)]
+    advs = [ph.AdvertiserAgent(f"ADV{i}", f"ADX{adx_of[i]}", theme=themes[i]) for i in range(N)]
+    adxs = [ph.AdExchangeAgent(f"ADX{p}", publisher_id=f"PUB{p}", advertiser_ids=[a.id for i, a in enumerate(advs) if adx_of[i] == p],
+                               strategy=("second" if rng.rand() < 0.5 else "first")) for p in range(P)]
+    agents = adxs + pubs + advs
+    agents = [agents[i] for i in rng.permutation(len(agents))]
+    rl = None if rng.rand() < 0.3 else int(rng.randint(2, 7))
+    ignore = bool(rng.rand() < 0.7)
+    net = ph.StochasticNetwork(agents, ph.BatchResolver(round_limit=rl, enable_tracking=bool(rng.rand() < 0.4)),
+                               ignore_connection_errors=ignore, enforce_msg_payload_checks=bool(rng.rand() < 0.8))
+    rate = lambda: float(rng.choice([1.0, 1.0, 0.9, 0.6])) if ignore or rng.rand() < 0.5 else 1.0
+    for p in range(P):
+        net.add_connection(f"ADX{p}", f"PUB{p}", rate())
+        for a in adxs[p].advertiser_ids: net.add_connection(f"ADX{p}", a, rate())
+        for a in adxs[p].advertiser_ids:
+            if rng.rand() < 0.9: net.add_connection(f"PUB{p}", a, rate())
+    sm = [ph.UniformFloatSampler(0.5, 2.0), ph.UniformFloatSampler(0.4, 1.6, 0.5, 1.5)]
+    sup = {a.id: ph.AdvertiserAgent.Supertype(budget=(sm[int(rng.randint(2))] if rng.rand() < 0.5 else float(rng.choice([0.5, 1.0, 1.7, 3.0]))))
+           for a in advs}
+    kw = dict(batch_size=B, seed=int(rng.randint(1 << 30)), env_offset=int(rng.randint(1 << 20)), exogenous="device",
+              agent_supertypes=sup)
+    fsm = rng.rand() < 0.6
+    if fsm:
+        env = ph.FiniteStateMachineEnv(num_steps, net, initial_stage="pub", stages=[
+            ph.FSMStage("pub", next_stages=["adv"], acting_agents=[p.id for p in pubs], rewarded_agents=[p.id for p in pubs]),
+            ph.FSMStage("adv", next_stages=["pub"], acting_agents=[a.id for a in advs],
+                        rewarded_agents=(None if rng.rand() < 0.2 else [a.id for a in advs]))], **kw)
+    else:
+        env = ph.PhantomEnv(num_steps, net, **kw)
+    spec = env.spec
+    o, d = OracleEnv(spec), DeviceRunner(spec)
+    S, nx = spec.n_strategic, spec.n_exo
+    slot = spec.exo_slot()
+    user_cols = [int(slot[a]) for a in range(spec.n_agents) if spec.kind[a] == ph._abi.KIND_PUBLISHER]
+
+    def state(tag):
+        for f in ("adv.left", "adv.bid"):
+            assert np.array_equal(f64_bits(d.get_f64(f)), f64_bits(o.get_f64(f))), (case, tag, f)
+        for f in ("adv.left_tag", "adv.bid_tag", "adv.step_clicks", "adv.step_wins", "adv.user", "adv.total_clicks",
+                  "adv.total_requests", "adv.total_wins"):
+            assert np.array_equal(d.get_i32(f), o.get_i32(f)), (case, tag, f)
+
+    def reset(mask=None):
+        (oo, ov), (do, dv) = o.reset(mask), d.reset(mask)
+        m = slice(None) if mask is None else mask.astype(bool)
+        assert np.array_equal(dv[m], ov[m]) and np.array_equal(f32_bits(do[m]), f32_bits(oo[m])), (case, "reset")
+        assert np.array_equal(d.get_u8("net.conn_on"), o.get_u8("net.conn_on")), (case, "conn")
+
+    reset()
+    for t in range(T):
+        act = np.where(rng.rand(B, S) < 0.85, rng.uniform(0, 1.3, (B, S)), rng.randint(0, 3, (B, S)) / 2.0).astype(np.float32)
+        valid = (rng.rand(B, S) < 0.9).astype(np.uint8) if rng.rand() < 0.5 else None
+        exo = None
+        if rng.rand() < 0.5:
+            exo = rng.randint(0, 2, (B, nx)).astype(np.uint8)
+            exo[:, user_cols] += 1                                # user ids are 1 or 2
+        o.step(act, valid, exo); d.step(act, valid, exo)
+        cmp(o, d, (case, t))
+        if (o.err == 0).all():
+            state(t)
+            if spec.trace_cap:
+                assert np.array_equal(d.msg_count, o.msg_count), (case, t, "msg_count")
+                b0 = int(rng.randint(B))
+                assert np.array_equal(d.log(b0), o.log(b0)), (case, t, "log")
+        else:
+            reset((o.err != 0).astype(np.uint8))
+            if (o.err != 0).any():
+                return f"ads N={N} P={P} err={int(o.err.max())} rl={rl}"
+        done = ((o.all_truncated > 0) | (o.all_terminated > 0) | (rng.rand(B) < 0.05)).astype(np.uint8)
+        if done.any():
+            reset(done)
+    if rng.rand() < 0.6 and (o.err == 0).all():                   # launch-loop rollout, device policy and draws
+        Tr = int(rng.randint(1, 40))
+        ro, rd = o.rollout(Tr, None, None), d.rollout(Tr, None, None)
+        assert np.array_equal(d.err, o.err), (case, "rollout err", d.err, o.err)
+        ok = o.err == 0                                           # an env's outputs are unspecified after its first error
+        for k in ("obs", "actions", "rewards"):
+            assert np.array_equal(f32_bits(rd[k])[:, ok], f32_bits(ro[k])[:, ok]), (case, "rollout", k)
+        assert np.array_equal(f32_bits(rd["last_obs"])[ok], f32_bits(ro["last_obs"])[ok]), (case, "rollout last_obs")
+        for k in ("truncated", "terminated", "obs_valid", "reward_valid"):
+            assert np.array_equal(rd[k][:, ok], ro[k][:, ok]), (case, "rollout", k)
+        if ok.all():
+            state("rollout")
+    return f"ads N={N} P={P} B={B} fsm={fsm} rl={rl} ignore={ignore} flags={spec.flags}"
+
+
 def run_case(case):
     rng = np.random.RandomState(case)
     np.random.seed(case)
+    if case % 7 == 6:
+        return ads_case(rng, case)
     if case % 5 == 4:
         return net_case(rng, case)
     return (stk_case if case % 3 == 2 else sc_case)(rng, case)

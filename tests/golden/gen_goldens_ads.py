@@ -197,14 +197,17 @@ def run_ads(name, themes, budgets, num_steps, T, seed, strategy="first", rates=N
             need_reset = True
     click = env.agents["PUB"].user_click_proba
     table = np.asarray([[click[u].get(th, 0.0) for th in THEMES] for u in (1, 2)])
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), T=T, num_steps=num_steps,
-                        themes=np.asarray([THEMES.index(t) for t in themes]), second=int(strategy == "second"),
-                        sampler_cols=np.asarray(sampler_cols), click_table=table,
-                        sampler_params=np.asarray([[x if x is not None else np.nan for x in
-                                                    (b[1], b[2]) + (tuple(b[3:5]) if b[0] == "clipped" else (None, None))]
-                                                   for _, b in samplers]).reshape(len(samplers), 4),
-                        const_budgets=np.asarray([b if not isinstance(b, tuple) else np.nan for b in budgets]),
-                        **A, **logs)
+    out = dict(T=np.asarray(T), num_steps=np.asarray(num_steps),
+               themes=np.asarray([THEMES.index(t) for t in themes]), second=np.asarray(int(strategy == "second")),
+               sampler_cols=np.asarray(sampler_cols), click_table=table,
+               sampler_params=np.asarray([[x if x is not None else np.nan for x in
+                                           (b[1], b[2]) + (tuple(b[3:5]) if b[0] == "clipped" else (None, None))]
+                                          for _, b in samplers], dtype=np.float64).reshape(len(samplers), 4),
+               const_budgets=np.asarray([b if not isinstance(b, tuple) else np.nan for b in budgets]),
+               **A, **logs)
+    if name is None:
+        return out                      # live cross-check (tests/test_oracle_vs_live_reference.py)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(f"{name}: S={S} T={T} wins={A['step_wins'].sum()} clicks={A['step_clicks'].sum()} "
           f"terminated={int(A['terminated'].sum())} tags={sorted(set(A['left_tag'].ravel()))} "
           f"none_obs={int(((A['stage'] == 0)[:, None] & (A['obs_valid'] == 0)).sum())} msgs={A['n_msgs'][:6]}")
