@@ -391,6 +391,130 @@ __device__ __forceinline__ void adexchange_batch(const DevSpec& sp, const Topo& 
   if (!emit) counts[c - 1] = n;
 }
 
+// ---- the same reduction, by the whole workgroup ------------------------------------------------------
+// The single lane above is the critical path of an ads-market step (a 120-bid auction costs it ~10^6
+// cycles); here every thread takes batch positions k = tid, tid + NT, ...  Phase A (before the
+// receivers' lanes run): rank-sort the batch into send order, classify every message, count what each
+// position sends and reduce the winner; phase B (after the block scan): write the messages.  Sends are
+// booked in position order, which is the reference's order unless an ImpressionRequest follows a Bid
+// in the batch -- then `mode[a]` = -1 and lane `a` runs the sequential adexchange_batch instead.
+//   cls[k] (kept in the round's dead slot[] array): 0 dropped, 1 Bid, 2 ImpressionRequest, 3 no handler,
+//   | 16 the first bid of the batch; mode[a] = winner position | (second + 1) << 16.
+__device__ __forceinline__ TVal adx_bid(const DevMsg* qc, const int* seg, int k) {
+  const DevMsg m = qc[seg[k]];
+  return tv(m.p.f, (m.pad >> 8) & 3);
+}
+// first maximum in position order: of two candidates the earlier one wins unless it is smaller
+__device__ __forceinline__ int adx_better(const DevMsg* qc, const int* seg, int x, int y) {
+  if (x < 0) return y;
+  if (y < 0) return x;
+  const int lo = x < y ? x : y, hi = x < y ? y : x;
+  return t_lt(adx_bid(qc, seg, lo), adx_bid(qc, seg, hi)) ? hi : lo;
+}
+template <int NT, typename F>
+__device__ __forceinline__ int block_fold(int v, int* red, F combine) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) v = combine(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r = combine(r, red[w]);
+  return r;
+}
+__device__ __forceinline__ bool adx_delivered(const DevSpec& sp, const Topo& tp, const uint8_t* live, int a, const DevMsg& m) {
+  return live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst));
+}
+__device__ __forceinline__ int adx_fanout(const DevSpec& sp, const Topo& tp, int a, const DevMsg& m, DevMsg* out, int* errkey, int key) {
+  int n = 0;                                                   // forward to self.advertiser_ids :427
+  for (int e = tp.row_ptr[a]; e < tp.row_ptr[a + 1]; ++e) {
+    const int dst = tp.col[e];
+    if (tp.kind[dst] != PHX_KIND_ADVERTISER) continue;
+    if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !edge_on(tp, e)) { if (!out) set_errkey(errkey, key, PHX_ERR_NETWORK); continue; }
+    if (out) { DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)dst; o.type = PHX_MSG_IMPRESSION_REQ; o.pad = 0; o.p.i = m.p.i; out[n] = o; }
+    ++n;
+  }
+  return n;
+}
+
+template <int NT>
+__device__ __forceinline__ void adx_coop_count(const DevSpec& sp, const Topo& tp, int a, const uint8_t* live, const DevMsg* qc,
+                                               int* seg, int c, int* cls, int* counts, DevMsg* resp, int* red, int* mode,
+                                               int* errkey, int seq0) {
+  const int tid = threadIdx.x;
+  if (c > 1) {                                                 // rank sort by send sequence number
+    for (int k = tid; k < c; k += NT) {
+      const int v = seg[k]; int r = 0;
+      for (int j = 0; j < c; ++j) r += seg[j] < v;
+      cls[r] = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < c; k += NT) seg[k] = cls[k];
+    __syncthreads();
+  }
+  int first_bid = 0x7fffffff, last_req = -1, best = -1;
+  for (int k = tid; k < c; k += NT) {
+    const DevMsg m = qc[seg[k]];
+    int cl = 0, n = 0;
+    if (adx_delivered(sp, tp, live, a, m)) {
+      if (m.type == PHX_MSG_BID) { cl = 1; first_bid = min(first_bid, k); best = adx_better(qc, seg, best, k); }
+      else if (m.type == PHX_MSG_IMPRESSION_REQ) { cl = 2; last_req = k; n = adx_fanout(sp, tp, a, m, nullptr, errkey, seq0 + k); }
+      else { cl = 3; set_errkey(errkey, seq0 + k, PHX_ERR_UNKNOWN_MSG); }          // agents.py:140-143
+    }
+    cls[k] = cl; counts[k] = n; resp[k].type = 0;
+  }
+  first_bid = block_fold<NT>(first_bid, red, [](int x, int y) { return x < y ? x : y; });
+  last_req = block_fold<NT>(last_req, red, [](int x, int y) { return x > y ? x : y; });
+  if (first_bid == 0x7fffffff) { if (tid == 0) mode[a] = 0; __syncthreads(); return; }
+  if (last_req > first_bid) { if (tid == 0) mode[a] = -1; __syncthreads(); return; }   // sequential fallback
+  const int w = block_fold<NT>(best, red, [&](int x, int y) { return adx_better(qc, seg, x, y); });
+  int best2 = -1;
+  for (int k = tid; k < c; k += NT) if (k != w && (cls[k] & 15) == 1) best2 = adx_better(qc, seg, best2, k);
+  const int w2 = block_fold<NT>(best2, red, [&](int x, int y) { return adx_better(qc, seg, x, y); });
+  const int32_t* pi = tp.param_i + a * PHX_NPI;
+  for (int k = tid; k < c; k += NT) {
+    if ((cls[k] & 15) != 1) continue;
+    int n = 0;
+    if (k == first_bid) {                                      // Ads to the publisher :472-482
+      cls[k] |= 16;
+      const int sc = dev_send_check(sp, tp, a, pi[0], PHX_MSG_ADS);
+      if (sc) set_errkey(errkey, seq0 + c - 1, sc); else ++n;
+    }
+    const int sc = dev_send_check(sp, tp, a, qc[seg[k]].src, PHX_MSG_AUCTION_RESULT);   // :484-492
+    if (sc) set_errkey(errkey, seq0 + c - 1, sc); else ++n;
+    counts[k] = n;
+  }
+  if (tid == 0) mode[a] = w | ((w2 + 1) << 16);
+  __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void adx_coop_emit(const DevSpec& sp, const Topo& tp, int a, const DevMsg* qc, const int* seg, int c,
+                                              const int* cls, const int* offs, DevMsg* qn, int md) {
+  const int32_t* pi = tp.param_i + a * PHX_NPI;
+  const int w = md & 0xffff, w2 = (md >> 16) - 1;
+  for (int k = threadIdx.x; k < c; k += NT) {
+    const int cl = cls[k] & 15;
+    const DevMsg m = qc[seg[k]];
+    if (cl == 2) { adx_fanout(sp, tp, a, m, qn + offs[k], nullptr, 0); continue; }
+    if (cl != 1) continue;
+    const DevMsg win = qc[seg[w]];
+    const DevMsg costm = (pi[1] && w2 >= 0) ? qc[seg[w2]] : win;        // second / first price :498-516
+    int off = offs[k];
+    if ((cls[k] & 16) && dev_send_check(sp, tp, a, pi[0], PHX_MSG_ADS) == 0) {
+      DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)pi[0]; o.type = PHX_MSG_ADS; o.pad = win.pad & 0xff; o.p.i = win.src;
+      qn[off++] = o;
+    }
+    if (dev_send_check(sp, tp, a, m.src, PHX_MSG_AUCTION_RESULT) == 0) {
+      DevMsg o; o.src = (uint16_t)a; o.dst = m.src; o.type = PHX_MSG_AUCTION_RESULT;
+      if (m.src == win.src) { o.pad = costm.pad & 0x300; o.p.f = costm.p.f; }
+      else { o.pad = PHX_TAG_PYF << 8; o.p.f = 0.0; }
+      qn[off] = o;
+    }
+  }
+}
+
 template <int NT, bool LDSQ, bool TABLDS>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, const GenArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -571,10 +695,17 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     for (int i = tid; i < n; i += NT) order[goff[qc[i].dst] + slot[i]] = i;
     __syncthreads();
     GTICK(9);
+    const bool has_adx = sp.kind_count[PHX_KIND_ADEXCHANGE] > 0;
+    if (has_adx)                                               // exchanges: workgroup-wide batch reduction (phase A)
+      for (int a = 0; a < A; ++a)
+        if (tp.kind[a] == PHX_KIND_ADEXCHANGE && cnt[a] > 0)
+          adx_coop_count<NT>(sp, tp, a, live, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], resp + goff[a],
+                             wave_sums, first, &s_errkey, seq_base + goff[a]);
     // one lane per receiver: batch in send order, handled one message at a time (agents.py:96-120)
     for (int a = tid; a < A; a += NT) {
       const int c = cnt[a];
       if (c == 0) continue;
+      if (has_adx && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;    // done by phase A
       int* seg = order + goff[a];
       for (int x = 1; x < c; ++x) {                             // insertion sort by sequence number
         const int v = seg[x]; int y = x - 1;
@@ -617,9 +748,13 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     else {
       for (int P = tid; P < n; P += NT)
         if (resp[P].type != 0) qn[scanbuf[P]] = resp[P];
-      if (sp.kind_count[PHX_KIND_ADEXCHANGE] > 0)
+      if (has_adx)
+        for (int a = 0; a < A; ++a)
+          if (tp.kind[a] == PHX_KIND_ADEXCHANGE && cnt[a] > 0 && first[a] != -1)
+            adx_coop_emit<NT>(sp, tp, a, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], qn, first[a]);
+      if (has_adx)
         for (int a = tid; a < A; a += NT)
-          if (cnt[a] > 0 && tp.kind[a] == PHX_KIND_ADEXCHANGE)
+          if (cnt[a] > 0 && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] == -1)
             adexchange_batch(sp, tp, a, qc, order + goff[a], cnt[a],
                              [&](int k) { const DevMsg m = qc[order[goff[a] + k]];
                                           return live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst)); },

@@ -935,3 +935,41 @@ def test_host_clock_mirrors_after_rollout():
     out = env.step(torch.zeros(3, 2, device=env._device().device))
     assert list(env.current_step) == [4, 4, 4] and env.current_stage == ["RESTOCK"] * 3
     assert int(out.obs_valid.sum()) == 6            # shops observe on the SELL -> RESTOCK transition
+
+
+def test_digital_ads_env_python_surface():
+    """ph.DigitalAdsEnv built like digital_ads_market.py:525-596 and driven through the dict API: Dict
+    observations, None rewards before the first auction, attribute reflection for the metrics of
+    :603-713, and a device-policy rollout against the oracle."""
+    st = {f"ADV_{i + 1}": ph.AdvertiserAgent.Supertype(budget=b) for i, b in enumerate([1.5, 2.0, 0.75, 1.0])}
+    env = ph.DigitalAdsEnv(num_steps=8, num_agents_theme={"travel": 2, "tech": 1, "sport": 1}, agent_supertypes=st, seed=3)
+    assert env.agent_ids[:2] == ["ADX", "PUB"] and env.strategic_agent_ids == [f"ADV_{i}" for i in range(1, 5)]
+    obs, _ = env.reset()
+    assert obs == {} and env.current_stage == "publisher_step"           # the publisher is not strategic
+    step = env.step({})
+    assert env.current_stage == "advertiser_step" and set(step.observations) == set(env.strategic_agent_ids)
+    o1 = step.observations["ADV_1"]
+    assert set(o1) == {"type", "budget_left", "user_id"} and o1["type"]["budget"].dtype == np.float32
+    assert o1["budget_left"].dtype == np.float64 and float(o1["budget_left"][0]) == 1.0 and o1["user_id"] in (0, 1)
+    assert step.rewards == {aid: None for aid in env.strategic_agent_ids}   # fsm.py:234,378: nothing cached yet
+    user = env["ADV_1"]._current_user_id
+    assert user in (1, 2) and int(env["ADV_1"].total_requests[user]) == 1
+    step = env.step({aid: np.array([0.5], np.float32) for aid in env.strategic_agent_ids})
+    lefts = [env[aid].left for aid in env.strategic_agent_ids]
+    wins = [env[aid].step_wins for aid in env.strategic_agent_ids]
+    assert sum(wins) == 1 and wins[1] == 1                                # ADV_2 bids 0.5 * 2.0, the highest
+    assert lefts[1] == float(np.float32(2.0) - np.float32(1.0)) and lefts[0] == 1.5
+    assert env["ADV_2"].bid == 1.0 and step.observations == {}           # publishers act next: nobody observes
+    # device-policy rollout (launch loop: FSM env on the generic engine) against the oracle
+    env2 = ph.DigitalAdsEnv(num_steps=8, num_agents_theme={"travel": 2, "tech": 1, "sport": 1}, agent_supertypes=st,
+                            seed=3, batch_size=16, connection_rates=(1.0, 0.8, 0.9))
+    o, d = OracleEnv(env2.spec), _dev(env2.spec)
+    o.reset(); d.reset()
+    ro, rd = o.rollout(30), d.rollout(30)
+    for k in ("obs_valid", "reward_valid", "truncated", "terminated"):
+        np.testing.assert_array_equal(rd[k], ro[k], err_msg=k)
+    for k in ("obs", "actions", "rewards", "last_obs"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    assert ro["rewards"].sum() > 0 and (ro["obs_valid"] == 0).any()
+    for f in ("adv.total_clicks", "adv.total_wins", "adv.left_tag"):
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)

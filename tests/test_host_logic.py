@@ -372,3 +372,34 @@ def test_stochastic_network_host_semantics_and_spec_tables():
             h = 2 * (i & 1)
             u = (float(int(w[h]) >> 5) * 67108864.0 + float(int(w[h + 1]) >> 6)) / 9007199254740992.0
             assert on[b, i] == (u < r)
+
+
+def test_ads_market_spec_compiles_like_the_example():
+    """ph.DigitalAdsEnv (digital_ads_market.py:525-596) -> flat spec: agent order, base connections,
+    exchange fan-out order, click table, budget kinds (NEP 50 tag), exo columns, queue capacity."""
+    from phantom_amd import _abi
+    clipped = ph.UniformFloatSampler(5.0, 15.001, clip_low=5.0, clip_high=15.0)
+    plain = ph.UniformFloatSampler(1.0, 2.0)
+    st = {"ADV_1": ph.AdvertiserAgent.Supertype(budget=clipped), "ADV_2": ph.AdvertiserAgent.Supertype(budget=plain),
+          "ADV_3": ph.AdvertiserAgent.Supertype(budget=2.5)}
+    env = ph.DigitalAdsEnv(num_steps=20, num_agents_theme={"travel": 1, "tech": 2}, agent_supertypes=st)
+    spec = env.spec
+    assert spec.agent_ids == ["ADX", "PUB", "ADV_1", "ADV_2", "ADV_3"]
+    assert spec.kind.tolist() == [_abi.KIND_ADEXCHANGE, _abi.KIND_PUBLISHER] + [_abi.KIND_ADVERTISER] * 3
+    assert spec.round_limit == 5 and spec.flags & _abi.F_IGNORE_CONN_ERRORS and spec.env_type == _abi.ENV_FSM
+    assert spec.n_conn == 1 + 3 + 3 and (spec.conn_rate == 1.0).all()
+    assert spec.col[spec.row_ptr[0]:spec.row_ptr[1]].tolist() == [1, 2, 3, 4]         # ADX: PUB, then advertiser_ids
+    assert spec.param_i[2:, 1].tolist() == [1, 3, 3] and spec.param_i[2:, 2].tolist() == [1, 0, 0]
+    assert spec.type_src[2:].tolist() == [0, 1, _abi.TYPE_CONST] and spec.param_f[4, 0] == 2.5
+    assert spec.param_f[1].tolist() == [0.0, 1.0, 0.2, 0.5, 1.0, 0.0, 0.7, 0.5]       # :531-534
+    assert spec.n_exo == 2 and spec.exo_slot().tolist() == [-1, 0, -1, -1, -1]
+    assert spec.queue_cap >= 3 + 2 and spec.n_strategic == 3
+    with pytest.raises(ValueError):
+        ph.AdExchangeAgent("X", "PUB", strategy="third")
+    with pytest.raises(ValueError):          # advertiser_ids must follow the exchange's connection order
+        net = ph.StochasticNetwork([ph.AdExchangeAgent("ADX", "PUB", ["A2", "A1"]), ph.PublisherAgent("PUB", "ADX"),
+                                    ph.AdvertiserAgent("A1", "ADX", "tech"), ph.AdvertiserAgent("A2", "ADX", "tech")])
+        net.add_connections_between(["ADX"], ["PUB", "A1", "A2"])
+        ph.compile_spec(net, num_steps=1)
+    with pytest.raises(ValueError):
+        ph.AdvertiserAgent("A", "ADX", theme="generic").device_params(lambda x: 0)    # not a key of the click table

@@ -93,6 +93,38 @@ def main():
                     trajectory_GBps=nbytes / T / (us * 1e-6) / 1e9))
     print(json.dumps(out[-1]), flush=True)
 
+    # the digital-ads market at the example's size (digital_ads_market.py:715-717: 40 + 40 + 40
+    # advertisers, clipped-sampler budgets of the training configuration): generic engine, the exchange's
+    # auction as an inbox reduction; per-step launches and the launch-loop rollout
+    import phantom_amd as ph
+    del traj, d, env
+    B, T = (256 if quick else 4096), 40
+    st = {}
+    for i in range(120):
+        lo = (5.0, 7.0, 10.0)[i // 40]
+        st[f"ADV_{i + 1}"] = ph.AdvertiserAgent.Supertype(
+            budget=ph.UniformFloatSampler(lo, lo + 10.001, clip_low=lo, clip_high=lo + 10.0))
+    env = ph.DigitalAdsEnv(num_steps=20, num_agents_theme={"travel": 40, "tech": 40, "sport": 40},
+                           agent_supertypes=st, batch_size=B, seed=1)
+    d = env._device(); env.reset()
+    us, wall = time_steps(d, lambda i: torch.rand(B, 120, device=dev0), n=40, warm=4)
+    out.append(dict(config=f"ADS 122 agents B={B}", engine="generic", agents=122, batch=B, us_per_step_events=us,
+                    us_per_step_wall=wall, agent_steps_per_s=122 * B / (us * 1e-6)))
+    print(json.dumps(out[-1]), flush=True)
+    env.reset()
+    traj = d.rollout(T)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        d.rollout(T, out=traj)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / (4 * T) * 1e3
+    out.append(dict(config=f"ADS 122 agents B={B} rollout T={T}", engine="generic launch loop", agents=122, batch=B,
+                    us_per_step_events=us, us_per_step_wall=us, agent_steps_per_s=122 * B / (us * 1e-6),
+                    clicks_per_env_step=float(traj.rewards.sum().item()) / (T * B)))
+    print(json.dumps(out[-1]), flush=True)
+
 
 if __name__ == "__main__":
     main()
