@@ -156,7 +156,8 @@ typedef struct phx_spec {
   const int32_t* param_i;       /* [A][PHX_NPI]                                              */
   const double*  param_f;       /* [A][PHX_NPF]                                              */
   const int32_t* row_ptr;       /* [A+1] CSR of directed edges u->v, neighbours in           */
-  const int32_t* col;           /* [nnz]  nx adjacency (insertion) order network.py:122-123  */
+  const int32_t* col;           /* [nnz]  nx adjacency (insertion) order network.py:122-123;
+                                   connections are undirected: u->v and v->u both present   */
   /* FSM (fsm.py:26-63): ordered acting lists, rewarded masks, handler-less next stage      */
   int32_t n_stages;
   int32_t initial_stage;

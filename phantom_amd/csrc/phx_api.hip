@@ -8,12 +8,14 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "phx_dev.h"
 
 
 size_t phx_generic_queue_bytes(int A, int Q, int scan_cap);
+size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
@@ -138,6 +140,20 @@ static int derive(const phx_spec* sp, Derived& d) {
     if (k == PHX_KIND_ADVERTISER && d.type_src[a] == PHX_TYPE_NONE) return fail(PHX_EINVAL, "agent %d: AdvertiserAgent needs a budget (type_src)", a);
     if (k == PHX_KIND_CUSTOMER && sp->kind[pi[0]] != PHX_KIND_SHOP)
       return fail(PHX_EINVAL, "agent %d: CustomerAgent.shop_id is not a ShopAgent", a);
+  }
+  {  // connections are undirected: every CSR entry u->v has its mirror v->u on the same base connection
+    std::unordered_map<uint64_t, int32_t> ent;
+    ent.reserve((size_t)d.nnz * 2);
+    for (int u = 0; u < A; ++u)
+      for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k)
+        if (!ent.emplace(((uint64_t)u << 32) | (uint32_t)sp->col[k], sp->n_conn > 0 ? sp->col_conn[k] : 0).second)
+          return fail(PHX_EINVAL, "agent %d: duplicate edge to %d", u, sp->col[k]);
+    for (int u = 0; u < A; ++u)
+      for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k) {
+        auto it = ent.find(((uint64_t)sp->col[k] << 32) | (uint32_t)u);
+        if (it == ent.end() || it->second != (sp->n_conn > 0 ? sp->col_conn[k] : 0))
+          return fail(PHX_EINVAL, "edge %d->%d has no mirror edge (connections are undirected, network.py:122-123)", u, sp->col[k]);
+      }
   }
   d.buyer_nnz = d.buyer_dmax * d.kind_count[PHX_KIND_BUYER];   // slot-major (ELL) price table per env
   // acting lists + masks
@@ -449,6 +465,27 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(stk_rec, der.stk_rec.data(), der.stk_rec.size()); UP(stk_flags, der.stk_flags.data(), der.stk_flags.size());
   UP(sampler_kind, spec->sampler_kind, spec->n_samplers); UP(sampler_param, spec->sampler_param, 4 * spec->n_samplers);
   UP(type_src, der.type_src.data(), A);
+  {                                                            // phx_generic_step_kernel's LDS table layout, packed
+    std::vector<char> blob(phx_generic_table_bytes(A, der.nnz), 0);
+    char* tb = blob.data();
+    auto put = [&](const void* src, size_t bytes) { if (bytes) memcpy(tb, src, bytes); tb += (bytes + 15) & ~(size_t)15; };
+    put(spec->row_ptr, (size_t)(A + 1) * 4); put(spec->col, (size_t)der.nnz * 4); put(spec->param_i, (size_t)A * PHX_NPI * 4);
+    put(der.strat_rank.data(), (size_t)A * 4); put(der.kind_rank.data(), (size_t)A * 4); put(der.exo_rank.data(), (size_t)A * 4);
+    put(spec->kind, (size_t)A);
+    d.tab_bytes = (int32_t)blob.size();
+    UP(tab_blob, blob.data(), blob.size());
+    std::vector<int32_t> adx;
+    for (int a = 0; a < A; ++a) if (spec->kind[a] == PHX_KIND_ADEXCHANGE) adx.push_back(a);
+    d.n_adx = (int32_t)adx.size();
+    UP(adx_idx, adx.data(), adx.size());
+    std::vector<int32_t> nptr = {0}, ne;
+    for (int a : adx) {
+      for (int k = spec->row_ptr[a]; k < spec->row_ptr[a + 1]; ++k) if (spec->kind[spec->col[k]] == PHX_KIND_ADVERTISER) ne.push_back(k);
+      nptr.push_back((int32_t)ne.size());
+    }
+    UP(adx_nbr_ptr, nptr.data(), nptr.size()); UP(adx_nbr_e, ne.data(), ne.size());
+    d.dynamic_graph = der.dynamic_graph ? 1 : 0;
+  }
   UP(shop_type_src, der.shop_type_src.data(), der.shop_type_src.size());
   UP(shop_type_prm, der.shop_type_prm.data(), der.shop_type_prm.size());
   d.n_samplers = spec->n_samplers; d.any_typed = der.any_typed ? 1 : 0; d.device_sampling = der.device_sampling ? 1 : 0;

@@ -101,6 +101,14 @@ struct DevSpec {
   const int32_t* type_src;       // [A] sampler column, PHX_TYPE_CONST or PHX_TYPE_NONE
   const int32_t* shop_type_src;  // [nS] the same per shop (kind-rank order)
   const double*  shop_type_prm;  // [nS][2] constant weight, obs normaliser (param_f of the shop)
+  // the generic engine's LDS-staged topology tables, packed in the kernel's LDS layout (one flat copy)
+  const char* tab_blob;
+  int32_t tab_bytes;
+  int32_t n_adx;                 // AdExchangeAgents (their batches are reduced by the whole workgroup)
+  const int32_t* adx_idx;        // [n_adx] agent indices
+  const int32_t* adx_nbr_ptr;    // [n_adx+1] the CSR entries of each exchange's AdvertiserAgent neighbours
+  const int32_t* adx_nbr_e;      //           (= self.advertiser_ids, in order)
+  int32_t dynamic_graph;         // StochasticNetwork with some rate < 1
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env
@@ -168,6 +176,9 @@ __device__ __forceinline__ int dev_nbr_slot(const DevSpec& sp, const Topo& tp, i
   return -1;
 }
 __device__ __forceinline__ bool dev_has_edge(const DevSpec& sp, const Topo& tp, int u, int v) {   // network.py:224-231
+  // connections are undirected (add_connection adds u->v and v->u with one rate, network.py:122-123,
+  // 383-391; phx_create checks the CSR is symmetric): search the shorter of the two adjacency rows
+  if (tp.row_ptr[v + 1] - tp.row_ptr[v] < tp.row_ptr[u + 1] - tp.row_ptr[u]) { const int w = u; u = v; v = w; }
   const int lo = tp.row_ptr[u], hi = tp.row_ptr[u + 1];
   for (int k = lo; k < hi; ++k)
     if (tp.col[k] == v && edge_on(tp, k)) return true;

@@ -426,20 +426,25 @@ __device__ __forceinline__ int block_fold(int v, int* red, F combine) {
 __device__ __forceinline__ bool adx_delivered(const DevSpec& sp, const Topo& tp, const uint8_t* live, int a, const DevMsg& m) {
   return live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst));
 }
-__device__ __forceinline__ int adx_fanout(const DevSpec& sp, const Topo& tp, int a, const DevMsg& m, DevMsg* out, int* errkey, int key) {
-  int n = 0;                                                   // forward to self.advertiser_ids :427
-  for (int e = tp.row_ptr[a]; e < tp.row_ptr[a + 1]; ++e) {
-    const int dst = tp.col[e];
-    if (tp.kind[dst] != PHX_KIND_ADVERTISER) continue;
+// every send of the fan-out passes Network.send's checks (no per-entry work, parallel emission)
+__device__ __forceinline__ bool adx_fanout_all(const DevSpec& sp) {
+  return (sp.flags & PHX_F_IGNORE_CONN_ERRORS) || !sp.dynamic_graph;
+}
+__device__ __forceinline__ int adx_fanout(const DevSpec& sp, const Topo& tp, int x, int a, const DevMsg& m, DevMsg* out, int* errkey, int key) {
+  const int lo = sp.adx_nbr_ptr[x], hi = sp.adx_nbr_ptr[x + 1];
+  if (!out && adx_fanout_all(sp)) return hi - lo;              // forward to self.advertiser_ids :427
+  int n = 0;
+  for (int j = lo; j < hi; ++j) {
+    const int e = sp.adx_nbr_e[j];
     if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !edge_on(tp, e)) { if (!out) set_errkey(errkey, key, PHX_ERR_NETWORK); continue; }
-    if (out) { DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)dst; o.type = PHX_MSG_IMPRESSION_REQ; o.pad = 0; o.p.i = m.p.i; out[n] = o; }
+    if (out) { DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)tp.col[e]; o.type = PHX_MSG_IMPRESSION_REQ; o.pad = 0; o.p.i = m.p.i; out[n] = o; }
     ++n;
   }
   return n;
 }
 
 template <int NT>
-__device__ __forceinline__ void adx_coop_count(const DevSpec& sp, const Topo& tp, int a, const uint8_t* live, const DevMsg* qc,
+__device__ __forceinline__ void adx_coop_count(const DevSpec& sp, const Topo& tp, int x, int a, const uint8_t* live, const DevMsg* qc,
                                                int* seg, int c, int* cls, int* counts, DevMsg* resp, int* red, int* mode,
                                                int* errkey, int seq0) {
   const int tid = threadIdx.x;
@@ -459,7 +464,7 @@ __device__ __forceinline__ void adx_coop_count(const DevSpec& sp, const Topo& tp
     int cl = 0, n = 0;
     if (adx_delivered(sp, tp, live, a, m)) {
       if (m.type == PHX_MSG_BID) { cl = 1; first_bid = min(first_bid, k); best = adx_better(qc, seg, best, k); }
-      else if (m.type == PHX_MSG_IMPRESSION_REQ) { cl = 2; last_req = k; n = adx_fanout(sp, tp, a, m, nullptr, errkey, seq0 + k); }
+      else if (m.type == PHX_MSG_IMPRESSION_REQ) { cl = 2; last_req = k; n = adx_fanout(sp, tp, x, a, m, nullptr, errkey, seq0 + k); }
       else { cl = 3; set_errkey(errkey, seq0 + k, PHX_ERR_UNKNOWN_MSG); }          // agents.py:140-143
     }
     cls[k] = cl; counts[k] = n; resp[k].type = 0;
@@ -490,14 +495,14 @@ __device__ __forceinline__ void adx_coop_count(const DevSpec& sp, const Topo& tp
 }
 
 template <int NT>
-__device__ __forceinline__ void adx_coop_emit(const DevSpec& sp, const Topo& tp, int a, const DevMsg* qc, const int* seg, int c,
+__device__ __forceinline__ void adx_coop_emit(const DevSpec& sp, const Topo& tp, int x, int a, const DevMsg* qc, const int* seg, int c,
                                               const int* cls, const int* offs, DevMsg* qn, int md) {
   const int32_t* pi = tp.param_i + a * PHX_NPI;
   const int w = md & 0xffff, w2 = (md >> 16) - 1;
   for (int k = threadIdx.x; k < c; k += NT) {
     const int cl = cls[k] & 15;
     const DevMsg m = qc[seg[k]];
-    if (cl == 2) { adx_fanout(sp, tp, a, m, qn + offs[k], nullptr, 0); continue; }
+    if (cl == 2) { if (!adx_fanout_all(sp)) adx_fanout(sp, tp, x, a, m, qn + offs[k], nullptr, 0); continue; }
     if (cl != 1) continue;
     const DevMsg win = qc[seg[w]];
     const DevMsg costm = (pi[1] && w2 >= 0) ? qc[seg[w2]] : win;        // second / first price :498-516
@@ -512,6 +517,29 @@ __device__ __forceinline__ void adx_coop_emit(const DevSpec& sp, const Topo& tp,
       else { o.pad = PHX_TAG_PYF << 8; o.p.f = 0.0; }
       qn[off] = o;
     }
+  }
+  if (adx_fanout_all(sp) && (md >> 16) == 0 && (md & 0xffff) == 0) {
+    // no auction ran (requests only -- mode 0): the fan-outs are written by all threads, entry-parallel.
+    // (mode 0 is also "one bid at position 0", which has no requests after it: the loop finds none)
+    const int lo = sp.adx_nbr_ptr[x], nn = sp.adx_nbr_ptr[x + 1] - lo;
+    for (int k = 0; k < c; ++k) {
+      if ((cls[k] & 15) != 2) continue;
+      const DevMsg m = qc[seg[k]];
+      for (int j = threadIdx.x; j < nn; j += NT) {
+        DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)tp.col[sp.adx_nbr_e[lo + j]]; o.type = PHX_MSG_IMPRESSION_REQ; o.pad = 0; o.p.i = m.p.i;
+        qn[offs[k] + j] = o;
+      }
+    }
+  } else if (adx_fanout_all(sp)) {                             // requests ahead of an auction: each by its own thread
+    for (int k = threadIdx.x; k < c; k += NT)
+      if ((cls[k] & 15) == 2) {
+        const DevMsg m = qc[seg[k]];
+        const int lo = sp.adx_nbr_ptr[x], nn = sp.adx_nbr_ptr[x + 1] - lo;
+        for (int j = 0; j < nn; ++j) {
+          DevMsg o; o.src = (uint16_t)a; o.dst = (uint16_t)tp.col[sp.adx_nbr_e[lo + j]]; o.type = PHX_MSG_IMPRESSION_REQ; o.pad = 0; o.p.i = m.p.i;
+          qn[offs[k] + j] = o;
+        }
+      }
   }
 }
 
@@ -555,11 +583,10 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     int32_t* t_kr = (int32_t*)tb;             tb += (A * 4 + 15) & ~15;
     int32_t* t_xr = (int32_t*)tb;             tb += (A * 4 + 15) & ~15;
     uint8_t* t_kind = (uint8_t*)tb;
-    for (int k = threadIdx.x; k <= A; k += NT) t_row[k] = sp.row_ptr[k];
-    for (int k = threadIdx.x; k < nnz; k += NT) t_col[k] = sp.col[k];
-    for (int k = threadIdx.x; k < A * PHX_NPI; k += NT) t_pi[k] = sp.param_i[k];
-    for (int k = threadIdx.x; k < A; k += NT) {
-      t_sr[k] = sp.strat_rank[k]; t_kr[k] = sp.kind_rank[k]; t_xr[k] = sp.exo_rank[k]; t_kind[k] = sp.kind[k];
+    {                                                          // one flat 16-byte copy of the host-packed blob
+      const uint4* src = (const uint4*)sp.tab_blob;
+      uint4* dst = (uint4*)(smem + g.tab_off);
+      for (int k = threadIdx.x; k < sp.tab_bytes / 16; k += NT) dst[k] = src[k];
     }
     tp.row_ptr = t_row; tp.col = t_col; tp.param_i = t_pi; tp.strat_rank = t_sr; tp.kind_rank = t_kr;
     tp.exo_rank = t_xr; tp.kind = t_kind;
@@ -695,12 +722,13 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     for (int i = tid; i < n; i += NT) order[goff[qc[i].dst] + slot[i]] = i;
     __syncthreads();
     GTICK(9);
-    const bool has_adx = sp.kind_count[PHX_KIND_ADEXCHANGE] > 0;
-    if (has_adx)                                               // exchanges: workgroup-wide batch reduction (phase A)
-      for (int a = 0; a < A; ++a)
-        if (tp.kind[a] == PHX_KIND_ADEXCHANGE && cnt[a] > 0)
-          adx_coop_count<NT>(sp, tp, a, live, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], resp + goff[a],
+    const bool has_adx = sp.n_adx > 0;
+    for (int x = 0; x < sp.n_adx; ++x) {                       // exchanges: workgroup-wide batch reduction (phase A)
+      const int a = sp.adx_idx[x];
+      if (cnt[a] > 0)
+          adx_coop_count<NT>(sp, tp, x, a, live, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], resp + goff[a],
                              wave_sums, first, &s_errkey, seq_base + goff[a]);
+    }
     // one lane per receiver: batch in send order, handled one message at a time (agents.py:96-120)
     for (int a = tid; a < A; a += NT) {
       const int c = cnt[a];
@@ -748,10 +776,11 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     else {
       for (int P = tid; P < n; P += NT)
         if (resp[P].type != 0) qn[scanbuf[P]] = resp[P];
-      if (has_adx)
-        for (int a = 0; a < A; ++a)
-          if (tp.kind[a] == PHX_KIND_ADEXCHANGE && cnt[a] > 0 && first[a] != -1)
-            adx_coop_emit<NT>(sp, tp, a, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], qn, first[a]);
+      for (int x = 0; x < sp.n_adx; ++x) {
+        const int a = sp.adx_idx[x];
+        if (cnt[a] > 0 && first[a] != -1)
+          adx_coop_emit<NT>(sp, tp, x, a, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], qn, first[a]);
+      }
       if (has_adx)
         for (int a = tid; a < A; a += NT)
           if (cnt[a] > 0 && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] == -1)
