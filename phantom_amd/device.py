@@ -352,4 +352,6 @@ class DeviceEnv:
         if code == _abi.ERR_ROUND_LIMIT:
             raise RuntimeError("message(s) still in queue after BatchResolver round limit "
                                f"reached ({where}).")
+        if code == _abi.ERR_CONTEXT:                       # ctx[agent_id] of a non-neighbour, context.py:36-37
+            raise KeyError(f"agent view / table entry not present in the handler's context ({where}).")
         raise DeviceError(f"per-round message capacity exceeded ({where}); raise queue capacity")
