@@ -28,6 +28,8 @@ hipError_t phx_launch_gen_collect(const DevSpec& sp, int t, const phx_step_io& s
 hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st);
 size_t phx_stk_rollout_lds(const DevSpec& sp);
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+hipError_t phx_launch_ads_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
+hipError_t phx_launch_ads_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -56,7 +58,8 @@ struct Derived {
   std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
-  bool sc_static = false, stk_static = false;
+  bool sc_static = false, stk_static = false, ads_static = false;
+  int ads_pub = -1, ads_adx = -1, ads_pub_stage = 0;
   bool dynamic_graph = false;      // StochasticNetwork with some rate < 1: edges differ per env
   std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
   std::vector<uint8_t> shop_cust_act;
@@ -250,6 +253,36 @@ static int derive(const phx_spec* sp, Derived& d) {
                                                    (d.rew_mask[(size_t)l * A + a] ? 4 : 0));
     }
   }
+  // ---- static digital-ads schedule? (phx_ads_fused.hip) -------------------------------------------------
+  // the shipped env (digital_ads_market.py:525-596): one exchange, one publisher, N advertisers, every
+  // connection present, stage P {acting = [publisher]} <-> stage A {acting = the advertisers in agent order}
+  {
+    const int N = d.kind_count[PHX_KIND_ADVERTISER];
+    bool ads = sp->env_type == PHX_ENV_FSM && sp->n_stages == 2 && N >= 1 && N <= 1024 && d.kind_count[PHX_KIND_PUBLISHER] == 1 &&
+               d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
+               (sp->round_limit < 0 || sp->round_limit >= 3) && !d.dynamic_graph && d.D == 3 &&
+               sp->stage_next[0] == 1 && sp->stage_next[1] == 0;
+    if (ads) {
+      for (int a = 0; a < A; ++a) { if (sp->kind[a] == PHX_KIND_PUBLISHER) d.ads_pub = a; if (sp->kind[a] == PHX_KIND_ADEXCHANGE) d.ads_adx = a; }
+      const int pub = d.ads_pub, adx = d.ads_adx;
+      ads = sp->param_i[pub * PHX_NPI] == adx && sp->param_i[adx * PHX_NPI] == pub && sp->param_i[pub * PHX_NPI + 1] >= 1 &&
+            edge(pub, adx) && sp->row_ptr[adx + 1] - sp->row_ptr[adx] == N + 1 && sp->row_ptr[pub + 1] - sp->row_ptr[pub] == N + 1;
+      for (int a = 0; a < A && ads; ++a)
+        if (sp->kind[a] == PHX_KIND_ADVERTISER)
+          ads = sp->param_i[a * PHX_NPI] == adx && edge(a, adx) && edge(a, pub) && sp->row_ptr[a + 1] - sp->row_ptr[a] == 2;
+      int ps = -1;                                            // which stage is the publisher's
+      for (int l = 0; l < 2 && ads; ++l)
+        if (d.act_ptr[l + 1] - d.act_ptr[l] == 1 && d.act_idx[d.act_ptr[l]] == pub) ps = l;
+      ads = ads && ps >= 0;
+      if (ads) {
+        const int l = 1 - ps;
+        ads = d.act_ptr[l + 1] - d.act_ptr[l] == N;
+        for (int k = 0; k < N && ads; ++k) ads = d.act_idx[d.act_ptr[l] + k] == d.strat_idx[k];
+        d.ads_pub_stage = ps;
+      }
+    }
+    d.ads_static = ads;
+  }
   if (d.kind_count[PHX_KIND_SHOP] > 0) {
     const int nS = d.kind_count[PHX_KIND_SHOP];
     d.shop_agent.assign(nS, 0); d.shop_norm.assign(nS, 1);
@@ -370,7 +403,7 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     out.push_back(w);
   }
   // step-shaped scratch of the launch-loop rollout (envs without a fused rollout kernel)
-  if (!d.sc_static && !d.stk_static) {
+  if (!d.sc_static && !d.stk_static) {       // (the fused ads kernels keep it: injected sends fall back to the loop)
     const int64_t n = gen_rollout_scratch_bytes(B, S, d.D);
     FieldDef r = {F_ROLLOUT_SCRATCH, "rollout.scratch", 2, 0, 1, n, 1, off};
     off += n;
@@ -386,7 +419,7 @@ struct phx_env {
   std::vector<FieldDef> fields;
   std::vector<void*> dev_allocs;
   int device = 0;
-  bool use_fused = false, use_stk = false, lds_ok = true;
+  bool use_fused = false, use_stk = false, use_ads = false, lds_ok = true;
   bool prices_compressed = false;   // buyer.prices is represented by seller.posted (fused Stackelberg kernel)
   DevMsg* inject_dev = nullptr;
   DevMsg inject_host[PHX_MAX_INJECT];
@@ -497,6 +530,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   e->lds_ok = ws_stride == 0;
   e->use_fused = der.sc_static;
   e->use_stk = der.stk_static;
+  e->use_ads = der.ads_static;
+  d.ads_pub = der.ads_pub; d.ads_adx = der.ads_adx; d.ads_pub_stage = der.ads_pub_stage;
   e->prices_compressed = der.stk_static;
   he = hipMalloc((void**)&e->inject_dev, sizeof(DevMsg) * PHX_MAX_INJECT);
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMalloc: %s", hipGetErrorString(he)); }
@@ -534,7 +569,7 @@ int phx_field_info(const phx_env* e, int index, phx_field* out) {
   return PHX_OK;
 }
 
-int phx_uses_fused(const phx_env* e) { return e && (e->use_fused || e->use_stk) ? 1 : 0; }
+int phx_uses_fused(const phx_env* e) { return e && (e->use_fused || e->use_stk || e->use_ads) ? 1 : 0; }
 
 
 // the handle's device becomes the calling thread's current device (a no-op when it already is)
@@ -591,6 +626,10 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   }
   if (e->use_stk && e->n_inject == 0) {
     HIPCHK(phx_launch_stk_step(e->d, *io, st));
+    return PHX_OK;
+  }
+  if (e->use_ads && e->n_inject == 0 && !io->msg_log && !io->msg_count) {
+    HIPCHK(phx_launch_ads_step(e->d, *io, st));
     return PHX_OK;
   }
   if (e->prices_compressed) {       // host-injected messages can address a single price slot: materialise
@@ -654,6 +693,11 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   if (e->use_fused && e->d.max_cust >= 65535) return fail(PHX_EUNSUPPORTED, "phx_rollout: at most 65534 customers per shop");
   HIPCHK(use_device(e));
+  if (e->use_ads && e->n_inject == 0) {
+    if (!io->obs_valid || !io->reward_valid) return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");
+    HIPCHK(phx_launch_ads_rollout(e->d, *io, (hipStream_t)stream));
+    return PHX_OK;
+  }
   if (!e->use_fused && !(e->use_stk && e->prices_compressed)) {
     // Launch loop for every other env (any topology of the device kinds, tracking off): per step a
     // policy kernel, the generic engine, a collect kernel and the masked auto-reset, all stream

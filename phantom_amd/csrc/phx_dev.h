@@ -109,6 +109,7 @@ struct DevSpec {
   const int32_t* adx_nbr_ptr;    // [n_adx+1] the CSR entries of each exchange's AdvertiserAgent neighbours
   const int32_t* adx_nbr_e;      //           (= self.advertiser_ids, in order)
   int32_t dynamic_graph;         // StochasticNetwork with some rate < 1
+  int32_t ads_pub, ads_adx, ads_pub_stage;   // static digital-ads schedule (phx_ads_fused.hip)
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env

@@ -215,7 +215,8 @@ def ads_case(rng, case):
     """digital-ads market on random topologies: several publisher / exchange pairs, advertisers spread
     over the exchanges, random connectivity rates, first / second price, constant and sampled budgets,
     plain env (requests and bids meet in one batch) or the two-stage FSM, exogenous or device draws."""
-    P = int(rng.randint(1, 3)); N = int(rng.randint(1, 14)); B = int(rng.randint(1, 40))
+    shipped = rng.rand() < 0.45        # the example's layout: static schedule -> phx_ads_fused.hip (unless forced generic)
+    P = 1 if shipped else int(rng.randint(1, 3)); N = int(rng.randint(1, 150 if (shipped and rng.rand() < 0.2) else 14)); B = int(rng.randint(1, 40))
     num_steps = int(rng.randint(2, 14)); T = int(rng.randint(4, 30))
     themes = [ph.ads_market.THEMES[i] for i in rng.randint(0, 4, N)]
     adx_of = rng.randint(0, P, N)
@@ -226,25 +227,26 @@ def ads_case(rng, case):
     adxs = [ph.AdExchangeAgent(f"ADX{p}", publisher_id=f"PUB{p}", advertiser_ids=[a.id for i, a in enumerate(advs) if adx_of[i] == p],
                                strategy=("second" if rng.rand() < 0.5 else "first")) for p in range(P)]
     agents = adxs + pubs + advs
-    agents = [agents[i] for i in rng.permutation(len(agents))]
+    if not shipped:
+        agents = [agents[i] for i in rng.permutation(len(agents))]
     rl = None if rng.rand() < 0.3 else int(rng.randint(2, 7))
     ignore = bool(rng.rand() < 0.7)
-    net = ph.StochasticNetwork(agents, ph.BatchResolver(round_limit=rl, enable_tracking=bool(rng.rand() < 0.4)),
+    net = ph.StochasticNetwork(agents, ph.BatchResolver(round_limit=rl, enable_tracking=bool(not shipped and rng.rand() < 0.4)),
                                ignore_connection_errors=ignore, enforce_msg_payload_checks=bool(rng.rand() < 0.8))
-    rate = lambda: float(rng.choice([1.0, 1.0, 0.9, 0.6])) if ignore or rng.rand() < 0.5 else 1.0
+    rate = lambda: 1.0 if shipped else (float(rng.choice([1.0, 1.0, 0.9, 0.6])) if ignore or rng.rand() < 0.5 else 1.0)
     for p in range(P):
         net.add_connection(f"ADX{p}", f"PUB{p}", rate())
         for a in adxs[p].advertiser_ids: net.add_connection(f"ADX{p}", a, rate())
         for a in adxs[p].advertiser_ids:
-            if rng.rand() < 0.9: net.add_connection(f"PUB{p}", a, rate())
+            if shipped or rng.rand() < 0.9: net.add_connection(f"PUB{p}", a, rate())
     sm = [ph.UniformFloatSampler(0.5, 2.0), ph.UniformFloatSampler(0.4, 1.6, 0.5, 1.5)]
     sup = {a.id: ph.AdvertiserAgent.Supertype(budget=(sm[int(rng.randint(2))] if rng.rand() < 0.5 else float(rng.choice([0.5, 1.0, 1.7, 3.0]))))
            for a in advs}
     kw = dict(batch_size=B, seed=int(rng.randint(1 << 30)), env_offset=int(rng.randint(1 << 20)), exogenous="device",
-              agent_supertypes=sup)
-    fsm = rng.rand() < 0.6
+              agent_supertypes=sup, force_generic=bool(shipped and rng.rand() < 0.25))
+    fsm = shipped or rng.rand() < 0.6
     if fsm:
-        env = ph.FiniteStateMachineEnv(num_steps, net, initial_stage="pub", stages=[
+        env = ph.FiniteStateMachineEnv(num_steps, net, initial_stage=("adv" if rng.rand() < 0.15 else "pub"), stages=[
             ph.FSMStage("pub", next_stages=["adv"], acting_agents=[p.id for p in pubs], rewarded_agents=[p.id for p in pubs]),
             ph.FSMStage("adv", next_stages=["pub"], acting_agents=[a.id for a in advs],
                         rewarded_agents=(None if rng.rand() < 0.2 else [a.id for a in advs]))], **kw)
@@ -304,7 +306,7 @@ def ads_case(rng, case):
             assert np.array_equal(rd[k][:, ok], ro[k][:, ok]), (case, "rollout", k)
         if ok.all():
             state("rollout")
-    return f"ads N={N} P={P} B={B} fsm={fsm} rl={rl} ignore={ignore} flags={spec.flags}"
+    return f"ads N={N} P={P} B={B} fsm={fsm} rl={rl} ignore={ignore} flags={spec.flags} fused={d.dev.uses_fused}"
 
 
 def run_case(case):

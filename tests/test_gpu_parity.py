@@ -68,6 +68,16 @@ def test_generic_engine_ads_market_matches_reference(name):
     replay_ads(golden(name), _dev)
 
 
+@pytest.mark.parametrize("name", ["ads_first", "ads_second", "ads_sampled"])
+def test_fused_ads_kernel_matches_reference(name):
+    """the same goldens through phx_ads_fused.hip (static schedule: no tracking, every rate 1)."""
+    def make(spec):
+        r = _dev(spec)
+        assert r.dev.uses_fused
+        return r
+    replay_ads(golden(name), make, tracking=False)
+
+
 @pytest.mark.parametrize("name", ["stk_small", "stk_full"])
 def test_fused_market_kernel_matches_reference(name):
     def make(spec):
