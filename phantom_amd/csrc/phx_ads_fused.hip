@@ -112,6 +112,7 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
   }
   const int btag = strong ? PHX_TAG_F64 : PHX_TAG_PYF;
   const int T = ROLLOUT ? args.rio.T : 1;
+  RngQuadCache rq; rq.q = 0xffffffffu;
   const int64_t total = (int64_t)sp.B * N;
 
   for (int t = 0; t < T; ++t) {
@@ -122,7 +123,11 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     if (mine) {
       if (ROLLOUT) {
         if (args.rio.actions) action = args.rio.actions[(int64_t)t * total + g];
-        else { uint32_t j; rng_group_y(sp.seed, genv, tick, r, 0, 0, &j); action = (float)j * (1.0f / 274877.0f); }
+        else {                                                 // one Philox block serves four ticks of the agent
+          uint32_t j; rng_quad_block(rq, sp.seed, genv, tick, r);
+          rng_orders_from_block(rq.w, sp.seed, genv, tick, r, 0, nullptr, &j);
+          action = (float)j * (1.0f / 274877.0f);
+        }
         has = true;
       } else {
         has = args.sio.actions && (!args.sio.action_valid || args.sio.action_valid[g]);     // aid in actions, env.py:330
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
       const AdsBid w = ads_fold<NT>(cand, red_v, red_i);
       if (w.r >= 0) {
         AdsBid c2 = cand; if (cand.r == w.r) c2.r = -1;
-        const AdsBid w2 = ads_fold<NT>(c2, red_v, red_i);
+        AdsBid w2; w2.r = -1; w2.v = 0; w2.tag = 0;
+        if (second) w2 = ads_fold<NT>(c2, red_v, red_i);          // sorted_bids[1], only the second-price rule reads it
         __syncthreads();
         if (r == w.r) { s_win[0] = my_aux & 0xffff; }
         const AdsBid& cm = (second && w2.r >= 0) ? w2 : w;       // second / first price :498-516

@@ -108,7 +108,7 @@ def main():
                            agent_supertypes=st, batch_size=B, seed=1)
     d = env._device(); env.reset()
     us, wall = time_steps(d, lambda i: torch.rand(B, 120, device=dev0), n=40, warm=4)
-    out.append(dict(config=f"ADS 122 agents B={B}", engine="generic", agents=122, batch=B, us_per_step_events=us,
+    out.append(dict(config=f"ADS 122 agents B={B}", engine="fused" if d.uses_fused else "generic", agents=122, batch=B, us_per_step_events=us,
                     us_per_step_wall=wall, agent_steps_per_s=122 * B / (us * 1e-6)))
     print(json.dumps(out[-1]), flush=True)
     env.reset()
@@ -120,7 +120,7 @@ def main():
         d.rollout(T, out=traj)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / (4 * T) * 1e3
-    out.append(dict(config=f"ADS 122 agents B={B} rollout T={T}", engine="generic launch loop", agents=122, batch=B,
+    out.append(dict(config=f"ADS 122 agents B={B} rollout T={T}", engine="fused" if d.uses_fused else "generic launch loop", agents=122, batch=B,
                     us_per_step_events=us, us_per_step_wall=us, agent_steps_per_s=122 * B / (us * 1e-6),
                     clicks_per_env_step=float(traj.rewards.sum().item()) / (T * B)))
     print(json.dumps(out[-1]), flush=True)
