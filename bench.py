@@ -136,6 +136,23 @@ def other_configs(device):
     add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 20, timed(lambda: dev.rollout(20, out=tr), 2), "fused rollout T=20")
     del env, dev, tr
     torch.cuda.empty_cache()
+    # not a BASELINE config: the reference's digital-ads example at its own size (the exchange's
+    # handle_batch auction), 1 exchange + 1 publisher + 120 advertisers with clipped-sampler budgets, B = 4096
+    st = {}
+    for i in range(120):
+        lo = (5.0, 7.0, 10.0)[i // 40]
+        st[f"ADV_{i + 1}"] = ph.AdvertiserAgent.Supertype(
+            budget=ph.UniformFloatSampler(lo, lo + 10.001, clip_low=lo, clip_high=lo + 10.0))
+    env = ph.DigitalAdsEnv(num_steps=20, num_agents_theme={"travel": 40, "tech": 40, "sport": 40},
+                           agent_supertypes=st, batch_size=4096, seed=42, device=device)
+    env.reset(); dev = env._device()
+    acts = torch.rand(4096, 120, device=dev.device)
+    add("digital-ads market 122 agents B=4096 (SURVEY 8f-4)", 122, 4096, 1, timed(lambda: dev.step(acts), 40), "one launch per step")
+    tr = dev.rollout(40)
+    add("digital-ads market 122 agents B=4096 (SURVEY 8f-4)", 122, 4096, 40, timed(lambda: dev.rollout(40, out=tr), 3),
+        "fused rollout T=40")
+    del env, dev, tr, acts
+    torch.cuda.empty_cache()
     return res
 
 
