@@ -390,11 +390,11 @@ static void agent_act(const phxo_env* E, oenv* e, int b, int a, int has_action, 
       int order_size;
       if (exo_b) order_size = exo_b[E->exo_rank[a]];
       else {
-        /* device stream: k-th accepted field of the shop's block sequence */
-        uint8_t tmp[4096];
-        int K = pi[1] + 1;
-        phxo_rng_orders(E->s.seed, E->s.env_offset + b, e->tick, E->kind_rank[pi[0]], K, tmp);
-        order_size = tmp[K - 1];
+        /* device stream: base-5 digit pi1 % 6 of the word of customer group pi1 / 6 (pi1 = index among
+         * the shop's customers) */
+        uint32_t y = rng_group_y(E->s.seed, E->s.env_offset + b, e->tick, E->kind_rank[pi[0]], pi[1] / 6, NULL);
+        for (int i = 0; i < pi[1] % 6; ++i) y /= 5u;
+        order_size = (int)(y % 5u);
       }
       network_send(E, e, a, pi[0], PHX_MSG_ORDER_REQUEST, mk_i(order_size));
       break;
@@ -706,6 +706,7 @@ static void adexchange_handle_batch(const phxo_env* E, oenv* e, int a, const oin
 /* BatchResolver.resolve resolvers.py:128-163; `live` = receiver_id in contexts */
 static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
   e->round = 0;
+  uint8_t* ok = (uint8_t*)alloca(E->s.queue_cap > 0 ? E->s.queue_cap : 1);   /* exchange batches: delivered flags */
   for (int i = 0;; ++i) {
     if (E->s.round_limit >= 0 && i >= E->s.round_limit) break;        /* range(round_limit) :129-131 */
     if (i >= PHX_MAX_ROUNDS) break;                                   /* itertools.count(): build-specific safety cap */
@@ -717,7 +718,6 @@ static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
     for (int r = 0; r < proc->n_recv; ++r) {                          /* dict order :142 */
       int receiver = proc->order[r];
       if (E->s.kind[receiver] == PHX_KIND_ADEXCHANGE) {               /* overrides handle_batch */
-        uint8_t* ok = (uint8_t*)alloca(proc->n > 0 ? proc->n : 1);
         const int clock0 = e->clock;
         for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) {
           e->clock++;
