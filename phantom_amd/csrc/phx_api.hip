@@ -300,6 +300,9 @@ static int derive(const phx_spec* sp, Derived& d) {
       d.shop_cust_ptr.push_back((int)d.shop_cust_agent.size());
       d.max_cust = std::max(d.max_cust, (int)cust[s].size());
     }
+    // device-RNG counter word = shop | customer group << 20 (six customers per group)
+    if (d.max_cust > 6 * 4096 || nS > (1 << 20))
+      return fail(PHX_EUNSUPPORTED, "at most 24576 customers per shop and 2^20 shops (device RNG counter layout)");
     // lookup tables of the rollout kernel: the reference's own formulas evaluated on the host
     //   obs   np.float32(x / n)            supply_chain.py:127-134
     //   penalty 0.1*stock (f64)            supply_chain.py:147
@@ -691,7 +694,6 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EINVAL, "bad rollout io");
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
-  if (e->use_fused && e->d.max_cust >= 65535) return fail(PHX_EUNSUPPORTED, "phx_rollout: at most 65534 customers per shop");
   HIPCHK(use_device(e));
   if (e->use_ads && e->n_inject == 0) {
     if (!io->obs_valid || !io->reward_valid) return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");

@@ -296,7 +296,13 @@ def ads_case(rng, case):
             reset(done)
     if rng.rand() < 0.6 and (o.err == 0).all():                   # launch-loop rollout, device policy and draws
         Tr = int(rng.randint(1, 40))
-        ro, rd = o.rollout(Tr, None, None), d.rollout(Tr, None, None)
+        racts = rexo = None
+        if rng.rand() < 0.4:                                      # replayed policy and draws
+            racts = rng.uniform(0, 1.2, (Tr, B, S)).astype(np.float32)
+            if rng.rand() < 0.7:
+                rexo = rng.randint(0, 2, (Tr, B, nx)).astype(np.uint8)
+                rexo[:, :, user_cols] += 1
+        ro, rd = o.rollout(Tr, racts, rexo), d.rollout(Tr, racts, rexo)
         assert np.array_equal(d.err, o.err), (case, "rollout err", d.err, o.err)
         ok = o.err == 0                                           # an env's outputs are unspecified after its first error
         for k in ("obs", "actions", "rewards"):
