@@ -70,7 +70,7 @@ def log_array(msgs, index):
     return out
 
 
-def run_ads(name, themes, budgets, num_steps, T, seed, strategy="first", rates=None, act_hi=1.0):
+def run_ads(name, themes, budgets, num_steps, T, seed, strategy="first", rates=None, act_hi=1.0, p_uniform=0.85):
     """``budgets[i]``: a python float, ("uniform", low, high) or ("clipped", low, high, clip_low,
     clip_high) per advertiser; ``rates`` = (adx-pub, adx-adv, pub-adv) connectivity or None (1.0)."""
     np.random.seed(seed)
@@ -155,7 +155,8 @@ def run_ads(name, themes, budgets, num_steps, T, seed, strategy="first", rates=N
                     continue
                 if rng.rand() < 0.1:
                     continue                              # no action -> generate_messages (env.py:332)
-                a = np.float32(rng.uniform(0.0, act_hi)) if rng.rand() < 0.85 else np.float32(rng.randint(0, 3) / 2.0)
+                # continuous actions with probability p_uniform, else a coarse grid so that bids tie
+                a = np.float32(rng.uniform(0.0, act_hi)) if rng.rand() < p_uniform else np.float32(rng.randint(0, 3) / 2.0)
                 acts[aid] = np.array([a], dtype=np.float32)
                 A["actions"][t, s], A["action_valid"][t, s] = a, 1
         net.resolver.clear_tracked_messages()

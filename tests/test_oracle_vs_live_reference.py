@@ -47,3 +47,21 @@ def test_oracle_matches_live_reference_ads_market(first):
                         strategy=("second" if rng.rand() < 0.5 else "first"), rates=rates,
                         act_hi=float(rng.choice([1.0, 1.2, 2.0])))
         replay_ads(g, lambda spec: OracleEnv(spec))
+
+
+def test_oracle_matches_live_reference_ads_auction_ties():
+    """equal budgets and grid actions: many equal bids, so the winner / second bid are decided by the
+    stable sort's arrival order (digital_ads_market.py:498-516)."""
+    import numpy as np
+    import gen_goldens_ads as gga
+    from oracle import OracleEnv
+    from test_oracle_vs_goldens import replay_ads
+    for case in range(8):
+        rng = np.random.RandomState(19000 + case)
+        k = int(rng.randint(2, 21))
+        themes = sorted(rng.choice(gga.THEMES, k).tolist(), key=gga.THEMES.index)
+        budgets = [[1.0] * k, [float(rng.choice([1.0, 2.0])) for _ in range(k)], [("clipped", 0.5, 1.5, 1.0, 1.0)] * k][case % 3]
+        g = gga.run_ads(None, themes, budgets, int(rng.randint(4, 30)), int(rng.randint(20, 90)), seed=case,
+                        strategy=("second" if case % 2 else "first"), p_uniform=0.3)
+        assert (g["step_wins"].sum() > 0)
+        replay_ads(g, lambda spec: OracleEnv(spec))
