@@ -80,3 +80,26 @@ def test_shard_batch_rejects_uneven_split():
     with pytest.raises(ValueError):
         shard_batch(10, rank=0, world_size=4)
     assert shard_batch(4096 * 8, rank=3, world_size=8).env_offset == 3 * 4096
+
+
+def test_ads_market_shards_are_independent_of_the_split():
+    """every device draw of the ads market (publisher's user / click, budget samplers, connectivity) is
+    keyed by the GLOBAL env index: two shards with env_offset reproduce the unsharded rollout."""
+    sys.path.insert(0, HERE)
+    import phantom_amd as ph
+    from oracle import OracleEnv
+
+    def make(batch, offset):
+        st = {f"ADV_{i + 1}": ph.AdvertiserAgent.Supertype(budget=ph.UniformFloatSampler(0.5, 1.6, 0.6, 1.5)) for i in range(5)}
+        return ph.DigitalAdsEnv(num_steps=6, num_agents_theme={"travel": 2, "tech": 3}, agent_supertypes=st, strategy="second",
+                                connection_rates=(1.0, 0.8, 0.9), batch_size=batch, seed=77, env_offset=offset)
+    T = 25
+    full = OracleEnv(make(6, 0).spec); full.reset()
+    rf = full.rollout(T)
+    parts = []
+    for off in (0, 3):
+        o = OracleEnv(make(3, off).spec); o.reset()
+        parts.append(o.rollout(T))
+    for k in ("obs", "actions", "rewards", "terminated", "truncated", "obs_valid", "reward_valid"):
+        np.testing.assert_array_equal(np.concatenate([p[k] for p in parts], axis=1), rf[k], err_msg=k)
+    assert rf["rewards"].sum() > 0 and rf["truncated"].sum() > 0
