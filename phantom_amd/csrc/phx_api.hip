@@ -67,6 +67,7 @@ struct Derived {
   int n_tabn = 0, n_quot = 0, rew_smax = -1;
   int max_cust = 0;
   std::vector<uint16_t> stk_nbr;
+  std::vector<int32_t> stk_nbr_conn;
   std::vector<uint32_t> stk_rec;
   std::vector<uint8_t> stk_flags;
   // supertypes
@@ -226,7 +227,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   // ---- static Stackelberg-market schedule? (fused kernel) ----------------------------------------
   bool stk = sp->env_type == PHX_ENV_STACKELBERG && d.kind_count[PHX_KIND_SELLER] > 0 &&
              !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS)) && sp->trace_cap == 0 &&
-             (sp->round_limit < 0 || sp->round_limit >= 1) && !d.dynamic_graph;
+             (sp->round_limit < 0 || sp->round_limit >= 1) && (!d.dynamic_graph || sp->n_samplers == 0);
   for (int a = 0; a < A && stk; ++a) {
     const int k = sp->kind[a];
     if (k != PHX_KIND_SELLER && k != PHX_KIND_BUYER) { stk = false; break; }
@@ -239,10 +240,13 @@ static int derive(const phx_spec* sp, Derived& d) {
   if (d.stk_static) {                       // slot-major neighbour table of the buyers (seller ranks)
     const int nB = d.kind_count[PHX_KIND_BUYER];
     d.stk_nbr.assign((size_t)std::max(d.buyer_dmax, 1) * std::max(nB, 1), 0xFFFF);
+    d.stk_nbr_conn.assign(d.stk_nbr.size(), 0);
     for (int a = 0; a < A; ++a)
       if (sp->kind[a] == PHX_KIND_BUYER)
-        for (int e = sp->row_ptr[a]; e < sp->row_ptr[a + 1]; ++e)
+        for (int e = sp->row_ptr[a]; e < sp->row_ptr[a + 1]; ++e) {
           d.stk_nbr[(size_t)(e - sp->row_ptr[a]) * nB + d.kind_rank[a]] = (uint16_t)d.kind_rank[sp->col[e]];
+          if (sp->n_conn > 0) d.stk_nbr_conn[(size_t)(e - sp->row_ptr[a]) * nB + d.kind_rank[a]] = sp->col_conn[e];
+        }
     d.stk_rec.assign(A, 0); d.stk_flags.assign((size_t)2 * A, 0);
     for (int a = 0; a < A; ++a) {
       // buyers: deg <= buyer_dmax < 256; a seller's degree (its obs divisor) is read from row_ptr
@@ -497,7 +501,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(sc_tab, der.sc_tab.data(), der.sc_tab.size());
   UP(conn_rate, spec->conn_rate, spec->n_conn); UP(col_conn, spec->col_conn, spec->n_conn > 0 ? der.nnz : 0);
   d.n_conn = spec->n_conn;
-  UP(stk_nbr, der.stk_nbr.data(), der.stk_nbr.size());
+  UP(stk_nbr, der.stk_nbr.data(), der.stk_nbr.size()); UP(stk_nbr_conn, der.stk_nbr_conn.data(), der.stk_nbr_conn.size());
   UP(stk_rec, der.stk_rec.data(), der.stk_rec.size()); UP(stk_flags, der.stk_flags.data(), der.stk_flags.size());
   UP(sampler_kind, spec->sampler_kind, spec->n_samplers); UP(sampler_param, spec->sampler_param, 4 * spec->n_samplers);
   UP(type_src, der.type_src.data(), A);

@@ -86,6 +86,7 @@ struct DevSpec {
   int32_t n_tabn, n_quot, rew_smax;
   // Stackelberg market static schedule (fused kernel): neighbour table of the buyers, slot-major
   const uint16_t* stk_nbr;       // [buyer_dmax][nBuyers] seller rank of neighbour k, 0xFFFF = none
+  const int32_t* stk_nbr_conn;   // same shape: base connection of that slot (StochasticNetwork)
   const uint32_t* stk_rec;       // [A] kind | deg << 8 | kind_rank << 16
   const uint8_t*  stk_flags;     // [2][A] 1 acts, 2 observes, 4 rewarded in list 0 (leaders' step) / 1
   // StochasticNetwork (network.py:340-453): per-env on/off byte per base connection

@@ -48,6 +48,9 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   const uint8_t* av_b = io.action_valid ? io.action_valid + (int64_t)b * A : nullptr;
   const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy;
   double* posted_b = fld<double>(sp, F_SELLER_POSTED) + sbase;
+  // StochasticNetwork (network.py:340-453): the env's surviving connections; a slot whose connection is
+  // off is not a neighbour this episode (sellers do not post to it, buyers do not consider it)
+  const uint8_t* conn_b = sp.dynamic_graph ? fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn : nullptr;
 
   for (int k = tid; k < nSell; k += STK_NT) {
     s_posted[k] = posted_b[k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
@@ -71,10 +74,16 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       int bought = 0; double paid = 0.0;
       if (action > 0.5f && deg > 0) {
         const uint16_t* nb = sp.stk_nbr + kr;
-        int jr = nb[0]; double best = s_posted[jr];                           // first minimum in neighbour order
-        for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
-        bought = 1; paid = best;
-        atomicAdd(&s_count[jr], 1);                                          // Order(1) -> that seller's inbox
+        int jr = -1; double best = 0.0;                                      // first minimum in (current) neighbour order
+        for (int k = 0; k < deg; ++k) {
+          if (conn_b && !conn_b[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+          const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
+          if (jr < 0 || v < best) { best = v; jr = l; }
+        }
+        if (jr >= 0) {
+          bought = 1; paid = best;
+          atomicAdd(&s_count[jr], 1);                                        // Order(1) -> that seller's inbox
+        }
       }
       fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr] = bought;
       fld<double>(sp, F_BUYER_PAID)[bbase + kr] = paid;
@@ -113,11 +122,18 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     float ob0 = 0.f, ob1 = 0.f; uint8_t ov = 0;
     if (fl & 2) {                                                            // encode_observation
       ov = 1;
-      if (seller) { const int sd = sp.row_ptr[a + 1] - sp.row_ptr[a]; ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr]; }
-      else {
+      if (seller) {
+        int sd = sp.row_ptr[a + 1] - sp.row_ptr[a];                          // len(ctx.neighbour_ids)
+        if (conn_b) { sd = 0; for (int e = sp.row_ptr[a]; e < sp.row_ptr[a + 1]; ++e) sd += conn_b[sp.col_conn[e]] ? 1 : 0; }
+        ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
+      } else {
         const uint16_t* nb = sp.stk_nbr + kr;
-        double mn = deg > 0 ? s_posted[nb[0]] : 1.0;                         // min over the price slots (none: 1.0)
-        for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
+        double mn = 1.0; bool any = false;                                   // min over the price slots (none: 1.0)
+        for (int k = 0; k < deg; ++k) {
+          if (conn_b && !conn_b[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+          const double v = s_posted[nb[(int64_t)k * nBuy]];
+          if (!any || v < mn) { mn = v; any = true; }
+        }
         ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
       }
     }
@@ -165,8 +181,13 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
   uint8_t* s_sent = (uint8_t*)(s_act + A);
   uint8_t* s_cv = s_sent + nSell;                        // [A] reward cache valid
   uint8_t* s_bought = s_cv + A;                          // [nBuy]
+  uint8_t* s_conn = s_bought + nBuy;                     // [n_conn] StochasticNetwork: connection is in this episode's graph
+  const bool dyn = sp.dynamic_graph != 0;
   const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy, abase = (int64_t)b * A;
   const int64_t genv = sp.env_offset + b;
+  uint32_t episode = dyn ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
+  int n_resets = 0;
+  if (dyn) for (int i = tid; i < sp.n_conn; i += STKR_NT) s_conn[i] = fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i];
 
   for (int k = tid; k < nSell; k += STKR_NT) {
     s_posted[k] = fld<double>(sp, F_SELLER_POSTED)[sbase + k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
@@ -207,10 +228,13 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
           int bought = 0; double paid = 0.0;
           if (action > 0.5f && deg > 0) {
             const uint16_t* nb = sp.stk_nbr + kr;
-            int jr = nb[0]; double best = s_posted[jr];
-            for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
-            bought = 1; paid = best;
-            atomicAdd(&s_count[jr], 1);
+            int jr = -1; double best = 0.0;
+            for (int k = 0; k < deg; ++k) {
+              if (dyn && !s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+              const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
+              if (jr < 0 || v < best) { best = v; jr = l; }
+            }
+            if (jr >= 0) { bought = 1; paid = best; atomicAdd(&s_count[jr], 1); }
           }
           s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;
         }
@@ -243,11 +267,18 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
       ob0 = 0.f; ob1 = 0.f; ov = 0;
       if (fl & 2) {
         ov = 1;
-        if (seller) { const int sd = sp.row_ptr[a + 1] - sp.row_ptr[a]; ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr]; }
-        else {
+        if (seller) {
+          int sd = sp.row_ptr[a + 1] - sp.row_ptr[a];
+          if (dyn) { sd = 0; for (int e = sp.row_ptr[a]; e < sp.row_ptr[a + 1]; ++e) sd += s_conn[sp.col_conn[e]] ? 1 : 0; }
+          ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
+        } else {
           const uint16_t* nb = sp.stk_nbr + kr;
-          double mn = deg > 0 ? s_posted[nb[0]] : 1.0;
-          for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
+          double mn = 1.0; bool any = false;
+          for (int k = 0; k < deg; ++k) {
+            if (dyn && !s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+            const double v = s_posted[nb[(int64_t)k * nBuy]];
+            if (!any || v < mn) { mn = v; any = true; }
+          }
           ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
         }
       }
@@ -291,9 +322,17 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
       for (int k = tid; k < nSell; k += STKR_NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
       for (int k = tid; k < nBuy; k += STKR_NT) { s_paid[k] = 0.0; s_bought[k] = 0; }
       for (int a = tid; a < A; a += STKR_NT) s_cv[a] = 0;
+      if (dyn) {                                                             // resample_connectivity network.py:438-447
+        for (int i = tid; i < sp.n_conn; i += STKR_NT) s_conn[i] = (uint8_t)rng_connection(sp.seed, genv, episode, i, sp.conn_rate[i]);
+        ++episode; ++n_resets;
+      }
       step = 0;
       __syncthreads();
     }
+  }
+  if (dyn && n_resets > 0) {
+    for (int i = tid; i < sp.n_conn; i += STKR_NT) fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i] = s_conn[i];
+    if (tid == 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)episode;
   }
   for (int k = tid; k < nSell; k += STKR_NT) {
     fld<double>(sp, F_SELLER_POSTED)[sbase + k] = s_posted[k]; fld<double>(sp, F_SELLER_PRICE)[sbase + k] = s_price[k];
@@ -310,7 +349,7 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
 
 size_t phx_stk_rollout_lds(const DevSpec& sp) {
   const size_t nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER], A = sp.A;
-  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell + A) + nSell + A + nBuy + 32;
+  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell + A) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32;
 }
 
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
@@ -325,7 +364,10 @@ __global__ __launch_bounds__(256) void phx_stk_materialise_kernel(const DevSpec 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = i / sp.buyer_nnz; const int slot = (int)(i - b * sp.buyer_nnz);
     const int l = sp.stk_nbr[slot];
-    if (l != 0xFFFF) fld<double>(sp, F_BUYER_PRICES)[i] = fld<double>(sp, F_SELLER_POSTED)[b * nSell + l];
+    if (l == 0xFFFF) continue;
+    // a slot whose connection is off this episode was not written since the reset: 1.0
+    const bool on = !sp.dynamic_graph || fld<uint8_t>(sp, F_NET_CONN_ON)[b * sp.n_conn + sp.stk_nbr_conn[slot]];
+    fld<double>(sp, F_BUYER_PRICES)[i] = on ? fld<double>(sp, F_SELLER_POSTED)[b * nSell + l] : 1.0;
   }
   (void)nBuy;
 }

@@ -695,18 +695,19 @@ def test_market_compressed_prices_materialise_on_inject():
 
 
 @pytest.mark.parametrize("device_draw", [False, True])
-def test_stochastic_network_differential_vs_oracle(device_draw):
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_stochastic_network_differential_vs_oracle(device_draw, force_generic):
     """StochasticNetwork (network.py:340-453): per-env connectivity resampled at every reset, fed by
     the host or drawn by the device Philox stream; market kinds iterate / check the per-env graph."""
     rng = np.random.RandomState(31)
     L, Fw, d, B, T = 6, 24, 3, 40, 36
     S = L + Fw
     np.random.seed(5)
-    env = market_env(L, Fw, d, 9, B, rates=[0.8, 0.3, 1.0, 0.0, 0.55], seed=21, env_offset=100)
+    env = market_env(L, Fw, d, 9, B, rates=[0.8, 0.3, 1.0, 0.0, 0.55], seed=21, env_offset=100, force_generic=force_generic)
     spec = env.spec
     assert spec.n_conn == Fw * d and len(spec.col_conn) == 2 * spec.n_conn
     o, x = OracleEnv(spec), _dev(spec)
-    assert not x.dev.uses_fused
+    assert x.dev.uses_fused == (not force_generic)      # the fused market kernels read the per-env connectivity too
     np.testing.assert_array_equal(x.get_u8("net.conn_on"), o.get_u8("net.conn_on"))   # constructor draw
 
     def reset(mask=None):
@@ -736,6 +737,8 @@ def test_stochastic_network_differential_vs_oracle(device_draw):
         np.testing.assert_array_equal(f64_bits(x.reward), f64_bits(o.reward), err_msg=f"rew t={t}")
         for f in ("seller.tx", "buyer.bought"):
             np.testing.assert_array_equal(x.get_i32(f), o.get_i32(f), err_msg=f)
+        if t % 7 == 3:      # BuyerAgent.prices: slots of connections that are off this episode keep the reset's 1.0
+            np.testing.assert_array_equal(f64_bits(x.get_f64("buyer.prices")), f64_bits(o.get_f64("buyer.prices")), err_msg=f"prices t={t}")
         done = o.all_truncated.astype(np.uint8)
         if done.any():
             reset(done)
@@ -908,17 +911,20 @@ def test_env_supertype_and_dict_vs_tensor_api():
 def test_launch_loop_rollout_for_generic_engine_envs():
     """phx_rollout on envs without a fused rollout kernel (stochastic market; supply chain forced onto
     the generic engine): the stream-ordered launch loop vs the oracle, incl. auto-reset redraws."""
-    env = market_env(5, 14, 3, 6, 9, rates=[0.8, 0.3, 1.0, 0.0, 0.55], seed=4, env_offset=2, exogenous="device")
-    o, x = OracleEnv(env.spec), _dev(env.spec)
-    assert not x.dev.uses_fused
-    o.reset(); x.reset()
-    ro, rd = o.rollout(20), x.rollout(20)
-    for k in ("obs_valid", "reward_valid", "truncated", "terminated"):
-        np.testing.assert_array_equal(rd[k], ro[k], err_msg=k)
-    for k in ("obs", "actions", "rewards", "last_obs"):
-        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
-    np.testing.assert_array_equal(x.get_u8("net.conn_on"), o.get_u8("net.conn_on"))     # redrawn 3 times
-    assert ro["truncated"].sum() > 0
+    for force_generic in (True, False):        # launch loop on the generic engine; fused market rollout with in-kernel redraws
+        env = market_env(5, 14, 3, 6, 9, rates=[0.8, 0.3, 1.0, 0.0, 0.55], seed=4, env_offset=2, exogenous="device",
+                         force_generic=force_generic)
+        o, x = OracleEnv(env.spec), _dev(env.spec)
+        assert x.dev.uses_fused == (not force_generic)
+        o.reset(); x.reset()
+        ro, rd = o.rollout(20), x.rollout(20)
+        for k in ("obs_valid", "reward_valid", "truncated", "terminated"):
+            np.testing.assert_array_equal(rd[k], ro[k], err_msg=k)
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+        np.testing.assert_array_equal(x.get_u8("net.conn_on"), o.get_u8("net.conn_on"))     # redrawn 3 times
+        np.testing.assert_array_equal(x.get_i32("env.episode"), o.get_i32("env.episode"))
+        assert ro["truncated"].sum() > 0
     env = supply_chain_env(4, [2, 7, 0, 3], 5, 11, force_generic=True, seed=9, norm_customers=3)
     o, d = OracleEnv(env.spec), _dev(env.spec)
     o.reset(); d.reset()
