@@ -86,11 +86,27 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
   const int strong = mine ? sp.param_i[a * PHX_NPI + 2] : 0;
   const int tsrc = mine ? sp.type_src[a] : PHX_TYPE_CONST;
   const int pub_x = sp.exo_rank[pub];
+  // StochasticNetwork with rates < 1 (and ignore_connection_errors, network.py:246-249): a message along a
+  // connection that is off this episode is sent, tracked and dropped at the receiver (resolvers.py:146-148).
+  // Connections of this thread's advertiser: to the exchange (c_adx) and to the publisher (c_pub).
+  const bool dyn = sp.dynamic_graph != 0;
+  int c_adx = 0, c_pub = 0, c_ap = 0;
+  if (dyn) {
+    if (mine) {
+      const int e0 = sp.row_ptr[a];
+      const bool first_is_adx = sp.col[e0] == adx;
+      c_adx = sp.col_conn[first_is_adx ? e0 : e0 + 1]; c_pub = sp.col_conn[first_is_adx ? e0 + 1 : e0];
+    }
+    for (int e = sp.row_ptr[pub]; e < sp.row_ptr[pub + 1]; ++e) if (sp.col[e] == adx) c_ap = sp.col_conn[e];
+  }
+  const uint8_t* conn_b = dyn ? fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn : nullptr;
+  bool e_adx = !dyn || !mine || conn_b[c_adx] != 0, e_pub = !dyn || !mine || conn_b[c_pub] != 0;
+  bool e_ap = !dyn || conn_b[c_ap] != 0;
 
   // ---- state -> registers ------------------------------------------------------------------------
   int step = fld<int32_t>(sp, F_ENV_STEP)[b], stage = fld<int32_t>(sp, F_ENV_STAGE)[b], prev_stage = fld<int32_t>(sp, F_ENV_PREV_STAGE)[b];
   uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-  uint32_t episode = sp.n_samplers > 0 ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
+  uint32_t episode = (sp.n_samplers > 0 || sp.n_conn > 0) ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
   int n_resets = 0, err = 0, ads_seen = fld<int32_t>(sp, F_PUB_ADS_SEEN)[b];
   double left = 0, bid = 0, budget = 0, rc = 0;
   int left_tag = 0, bid_tag = 0, clicks = 0, wins = 0, user = 0, tq[3] = {0, 0, 0}, tw[3] = {0, 0, 0}, tc[3] = {0, 0, 0};
@@ -140,7 +156,10 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     if (stage == sp.ads_pub_stage) {
       // PUB generate_messages :164-165 -> ADX forwards :415-427 -> live advertisers cache the user :249-271
       const int u = exo_b ? exo_b[pub_x] : rng_publisher(sp.seed, genv, tick, pub, 0, 0.0);
-      if (live) { clicks = 0; wins = 0; user = u; if (u >= 0 && u <= 2) tq[u] += 1; }     // pre_message_resolution :241-247
+      if (live) {
+        clicks = 0; wins = 0;                                  // pre_message_resolution :241-247
+        if (e_ap && e_adx) { user = u; if (u >= 0 && u <= 2) tq[u] += 1; }
+      }
       ads_seen = 0;
     } else {
       // decode_action :318-333
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
         TVal bv = t_mul(tv((double)action, PHX_TAG_F32), tv(budget, btag));
         if (t_lt(tv(left, left_tag), bv)) bv = tv(left, left_tag);           // min(action[0] * budget, self.left)
         bid = bv.v; bid_tag = bv.tag;
-        if (bv.v > 0.0) { cand.v = bv.v; cand.tag = bv.tag; cand.r = r; my_aux = theme | (user << 4) | (bv.tag << 8); }
+        if (bv.v > 0.0 && e_adx) { cand.v = bv.v; cand.tag = bv.tag; cand.r = r; my_aux = theme | (user << 4) | (bv.tag << 8); }
       }
       if (live) { clicks = 0; wins = 0; }
       ads_seen = 0;
@@ -170,7 +189,8 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
         // PublisherAgent.handle_ads :167-196
         const int wth = waux & 15, wuser = (waux >> 4) & 15;
         int clicked = 0; bool answered = false;
-        if (wuser < 1 || wuser > 2 || wth > 3) { if (!err) err = PHX_ERR_CONTEXT; }       // dict KeyError :194
+        if (!e_ap) { }                                                                     // the Ads message is dropped
+        else if (wuser < 1 || wuser > 2 || wth > 3) { if (!err) err = PHX_ERR_CONTEXT; }  // dict KeyError :194
         else {
           ads_seen = 1;
           if (exo_b && ppi[1] < 1) { if (!err) err = PHX_ERR_QUEUE_FULL; }
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
           wins += 1; if (user >= 0 && user <= 2) tw[user] += 1;
           const TVal nl = t_sub(tv(left, left_tag), tv(s_cost, s_win[1]));
           left = nl.v; left_tag = nl.tag;
-          if (answered) { clicks += clicked; if (user >= 0 && user <= 2) tc[user] += clicked; }   // ImpressionResult :284-292
+          if (answered && e_pub) { clicks += clicked; if (user >= 0 && user <= 2) tc[user] += clicked; }   // ImpressionResult :284-292
         }
       }
     }
@@ -238,6 +258,11 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     if (ROLLOUT && terminal) {
       // the caller's env.reset(): samplers env.py:211-212, agents :353-374, done sets, reward cache fsm.py:195-251
       if (tsrc >= 0) budget = rng_uniform(sp.seed, genv, episode, tsrc, sp.sampler_param + 4 * tsrc);
+      if (dyn) {                                               // resample_connectivity network.py:438-447
+        if (mine) { e_adx = rng_connection(sp.seed, genv, episode, c_adx, sp.conn_rate[c_adx]) != 0;
+                    e_pub = rng_connection(sp.seed, genv, episode, c_pub, sp.conn_rate[c_pub]) != 0; }
+        e_ap = rng_connection(sp.seed, genv, episode, c_ap, sp.conn_rate[c_ap]) != 0;
+      }
       ++episode; ++n_resets;
       left = budget; left_tag = btag; bid = 0.0; bid_tag = PHX_TAG_PYF; clicks = wins = user = 0;
       for (int u = 0; u < 3; ++u) tq[u] = tw[u] = tc[u] = 0;
@@ -260,6 +285,11 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g] = ocv;
     for (int d = 0; d < 3; ++d) fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + d] = oc[d];
     if (ROLLOUT && args.rio.last_obs) for (int d = 0; d < 3; ++d) args.rio.last_obs[g * 3 + d] = lo[d];
+    if (ROLLOUT && dyn && n_resets > 0) {
+      uint8_t* cw = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
+      cw[c_adx] = e_adx; cw[c_pub] = e_pub;
+      if (r == 0) cw[c_ap] = e_ap;
+    }
   }
   if (r == 0) {
     fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
@@ -267,8 +297,8 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     fld<int32_t>(sp, F_PUB_ADS_SEEN)[b] = ads_seen;
     int32_t* errp = ROLLOUT ? args.rio.err : args.sio.err;
     if (errp && errp[b] == 0 && err) errp[b] = err;
+    if (ROLLOUT && (sp.n_samplers > 0 || sp.n_conn > 0) && n_resets > 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)episode;
     if (ROLLOUT && sp.n_samplers > 0 && n_resets > 0) {        // every column as drawn at the last auto-reset
-      fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)episode;
       for (int j = 0; j < sp.n_samplers; ++j)
         fld<double>(sp, F_ENV_SAMPLER)[(int64_t)b * sp.n_samplers + j] =
             rng_uniform(sp.seed, genv, episode - 1u, j, sp.sampler_param + 4 * j);

@@ -264,7 +264,7 @@ static int derive(const phx_spec* sp, Derived& d) {
     const int N = d.kind_count[PHX_KIND_ADVERTISER];
     bool ads = sp->env_type == PHX_ENV_FSM && sp->n_stages == 2 && N >= 1 && N <= 1024 && d.kind_count[PHX_KIND_PUBLISHER] == 1 &&
                d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
-               (sp->round_limit < 0 || sp->round_limit >= 3) && !d.dynamic_graph && d.D == 3 &&
+               (sp->round_limit < 0 || sp->round_limit >= 3) && (!d.dynamic_graph || (sp->flags & PHX_F_IGNORE_CONN_ERRORS)) && d.D == 3 &&
                sp->stage_next[0] == 1 && sp->stage_next[1] == 0;
     if (ads) {
       for (int a = 0; a < A; ++a) { if (sp->kind[a] == PHX_KIND_PUBLISHER) d.ads_pub = a; if (sp->kind[a] == PHX_KIND_ADEXCHANGE) d.ads_adx = a; }

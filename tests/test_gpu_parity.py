@@ -68,9 +68,10 @@ def test_generic_engine_ads_market_matches_reference(name):
     replay_ads(golden(name), _dev)
 
 
-@pytest.mark.parametrize("name", ["ads_first", "ads_second", "ads_sampled"])
+@pytest.mark.parametrize("name", ADS_CASES)
 def test_fused_ads_kernel_matches_reference(name):
-    """the same goldens through phx_ads_fused.hip (static schedule: no tracking, every rate 1)."""
+    """the same goldens through phx_ads_fused.hip (static schedule, no tracking; ads_stochastic: connectivity
+    below 1, messages along connections that are off are dropped)."""
     def make(spec):
         r = _dev(spec)
         assert r.dev.uses_fused
