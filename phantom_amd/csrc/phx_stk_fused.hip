@@ -50,7 +50,13 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   double* posted_b = fld<double>(sp, F_SELLER_POSTED) + sbase;
   // StochasticNetwork (network.py:340-453): the env's surviving connections; a slot whose connection is
   // off is not a neighbour this episode (sellers do not post to it, buyers do not consider it)
-  const uint8_t* conn_b = sp.dynamic_graph ? fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn : nullptr;
+  const uint8_t* conn_b = nullptr;
+  if (sp.dynamic_graph) {                                // the env's connectivity row, staged in LDS (16-byte loads)
+    uint8_t* s_conn = s_sent + ((nSell + 15) & ~15);
+    const uint8_t* src = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
+    for (int i = tid; i < sp.n_conn; i += STK_NT) s_conn[i] = src[i];
+    conn_b = s_conn;
+  }
 
   for (int k = tid; k < nSell; k += STK_NT) {
     s_posted[k] = posted_b[k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void phx_stk_materialise_kernel(const DevSpec 
 
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
-  const size_t lds = (size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 16;
+  const size_t lds = (size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 32 + (sp.dynamic_graph ? (size_t)sp.n_conn : 0);
   hipLaunchKernelGGL(phx_stk_step_kernel, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   return hipGetLastError();
 }
