@@ -128,6 +128,13 @@ struct GenArgs {               // arguments of the generic engine kernel
 template <typename T>
 __device__ __forceinline__ T* fld(const DevSpec& sp, int id) { return (T*)sp.f[id]; }
 
+// XCD-aware workgroup index: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each); mapping id
+// to (id % 8) * n/8 + id / 8 gives every XCD a contiguous range of envs, so that the partial cache lines where
+// two neighbouring workgroups' output segments meet are merged in one L2 (measured history)
+__device__ __forceinline__ int xcd_block(bool on) {
+  return (on && (gridDim.x & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+}
+
 // The static topology tables the message handlers walk in dependent chains.  The generic engine
 // stages them in LDS (every env instance of a launch reads the same few cache lines otherwise);
 // other kernels use the global copies through topo_global().

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   // XCD-aware block -> env mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
   // L2; giving XCD x the x-th contiguous eighth of the envs lets the partial cache lines at the boundary of two
   // neighbouring workgroups' trajectory segments merge in ONE L2 instead of reaching HBM from two
-  const int bid = (a.xcd_remap && (gridDim.x & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int bid = xcd_block(a.xcd_remap != 0);
   const int64_t b_first = (int64_t)bid * a.epb;
   const int64_t b_end = (WIDE || b_first + a.epb < a.B) ? b_first + a.epb : a.B;
   const int nb = (int)(b_end - b_first);
