@@ -25,6 +25,7 @@
 // sellers) instead of one per (buyer, neighbour) (64 KB per env at 1024 x 8).  The kernel keeps
 // the per-seller array in LDS; buyers gather from it through the slot-major neighbour table
 // stk_nbr.  phx_sync_fields / the first host-injected message materialise buyer.prices.
+template <bool DYN>
 __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, const phx_step_io io) {
   // Static per-agent record stk_rec[a] = kind | deg << 8 | kind_rank << 16 and per-list flag byte
   // stk_flags[list][a] (1 acts, 2 observes, 4 rewarded) replace the kind / kind_rank / row_ptr /
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   // StochasticNetwork (network.py:340-453): the env's surviving connections; a slot whose connection is
   // off is not a neighbour this episode (sellers do not post to it, buyers do not consider it)
   const uint8_t* conn_b = nullptr;
-  if (sp.dynamic_graph) {                                // the env's connectivity row, staged in LDS (16-byte loads)
+  if (DYN) {                                             // the env's connectivity row, staged in LDS
     uint8_t* s_conn = s_sent + ((nSell + 15) & ~15);
     const uint8_t* src = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
     for (int i = tid; i < sp.n_conn; i += STK_NT) s_conn[i] = src[i];
@@ -81,10 +82,15 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       if (action > 0.5f && deg > 0) {
         const uint16_t* nb = sp.stk_nbr + kr;
         int jr = -1; double best = 0.0;                                      // first minimum in (current) neighbour order
-        for (int k = 0; k < deg; ++k) {
-          if (conn_b && !conn_b[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
-          const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
-          if (jr < 0 || v < best) { best = v; jr = l; }
+        if (!DYN) {
+          jr = nb[0]; best = s_posted[jr];
+          for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
+        } else {
+          for (int k = 0; k < deg; ++k) {
+            if (!conn_b[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+            const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
+            if (jr < 0 || v < best) { best = v; jr = l; }
+          }
         }
         if (jr >= 0) {
           bought = 1; paid = best;
@@ -130,15 +136,21 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       ov = 1;
       if (seller) {
         int sd = sp.row_ptr[a + 1] - sp.row_ptr[a];                          // len(ctx.neighbour_ids)
-        if (conn_b) { sd = 0; for (int e = sp.row_ptr[a]; e < sp.row_ptr[a + 1]; ++e) sd += conn_b[sp.col_conn[e]] ? 1 : 0; }
+        if (DYN) { sd = 0; for (int e = sp.row_ptr[a]; e < sp.row_ptr[a + 1]; ++e) sd += conn_b[sp.col_conn[e]] ? 1 : 0; }
         ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
       } else {
         const uint16_t* nb = sp.stk_nbr + kr;
-        double mn = 1.0; bool any = false;                                   // min over the price slots (none: 1.0)
-        for (int k = 0; k < deg; ++k) {
-          if (conn_b && !conn_b[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
-          const double v = s_posted[nb[(int64_t)k * nBuy]];
-          if (!any || v < mn) { mn = v; any = true; }
+        double mn = 1.0;                                                     // min over the price slots (none: 1.0)
+        if (!DYN) {
+          if (deg > 0) mn = s_posted[nb[0]];
+          for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
+        } else {
+          bool any = false;
+          for (int k = 0; k < deg; ++k) {
+            if (!conn_b[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+            const double v = s_posted[nb[(int64_t)k * nBuy]];
+            if (!any || v < mn) { mn = v; any = true; }
+          }
         }
         ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
       }
@@ -171,6 +183,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
 // acting agent's word of the tick (the stream the supply chain uses; its rank j in [0, 274877))
 // mapped onto its action space: seller price j / 274877, buyer buys iff j < 137438 (p = 1/2).
 // Auto-reset at the end of the terminal step (the caller's env.reset(), stackelberg.py:53-109).
+template <bool DYN>
 __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
   uint8_t* s_cv = s_sent + nSell;                        // [A] reward cache valid
   uint8_t* s_bought = s_cv + A;                          // [nBuy]
   uint8_t* s_conn = s_bought + nBuy;                     // [n_conn] StochasticNetwork: connection is in this episode's graph
-  const bool dyn = sp.dynamic_graph != 0;
+  constexpr bool dyn = DYN;
   const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy, abase = (int64_t)b * A;
   const int64_t genv = sp.env_offset + b;
   uint32_t episode = dyn ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
@@ -235,10 +248,15 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
           if (action > 0.5f && deg > 0) {
             const uint16_t* nb = sp.stk_nbr + kr;
             int jr = -1; double best = 0.0;
-            for (int k = 0; k < deg; ++k) {
-              if (dyn && !s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
-              const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
-              if (jr < 0 || v < best) { best = v; jr = l; }
+            if (!dyn) {
+              jr = nb[0]; best = s_posted[jr];
+              for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
+            } else {
+              for (int k = 0; k < deg; ++k) {
+                if (!s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+                const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
+                if (jr < 0 || v < best) { best = v; jr = l; }
+              }
             }
             if (jr >= 0) { bought = 1; paid = best; atomicAdd(&s_count[jr], 1); }
           }
@@ -279,11 +297,17 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
           ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
         } else {
           const uint16_t* nb = sp.stk_nbr + kr;
-          double mn = 1.0; bool any = false;
-          for (int k = 0; k < deg; ++k) {
-            if (dyn && !s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
-            const double v = s_posted[nb[(int64_t)k * nBuy]];
-            if (!any || v < mn) { mn = v; any = true; }
+          double mn = 1.0;
+          if (!dyn) {
+            if (deg > 0) mn = s_posted[nb[0]];
+            for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
+          } else {
+            bool any = false;
+            for (int k = 0; k < deg; ++k) {
+              if (!s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
+              const double v = s_posted[nb[(int64_t)k * nBuy]];
+              if (!any || v < mn) { mn = v; any = true; }
+            }
           }
           ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
         }
@@ -359,7 +383,8 @@ size_t phx_stk_rollout_lds(const DevSpec& sp) {
 }
 
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
-  hipLaunchKernelGGL(phx_stk_rollout_kernel, dim3(sp.B), dim3(STKR_NT), phx_stk_rollout_lds(sp), st, sp, io);
+  if (sp.dynamic_graph) hipLaunchKernelGGL(phx_stk_rollout_kernel<true>, dim3(sp.B), dim3(STKR_NT), phx_stk_rollout_lds(sp), st, sp, io);
+  else hipLaunchKernelGGL(phx_stk_rollout_kernel<false>, dim3(sp.B), dim3(STKR_NT), phx_stk_rollout_lds(sp), st, sp, io);
   return hipGetLastError();
 }
 
@@ -381,7 +406,8 @@ __global__ __launch_bounds__(256) void phx_stk_materialise_kernel(const DevSpec 
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
   const size_t lds = (size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 32 + (sp.dynamic_graph ? (size_t)sp.n_conn : 0);
-  hipLaunchKernelGGL(phx_stk_step_kernel, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
+  if (sp.dynamic_graph) hipLaunchKernelGGL(phx_stk_step_kernel<true>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
+  else hipLaunchKernelGGL(phx_stk_step_kernel<false>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   return hipGetLastError();
 }
 
