@@ -129,10 +129,12 @@ template <typename T>
 __device__ __forceinline__ T* fld(const DevSpec& sp, int id) { return (T*)sp.f[id]; }
 
 // XCD-aware workgroup index: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each); mapping id
-// to (id % 8) * n/8 + id / 8 gives every XCD a contiguous range of envs, so that the partial cache lines where
+// to start(id % 8) + id / 8 gives every XCD a contiguous range of envs, so that the partial cache lines where
 // two neighbouring workgroups' output segments meet are merged in one L2 (measured history)
 __device__ __forceinline__ int xcd_block(bool on) {
-  return (on && (gridDim.x & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  if (!on) return (int)blockIdx.x;
+  const unsigned n = gridDim.x, x = blockIdx.x & 7u, q = n >> 3, rem = n & 7u;    // XCD x runs ids x, x + 8, ...
+  return (int)(x * q + (x < rem ? x : rem) + (blockIdx.x >> 3));
 }
 
 // The static topology tables the message handlers walk in dependent chains.  The generic engine

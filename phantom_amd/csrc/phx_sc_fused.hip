@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
 // keeps the lane-per-pair loop and relies on the batch for parallelism (SC256 x B = 8192 gives
 // 6 500 waves).  Per-(stage, shop) mask bits are staged in LDS once per block.
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec sp, const phx_rollout_io io,
-                                                                  const int epb) {
+                                                                  const int epb, const int remap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fl[];   // [n_lists][S]
   const int nS = sp.S, A = sp.A, nL = sp.n_lists;
   for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) {
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
                           (sp.obs_mask[(int64_t)l * A + a_shop] ? 8 : 0) | (sp.rew_mask[(int64_t)l * A + a_shop] ? 16 : 0));
   }
   const int64_t total = (int64_t)sp.B * nS;
-  const int64_t b_first = (int64_t)blockIdx.x * epb;
+  const int64_t b_first = (int64_t)xcd_block(remap != 0) * epb;
   const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
   const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
   const int64_t g = b_first * nS + threadIdx.x;
@@ -653,8 +653,10 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
 
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const int epb = SC_NT / sp.S;
+  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  const int remap = remap_env >= 0 ? remap_env : (sp.B >= 8192 ? 1 : 0);
   hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
-                     (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb);
+                     (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb, remap);
   return hipGetLastError();
 }
 
