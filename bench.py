@@ -159,8 +159,8 @@ def other_configs(device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="sc64")
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,11 +236,15 @@ def main():
     value = N_AGENTS * B * world * K / elapsed
 
     # ---- kernel-level timing for the roofline (HIP events on the launch stream) -------------
-    events = []
-    run(max(K, T), events)
+    # One event pair around a run of full-length launches, divided by their number: the average launch
+    # duration as the stream sees it (an event pair per launch adds ~2 us of marker packets to each).
+    n_full = max(K // T, 1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    run(n_full * T)
+    ev1.record()
     torch.cuda.synchronize()
-    full = [(t, e0.elapsed_time(e1)) for t, e0, e1 in events if t == T]
-    launch_ms = float(np.mean([ms for _, ms in full]))
+    launch_ms = ev0.elapsed_time(ev1) / n_full
     alg = algorithmic_bytes_rollout(B, S, T)
     achieved = alg / (launch_ms * 1e-3) / 1e9
     traffic = None
