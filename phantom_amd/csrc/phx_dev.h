@@ -123,6 +123,7 @@ struct GenArgs {               // arguments of the generic engine kernel
   int32_t resolve_only;         // Network.resolve() alone: no clock tick, no acting, no epilogue
   unsigned long long* timing;   // PHX_TIMING builds only
   int32_t tab_off;              // byte offset of the LDS-staged topology tables (generic engine)
+  int32_t xcd_remap;            // XCD-aware workgroup -> env mapping (xcd_block)
 };
 
 template <typename T>
