@@ -137,6 +137,13 @@ __device__ __forceinline__ int xcd_block(bool on) {
   const unsigned n = gridDim.x, x = blockIdx.x & 7u, q = n >> 3, rem = n & 7u;    // XCD x runs ids x, x + 8, ...
   return (int)(x * q + (x < rem ? x : rem) + (blockIdx.x >> 3));
 }
+// the same with locality groups of gs workgroups (gs consecutive envs ranges per XCD, groups round-robin);
+// gs must divide gridDim.x / 8
+__device__ __forceinline__ int xcd_block_grouped(int gs) {
+  if (gs <= 1 || (gridDim.x % (8u * (unsigned)gs)) != 0u) return (int)blockIdx.x;
+  const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  return (int)((j / (unsigned)gs) * (8u * (unsigned)gs) + x * (unsigned)gs + (j % (unsigned)gs));
+}
 
 // The static topology tables the message handlers walk in dependent chains.  The generic engine
 // stages them in LDS (every env instance of a launch reads the same few cache lines otherwise);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
   // XCD-aware block -> env mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
   // L2; giving XCD x the x-th contiguous eighth of the envs lets the partial cache lines at the boundary of two
   // neighbouring workgroups' trajectory segments merge in ONE L2 instead of reaching HBM from two
-  const int bid = xcd_block(a.xcd_remap != 0);
+  const int bid = a.xcd_remap > 1 ? xcd_block_grouped(a.xcd_remap) : xcd_block(a.xcd_remap != 0);
   const int64_t b_first = (int64_t)bid * a.epb;
   const int64_t b_end = (WIDE || b_first + a.epb < a.B) ? b_first + a.epb : a.B;
   const int nb = (int)(b_end - b_first);
@@ -654,7 +654,7 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const int epb = SC_NT / sp.S;
   static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
-  const int remap = remap_env >= 0 ? remap_env : (sp.B >= 8192 ? 1 : 0);
+  const int remap = remap_env >= 0 ? remap_env : 1;
   hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
                      (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb, remap);
   return hipGetLastError();
@@ -716,10 +716,11 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
                      (size_t)((G + 3) & ~3) * 4 + (size_t)((epb + 3) & ~3) * 12 + (size_t)((sp.S + 4) & ~3) * 4 +
                      (size_t)((sp.S + 3) & ~3) * 4 + 128 + (size_t)(101 + sp.n_tabn + 202) * 4 + 64;
   a.epb = epb; a.TC = TC;
-  // measured (SC64, T = 100): HBM write traffic 90.8 -> 80.8 MB per launch at B = 4096 (the algorithmic 82.3 MB);
-  // time -1.5 % at B = 4096 (not bandwidth-bound there), 0 at 8192, +5 % at 16384, +8 % at 65536
+  // XCD-aware workgroup -> env mapping (xcd_block).  Measured, SC64, T = 100, back-to-back launches: HBM write
+  // traffic 90.8 -> 80.8 MB per launch at B = 4096 (the algorithmic 82.3 MB); +1 % at B = 4096, +5 % at 16384,
+  // +8 % at 65536.  PHX_ROLLOUT_REMAP = 0 identity, 1 contiguous eighths, n > 1 locality groups of n workgroups.
   static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
-  a.xcd_remap = remap_env >= 0 ? remap_env : (sp.B >= 8192 ? 1 : 0);
+  a.xcd_remap = remap_env >= 0 ? remap_env : 1;
   const dim3 grid((sp.B + epb - 1) / epb);
   const bool replay = io.actions != nullptr || io.exo != nullptr;
   const int64_t total = (int64_t)sp.B * sp.S;
