@@ -15,6 +15,10 @@
 // shop's inbox -- is staged through LDS from 16-byte coalesced loads of the exo rows.
 // Results are bit-identical to the generic engine (tests/test_gpu_parity.py).
 #include "phx_dev.h"
+
+#ifndef PHX_STEP_REMAP
+#define PHX_STEP_REMAP 1     // XCD-aware env mapping: SC256-FSM B=8192 step 12.0 -> 10.9 us, SC64 B=65536 13.3 -> 12.7 us, neutral at B=4096 (graph replay)
+#endif
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   // must sit in one workgroup with a barrier between the two.
   extern __shared__ __attribute__((aligned(16))) unsigned char s_exo[];
   const int nS = sp.S, A = sp.A;
-  const int64_t b_first = (int64_t)blockIdx.x * epb;
+  const int64_t b_first = (int64_t)xcd_block(stage_exo >= 0 && PHX_STEP_REMAP) * epb;
   const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
   const int lanes = (int)(b_end - b_first) * nS;
   const bool active = (int)threadIdx.x < lanes;
