@@ -827,7 +827,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask,
                                                        const double* sampler_values, const uint8_t* conn_values,
                                                        float* obs, uint8_t* obs_valid) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = xcd_block(true), tid = threadIdx.x;       // the generic engine's env -> XCD mapping
   if (mask && !mask[b]) return;
   const int A = sp.A, S = sp.S, D = sp.D;
   const Topo tp = topo_env(sp, b);
