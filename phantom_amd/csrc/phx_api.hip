@@ -23,8 +23,6 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st);
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
-hipError_t phx_launch_gen_policy(const DevSpec& sp, int t, const float* actions_in, float* actions, float* action_out, hipStream_t st);
-hipError_t phx_launch_gen_collect(const DevSpec& sp, int t, const phx_step_io& step, const phx_rollout_io& io, uint8_t* done, hipStream_t st);
 hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st);
 size_t phx_stk_rollout_lds(const DevSpec& sp);
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
@@ -643,7 +641,7 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
     HIPCHK(phx_launch_stk_materialise(e->d, st));   // the table and stay on the generic engine from here on
     e->prices_compressed = false; e->use_stk = false;
   }
-  GenArgs g; g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0; g.timing = nullptr;
+  GenArgs g; memset(&g, 0, sizeof g); g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0; g.timing = nullptr; g.roll_t = -1;
 #ifdef PHX_TIMING
   { static unsigned long long* tb = nullptr; static int calls = 0;
     if (!tb) { (void)hipMalloc((void**)&tb, 16 * 8); (void)hipMemset(tb, 0, 16 * 8); }
@@ -681,7 +679,7 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
   }
   GenArgs g; memset(&g, 0, sizeof g);
   g.io.err = err; g.io.msg_log = msg_log; g.io.msg_count = msg_count;
-  g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 1; g.timing = nullptr;
+  g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 1; g.timing = nullptr; g.roll_t = -1;
   int rc = upload_inject(e, st);
   if (rc != PHX_OK) return rc;
   if (e->n_inject) HIPCHK(hipStreamSynchronize(st));
@@ -705,9 +703,9 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return PHX_OK;
   }
   if (!e->use_fused && !(e->use_stk && e->prices_compressed)) {
-    // Launch loop for every other env (any topology of the device kinds, tracking off): per step a
-    // policy kernel, the generic engine, a collect kernel and the masked auto-reset, all stream
-    // ordered, the step-shaped intermediates in the blob's rollout.scratch field.
+    // Launch loop for every other env (any topology of the device kinds, tracking off): per step the
+    // generic engine (policy and trajectory row fused in) and the masked auto-reset, stream ordered,
+    // the step-shaped intermediates in the blob's rollout.scratch field.
     if (!e->d.f[F_ROLLOUT_SCRATCH]) return fail(PHX_EUNSUPPORTED, "phx_rollout: this env switched engines after creation");
     if (e->n_inject) return fail(PHX_EINVAL, "phx_rollout with injected messages pending");
     hipStream_t st = (hipStream_t)stream;
@@ -722,13 +720,12 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     sio.all_terminated = (uint8_t*)(base + gs.all_term); sio.all_truncated = (uint8_t*)(base + gs.all_trunc);
     sio.err = io->err;
     uint8_t* done = (uint8_t*)(base + gs.done);
-    GenArgs g; g.io = sio; g.inject = e->inject_dev; g.n_inject = 0; g.resolve_only = 0; g.timing = nullptr;
-    for (int t = 0; t < io->T; ++t) {
+    GenArgs g; memset(&g, 0, sizeof g); g.io = sio; g.inject = e->inject_dev; g.n_inject = 0; g.resolve_only = 0; g.timing = nullptr;
+    g.roll = *io; g.roll_actions_in = io->actions; g.roll_actions = (float*)(base + gs.actions); g.roll_done = done;
+    for (int t = 0; t < io->T; ++t) {            // two launches per step: engine (policy + step + trajectory row), masked reset
       sio.exo = io->exo ? io->exo + (int64_t)t * e->d.B * e->d.n_exo : nullptr;
-      g.io = sio;
-      HIPCHK(phx_launch_gen_policy(e->d, t, io->actions, (float*)(base + gs.actions), io->action_out, st));
+      g.io = sio; g.roll_t = t;
       HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
-      HIPCHK(phx_launch_gen_collect(e->d, t, sio, *io, done, st));
       HIPCHK(phx_launch_reset(e->d, done, nullptr, nullptr, sio.obs, sio.obs_valid, st));     // the caller's env.reset()
     }
     if (io->last_obs) HIPCHK(phx_launch_gen_last_obs(e->d, sio.obs, io->last_obs, st));

@@ -613,6 +613,27 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     const int s = tp.strat_rank[a];
     live[a] = (g.resolve_only || s < 0) ? 1 : !(term[s] | trunc[s]);
   }
+  if (g.roll_t >= 0) {
+    // the policy of a launch-loop rollout, fused: every strategic agent's action of this tick (random policy = the
+    // agent's word of the tick, rank j mapped onto the kind's action space), recorded in the trajectory whether or not it acts
+    for (int s = tid; s < S; s += NT) {
+      const int a = sp.strat_idx[s], kind = tp.kind[a];
+      bool acts = true;
+      if (sp.env_type == PHX_ENV_STACKELBERG) acts = sp.act_mask[(int64_t)list * A + a] != 0;
+      float action = 0.f;
+      if (acts) {
+        if (g.roll_actions_in) action = g.roll_actions_in[((int64_t)g.roll_t * sp.B + b) * S + s];
+        else {
+          uint32_t j;
+          rng_group_y(sp.seed, sp.env_offset + b, tick, s, 0, 0, &j);
+          action = (kind == PHX_KIND_SELLER || kind == PHX_KIND_ADVERTISER) ? (float)j * (1.0f / 274877.0f)
+                 : kind == PHX_KIND_BUYER ? (j < 137438u ? 1.0f : 0.0f) : rng_j_to_action(j);
+        }
+      }
+      g.roll_actions[(int64_t)b * S + s] = action;
+      g.roll.action_out[((int64_t)g.roll_t * sp.B + b) * S + s] = action;
+    }
+  }
   __syncthreads();
   GTICK(0);
 
@@ -817,6 +838,21 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   GTICK(13);
   strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc);
   GTICK(14);
+  if (g.roll_t >= 0) {                                         // the step's outputs -> trajectory row roll_t
+    __syncthreads();
+    const phx_step_io& st = g.io; const phx_rollout_io& io = g.roll;
+    const uint8_t at = st.all_terminated[b], au = st.all_truncated[b];
+    for (int s = tid; s < S; s += NT) {
+      const int64_t i = (int64_t)b * S + s, o = ((int64_t)g.roll_t * sp.B + b) * S + s;
+      for (int d = 0; d < sp.D; ++d) io.obs[o * sp.D + d] = st.obs[i * sp.D + d];
+      io.reward[o] = (float)st.reward[i];
+      io.terminated[o] = (uint8_t)(st.terminated[i] | at);
+      io.truncated[o] = (uint8_t)(st.truncated[i] | au);
+      if (io.obs_valid) io.obs_valid[o] = st.obs_valid[i];
+      if (io.reward_valid) io.reward_valid[o] = st.reward_valid[i];
+    }
+    if (tid == 0) g.roll_done[b] = (uint8_t)(at | au);
+  }
 #ifdef PHX_TIMING
   if (g.timing && threadIdx.x == 0) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
 #endif
@@ -914,65 +950,15 @@ hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double
 }
 
 // ---- launch-loop rollout for envs without a fused rollout kernel (phx_api.hip: phx_rollout) ------------
-// random policy = the strategic agent's word of the tick (rank j, see the device-RNG definition):
-// ShopAgent / mock agents j * 100 / 274877, Seller price j / 274877, Buyer buys iff j < 137438; on a
-// Stackelberg env only the side that acts takes (and records) an action.
-__global__ void phx_gen_policy_kernel(const DevSpec sp, const int t, const float* actions_in, float* actions,
-                                      float* action_out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)sp.B * sp.S) return;
-  const int b = (int)(i / sp.S), s = (int)(i - (int64_t)b * sp.S);
-  const int a = sp.strat_idx[s], kind = sp.kind[a];
-  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-  bool acts = true;
-  if (sp.env_type == PHX_ENV_STACKELBERG) {
-    const int list = ((fld<int32_t>(sp, F_ENV_STEP)[b] + 1) & 1) ? 0 : 1;
-    acts = sp.act_mask[(int64_t)list * sp.A + a] != 0;
-  }
-  float action = 0.f;
-  if (acts) {
-    if (actions_in) action = actions_in[(int64_t)t * sp.B * sp.S + i];
-    else {
-      uint32_t j;
-      rng_group_y(sp.seed, sp.env_offset + b, tick, s, 0, 0, &j);
-      action = (kind == PHX_KIND_SELLER || kind == PHX_KIND_ADVERTISER) ? (float)j * (1.0f / 274877.0f)
-             : kind == PHX_KIND_BUYER ? (j < 137438u ? 1.0f : 0.0f) : rng_j_to_action(j);
-    }
-  }
-  actions[i] = action;
-  action_out[(int64_t)t * sp.B * sp.S + i] = action;
-}
-// one step's outputs -> trajectory row t; done[b] = the env's episode ended (the caller would reset)
-__global__ void phx_gen_collect_kernel(const DevSpec sp, const int t, const phx_step_io step, const phx_rollout_io io,
-                                       uint8_t* done) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)sp.B * sp.S) return;
-  const int b = (int)(i / sp.S);
-  const int64_t o = (int64_t)t * sp.B * sp.S + i;
-  const uint8_t at = step.all_terminated[b], au = step.all_truncated[b];
-  for (int d = 0; d < sp.D; ++d) io.obs[o * sp.D + d] = step.obs[i * sp.D + d];
-  io.reward[o] = (float)step.reward[i];
-  io.terminated[o] = (uint8_t)(step.terminated[i] | at);
-  io.truncated[o] = (uint8_t)(step.truncated[i] | au);
-  if (io.obs_valid) io.obs_valid[o] = step.obs_valid[i];
-  if (io.reward_valid) io.reward_valid[o] = step.reward_valid[i];
-  if (i - (int64_t)b * sp.S == 0) done[b] = (uint8_t)(at | au);
-}
+// The policy (random: the strategic agent's word of the tick, rank j -- ShopAgent / mock agents j * 100 / 274877,
+// Seller price and Advertiser bid fraction j / 274877, Buyer buys iff j < 137438; on a Stackelberg env only the
+// side that acts takes and records an action) and the copy of a step's outputs into trajectory row t are fused
+// into phx_generic_step_kernel (GenArgs::roll_t >= 0); per step the loop launches the engine and the masked reset.
 __global__ void phx_gen_last_obs_kernel(const int64_t n, const float* obs, float* last_obs) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) last_obs[i] = obs[i];
 }
 
-hipError_t phx_launch_gen_policy(const DevSpec& sp, int t, const float* actions_in, float* actions, float* action_out, hipStream_t st) {
-  const int64_t n = (int64_t)sp.B * sp.S;
-  if (n > 0) hipLaunchKernelGGL(phx_gen_policy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp, t, actions_in, actions, action_out);
-  return hipGetLastError();
-}
-hipError_t phx_launch_gen_collect(const DevSpec& sp, int t, const phx_step_io& step, const phx_rollout_io& io, uint8_t* done, hipStream_t st) {
-  const int64_t n = (int64_t)sp.B * sp.S;
-  if (n > 0) hipLaunchKernelGGL(phx_gen_collect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp, t, step, io, done);
-  return hipGetLastError();
-}
 hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st) {
   const int64_t n = (int64_t)sp.B * sp.S * sp.D;
   if (n > 0) hipLaunchKernelGGL(phx_gen_last_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, obs, last_obs);
