@@ -295,8 +295,8 @@ int  phx_resolve(phx_env* env, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
 /* T consecutive steps with auto-reset at episode end (the list-of-envs loop of
  * utils/rllib/rollout.py:361-363).  Static supply-chain schedules (plain or FSM env) and the static
  * Stackelberg / digital-ads markets run as ONE fused kernel; every other env runs as a stream-ordered
- * launch loop (generic engine with the policy and the trajectory row fused in, masked reset; intermediates
- * in the state blob's "rollout.scratch" field).  PHX_EUNSUPPORTED for envs with PHX_SAMPLER_HOST samplers: the
+ * launch loop (one generic-engine launch per step with the policy, the trajectory row and the reset at an
+ * episode end fused in; intermediates in the state blob's "rollout.scratch" field).  PHX_EUNSUPPORTED for envs with PHX_SAMPLER_HOST samplers: the
  * auto-reset resamples on the device.                                                          */
 int  phx_rollout(phx_env* env, const phx_rollout_io* io, void* stream);
 

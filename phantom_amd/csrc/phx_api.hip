@@ -703,8 +703,8 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return PHX_OK;
   }
   if (!e->use_fused && !(e->use_stk && e->prices_compressed)) {
-    // Launch loop for every other env (any topology of the device kinds, tracking off): per step the
-    // generic engine (policy and trajectory row fused in) and the masked auto-reset, stream ordered,
+    // Launch loop for every other env (any topology of the device kinds, tracking off): per step ONE
+    // launch of the generic engine (policy, trajectory row and auto-reset fused in), stream ordered,
     // the step-shaped intermediates in the blob's rollout.scratch field.
     if (!e->d.f[F_ROLLOUT_SCRATCH]) return fail(PHX_EUNSUPPORTED, "phx_rollout: this env switched engines after creation");
     if (e->n_inject) return fail(PHX_EINVAL, "phx_rollout with injected messages pending");
@@ -719,14 +719,12 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     sio.done_valid = (uint8_t*)(base + gs.done_valid);
     sio.all_terminated = (uint8_t*)(base + gs.all_term); sio.all_truncated = (uint8_t*)(base + gs.all_trunc);
     sio.err = io->err;
-    uint8_t* done = (uint8_t*)(base + gs.done);
     GenArgs g; memset(&g, 0, sizeof g); g.io = sio; g.inject = e->inject_dev; g.n_inject = 0; g.resolve_only = 0; g.timing = nullptr;
-    g.roll = *io; g.roll_actions_in = io->actions; g.roll_actions = (float*)(base + gs.actions); g.roll_done = done;
-    for (int t = 0; t < io->T; ++t) {            // two launches per step: engine (policy + step + trajectory row), masked reset
+    g.roll = *io; g.roll_actions_in = io->actions; g.roll_actions = (float*)(base + gs.actions);
+    for (int t = 0; t < io->T; ++t) {            // one launch per step: policy + step + trajectory row + the caller's reset
       sio.exo = io->exo ? io->exo + (int64_t)t * e->d.B * e->d.n_exo : nullptr;
       g.io = sio; g.roll_t = t;
       HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
-      HIPCHK(phx_launch_reset(e->d, done, nullptr, nullptr, sio.obs, sio.obs_valid, st));     // the caller's env.reset()
     }
     if (io->last_obs) HIPCHK(phx_launch_gen_last_obs(e->d, sio.obs, io->last_obs, st));
     return PHX_OK;

@@ -124,13 +124,12 @@ struct GenArgs {               // arguments of the generic engine kernel
   unsigned long long* timing;   // PHX_TIMING builds only
   int32_t tab_off;              // byte offset of the LDS-staged topology tables (generic engine)
   int32_t xcd_remap;            // XCD-aware workgroup -> env mapping (xcd_block)
-  // launch-loop rollout (phx_rollout on the generic engine): the policy and the trajectory row of step
-  // roll_t are fused into the step kernel (roll_t < 0: a plain phx_step)
+  // launch-loop rollout (phx_rollout on the generic engine): the policy, the trajectory row of step roll_t and
+  // the caller's reset at an episode end are fused into the step kernel (roll_t < 0: a plain phx_step)
   int32_t roll_t;
   const float* roll_actions_in; // [T][B][S] replayed policy or NULL -> random policy
   float* roll_actions;          // [B][S] scratch the acting phase reads (= io.actions)
   phx_rollout_io roll;
-  uint8_t* roll_done;           // [B] episode ended: the masked reset that follows
 };
 
 template <typename T>

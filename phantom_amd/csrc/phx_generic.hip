@@ -543,6 +543,54 @@ __device__ __forceinline__ void adx_coop_emit(const DevSpec& sp, const Topo& tp,
   }
 }
 
+// ---- PhantomEnv.reset of env b by its workgroup (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109):
+// the body of phx_reset_kernel, also the tail of a launch-loop rollout step whose episode ended.
+// Contains __syncthreads(): call it from uniform control flow.
+template <int NT>
+__device__ __forceinline__ void reset_env(const DevSpec& sp, const int b, const double* sampler_values, const uint8_t* conn_values,
+                                          float* obs, uint8_t* obs_valid) {
+  const int tid = threadIdx.x;
+  const int A = sp.A, S = sp.S, D = sp.D;
+  const Topo tp = topo_env(sp, b);
+  if (sp.n_samplers > 0 || sp.n_conn > 0) {                             // env.py:211-218
+    const uint32_t ep = (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b];
+    if (sp.n_samplers > 0) {
+      double* sv = fld<double>(sp, F_ENV_SAMPLER) + (int64_t)b * sp.n_samplers;
+      for (int j = tid; j < sp.n_samplers; j += NT) sv[j] = dev_sample_column(sp, b, j, ep, sampler_values, sv[j]);
+    }
+    if (sp.n_conn > 0) {                                                // resample_connectivity network.py:438-447
+      uint8_t* cv = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
+      for (int i = tid; i < sp.n_conn; i += NT)
+        cv[i] = conn_values ? (conn_values[(int64_t)b * sp.n_conn + i] != 0)
+                            : (uint8_t)rng_connection(sp.seed, sp.env_offset + b, ep, i, sp.conn_rate[i]);
+    }
+    __syncthreads();
+    if (tid == 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)(ep + 1);
+  }
+  for (int a = tid; a < A; a += NT) dev_agent_reset(sp, tp, b, a);          // network.py:183-184
+  for (int s = tid; s < S; s += NT) {
+    fld<uint8_t>(sp, F_ENV_TERM)[(int64_t)b * S + s] = 0;               // env.py:223-224
+    fld<uint8_t>(sp, F_ENV_TRUNC)[(int64_t)b * S + s] = 0;
+    if (sp.env_type != PHX_ENV_PLAIN) fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[(int64_t)b * S + s] = 0;
+    if (obs_valid) obs_valid[(int64_t)b * S + s] = 0;
+    if (obs) for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = 0.f;
+  }
+  if (tid == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = 0;                                // env.py:209
+    if (sp.env_type == PHX_ENV_FSM) fld<int32_t>(sp, F_ENV_STAGE)[b] = sp.initial_stage;   // fsm.py:217
+  }
+  __syncthreads();
+  if (!obs) return;
+  for (int k = tid; k < sp.n_reset_obs; k += NT) {                      // env.py:227-237
+    const int a = sp.reset_obs_idx[k], s = tp.strat_rank[a];
+    if (s < 0) continue;
+    float ob[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool v = dev_encode_obs(sp, tp, b, a, 0, ob);              // `if v is not None` env.py:237
+    for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = v ? ob[d] : 0.f;
+    if (obs_valid) obs_valid[(int64_t)b * S + s] = v ? 1 : 0;
+  }
+}
+
 template <int NT, bool LDSQ, bool TABLDS>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, const GenArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -851,7 +899,10 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
       if (io.obs_valid) io.obs_valid[o] = st.obs_valid[i];
       if (io.reward_valid) io.reward_valid[o] = st.reward_valid[i];
     }
-    if (tid == 0) g.roll_done[b] = (uint8_t)(at | au);
+    if (at | au) {                                             // the caller's env.reset(), same launch
+      __syncthreads();
+      reset_env<NT>(sp, b, nullptr, nullptr, st.obs, st.obs_valid);
+    }
   }
 #ifdef PHX_TIMING
   if (g.timing && threadIdx.x == 0) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
@@ -863,47 +914,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask,
                                                        const double* sampler_values, const uint8_t* conn_values,
                                                        float* obs, uint8_t* obs_valid) {
-  const int b = xcd_block(true), tid = threadIdx.x;       // the generic engine's env -> XCD mapping
+  const int b = xcd_block(true);                           // the generic engine's env -> XCD mapping
   if (mask && !mask[b]) return;
-  const int A = sp.A, S = sp.S, D = sp.D;
-  const Topo tp = topo_env(sp, b);
-  if (sp.n_samplers > 0 || sp.n_conn > 0) {                             // env.py:211-218
-    const uint32_t ep = (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b];
-    if (sp.n_samplers > 0) {
-      double* sv = fld<double>(sp, F_ENV_SAMPLER) + (int64_t)b * sp.n_samplers;
-      for (int j = tid; j < sp.n_samplers; j += NT) sv[j] = dev_sample_column(sp, b, j, ep, sampler_values, sv[j]);
-    }
-    if (sp.n_conn > 0) {                                                // resample_connectivity network.py:438-447
-      uint8_t* cv = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
-      for (int i = tid; i < sp.n_conn; i += NT)
-        cv[i] = conn_values ? (conn_values[(int64_t)b * sp.n_conn + i] != 0)
-                            : (uint8_t)rng_connection(sp.seed, sp.env_offset + b, ep, i, sp.conn_rate[i]);
-    }
-    __syncthreads();
-    if (tid == 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)(ep + 1);
-  }
-  for (int a = tid; a < A; a += NT) dev_agent_reset(sp, tp, b, a);          // network.py:183-184
-  for (int s = tid; s < S; s += NT) {
-    fld<uint8_t>(sp, F_ENV_TERM)[(int64_t)b * S + s] = 0;               // env.py:223-224
-    fld<uint8_t>(sp, F_ENV_TRUNC)[(int64_t)b * S + s] = 0;
-    if (sp.env_type != PHX_ENV_PLAIN) fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[(int64_t)b * S + s] = 0;
-    if (obs_valid) obs_valid[(int64_t)b * S + s] = 0;
-    if (obs) for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = 0.f;
-  }
-  if (tid == 0) {
-    fld<int32_t>(sp, F_ENV_STEP)[b] = 0;                                // env.py:209
-    if (sp.env_type == PHX_ENV_FSM) fld<int32_t>(sp, F_ENV_STAGE)[b] = sp.initial_stage;   // fsm.py:217
-  }
-  __syncthreads();
-  if (!obs) return;
-  for (int k = tid; k < sp.n_reset_obs; k += NT) {                      // env.py:227-237
-    const int a = sp.reset_obs_idx[k], s = tp.strat_rank[a];
-    if (s < 0) continue;
-    float ob[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool v = dev_encode_obs(sp, tp, b, a, 0, ob);              // `if v is not None` env.py:237
-    for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = v ? ob[d] : 0.f;
-    if (obs_valid) obs_valid[(int64_t)b * S + s] = v ? 1 : 0;
-  }
+  reset_env<NT>(sp, b, sampler_values, conn_values, obs, obs_valid);
 }
 
 // ---- launchers (called from phx_api.hip) -----------------------------------------------------
