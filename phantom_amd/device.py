@@ -109,6 +109,7 @@ class DeviceEnv:
             total += (n + 255) & ~255
         self._out_flat = z(total, dtype=torch.uint8)
         self._out_host = None
+        self._rollout_io_cache = {}
         for name, shape, dtype, off, n in self._out_layout:
             setattr(self, name, self._out_flat[off:off + n].view(dtype).view(*shape))
         self.ones_valid = None
@@ -262,23 +263,32 @@ class DeviceEnv:
         B, S, D = self.B, self.S, self.D
         if out is None:
             out = self.alloc_trajectory(T)
-        io = _abi.PhxRolloutIO()
-        io.T = T
-        if actions is not None:
-            assert actions.dtype == torch.float32 and actions.shape == (T, B, S) and actions.is_contiguous()
-            io.actions = actions.data_ptr()
-        if exo is not None:
-            assert exo.dtype == torch.uint8 and exo.shape == (T, B, self.n_exo) and exo.is_contiguous()
-            io.exo = exo.data_ptr()
-        io.obs, io.action_out, io.reward = (out.observations.data_ptr(), out.actions.data_ptr(),
-                                            out.rewards.data_ptr())
-        io.terminated, io.truncated = out.terminations.data_ptr(), out.truncations.data_ptr()
-        io.last_obs = out.last_obs.data_ptr()
-        if out.obs_valid is not None:
-            io.obs_valid, io.reward_valid = out.obs_valid.data_ptr(), out.reward_valid.data_ptr()
-        io.err = self.err.data_ptr()
-        with torch.cuda.device(self.device):
-            self._check(self.lib.phx_rollout(self.handle, C.byref(io), self._stream()), "phx_rollout")
+        # the argument block of a repeated call (same fragment buffers, same replay tensors) is built once
+        key = (T, id(out), None if actions is None else actions.data_ptr(), None if exo is None else exo.data_ptr())
+        cached = self._rollout_io_cache.get(key)
+        if cached is None:
+            io = _abi.PhxRolloutIO()
+            io.T = T
+            if actions is not None:
+                assert actions.dtype == torch.float32 and actions.shape == (T, B, S) and actions.is_contiguous()
+                io.actions = actions.data_ptr()
+            if exo is not None:
+                assert exo.dtype == torch.uint8 and exo.shape == (T, B, self.n_exo) and exo.is_contiguous()
+                io.exo = exo.data_ptr()
+            assert out.observations.shape[0] >= T
+            io.obs, io.action_out, io.reward = (out.observations.data_ptr(), out.actions.data_ptr(),
+                                                out.rewards.data_ptr())
+            io.terminated, io.truncated = out.terminations.data_ptr(), out.truncations.data_ptr()
+            io.last_obs = out.last_obs.data_ptr()
+            if out.obs_valid is not None:
+                io.obs_valid, io.reward_valid = out.obs_valid.data_ptr(), out.reward_valid.data_ptr()
+            io.err = self.err.data_ptr()
+            if len(self._rollout_io_cache) > 64:
+                self._rollout_io_cache.clear()
+            cached = self._rollout_io_cache[key] = (io, C.byref(io), out, actions, exo)   # keeps the tensors alive
+        rc = self.lib.phx_rollout(self.handle, cached[1], self._stream())        # the library selects its device itself
+        if rc != 0:
+            self._check(rc, "phx_rollout")
         return out
 
     def inject(self, messages: List[Message]):
