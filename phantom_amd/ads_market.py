@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _abi
 from .agents import Agent, Box, StrategicAgent
+from .views import AgentView
 from .fsm import FiniteStateMachineEnv, FSMStage
 from .message import Ads, AuctionResult, Bid, ImpressionRequest, ImpressionResult  # noqa: F401
 from .network import StochasticNetwork
@@ -27,6 +28,21 @@ def _theme_index(theme: str) -> int:
     if theme not in THEMES:
         raise ValueError(f"theme '{theme}' is not one of {THEMES} (the click table's keys)")
     return THEMES.index(theme)
+
+
+USERS_INFO = {1: {"age": 18, "zipcode": 94025}, 2: {"age": 40, "zipcode": 90250}}      # AdExchangeAgent.view :407-410
+
+
+def _lookup_user(user, field):
+    if isinstance(user, np.ndarray):
+        return np.array([USERS_INFO[int(u)][field] if int(u) in USERS_INFO else 0.0 for u in user])
+    return USERS_INFO[int(user)][field] if int(user) in USERS_INFO else 0.0
+
+
+@dataclass(frozen=True)
+class AdExchangeView(AgentView):
+    """digital_ads_market.py:383-393: what the exchange exposes to its advertisers."""
+    users_info: dict
 
 
 class PublisherAgent(Agent):
@@ -74,6 +90,16 @@ class AdvertiserAgent(StrategicAgent):
     def device_params(self, index_of):
         return (index_of(self.exchange_id), _theme_index(self.theme), 0), (0.0,)   # pi2, pf0: compile_spec
 
+    # handle_impression_request also caches the user's age / zipcode from the exchange's view (:261-266);
+    # the shipped observation does not use them (commented out there), so they are derived on the host
+    @property
+    def _current_age(self):
+        return _lookup_user(self._current_user_id, "age")
+
+    @property
+    def _current_zipcode(self):
+        return _lookup_user(self._current_user_id, "zipcode")
+
     @staticmethod
     def format_observation(row: np.ndarray) -> Dict:
         """the Dict observation of :294-316 from the device row (budget_left was computed in the
@@ -95,6 +121,12 @@ class AdExchangeAgent(Agent):
         self.publisher_id = publisher_id
         self.advertiser_ids = list(advertiser_ids)
         self.strategy = strategy
+
+    def view(self, neighbour_id=None):
+        """:399-413: advertisers (ids starting with "ADV") get the users' info, everybody else nothing."""
+        if neighbour_id and str(neighbour_id).startswith("ADV"):
+            return AdExchangeView(users_info=USERS_INFO)
+        return super().view(neighbour_id)
 
     def device_params(self, index_of):
         for aid in self.advertiser_ids:

@@ -971,6 +971,7 @@ def test_digital_ads_env_python_surface():
     assert step.rewards == {aid: None for aid in env.strategic_agent_ids}   # fsm.py:234,378: nothing cached yet
     user = env["ADV_1"]._current_user_id
     assert user in (1, 2) and int(env["ADV_1"].total_requests[user]) == 1
+    assert env["ADV_1"]._current_age == {1: 18, 2: 40}[user] and env["ADX"].view("ADV_1").users_info[2]["zipcode"] == 90250
     step = env.step({aid: np.array([0.5], np.float32) for aid in env.strategic_agent_ids})
     lefts = [env[aid].left for aid in env.strategic_agent_ids]
     wins = [env[aid].step_wins for aid in env.strategic_agent_ids]
