@@ -978,6 +978,10 @@ def test_digital_ads_env_python_surface():
     assert sum(wins) == 1 and wins[1] == 1                                # ADV_2 bids 0.5 * 2.0, the highest
     assert lefts[1] == float(np.float32(2.0) - np.float32(1.0)) and lefts[0] == 1.5
     assert env["ADV_2"].bid == 1.0 and step.observations == {}           # publishers act next: nobody observes
+    # the example's metrics (:603-713) reflect on agent attributes: SimpleAgentMetric(aid, "left", "mean") etc.
+    assert ph.metrics.SimpleAgentMetric("ADV_2", "left", "mean").extract(env) == lefts[1]
+    assert ph.metrics.SimpleAgentMetric("ADV_2", "step_wins", "mean").extract(env) == 1
+    assert int(env["ADV_2"].total_wins[user]) == 1 and int(env["ADV_1"].total_wins[user]) == 0
     # device-policy rollout (launch loop: FSM env on the generic engine) against the oracle
     env2 = ph.DigitalAdsEnv(num_steps=8, num_agents_theme={"travel": 2, "tech": 1, "sport": 1}, agent_supertypes=st,
                             seed=3, batch_size=16, connection_rates=(1.0, 0.8, 0.9))
