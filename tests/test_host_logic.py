@@ -403,3 +403,33 @@ def test_ads_market_spec_compiles_like_the_example():
         ph.compile_spec(net, num_steps=1)
     with pytest.raises(ValueError):
         ph.AdvertiserAgent("A", "ADX", theme="generic").device_params(lambda x: 0)    # not a key of the click table
+
+
+def test_spec_validation_through_the_abi_without_gpu():
+    """derive() rejects what the device path cannot represent: a directed (asymmetric) CSR, duplicate
+    edges, more customers per shop than the RNG counter layout holds; message text via phx_last_error."""
+    lib = _abi.load_library()
+    env = ph.SupplyChainEnv(n_shops=2, customers_per_shop=2, batch_size=4)
+    spec = env.spec
+    cs, keep = spec.to_ctypes()
+    assert lib.phx_state_nbytes(ctypes.byref(cs)) > 0
+    col = spec.col.copy()
+    # drop the mirror of the first edge: agent 0 (SHOP0) -> factory stays, factory -> SHOP0 is redirected
+    a0, f = 0, int(spec.col[spec.row_ptr[0]])
+    lo, hi = spec.row_ptr[f], spec.row_ptr[f + 1]
+    k = lo + int(np.flatnonzero(spec.col[lo:hi] == a0)[0])
+    col[k] = f                                               # a self-loop instead of the mirror edge
+    spec2 = type(spec)(**{**spec.__dict__, "col": col})
+    cs2, keep2 = spec2.to_ctypes()
+    assert lib.phx_state_nbytes(ctypes.byref(cs2)) < 0
+    assert b"mirror" in lib.phx_last_error() or b"duplicate" in lib.phx_last_error()
+    # an AdvertiserAgent without a budget has no type_src: EINVAL
+    net = ph.StochasticNetwork([ph.AdExchangeAgent("ADX", "PUB", ["A1"]), ph.PublisherAgent("PUB", "ADX"),
+                                ph.AdvertiserAgent("A1", "ADX", "tech", supertype=ph.AdvertiserAgent.Supertype(budget=1.0))])
+    net.add_connections_between(["ADX"], ["PUB", "A1"]); net.add_connection("PUB", "A1")
+    s3 = ph.compile_spec(net, num_steps=4)
+    cs3, keep3 = s3.to_ctypes()
+    assert lib.phx_state_nbytes(ctypes.byref(cs3)) > 0
+    s3.type_src[:] = _abi.TYPE_NONE
+    cs3, keep3 = s3.to_ctypes()
+    assert lib.phx_state_nbytes(ctypes.byref(cs3)) < 0 and b"budget" in lib.phx_last_error()
