@@ -6,11 +6,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one PhantomEnv.step() of every env instance of the batch.  The timed region runs K
-steps as fused on-device rollouts (phx_rollout, T=100 = one episode per launch; every step's
-observation, action, reward and done flags are written to the trajectory buffer in HBM) with
-inputs/state already resident in HBM, bracketed by barrier + synchronize, max over ranks.
-value = A * B_total * K / time  (agent-steps/s, whole job).  The per-launch PhantomEnv.step
+A "step" is one PhantomEnv.step() of every env instance of the batch.  The timed region runs the
+K-step region R times back to back (R chosen so that it lasts >= 50 ms; printed as "repeats") as
+fused on-device rollouts (phx_rollout, T=100 = one episode per launch; every step's observation,
+action, reward and done flags are written to the trajectory buffer in HBM) with inputs/state
+already resident in HBM, bracketed by barrier + synchronize, max over ranks.
+value = A * B_total * R * K / time  (agent-steps/s, whole job); ms_per_step = time / (R * K).
+`--gpus N` without a torchrun environment re-executes itself under torch.distributed.run.  The per-launch PhantomEnv.step
 mode (one kernel per step) is measured right after and reported under "per_step".
 
 Extra objects on the JSON line:
@@ -156,6 +158,25 @@ def other_configs(device):
     return res
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_spawn(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: re-exec this script under
+    torch.distributed.run, one rank per GPU over RCCL, and pass its output (rank 0's JSON line) through."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,25 +184,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="sc64")
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's)")
+    ap.add_argument("--min-region-ms", type=float, default=50.0,
+                    help="the K-step region is repeated back to back until the timed region lasts at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the PhantomEnv.step() path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PHX_BENCH_FORCE_DIST"):
         # one process per GPU over RCCL (backend "nccl" on ROCm); also taken with a single rank
-        # under torchrun so that the collective path can be exercised on a 1-GPU box
+        # (torchrun with one process, or PHX_BENCH_FORCE_DIST=1) so that the collective path can be
+        # exercised on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -191,6 +218,8 @@ def main():
     N_SHOPS, CUST_PER_SHOP, default_batch = CONFIGS[args.config]
     N_AGENTS = 1 + N_SHOPS + N_SHOPS * CUST_PER_SHOP
     B, S, K, W = args.batch or default_batch, N_SHOPS, args.steps, args.warmup
+    if K < 1:
+        raise SystemExit("--steps must be >= 1")
     # one process per GPU owns envs [rank*B, (rank+1)*B); the RNG is keyed by the GLOBAL env
     # index so results do not depend on the number of GPUs.  No collective inside a step.
     env = ph.SupplyChainEnv(n_shops=N_SHOPS, customers_per_shop=CUST_PER_SHOP, num_steps=NUM_STEPS,
@@ -201,20 +230,10 @@ def main():
     env.reset()
     T = NUM_STEPS
     traj = dev.rollout(T)                                   # allocates the trajectory buffers once
-    frags = lambda n: [T] * (n // T) + ([n % T] if n % T else [])
 
-    def run(n, events=None):
-        for t in frags(n):
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if t == T:
-                dev.rollout(T, out=traj)
-            else:
-                dev.rollout(t, out=type(traj)(*[x[:t] for x in traj[:5]], traj.last_obs))
-            if events is not None:
-                e1.record()
-                events.append((t, e0, e1))
+    def launches(n):                                        # n full-length fragments, back to back
+        for _ in range(n):
+            dev.rollout(T, out=traj)
 
     def sync_barrier():
         torch.cuda.synchronize()
@@ -222,36 +241,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(W)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # The env steps as a continuous stream (auto-reset at every episode end), issued as fragments of T = 100
+    # steps per launch.  A K-step region shorter than ~50 ms would time launch + sync latency, not the path
+    # (K = 20 is ONE 8 us slice): the region is therefore repeated R times back to back, R the smallest
+    # count that makes R*K a whole number of fragments and the timed region >= --min-region-ms; the line
+    # reports steps = K, repeats = R and ms_per_step = elapsed / (R*K).  Warm-up: W steps rounded up to whole
+    # fragments (at least 20 fragments, which also calibrates R -- identically on every rank).
+    import math
+    n_warm = max(20, -(-W // T))
+    launches(n_warm)
+    sync_barrier()
+    t0 = time.perf_counter(); launches(20); torch.cuda.synchronize()
+    per_launch = max_over_ranks((time.perf_counter() - t0) / 20)
+    unit = T // math.gcd(K, T)                              # repeats per whole number of fragments
+    R = max(1, math.ceil(args.min_region_ms * 1e-3 / per_launch * T / K))
+    R = -(-R // unit) * unit
+    n_launch = R * K // T
     sync_barrier()
     t0 = time.perf_counter()
-    run(K)
-    torch.cuda.synchronize()                 # this rank's K steps are done ...
+    launches(n_launch)
+    torch.cuda.synchronize()                 # this rank's R*K steps are done ...
     elapsed = time.perf_counter() - t0
     sync_barrier()                           # ... all ranks are; the job's time is the MAX over ranks
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    value = N_AGENTS * B * world * K / elapsed
+    elapsed = max_over_ranks(elapsed)
+    value = N_AGENTS * B * world * (R * K) / elapsed
 
     # ---- kernel-level timing for the roofline (HIP events on the launch stream) -------------
-    # One event pair around a run of full-length launches, divided by their number: the average launch
-    # duration as the stream sees it (an event pair per launch adds ~2 us of marker packets to each).
-    n_full = max(K // T, 1)
+    # ONE event pair around >= 200 full-length launches (independent of K), divided by their number: the
+    # average launch duration as the stream sees it, which is what the rocprofv3 kernel trace in profiles/
+    # averages too (an event pair per launch would add ~2 us of marker packets to each interval).
+    n_full = 200
+    launches(10)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
-    run(n_full * T)
+    launches(n_full)
     ev1.record()
     torch.cuda.synchronize()
     launch_ms = ev0.elapsed_time(ev1) / n_full
     alg = algorithmic_bytes_rollout(B, S, T)
     achieved = alg / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and args.config == "sc64" and B == BATCH:
         try:
-            traffic = json.load(open(pmc)).get("phx_sc_rollout_kernel", {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc)).get("phx_sc_rollout_kernel", {})
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command: " + \
+                str(rec.get("source", "see file")) + "); not re-measured by this run"
         except Exception:
             traffic = None
     # achievable write bandwidth of this box for a buffer of the trajectory's size (a plain fill)
@@ -268,13 +311,13 @@ def main():
     del fill_buf
     roofline = {"bound": "hbm", "kernel": "phx_sc_rollout_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                "launch_ms": launch_ms, "launch": f"T={T} steps x B={B} envs",
+                "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg,
+                "launch_ms": launch_ms, "launches_timed": n_full, "launch": f"T={T} steps x B={B} envs",
                 "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs}
 
     out = {
         "metric": "agent_steps_per_sec", "value": value, "unit": "agent-steps/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / (R * K) * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i32", "data": "synthetic",
         "config": {"workload": f"supply-chain {args.config.upper()} (1 factory + {N_SHOPS} shops + "
@@ -283,13 +326,18 @@ def main():
                                "fused on-device rollout T=100 with full trajectory written to HBM",
                    "agents": N_AGENTS, "envs_per_gpu": B, "global_envs": B * world,
                    "num_steps": NUM_STEPS, "mode": "phx_rollout", "sharding": f"env-batch x{world}, no step-time collective"},
-        "env_steps_per_sec": B * world * K / elapsed,
+        "repeats": R, "timed_steps": R * K, "timed_launches": n_launch, "timed_region_ms": elapsed * 1e3,
+        "warmup_launches": n_warm,
+        "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} fragments of {T} steps; "
+                       "ms_per_step = timed_region_ms / (repeats * steps)",
+        "env_steps_per_sec": B * world * (R * K) / elapsed,
+        "rccl_ranks_seen": (dist.get_world_size() if dist is not None else 0),
         "roofline": roofline,
     }
 
     # ---- per-launch PhantomEnv.step mode (one kernel launch per step) ---------------------------
     if not args.no_per_step:
-        ksteps = min(K, 1000)
+        ksteps = 1000
         acts = torch.rand(ksteps, B, S, device=dev.device) * 100.0
         env.reset()
         for i in range(20):
@@ -302,8 +350,8 @@ def main():
         e1.record()
         sync_barrier()
         dt = time.perf_counter() - t0
-        # kernel-only duration: same launches captured in a hipGraph-free tight loop is host
-        # bound, so the kernel time is taken from a second pass with per-launch events
+        # kernel-only duration: the tight loop above is host bound, so the kernel time is taken from a
+        # second pass with per-launch events
         evs = []
         for i in range(200):
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -311,22 +359,18 @@ def main():
         torch.cuda.synchronize()
         kms = float(np.median([a.elapsed_time(b_) for a, b_ in evs]))
         alg_s = algorithmic_bytes_step(B, S, CUST_PER_SHOP, device_rng=True)
-        # the same per-step launches captured once into a hipGraph (100 steps per replay)
+        # the same per-step launches captured once into a hipGraph (DeviceEnv.step_graph: 100 steps per replay)
         graph_us = None
         try:
-            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=side):
-                for i in range(100):
-                    dev.step(acts[i % ksteps])
+            sg = dev.step_graph(acts[:100])
             for _ in range(3):
-                g.replay()
+                sg.replay()
             torch.cuda.synchronize()
             tg = time.perf_counter()
-            for _ in range(10):
-                g.replay()
+            for _ in range(20):
+                sg.replay()
             torch.cuda.synchronize()
-            graph_us = (time.perf_counter() - tg) / 1000 * 1e6
+            graph_us = (time.perf_counter() - tg) / 2000 * 1e6
         except Exception as e:                                   # report, do not hide
             graph_us = f"capture failed: {e}"
         out["per_step"] = {"value": N_AGENTS * B * world * ksteps / dt, "unit": "agent-steps/s",
@@ -341,37 +385,18 @@ def main():
 
     # ---- rollout collection exchange (BASELINE config 4's RCCL all-gather), outside `value` ------
     if dist is not None:
-        from phantom_amd.distributed import all_gather_trajectory
-        payload = [traj.observations, traj.actions, traj.rewards, traj.terminations, traj.truncations]
-        outs = all_gather_trajectory(payload)                  # allocates [world, T, B, ...] once
-        sync_barrier()
-        t0 = time.perf_counter()
-        all_gather_trajectory(payload, out=outs)
-        sync_barrier()
-        ag = time.perf_counter() - t0
-        assert torch.equal(outs[0][rank], payload[0])            # own shard lands in its slot
-        nbytes = sum(x.numel() * x.element_size() for x in payload)
-        out["rollout_allgather"] = {"ms": ag * 1e3, "bytes_per_rank": nbytes,
-                                    "recv_GBps_per_rank": nbytes * (world - 1) / ag / 1e9,
-                                    "note": "one T=100 fragment, RCCL all_gather; not in `value`"}
-        # produce + collect, pipelined: chunk c is gathered on a side stream while chunk c+1 rolls out
-        from phantom_amd.distributed import device_env_collector
-        col = device_env_collector(dev, T)                     # chunking by bytes (auto_chunk)
-        col.collect(); sync_barrier()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            col.collect()
-        sync_barrier()
-        pc = (time.perf_counter() - t0) / reps
-        out["rollout_allgather"]["pipelined_rollout_plus_gather_ms"] = pc * 1e3
-        out["rollout_allgather"]["pipelined_agent_steps_per_sec"] = N_AGENTS * B * world * T / pc
-        out["rollout_allgather"]["pipeline"] = (f"{col.n_chunks} chunk(s) of {col.chunk} steps, "
-                                                 "2 staging buffers, gather on a side stream")
+        out["rollout_allgather"] = bench_collection(dist, dev, traj, T, B, world, rank, sync_barrier,
+                                                    max_over_ranks, N_AGENTS)
+        if args.config == "sc64":
+            # BASELINE config 4, one GPU's share: SC256 (1 + 51 + 204), B = 8192 per GPU, plain env, T = 100 fused
+            # rollouts; throughput with the trajectory all-gather excluded and included
+            del traj
+            torch.cuda.empty_cache()
+            out["config4_share"] = bench_config4(ph, dist, world, rank, local_rank, sync_barrier, max_over_ranks)
 
     # ---- BASELINE.json configs 3-5 on this GPU (parity-test cases; reported for orientation only) ------
     if rank == 0 and world == 1 and args.config == "sc64" and not args.no_other_configs:
-        del traj
+        traj = None
         torch.cuda.empty_cache()
         out["other_configs"] = other_configs(f"cuda:{local_rank}")
 
@@ -381,6 +406,76 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_collection(dist, dev, traj, T, B, world, rank, sync_barrier, max_over_ranks, n_agents):
+    """rollout collection of one T-step fragment: ONE flat RCCL all-gather (payload without the
+    all-zero `terminated` plane, `truncated` bit-packed), and the produce + collect pipeline."""
+    from phantom_amd.distributed import TrajectoryGather, device_env_collector
+    tg = TrajectoryGather(dev, traj)
+    tg.gather(); sync_barrier()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tg.gather()
+    sync_barrier()
+    ag = max_over_ranks((time.perf_counter() - t0) / reps)
+    got = tg.unpack(rank)
+    assert torch.equal(got.observations, traj.observations) and torch.equal(got.truncations, traj.truncations)
+    res = {"ms": ag * 1e3, "bytes_per_rank": tg.nbytes, "raw_trajectory_bytes_per_rank": tg.raw_nbytes,
+           "recv_GBps_per_rank": tg.nbytes * (world - 1) / ag / 1e9,
+           "per_link_GBps_if_direct": tg.nbytes / ag / 1e9,
+           "payload": tg.describe(),
+           "note": "one T=100 fragment, one all_gather_into_tensor over RCCL; not in `value`"}
+    # produce + collect, pipelined: chunk c is gathered on a side stream while chunk c+1 rolls out
+    col = device_env_collector(dev, T)                     # chunking by bytes (auto_chunk)
+    col.collect(); sync_barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        col.collect()
+    sync_barrier()
+    pc = max_over_ranks((time.perf_counter() - t0) / reps)
+    res["pipelined_rollout_plus_gather_ms"] = pc * 1e3
+    res["pipelined_agent_steps_per_sec"] = n_agents * B * world * T / pc
+    res["pipeline"] = f"{col.n_chunks} chunk(s) of {col.chunk} steps, 2 staging buffers, gather on a side stream"
+    return res
+
+
+def bench_config4(ph, dist, world, rank, local_rank, sync_barrier, max_over_ranks):
+    from phantom_amd.distributed import device_env_collector
+    nS, nK, Bc, T = 51, 4, 8192, 100
+    A = 1 + nS + nS * nK
+    env = ph.SupplyChainEnv(n_shops=nS, customers_per_shop=nK, num_steps=T, batch_size=Bc, seed=42,
+                            env_offset=rank * Bc, exogenous="device", device=f"cuda:{local_rank}")
+    env.reset(); dev = env._device()
+    tr = dev.rollout(T)
+    for _ in range(3):
+        dev.rollout(T, out=tr)
+    sync_barrier()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        dev.rollout(T, out=tr)
+    torch.cuda.synchronize()
+    dt = max_over_ranks((time.perf_counter() - t0) / n)
+    sync_barrier()
+    res = {"workload": f"SC256 plain env, B={Bc} per GPU x {world} GPUs (global {Bc * world}), T={T} fused rollouts",
+           "rollout_ms_per_fragment": dt * 1e3,
+           "agent_steps_per_sec_gather_excluded": A * Bc * world * T / dt}
+    del tr
+    torch.cuda.empty_cache()
+    col = device_env_collector(dev, T, chunk=10)           # 10-step chunks (~92 MB per rank), SURVEY 8e (i)
+    col.collect(); sync_barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        col.collect()
+    sync_barrier()
+    pc = max_over_ranks((time.perf_counter() - t0) / 3)
+    res["rollout_plus_allgather_ms_per_fragment"] = pc * 1e3
+    res["agent_steps_per_sec_gather_included"] = A * Bc * world * T / pc
+    res["gather_bytes_per_rank"] = col.nbytes * col.n_chunks
+    res["pipeline"] = f"{col.n_chunks} chunks of {col.chunk} steps on a side stream, payload: {col.payload}"
+    return res
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 3
+#define PHX_ABI_VERSION 4
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -243,6 +243,11 @@ typedef struct phx_rollout_io {
   uint8_t*  reward_valid;      /* [T][B][S] or NULL: 0 absent, 1 value, 2 None (FSM envs)      */
   float*    last_obs;          /* [B][S][D]     observation the next fragment starts from   */
   int32_t*  err;               /* [B]                                                       */
+  /* ABI 4: Resolver.tracked_messages of every step of the fragment (rollout.py:369-373,
+   * record_messages=True).  Needs trace_cap > 0 (tracking on, which keeps the env on the
+   * generic engine's launch loop); both NULL = not recorded.                               */
+  phx_msg_rec* msg_log;        /* [T][B][trace_cap] or NULL                                 */
+  int32_t*  msg_count;         /* [T][B] or NULL                                            */
 } phx_rollout_io;
 
 /* ---- entry points ---------------------------------------------------------------------- */
@@ -299,6 +304,27 @@ int  phx_resolve(phx_env* env, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
  * episode end fused in; intermediates in the state blob's "rollout.scratch" field).  PHX_EUNSUPPORTED for envs with PHX_SAMPLER_HOST samplers: the
  * auto-reset resamples on the device.                                                          */
 int  phx_rollout(phx_env* env, const phx_rollout_io* io, void* stream);
+
+/* ---- state / trace access by name.  The state blob is CALLER-owned and phx_field_info
+ * gives zero-copy views of it; these two are the copying form of the same access, for bindings that
+ * cannot alias device memory: `field` is a phx_field.name ("shop.stock", "env.step", ...), `buf` a
+ * device or host pointer (hipMemcpyDefault) of at least the field's byte size; returns the number of
+ * bytes copied or a negative PHX_E* code.  Lazily maintained fields are brought up to date first
+ * (phx_sync_fields).  Replace reading / poking agent attributes on the reference's Python objects
+ * (metrics.py:189-231 reflection; tests that set ShopAgent.stock).                                */
+int64_t phx_get_state(phx_env* env, const char* field, void* buf, int64_t buf_nbytes, void* stream);
+int64_t phx_set_state(phx_env* env, const char* field, const void* buf, int64_t buf_nbytes, void* stream);
+/* Resolver.tracked_messages of the last phx_step / phx_resolve that was given a message log
+ * (resolvers.py:35-60): copies min(count[b], trace_cap) records of env `b` from the caller's log
+ * buffers to HOST memory `out` (capacity `cap` records) and returns count[b] -- the copying form of
+ * reading phx_step_io.msg_log / msg_count directly.  Synchronises `stream`.                       */
+int  phx_trace(phx_env* env, const phx_msg_rec* msg_log, const int32_t* msg_count, int b,
+               phx_msg_rec* out, int cap, void* stream);
+
+/* ---- rollout collection helpers (SURVEY 8e iii): done-flag planes bit-packed for the all-gather.
+ * dst word w, bit j = (src[64 w + j] != 0), n = number of source bytes, dst = ceil(n / 64) words.   */
+int  phx_pack_flags(const uint8_t* src, uint64_t* dst, int64_t n, void* stream);
+int  phx_unpack_flags(const uint64_t* src, uint8_t* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1144,6 +1144,10 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
   uint8_t* u8 = (uint8_t*)alloca(5 * (S ? S : 1));
   e->log = NULL; e->err = io->err ? io->err[b] : 0;
   for (int t = 0; t < T; ++t) {
+    if (io->msg_log) {   /* rollout.py:369-373: tracked_messages recorded per step, cleared before the next */
+      e->log = io->msg_log + ((size_t)t * B + b) * E->s.trace_cap; e->log_cap = E->s.trace_cap;
+      e->log_n = 0; e->round = 0;
+    }
     for (int s = 0; s < S; ++s) {
       const int a = E->strat_idx[s];
       if (E->s.env_type == PHX_ENV_STACKELBERG) {
@@ -1170,6 +1174,7 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
       if (io->obs_valid) io->obs_valid[base + s] = u8[s];
       if (io->reward_valid) io->reward_valid[base + s] = u8[S + s];
     }
+    if (io->msg_count) io->msg_count[(size_t)t * B + b] = e->log_n;
     if (at || au) {                                                   /* caller's env.reset() */
       const int32_t first_err = e->err;                               /* io->err reports the rollout's first error */
       env_reset_one(E, e, b, NULL, NULL, o, u8);

@@ -9,7 +9,8 @@ __version__ = "0.1.0"
 from . import _abi
 from .agents import (Agent, BuyerAgent, CashboxAgent, CustomerAgent, FactoryAgent,
                      ForwarderAgent, HalverAgent, MockAgent, MockStrategicAgent, ReqRespAgent,
-                     SellerAgent, ShopAgent, StrategicAgent, TypedShopAgent, msg_handler)
+                     SellerAgent, ShopAgent, StrategicAgent, TypedShopAgent, UnsupportedAgentBehaviour,
+                     msg_handler)
 from .env import PhantomEnv
 from .fsm import (FiniteStateMachineEnv, FSMRuntimeError, FSMStage, FSMValidationError)
 from .message import (AgentID, CashMessage, HalveMessage, Message, MsgPayload, Order,

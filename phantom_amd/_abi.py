@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -84,7 +84,7 @@ class PhxStepIO(C.Structure):
 class PhxRolloutIO(C.Structure):
     _fields_ = [("T", C.c_int32)] + [(n, C.c_void_p) for n in (
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
-        "reward_valid", "last_obs", "err")]
+        "reward_valid", "last_obs", "err", "msg_log", "msg_count")]
 
 
 assert C.sizeof(PhxMsgRec) == 16
@@ -96,7 +96,29 @@ LIB_PATH = os.path.join(LIB_DIR, "libphantom_amd.so")
 EXPORTS = ("phx_abi_version", "phx_last_error", "phx_state_nbytes", "phx_obs_dim",
            "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",
            "phx_field_info", "phx_uses_fused", "phx_sync_fields", "phx_reset", "phx_step", "phx_inject",
-           "phx_resolve", "phx_rollout")
+           "phx_resolve", "phx_rollout", "phx_get_state", "phx_set_state", "phx_trace",
+           "phx_pack_flags", "phx_unpack_flags")
+
+
+def built_archs():
+    """offload architectures the in-tree library was compiled for (phantom_amd/build.py)."""
+    try:
+        return [a for a in open(os.path.join(LIB_DIR, "ARCH")).read().strip().split(";") if a]
+    except OSError:
+        return ["gfx950"]
+
+
+def _check_arch(torch):
+    """Fail at load time, not at the first launch ('invalid device function'), when the visible
+    GPU is not one the library holds a code object for."""
+    if not torch.cuda.is_available():
+        return                         # symbol / spec-size calls work without a GPU; DeviceEnv raises
+    name = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+    arch = name.split(":")[0]
+    if arch and arch not in built_archs():
+        raise RuntimeError(
+            f"libphantom_amd.so was built for {built_archs()} but the visible GPU is {arch}: rebuild with "
+            f"PHX_OFFLOAD_ARCH='{arch}' (the kernels are tuned for gfx950 / MI355X only)")
 
 
 def load_library():
@@ -143,7 +165,18 @@ def load_library():
     lib.phx_resolve.argtypes = [vp, vp, vp, vp, vp]
     lib.phx_rollout.restype = i32
     lib.phx_rollout.argtypes = [vp, C.POINTER(PhxRolloutIO), vp]
+    lib.phx_get_state.restype = i64
+    lib.phx_get_state.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    lib.phx_set_state.restype = i64
+    lib.phx_set_state.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    lib.phx_trace.restype = i32
+    lib.phx_trace.argtypes = [vp, vp, vp, i32, C.POINTER(PhxMsgRec), i32, vp]
+    lib.phx_pack_flags.restype = i32
+    lib.phx_pack_flags.argtypes = [vp, vp, i64, vp]
+    lib.phx_unpack_flags.restype = i32
+    lib.phx_unpack_flags.argtypes = [vp, vp, i64, vp]
     if lib.phx_abi_version() != ABI_VERSION:
         raise RuntimeError("libphantom_amd.so ABI version mismatch")
+    _check_arch(torch)
     _LIB = lib
     return lib

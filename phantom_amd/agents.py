@@ -90,11 +90,53 @@ class StrategicAgent(Agent):
 
 
 def msg_handler(message_type):
-    """agents.py:344-349 -- kept so reference-style class bodies import; device kinds ignore it."""
+    """agents.py:344-349.  The decorator itself only tags the function, as the reference's does; a
+    class that CARRIES such a method has Python behaviour the device cannot run, and
+    ``compile_spec`` rejects it (see ``check_device_executable``)."""
     def decorator(fn):
         setattr(fn, "_message_type", message_type)
         return fn
     return decorator
+
+
+class UnsupportedAgentBehaviour(TypeError, NotImplementedError):
+    """A user agent class defines Python behaviour (a handler, an observation encoder, ...) that
+    the reference would call (agents.py:69-79,96-155) and the device path cannot."""
+
+
+#: methods of the reference's Agent / StrategicAgent whose bodies ARE the agent's behaviour on the
+#: step path (agents.py:96-155,221-338); device kinds hard-wire them in HIP.
+BEHAVIOUR_METHODS = ("handle_batch", "handle_message", "generate_messages", "encode_observation",
+                     "decode_action", "compute_reward", "is_terminated", "is_truncated",
+                     "pre_message_resolution", "post_message_resolution", "collect_infos")
+
+
+def _is_builtin_agent_class(cls) -> bool:
+    return cls.__module__ == __name__ or cls.__module__.startswith(__name__.rsplit(".", 1)[0] + ".")
+
+
+def check_device_executable(agent) -> None:
+    """Raise ``UnsupportedAgentBehaviour`` when a user-defined subclass adds behaviour on top of the
+    device kind it inherits: a ``@msg_handler`` method or an override of one of
+    ``BEHAVIOUR_METHODS``.  The reference would run that Python (agents.py:69-79 collects the
+    decorated handlers, env.py:273-292 calls the overrides); silently running the parent kind's
+    device handlers instead would return wrong observations and rewards without any error."""
+    for cls in type(agent).__mro__:
+        if cls is object or _is_builtin_agent_class(cls):
+            break                      # everything from here up has hand-written device handlers
+        for name, attr in vars(cls).items():
+            fn = getattr(attr, "__func__", attr)
+            if name in BEHAVIOUR_METHODS and callable(fn):
+                raise UnsupportedAgentBehaviour(
+                    f"agent '{agent.id}': {cls.__name__}.{name}() is Python behaviour; the device path "
+                    f"runs only the hand-written handlers of kind "
+                    f"'{_abi.KIND_NAMES.get(int(agent.device_kind), agent.device_kind)}' and would ignore it. "
+                    "Use one of the device agent kinds unchanged, or add a kind (DESIGN.md \u00a71).")
+            if hasattr(fn, "_message_type"):
+                raise UnsupportedAgentBehaviour(
+                    f"agent '{agent.id}': {cls.__name__}.{name} is a @msg_handler; Python message "
+                    "handlers cannot run on the device (the closed set of kinds is listed in "
+                    "include/phantom_amd.h, phx_kind).")
 
 
 class Box:

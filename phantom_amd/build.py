@@ -14,7 +14,12 @@ SOURCES = ["phx_api.hip", "phx_generic.hip", "phx_sc_fused.hip", "phx_stk_fused.
 HEADERS = ["phx_dev.h", "phx_epilogue.h", os.path.join("..", "..", "include", "phantom_amd.h")]
 # -ffp-contract=off: rewards are f64 "sales - 0.1*stock" with product and difference rounded
 # separately, as the reference's Python floats are (supply_chain.py:147)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+# The kernels are written and tuned for gfx950 (MI355X) only.  PHX_OFFLOAD_ARCH="gfx950;gfx942" adds code
+# objects for other CDNA parts (untested, untuned); _abi.load_library checks the visible GPU against
+# the list the library was built for and fails up front instead of at the first launch.
+ARCHS = [a for a in os.environ.get("PHX_OFFLOAD_ARCH", "gfx950").replace(",", ";").split(";") if a]
+ARCH_FILE = os.path.join(LIB_DIR, "ARCH")
+FLAGS = [f"--offload-arch={a}" for a in ARCHS] + ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -30,7 +35,12 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:
+        return open(ARCH_FILE).read().strip().split(";") != ARCHS
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=True):
@@ -41,6 +51,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(ARCH_FILE, "w") as f:
+        f.write(";".join(ARCHS) + "\n")
     return LIB
 
 

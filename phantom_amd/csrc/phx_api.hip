@@ -694,6 +694,8 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->terminated || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
+  if ((io->msg_log || io->msg_count) && (e->d.trace_cap <= 0 || !io->msg_log || !io->msg_count))
+    return fail(PHX_EINVAL, "rollout message log needs trace_cap > 0 and both msg_log and msg_count");
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   HIPCHK(use_device(e));
@@ -723,6 +725,8 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     g.roll = *io; g.roll_actions_in = io->actions; g.roll_actions = (float*)(base + gs.actions);
     for (int t = 0; t < io->T; ++t) {            // one launch per step: policy + step + trajectory row + the caller's reset
       sio.exo = io->exo ? io->exo + (int64_t)t * e->d.B * e->d.n_exo : nullptr;
+      sio.msg_log = io->msg_log ? io->msg_log + (int64_t)t * e->d.B * e->d.trace_cap : nullptr;   // rollout.py:369-373
+      sio.msg_count = io->msg_count ? io->msg_count + (int64_t)t * e->d.B : nullptr;
       g.io = sio; g.roll_t = t;
       HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
     }
@@ -737,6 +741,90 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
+  return PHX_OK;
+}
+
+// ---- copying state access by field name -------------------------------------------------
+static const FieldDef* find_field_by_name(const phx_env* e, const char* name) {
+  for (const FieldDef& f : e->fields) if (!strcmp(f.name, name)) return &f;
+  return nullptr;
+}
+static int64_t field_nbytes(const FieldDef& f) {
+  static const int esz[4] = {4, 8, 1, 4};
+  return (int64_t)f.dim0 * f.dim1 * f.dim2 * esz[f.dtype];
+}
+
+int64_t phx_get_state(phx_env* e, const char* field, void* buf, int64_t buf_nbytes, void* stream) {
+  if (!e || !field || !buf) return fail(PHX_EINVAL, "null argument");
+  const FieldDef* f = find_field_by_name(e, field);
+  if (!f) return fail(PHX_EINVAL, "unknown state field '%s'", field);
+  const int64_t nb = field_nbytes(*f);
+  if (!e->d.f[f->id]) return fail(PHX_EINVAL, "field '%s' is not bound", field);
+  if (buf_nbytes < nb) return fail(PHX_EINVAL, "buffer of %lld bytes for field '%s' of %lld bytes", (long long)buf_nbytes, field, (long long)nb);
+  HIPCHK(use_device(e));
+  if (e->prices_compressed && !strcmp(field, "buyer.prices")) HIPCHK(phx_launch_stk_materialise(e->d, (hipStream_t)stream));
+  HIPCHK(hipMemcpyAsync(buf, (const char*)e->d.f[f->id], (size_t)nb, hipMemcpyDefault, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return nb;
+}
+
+int64_t phx_set_state(phx_env* e, const char* field, const void* buf, int64_t buf_nbytes, void* stream) {
+  if (!e || !field || !buf) return fail(PHX_EINVAL, "null argument");
+  const FieldDef* f = find_field_by_name(e, field);
+  if (!f) return fail(PHX_EINVAL, "unknown state field '%s'", field);
+  const int64_t nb = field_nbytes(*f);
+  if (!e->d.f[f->id]) return fail(PHX_EINVAL, "field '%s' is not bound", field);
+  if (buf_nbytes != nb) return fail(PHX_EINVAL, "field '%s' holds %lld bytes, got %lld", field, (long long)nb, (long long)buf_nbytes);
+  HIPCHK(use_device(e));
+  if (e->prices_compressed && !strcmp(field, "buyer.prices"))
+    return fail(PHX_EUNSUPPORTED, "buyer.prices is kept compressed by the fused market kernel: set seller.posted instead");
+  HIPCHK(hipMemcpyAsync((char*)e->d.f[f->id], buf, (size_t)nb, hipMemcpyDefault, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return nb;
+}
+
+int phx_trace(phx_env* e, const phx_msg_rec* msg_log, const int32_t* msg_count, int b, phx_msg_rec* out, int cap, void* stream) {
+  if (!e || !msg_log || !msg_count || (cap > 0 && !out)) return fail(PHX_EINVAL, "null argument");
+  if (e->d.trace_cap <= 0) return fail(PHX_EINVAL, "tracking is off (trace_cap == 0)");
+  if (b < 0 || b >= e->d.B) return fail(PHX_EINVAL, "env index out of range");
+  HIPCHK(use_device(e));
+  int32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, msg_count + b, sizeof n, hipMemcpyDefault, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  int m = n < e->d.trace_cap ? n : e->d.trace_cap;
+  if (m > cap) m = cap;
+  if (m > 0) {
+    HIPCHK(hipMemcpyAsync(out, msg_log + (int64_t)b * e->d.trace_cap, sizeof(phx_msg_rec) * m, hipMemcpyDefault, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  }
+  return n;
+}
+
+// ---- done-flag planes, bit-packed for rollout collection (SURVEY 8e iii) ----------------------------
+__global__ __launch_bounds__(256) void phx_pack_flags_kernel(const uint8_t* __restrict__ src, uint64_t* __restrict__ dst, const int64_t n) {
+  // one wave packs 64 consecutive bytes into one word with a ballot; consecutive waves take consecutive words
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < n && src[i] != 0;
+  const uint64_t bits = __ballot(on);
+  if ((threadIdx.x & 63) == 0 && (i >> 6) < ((n + 63) >> 6)) dst[i >> 6] = bits;
+}
+__global__ __launch_bounds__(256) void phx_unpack_flags_kernel(const uint64_t* __restrict__ src, uint8_t* __restrict__ dst, const int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (uint8_t)((src[i >> 6] >> (i & 63)) & 1u);
+}
+
+int phx_pack_flags(const uint8_t* src, uint64_t* dst, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return fail(PHX_EINVAL, "bad argument");
+  if (n == 0) return PHX_OK;
+  hipLaunchKernelGGL(phx_pack_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  HIPCHK(hipGetLastError());
+  return PHX_OK;
+}
+int phx_unpack_flags(const uint64_t* src, uint8_t* dst, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return fail(PHX_EINVAL, "bad argument");
+  if (n == 0) return PHX_OK;
+  hipLaunchKernelGGL(phx_unpack_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  HIPCHK(hipGetLastError());
   return PHX_OK;
 }
 

@@ -46,10 +46,27 @@ class Trajectory(NamedTuple):
     last_obs: "object"       # f32 [B, S, D]
     obs_valid: "object" = None      # u8 [T, B, S]  (FSM envs: key present in step.observations)
     reward_valid: "object" = None   # u8 [T, B, S]  (FSM envs: 0 absent / 1 value / 2 None)
+    msg_log: "object" = None        # u8 [T, B, trace_cap, 16]  ordered message records per step (tracking on)
+    msg_count: "object" = None      # i32 [T, B]
+    flat: "object" = None           # u8 [nbytes]: the one buffer every plane above is a section of (alloc_trajectory(flat=True))
+    packed_flags: "object" = None   # u8 view of `flat`: bit-packed done flags for rollout collection (pack_done_flags)
+    gather_nbytes: int = 0          # prefix of `flat` a learner needs from every rank (distributed.TrajectoryGather)
 
 
 class DeviceError(RuntimeError):
     pass
+
+
+class StepGraph:
+    """``n`` captured ``phx_step`` launches (DeviceEnv.step_graph); ``replay()`` enqueues them on the
+    current stream without per-step host work."""
+
+    def __init__(self, graph, actions, out, n):
+        self.graph, self.actions, self.out, self.n = graph, actions, out, n
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
 
 
 class DeviceEnv:
@@ -75,6 +92,9 @@ class DeviceEnv:
             raise DeviceError("phx_state_nbytes failed: " + self._err())
         self.state = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
         handle = C.c_void_p()
+        # phx_create uploads tables and runs the initial reset on the NULL stream; the zero fill above ran
+        # on torch's current stream, which need not be ordered against it (non-blocking side streams)
+        torch.cuda.current_stream(self.device).synchronize()
         with torch.cuda.device(self.device):
             rc = self.lib.phx_create(cs, self.device.index, self.state.data_ptr(), nbytes,
                                      C.byref(handle))
@@ -197,25 +217,33 @@ class DeviceEnv:
         """Network.reset() without an env: agent.reset() for every agent."""
         self.reset()
 
+    def _fill_step_io(self, io):
+        io.obs, io.obs_valid = self.obs.data_ptr(), self.obs_valid.data_ptr()
+        io.reward, io.reward_valid = self.reward.data_ptr(), self.reward_valid.data_ptr()
+        io.terminated, io.truncated = self.terminated.data_ptr(), self.truncated.data_ptr()
+        io.done_valid = self.done_valid.data_ptr()
+        io.all_terminated = self.all_terminated.data_ptr()
+        io.all_truncated = self.all_truncated.data_ptr()
+        io.err = self.err.data_ptr()
+        if self.msg_log is not None:
+            io.msg_log, io.msg_count = self.msg_log.data_ptr(), self.msg_count.data_ptr()
+        self._step_io_ref = C.byref(io)
+        self._step_out = StepTensors(self.obs, self.reward, self.terminated, self.truncated,
+                                     self.obs_valid, self.reward_valid, self.done_valid,
+                                     self.all_terminated, self.all_truncated)
+
+    def _ensure_step_io(self):
+        # the output pointers never change: build the struct once, patch the inputs per call
+        if self._step_io is None:
+            io = self._step_io = _abi.PhxStepIO()
+            self._fill_step_io(io)
+        return self._step_io
+
     def step(self, actions, action_valid=None, exo=None) -> StepTensors:
         torch = _torch()
         io = self._step_io
         if io is None:
-            # the output pointers never change: build the struct once, patch the inputs per call
-            io = self._step_io = _abi.PhxStepIO()
-            io.obs, io.obs_valid = self.obs.data_ptr(), self.obs_valid.data_ptr()
-            io.reward, io.reward_valid = self.reward.data_ptr(), self.reward_valid.data_ptr()
-            io.terminated, io.truncated = self.terminated.data_ptr(), self.truncated.data_ptr()
-            io.done_valid = self.done_valid.data_ptr()
-            io.all_terminated = self.all_terminated.data_ptr()
-            io.all_truncated = self.all_truncated.data_ptr()
-            io.err = self.err.data_ptr()
-            if self.msg_log is not None:
-                io.msg_log, io.msg_count = self.msg_log.data_ptr(), self.msg_count.data_ptr()
-            self._step_io_ref = C.byref(io)
-            self._step_out = StepTensors(self.obs, self.reward, self.terminated, self.truncated,
-                                         self.obs_valid, self.reward_valid, self.done_valid,
-                                         self.all_terminated, self.all_truncated)
+            io = self._ensure_step_io()
         if self.S > 0:
             if actions.dtype != torch.float32 or not actions.is_contiguous() \
                     or actions.shape != (self.B, self.S) or actions.device != self.device:
@@ -245,51 +273,184 @@ class DeviceEnv:
         return {name: h[off:off + n].view(np.dtype(str(dtype).replace("torch.", ""))).reshape(shape)
                 for name, shape, dtype, off, n in self._out_layout}
 
-    def alloc_trajectory(self, T: int) -> Trajectory:
-        """Uninitialised device buffers for a T-step fragment (time-major)."""
+    def _needs_valid_planes(self) -> bool:
+        # validity masks: stage-masked envs, and kinds whose encode_observation can return None
+        return self.spec.env_type != _abi.ENV_PLAIN or bool((self.spec.kind == _abi.KIND_ADVERTISER).any())
+
+    def never_terminates(self) -> bool:
+        """no strategic kind of this env can return is_terminated() == True (ShopAgent, the market's
+        Seller/Buyer: agents.py:292-323 defaults), so the `terminations` plane of a trajectory is all zero."""
+        k = self.spec.kind[self.spec.strategic_idx] if self.S else np.zeros(0, np.uint8)
+        return bool(np.isin(k, (_abi.KIND_SHOP, _abi.KIND_SELLER, _abi.KIND_BUYER)).all())
+
+    def alloc_trajectory(self, T: int, record_messages: bool = False, flat: bool = False) -> Trajectory:
+        """Uninitialised device buffers for a T-step fragment (time-major).  ``record_messages``:
+        also the per-step ordered message log (rollout.py:369-373, needs enable_tracking).
+        ``flat``: every plane is a 256-byte aligned section of ONE buffer, ordered so that what a
+        learner on another GPU needs is a prefix: obs | actions | rewards | [obs_valid | reward_valid] |
+        bit-packed done flags, then (not gathered) the u8 truncations / terminations planes."""
         torch = _torch()
         B, S, D = self.B, self.S, self.D
         e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=self.device)
-        # validity masks: stage-masked envs, and kinds whose encode_observation can return None
-        fsm = self.spec.env_type != _abi.ENV_PLAIN or bool((self.spec.kind == _abi.KIND_ADVERTISER).any())
+        fsm = self._needs_valid_planes()
+        if record_messages and self.spec.trace_cap <= 0:
+            raise DeviceError("record_messages needs BatchResolver(enable_tracking=True)")
+        if flat:
+            n = T * B * S
+            words = (n + 63) // 64
+            planes = 1 if self.never_terminates() else 2
+            sections = [("observations", (T, B, S, D), torch.float32), ("actions", (T, B, S), torch.float32),
+                        ("rewards", (T, B, S), torch.float32)]
+            if fsm:
+                sections += [("obs_valid", (T, B, S), torch.uint8), ("reward_valid", (T, B, S), torch.uint8)]
+            sections += [("packed_flags", (planes * words * 8,), torch.uint8)]
+            tail = [("truncations", (T, B, S), torch.uint8), ("terminations", (T, B, S), torch.uint8),
+                    ("last_obs", (B, S, D), torch.float32)]
+            offs, total, gather_nbytes = {}, 0, 0
+            for name, shape, dtype in sections + tail:
+                nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+                offs[name] = (total, nb, shape, dtype)
+                total += (nb + 255) & ~255
+                if name == "packed_flags":
+                    gather_nbytes = total
+            buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+            v = {k: buf[o:o + nb].view(dt).view(*sh) for k, (o, nb, sh, dt) in offs.items()}
+            return Trajectory(v["observations"], v["actions"], v["rewards"], v["terminations"], v["truncations"],
+                              v["last_obs"], v.get("obs_valid"), v.get("reward_valid"), None, None,
+                              buf, v["packed_flags"], gather_nbytes)
         return Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
                           e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
                           e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),
                           e(T, B, S, dtype=torch.uint8) if fsm else None,
-                          e(T, B, S, dtype=torch.uint8) if fsm else None)
+                          e(T, B, S, dtype=torch.uint8) if fsm else None,
+                          e(T, B, self.spec.trace_cap, 16, dtype=torch.uint8) if record_messages else None,
+                          e(T, B, dtype=torch.int32) if record_messages else None)
 
-    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
+    def _check_rollout_buffers(self, T, actions, exo, out: Trajectory):
+        """Raw pointers go straight to the kernel: every buffer is checked for dtype, shape,
+        contiguity and device here (python -O strips asserts, so these are real errors)."""
         torch = _torch()
         B, S, D = self.B, self.S, self.D
-        if out is None:
+
+        def need(name, x, dtype, tail, lead=None):
+            if x is None:
+                raise ValueError(f"rollout: `{name}` is required for this env")
+            if x.dtype != dtype or x.device != self.device or not x.is_contiguous():
+                raise ValueError(f"rollout: `{name}` must be a contiguous {dtype} tensor on {self.device}")
+            if tuple(x.shape[1:]) != tuple(tail) or (lead is not None and x.shape[0] != lead) \
+                    or (lead is None and x.shape[0] < T):
+                want = (lead if lead is not None else f">={T}",) + tuple(tail)
+                raise ValueError(f"rollout: `{name}` has shape {tuple(x.shape)}, expected {want}")
+
+        if T < 1:
+            raise ValueError("rollout: T must be >= 1")
+        if actions is not None:
+            need("actions", actions, torch.float32, (B, S), lead=T)
+        if exo is not None:
+            need("exo", exo, torch.uint8, (B, self.n_exo), lead=T)
+        need("out.observations", out.observations, torch.float32, (B, S, D))
+        need("out.actions", out.actions, torch.float32, (B, S))
+        need("out.rewards", out.rewards, torch.float32, (B, S))
+        need("out.terminations", out.terminations, torch.uint8, (B, S))
+        need("out.truncations", out.truncations, torch.uint8, (B, S))
+        need("out.last_obs", out.last_obs, torch.float32, (S, D), lead=B)
+        if self._needs_valid_planes():
+            need("out.obs_valid", out.obs_valid, torch.uint8, (B, S))
+            need("out.reward_valid", out.reward_valid, torch.uint8, (B, S))
+        elif out.obs_valid is not None or out.reward_valid is not None:
+            need("out.obs_valid", out.obs_valid, torch.uint8, (B, S))
+            need("out.reward_valid", out.reward_valid, torch.uint8, (B, S))
+        if out.msg_log is not None or out.msg_count is not None:
+            if self.spec.trace_cap <= 0:
+                raise ValueError("rollout: a message log needs BatchResolver(enable_tracking=True)")
+            need("out.msg_count", out.msg_count, torch.int32, (B,))
+            need("out.msg_log", out.msg_log, torch.uint8, (B, self.spec.trace_cap, 16))
+
+    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
+        owned = out is None
+        if owned:
             out = self.alloc_trajectory(T)
-        # the argument block of a repeated call (same fragment buffers, same replay tensors) is built once
-        key = (T, id(out), None if actions is None else actions.data_ptr(), None if exo is None else exo.data_ptr())
-        cached = self._rollout_io_cache.get(key)
+        # The argument block of a repeated call into CALLER-owned buffers is built once.  The key is
+        # the buffers' addresses and the entry holds no tensor: a fragment allocated here (out=None)
+        # is never cached, so repeated env.rollout(T) calls pin nothing (a T=100 SC64 fragment is
+        # ~80 MB at B=4096).
+        ptr = lambda x: None if x is None else x.data_ptr()
+        key = (T,) + tuple(ptr(x) for x in out) + (ptr(actions), ptr(exo))
+        cached = None if owned else self._rollout_io_cache.get(key)
         if cached is None:
+            self._check_rollout_buffers(T, actions, exo, out)
             io = _abi.PhxRolloutIO()
             io.T = T
-            if actions is not None:
-                assert actions.dtype == torch.float32 and actions.shape == (T, B, S) and actions.is_contiguous()
-                io.actions = actions.data_ptr()
-            if exo is not None:
-                assert exo.dtype == torch.uint8 and exo.shape == (T, B, self.n_exo) and exo.is_contiguous()
-                io.exo = exo.data_ptr()
-            assert out.observations.shape[0] >= T
-            io.obs, io.action_out, io.reward = (out.observations.data_ptr(), out.actions.data_ptr(),
-                                                out.rewards.data_ptr())
-            io.terminated, io.truncated = out.terminations.data_ptr(), out.truncations.data_ptr()
-            io.last_obs = out.last_obs.data_ptr()
-            if out.obs_valid is not None:
-                io.obs_valid, io.reward_valid = out.obs_valid.data_ptr(), out.reward_valid.data_ptr()
+            io.actions, io.exo = ptr(actions), ptr(exo)
+            io.obs, io.action_out, io.reward = ptr(out.observations), ptr(out.actions), ptr(out.rewards)
+            io.terminated, io.truncated = ptr(out.terminations), ptr(out.truncations)
+            io.last_obs = ptr(out.last_obs)
+            io.obs_valid, io.reward_valid = ptr(out.obs_valid), ptr(out.reward_valid)
+            io.msg_log, io.msg_count = ptr(out.msg_log), ptr(out.msg_count)
             io.err = self.err.data_ptr()
-            if len(self._rollout_io_cache) > 64:
-                self._rollout_io_cache.clear()
-            cached = self._rollout_io_cache[key] = (io, C.byref(io), out, actions, exo)   # keeps the tensors alive
+            cached = (io, C.byref(io))
+            if not owned:
+                if len(self._rollout_io_cache) >= 4:           # tiny LRU: drop the oldest entry
+                    self._rollout_io_cache.pop(next(iter(self._rollout_io_cache)))
+                self._rollout_io_cache[key] = cached
         rc = self.lib.phx_rollout(self.handle, cached[1], self._stream())        # the library selects its device itself
         if rc != 0:
             self._check(rc, "phx_rollout")
         return out
+
+    def pack_done_flags(self, traj: Trajectory):
+        """bit-pack the done planes of a flat fragment into its ``packed_flags`` section (SURVEY 8e iii):
+        word w, bit j = truncations.flat[64 w + j] != 0; a second block of words holds `terminations` unless
+        the env's kinds never terminate.  One small launch on the current stream."""
+        if traj.flat is None:
+            raise ValueError("pack_done_flags needs a fragment from alloc_trajectory(flat=True)")
+        n = traj.truncations.numel()
+        words = (n + 63) // 64
+        pf = traj.packed_flags
+        self._check(self.lib.phx_pack_flags(traj.truncations.data_ptr(), pf.data_ptr(), n, self._stream()),
+                    "phx_pack_flags")
+        if pf.numel() >= 2 * words * 8:
+            self._check(self.lib.phx_pack_flags(traj.terminations.data_ptr(), pf.data_ptr() + words * 8, n,
+                                                self._stream()), "phx_pack_flags")
+
+    def unpack_flags(self, packed, n: int, out=None):
+        """inverse of the packing above: u8 [n] (0 / 1) from ceil(n / 64) little-endian 64-bit words."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.phx_unpack_flags(packed.data_ptr(), out.data_ptr(), n, self._stream()),
+                    "phx_unpack_flags")
+        return out
+
+    def step_graph(self, actions=None, n: Optional[int] = None, policy=None, action_valid=None):
+        """Capture ``n`` consecutive ``phx_step`` launches ONCE into a hipGraph and return a replayable
+        ``StepGraph``: per-step launch cadence drops from the host's ~6-9 us to the graph's.
+
+        * ``actions`` f32 [n, B, S]: step i reads ``actions[i]`` -- refill the tensor in place between
+          replays (``graph.actions``);
+        * or ``policy(step_tensors) -> f32 [B, S]``: a capturable torch callable (no host sync) that maps
+          the previous step's device outputs to the next actions -- the whole act/step loop is one graph.
+        Outputs of the LAST captured step are in ``graph.out`` (the env's persistent StepTensors)."""
+        torch = _torch()
+        if actions is None and policy is None:
+            raise ValueError("step_graph needs an actions tensor [n, B, S] or a policy callable")
+        if actions is not None:
+            n = actions.shape[0] if n is None else n
+            if actions.dtype != torch.float32 or tuple(actions.shape) != (n, self.B, self.S) \
+                    or not actions.is_contiguous() or actions.device != self.device:
+                raise ValueError(f"actions must be a contiguous f32 tensor [{n}, {self.B}, {self.S}] on {self.device}")
+        elif n is None:
+            raise ValueError("step_graph(policy=...) needs n")
+        self._ensure_step_io()
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(self.device)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(g, stream=side):          # stream capture records the launches, it does not run them
+            out = self._step_out                        # the first policy call sees the env's current outputs
+            for i in range(n):                          # (after reset(): the reset observations)
+                a = actions[i] if actions is not None else policy(out).contiguous()
+                out = self.step(a, action_valid)
+        torch.cuda.synchronize(self.device)
+        return StepGraph(g, actions, self._step_out, n)
 
     def inject(self, messages: List[Message]):
         if not messages:

@@ -84,7 +84,12 @@ class RolloutCollector:
     On a CPU device (gloo tests) the same schedule runs without streams.
     """
 
-    def __init__(self, produce, like, T: int, chunk: int, group=None, n_buffers: int = 2):
+    def __init__(self, produce, like, T: int, chunk: int, group=None, n_buffers: int = 2,
+                 n_gathered: Optional[int] = None, before_gather=None, payload: str = "every field as is"):
+        """``n_gathered``: only the first n fields of ``like`` travel (they form a prefix of the staging
+        buffer; the remaining fields are produced into the buffer's tail and stay local) -- used to leave
+        out the u8 done planes once ``before_gather(bufs)`` (enqueued on the producing stream) has
+        bit-packed them into a gathered field."""
         import torch
         import torch.distributed as dist
         if T % chunk:
@@ -99,20 +104,24 @@ class RolloutCollector:
         shapes = [(chunk,) + tuple(x.shape[1:]) for x in like]
         nbytes = [int(torch.tensor(sh).prod()) * x.element_size() for sh, x in zip(shapes, like)]
         offs, total = [], 0
-        for n in nbytes:
+        n_gathered = len(like) if n_gathered is None else n_gathered
+        self.before_gather, self.payload = before_gather, payload
+        for k, n in enumerate(nbytes):
             offs.append(total)
             total += (n + 255) & ~255
-        self.nbytes = total
+            if k == n_gathered - 1:
+                self.nbytes = total                      # what one chunk sends per rank
+        staging_total = total
 
         def views(flat, lead):
             # flat: uint8 [..., total] -> one typed view [..., chunk, B_local, ...] per field
             return tuple(flat[..., o:o + n].view(x.dtype).unflatten(-1, sh)
-                         for o, n, sh, x in zip(offs, nbytes, shapes, like))
+                         for o, n, sh, x in zip(offs, nbytes, shapes, like) if o + n <= flat.shape[-1])
 
-        self._flat = [torch.empty(total, dtype=torch.uint8, device=self.device) for _ in range(n_buffers)]
+        self._flat = [torch.empty(staging_total, dtype=torch.uint8, device=self.device) for _ in range(n_buffers)]
         self.bufs = [views(f, ()) for f in self._flat]
-        self._out_flat = torch.empty((self.n_chunks, self.world, total), dtype=torch.uint8, device=self.device)
-        self.out = views(self._out_flat, (self.n_chunks, self.world))
+        self._out_flat = torch.empty((self.n_chunks, self.world, self.nbytes), dtype=torch.uint8, device=self.device)
+        self.out = views(self._out_flat, (self.n_chunks, self.world))[:n_gathered]
         self.cuda = self.device.type == "cuda"
         if self.cuda:
             self.side = torch.cuda.Stream(self.device)
@@ -121,10 +130,11 @@ class RolloutCollector:
 
     def _gather(self, c, k):
         import torch.distributed as dist
+        send = self._flat[k][:self.nbytes]
         if self.world == 1:
-            self._out_flat[c, 0].copy_(self._flat[k], non_blocking=True)
+            self._out_flat[c, 0].copy_(send, non_blocking=True)
         else:
-            dist.all_gather_into_tensor(self._out_flat[c].view(-1), self._flat[k], group=self.group)
+            dist.all_gather_into_tensor(self._out_flat[c].view(-1), send, group=self.group)
 
     def collect(self):
         """Run one fragment; returns ``self.out`` (valid on the caller's stream on return)."""
@@ -133,6 +143,8 @@ class RolloutCollector:
             for c in range(self.n_chunks):
                 k = c % len(self.bufs)
                 self.produce(c * self.chunk, self.chunk, self.bufs[k])
+                if self.before_gather is not None:
+                    self.before_gather(self.bufs[k])
                 self._gather(c, k)
             return self.out
         main = torch.cuda.current_stream(self.device)
@@ -141,6 +153,8 @@ class RolloutCollector:
             if c >= len(self.bufs):
                 main.wait_event(self.free[k])          # gather of chunk c - n_buffers has read buffer k
             self.produce(c * self.chunk, self.chunk, self.bufs[k])
+            if self.before_gather is not None:
+                self.before_gather(self.bufs[k])
             self.ready[k].record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ready[k])
@@ -161,25 +175,144 @@ def auto_chunk(T: int, bytes_per_step: int, min_chunk_bytes: int = 128 << 20) ->
 
 
 def device_env_collector(dev, T: int, chunk: Optional[int] = None, group=None,
-                         n_buffers: int = 2) -> RolloutCollector:
+                         n_buffers: int = 2, pack_flags: bool = True) -> RolloutCollector:
     """RolloutCollector over a DeviceEnv: each chunk is one phx_rollout of ``chunk`` steps
-    (default: auto_chunk on the fragment's bytes per step)."""
+    (default: auto_chunk on the fragment's bytes per step).  With ``pack_flags`` the gathered payload
+    is obs | actions | rewards | [obs_valid | reward_valid] | bit-packed done flags (SURVEY 8e iii): the
+    u8 truncations / terminations planes stay local, `truncations` travels as 1 bit per entry and the
+    all-zero `terminations` plane of kinds that never terminate does not travel at all
+    (``unpack_done_flags`` restores u8 planes on the receiving side)."""
+    import torch
     from .device import Trajectory
     if chunk is None:
         one = dev.alloc_trajectory(1)
-        per_step = sum(x.numel() * x.element_size() for x in one
-                       if x is not None and x is not one.last_obs)
+        per_step = sum(x.numel() * x.element_size() for x in
+                       (one.observations, one.actions, one.rewards, one.terminations, one.truncations,
+                        one.obs_valid, one.reward_valid) if x is not None)
         chunk = auto_chunk(T, per_step)
     probe = dev.alloc_trajectory(chunk)             # shapes/dtypes only; nothing is launched
-    fields = [x for x in (probe.observations, probe.actions, probe.rewards, probe.terminations,
-                          probe.truncations, probe.obs_valid, probe.reward_valid) if x is not None]
-    has_masks = probe.obs_valid is not None
+    masks = [x for x in (probe.obs_valid, probe.reward_valid) if x is not None]
+    has_masks = bool(masks)
+    n = probe.truncations.numel()
+    words = (n + 63) // 64
+    planes = 1 if dev.never_terminates() else 2
+    if not pack_flags:
+        fields = [probe.observations, probe.actions, probe.rewards, probe.terminations, probe.truncations] + masks
+
+        def produce(t0, tc, bufs):
+            m = (bufs[5], bufs[6]) if has_masks else (None, None)
+            dev.rollout(tc, out=Trajectory(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], probe.last_obs, *m))
+
+        return RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers,
+                                payload="obs, actions, rewards f32; terminations, truncations u8 planes")
+    # the packed flags of a chunk, shaped [chunk, bytes / chunk] so that every field has the chunk axis
+    # first (padded to whole 64-bit words per plane and to a multiple of the chunk length)
+    pbytes = planes * words * 8
+    while pbytes % chunk:
+        pbytes += 8
+    packed = torch.empty((chunk, pbytes // chunk), dtype=torch.uint8, device=probe.truncations.device)
+    # field order = staging order: the gathered prefix first, the local u8 done planes last
+    fields = [probe.observations, probe.actions, probe.rewards] + masks + [packed]
+    n_gathered = len(fields)
+    fields += [probe.truncations, probe.terminations]
+    ip, it, ie = n_gathered - 1, n_gathered, n_gathered + 1
 
     def produce(t0, tc, bufs):
-        masks = (bufs[5], bufs[6]) if has_masks else (None, None)
-        dev.rollout(tc, out=Trajectory(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], probe.last_obs, *masks))
+        m = (bufs[3], bufs[4]) if has_masks else (None, None)
+        dev.rollout(tc, out=Trajectory(bufs[0], bufs[1], bufs[2], bufs[ie], bufs[it], probe.last_obs, *m))
 
-    return RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers)
+    def before_gather(bufs):
+        pf = bufs[ip]
+        dev._check(dev.lib.phx_pack_flags(bufs[it].data_ptr(), pf.data_ptr(), n, dev._stream()), "phx_pack_flags")
+        if planes == 2:
+            dev._check(dev.lib.phx_pack_flags(bufs[ie].data_ptr(), pf.data_ptr() + words * 8, n, dev._stream()),
+                       "phx_pack_flags")
+
+    col = RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers, n_gathered=n_gathered,
+                           before_gather=before_gather,
+                           payload="obs, actions, rewards f32" + (", obs_valid, reward_valid u8" if has_masks else "") +
+                                   ", truncations bit-packed" + (", terminations bit-packed" if planes == 2
+                                                                 else " (terminations: all zero for these kinds, not sent)"))
+    col.flag_words, col.flag_planes, col.flags_per_chunk = words, planes, n
+    return col
+
+
+def unpack_done_flags(dev, packed_row, n: int, planes: int):
+    """(truncations, terminations) u8 [n] from one rank's packed flags of one chunk (device tensors)."""
+    import torch
+    words = (n + 63) // 64
+    flat = packed_row.reshape(-1)
+    trunc = dev.unpack_flags(flat, n)
+    term = dev.unpack_flags(flat[words * 8:], n) if planes == 2 else torch.zeros(n, dtype=torch.uint8, device=flat.device)
+    return trunc, term
+
+
+class TrajectoryGather:
+    """ONE flat collective for a whole rollout fragment (BASELINE config 4's exchange).
+
+    The fragment lives in one buffer (DeviceEnv.alloc_trajectory(flat=True)) whose prefix is exactly
+    what a learner on another GPU needs: obs | actions | rewards f32 | [validity planes] | bit-packed
+    done flags.  ``gather()`` packs the flags (one small launch) and issues a single
+    all_gather_into_tensor of that prefix on the current stream; ``unpack(r)`` returns rank r's
+    fragment as a Trajectory of views (done planes re-expanded to u8)."""
+
+    def __init__(self, dev, T_or_traj, group=None):
+        import torch
+        import torch.distributed as dist
+        from .device import Trajectory
+        self.dev, self.group = dev, group
+        self.traj = T_or_traj if isinstance(T_or_traj, Trajectory) else dev.alloc_trajectory(int(T_or_traj), flat=True)
+        if self.traj.flat is None:
+            raise ValueError("TrajectoryGather needs a fragment from alloc_trajectory(flat=True)")
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.nbytes = int(self.traj.gather_nbytes)
+        t = self.traj
+        self.raw_nbytes = sum(x.numel() * x.element_size() for x in
+                              (t.observations, t.actions, t.rewards, t.terminations, t.truncations,
+                               t.obs_valid, t.reward_valid) if x is not None)
+        self.out = torch.empty((self.world, self.nbytes), dtype=torch.uint8, device=t.flat.device)
+
+    def describe(self) -> str:
+        t = self.traj
+        planes = "truncations bit-packed" + ("" if self.dev.never_terminates() is False else
+                                              "; terminations all zero for these kinds, not sent")
+        if not self.dev.never_terminates():
+            planes = "truncations + terminations bit-packed"
+        return ("obs, actions, rewards f32" + (", obs_valid, reward_valid u8" if t.obs_valid is not None else "") +
+                f"; {planes}; {self.nbytes} of {self.raw_nbytes} raw bytes")
+
+    def gather(self):
+        import torch.distributed as dist
+        self.dev.pack_done_flags(self.traj)
+        send = self.traj.flat[:self.nbytes]
+        if self.world == 1:
+            self.out[0].copy_(send, non_blocking=True)
+        else:
+            dist.all_gather_into_tensor(self.out.view(-1), send, group=self.group)
+        return self.out
+
+    def unpack(self, r: int):
+        """rank r's fragment out of the gathered buffer (views; done planes unpacked to fresh u8 tensors)."""
+        import torch
+        from .device import Trajectory
+        t, row = self.traj, self.out[r]
+        base = t.flat.data_ptr()
+
+        def view(x):
+            o = x.data_ptr() - base
+            return row[o:o + x.numel() * x.element_size()].view(x.dtype).view(x.shape)
+
+        n = t.truncations.numel()
+        words = (n + 63) // 64
+        pf = view(t.packed_flags)
+        trunc = self.dev.unpack_flags(pf, n).view(t.truncations.shape)
+        if pf.numel() >= 2 * words * 8:
+            term = self.dev.unpack_flags(pf[words * 8:], n).view(t.terminations.shape)
+        else:
+            term = torch.zeros_like(trunc)
+        return Trajectory(view(t.observations), view(t.actions), view(t.rewards), term, trunc, None,
+                          view(t.obs_valid) if t.obs_valid is not None else None,
+                          view(t.reward_valid) if t.reward_valid is not None else None)
 
 
 def global_env_index(shard_index: int, local_env: int, local_batch: int) -> int:

@@ -76,6 +76,20 @@ class _EnvRow(Mapping):
         return len(self._keys()) + len(self._extra)
 
 
+class _InfoRow(_EnvRow):
+    """infos of one env instance: `{}` for every agent that has an observation this step
+    (env.py:279-283 with the default collect_infos, agents.py:301-306)."""
+
+    def __init__(self, ids, valid, b):
+        super().__init__(ids, None, valid, b)
+
+    def __getitem__(self, key):
+        s = self._ids.index(key) if key in self._ids else -1
+        if s < 0 or (self._valid is not None and not self._valid[self._b, s]):
+            raise KeyError(key)
+        return {}
+
+
 class SubEnvView:
     """``base_env.envs[i]``-style shim (train.py:294-297): env instance ``i`` of the batch as
     seen by metric code -- ``.agents[id].<attr>`` returns that instance's scalar."""
@@ -165,5 +179,5 @@ class BatchedBaseEnv:
         rew_d = {b: _EnvRow(self._ids, rew, rv, b, scalar=True) for b in range(B)}
         term_d = {b: _EnvRow(self._ids, term, dv, b, {"__all__": bool(at[b])}, scalar=True) for b in range(B)}
         trunc_d = {b: _EnvRow(self._ids, trunc, dv, b, {"__all__": bool(au[b])}, scalar=True) for b in range(B)}
-        info_d = {b: _EnvRow(self._ids, np.empty((B, len(self._ids)), dtype=object), ov, b) for b in range(B)}
+        info_d = {b: _InfoRow(self._ids, ov, b) for b in range(B)}       # infos[aid] = {} (agents.py:301-306)
         return obs_d, rew_d, term_d, trunc_d, info_d, {}

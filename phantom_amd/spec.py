@@ -181,7 +181,7 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                  seed: int = 0, env_offset: int = 0, force_generic: bool = False,
                  extra_queue: int = 16, samplers: Optional[Sequence] = None,
                  device_sampling: bool = False) -> EnvSpec:
-    from .agents import Agent, StrategicAgent
+    from .agents import Agent, StrategicAgent, check_device_executable
     agent_ids = list(network.agents.keys())
     A = len(agent_ids)
     if A == 0:
@@ -202,6 +202,7 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         agent = network.agents[aid]
         if not isinstance(agent, Agent):
             raise TypeError(f"{agent!r} is not a phantom_amd.Agent")
+        check_device_executable(agent)
         k = int(agent.device_kind)
         if isinstance(agent, StrategicAgent) != (k in _abi.STRATEGIC_KINDS):
             raise TypeError(f"agent '{aid}': StrategicAgent-ness and device kind disagree")

@@ -154,7 +154,7 @@ class OracleEnv:
         self.err[:] = 0
         self.L.phxo_resolve(self.h, _p(self.err), _p(self.msg_log), _p(self.msg_count))
 
-    def rollout(self, T, actions=None, exo=None):
+    def rollout(self, T, actions=None, exo=None, record_messages=False):
         B, S, D = self.B, self.S, self.D
         out = dict(obs=np.zeros((T, B, S, D), np.float32), actions=np.zeros((T, B, S), np.float32),
                    rewards=np.zeros((T, B, S), np.float32), terminated=np.zeros((T, B, S), np.uint8),
@@ -169,6 +169,10 @@ class OracleEnv:
         io.terminated, io.truncated = _p(out["terminated"]), _p(out["truncated"])
         io.obs_valid, io.reward_valid = _p(out["obs_valid"]), _p(out["reward_valid"])
         io.last_obs, io.err = _p(out["last_obs"]), _p(self.err)
+        if record_messages:
+            out["msg_log"] = np.zeros((T, B, self.spec.trace_cap), LOG_DTYPE)
+            out["msg_count"] = np.zeros((T, B), np.int32)
+            io.msg_log, io.msg_count = _p(out["msg_log"]), _p(out["msg_count"])
         self.L.phxo_rollout(self.h, C.byref(io))
         return out
 

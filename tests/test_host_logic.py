@@ -433,3 +433,46 @@ def test_spec_validation_through_the_abi_without_gpu():
     s3.type_src[:] = _abi.TYPE_NONE
     cs3, keep3 = s3.to_ctypes()
     assert lib.phx_state_nbytes(ctypes.byref(cs3)) < 0 and b"budget" in lib.phx_last_error()
+
+
+def test_python_behaviour_on_a_device_kind_is_rejected():
+    """A reference-style user class (agents.py:69-79,96-155: @msg_handler methods, overridden
+    encode_observation / compute_reward / handle_batch ...) must not silently run as its parent's
+    device kind: compile_spec raises and names the method."""
+    import phantom_amd as ph
+
+    class MyShop(ph.ShopAgent):
+        def compute_reward(self, ctx):
+            return 42.0
+
+    class MyAgent(ph.Agent):
+        @ph.msg_handler(ph.StockRequest)
+        def handle_stock_request(self, ctx, message):
+            return []
+
+    class Renamed(ph.ShopAgent):          # no behaviour added: still the SHOP kind
+        def helper(self):
+            return 1
+
+    class Batchy(ph.StrategicAgent):
+        def handle_batch(self, ctx, batch):
+            return []
+
+    def net(shop_cls):
+        agents = [ph.FactoryAgent("F"), shop_cls("S", "F", 1), ph.CustomerAgent("C", "S")]
+        n = ph.Network(agents)
+        n.add_connection("F", "S"); n.add_connection("S", "C")
+        return n
+
+    ph.compile_spec(net(Renamed), num_steps=3)
+    with pytest.raises(ph.UnsupportedAgentBehaviour, match="compute_reward"):
+        ph.compile_spec(net(MyShop), num_steps=3)
+    with pytest.raises(TypeError, match="msg_handler"):
+        ph.compile_spec(ph.Network([MyAgent("A")]), num_steps=3)
+    with pytest.raises(NotImplementedError, match="handle_batch"):
+        ph.compile_spec(ph.Network([Batchy("B")]), num_steps=3)
+    # a grandchild of a user class that overrides is rejected too
+    class Deeper(MyShop):
+        pass
+    with pytest.raises(ph.UnsupportedAgentBehaviour):
+        ph.compile_spec(net(Deeper), num_steps=3)
