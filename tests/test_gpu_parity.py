@@ -491,8 +491,13 @@ def test_pipelined_collector_equals_one_shot_rollout(fsm):
     col = device_env_collector(d2.dev, T, chunk, n_buffers=2)
     out = col.collect()
     torch.cuda.synchronize()
-    names = ["obs", "actions", "rewards", "terminated", "truncated"] + (["obs_valid", "reward_valid"] if fsm else [])
-    assert out[0].shape == (T // chunk, 1, chunk, B, S, 3)
+    # gathered payload: obs | actions | rewards | [validity planes] | bit-packed done flags (SURVEY 8e iii)
+    names = ["obs", "actions", "rewards"] + (["obs_valid", "reward_valid"] if fsm else [])
+    assert out[0].shape == (T // chunk, 1, chunk, B, S, 3) and len(out) == len(names) + 1
+    from phantom_amd.distributed import unpack_done_flags
+    tr = [unpack_done_flags(d2.dev, out[-1][c, 0], col.flags_per_chunk, col.flag_planes) for c in range(T // chunk)]
+    np.testing.assert_array_equal(torch.cat([t.view(chunk, B, S) for t, _ in tr], 0).cpu().numpy(), ro["truncated"])
+    np.testing.assert_array_equal(torch.cat([e.view(chunk, B, S) for _, e in tr], 0).cpu().numpy(), ro["terminated"])
     for name, x in zip(names, out):
         got = x[:, 0].reshape((T,) + tuple(x.shape[3:])).cpu().numpy()
         want = ro[name]
