@@ -91,7 +91,8 @@ assert C.sizeof(PhxMsgRec) == 16
 
 _LIB = None
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
-LIB_PATH = os.path.join(LIB_DIR, "libphantom_amd.so")
+# PHX_LIB_PATH: development override (A/B runs of experimental builds); the default is the in-tree library
+LIB_PATH = os.environ.get("PHX_LIB_PATH") or os.path.join(LIB_DIR, "libphantom_amd.so")
 
 EXPORTS = ("phx_abi_version", "phx_last_error", "phx_state_nbytes", "phx_obs_dim",
            "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",

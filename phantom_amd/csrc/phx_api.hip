@@ -25,6 +25,7 @@ hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st);
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st);
 size_t phx_stk_rollout_lds(const DevSpec& sp);
+#include "phx_sc_fast.h"
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 hipError_t phx_launch_ads_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_ads_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
@@ -530,6 +531,24 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.n_tabn = der.n_tabn; d.n_quot = der.n_quot; d.rew_smax = der.rew_smax;
 #undef UP
   d.max_cust = der.max_cust;
+  if (der.sc_static && spec->env_type == PHX_ENV_PLAIN && !der.any_typed && d.S > 0) {
+    // fast rollout kernel (phx_sc_rollout.hip): every shop with the same 1..6 customers and the same normaliser
+    int Ku = der.shop_cust_ptr.size() > 1 ? der.shop_cust_ptr[1] - der.shop_cust_ptr[0] : -1;
+    bool nu = true;
+    for (int s2 = 0; s2 < d.S; ++s2) {
+      if (der.shop_cust_ptr[s2 + 1] - der.shop_cust_ptr[s2] != Ku) Ku = -1;
+      nu = nu && der.shop_norm[s2] == der.shop_norm[0];
+    }
+    ScFastPlan plan;
+    if (phx_sc_fast_plan(d.B, d.S, Ku, nu, d.num_steps, &plan)) {
+      std::vector<char> blob;
+      plan.norm = der.shop_norm[0];
+      phx_sc_fast_blob(plan, d.S, plan.norm, blob, &plan);
+      rc = upload(e, blob.data(), blob.size(), &d.sc_fast_blob);
+      if (rc != PHX_OK) { phx_destroy(e); return rc; }
+      d.sc_fast = plan;
+    }
+  }
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
   d.ws_stride = ws_stride;
   e->lds_ok = ws_stride == 0;
@@ -740,6 +759,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   }
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
+  if (e->d.sc_fast.ok && !io->actions && !io->exo) { HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
   return PHX_OK;
 }

@@ -38,6 +38,13 @@ enum {
   F_COUNT
 };
 
+// block shape and constant-table offsets of the round-2 supply-chain rollout kernel (phx_sc_rollout.hip)
+#define PHX_FAST_TC 20          // steps per chunk (one Philox block serves 4 ticks: 5 row quads)
+struct ScFastPlan {
+  int32_t ok, epb, G, K, nt, norm;
+  int32_t blob_bytes, off_ds, off_tabs, off_tabn, off_rew;
+};
+
 struct DevSpec {
   int32_t A, S, B, D, n_exo, nnz;
   int32_t num_steps, round_limit, env_type;
@@ -79,6 +86,8 @@ struct DevSpec {
   const int32_t* shop_cust_agent;// agent index of each customer
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
   int32_t max_cust;              // max customers of one shop
+  ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable) and its constant LDS image
+  const char* sc_fast_blob;
   // host-built lookup tables of the rollout kernel (exactly the values the formulas give):
   //   [0,101) f32 stock/100 ; [101, 101+n_tabn) f32 x/norm, n_quot valid entries (0 unless
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)

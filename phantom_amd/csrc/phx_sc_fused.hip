@@ -377,6 +377,12 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
     const int t1 = t0 + TC, tc1 = (a.T - t1 < TC) ? a.T - t1 : TC;     // next chunk
     // ---- phase 2: the stock recurrence, one lane per pair ---------------------------------------
     if (tid < G) {
+#ifndef PHX_NO_P2_PRIO
+      // the recurrence is a dependent chain on ONE wave while the three other waves of its SIMD issue Philox
+      // work: at equal priority it gets every fourth issue slot (measured 212 cycles per step); raised, it
+      // issues as soon as its operands are ready and the draw waves fill the gaps
+      __builtin_amdgcn_s_setprio(3);
+#endif
       // A lone wave issues about one instruction every 4-5 cycles, so this phase costs
       // (instructions per step) x T: the loop body is kept to two LDS instructions and seven
       // VALU ops.  stock' = min(max(x - D, 0) + min(R, 100 - x), 100); sales = x - max(x - D, 0).
@@ -415,6 +421,9 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
       st.stock = x; st.sales = sales; st.missed = hasK ? Dl - sales : 0; st.delivered = req;
       step += tc;
       if (tend >= 0 && tend < tc) step -= a.num_steps;
+#ifndef PHX_NO_P2_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     TICK(3);
     // ---- phase 1 of the NEXT chunk, overlapped with the recurrence above -------------------------

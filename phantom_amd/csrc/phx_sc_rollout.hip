@@ -1,0 +1,373 @@
+// phx_sc_rollout.hip -- the time-parallel supply-chain rollout kernel, round-2 structure.
+//
+// Same path as phx_sc_rollout_kernel (phx_sc_fused.hip): T consecutive PhantomEnv.step() calls of a
+// FACTORY / SHOP / CUSTOMER env (supply_chain.py:36-150, env.py:239-303) per launch, random policy and
+// device-RNG orders, auto-reset at episode end (the list-of-envs loop of utils/rllib/rollout.py:361-363),
+// bit-identical trajectories.  What changed is who does what.  Measured on the round-1 kernel (PHX_TIMING):
+// the stock recurrence -- one lane per (env, shop), sequential in time -- was the critical path of every
+// chunk: 210 cycles per step for ~21 instructions, because each of its instructions queues behind the
+// quarter-rate multiplies of the three draw waves sharing its SIMD, and the draw and output waves idled at
+// the barrier meanwhile (4.4 k of 48 k cycles); setup took another 7 k (six dependent global round trips).
+// Here
+//   * the recurrence wave does ONLY the dependent chain: its operands (one packed word per step: request R
+//     and demand D) are fetched from LDS in one burst before the chain, the episode reset is folded into the
+//     operands (D' = 4096, R' = 0 at the episode's last step give stock' = 0 without a select on the chain),
+//     and per step it stores one word (the stock BEFORE the step) -- sub, max, add per step on the chain;
+//   * everything derived (sales, missed sales, stock after the step, observation, reward) is recomputed
+//     from (stock before, D, R) in the output phase, which is parallel over (time, pairs);
+//   * the f64 reward (sales - 0.1 * stock, supply_chain.py:147) rounded to the trajectory's f32 comes
+//     from a host-built [sales][stock] table (the formula evaluated on the host in f64, like the observation
+//     tables), so the output phase has no f64 instruction;
+//   * all per-block constants (pair table, digit-sum table, observation / reward tables) are ONE
+//     host-packed blob copied into LDS with 16-byte loads issued together with the state loads: one global
+//     round trip of setup.
+// Fast-path conditions (checked at phx_create / by the launcher; everything else takes
+// phx_sc_rollout_kernel): device RNG and random policy (no replay), every shop with the same 1..6 customers
+// and the same normaliser, whole envs per block with 16-byte aligned tile rows, num_steps >= the chunk length.
+#include "phx_dev.h"
+#include "phx_sc_fast.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+struct FastArgs {
+  int32_t B, S, epb, G, K, T, num_steps, xcd_remap;
+  uint32_t pK; float inv_pK;        // 5^K and its f32 reciprocal (floor(y * inv) == y / 5^K for y < 5^6: tests/test_host_logic.py)
+  uint32_t mG, mG4, mS;             // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S  for i < 2^16
+  int32_t blob_bytes, off_ds, off_tabs, off_tabn, off_rew;
+  int32_t norm;                     // the shops' common max_sales_per_step
+  uint64_t seed; int64_t env_offset;
+  const char* blob;
+  unsigned long long* timing;       // PHX_TIMING builds only
+  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick;
+  phx_rollout_io io;
+};
+
+__device__ __forceinline__ void fast_lds_barrier() {     // orders LDS traffic only: trajectory stores stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TC = PHX_FAST_TC;
+  const phx_rollout_io& io = a.io;
+  const int tid = threadIdx.x, nS = a.S, G = a.G;
+  const int64_t total = (int64_t)a.B * nS;
+  const int bid = xcd_block(a.xcd_remap != 0);
+  const int64_t b_first = (int64_t)bid * a.epb;
+  const int64_t g_base = b_first * nS;
+#ifdef PHX_TIMING
+  unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define FTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define FTICK(k) do {} while (0)
+#endif
+
+  // ---- LDS carve (16-byte aligned sections).  The constant tables are COMPUTED here, not loaded: 1 024 workgroups
+  //      fetching the same few cache lines at launch cost ~10 k cycles of setup (measured, PHX_TIMING) ------------
+  uint32_t* s_pair = (uint32_t*)smem;                                   // [G] shop | env_local << 8
+  uint8_t* s_ds = (uint8_t*)(s_pair + ((G + 3) & ~3));                  // [125] base-5 digit sum of k < 5^3
+  float* s_tabs = (float*)(s_ds + 128);                                 // [101] stock / 100            encode_observation,
+  float* s_tabn = s_tabs + 104;                                         // [5K+1 <= 31] x / norm        supply_chain.py:124-134
+  double* s_pen = (double*)(s_tabn + 32);                               // [101] 0.1 * stock in f64     compute_reward :147
+  const int items = TC * G;
+  int* s_rd0 = (int*)(s_pen + 102);                                     // 2 x [TC][G]  R | D << 8
+  float* s_act0 = (float*)(s_rd0 + 2 * items);                          // 2 x [TC][G]
+  int* s_xb = (int*)(s_act0 + 2 * items);                               // [TC][G] stock before the step
+  int* s_ptend = s_xb + items;                                          // [G] chunk row that ends the pair's episode, or -1
+  int* s_tick0 = s_ptend + ((G + 3) & ~3);                              // [epb]
+  int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
+
+  // ---- setup: the state loads are in flight while the tables are computed --------------------------------------
+  int x = 0, step = 0;                    // lane state of the recurrence (lane tid owns pair g_base + tid)
+  {
+    int tk = 0;
+    const uint32_t el = nS == 1 ? (uint32_t)tid : __umulhi((uint32_t)tid, a.mS);     // tid / S (the magic of 1 does not fit 32 bits)
+    if (tid < G) { x = a.stock[g_base + tid]; step = a.env_step[b_first + el]; }
+    if (tid < a.epb) tk = a.env_tick[b_first + tid];
+    if (tid < G) { s_pair[tid] = ((uint32_t)tid - el * (uint32_t)nS) | (el << 8); }
+    if (tid < 125) s_ds[tid] = (uint8_t)(tid % 5 + (tid / 5) % 5 + tid / 25);
+    if (tid <= PHX_SHOP_MAX_STOCK) {
+      // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24 (phx_dev.h: shop_obs_f32)
+      s_tabs[tid] = (float)tid / (float)PHX_SHOP_MAX_STOCK;
+      s_pen[tid] = __dmul_rn(0.1, (double)tid);
+    }
+    if (tid <= 5 * a.K) s_tabn[tid] = (float)tid / (float)a.norm;
+    if (tid < 2) s_flags[tid] = 0;
+    FTICK(6);
+    __syncthreads();
+    if (tid < a.epb) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
+    if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
+    __syncthreads();
+  }
+  const int quad_extra = s_flags[0];      // chunk starts are not quad-aligned for every env: one more row quad
+  const bool weird = s_flags[1] != 0;     // only possible in the first chunk (any step brings the stock into [0, 100])
+
+  // thread roles in the overlapped phase: the waves that hold a recurrence lane walk the recurrence, the
+  // others draw the next chunk (when no wave is left over, everybody draws after the recurrence)
+  const int p2_threads = ((G + 63) >> 6) << 6;
+  const int p1_first = (p2_threads + 64 <= NT) ? p2_threads : 0;
+
+  // ---- draws of the chunk starting at step t0 (tc rows) into buffer `buf`, by threads [first, NT).
+  //      One Philox block serves ticks 4q .. 4q + 3 of a shop: work items are (row quad jr, pair gl).
+  auto draws_impl = [&](int t0, int tc, int buf, int first, auto ALIGNED) __attribute__((always_inline)) {
+    // ALIGNED: every env's chunk starts on a tick quad and tc is a multiple of 4 -> every row of a unit exists
+    constexpr bool aligned = decltype(ALIGNED)::value;
+    if (tid < first) return;
+    int* s_rd = s_rd0 + buf * items;
+    float* s_act = s_act0 + buf * items;
+    const int nw = NT - first;
+    const int n_work = (((tc + 3) >> 2) + (aligned ? 0 : quad_extra)) * G;
+    for (int iw = tid - first; iw < n_work; iw += nw) {
+      const int jr = (int)__umulhi((uint32_t)iw, a.mG), gl = iw - (int)__umul24(jr, G);
+      const uint32_t pr = s_pair[gl];
+      const int s = (int)(pr & 255u), bl = (int)(pr >> 8);
+      const int64_t genv = a.env_offset + b_first + bl;
+      const uint32_t tick_base = (uint32_t)s_tick0[bl] + (uint32_t)t0;
+      const int tla = 4 * jr - (aligned ? 0 : (int)(tick_base & 3u));
+      if (!aligned && (tla + 3 < 0 || tla >= tc)) continue;
+      const uint32_t tick_a = tick_base + (uint32_t)tla;                 // multiple of 4
+      uint32_t w[4];
+      rng_block(a.seed, genv, tick_a, s, 0, 0, w);
+      int i = (int)__umul24(tla, G) + gl;                                // (tla < 0 only when !aligned: the row is then skipped)
+      if (!aligned) i = tla * G + gl;
+#pragma unroll
+      for (int h = 0; h < 4; ++h, i += G) {
+        if (!aligned) { const int tl = tla + h; if (tl < 0 || tl >= tc) continue; }
+        uint32_t y, aj;
+        if (!rng_split(w[h], y, aj)) y = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj);     // 3.3e-6
+        if (a.K < 6) y -= __umul24((uint32_t)((float)y * a.inv_pK), a.pK);   // the first K base-5 digits: y mod 5^K
+        const uint32_t hi = (uint32_t)((float)y * 0.008f);               // y / 125, exact through f32
+        const int D = (int)s_ds[hi] + (int)s_ds[y - __umul24(125u, hi)]; // sum of the customers' order sizes, supply_chain.py:61-67
+        const float action = rng_j_to_action(aj);                        // random policy, [0, 100)
+        s_act[i] = action;
+        s_rd[i] = (int)rintf(action) | (D << 8);                         // decode_action: int(round(action)), supply_chain.py:139
+      }
+    }
+  };
+  auto draws = [&](int t0, int tc, int buf, int first) __attribute__((always_inline)) {
+    if (!quad_extra && (tc & 3) == 0) draws_impl(t0, tc, buf, first, std::true_type{});
+    else draws_impl(t0, tc, buf, first, std::false_type{});
+  };
+
+  FTICK(0);
+  draws(0, a.T < TC ? a.T : TC, 0, 0);
+  FTICK(1); fast_lds_barrier(); FTICK(2);
+  int buf = 0;
+  int fin_xb = 0, fin_rd = 0;             // the launch's last step: stock before it and its packed (R, D)
+  for (int t0 = 0; t0 < a.T; t0 += TC, buf ^= 1) {
+    const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
+    const int t1 = t0 + TC, tc1 = (a.T - t1 < TC) ? a.T - t1 : TC;      // next chunk
+    const int* s_rd = s_rd0 + buf * items;
+    const float* s_act = s_act0 + buf * items;
+    // ---- the stock recurrence, one lane per pair ------------------------------------------------------
+    //   stock' = max(stock - D, 0) + min(R, 100 - stock)      handle_order_request / handle_stock_response,
+    //   supply_chain.py:98-122 with decode_action's clamp :139 (<= 100 whenever 0 <= stock <= 100); at the
+    //   episode's last step the caller's env.reset() zeroes the stock (ShopAgent.reset)
+    if (tid < G) {
+      __builtin_amdgcn_s_setprio(3);
+      const int tend = a.num_steps - 1 - step;                          // chunk row that ends the episode (one at most: TC <= num_steps)
+      const bool ends = tend >= 0 && tend < tc;
+      s_ptend[tid] = ends ? tend : -1;
+      int* xb = s_xb + tid;
+      const int* rdp = s_rd + tid;
+#ifdef PHX_TIMING
+      FTICK(7);
+#endif
+      // one step of the chain; `MINCAP` keeps the general form for a stock the caller set outside [0, 100]
+#define FAST_STEP(h_, rd_, MINCAP)                                                                         \
+      {                                                                                                    \
+        const bool end_ = ((h_) == tend);                                                                  \
+        const int Dm_ = end_ ? 4096 : ((rd_) >> 8), Rm_ = end_ ? 0 : ((rd_) & 255);                        \
+        xb[(h_) * G] = x;                                                                                  \
+        const int xn_ = max(x - Dm_, 0) + min(Rm_, PHX_SHOP_MAX_STOCK - x);                                \
+        x = (MINCAP) ? (end_ ? 0 : min(xn_, PHX_SHOP_MAX_STOCK)) : xn_;                                    \
+      }
+      if (tc == TC && !weird) {                 // the common case: straight-line code, operands fetched in one burst
+        int rd[TC];
+#pragma unroll
+        for (int h = 0; h < TC; ++h) rd[h] = rdp[h * G];
+#pragma unroll
+        for (int h = 0; h < TC; ++h) FAST_STEP(h, rd[h], false)
+        fin_rd = rd[TC - 1];
+      } else {                                  // a shorter last chunk, or the first chunk of an out-of-range stock
+        for (int h = 0; h < tc; ++h) { const int rdh = rdp[h * G]; FAST_STEP(h, rdh, true) fin_rd = rdh; }
+      }
+#undef FAST_STEP
+      step += tc;
+      if (ends) step -= a.num_steps;
+      __builtin_amdgcn_s_setprio(0);
+    }
+    FTICK(3);
+    // ---- draws of the NEXT chunk, overlapped with the recurrence above ------------------------------------
+    if (t1 < a.T) draws(t1, tc1, buf ^ 1, p1_first);
+    FTICK(1); fast_lds_barrier(); FTICK(4);
+    if (t1 >= a.T && tid < G) fin_xb = s_xb[(tc - 1) * G + tid];
+    // ---- outputs: observation / reward / flags straight to HBM -----------------------------------------------
+    // A work unit is 4 consecutive pairs of one tile row: 12 observation floats, 4 rewards, 4 actions and 4 + 4
+    // flag bytes = whole 16-byte (4-byte for the flags) segments of the [T][B][S] arrays, computed in registers
+    // from (stock before, D, R) and written with dwordx4 stores.
+    {
+      // scalar 64-bit bases of the chunk's first row + 32-bit element offsets per work unit (TC * B * S * 12 < 2^32
+      // is checked by the plan): the stores take the SGPR-base + VGPR-offset form, no 64-bit address arithmetic
+      const int64_t row0 = (int64_t)t0 * total + g_base;
+      char* const p_obs = (char*)(io.obs + row0 * 3);
+      char* const p_rew = (char*)(io.reward + row0);
+      char* const p_act = (char*)(io.action_out + row0);
+      char* const p_tru = (char*)(io.truncated + row0);
+      char* const p_ter = (char*)(io.terminated + row0);
+      const uint32_t utotal = (uint32_t)total;
+      auto outputs = [&](auto GUARD) __attribute__((always_inline)) {
+        constexpr bool guard = decltype(GUARD)::value;
+        const int G4 = G >> 2;
+        for (int u = tid; u < tc * G4; u += NT) {
+          const int r = (int)__umulhi((uint32_t)u, a.mG4);
+          const int gl0 = (u - (int)__umul24(r, G4)) << 2, i0 = (int)__umul24(r, G) + gl0;
+          const uint4 vr = *(const uint4*)(s_rd + i0), vx = *(const uint4*)(s_xb + i0), ve = *(const uint4*)(s_ptend + gl0);
+          const float4 va = *(const float4*)(s_act + i0);
+          const int rdv[4] = {(int)vr.x, (int)vr.y, (int)vr.z, (int)vr.w}, xbv[4] = {(int)vx.x, (int)vx.y, (int)vx.z, (int)vx.w};
+          float o[12], rw[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int R = rdv[k] & 255, D = rdv[k] >> 8, x0 = xbv[k];
+            const int a0 = max(x0 - D, 0);                                // handle_order_request :105-122
+            const int sales = x0 - a0, missed = D - sales;
+            int xa = a0 + min(R, PHX_SHOP_MAX_STOCK - x0);                // handle_stock_response :98-103
+            if (guard) xa = min(xa, PHX_SHOP_MAX_STOCK);
+            if (!guard || ((unsigned)x0 <= (unsigned)PHX_SHOP_MAX_STOCK)) {
+              o[3 * k] = s_tabs[xa]; o[3 * k + 1] = s_tabn[sales]; o[3 * k + 2] = s_tabn[missed];   // encode_observation :124-134
+              rw[k] = (float)__dsub_rn((double)sales, s_pen[xa]);                                 // compute_reward :147, rounded once to f32
+            } else {                                                      // a stock the caller set outside [0, 100]: the formulas
+              float ob[3];
+              shop_obs_f32(xa, sales, missed, (float)a.norm, ob);
+              o[3 * k] = ob[0]; o[3 * k + 1] = ob[1]; o[3 * k + 2] = ob[2];
+              rw[k] = (float)shop_reward(sales, xa);
+            }
+          }
+          const uint32_t tr = (uint32_t)(r == (int)ve.x) | ((uint32_t)(r == (int)ve.y) << 8) |
+                              ((uint32_t)(r == (int)ve.z) << 16) | ((uint32_t)(r == (int)ve.w) << 24);   // truncations["__all__"], env.py:312-318
+          const uint32_t eo = (uint32_t)r * utotal + (uint32_t)gl0;       // element offset from the chunk's first row
+          float4* po = (float4*)(p_obs + (size_t)(eo * 12u));
+          po[0] = make_float4(o[0], o[1], o[2], o[3]); po[1] = make_float4(o[4], o[5], o[6], o[7]); po[2] = make_float4(o[8], o[9], o[10], o[11]);
+          *(float4*)(p_rew + (size_t)(eo * 4u)) = make_float4(rw[0], rw[1], rw[2], rw[3]);
+          *(float4*)(p_act + (size_t)(eo * 4u)) = va;
+          *(uint32_t*)(p_tru + (size_t)eo) = tr;
+          *(uint32_t*)(p_ter + (size_t)eo) = 0u;
+        }
+      };
+      if (weird && t0 == 0) outputs(std::true_type{}); else outputs(std::false_type{});
+    }
+    FTICK(5); fast_lds_barrier(); FTICK(6);
+  }
+#ifdef PHX_TIMING
+  if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 8 + q] = tm[q];
+#endif
+  // ---- state after the fragment ---------------------------------------------------------------------------------
+  if (tid < G) {
+    const int64_t g = g_base + tid;
+    const int R = fin_rd & 255, D = fin_rd >> 8;
+    const int a0 = max(fin_xb - D, 0), sales = fin_xb - a0, missed = D - sales;
+    a.stock[g] = x; a.sales[g] = sales; a.missed[g] = missed; a.delivered[g] = min(R, PHX_SHOP_MAX_STOCK - fin_xb);
+    if (io.last_obs) {
+      float ob[3];
+      shop_obs(x, sales, missed, a.norm, ob);
+      io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
+    }
+    const uint32_t pr = s_pair[tid];
+    if ((pr & 255u) == 0u) {
+      const int bl = (int)(pr >> 8);
+      a.env_step[b_first + bl] = step;
+      a.env_tick[b_first + bl] = s_tick0[bl] + a.T;
+    }
+  }
+}
+
+// ---- host: plan, blob, launcher -------------------------------------------------------------------------------------
+static uint32_t magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); }
+
+bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, ScFastPlan* p) {
+  memset(p, 0, sizeof *p);
+  static const int off = getenv("PHX_ROLLOUT_FAST") ? atoi(getenv("PHX_ROLLOUT_FAST")) == 0 : 0;
+  if (off) return false;
+  if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || num_steps < PHX_FAST_TC) return false;
+  // whole envs per block, a multiple of 4 of them so that every tile row is a whole number of 16-byte
+  // segments; ~32..64 pairs per block (one recurrence wave)
+  int epb = 0;
+  for (int cand = 4; cand * S <= 96 && cand <= 255; cand += 4) if (cand * S >= 32) { epb = cand; break; }
+  if (!epb && 4 * S <= 96) epb = 4;
+  if (!epb || B % epb != 0 || ((int64_t)B * S) % 4 != 0) return false;
+  if ((int64_t)PHX_FAST_TC * B * S * 12 >= ((int64_t)1 << 32)) return false;      // 32-bit store offsets within a chunk
+  p->epb = epb; p->G = epb * S; p->K = K_uniform;
+  const int p2w = (p->G + 63) / 64, p1w = ((PHX_FAST_TC / 4) * p->G + 63) / 64;     // draws of a chunk in one pass
+  int want = 64 * (p2w + p1w);
+  p->nt = want <= 256 ? 256 : (want <= 320 ? 320 : (want <= 384 ? 384 : 512));
+  p->ok = 1;
+  return true;
+}
+
+// one flat, 16-byte aligned image of the kernel's constant LDS sections
+void phx_sc_fast_blob(const ScFastPlan& p, int S, int norm, std::vector<char>& blob, ScFastPlan* offs) {
+  blob.clear();
+  auto section = [&](size_t bytes) { const size_t o = blob.size(); blob.resize(o + ((bytes + 15) & ~(size_t)15), 0); return o; };
+  const int G = p.G, nq = 5 * p.K + 1;
+  size_t o = section((size_t)G * 4);
+  for (int gl = 0; gl < G; ++gl) { const uint32_t v = (uint32_t)(gl % S) | ((uint32_t)(gl / S) << 8); memcpy(&blob[o + (size_t)gl * 4], &v, 4); }
+  offs->off_ds = (int)section(128);
+  for (int k = 0; k < 125; ++k) blob[offs->off_ds + k] = (char)(k % 5 + (k / 5) % 5 + k / 25);
+  offs->off_tabs = (int)section(101 * 4);
+  for (int xs = 0; xs <= 100; ++xs) { const float f = (float)((double)xs / 100.0); memcpy(&blob[offs->off_tabs + xs * 4], &f, 4); }   // supply_chain.py:127-134
+  offs->off_tabn = (int)section((size_t)nq * 4);
+  for (int q = 0; q < nq; ++q) { const float f = (float)((double)q / (double)norm); memcpy(&blob[offs->off_tabn + q * 4], &f, 4); }
+  offs->off_rew = (int)section((size_t)nq * 101 * 4);
+  for (int sl = 0; sl < nq; ++sl)
+    for (int st = 0; st <= 100; ++st) {                              // sales - 0.1 * stock, product and difference rounded separately (:147)
+      volatile double pen = 0.1 * (double)st;
+      volatile double rw = (double)sl - pen;
+      const float f = (float)rw;
+      memcpy(&blob[offs->off_rew + ((size_t)sl * 101 + st) * 4], &f, 4);
+    }
+  offs->blob_bytes = (int)blob.size();
+}
+
+hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  const ScFastPlan& p = sp.sc_fast;
+  FastArgs a;
+  a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
+  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  a.xcd_remap = remap_env >= 0 ? remap_env : 1;
+  uint32_t pk = 1; for (int k = 0; k < p.K; ++k) pk *= 5u;
+  static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
+  a.pK = pk; a.inv_pK = inv[p.K];
+  a.mG = magic32(p.G); a.mG4 = magic32(p.G / 4); a.mS = magic32(sp.S);
+  a.blob_bytes = p.blob_bytes; a.off_ds = p.off_ds; a.off_tabs = p.off_tabs; a.off_tabn = p.off_tabn; a.off_rew = p.off_rew;
+  a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset; a.blob = sp.sc_fast_blob;
+  a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
+  a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
+  a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
+  a.io = io;
+  a.timing = nullptr;
+#ifdef PHX_TIMING
+  { static unsigned long long* tbuf = nullptr; if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 8 * 8192 * sizeof(unsigned long long)); a.timing = tbuf;
+    if (getenv("PHX_TIMING_DUMP")) { static int calls = 0; if (++calls == 20) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(8 * 8 * 8192); (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+      const int wpb = p.nt / 64, nw = (sp.B / p.epb) * wpb; double sum[8] = {0}, w0[8] = {0}; for (int w = 0; w < nw; ++w) for (int q = 0; q < 8; ++q) { sum[q] += h[(size_t)w * 8 + q]; if (w % wpb == 0) w0[q] += h[(size_t)w * 8 + q]; }
+      fprintf(stderr, "FAST_TIMING avg cycles per wave:  setup %.0f | draws %.0f | bar %.0f | P2 %.0f | bar %.0f | out %.0f | bar+setup-loads %.0f | P2 preload %.0f\n", sum[0]/nw, sum[1]/nw, sum[2]/nw, sum[3]/nw, sum[4]/nw, sum[5]/nw, sum[6]/nw, sum[7]/nw);
+      fprintf(stderr, "FAST_TIMING wave0 of each block:  setup %.0f | draws %.0f | bar %.0f | P2 %.0f | bar %.0f | out %.0f | bar+setup-loads %.0f | P2 preload %.0f\n", w0[0]*wpb/nw, w0[1]*wpb/nw, w0[2]*wpb/nw, w0[3]*wpb/nw, w0[4]*wpb/nw, w0[5]*wpb/nw, w0[6]*wpb/nw, w0[7]*wpb/nw); } } }
+#endif
+  const int items = PHX_FAST_TC * p.G;
+  const size_t lds = (size_t)((p.G + 3) & ~3) * 4 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)items * 4 * 5 +
+                     (size_t)((p.G + 3) & ~3) * 4 + (size_t)((p.epb + 3) & ~3) * 4 + 16;
+  const dim3 grid(sp.B / p.epb);
+  static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
+  const int nt = nt_env ? nt_env : p.nt;
+  if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<512>), grid, dim3(512), lds, st, a);
+  else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<384>), grid, dim3(384), lds, st, a);
+  else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<320>), grid, dim3(320), lds, st, a);
+  else hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<256>), grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}

@@ -307,3 +307,37 @@ def test_bench_collective_path_on_one_gpu():
     assert ag["bytes_per_rank"] < ag["raw_trajectory_bytes_per_rank"]
     c4 = r["config4_share"]
     assert c4["agent_steps_per_sec_gather_included"] > 0 and c4["agent_steps_per_sec_gather_excluded"] > 0
+
+
+# ---- the round-2 rollout kernel (phx_sc_rollout.hip): its special cases against the oracle ---------------------
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (9, 6, 64, 23), (3, 2, 48, 40), (12, 5, 16, 31), (1, 1, 64, 20),
+                                             (51, 4, 16, 100), (20, 3, 8, 57)])
+def test_fast_rollout_kernel_edge_cases_match_oracle(S, K, B, num_steps):
+    """device-RNG rollouts through the fast kernel where its plan applies (uniform 1..6 customers, whole envs per
+    block) and through the general kernel otherwise: fragments that start on ticks that are not multiples of 4
+    (per-step launches first), fragment lengths that are no multiple of the chunk, several episode ends per
+    fragment, stocks poked outside [0, 100] (the reference's arithmetic for a negative stock), state hand-over to
+    per-step launches."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, seed=11 + S, env_offset=1000)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S * 100 + K)
+    for t in range(3):                                           # ticks 0..2: the next fragment is not quad-aligned
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+    for T in (1, 7, 20, 41, 100, 3):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, False)
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    # stocks outside [0, 100] (a caller poking ShopAgent.stock): negative sales / a request clamp below zero
+    st = rng.integers(-40, 160, (B, S)).astype(np.int32)
+    o.set_i32("shop.stock", st); d.set_i32("shop.stock", st)
+    for T in (20, 9):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, False)
+    a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+    o.step(a, None, None); d.step(a, None, None)
+    np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
+    np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward))
+    assert (d.err == 0).all()
