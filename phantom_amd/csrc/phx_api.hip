@@ -541,11 +541,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     }
     ScFastPlan plan;
     if (phx_sc_fast_plan(d.B, d.S, Ku, nu, d.num_steps, &plan)) {
-      std::vector<char> blob;
       plan.norm = der.shop_norm[0];
-      phx_sc_fast_blob(plan, d.S, plan.norm, blob, &plan);
-      rc = upload(e, blob.data(), blob.size(), &d.sc_fast_blob);
-      if (rc != PHX_OK) { phx_destroy(e); return rc; }
       d.sc_fast = plan;
     }
   }

@@ -42,7 +42,6 @@ enum {
 #define PHX_FAST_TC 20          // steps per chunk (one Philox block serves 4 ticks: 5 row quads)
 struct ScFastPlan {
   int32_t ok, epb, G, K, nt, norm;
-  int32_t blob_bytes, off_ds, off_tabs, off_tabn, off_rew;
 };
 
 struct DevSpec {
@@ -86,8 +85,7 @@ struct DevSpec {
   const int32_t* shop_cust_agent;// agent index of each customer
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
   int32_t max_cust;              // max customers of one shop
-  ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable) and its constant LDS image
-  const char* sc_fast_blob;
+  ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   // host-built lookup tables of the rollout kernel (exactly the values the formulas give):
   //   [0,101) f32 stock/100 ; [101, 101+n_tabn) f32 x/norm, n_quot valid entries (0 unless
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)
@@ -241,8 +239,11 @@ __device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp,
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
   // one 32x32->64 product per multiplier and round (v_mad_u64_u32 gives hi and lo together)
+#ifndef PHX_PHILOX_ROUNDS
+#define PHX_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < PHX_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
     c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;

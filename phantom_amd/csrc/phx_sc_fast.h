@@ -6,6 +6,4 @@
 
 // decides whether an env shape takes the fast rollout kernel and with which block shape
 bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, ScFastPlan* p);
-// the kernel's constant LDS image (pair table, digit sums, observation / reward tables); fills the offsets of *offs
-void phx_sc_fast_blob(const ScFastPlan& p, int S, int norm, std::vector<char>& blob, ScFastPlan* offs);
 hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);

@@ -15,12 +15,14 @@
 //     and per step it stores one word (the stock BEFORE the step) -- sub, max, add per step on the chain;
 //   * everything derived (sales, missed sales, stock after the step, observation, reward) is recomputed
 //     from (stock before, D, R) in the output phase, which is parallel over (time, pairs);
-//   * the f64 reward (sales - 0.1 * stock, supply_chain.py:147) rounded to the trajectory's f32 comes
-//     from a host-built [sales][stock] table (the formula evaluated on the host in f64, like the observation
-//     tables), so the output phase has no f64 instruction;
-//   * all per-block constants (pair table, digit-sum table, observation / reward tables) are ONE
-//     host-packed blob copied into LDS with 16-byte loads issued together with the state loads: one global
-//     round trip of setup.
+//   * all per-block constants (pair table, digit-sum table, observation / penalty tables) are COMPUTED into
+//     LDS at setup (1 024 workgroups fetching the same cache lines at launch cost ~10 k cycles);
+//   * the recurrence waves do nothing else: the other waves write the outputs of chunk c and draw chunk c + 2
+//     while the recurrence of chunk c + 1 runs -- one barrier per chunk;
+//   * what bounds the kernel now is how fast the memory system takes the trajectory (stores ablated: 15.5 us;
+//     a store-only kernel with this access pattern: 16-20 us): the observation pieces of a work unit are
+//     transposed through LDS so that consecutive lanes write consecutive 16-byte pieces, and a short first
+//     chunk starts the stores early.
 // Fast-path conditions (checked at phx_create / by the launcher; everything else takes
 // phx_sc_rollout_kernel): device RNG and random policy (no replay), every shop with the same 1..6 customers
 // and the same normaliser, whole envs per block with 16-byte aligned tile rows, num_steps >= the chunk length.
@@ -34,13 +36,11 @@
 #include <vector>
 
 struct FastArgs {
-  int32_t B, S, epb, G, K, T, num_steps, xcd_remap;
+  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
   uint32_t pK; float inv_pK;        // 5^K and its f32 reciprocal (floor(y * inv) == y / 5^K for y < 5^6: tests/test_host_logic.py)
-  uint32_t mG, mG4, mS;             // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S  for i < 2^16
-  int32_t blob_bytes, off_ds, off_tabs, off_tabn, off_rew;
+  uint32_t mG, mG4, mS, mPR;        // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4)  for i < 2^16
   int32_t norm;                     // the shops' common max_sales_per_step
   uint64_t seed; int64_t env_offset;
-  const char* blob;
   unsigned long long* timing;       // PHX_TIMING builds only
   int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick;
   phx_rollout_io io;
@@ -52,8 +52,9 @@ __device__ __forceinline__ void fast_lds_barrier() {     // orders LDS traffic o
   asm volatile("" ::: "memory");
 }
 
+// four workgroups per CU must stay co-resident (B = 4096 is ONE round of 1 024 workgroups): NT / 64 waves per SIMD
 template <int NT>
-__global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs a) {
+__global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TC = PHX_FAST_TC;
   const phx_rollout_io& io = a.io;
@@ -77,11 +78,13 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs 
   float* s_tabn = s_tabs + 104;                                         // [5K+1 <= 31] x / norm        supply_chain.py:124-134
   double* s_pen = (double*)(s_tabn + 32);                               // [101] 0.1 * stock in f64     compute_reward :147
   const int items = TC * G;
-  int* s_rd0 = (int*)(s_pen + 102);                                     // 2 x [TC][G]  R | D << 8
-  float* s_act0 = (float*)(s_rd0 + 2 * items);                          // 2 x [TC][G]
-  int* s_xb = (int*)(s_act0 + 2 * items);                               // [TC][G] stock before the step
-  int* s_ptend = s_xb + items;                                          // [G] chunk row that ends the pair's episode, or -1
-  int* s_tick0 = s_ptend + ((G + 3) & ~3);                              // [epb]
+  int* s_rd0 = (int*)(s_pen + 102);                                     // 3 x [TC][G]  R | D << 8        (chunk c in tile c % 3)
+  float* s_act0 = (float*)(s_rd0 + 3 * items);                          // 3 x [TC][G]  action
+  int* s_xb0 = (int*)(s_act0 + 3 * items);                              // 2 x [TC][G]  stock before the step (chunk c in c & 1)
+  const int G4p = (G + 3) & ~3;
+  int* s_ptend0 = s_xb0 + 2 * items;                                    // 2 x [G] chunk row that ends the pair's episode, or -1
+  float* s_ostage = (float*)(s_ptend0 + 2 * G4p);                       // [TC][G][3] observation pieces on their way out (wave-private regions)
+  int* s_tick0 = (int*)(s_ostage + 3 * items);                          // [epb]
   int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
 
   // ---- setup: the state loads are in flight while the tables are computed --------------------------------------
@@ -100,21 +103,29 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs 
     }
     if (tid <= 5 * a.K) s_tabn[tid] = (float)tid / (float)a.norm;
     if (tid < 2) s_flags[tid] = 0;
-    FTICK(6);
     __syncthreads();
     if (tid < a.epb) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
     if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
     __syncthreads();
   }
   const int quad_extra = s_flags[0];      // chunk starts are not quad-aligned for every env: one more row quad
-  const bool weird = s_flags[1] != 0;     // only possible in the first chunk (any step brings the stock into [0, 100])
+  const bool weird = s_flags[1] != 0;     // a stock the caller set outside [0, 100] (any step brings it back into range)
+  FTICK(0);
 
-  // thread roles in the overlapped phase: the waves that hold a recurrence lane walk the recurrence, the
-  // others draw the next chunk (when no wave is left over, everybody draws after the recurrence)
-  const int p2_threads = ((G + 63) >> 6) << 6;
-  const int p1_first = (p2_threads + 64 <= NT) ? p2_threads : 0;
+  // Thread roles: the waves that hold a recurrence lane (tid < rec_threads) walk the stock recurrence and nothing
+  // else after the first chunk's draws; the other waves ("workers") write the outputs of chunk c and draw chunk
+  // c + 2 while the recurrence of chunk c + 1 runs beside them -- one barrier per chunk.
+  const int rec_threads = ((G + 63) >> 6) << 6;
+  // Chunks: a.first_rows rows first, then TC rows each.  (A short first chunk would start the trajectory stores
+  // earlier -- nothing is stored before the first chunk is drawn and walked -- but every extra iteration costs
+  // more than that buys: first_rows = 4 / 8 / 12 measured 23.3 / 23.3 / 23.5 us per launch against 21.5 us for
+  // first_rows = TC, SC64, B = 4096, T = 100.  PHX_ROLLOUT_FIRST overrides.)
+  const int first_rows = a.first_rows;
+  const int n_chunks = 1 + (a.T - first_rows + TC - 1) / TC;
+  auto start_of = [&](int c) { return c == 0 ? 0 : first_rows + (c - 1) * TC; };
+  auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c == 0 ? first_rows : (left < TC ? left : TC); };
 
-  // ---- draws of the chunk starting at step t0 (tc rows) into buffer `buf`, by threads [first, NT).
+  // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by threads [first, NT).
   //      One Philox block serves ticks 4q .. 4q + 3 of a shop: work items are (row quad jr, pair gl).
   auto draws_impl = [&](int t0, int tc, int buf, int first, auto ALIGNED) __attribute__((always_inline)) {
     // ALIGNED: every env's chunk starts on a tick quad and tc is a multiple of 4 -> every row of a unit exists
@@ -135,8 +146,7 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs 
       const uint32_t tick_a = tick_base + (uint32_t)tla;                 // multiple of 4
       uint32_t w[4];
       rng_block(a.seed, genv, tick_a, s, 0, 0, w);
-      int i = (int)__umul24(tla, G) + gl;                                // (tla < 0 only when !aligned: the row is then skipped)
-      if (!aligned) i = tla * G + gl;
+      int i = aligned ? (int)__umul24(tla, G) + gl : tla * G + gl;
 #pragma unroll
       for (int h = 0; h < 4; ++h, i += G) {
         if (!aligned) { const int tl = tla + h; if (tl < 0 || tl >= tc) continue; }
@@ -156,114 +166,148 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs 
     else draws_impl(t0, tc, buf, first, std::false_type{});
   };
 
-  FTICK(0);
-  draws(0, a.T < TC ? a.T : TC, 0, 0);
-  FTICK(1); fast_lds_barrier(); FTICK(2);
-  int buf = 0;
+  // ---- the stock recurrence of chunk c (tc rows), one lane per pair ----------------------------------------------
+  //   stock' = max(stock - D, 0) + min(R, 100 - stock)      handle_order_request / handle_stock_response,
+  //   supply_chain.py:98-122 with decode_action's clamp :139 (<= 100 whenever 0 <= stock <= 100); at the
+  //   episode's last step the caller's env.reset() zeroes the stock (ShopAgent.reset): folded into the operands
+  //   (D' = 4096, R' = 0 give stock' = 0), so the chain carries no select.  Per step it stores ONE word, the stock
+  //   before the step; sales, missed sales and the stock after it are recomputed by the output phase.
   int fin_xb = 0, fin_rd = 0;             // the launch's last step: stock before it and its packed (R, D)
-  for (int t0 = 0; t0 < a.T; t0 += TC, buf ^= 1) {
-    const int tc = (a.T - t0 < TC) ? a.T - t0 : TC;
-    const int t1 = t0 + TC, tc1 = (a.T - t1 < TC) ? a.T - t1 : TC;      // next chunk
-    const int* s_rd = s_rd0 + buf * items;
-    const float* s_act = s_act0 + buf * items;
-    // ---- the stock recurrence, one lane per pair ------------------------------------------------------
-    //   stock' = max(stock - D, 0) + min(R, 100 - stock)      handle_order_request / handle_stock_response,
-    //   supply_chain.py:98-122 with decode_action's clamp :139 (<= 100 whenever 0 <= stock <= 100); at the
-    //   episode's last step the caller's env.reset() zeroes the stock (ShopAgent.reset)
-    if (tid < G) {
-      __builtin_amdgcn_s_setprio(3);
-      const int tend = a.num_steps - 1 - step;                          // chunk row that ends the episode (one at most: TC <= num_steps)
-      const bool ends = tend >= 0 && tend < tc;
-      s_ptend[tid] = ends ? tend : -1;
-      int* xb = s_xb + tid;
-      const int* rdp = s_rd + tid;
-#ifdef PHX_TIMING
-      FTICK(7);
-#endif
-      // one step of the chain; `MINCAP` keeps the general form for a stock the caller set outside [0, 100]
+  auto recurrence = [&](int c, int tc) __attribute__((always_inline)) {
+    if (tid >= G) return;
+    __builtin_amdgcn_s_setprio(3);        // a dependent chain beside waves of Philox / output work: issue whenever ready
+    const int* rdp = s_rd0 + (c % 3) * items + tid;
+    int* xb = s_xb0 + (c & 1) * items + tid;
+    const int tend = a.num_steps - 1 - step;                            // chunk row that ends the episode (one at most: TC <= num_steps)
+    const bool ends = tend >= 0 && tend < tc;
+    s_ptend0[(c & 1) * G4p + tid] = ends ? tend : -1;
+    // one step of the chain; `MINCAP` keeps the general form for a stock the caller set outside [0, 100]
 #define FAST_STEP(h_, rd_, MINCAP)                                                                         \
-      {                                                                                                    \
-        const bool end_ = ((h_) == tend);                                                                  \
-        const int Dm_ = end_ ? 4096 : ((rd_) >> 8), Rm_ = end_ ? 0 : ((rd_) & 255);                        \
-        xb[(h_) * G] = x;                                                                                  \
-        const int xn_ = max(x - Dm_, 0) + min(Rm_, PHX_SHOP_MAX_STOCK - x);                                \
-        x = (MINCAP) ? (end_ ? 0 : min(xn_, PHX_SHOP_MAX_STOCK)) : xn_;                                    \
-      }
-      if (tc == TC && !weird) {                 // the common case: straight-line code, operands fetched in one burst
-        int rd[TC];
+    {                                                                                                      \
+      const bool end_ = ((h_) == tend);                                                                    \
+      const int Dm_ = end_ ? 4096 : ((rd_) >> 8), Rm_ = end_ ? 0 : ((rd_) & 255);                          \
+      xb[(h_) * G] = x; fin_xb = x;                                                                        \
+      const int xn_ = max(x - Dm_, 0) + min(Rm_, PHX_SHOP_MAX_STOCK - x);                                  \
+      x = (MINCAP) ? (end_ ? 0 : min(xn_, PHX_SHOP_MAX_STOCK)) : xn_;                                      \
+    }
+    if (tc == TC && !weird) {               // straight-line code, the chunk's operands fetched in one burst
+      int rd[TC];
 #pragma unroll
-        for (int h = 0; h < TC; ++h) rd[h] = rdp[h * G];
+      for (int h = 0; h < TC; ++h) rd[h] = rdp[h * G];
 #pragma unroll
-        for (int h = 0; h < TC; ++h) FAST_STEP(h, rd[h], false)
-        fin_rd = rd[TC - 1];
-      } else {                                  // a shorter last chunk, or the first chunk of an out-of-range stock
-        for (int h = 0; h < tc; ++h) { const int rdh = rdp[h * G]; FAST_STEP(h, rdh, true) fin_rd = rdh; }
-      }
+      for (int h = 0; h < TC; ++h) FAST_STEP(h, rd[h], false)
+      fin_rd = rd[TC - 1];
+    } else {                                // a ragged last chunk, or an out-of-range stock at launch
+      for (int h = 0; h < tc; ++h) { const int rdh = rdp[h * G]; FAST_STEP(h, rdh, true) fin_rd = rdh; }
+    }
 #undef FAST_STEP
-      step += tc;
-      if (ends) step -= a.num_steps;
-      __builtin_amdgcn_s_setprio(0);
-    }
-    FTICK(3);
-    // ---- draws of the NEXT chunk, overlapped with the recurrence above ------------------------------------
-    if (t1 < a.T) draws(t1, tc1, buf ^ 1, p1_first);
-    FTICK(1); fast_lds_barrier(); FTICK(4);
-    if (t1 >= a.T && tid < G) fin_xb = s_xb[(tc - 1) * G + tid];
-    // ---- outputs: observation / reward / flags straight to HBM -----------------------------------------------
-    // A work unit is 4 consecutive pairs of one tile row: 12 observation floats, 4 rewards, 4 actions and 4 + 4
-    // flag bytes = whole 16-byte (4-byte for the flags) segments of the [T][B][S] arrays, computed in registers
-    // from (stock before, D, R) and written with dwordx4 stores.
-    {
-      // scalar 64-bit bases of the chunk's first row + 32-bit element offsets per work unit (TC * B * S * 12 < 2^32
-      // is checked by the plan): the stores take the SGPR-base + VGPR-offset form, no 64-bit address arithmetic
-      const int64_t row0 = (int64_t)t0 * total + g_base;
-      char* const p_obs = (char*)(io.obs + row0 * 3);
-      char* const p_rew = (char*)(io.reward + row0);
-      char* const p_act = (char*)(io.action_out + row0);
-      char* const p_tru = (char*)(io.truncated + row0);
-      char* const p_ter = (char*)(io.terminated + row0);
-      const uint32_t utotal = (uint32_t)total;
-      auto outputs = [&](auto GUARD) __attribute__((always_inline)) {
-        constexpr bool guard = decltype(GUARD)::value;
-        const int G4 = G >> 2;
-        for (int u = tid; u < tc * G4; u += NT) {
-          const int r = (int)__umulhi((uint32_t)u, a.mG4);
-          const int gl0 = (u - (int)__umul24(r, G4)) << 2, i0 = (int)__umul24(r, G) + gl0;
-          const uint4 vr = *(const uint4*)(s_rd + i0), vx = *(const uint4*)(s_xb + i0), ve = *(const uint4*)(s_ptend + gl0);
-          const float4 va = *(const float4*)(s_act + i0);
-          const int rdv[4] = {(int)vr.x, (int)vr.y, (int)vr.z, (int)vr.w}, xbv[4] = {(int)vx.x, (int)vx.y, (int)vx.z, (int)vx.w};
-          float o[12], rw[4];
+    step += tc;
+    if (ends) step -= a.num_steps;
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- outputs of chunk c: observation / reward / flags straight to HBM, by the workers ----------------------------
+  // A work unit is 4 consecutive pairs of one tile row: 12 observation floats, 4 rewards, 4 actions and 4 + 4
+  // flag bytes = whole 16-byte (4-byte for the flags) segments of the [T][B][S] arrays, computed in registers
+  // from (stock before, D, R).
+  auto outputs_impl = [&](int c, int t0, int tc, auto GUARD) __attribute__((always_inline)) {
+    constexpr bool guard = decltype(GUARD)::value;
+    const int first = rec_threads;
+    if (tid < first) return;
+    const int* s_rd = s_rd0 + (c % 3) * items;
+    const float* s_act = s_act0 + (c % 3) * items;
+    const int* s_xb = s_xb0 + (c & 1) * items;
+    const int* s_ptend = s_ptend0 + (c & 1) * G4p;
+    // scalar 64-bit bases of the chunk's first row + 32-bit element offsets per work unit (TC * B * S * 12 < 2^32
+    // is checked by the plan): the stores take the SGPR-base + VGPR-offset form, no 64-bit address arithmetic
+    const int64_t row0 = (int64_t)t0 * total + g_base;
+    char* const p_obs = (char*)(io.obs + row0 * 3);
+    char* const p_rew = (char*)(io.reward + row0);
+    char* const p_act = (char*)(io.action_out + row0);
+    char* const p_tru = (char*)(io.truncated + row0);
+    char* const p_ter = (char*)(io.terminated + row0);
+    const uint32_t utotal = (uint32_t)total;
+    const int G4 = G >> 2, nw = NT - first, n_units = tc * G4;
+    const uint32_t PR = 3u * (uint32_t)G4;                              // 16-byte observation pieces per tile row
+    const int lane = tid & 63;
+    for (int ub = (tid - first) - lane; ub < n_units; ub += nw) {       // ub: the wave's first unit (uniform per wave)
+      const int u = ub + lane;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vrw = va;
+      uint32_t tr = 0u, eo = 0u;
+      if (u < n_units) {
+        const int r = (int)__umulhi((uint32_t)u, a.mG4);
+        const int gl0 = (u - (int)__umul24(r, G4)) << 2, i0 = (int)__umul24(r, G) + gl0;
+        const uint4 vr = *(const uint4*)(s_rd + i0), vx = *(const uint4*)(s_xb + i0), ve = *(const uint4*)(s_ptend + gl0);
+        va = *(const float4*)(s_act + i0);
+        const int rdv[4] = {(int)vr.x, (int)vr.y, (int)vr.z, (int)vr.w}, xbv[4] = {(int)vx.x, (int)vx.y, (int)vx.z, (int)vx.w};
+        float o[12], rw[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int R = rdv[k] & 255, D = rdv[k] >> 8, x0 = xbv[k];
-            const int a0 = max(x0 - D, 0);                                // handle_order_request :105-122
-            const int sales = x0 - a0, missed = D - sales;
-            int xa = a0 + min(R, PHX_SHOP_MAX_STOCK - x0);                // handle_stock_response :98-103
-            if (guard) xa = min(xa, PHX_SHOP_MAX_STOCK);
-            if (!guard || ((unsigned)x0 <= (unsigned)PHX_SHOP_MAX_STOCK)) {
-              o[3 * k] = s_tabs[xa]; o[3 * k + 1] = s_tabn[sales]; o[3 * k + 2] = s_tabn[missed];   // encode_observation :124-134
-              rw[k] = (float)__dsub_rn((double)sales, s_pen[xa]);                                 // compute_reward :147, rounded once to f32
-            } else {                                                      // a stock the caller set outside [0, 100]: the formulas
-              float ob[3];
-              shop_obs_f32(xa, sales, missed, (float)a.norm, ob);
-              o[3 * k] = ob[0]; o[3 * k + 1] = ob[1]; o[3 * k + 2] = ob[2];
-              rw[k] = (float)shop_reward(sales, xa);
-            }
+        for (int k = 0; k < 4; ++k) {
+          const int R = rdv[k] & 255, D = rdv[k] >> 8, x0 = xbv[k];
+          const int sales = min(x0, D);                                 // handle_order_request :105-122 (== x0 - max(x0 - D, 0))
+          const int missed = D - sales;
+          int xa = x0 - sales + min(R, PHX_SHOP_MAX_STOCK - x0);        // handle_stock_response :98-103
+          if (guard) xa = min(xa, PHX_SHOP_MAX_STOCK);
+          if (!guard || ((unsigned)x0 <= (unsigned)PHX_SHOP_MAX_STOCK)) {
+            o[3 * k] = s_tabs[xa]; o[3 * k + 1] = s_tabn[sales]; o[3 * k + 2] = s_tabn[missed];   // encode_observation :124-134
+            rw[k] = (float)__dsub_rn((double)sales, s_pen[xa]);                                 // compute_reward :147, rounded once to f32
+          } else {                                                      // a stock the caller set outside [0, 100]: the formulas
+            float ob[3];
+            shop_obs_f32(xa, sales, missed, (float)a.norm, ob);
+            o[3 * k] = ob[0]; o[3 * k + 1] = ob[1]; o[3 * k + 2] = ob[2];
+            rw[k] = (float)shop_reward(sales, xa);
           }
-          const uint32_t tr = (uint32_t)(r == (int)ve.x) | ((uint32_t)(r == (int)ve.y) << 8) |
-                              ((uint32_t)(r == (int)ve.z) << 16) | ((uint32_t)(r == (int)ve.w) << 24);   // truncations["__all__"], env.py:312-318
-          const uint32_t eo = (uint32_t)r * utotal + (uint32_t)gl0;       // element offset from the chunk's first row
-          float4* po = (float4*)(p_obs + (size_t)(eo * 12u));
-          po[0] = make_float4(o[0], o[1], o[2], o[3]); po[1] = make_float4(o[4], o[5], o[6], o[7]); po[2] = make_float4(o[8], o[9], o[10], o[11]);
-          *(float4*)(p_rew + (size_t)(eo * 4u)) = make_float4(rw[0], rw[1], rw[2], rw[3]);
-          *(float4*)(p_act + (size_t)(eo * 4u)) = va;
-          *(uint32_t*)(p_tru + (size_t)eo) = tr;
-          *(uint32_t*)(p_ter + (size_t)eo) = 0u;
         }
-      };
-      if (weird && t0 == 0) outputs(std::true_type{}); else outputs(std::false_type{});
+        vrw = make_float4(rw[0], rw[1], rw[2], rw[3]);
+        tr = (uint32_t)(r == (int)ve.x) | ((uint32_t)(r == (int)ve.y) << 8) |
+             ((uint32_t)(r == (int)ve.z) << 16) | ((uint32_t)(r == (int)ve.w) << 24);            // truncations["__all__"], env.py:312-318
+        eo = (uint32_t)r * utotal + (uint32_t)gl0;                      // element offset from the chunk's first row
+        // The unit's three 16-byte observation pieces go through LDS: piece 3 u + j is their position in the chunk's
+        // row-major observation block, so that each store instruction below writes CONSECUTIVE pieces from
+        // consecutive lanes.  (A 48-byte lane stride costs ~3x the L2 write transactions: the store-only
+        // microbenchmark of this trajectory takes 19.9 us per launch with it, 16.2 us with contiguous pieces,
+        // 14 us for a plain fill of the same bytes.)
+        float4* st = (float4*)(s_ostage + 12 * u);
+        st[0] = make_float4(o[0], o[1], o[2], o[3]); st[1] = make_float4(o[4], o[5], o[6], o[7]); st[2] = make_float4(o[8], o[9], o[10], o[11]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave's own pieces are in LDS (wave-private region: no barrier)
+      const uint32_t q0 = 3u * (uint32_t)ub, qn = 3u * (uint32_t)n_units;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t q = q0 + (uint32_t)lane + 64u * (uint32_t)k;
+        if (q < qn) {
+          const uint32_t rr = __umulhi(q, a.mPR), pc = q - rr * PR;     // tile row and piece within the row
+          *(float4*)(p_obs + (size_t)(rr * (utotal * 12u) + pc * 16u)) = *(const float4*)(s_ostage + 4 * q);
+        }
+      }
+      if (u < n_units) {
+        *(float4*)(p_rew + (size_t)(eo * 4u)) = vrw;
+        *(float4*)(p_act + (size_t)(eo * 4u)) = va;
+        *(uint32_t*)(p_tru + (size_t)eo) = tr;
+        *(uint32_t*)(p_ter + (size_t)eo) = 0u;
+      }
     }
-    FTICK(5); fast_lds_barrier(); FTICK(6);
+  };
+  auto outputs = [&](int c, int t0, int tc) __attribute__((always_inline)) {
+    if (weird && c == 0) outputs_impl(c, t0, tc, std::true_type{});
+    else outputs_impl(c, t0, tc, std::false_type{});
+  };
+
+  // ---- schedule.  Iteration it = -2: everybody draws chunk 0;  it = -1: recurrence(0) beside draws(1);  it >= 0:
+  //        workers: outputs(it), draws(it + 2)    beside    recurrence lanes: recurrence(it + 1)        one barrier
+  //      Draw tiles rotate over three buffers (draws(c + 2) overwrites what outputs(c - 1) read before the last
+  //      barrier), stock tiles over two.  One call site per phase keeps the code small.
+  for (int it = -2; it < n_chunks; ++it) {
+    const int co = it, cr = it + 1, cd = it + 2;
+    if (tid < rec_threads && it > -2) {
+      if (cr < n_chunks) recurrence(cr, rows_of(cr));
+      FTICK(3);
+    } else {
+      if (co >= 0) { outputs(co, start_of(co), rows_of(co)); FTICK(5); }
+      if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd % 3, it == -2 ? 0 : rec_threads);
+      FTICK(1);
+    }
+    fast_lds_barrier(); FTICK(6);
   }
 #ifdef PHX_TIMING
   if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 8 + q] = tm[q];
@@ -272,7 +316,7 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_fast_kernel(const FastArgs 
   if (tid < G) {
     const int64_t g = g_base + tid;
     const int R = fin_rd & 255, D = fin_rd >> 8;
-    const int a0 = max(fin_xb - D, 0), sales = fin_xb - a0, missed = D - sales;
+    const int sales = min(fin_xb, D), missed = D - sales;
     a.stock[g] = x; a.sales[g] = sales; a.missed[g] = missed; a.delivered[g] = min(R, PHX_SHOP_MAX_STOCK - fin_xb);
     if (io.last_obs) {
       float ob[3];
@@ -311,30 +355,6 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
   return true;
 }
 
-// one flat, 16-byte aligned image of the kernel's constant LDS sections
-void phx_sc_fast_blob(const ScFastPlan& p, int S, int norm, std::vector<char>& blob, ScFastPlan* offs) {
-  blob.clear();
-  auto section = [&](size_t bytes) { const size_t o = blob.size(); blob.resize(o + ((bytes + 15) & ~(size_t)15), 0); return o; };
-  const int G = p.G, nq = 5 * p.K + 1;
-  size_t o = section((size_t)G * 4);
-  for (int gl = 0; gl < G; ++gl) { const uint32_t v = (uint32_t)(gl % S) | ((uint32_t)(gl / S) << 8); memcpy(&blob[o + (size_t)gl * 4], &v, 4); }
-  offs->off_ds = (int)section(128);
-  for (int k = 0; k < 125; ++k) blob[offs->off_ds + k] = (char)(k % 5 + (k / 5) % 5 + k / 25);
-  offs->off_tabs = (int)section(101 * 4);
-  for (int xs = 0; xs <= 100; ++xs) { const float f = (float)((double)xs / 100.0); memcpy(&blob[offs->off_tabs + xs * 4], &f, 4); }   // supply_chain.py:127-134
-  offs->off_tabn = (int)section((size_t)nq * 4);
-  for (int q = 0; q < nq; ++q) { const float f = (float)((double)q / (double)norm); memcpy(&blob[offs->off_tabn + q * 4], &f, 4); }
-  offs->off_rew = (int)section((size_t)nq * 101 * 4);
-  for (int sl = 0; sl < nq; ++sl)
-    for (int st = 0; st <= 100; ++st) {                              // sales - 0.1 * stock, product and difference rounded separately (:147)
-      volatile double pen = 0.1 * (double)st;
-      volatile double rw = (double)sl - pen;
-      const float f = (float)rw;
-      memcpy(&blob[offs->off_rew + ((size_t)sl * 101 + st) * 4], &f, 4);
-    }
-  offs->blob_bytes = (int)blob.size();
-}
-
 hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const ScFastPlan& p = sp.sc_fast;
   FastArgs a;
@@ -344,9 +364,13 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   uint32_t pk = 1; for (int k = 0; k < p.K; ++k) pk *= 5u;
   static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
   a.pK = pk; a.inv_pK = inv[p.K];
-  a.mG = magic32(p.G); a.mG4 = magic32(p.G / 4); a.mS = magic32(sp.S);
-  a.blob_bytes = p.blob_bytes; a.off_ds = p.off_ds; a.off_tabs = p.off_tabs; a.off_tabn = p.off_tabn; a.off_rew = p.off_rew;
-  a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset; a.blob = sp.sc_fast_blob;
+  a.mG = magic32(p.G); a.mG4 = magic32(p.G / 4); a.mS = magic32(sp.S); a.mPR = magic32(3 * (p.G / 4));
+  a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset;
+  static const int first_env = getenv("PHX_ROLLOUT_FIRST") ? atoi(getenv("PHX_ROLLOUT_FIRST")) : 0;
+  int first = first_env > 0 ? first_env : PHX_FAST_TC;
+  if (first > PHX_FAST_TC) first = PHX_FAST_TC;
+  if (io.T <= PHX_FAST_TC) first = io.T;
+  a.first_rows = first;
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
@@ -360,11 +384,14 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
       fprintf(stderr, "FAST_TIMING wave0 of each block:  setup %.0f | draws %.0f | bar %.0f | P2 %.0f | bar %.0f | out %.0f | bar+setup-loads %.0f | P2 preload %.0f\n", w0[0]*wpb/nw, w0[1]*wpb/nw, w0[2]*wpb/nw, w0[3]*wpb/nw, w0[4]*wpb/nw, w0[5]*wpb/nw, w0[6]*wpb/nw, w0[7]*wpb/nw); } } }
 #endif
   const int items = PHX_FAST_TC * p.G;
-  const size_t lds = (size_t)((p.G + 3) & ~3) * 4 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)items * 4 * 5 +
-                     (size_t)((p.G + 3) & ~3) * 4 + (size_t)((p.epb + 3) & ~3) * 4 + 16;
+  // constants (pair table, digit sums, observation / penalty tables) + 3 draw tiles x 2 planes + 2 stock tiles +
+  // 2 episode-end rows + the observation staging tile (3 floats per item) + ticks + flags
+  const size_t lds = (size_t)((p.G + 3) & ~3) * 4 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)items * 4 * (6 + 2 + 3) +
+                     (size_t)((p.G + 3) & ~3) * 8 + (size_t)((p.epb + 3) & ~3) * 4 + 16;
   const dim3 grid(sp.B / p.epb);
   static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
-  const int nt = nt_env ? nt_env : p.nt;
+  const int rec = ((p.G + 63) / 64) * 64;
+  const int nt = (nt_env && nt_env >= rec + 64) ? nt_env : p.nt;
   if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<512>), grid, dim3(512), lds, st, a);
   else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<384>), grid, dim3(384), lds, st, a);
   else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<320>), grid, dim3(320), lds, st, a);
