@@ -291,7 +291,7 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and args.config == "sc64" and B == BATCH:
         try:
-            rec = json.load(open(pmc)).get("phx_sc_rollout_kernel", {})
+            rec = json.load(open(pmc)).get("phx_sc_rollout_fast_kernel", {})
             traffic = rec.get("hbm_bytes_per_launch")
             traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command: " + \
                 str(rec.get("source", "see file")) + "); not re-measured by this run"
@@ -309,7 +309,7 @@ def main():
     f1.record(); torch.cuda.synchronize()
     fill_gbs = alg / (f0.elapsed_time(f1) / 20 * 1e-3) / 1e9
     del fill_buf
-    roofline = {"bound": "hbm", "kernel": "phx_sc_rollout_kernel", "achieved": achieved,
+    roofline = {"bound": "hbm", "kernel": "phx_sc_rollout_fast_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg,
                 "launch_ms": launch_ms, "launches_timed": n_full, "launch": f"T={T} steps x B={B} envs",
