@@ -26,6 +26,8 @@
 #include "phx_epilogue.h"
 
 #define ERRKEY_NONE 0x7fffffff
+#define PHX_HUB_MIN 12        // batches longer than this are rank-sorted by the whole workgroup
+#define PHX_MAX_HUBS 32
 
 
 template <int NT>
@@ -195,10 +197,52 @@ __device__ __forceinline__ void pre_resolution(const DevSpec& sp, const Topo& tp
   }
 }
 
+// The mutable attributes a receiver's handlers touch, held in registers while its lane walks the batch: every
+// message of a shop's inbox used to be three or four DEPENDENT read-modify-write round trips to the state blob
+// (stock, missed_sales, sales; a load after a store to the same address waits for the store), ~20 k of the
+// ~80 k cycles of an SC64 env-step.  Kinds with larger state (advertisers, buyers' price tables) stay in the blob.
+struct AgentState { int32_t i0, i1, i2, i3; double f0, f1; };
+__device__ __forceinline__ bool kind_state_cached(int kind) {
+  return kind == PHX_KIND_SHOP || kind == PHX_KIND_SELLER || kind == PHX_KIND_CASHBOX || kind == PHX_KIND_REQRESP;
+}
+__device__ __forceinline__ void load_state(const DevSpec& sp, const AgentRef& r, AgentState& st) {
+  switch (r.kind) {
+    case PHX_KIND_SHOP:
+      st.i0 = fld<int32_t>(sp, F_SHOP_STOCK)[r.base]; st.i1 = fld<int32_t>(sp, F_SHOP_SALES)[r.base];
+      st.i2 = fld<int32_t>(sp, F_SHOP_MISSED)[r.base]; st.i3 = fld<int32_t>(sp, F_SHOP_DELIVERED)[r.base]; break;
+    case PHX_KIND_SELLER:
+      st.f0 = fld<double>(sp, F_SELLER_PRICE)[r.base]; st.f1 = fld<double>(sp, F_SELLER_REVENUE)[r.base];
+      st.i0 = fld<int32_t>(sp, F_SELLER_TX)[r.base]; break;
+    case PHX_KIND_CASHBOX: st.f0 = fld<double>(sp, F_CASHBOX_TOTAL)[r.base]; break;
+    case PHX_KIND_REQRESP: st.i0 = fld<int32_t>(sp, F_REQRESP_REQ)[r.base]; st.i1 = fld<int32_t>(sp, F_REQRESP_RES)[r.base]; break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void store_state(const DevSpec& sp, const AgentRef& r, const AgentState& st) {
+  switch (r.kind) {
+    case PHX_KIND_SHOP:
+      fld<int32_t>(sp, F_SHOP_STOCK)[r.base] = st.i0; fld<int32_t>(sp, F_SHOP_SALES)[r.base] = st.i1;
+      fld<int32_t>(sp, F_SHOP_MISSED)[r.base] = st.i2; fld<int32_t>(sp, F_SHOP_DELIVERED)[r.base] = st.i3; break;
+    case PHX_KIND_SELLER:
+      fld<double>(sp, F_SELLER_REVENUE)[r.base] = st.f1; fld<int32_t>(sp, F_SELLER_TX)[r.base] = st.i0; break;
+    case PHX_KIND_CASHBOX: fld<double>(sp, F_CASHBOX_TOTAL)[r.base] = st.f0; break;
+    case PHX_KIND_REQRESP: fld<int32_t>(sp, F_REQRESP_REQ)[r.base] = st.i0; fld<int32_t>(sp, F_REQRESP_RES)[r.base] = st.i1; break;
+    default: break;
+  }
+}
+// receivers whose handlers neither read nor write agent state: their messages are handled one lane per MESSAGE
+// (a factory's 51 StockRequests in SC256 were one lane's sequential chain, the longest of the step)
+__device__ __forceinline__ bool kind_stateless(int kind) {
+  return kind == PHX_KIND_FACTORY || kind == PHX_KIND_CUSTOMER || kind == PHX_KIND_HALVER || kind == PHX_KIND_FORWARDER ||
+         kind == PHX_KIND_MOCK_STRAT || kind == PHX_KIND_MOCK_AGENT;
+}
+
 // Agent.handle_message (agents.py:122-155): returns true and fills `resp` (dst/type/payload)
 // when the handler answers; sets `code` to PHX_ERR_UNKNOWN_MSG for an unhandled payload type.
+// `st`: the receiver's register-cached state (kind_state_cached kinds).
 __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp, int b, int a, const DevMsg& m,
-                                               int clock, const uint8_t* exo_b, uint32_t tick, DevMsg& resp, int& code) {
+                                               int clock, const uint8_t* exo_b, uint32_t tick, DevMsg& resp, int& code,
+                                               AgentState& st) {
   const AgentRef r = agent_ref(sp, tp, b, a);
   const int32_t* pi = tp.param_i + a * PHX_NPI;
   resp.src = (uint16_t)a; resp.dst = m.src; resp.pad = 0; resp.type = 0;
@@ -208,22 +252,21 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp
         resp.type = PHX_MSG_STOCK_RESPONSE; resp.p.i = m.p.i; return true;
       }
       break;
-    case PHX_KIND_SHOP: {
-      int32_t* stock = fld<int32_t>(sp, F_SHOP_STOCK) + r.base;
+    case PHX_KIND_SHOP: {                                      // st: i0 stock, i1 sales, i2 missed_sales, i3 delivered_stock
       if (m.type == PHX_MSG_STOCK_RESPONSE) {                  // supply_chain.py:98-103
-        fld<int32_t>(sp, F_SHOP_DELIVERED)[r.base] = (int32_t)m.p.i;
-        const int ns = *stock + (int32_t)m.p.i;
-        *stock = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
+        st.i3 = (int32_t)m.p.i;
+        const int ns = st.i0 + (int32_t)m.p.i;
+        st.i0 = ns < PHX_SHOP_MAX_STOCK ? ns : PHX_SHOP_MAX_STOCK;
         return false;
       }
       if (m.type == PHX_MSG_ORDER_REQUEST) {                   // supply_chain.py:105-122
         const int req = (int)m.p.i;
         int sell;
-        if (req > *stock) {
-          fld<int32_t>(sp, F_SHOP_MISSED)[r.base] += req - *stock;
-          sell = *stock; *stock = 0;
-        } else { sell = req; *stock -= req; }
-        fld<int32_t>(sp, F_SHOP_SALES)[r.base] += sell;
+        if (req > st.i0) {
+          st.i2 += req - st.i0;
+          sell = st.i0; st.i0 = 0;
+        } else { sell = req; st.i0 -= req; }
+        st.i1 += sell;
         resp.type = PHX_MSG_ORDER_RESPONSE; resp.p.i = sell; return true;
       }
       break;
@@ -231,11 +274,11 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp
     case PHX_KIND_CUSTOMER:
       if (m.type == PHX_MSG_ORDER_RESPONSE) return false;      // supply_chain.py:55-59
       break;
-    case PHX_KIND_SELLER:
+    case PHX_KIND_SELLER:                                      // st: f0 price, f1 revenue, i0 tx
       if (m.type == PHX_MSG_ORDER) {
-        const double amount = __dmul_rn(fld<double>(sp, F_SELLER_PRICE)[r.base], (double)m.p.i);
-        fld<double>(sp, F_SELLER_REVENUE)[r.base] = __dadd_rn(fld<double>(sp, F_SELLER_REVENUE)[r.base], amount);
-        fld<int32_t>(sp, F_SELLER_TX)[r.base] += (int32_t)m.p.i;
+        const double amount = __dmul_rn(st.f0, (double)m.p.i);
+        st.f1 = __dadd_rn(st.f1, amount);
+        st.i0 += (int32_t)m.p.i;
         return false;
       }
       break;
@@ -256,7 +299,7 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp
     case PHX_KIND_CASHBOX:
       if (m.type == PHX_MSG_CASH) {                            // test_network.py:26-34
         if (m.p.f > 25) {
-          fld<double>(sp, F_CASHBOX_TOTAL)[r.base] += m.p.f / 2.0;
+          st.f0 += m.p.f / 2.0;
           resp.type = PHX_MSG_CASH; resp.p.f = m.p.f / 2.0; return true;
         }
         return false;
@@ -264,10 +307,10 @@ __device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp
       break;
     case PHX_KIND_REQRESP:
       if (m.type == PHX_MSG_REQUEST) {                         // test_resolver.py:31-37
-        fld<int32_t>(sp, F_REQRESP_REQ)[r.base] = clock;
+        st.i0 = clock;
         resp.type = PHX_MSG_RESPONSE; resp.p.f = m.p.f / 2.0; return true;
       }
-      if (m.type == PHX_MSG_RESPONSE) { fld<int32_t>(sp, F_REQRESP_RES)[r.base] = clock; return false; }
+      if (m.type == PHX_MSG_RESPONSE) { st.i1 = clock; return false; }
       break;
     case PHX_KIND_FORWARDER:                                   // test_resolver.py:93-96
       if (pi[0] >= 0) { resp.dst = (uint16_t)pi[0]; resp.type = PHX_MSG_PING; resp.p.i = 1; return true; }
@@ -596,7 +639,8 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   __shared__ int wave_sums[NT / 64];
-  __shared__ int s_errkey, s_nterm, s_ntrunc;
+  __shared__ int s_errkey, s_nterm, s_ntrunc, s_nhub;
+  __shared__ int s_hub[PHX_MAX_HUBS];
 #ifdef PHX_TIMING
   unsigned long long gtm[16] = {0}, gprev = __builtin_readcyclecounter();
 #define GTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
@@ -798,18 +842,73 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
           adx_coop_count<NT>(sp, tp, x, a, live, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], resp + goff[a],
                              wave_sums, first, &s_errkey, seq_base + goff[a]);
     }
-    // one lane per receiver: batch in send order, handled one message at a time (agents.py:96-120)
+    // ---- batches in send order.  A short batch is insertion-sorted by its receiver's lane; a long one (a hub: the
+    //      factory of SC256 receives 51 requests) is rank-sorted by the whole workgroup first
+    if (tid == 0) s_nhub = 0;
+    __syncthreads();
+    for (int a = tid; a < A; a += NT)
+      if (cnt[a] > PHX_HUB_MIN && !(has_adx && tp.kind[a] == PHX_KIND_ADEXCHANGE)) { const int k = atomicAdd(&s_nhub, 1); if (k < PHX_MAX_HUBS) s_hub[k] = a; }
+    __syncthreads();
+    const int n_hub = s_nhub < PHX_MAX_HUBS ? s_nhub : 0;      // more hubs than slots: their lanes sort (slow, correct)
+    for (int hx = 0; hx < n_hub; ++hx) {
+      const int a = s_hub[hx], c = cnt[a];
+      int* seg = order + goff[a];
+      int* tmp = slot + goff[a];                               // the round's slot[] entries of this segment are dead
+      for (int k = tid; k < c; k += NT) {
+        const int v = seg[k]; int r = 0;
+        for (int j = 0; j < c; ++j) r += seg[j] < v;
+        tmp[r] = v;
+      }
+      __syncthreads();
+      for (int k = tid; k < c; k += NT) seg[k] = tmp[k];
+      __syncthreads();
+    }
     for (int a = tid; a < A; a += NT) {
       const int c = cnt[a];
-      if (c == 0) continue;
-      if (has_adx && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;    // done by phase A
+      if (c < 2 || (n_hub > 0 && c > PHX_HUB_MIN)) continue;
+      if (has_adx && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;
       int* seg = order + goff[a];
       for (int x = 1; x < c; ++x) {                             // insertion sort by sequence number
         const int v = seg[x]; int y = x - 1;
         while (y >= 0 && seg[y] > v) { seg[y + 1] = seg[y]; --y; }
         seg[y + 1] = v;
       }
-      if (tp.kind[a] == PHX_KIND_ADEXCHANGE) {                  // overrides handle_batch: count now, emit after the scan
+    }
+    __syncthreads();
+    // dropped: receiver not in contexts (resolvers.py:143-144), edge filter (:146-148), or a send that already
+    // failed its checks (type 0).  The receive-side edge filter can only drop something when sends skipped the
+    // edge check (ignore_connection_errors): every queued message already passed has_edge.
+    auto deliver = [&](int a, int P, const DevMsg& m, AgentState& st) {
+      DevMsg out; out.type = 0;
+      if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
+        int code = 0;
+        const bool answered = handle_message(sp, tp, b, a, m, clock + P, exo_b, tick, out, code, st);
+        if (code) set_errkey(&s_errkey, seq_base + P, code);
+        if (answered) {                                         // network.send(receiver, sub_receiver, payload) :156-158
+          const int sc = dev_send_check(sp, tp, out.src, out.dst, out.type);
+          if (sc) { set_errkey(&s_errkey, seq_base + P, sc); out.type = 0; }
+        } else out.type = 0;
+      }
+      resp[P] = out;
+      scanbuf[P] = out.type != 0;
+    };
+    // receivers without state (factory, customer, ...): one lane per MESSAGE -- the handlers of a batch commute
+    for (int P = tid; P < n; P += NT) {
+      const DevMsg m = qc[order[P]];
+      const int a = m.dst;
+      if (!kind_stateless(tp.kind[a])) continue;
+      AgentState none;
+      deliver(a, P, m, none);
+    }
+    // every other receiver: one lane walks its batch, handled one message at a time (agents.py:96-120)
+    for (int a = tid; a < A; a += NT) {
+      const int c = cnt[a];
+      if (c == 0) continue;
+      const int kind_a = tp.kind[a];
+      if (kind_stateless(kind_a)) continue;
+      if (has_adx && kind_a == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;    // done by phase A
+      int* seg = order + goff[a];
+      if (kind_a == PHX_KIND_ADEXCHANGE) {                      // overrides handle_batch: count now, emit after the scan
         for (int k = 0; k < c; ++k) resp[goff[a] + k].type = 0;
         adexchange_batch(sp, tp, a, qc, seg, c,
                          [&](int k) { const DevMsg m = qc[seg[k]];
@@ -817,26 +916,12 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
                          false, scanbuf + goff[a], nullptr, nullptr, &s_errkey, seq_base + goff[a]);
         continue;
       }
-      for (int k = 0; k < c; ++k) {
-        const int P = goff[a] + k;
-        DevMsg out; out.type = 0;
-        const DevMsg m = qc[seg[k]];
-        // dropped: receiver not in contexts (resolvers.py:143-144), edge filter (:146-148),
-        // or a send that already failed its checks (type 0)
-        // the receive-side edge filter can only drop something when sends skipped the edge
-        // check (ignore_connection_errors): every queued message already passed has_edge
-        if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
-          int code = 0;
-          const bool answered = handle_message(sp, tp, b, a, m, clock + P, exo_b, tick, out, code);
-          if (code) set_errkey(&s_errkey, seq_base + P, code);
-          if (answered) {                                       // network.send(receiver, sub_receiver, payload) :156-158
-            const int sc = dev_send_check(sp, tp, out.src, out.dst, out.type);
-            if (sc) { set_errkey(&s_errkey, seq_base + P, sc); out.type = 0; }
-          } else out.type = 0;
-        }
-        resp[P] = out;
-        scanbuf[P] = out.type != 0;
-      }
+      const AgentRef r = agent_ref(sp, tp, b, a);
+      const bool cached = kind_state_cached(kind_a);
+      AgentState st;
+      if (cached) load_state(sp, r, st);
+      for (int k = 0; k < c; ++k) deliver(a, goff[a] + k, qc[seg[k]], st);
+      if (cached) store_state(sp, r, st);
     }
     __syncthreads();
     GTICK(10);
