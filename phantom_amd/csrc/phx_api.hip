@@ -662,7 +662,7 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
     if (!tb) { (void)hipMalloc((void**)&tb, 16 * 8); (void)hipMemset(tb, 0, 16 * 8); }
     g.timing = tb;
     if (getenv("PHX_TIMING_DUMP") && ++calls == 100) { (void)hipDeviceSynchronize(); unsigned long long h[16]; (void)hipMemcpy(h, tb, sizeof h, hipMemcpyDeviceToHost);
-      const double n = 99.0 * e->d.B; fprintf(stderr, "PHX_GTIMING cycles/block:"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %d:%.0f", q, h[q] / n); fprintf(stderr, "\n"); } }
+      const double n = 99.0 * 64; fprintf(stderr, "PHX_GTIMING cycles/block:"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %d:%.0f", q, h[q] / n); fprintf(stderr, "\n"); } }
 #endif
   rc = upload_inject(e, st);
   if (rc != PHX_OK) return rc;

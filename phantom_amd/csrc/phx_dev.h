@@ -222,9 +222,8 @@ __device__ __forceinline__ Topo topo_env(const DevSpec& sp, int b) {
   if (sp.n_conn > 0) t.conn_on = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
   return t;
 }
-// Network.send checks (network.py:246-252, 297-331); returns PHX_ERR_* (0 = deliverable)
-__device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp, int src, int dst, int type) {
-  if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, tp, src, dst)) return PHX_ERR_NETWORK;
+// the payload whitelist half of Network.send's checks (network.py:297-331)
+__device__ __forceinline__ int dev_payload_check(const DevSpec& sp, const Topo& tp, int src, int dst, int type) {
   if (!(sp.flags & PHX_F_NO_PAYLOAD_CHECKS)) {
     int sk, rk, dec;
     dev_payload_types(type, sk, rk, dec);
@@ -233,6 +232,11 @@ __device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp,
     if (rk && tp.kind[dst] != rk) return PHX_ERR_PAYLOAD;
   }
   return 0;
+}
+// Network.send checks (network.py:246-252, 297-331); returns PHX_ERR_* (0 = deliverable)
+__device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp, int src, int dst, int type) {
+  if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, tp, src, dst)) return PHX_ERR_NETWORK;
+  return dev_payload_check(sp, tp, src, dst, type);
 }
 
 // ---- device RNG (the definition is stated in DESIGN.md; the oracle restates it) ---------------
@@ -524,12 +528,17 @@ __device__ __forceinline__ void dev_agent_reset(const DevSpec& sp, const Topo& t
 __device__ __forceinline__ bool dev_encode_obs(const DevSpec& sp, const Topo& tp, int b, int a, int step, float* o) {
   const AgentRef r = agent_ref(sp, tp, b, a);
   switch (r.kind) {
-    case PHX_KIND_SHOP:
-      shop_obs(fld<int32_t>(sp, F_SHOP_STOCK)[r.base], fld<int32_t>(sp, F_SHOP_SALES)[r.base],
-               fld<int32_t>(sp, F_SHOP_MISSED)[r.base], tp.param_i[a * PHX_NPI + 1], o);
+    case PHX_KIND_SHOP: {
+      const int st = fld<int32_t>(sp, F_SHOP_STOCK)[r.base], sl = fld<int32_t>(sp, F_SHOP_SALES)[r.base],
+                ms = fld<int32_t>(sp, F_SHOP_MISSED)[r.base], nm = tp.param_i[a * PHX_NPI + 1];
+      // f32 division == the f64 quotient cast to f32 while the integers are exact in f32 (shop_obs_f32)
+      if ((((unsigned)st + (1u << 24)) | ((unsigned)sl + (1u << 24)) | ((unsigned)ms + (1u << 24)) | ((unsigned)nm + (1u << 24))) < (2u << 24))
+        shop_obs_f32(st, sl, ms, (float)nm, o);
+      else shop_obs(st, sl, ms, nm, o);
       if (sp.any_typed && sp.shop_type_src[r.kr] != PHX_TYPE_NONE)          // tutorial2.rst:283-294
         o[3] = (float)(shop_type_value(sp, b, r.kr) / sp.shop_type_prm[2 * r.kr + 1]);
       break;
+    }
     case PHX_KIND_SELLER: {
       int deg = 0;                                             // len(ctx.neighbour_ids)
       for (int k = tp.row_ptr[a]; k < tp.row_ptr[a + 1]; ++k) deg += edge_on(tp, k) ? 1 : 0;

@@ -663,6 +663,12 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   int* goff = first + A;
   uint8_t* live = (uint8_t*)(goff + A);
 
+  // the env's scalar words first: their round trip overlaps the table copy below
+  const bool full = !g.resolve_only;
+  const int step_in = fld<int32_t>(sp, F_ENV_STEP)[b];
+  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  const int clock0 = fld<int32_t>(sp, F_ENV_CLOCK)[b];
+  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
   // static topology tables: LDS copies behind the queues (TABLDS) or the global arrays
   Topo tp = topo_env(sp, b);
   if (TABLDS) {
@@ -685,16 +691,10 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     __syncthreads();
   }
 
-  int32_t* step_p = fld<int32_t>(sp, F_ENV_STEP) + b;
-  int32_t* stage_p = fld<int32_t>(sp, F_ENV_STAGE) + b;
   uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
   uint8_t* trunc = fld<uint8_t>(sp, F_ENV_TRUNC) + (int64_t)b * S;
 
-  const bool full = !g.resolve_only;
-  const int t = full ? *step_p + 1 : *step_p;                  // env.py:252
-  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-  const int clock0 = fld<int32_t>(sp, F_ENV_CLOCK)[b];
-  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? *stage_p : 0;
+  const int t = full ? step_in + 1 : step_in;                  // env.py:252
   int list = 0;                                                // which acting list / mask row
   if (sp.env_type == PHX_ENV_FSM) list = cur_stage;                          // fsm.py:276
   else if (sp.env_type == PHX_ENV_STACKELBERG) list = (t & 1) ? 0 : 1;       // stackelberg.py:133-137
@@ -885,7 +885,10 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
         const bool answered = handle_message(sp, tp, b, a, m, clock + P, exo_b, tick, out, code, st);
         if (code) set_errkey(&s_errkey, seq_base + P, code);
         if (answered) {                                         // network.send(receiver, sub_receiver, payload) :156-158
-          const int sc = dev_send_check(sp, tp, out.src, out.dst, out.type);
+          // a reply to the sender travels the edge the delivered message came along (connections are undirected,
+          // also per env on a StochasticNetwork): only the payload whitelist is left to check
+          const int sc = out.dst == m.src ? dev_payload_check(sp, tp, out.src, out.dst, out.type)
+                                          : dev_send_check(sp, tp, out.src, out.dst, out.type);
           if (sc) { set_errkey(&s_errkey, seq_base + P, sc); out.type = 0; }
         } else out.type = 0;
       }
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     }
   }
 #ifdef PHX_TIMING
-  if (g.timing && threadIdx.x == 0) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
+  if (g.timing && threadIdx.x == 0 && blockIdx.x < 64) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
 #endif
 }
 
