@@ -62,6 +62,7 @@ struct Derived {
   bool dynamic_graph = false;      // StochasticNetwork with some rate < 1: edges differ per env
   std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
   std::vector<uint8_t> shop_cust_act;
+  std::vector<uint8_t> sc_shop_flags;   // [n_lists][nS]: 1 acts, 2 a customer acts, 4 every customer acts, 8 observes, 16 rewarded
   std::vector<float> sc_tab;
   int n_tabn = 0, n_quot = 0, rew_smax = -1;
   int max_cust = 0;
@@ -327,6 +328,15 @@ static int derive(const phx_spec* sp, Derived& d) {
     for (int l = 0; l < d.n_lists; ++l)
       for (size_t k = 0; k < d.shop_cust_agent.size(); ++k)
         d.shop_cust_act[(size_t)l * d.n_exo + k] = d.act_mask[(size_t)l * A + d.shop_cust_agent[k]];
+    d.sc_shop_flags.assign((size_t)d.n_lists * nS, 0);
+    for (int l = 0; l < d.n_lists; ++l)
+      for (int s2 = 0; s2 < nS; ++s2) {
+        const int a_shop = d.shop_agent[s2];
+        bool any = false, all = true;
+        for (int k = d.shop_cust_ptr[s2]; k < d.shop_cust_ptr[s2 + 1]; ++k) { const bool on = d.shop_cust_act[(size_t)l * d.n_exo + k] != 0; any |= on; all &= on; }
+        d.sc_shop_flags[(size_t)l * nS + s2] = (uint8_t)((d.act_mask[(size_t)l * A + a_shop] ? 1 : 0) | (any ? 2 : 0) | ((any && all) ? 4 : 0) |
+                                                         (d.obs_mask[(size_t)l * A + a_shop] ? 8 : 0) | (d.rew_mask[(size_t)l * A + a_shop] ? 16 : 0));
+      }
   }
   return PHX_OK;
 }
@@ -497,6 +507,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(shop_cust_exo, der.shop_cust_exo.data(), der.shop_cust_exo.size());
   UP(shop_cust_agent, der.shop_cust_agent.data(), der.shop_cust_agent.size());
   UP(shop_cust_act, der.shop_cust_act.data(), der.shop_cust_act.size());
+  UP(sc_shop_flags, der.sc_shop_flags.data(), der.sc_shop_flags.size());
   UP(sc_tab, der.sc_tab.data(), der.sc_tab.size());
   UP(conn_rate, spec->conn_rate, spec->n_conn); UP(col_conn, spec->col_conn, spec->n_conn > 0 ? der.nnz : 0);
   d.n_conn = spec->n_conn;

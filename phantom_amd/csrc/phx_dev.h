@@ -84,6 +84,7 @@ struct DevSpec {
   const int32_t* shop_cust_exo;  // exo rank of each customer of the shop, acting order
   const int32_t* shop_cust_agent;// agent index of each customer
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
+  const uint8_t* sc_shop_flags;  // [n_lists][nS] 1 shop acts, 2 a customer acts, 4 every customer acts, 8 observes, 16 rewarded
   int32_t max_cust;              // max customers of one shop
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   // host-built lookup tables of the rollout kernel (exactly the values the formulas give):

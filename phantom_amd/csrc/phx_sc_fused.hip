@@ -82,10 +82,20 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   }
   const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
   const int s = active ? (int)(threadIdx.x % nS) : 0;
+  // every load of the step is issued here, BEFORE the barrier (a launch this small lasts as long as its chain of
+  // dependent global round trips: the state / action loads do not depend on the env words)
   const int a_shop = sp.shop_agent[s];
   const int cur_stage0 = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
   const int step0 = fld<int32_t>(sp, F_ENV_STEP)[b];
   const uint32_t tick0 = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  ShopLane st;
+  st.stock = active ? fld<int32_t>(sp, F_SHOP_STOCK)[g] : 0;
+  st.delivered = active ? fld<int32_t>(sp, F_SHOP_DELIVERED)[g] : 0;
+  const bool av_in = active && (io.action_valid == nullptr || io.action_valid[g] != 0);
+  const float action_in = (active && io.actions) ? io.actions[g] : 0.0f;
+  const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
+  // who acts / observes / is rewarded in a stage: one flag byte per (list, shop); a plain env has one list
+  int fl = sp.env_type == PHX_ENV_FSM ? 0 : sp.sc_shop_flags[s];
   __syncthreads();          // exo rows staged; every lane has read the per-env words
   if (!active) return;
 
@@ -94,28 +104,24 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   const int t = step0 + 1;                                                   // env.py:252
   const uint32_t tick = tick0;
 
-  ShopLane st;
-  st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g];
-  st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
-  const bool shop_acts = sp.act_mask[(int64_t)list * A + a_shop] != 0;
-  const bool has_action = shop_acts && (io.action_valid == nullptr || io.action_valid[g] != 0);
-  const float action = has_action ? io.actions[g] : 0.0f;
+  if (sp.env_type == PHX_ENV_FSM) fl = sp.sc_shop_flags[(int64_t)list * nS + s];
+  const bool shop_acts = (fl & 1) != 0;
+  const bool has_action = shop_acts && av_in;
+  const float action = has_action ? action_in : 0.0f;
 
   // D = sum over the shop's inbox of OrderRequest sizes (customers that act in this stage)
-  const int c_lo = sp.shop_cust_ptr[s], c_hi = sp.shop_cust_ptr[s + 1];
   const uint8_t* cact = sp.shop_cust_act + (int64_t)list * sp.n_exo;
-  int D = 0; bool any_order = false;
+  int D = 0;
+  const bool any_order = (fl & 2) != 0, all_order = (fl & 4) != 0 || c_hi == c_lo;
   if (io.exo) {
     const int64_t row = (int64_t)b * sp.n_exo;
-    for (int k = c_lo; k < c_hi; ++k)
-      if (cact[k]) {
-        any_order = true;
-        const int64_t idx = row + sp.shop_cust_exo[k];
-        D += staged ? s_exo[idx - lds_base] : io.exo[idx];
-      }
+    if (any_order)
+      for (int k = c_lo; k < c_hi; ++k)
+        if (all_order || cact[k]) {
+          const int64_t idx = row + sp.shop_cust_exo[k];
+          D += staged ? s_exo[idx - lds_base] : io.exo[idx];
+        }
   } else {
-    bool all_order = true;
-    for (int k = c_lo; k < c_hi; ++k) { any_order |= cact[k] != 0; all_order &= cact[k] != 0; }
     if (all_order) D = rng_shop_order_sum(sp.seed, sp.env_offset + b, tick, s, c_hi - c_lo, nullptr);
     else if (any_order)
       D = rng_shop_orders(sp.seed, sp.env_offset + b, tick, s, c_hi - c_lo, cact + c_lo, -1);
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
     uint8_t* rcv = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + g;
     float* oc = fld<float>(sp, F_ENV_OBS_CACHE) + g * OD;
     uint8_t* ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + g;
-    const bool observes = sp.obs_mask[(int64_t)list * A + a_shop] != 0;
+    const bool observes = (fl & 8) != 0;
     if (observes) {
       shop_obs_f32(st.stock, st.sales, st.missed, (float)sp.param_i[a_shop * PHX_NPI + 1], ob);
       ob[3] = tobs;
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
       if (OD == 4) oc[3] = ob[3];
     }
     uint8_t cache_valid = *rcv; double cache = *rc;
-    if (sp.rew_mask[(int64_t)list * A + a_shop]) {                            // fsm.py:334-335,350
+    if (fl & 16) {                                                            // fsm.py:334-335,350
       cache = typed ? shop_reward_w(st.sales, st.stock, tw) : shop_reward(st.sales, st.stock); cache_valid = 1;
       *rc = cache; *rcv = 1;
     }
