@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 4
+#define PHX_ABI_VERSION 5
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -137,6 +137,12 @@ typedef enum phx_msg_type {
 #define PHX_F_IGNORE_CONN_ERRORS 1u  /* Network(ignore_connection_errors=True) network.py:62 */
 #define PHX_F_NO_PAYLOAD_CHECKS  2u  /* Network(enforce_msg_payload_checks=False)  :63       */
 #define PHX_F_FORCE_GENERIC      4u  /* never use a fused static-schedule kernel             */
+#define PHX_F_SHUFFLE_BATCHES    8u  /* BatchResolver(shuffle_batches=True): every delivered batch is permuted before
+                                        handle_batch (resolvers.py:150-151).  phx_step_io.shuffle replays recorded
+                                        permutations (parity with a reference run); NULL -> the device draws them
+                                        (Fisher-Yates, Philox block (env | draw / 4 << 48, tick, 0x10000000 | round << 16 |
+                                        receiver), j = mulhi(word, i + 1)).  Always the generic engine.  Not with
+                                        PHX_F_IGNORE_CONN_ERRORS or PHX_KIND_ADEXCHANGE (PHX_EUNSUPPORTED).        */
 
 /*
  * Flat description of one env class: what the Python host compiles a
@@ -227,6 +233,11 @@ typedef struct phx_step_io {
   int32_t*  err;               /* [B]      PHX_ERR_*                                        */
   phx_msg_rec* msg_log;        /* [B][trace_cap] or NULL                                    */
   int32_t*  msg_count;         /* [B] or NULL                                               */
+  /* ABI 5, PHX_F_SHUFFLE_BATCHES only: recorded np.random.shuffle outcomes, or NULL -> device RNG.
+   * Entry (messages of the step's earlier rounds + P), P the inbox position of the round in
+   * receiver-major order (receivers in first-arrival order), holds the batch-local index (send
+   * order) of the message handled at that position.  shuffle_cap = 8 * queue_cap entries per env. */
+  const uint16_t* shuffle;     /* [B][8 * queue_cap] or NULL                                */
 } phx_step_io;
 
 /* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end */

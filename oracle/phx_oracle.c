@@ -79,6 +79,8 @@ typedef struct {
   phx_msg_rec* log;       /* Resolver._tracked_messages resolvers.py:37 */
   int log_cap, log_n;
   int round;
+  const uint16_t* shuffle_b; /* this step's replayed shuffle permutations (NULL -> device RNG) */
+  int shuf_pos;             /* queued messages of the step's earlier batches */
 } oenv;
 
 struct phxo_env {
@@ -703,9 +705,18 @@ static void adexchange_handle_batch(const phxo_env* E, oenv* e, int a, const oin
 
 /* ---- resolver ---------------------------------------------------------------------------- */
 
+/* shuffle_batches on the device stream (phx_dev.h: rng_shuffle_block): block `blk` of the Fisher-Yates draws of
+ * (env, tick, round, receiver); draw d uses word d & 3 of block d >> 2, j = (word * (i + 1)) >> 32 */
+static void shuffle_block(const phxo_env* E, const oenv* e, int round, int receiver, uint32_t blk, uint32_t w[4]) {
+  uint32_t key[2] = {(uint32_t)E->s.seed, (uint32_t)(E->s.seed >> 32)};
+  uint32_t ctr[4] = {(uint32_t)e->genv, (uint32_t)((uint64_t)e->genv >> 32) | (blk << 16), e->tick,
+                     0x10000000u | (((uint32_t)round & 0xfffu) << 16) | (uint32_t)receiver};
+  phxo_philox4x32_10(ctr, key, w);
+}
+
 /* BatchResolver.resolve resolvers.py:128-163; `live` = receiver_id in contexts */
 static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
-  e->round = 0;
+  e->round = 0; e->shuf_pos = 0;
   uint8_t* ok = (uint8_t*)alloca(E->s.queue_cap > 0 ? E->s.queue_cap : 1);   /* exchange batches: delivered flags */
   for (int i = 0;; ++i) {
     if (E->s.round_limit >= 0 && i >= E->s.round_limit) break;        /* range(round_limit) :129-131 */
@@ -724,6 +735,37 @@ static void batch_resolve(const phxo_env* E, oenv* e, const uint8_t* live) {
           ok[id] = live[receiver] && has_edge(E, e, proc->pool[id].src, proc->pool[id].dst);
         }
         if (live[receiver]) adexchange_handle_batch(E, e, receiver, proc, ok, clock0);
+        continue;
+      }
+      if (E->s.flags & PHX_F_SHUFFLE_BATCHES) {                       /* np.random.shuffle(msgs) :150-151 */
+        /* every queued message advances the logical clock and the replay stream's position; a receiver
+         * without context is skipped before the shuffle (:143-144), the edge filter (:146-148) cannot drop
+         * anything (shuffle_batches is rejected together with ignore_connection_errors) */
+        int c = 0;
+        for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) ++c;
+        const int clock0 = e->clock, pos0 = e->shuf_pos;
+        e->clock += c; e->shuf_pos += c;
+        if (!live[receiver]) continue;
+        int* ids = (int*)malloc(sizeof(int) * (size_t)(c > 0 ? c : 1));
+        int* tmp = (int*)malloc(sizeof(int) * (size_t)(c > 0 ? c : 1));
+        int k = 0;
+        for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) ids[k++] = id;
+        if (c > 1) {
+          if (e->shuffle_b) {                                         /* replayed permutation */
+            const int fits = pos0 + c <= 8 * E->s.queue_cap;
+            for (k = 0; k < c; ++k) { int j = fits ? e->shuffle_b[pos0 + k] : k; tmp[k] = ids[j < c ? j : k]; }
+            memcpy(ids, tmp, sizeof(int) * (size_t)c);
+          } else {                                                    /* Fisher-Yates on the device stream */
+            uint32_t w[4]; int have = -1;
+            for (int ii = c - 1, d = 0; ii >= 1; --ii, ++d) {
+              if ((d >> 2) != have) { have = d >> 2; shuffle_block(E, e, i, receiver, (uint32_t)have, w); }
+              int j = (int)(((uint64_t)w[d & 3] * (uint64_t)(ii + 1)) >> 32);
+              int v = ids[ii]; ids[ii] = ids[j]; ids[j] = v;
+            }
+          }
+        }
+        for (k = 0; k < c; ++k) agent_handle_message(E, e, receiver, &proc->pool[ids[k]], clock0 + k);
+        free(ids); free(tmp);
         continue;
       }
       for (int id = proc->head[receiver]; id >= 0; id = proc->next[id]) {
@@ -1089,6 +1131,7 @@ void phxo_step(phxo_env* E, const phx_step_io* io) {
     e->log_cap = E->s.trace_cap;
     e->err = io->err ? io->err[b] : 0;
     e->log_n = 0; e->round = 0;
+    e->shuffle_b = io->shuffle ? io->shuffle + (size_t)b * 8 * E->s.queue_cap : NULL;
     apply_injected(E, e);
     uint8_t at = 0, au = 0;
     env_step_one(E, e, b, io->actions ? io->actions + (size_t)b * S : NULL,
@@ -1111,7 +1154,7 @@ void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_
     oenv* e = &E->env[b];
     e->log = msg_log ? msg_log + (size_t)b * E->s.trace_cap : NULL;
     e->log_cap = E->s.trace_cap; e->log_n = 0; e->round = 0;
-    e->err = err ? err[b] : 0; e->exo_b = NULL;
+    e->err = err ? err[b] : 0; e->exo_b = NULL; e->shuffle_b = NULL;
     apply_injected(E, e);
     batch_resolve(E, e, live);
     if (err) err[b] = e->err;
@@ -1142,7 +1185,7 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
   float* o = (float*)alloca(sizeof(float) * (S ? S : 1) * D);
   double* rw = (double*)alloca(sizeof(double) * (S ? S : 1));
   uint8_t* u8 = (uint8_t*)alloca(5 * (S ? S : 1));
-  e->log = NULL; e->err = io->err ? io->err[b] : 0;
+  e->log = NULL; e->err = io->err ? io->err[b] : 0; e->shuffle_b = NULL;
   for (int t = 0; t < T; ++t) {
     if (io->msg_log) {   /* rollout.py:369-373: tracked_messages recorded per step, cleared before the next */
       e->log = io->msg_log + ((size_t)t * B + b) * E->s.trace_cap; e->log_cap = E->s.trace_cap;

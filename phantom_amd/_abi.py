@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -29,7 +29,7 @@ TAG_PYF, TAG_F32, TAG_F64 = 0, 1, 2      # PHX_TAG_*: numpy scalar kind of an ad
 ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
-F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC = 1, 2, 4
+F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES = 1, 2, 4, 8
 
 (ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL,
  ERR_CONTEXT) = range(7)
@@ -78,7 +78,7 @@ class PhxStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "actions", "action_valid", "exo", "obs", "obs_valid", "reward", "reward_valid",
         "terminated", "truncated", "done_valid", "all_terminated", "all_truncated", "err",
-        "msg_log", "msg_count")]
+        "msg_log", "msg_count", "shuffle")]
 
 
 class PhxRolloutIO(C.Structure):

@@ -79,6 +79,11 @@ struct Derived {
 static int derive(const phx_spec* sp, Derived& d) {
   if (!sp) return fail(PHX_EINVAL, "null spec");
   if (sp->abi_version != PHX_ABI_VERSION) return fail(PHX_EINVAL, "abi_version %d != %d", sp->abi_version, PHX_ABI_VERSION);
+  if (sp->flags & PHX_F_SHUFFLE_BATCHES) {                    // resolvers.py:150-151
+    if (sp->flags & PHX_F_IGNORE_CONN_ERRORS) return fail(PHX_EUNSUPPORTED, "shuffle_batches with ignore_connection_errors");
+    for (int a = 0; a < sp->n_agents; ++a)
+      if (sp->kind && sp->kind[a] == PHX_KIND_ADEXCHANGE) return fail(PHX_EUNSUPPORTED, "shuffle_batches with an AdExchangeAgent (its handle_batch is order sensitive in ties)");
+  }
   if (sp->n_agents <= 0 || sp->n_agents > 65535) return fail(PHX_EINVAL, "n_agents out of range");
   if (sp->batch <= 0) return fail(PHX_EINVAL, "batch must be positive");
   if (!sp->kind || !sp->param_i || !sp->param_f || !sp->row_ptr || !sp->col) return fail(PHX_EINVAL, "null table");
@@ -214,7 +219,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   // ---- static supply-chain schedule? (fused kernels) ------------------------------------------
   bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 &&
             d.kind_count[PHX_KIND_SHOP] <= 256 &&
-            !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
+            !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
             (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS) && !d.dynamic_graph;
   auto edge = [&](int u, int v) { for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k) if (sp->col[k] == v) return true; return false; };
   for (int a = 0; a < A && sc; ++a) {
@@ -226,7 +231,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   d.sc_static = sc;
   // ---- static Stackelberg-market schedule? (fused kernel) ----------------------------------------
   bool stk = sp->env_type == PHX_ENV_STACKELBERG && d.kind_count[PHX_KIND_SELLER] > 0 &&
-             !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS)) && sp->trace_cap == 0 &&
+             !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
              (sp->round_limit < 0 || sp->round_limit >= 1) && (!d.dynamic_graph || sp->n_samplers == 0);
   for (int a = 0; a < A && stk; ++a) {
     const int k = sp->kind[a];
@@ -263,7 +268,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   {
     const int N = d.kind_count[PHX_KIND_ADVERTISER];
     bool ads = sp->env_type == PHX_ENV_FSM && sp->n_stages == 2 && N >= 1 && N <= 1024 && d.kind_count[PHX_KIND_PUBLISHER] == 1 &&
-               d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(sp->flags & PHX_F_FORCE_GENERIC) && sp->trace_cap == 0 &&
+               d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
                (sp->round_limit < 0 || sp->round_limit >= 3) && (!d.dynamic_graph || (sp->flags & PHX_F_IGNORE_CONN_ERRORS)) && d.D == 3 &&
                sp->stage_next[0] == 1 && sp->stage_next[1] == 0;
     if (ads) {
@@ -636,6 +641,7 @@ static int check_step_io(const phx_env* e, const phx_step_io* io) {
       !io->done_valid || !io->all_terminated || !io->all_truncated)
     return fail(PHX_EINVAL, "a required output pointer is NULL");
   if ((io->msg_log || io->msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
+  if (io->shuffle && !(e->d.flags & PHX_F_SHUFFLE_BATCHES)) return fail(PHX_EINVAL, "shuffle given but the spec has no PHX_F_SHUFFLE_BATCHES");
   return PHX_OK;
 }
 

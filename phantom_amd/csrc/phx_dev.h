@@ -274,6 +274,14 @@ __device__ __forceinline__ void rng_block(uint64_t seed, int64_t genv, uint32_t 
   philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (attempt << 16), tick >> 2,
                 (uint32_t)shop | ((uint32_t)g << 20), (uint32_t)seed, (uint32_t)(seed >> 32), w);
 }
+// BatchResolver(shuffle_batches=True) on the device stream: block `blk` of the Fisher-Yates draws of
+// (env, tick, round, receiver); draw d uses word d & 3 of block d >> 2, j = mulhi(word, i + 1)
+// (definition restated in oracle/phx_oracle.c: shuffle_draw)
+__device__ __forceinline__ void rng_shuffle_block(uint64_t seed, int64_t genv, uint32_t tick, int round, int receiver,
+                                                  uint32_t blk, uint32_t w[4]) {
+  philox4x32_10((uint32_t)genv, (uint32_t)((uint64_t)genv >> 32) | (blk << 16), tick,
+                0x10000000u | (((uint32_t)round & 0xfffu) << 16) | (uint32_t)receiver, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+}
 // u -> (y, j), false when the word is rejected.  (x / 5^6 == umulhi(x, 2251799814) >> 13 for every
 // 32-bit x: ceil(2^45 / 5^6) with error 4918 <= 2^13.)
 __device__ __forceinline__ bool rng_split(uint32_t u, uint32_t& y, uint32_t& j) {

@@ -801,6 +801,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   int log_n = n;
   int seq_base = n_items;          // error ordering key continues after the acting items
   int clock = clock0;
+  int shuf_off = 0;             // messages of the step's earlier rounds (index into the replayed shuffle stream)
   __syncthreads();
   GTICK(4);
 
@@ -875,6 +876,28 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
       }
     }
     __syncthreads();
+    if (sp.flags & PHX_F_SHUFFLE_BATCHES) {                     // np.random.shuffle(msgs), resolvers.py:150-151
+      const uint16_t* sh = g.io.shuffle ? g.io.shuffle + (int64_t)b * 8 * Q + shuf_off : nullptr;
+      for (int a = tid; a < A; a += NT) {
+        const int c = cnt[a];
+        if (c < 2 || !live[a]) continue;                        // `receiver_id not in contexts`: no shuffle call
+        int* seg = order + goff[a];
+        int* tmp = slot + goff[a];                              // dead entries of this round
+        if (sh) {                                               // replayed permutation: batch position k takes message sh[k]
+          const bool fits = shuf_off + goff[a] + c <= 8 * Q;
+          for (int k = 0; k < c; ++k) { const int j = fits ? sh[goff[a] + k] : k; tmp[k] = seg[j < c ? j : k]; }
+          for (int k = 0; k < c; ++k) seg[k] = tmp[k];
+        } else {                                                // Fisher-Yates, the loop numpy's legacy shuffle runs
+          uint32_t w[4]; int have = -1;
+          for (int i = c - 1, d = 0; i >= 1; --i, ++d) {
+            if ((d >> 2) != have) { have = d >> 2; rng_shuffle_block(sp.seed, sp.env_offset + b, tick, round, a, (uint32_t)have, w); }
+            const int j = (int)__umulhi(w[d & 3], (uint32_t)(i + 1));
+            const int vi = seg[i]; seg[i] = seg[j]; seg[j] = vi;
+          }
+        }
+      }
+      __syncthreads();
+    }
     // dropped: receiver not in contexts (resolvers.py:143-144), edge filter (:146-148), or a send that already
     // failed its checks (type 0).  The receive-side edge filter can only drop something when sends skipped the
     // edge check (ignore_connection_errors): every queued message already passed has_edge.
@@ -956,7 +979,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     }
     __syncthreads();
     GTICK(11);
-    log_n += n_next; seq_base += n; clock += n;
+    log_n += n_next; seq_base += n; clock += n; shuf_off += n;
     n = n_next; ++round;
     DevMsg* tq = qc; qc = qn; qn = tq;
   }

@@ -239,7 +239,7 @@ class DeviceEnv:
             self._fill_step_io(io)
         return self._step_io
 
-    def step(self, actions, action_valid=None, exo=None) -> StepTensors:
+    def step(self, actions, action_valid=None, exo=None, shuffle=None) -> StepTensors:
         torch = _torch()
         io = self._step_io
         if io is None:
@@ -256,6 +256,15 @@ class DeviceEnv:
             io.exo = exo.data_ptr()
         else:
             io.exo = None
+        if shuffle is not None:                   # recorded np.random.shuffle outcomes (BatchResolver(shuffle_batches=True))
+            if shuffle.dtype != torch.int16 and shuffle.dtype != torch.uint16:
+                raise ValueError("shuffle must be a 16-bit integer tensor")
+            if tuple(shuffle.shape) != (self.B, 8 * self.spec.queue_cap) or not shuffle.is_contiguous() \
+                    or shuffle.device != self.device:
+                raise ValueError(f"shuffle must be a contiguous tensor [{self.B}, {8 * self.spec.queue_cap}] on {self.device}")
+            io.shuffle = shuffle.data_ptr()
+        else:
+            io.shuffle = None
         rc = self.lib.phx_step(self.handle, self._step_io_ref,
                                torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:

@@ -28,14 +28,14 @@ class Resolver:
 
 
 class BatchResolver(Resolver):
-    """resolvers.py:92-163.  ``shuffle_batches`` draws from the global numpy stream inside the
-    round loop (resolvers.py:150-151) and is not supported on the device."""
+    """resolvers.py:92-163.  ``shuffle_batches`` (resolvers.py:150-151: ``np.random.shuffle`` of every delivered
+    batch) runs on the generic engine: the device draws the permutations from its own Philox stream (one per
+    (env, tick, round, receiver)), or replays recorded ones (``DeviceEnv.step(..., shuffle=)``) -- the reference
+    draws from the global numpy stream INSIDE the round loop, which a batched launch cannot interleave with."""
 
     def __init__(self, enable_tracking: bool = False, round_limit: Optional[int] = None,
                  shuffle_batches: bool = False, trace_capacity: Optional[int] = None) -> None:
         super().__init__(enable_tracking)
-        if shuffle_batches:
-            raise NotImplementedError("shuffle_batches=True is not supported on the device")
         self.round_limit = round_limit
-        self.shuffle_batches = False
+        self.shuffle_batches = bool(shuffle_batches)
         self.trace_capacity = trace_capacity

@@ -244,6 +244,10 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         flags |= _abi.F_NO_PAYLOAD_CHECKS
     if force_generic:
         flags |= _abi.F_FORCE_GENERIC
+    if getattr(resolver, "shuffle_batches", False):                       # resolvers.py:150-151
+        if network.ignore_connection_errors:
+            raise NotImplementedError("shuffle_batches with ignore_connection_errors is not supported on the device")
+        flags |= _abi.F_SHUFFLE_BATCHES
 
     deg = np.diff(row_ptr)
     queue_cap = int(sum(_max_emissions(int(kind[a]), int(deg[a])) for a in range(A))) + extra_queue

