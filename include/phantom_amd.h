@@ -48,6 +48,7 @@ extern "C" {
 #define PHX_ERR_ROUND_LIMIT 4 /* RuntimeError: msgs left after round_limit resolvers.py:160  */
 #define PHX_ERR_QUEUE_FULL  5 /* build-specific: per-round message capacity exceeded         */
 #define PHX_ERR_CONTEXT     6 /* KeyError: ctx[agent_id] of a non-neighbour  context.py:36-37  */
+#define PHX_ERR_FSM_TRANSITION 7 /* FSMRuntimeError: handler returned a stage outside next_stages  fsm.py:304-307 */
 /* BatchResolver(round_limit=None) loops until no message is left (resolvers.py:129-131), i.e. forever
  * on a message cycle; this build stops after PHX_MAX_ROUNDS rounds with PHX_ERR_ROUND_LIMIT.        */
 #define PHX_MAX_ROUNDS 4096
@@ -192,6 +193,9 @@ typedef struct phx_spec {
   int32_t n_conn;
   const double*  conn_rate;     /* [n_conn]                                                  */
   const int32_t* col_conn;      /* [nnz] base connection of each CSR entry (both directions)  */
+  /* ABI 5: FSM stages with handlers: stage_allowed[s][n] != 0 <=> n in FSMStage(s).next_stages (fsm.py:304);
+   * NULL: only stage_next[s] is allowed (handler-less stages, fsm.py:281-292)                              */
+  const uint8_t* stage_allowed; /* [n_stages][n_stages] or NULL                               */
 } phx_spec;
 
 typedef struct phx_env phx_env;   /* opaque */
@@ -238,6 +242,12 @@ typedef struct phx_step_io {
    * receiver-major order (receivers in first-arrival order), holds the batch-local index (send
    * order) of the message handled at that position.  shuffle_cap = 8 * queue_cap entries per env. */
   const uint16_t* shuffle;     /* [B][8 * queue_cap] or NULL                                */
+  /* FiniteStateMachineEnv stage HANDLERS (fsm.py:294-307): the stage a Python handler returned for each env, decided
+   * on the host before the launch (a handler that only looks at the clock / the stage is deterministic), or NULL ->
+   * next_stages[0] of the current stage.  Checked against phx_spec.stage_allowed; an invalid transition sets
+   * PHX_ERR_FSM_TRANSITION.  The agents acting in THAT stage are the ones that observe (fsm.py:320).  Runs on the
+   * generic engine.                                                                                           */
+  const int32_t* next_stage;   /* [B] or NULL                                               */
 } phx_step_io;
 
 /* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end */

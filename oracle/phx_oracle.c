@@ -81,6 +81,7 @@ typedef struct {
   int round;
   const uint16_t* shuffle_b; /* this step's replayed shuffle permutations (NULL -> device RNG) */
   int shuf_pos;             /* queued messages of the step's earlier batches */
+  int next_in;              /* stage chosen by the stage handler for the coming step (-1: none, -2: out of range) */
 } oenv;
 
 struct phxo_env {
@@ -843,6 +844,7 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
                          uint8_t* terminated, uint8_t* truncated, uint8_t* done_valid,
                          uint8_t* all_term, uint8_t* all_trunc) {
   const int A = E->A, S = E->S, D = E->D;
+  const int next_in = e->next_in; e->next_in = -1;                    /* a stage handler's return value, this step only */
   e->step += 1;                                                       /* env.py:252 */
   e->exo_b = exo_b;
 
@@ -886,7 +888,16 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
   batch_resolve(E, e, live);                                                   /* network.py:256-265 */
   /* post_message_resolution: no kind overrides it (agents.py:93-94) */
 
-  if (E->s.env_type == PHX_ENV_FSM) next_stage = E->s.stage_next[cur_stage];  /* fsm.py:281-292 */
+  if (E->s.env_type == PHX_ENV_FSM) {
+    next_stage = E->s.stage_next[cur_stage];                          /* no handler: next_stages[0]  fsm.py:281-292 */
+    if (next_in >= 0 || next_in == -2) {                              /* env_handler() returned a stage  :294-302 */
+      int ok = next_in >= 0 && next_in < E->s.n_stages &&
+               (E->s.stage_allowed ? E->s.stage_allowed[(size_t)cur_stage * E->s.n_stages + next_in] != 0
+                                   : next_in == E->s.stage_next[cur_stage]);
+      if (ok) next_stage = next_in;
+      else set_err(e, PHX_ERR_FSM_TRANSITION);                        /* FSMRuntimeError :304-307 */
+    }
+  }
 
   memset(obs_valid, 0, S); memset(reward_valid, 0, S); memset(done_valid, 0, S);
   memset(terminated, 0, S); memset(truncated, 0, S);
@@ -1012,7 +1023,8 @@ phxo_env* phxo_create(const phx_spec* sp) {
     E->s.stage_rewarded = (const uint8_t*)dup_arr(sp->stage_rewarded, (size_t)ns * A);
     E->s.stage_rewarded_all = (const uint8_t*)dup_arr(sp->stage_rewarded_all, ns);
     E->s.stage_next = (const int32_t*)dup_arr(sp->stage_next, sizeof(int32_t) * ns);
-  }
+    E->s.stage_allowed = sp->stage_allowed ? (const uint8_t*)dup_arr(sp->stage_allowed, (size_t)ns * ns) : NULL;
+  } else E->s.stage_allowed = NULL;
   if (sp->env_type == PHX_ENV_STACKELBERG) {
     E->s.leaders = (const int32_t*)dup_arr(sp->leaders, sizeof(int32_t) * (sp->n_leaders ? sp->n_leaders : 1));
     E->s.followers = (const int32_t*)dup_arr(sp->followers, sizeof(int32_t) * (sp->n_followers ? sp->n_followers : 1));
@@ -1132,6 +1144,7 @@ void phxo_step(phxo_env* E, const phx_step_io* io) {
     e->err = io->err ? io->err[b] : 0;
     e->log_n = 0; e->round = 0;
     e->shuffle_b = io->shuffle ? io->shuffle + (size_t)b * 8 * E->s.queue_cap : NULL;
+    e->next_in = io->next_stage ? (io->next_stage[b] >= 0 ? io->next_stage[b] : -2) : -1;
     apply_injected(E, e);
     uint8_t at = 0, au = 0;
     env_step_one(E, e, b, io->actions ? io->actions + (size_t)b * S : NULL,
@@ -1205,6 +1218,7 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
       }
     }
     uint8_t at = 0, au = 0;
+    e->next_in = -1;
     env_step_one(E, e, b, act, NULL, io->exo ? io->exo + ((size_t)t * B + b) * E->n_exo : NULL,
                  o, u8, rw, u8 + S, u8 + 2 * S, u8 + 3 * S, u8 + 4 * S, &at, &au);
     size_t base = ((size_t)t * B + b) * S;

@@ -32,7 +32,7 @@ TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES = 1, 2, 4, 8
 
 (ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL,
- ERR_CONTEXT) = range(7)
+ ERR_CONTEXT, ERR_FSM_TRANSITION) = range(8)
 MAX_ROUNDS = 4096            # PHX_MAX_ROUNDS: cap on BatchResolver(round_limit=None) rounds
 
 _u8p, _i32p, _f32p, _f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),
@@ -56,6 +56,7 @@ class PhxSpec(C.Structure):
         ("n_samplers", C.c_int32), ("sampler_kind", C.c_void_p), ("sampler_param", C.c_void_p),
         ("type_src", C.c_void_p),
         ("n_conn", C.c_int32), ("conn_rate", C.c_void_p), ("col_conn", C.c_void_p),
+        ("stage_allowed", C.c_void_p),
     ]
 
 
@@ -78,7 +79,7 @@ class PhxStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "actions", "action_valid", "exo", "obs", "obs_valid", "reward", "reward_valid",
         "terminated", "truncated", "done_valid", "all_terminated", "all_truncated", "err",
-        "msg_log", "msg_count", "shuffle")]
+        "msg_log", "msg_count", "shuffle", "next_stage")]
 
 
 class PhxRolloutIO(C.Structure):

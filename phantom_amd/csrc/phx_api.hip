@@ -55,6 +55,7 @@ struct Derived {
   int kind_count[PHX_KIND_COUNT] = {0};
   std::vector<int32_t> strat_rank, strat_idx, kind_rank, exo_rank, buyer_off;
   std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
+  std::vector<uint8_t> stage_allowed, stage_rew_all;
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
   bool sc_static = false, stk_static = false, ads_static = false;
@@ -181,6 +182,11 @@ static int derive(const phx_spec* sp, Derived& d) {
     d.act_idx.assign(sp->stage_act_idx, sp->stage_act_idx + sp->stage_act_ptr[ns]);
     for (int v : d.act_idx) if (v < 0 || v >= A) return fail(PHX_EINVAL, "acting agent out of range");
     d.stage_next.assign(sp->stage_next, sp->stage_next + ns);
+    d.stage_rew_all.assign(sp->stage_rewarded_all, sp->stage_rewarded_all + ns);
+    d.stage_allowed.assign((size_t)ns * ns, 0);                               // fsm.py:304: next_stage in next_stages
+    for (int st = 0; st < ns; ++st)
+      for (int nx = 0; nx < ns; ++nx)
+        d.stage_allowed[(size_t)st * ns + nx] = sp->stage_allowed ? (sp->stage_allowed[(size_t)st * ns + nx] != 0) : (nx == sp->stage_next[st]);
     d.obs_mask.assign((size_t)ns * A, 0); d.rew_mask.assign((size_t)ns * A, 0);
     for (int st = 0; st < ns; ++st) {
       const int nx = sp->stage_next[st];
@@ -504,6 +510,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(act_mask, der.act_mask.data(), der.act_mask.size());
   UP(obs_mask, der.obs_mask.data(), der.obs_mask.size()); UP(rew_mask, der.rew_mask.data(), der.rew_mask.size());
   UP(stage_next, der.stage_next.data(), der.stage_next.size());
+  UP(stage_allowed, der.stage_allowed.data(), der.stage_allowed.size());
+  UP(stage_rew_all, der.stage_rew_all.data(), der.stage_rew_all.size());
   UP(reset_obs_idx, der.reset_obs_idx.data(), der.reset_obs_idx.size());
   d.n_reset_obs = (int)der.reset_obs_idx.size();
   UP(shop_agent, der.shop_agent.data(), der.shop_agent.size());
@@ -642,6 +650,7 @@ static int check_step_io(const phx_env* e, const phx_step_io* io) {
     return fail(PHX_EINVAL, "a required output pointer is NULL");
   if ((io->msg_log || io->msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
   if (io->shuffle && !(e->d.flags & PHX_F_SHUFFLE_BATCHES)) return fail(PHX_EINVAL, "shuffle given but the spec has no PHX_F_SHUFFLE_BATCHES");
+  if (io->next_stage && e->d.env_type != PHX_ENV_FSM) return fail(PHX_EINVAL, "next_stage given but the env is not a FiniteStateMachineEnv");
   return PHX_OK;
 }
 
@@ -657,7 +666,7 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   int rc = check_step_io(e, io);
   if (rc != PHX_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (e->use_fused && e->n_inject == 0) {
+  if (e->use_fused && e->n_inject == 0 && !io->next_stage) {       // handler-chosen transitions: generic engine
     HIPCHK(phx_launch_sc_step(e->d, *io, st));
     return PHX_OK;
   }
@@ -665,7 +674,7 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
     HIPCHK(phx_launch_stk_step(e->d, *io, st));
     return PHX_OK;
   }
-  if (e->use_ads && e->n_inject == 0 && !io->msg_log && !io->msg_count) {
+  if (e->use_ads && e->n_inject == 0 && !io->msg_log && !io->msg_count && !io->next_stage) {
     HIPCHK(phx_launch_ads_step(e->d, *io, st));
     return PHX_OK;
   }

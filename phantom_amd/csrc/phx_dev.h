@@ -74,6 +74,8 @@ struct DevSpec {
   const uint8_t* obs_mask;       // [n_lists][A] who observes after a step in this list/stage
   const uint8_t* rew_mask;       // [n_lists][A] who is rewarded
   const int32_t* stage_next;     // [n_lists]  (FSM)
+  const uint8_t* stage_allowed;  // [n_lists][n_lists] FSMStage.next_stages as a matrix (handler-chosen transitions), or NULL
+  const uint8_t* stage_rew_all;  // [n_lists] rewarded_agents is None (every strategic agent observes, fsm.py:315-317)
   const int32_t* reset_obs_ptr;  // agents that observe at reset: CSR with a single row
   const int32_t* reset_obs_idx;
   int32_t n_reset_obs;

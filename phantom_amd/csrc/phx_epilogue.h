@@ -12,13 +12,17 @@
 template <int NT, typename ObsFn>
 __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
                                                    int list, int cur_stage, uint32_t tick,
-                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc, ObsFn encode_obs) {
+                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc, ObsFn encode_obs,
+                                                   int next_in = -1) {
   const int tid = threadIdx.x;
   const int A = sp.A, S = sp.S, D = sp.D;
   uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
   uint8_t* trunc = fld<uint8_t>(sp, F_ENV_TRUNC) + (int64_t)b * S;
-  const int next_stage = (sp.env_type == PHX_ENV_FSM) ? sp.stage_next[cur_stage] : 0;
-  const uint8_t* obs_mask = sp.obs_mask + (int64_t)list * A;
+  // next stage: the handler's choice (next_in >= 0, already validated) or next_stages[0] (fsm.py:281-307); the
+  // agents acting in THAT stage observe (fsm.py:320) unless rewarded_agents is None (every strategic agent, :315-317)
+  const int next_stage = (sp.env_type == PHX_ENV_FSM) ? (next_in >= 0 ? next_in : sp.stage_next[cur_stage]) : 0;
+  const uint8_t* obs_mask = (sp.env_type == PHX_ENV_FSM && next_in >= 0 && !sp.stage_rew_all[cur_stage])
+                                ? sp.act_mask + (int64_t)next_stage * A : sp.obs_mask + (int64_t)list * A;
   const uint8_t* rew_mask = sp.rew_mask + (int64_t)list * A;
   float* obs_b = io.obs + (int64_t)b * S * D;
   double* rew_cache = fld<double>(sp, F_ENV_REW_CACHE) + (int64_t)b * S;
@@ -95,7 +99,7 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
 template <int NT>
 __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
                                                    int list, int cur_stage, uint32_t tick,
-                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc) {
+                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc, int next_in = -1) {
   strategic_epilogue<NT>(sp, tp, io, b, t, list, cur_stage, tick, live, s_nterm, s_ntrunc,
-                         [&](int a, int tt, float* ob) { return dev_encode_obs(sp, tp, b, a, tt, ob); });
+                         [&](int a, int tt, float* ob) { return dev_encode_obs(sp, tp, b, a, tt, ob); }, next_in);
 }

@@ -984,6 +984,15 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
     DevMsg* tq = qc; qc = qn; qn = tq;
   }
   if (n > 0 && tid == 0) set_errkey(&s_errkey, seq_base + 1, PHX_ERR_ROUND_LIMIT);   // resolvers.py:160-163
+  // a stage handler's return value (fsm.py:294-307), decided by the host: must be one of the stage's next_stages
+  int next_in = -1;
+  if (full && sp.env_type == PHX_ENV_FSM && g.io.next_stage) {
+    next_in = g.io.next_stage[b];
+    if (next_in < 0 || next_in >= sp.n_lists || !sp.stage_allowed[(int64_t)cur_stage * sp.n_lists + next_in]) {
+      if (tid == 0) set_errkey(&s_errkey, seq_base + 2, PHX_ERR_FSM_TRANSITION);     // FSMRuntimeError, after the resolution
+      next_in = -1;
+    }
+  }
   __syncthreads();
   GTICK(12);
 
@@ -995,7 +1004,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   if (g.resolve_only) return;
 
   GTICK(13);
-  strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc);
+  strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc, next_in);
   GTICK(14);
   if (g.roll_t >= 0) {                                         // the step's outputs -> trajectory row roll_t
     __syncthreads();

@@ -239,7 +239,7 @@ class DeviceEnv:
             self._fill_step_io(io)
         return self._step_io
 
-    def step(self, actions, action_valid=None, exo=None, shuffle=None) -> StepTensors:
+    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None) -> StepTensors:
         torch = _torch()
         io = self._step_io
         if io is None:
@@ -265,6 +265,13 @@ class DeviceEnv:
             io.shuffle = shuffle.data_ptr()
         else:
             io.shuffle = None
+        if next_stage is not None:                # FSM stage handlers' return values, one stage index per env
+            if next_stage.dtype != torch.int32 or tuple(next_stage.shape) != (self.B,) or not next_stage.is_contiguous() \
+                    or next_stage.device != self.device:
+                raise ValueError(f"next_stage must be a contiguous int32 tensor [{self.B}] on {self.device}")
+            io.next_stage = next_stage.data_ptr()
+        else:
+            io.next_stage = None
         rc = self.lib.phx_step(self.handle, self._step_io_ref,
                                torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
@@ -532,6 +539,9 @@ class DeviceEnv:
         if code == _abi.ERR_ROUND_LIMIT:
             raise RuntimeError("message(s) still in queue after BatchResolver round limit "
                                f"reached ({where}).")
+        if code == _abi.ERR_FSM_TRANSITION:                # fsm.py:304-307
+            from .fsm import FSMRuntimeError
+            raise FSMRuntimeError(f"FiniteStateMachineEnv attempted invalid transition ({where}).")
         if code == _abi.ERR_CONTEXT:                       # ctx[agent_id] of a non-neighbour, context.py:36-37
             raise KeyError(f"agent view / table entry not present in the handler's context ({where}).")
         raise DeviceError(f"per-round message capacity exceeded ({where}); raise queue capacity")

@@ -263,6 +263,10 @@ class PhantomEnv:
     def _host_advance(self):
         self._h_step += 1
 
+    def _step_extras(self) -> Dict[str, Any]:
+        """extra per-step inputs of the device step decided on the host (FSM stage handlers)."""
+        return {}
+
     def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None,
               *, mask=None) -> Tuple[Dict[AgentID, Any], Dict[str, Any]]:
         """env.py:185-237.  ``seed`` is accepted and ignored exactly as in the reference, where
@@ -326,7 +330,7 @@ class PhantomEnv:
         dev = self._device()
         act, valid = self._actions_tensor(actions)
         exo = self._draw_exo()
-        dev.step(act, valid, exo)
+        dev.step(act, valid, exo, **self._step_extras())
         self._host_advance()
         h = dev.pull_step()                                # one device-to-host copy for all outputs
         dev.raise_errors(self.network, err=h["err"])
@@ -341,7 +345,7 @@ class PhantomEnv:
         dev = self._device()
         if exo is None:
             exo = self._draw_exo()
-        out = dev.step(actions, action_valid, exo)
+        out = dev.step(actions, action_valid, exo, **self._step_extras())
         self._host_advance()
         if check_errors:
             dev.raise_errors(self.network)

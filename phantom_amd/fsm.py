@@ -2,9 +2,12 @@
 
 Stage masking -- which agents act, which observe (the next stage's acting agents) and which
 are rewarded -- is compiled into per-stage tables and applied inside the step kernel with the
-reward cache / emit-on-observe semantics of fsm.py:309-380.  Stage *handlers* are Python
-callbacks that would have to run between message resolution and the observation loop; only
-handler-less stages (exactly one next stage, fsm.py:281-292) can run on the device.
+reward cache / emit-on-observe semantics of fsm.py:309-380.  Handler-less stages (exactly one next
+stage, fsm.py:281-292) run entirely on the device.  Stage *handlers* (fsm.py:294-307) are Python
+callbacks: they are called on the host before the launch and the stage they return travels to the
+device as a per-env input column (phx_step_io.next_stage) -- exact for handlers that decide from the
+clock / the current stage (what the reference's own tests pin); a handler that inspects agent state
+sees the state BEFORE the step's acting phase, not after it.
 """
 from typing import Any, Callable, Dict, Optional, Sequence, Tuple
 
@@ -84,11 +87,12 @@ class FiniteStateMachineEnv(PhantomEnv):
                 raise FSMValidationError(
                     f"Stage '{stage.id}' without handler must have exactly one next stage "
                     f"(got {len(stage.next_stages)})")
-        for stage in self._stages.values():
-            if stage.handler is not None:
-                raise NotImplementedError(
-                    f"stage '{stage.id}' has a Python env handler; only handler-less, "
-                    "table-driven stages can run inside the device step (fsm.py:281-292)")
+        # Stage HANDLERS (fsm.py:294-307) are Python: they are called on the host, once per step and stage, BEFORE the
+        # launch; the stage they return goes to the device as a per-env input column (phx_step_io.next_stage).  The
+        # device step always resolves the network, so `self.resolve_network()` inside a handler is a no-op marker.
+        self._has_handlers = any(stage.handler is not None for stage in self._stages.values())
+        self._in_handler = False
+        self._chosen_next = None
         self._stage_list = list(self._stages.values())
         self._stage_index = {s.id: i for i, s in enumerate(self._stage_list)}
         self._h_stage[:] = self._stage_index[initial_stage]
@@ -138,8 +142,58 @@ class FiniteStateMachineEnv(PhantomEnv):
         self._h_stage = dev.field("env.stage")[:, 0].cpu().numpy().astype(np.int64)
         self.previous_stage_idx = dev.field("env.prev_stage")[:, 0].cpu().numpy().astype(np.int64)
 
+    def resolve_network(self):
+        """fsm.py handlers call this (env.py:175-183); on the device it is part of the step itself."""
+        if self._in_handler:
+            return None
+        raise NotImplementedError("message resolution is part of the device step (phx_step); "
+                                  "use env.network.resolve() for host-driven resolves outside a step")
+
+    def _step_extras(self):
+        """call the current stages' handlers (fsm.py:294-302) and hand their return values to the device."""
+        self._chosen_next = None
+        if not self._has_handlers:
+            return {}
+        import torch
+        B = self.batch_size
+        # what the reference's handler would see: the clock already incremented (fsm.py:268), the stage not yet
+        self._h_step += 1
+        try:
+            nxt = np.asarray([self._stage_index[s.next_stages[0]] if s.next_stages else -1
+                              for s in self._stage_list], dtype=np.int64)[self._h_stage]
+            for si in np.unique(self._h_stage):
+                stage = self._stage_list[int(si)]
+                if stage.handler is None:
+                    continue
+                sel = self._h_stage == si
+                self._in_handler = True
+                try:                                                     # bound method vs decorator form, fsm.py:294-302
+                    ret = stage.handler() if hasattr(stage.handler, "__self__") else stage.handler(self)
+                finally:
+                    self._in_handler = False
+                rets = [ret] * B if (isinstance(ret, str) or np.isscalar(ret) or ret is None) else list(ret)
+                if len(rets) != B:
+                    raise FSMRuntimeError(f"stage handler of '{stage.id}' returned {len(rets)} stages for {B} env instances")
+                for b in np.flatnonzero(sel):
+                    if rets[b] not in stage.next_stages:                 # fsm.py:304-307
+                        raise FSMRuntimeError(
+                            f"FiniteStateMachineEnv attempted invalid transition from '{stage.id}' to {rets[b]}")
+                    nxt[b] = self._stage_index[rets[b]]
+        finally:
+            self._h_step -= 1
+        self._chosen_next = nxt
+        dev = self._device()
+        return {"next_stage": torch.as_tensor(nxt.astype(np.int32), device=dev.device)}
+
+    def rollout(self, *args, **kwargs):
+        if self._has_handlers:
+            raise NotImplementedError("stage handlers are Python callables evaluated per step on the host: a fused "
+                                      "on-device rollout cannot call them (use step / step_tensors)")
+        return super().rollout(*args, **kwargs)
+
     def _host_advance(self):
         self._h_step += 1
-        nxt = np.asarray([self._stage_index[s.next_stages[0]] for s in self._stage_list])
+        nxt = np.asarray([self._stage_index[s.next_stages[0]] if s.next_stages else 0 for s in self._stage_list])
         self.previous_stage_idx = self._h_stage.copy()                   # fsm.py:355
-        self._h_stage = nxt[self._h_stage]
+        self._h_stage = nxt[self._h_stage] if self._chosen_next is None else self._chosen_next.copy()
+        self._chosen_next = None

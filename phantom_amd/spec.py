@@ -39,6 +39,7 @@ class EnvSpec:
     stage_rewarded: Optional[np.ndarray] = None
     stage_rewarded_all: Optional[np.ndarray] = None
     stage_next: Optional[np.ndarray] = None
+    stage_allowed: Optional[np.ndarray] = None     # u8 [n_stages][n_stages]: FSMStage.next_stages as a matrix
     # Stackelberg
     leaders: Optional[np.ndarray] = None
     followers: Optional[np.ndarray] = None
@@ -147,6 +148,7 @@ class EnvSpec:
         s.stage_rewarded = ptr(self.stage_rewarded, np.uint8)
         s.stage_rewarded_all = ptr(self.stage_rewarded_all, np.uint8)
         s.stage_next = ptr(self.stage_next, np.int32)
+        s.stage_allowed = ptr(self.stage_allowed, np.uint8) if self.stage_allowed is not None else None
         s.n_leaders = 0 if self.leaders is None else len(self.leaders)
         s.n_followers = 0 if self.followers is None else len(self.followers)
         s.leaders = ptr(self.leaders, np.int32)
@@ -269,6 +271,7 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         rewarded = np.zeros((len(stages), A), dtype=np.uint8)
         rewarded_all = np.zeros(len(stages), dtype=np.uint8)
         nxt = np.zeros(len(stages), dtype=np.int32)
+        allowed = np.zeros((len(stages), len(stages)), dtype=np.uint8)
         for i, st in enumerate(stages):
             idx.extend(index_of(aid) for aid in st.acting_agents)
             ptr.append(len(idx))
@@ -278,9 +281,12 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                 for aid in st.rewarded_agents:
                     rewarded[i, index_of(aid)] = 1
             nxt[i] = sidx[st.next_stages[0]]
+            for ns_id in st.next_stages:
+                allowed[i, sidx[ns_id]] = 1
         spec.stage_act_ptr = np.asarray(ptr, dtype=np.int32)
         spec.stage_act_idx = np.asarray(idx, dtype=np.int32)
         spec.stage_rewarded, spec.stage_rewarded_all, spec.stage_next = rewarded, rewarded_all, nxt
+        spec.stage_allowed = allowed
     elif env_type == _abi.ENV_STACKELBERG:
         spec.leaders = np.asarray([index_of(a) for a in leaders], dtype=np.int32)
         spec.followers = np.asarray([index_of(a) for a in followers], dtype=np.int32)

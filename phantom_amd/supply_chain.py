@@ -59,12 +59,15 @@ class SupplyChainFSMEnv(FiniteStateMachineEnv):
 
     def __init__(self, n_shops: int = 1, customers_per_shop=NUM_CUSTOMERS,
                  num_steps: int = NUM_EPISODE_STEPS, resolver=None, typed: bool = False,
-                 **device_kwargs):
+                 restock_handler=None, **device_kwargs):
+        """``restock_handler``: an FSM stage handler for RESTOCK (fsm.py:294-307) choosing between SELL and
+        another RESTOCK (called as ``handler(env)``); None -> the handler-less two-stage cycle."""
         network = build_network(n_shops, customers_per_shop, resolver, typed)
         shops = [a.id for a in network.agents.values() if isinstance(a, ShopAgent)]
         customers = [a.id for a in network.agents.values() if isinstance(a, CustomerAgent)]
         stages = [
-            FSMStage("RESTOCK", acting_agents=shops, rewarded_agents=shops, next_stages=["SELL"]),
+            FSMStage("RESTOCK", acting_agents=shops, rewarded_agents=shops,
+                     next_stages=["SELL", "RESTOCK"] if restock_handler else ["SELL"], handler=restock_handler),
             FSMStage("SELL", acting_agents=customers, rewarded_agents=[], next_stages=["RESTOCK"]),
         ]
         super().__init__(num_steps=num_steps, network=network, initial_stage="RESTOCK",

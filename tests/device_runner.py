@@ -33,12 +33,12 @@ class DeviceRunner:
         self.err = self.dev.err.cpu().numpy()
         return obs.cpu().numpy(), valid.cpu().numpy()
 
-    def step(self, actions, action_valid=None, exo=None, shuffle=None):
+    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None):
         if actions is None:
             actions = np.zeros((self.B, max(self.S, 1)), np.float32)
         sh = None if shuffle is None else torch.from_numpy(np.ascontiguousarray(shuffle, np.uint16).view(np.int16)).to(self.dev.device)
         self.dev.step(self._t(actions, np.float32), self._t(action_valid, np.uint8),
-                      self._t(exo, np.uint8), sh)
+                      self._t(exo, np.uint8), sh, self._t(next_stage, np.int32))
         self._pull()
         return self
 

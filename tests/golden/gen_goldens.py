@@ -113,8 +113,15 @@ def make_typed_shop_class():
     return ShopAgent
 
 
+def restock_handler(env):
+    """a deterministic FSM stage handler (fsm.py:294-302): resolves the network, then restocks AGAIN instead of
+    selling on every third step -- decided from the clock alone"""
+    env.resolve_network()
+    return "RESTOCK" if env.current_step % 3 == 0 else "SELL"
+
+
 def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=False, fsm=False,
-                           typed=None, shuffle=False):
+                           typed=None, shuffle=False, handler=False):
     """same ids / agent order / connection order as phantom_amd.supply_chain.build_network,
     built from the reference's own agent classes.  ``typed`` = (samplers, per_shop) with
     samplers = [(low, high, clip_low, clip_high)], per_shop[i] = ("sampler", j) | ("const", v) |
@@ -147,7 +154,8 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
         env = ph.FiniteStateMachineEnv(
             num_steps=num_steps, network=net, initial_stage="RESTOCK",
             stages=[ph.FSMStage("RESTOCK", acting_agents=shop_ids, rewarded_agents=shop_ids,
-                                next_stages=["SELL"]),
+                                next_stages=["SELL", "RESTOCK"] if handler else ["SELL"],
+                                handler=restock_handler if handler else None),
                     ph.FSMStage("SELL", acting_agents=flat_c, rewarded_agents=[],
                                 next_stages=["RESTOCK"])], **kw)
     else:
@@ -158,7 +166,7 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
 
 
 def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_customers=None,
-                     fsm=False, log_steps=0, use_shipped_env=False, typed=None, shuffle=False):
+                     fsm=False, log_steps=0, use_shipped_env=False, typed=None, shuffle=False, handler=False):
     """B = len(seeds) independent reference envs, each alone on the global numpy stream."""
     B, S = len(seeds), n_shops
     n_exo = sum(ks)
@@ -180,6 +188,8 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
     A["reset_obs"] = np.zeros((T, B, S, D), np.float32)
     A["reset_obs_valid"] = np.zeros((T, B, S), np.uint8)
     A["stage"] = np.zeros((T, B), np.int32)
+    if handler:                                    # the stage the RESTOCK handler / the table chose in each step
+        A["next_stage"] = np.zeros((T, B), np.int32)
     if shuffle:                                    # the np.random.shuffle outcomes of every step, in call order
         A["shuffle"] = np.zeros((T, B, 4 * (n_exo + n_shops)), np.uint16)
         A["shuffle_n"] = np.zeros((T, B), np.int32)
@@ -193,7 +203,8 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
         else:
             np.random.seed(seed)                   # the constructor already samples (env.py:118-119)
             env, shop_ids, cust_ids = build_ref_supply_chain(n_shops, ks, num_steps, norm_customers,
-                                                             tracking=log_steps > 0, fsm=fsm, typed=typed, shuffle=shuffle)
+                                                             tracking=log_steps > 0, fsm=fsm, typed=typed, shuffle=shuffle,
+                                                             handler=handler)
         index = {aid: i for i, aid in enumerate(env.agent_ids)}
         if not typed:
             np.random.seed(seed)
@@ -221,6 +232,8 @@ def run_supply_chain(name, n_shops, ks, num_steps, T, seeds, action_fn, norm_cus
             env.network.resolver.clear_tracked_messages()
             with DrawRecorder() as rec, ShuffleRecorder() as shr:
                 step = env.step(acts)
+            if handler:
+                A["next_stage"][t, b] = ["RESTOCK", "SELL"].index(env.current_stage)
             if shuffle:
                 A["shuffle"][t, b, :len(shr.perm)] = shr.perm
                 A["shuffle_n"][t, b] = len(shr.perm)
@@ -481,6 +494,9 @@ def main():
                      log_steps=3, shuffle=True)
     run_supply_chain("sc_shuffle_fsm", 2, [5, 3], 6, 16, [44, 45], act_mixed, norm_customers=5,
                      fsm=True, log_steps=2, shuffle=True)
+    # a FiniteStateMachineEnv whose RESTOCK stage has a HANDLER choosing among two next stages (fsm.py:294-307)
+    run_supply_chain("sc_fsm_handler", 3, [2, 4, 3], 7, 24, [51, 52], act_mixed, norm_customers=4,
+                     fsm=True, log_steps=3, handler=True)
     # config 5: Stackelberg market, small and full size
     run_market("stk_small", 8, 32, 4, 7, 16, seed=11)
     run_market("stk_full", 128, 1024, 8, 100, 6, seed=12)

@@ -42,13 +42,24 @@ def typed_supertypes(g):
     return out
 
 
+def golden_restock_handler(env):
+    """the RESTOCK stage handler of tests/golden/gen_goldens.py (restock_handler), against the phantom_amd surface"""
+    env.resolve_network()
+    step = np.asarray(env.current_step)
+    return np.where(step % 3 == 0, "RESTOCK", "SELL").tolist() if step.ndim else ("RESTOCK" if step % 3 == 0 else "SELL")
+
+
+def handler_kw(g):
+    return {"restock_handler": golden_restock_handler} if "next_stage" in g else {}
+
+
 def env_from_golden(g, batch=None, tracking=False, **kw):
     if "type_src" in g:
         kw.update(typed=True, agent_supertypes=typed_supertypes(g))
     return supply_chain_env(int(g["n_shops"]), g["ks"], int(g["num_steps"]),
                             batch or len(g["seeds"]), fsm=bool(g["fsm"]),
                             norm_customers=int(g["norm_customers"]), tracking=tracking,
-                            shuffle="shuffle" in g, **kw)
+                            shuffle="shuffle" in g, **kw, **handler_kw(g))
 
 
 def market_topology(L, Fw, d):

@@ -122,8 +122,10 @@ class OracleEnv:
         self.L.phxo_reset(self.h, _p(mask), _p(sampler_values), _p(conn_on), _p(self.obs), _p(self.obs_valid))
         return self.obs.copy(), self.obs_valid.copy()
 
-    def step(self, actions, action_valid=None, exo=None, shuffle=None):
+    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None):
         io = _abi.PhxStepIO()
+        self._ns = np.ascontiguousarray(next_stage, np.int32) if next_stage is not None else None
+        io.next_stage = _p(self._ns)
         self._sh = np.ascontiguousarray(shuffle, np.uint16) if shuffle is not None else None
         if self._sh is not None:
             assert self._sh.shape == (self.B, 8 * self.spec.queue_cap)

@@ -15,7 +15,7 @@ from helpers import (env_from_golden, f32_bits, f64_bits, golden, market_env, ma
                      supply_chain_env)
 from kats import ALL_KATS
 from oracle import OracleEnv
-from test_oracle_vs_goldens import (ADS_CASES, MARKET_CASES, SC_CASES, SHUFFLE_CASES, replay_ads, replay_market,
+from test_oracle_vs_goldens import (ADS_CASES, HANDLER_CASES, MARKET_CASES, SC_CASES, SHUFFLE_CASES, replay_ads, replay_market,
                                     replay_supply_chain)
 
 pytestmark = pytest.mark.gpu
@@ -38,7 +38,7 @@ def test_device_kat(kat):
     kat(_dev)
 
 
-@pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES)
+@pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES + HANDLER_CASES)
 def test_generic_engine_supply_chain_matches_reference(name):
     # tracking on -> the generic engine (with message log) runs
     replay_supply_chain(golden(name), _dev)

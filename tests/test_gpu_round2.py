@@ -374,3 +374,64 @@ def test_shuffle_batches_device_stream_matches_oracle(fsm):
     for t in range(9):
         d2.step(rng.uniform(0, 100, (B, 3)).astype(np.float32), None, None)
     assert not np.array_equal(d2.get_i32("shop.missed_sales"), d.get_i32("shop.missed_sales")) or True
+
+
+# ---- FSM stage handlers (fsm.py:294-307): the host calls the Python handler, the device gets its choice ---------
+def test_fsm_stage_handler_python_surface_matches_reference():
+    """the golden `sc_fsm_handler` is the reference running a FiniteStateMachineEnv whose RESTOCK stage has a handler
+    that restocks twice on every third step.  Here the same env is built from phantom_amd classes with a PYTHON
+    handler (tests/helpers.py: golden_restock_handler); step_tensors() calls it on the host before each launch and
+    the device validates and applies the transition: stage sequence, key sets, observations and rewards equal the
+    reference's."""
+    import torch
+    from helpers import env_from_golden, golden
+    g = golden("sc_fsm_handler")
+    T, B = int(g["T"]), len(g["seeds"])
+    env = env_from_golden(g, exogenous="device")
+    dev = env._device()
+    assert env._has_handlers and not env.is_fsm_deterministic()
+    for t in range(T):
+        if g["reset_before"][t].any():
+            env.reset()
+        np.testing.assert_array_equal(np.atleast_1d(env._h_stage), g["stage"][t], err_msg=f"stage before t={t}")
+        a = torch.from_numpy(g["actions"][t]).to(dev.device)
+        x = torch.from_numpy(g["exo"][t]).to(dev.device)
+        env.step_tensors(a, None, x, check_errors=True)
+        np.testing.assert_array_equal(np.atleast_1d(env._h_stage), g["next_stage"][t], err_msg=f"stage after t={t}")
+        np.testing.assert_array_equal(dev.field("env.stage")[:, 0].cpu().numpy(), g["next_stage"][t])
+        np.testing.assert_array_equal(dev.obs_valid.cpu().numpy(), g["obs_valid"][t], err_msg=f"obs_valid t={t}")
+        np.testing.assert_array_equal(dev.reward_valid.cpu().numpy(), g["reward_valid"][t], err_msg=f"reward_valid t={t}")
+        ov = g["obs_valid"][t].astype(bool)
+        np.testing.assert_array_equal(f32_bits(dev.obs.cpu().numpy()[ov]), f32_bits(g["obs"][t][ov]))
+        rv = g["reward_valid"][t] == 1
+        np.testing.assert_array_equal(f64_bits(dev.reward.cpu().numpy()[rv]), f64_bits(g["reward"][t][rv]))
+        np.testing.assert_array_equal(dev.field("shop.stock").cpu().numpy(), g["stock"][t])
+
+
+def test_fsm_invalid_transition_is_an_error():
+    """fsm.py:304-307: a handler returning a stage outside next_stages -> FSMRuntimeError.  Through the ABI the
+    device reports PHX_ERR_FSM_TRANSITION for exactly the envs that asked for it; the oracle agrees."""
+    from helpers import env_from_golden, golden
+    from phantom_amd import _abi
+    g = golden("sc_fsm_handler")
+    env = env_from_golden(g, batch=4, exogenous="device")
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    a = np.full((4, 3), 10.0, np.float32)
+    nxt = np.asarray([1, 0, 1, 1], np.int32)                 # from RESTOCK both SELL and RESTOCK are allowed
+    o.step(a, None, None, next_stage=nxt); d.step(a, None, None, next_stage=nxt)
+    assert (d.err == 0).all() and (o.err == 0).all()
+    np.testing.assert_array_equal(d.get_i32("env.stage")[:, 0], nxt)
+    np.testing.assert_array_equal(o.get_i32("env.stage")[:, 0], nxt)
+    np.testing.assert_array_equal(d.obs_valid, o.obs_valid)
+    bad = np.asarray([0, 1, 0, 7], np.int32)                 # env 0: SELL -> RESTOCK fine; env 1: RESTOCK -> SELL fine;
+    o.step(a, None, None, next_stage=bad); d.step(a, None, None, next_stage=bad)    # env 2: SELL -> RESTOCK; env 3: no stage 7
+    np.testing.assert_array_equal(d.err, o.err)
+    assert d.err.tolist() == [0, 0, 0, _abi.ERR_FSM_TRANSITION]
+    # the Python surface raises the reference's exception before launching
+    envp = env_from_golden(g, batch=2, exogenous="device")
+    envp._stage_list[0].handler = lambda e: "NOWHERE"
+    envp.reset()
+    import torch
+    with pytest.raises(ph.FSMRuntimeError):
+        envp.step_tensors(torch.zeros(2, 3, device=envp._device().device))

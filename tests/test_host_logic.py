@@ -114,9 +114,15 @@ def test_fsm_validation_parity():
     with pytest.raises(ph.FSMValidationError):
         ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[
             ph.FSMStage("A", acting_agents=["agent"], next_stages=[])])
-    with pytest.raises(NotImplementedError):      # python stage handlers cannot run on the device
-        ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[
-            ph.FSMStage("A", acting_agents=["agent"], next_stages=["A"], handler=lambda: "A")])
+    # a stage with a handler may name several next stages (fsm.py:168-173); the table of allowed transitions
+    # (fsm.py:304) goes into the spec, the handler itself runs on the host before each launch
+    envh = ph.FiniteStateMachineEnv(num_steps=1, network=net, initial_stage="A", stages=[
+        ph.FSMStage("A", acting_agents=["agent"], next_stages=["A", "B"], handler=lambda e: "B"),
+        ph.FSMStage("B", acting_agents=["agent"], next_stages=["A"])])
+    assert not envh.is_fsm_deterministic() and envh._has_handlers
+    assert envh.spec.stage_allowed.tolist() == [[1, 1], [1, 0]] and envh.spec.stage_next.tolist() == [0, 0]
+    with pytest.raises(NotImplementedError):
+        envh.rollout(4)                           # a fused rollout cannot call Python handlers
     env = ph.FiniteStateMachineEnv(num_steps=3, network=net, initial_stage="A", stages=[
         ph.FSMStage("A", acting_agents=["agent"], next_stages=["B"]),
         ph.FSMStage("B", acting_agents=["agent"], rewarded_agents=[], next_stages=["A"])])

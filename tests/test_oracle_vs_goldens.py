@@ -39,6 +39,8 @@ def replay_supply_chain(g, make_runner):
             assert n <= cap
             sh[:, :n] = g["shuffle"][t][:, :n]
             run.step(g["actions"][t], None, exo, sh)
+        elif "next_stage" in g:            # the stage the reference's handler returned (fsm.py:294-302), per env
+            run.step(g["actions"][t], None, exo, next_stage=g["next_stage"][t])
         else:
             run.step(g["actions"][t], None, exo)
         assert (run.err == 0).all()
@@ -63,6 +65,7 @@ def replay_supply_chain(g, make_runner):
 
 
 SHUFFLE_CASES = ["sc_shuffle", "sc_shuffle_fsm"]     # BatchResolver(shuffle_batches=True): generic engine only
+HANDLER_CASES = ["sc_fsm_handler"]                    # an FSM stage handler chooses the next stage: generic engine only
 
 
 def test_shuffle_goldens_are_not_the_identity():
@@ -76,7 +79,7 @@ def test_shuffle_goldens_are_not_the_identity():
         replay_supply_chain(g2, lambda spec: OracleEnv(spec))
 
 
-@pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES)
+@pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES + HANDLER_CASES)
 def test_oracle_supply_chain_matches_reference(name):
     replay_supply_chain(golden(name), lambda spec: OracleEnv(spec))
 
