@@ -14,7 +14,7 @@
 #include "phx_dev.h"
 
 
-size_t phx_generic_queue_bytes(int A, int Q, int scan_cap);
+size_t phx_generic_queue_bytes(int A, int Q, int scan_cap, int n_adx);
 size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
@@ -421,7 +421,9 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     out.push_back(x);
   }
   // workspace of the generic engine when its queues do not fit LDS
-  const size_t qb = phx_generic_queue_bytes(d.A, sp->queue_cap, d.scan_cap);
+  int n_adx_spec = 0;
+  for (int a = 0; a < d.A; ++a) n_adx_spec += sp->kind[a] == PHX_KIND_ADEXCHANGE;
+  const size_t qb = phx_generic_queue_bytes(d.A, sp->queue_cap, d.scan_cap, n_adx_spec);
   *ws_stride = 0;
   if (qb > (size_t)GENERIC_LDS_LIMIT) {
     *ws_stride = ((int64_t)qb + 255) & ~(int64_t)255;

@@ -652,9 +652,13 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   const int A = sp.A, S = sp.S, Q = sp.queue_cap;
 
   char* mem = LDSQ ? smem : ((char*)sp.f[F_WORKSPACE] + (int64_t)b * sp.ws_stride);
+  // queues: the round's messages, the responses by inbox position, and -- only where a handler still reads the old
+  // queue while the next one is written (the exchanges' cooperative emission) -- a second queue to compact into;
+  // otherwise the responses are compacted into the queue they answer (4.3 KB of LDS less per SC256 env)
+  const bool two_queues = sp.n_adx > 0;
   DevMsg* q0 = (DevMsg*)mem;
-  DevMsg* q1 = q0 + Q;
-  DevMsg* resp = q1 + Q;
+  DevMsg* q1 = two_queues ? q0 + Q : q0;
+  DevMsg* resp = q0 + (two_queues ? 2 : 1) * Q;
   int* order = (int*)(resp + Q);
   int* slot = order + Q;
   int* scanbuf = slot + Q;
@@ -1040,8 +1044,8 @@ __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const u
 }
 
 // ---- launchers (called from phx_api.hip) -----------------------------------------------------
-size_t phx_generic_queue_bytes(int A, int Q, int scan_cap) {
-  return (size_t)Q * (3 * sizeof(DevMsg) + 2 * sizeof(int)) + (size_t)scan_cap * sizeof(int) +
+size_t phx_generic_queue_bytes(int A, int Q, int scan_cap, int n_adx) {
+  return (size_t)Q * ((n_adx > 0 ? 3 : 2) * sizeof(DevMsg) + 2 * sizeof(int)) + (size_t)scan_cap * sizeof(int) +
          (size_t)A * 3 * sizeof(int) + (size_t)((A + 15) & ~15);
 }
 
@@ -1052,9 +1056,13 @@ size_t phx_generic_table_bytes(int A, int nnz) {
 
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
   GenArgs g = g_;
-  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.queue_cap, sp.scan_cap) + 15) & ~(size_t)15;
+  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.queue_cap, sp.scan_cap, sp.n_adx) + 15) & ~(size_t)15;
   const size_t tab = phx_generic_table_bytes(sp.A, sp.nnz);
-  const bool tablds = lds && tab <= 24 * 1024 && bytes + tab <= 60 * 1024;
+  static const int tablds_env = getenv("PHX_GENERIC_TABLDS") ? atoi(getenv("PHX_GENERIC_TABLDS")) : 1;
+  // Staging the topology tables in LDS saves latency per lookup but costs occupancy: every workgroup of the CU holds its
+  // own copy.  Worth it only while queues + tables stay small (SC64: 6 KB); at SC256 (15.5 KB of queues + 10.5 KB of
+  // tables = 6 workgroups per CU with them, 10 without) leaving them in global memory is 18 % faster (144 -> 118 us).
+  const bool tablds = lds && tablds_env && (tablds_env > 1 || bytes + tab <= 10 * 1024) && tab <= 24 * 1024 && bytes + tab <= 60 * 1024;
   g.tab_off = (int32_t)bytes;
   // one env per workgroup writes ~100-byte output segments: with consecutive envs on one XCD their shared cache
   // lines merge in one L2 (SC64 38.6 -> 37.1 us, SC256-FSM 352 -> 343 us per step)
@@ -1067,6 +1075,8 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   // agent state in LDS for the step was measured too: no gain, the wave is instruction-bound --
   // about 6 000 instructions and 90 memory operations per env-step at SC64.)
   static const int nt_env = getenv("PHX_GENERIC_NT") ? atoi(getenv("PHX_GENERIC_NT")) : 0;
+  // round 2, after the factory's serial chain went message-parallel: SC256-FSM B=8192 199 / 165 / 149 us per step
+  // (with the second queue gone -- 6 instead of 5 workgroups per CU -- 128 threads win again: 144 vs 177 us)
   int nt = nt_env ? nt_env : (sp.A <= 64 ? 64 : 128);
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_>), dim3(sp.B), dim3(NT_), bytes, st, sp, g)
   if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
