@@ -354,6 +354,13 @@ class PhantomEnv:
     def rollout(self, T: int, actions=None, exo=None, out=None):
         """T fused steps on the device with auto-reset at episode end (the loop of
         utils/rllib/rollout.py:300-363 in one launch).  Returns a device Trajectory."""
+        if exo is None and self.exogenous == "numpy" and self.spec.n_exo > 0:
+            # step() in this mode consumes np.random (bit-parity with a seeded reference run); a fused rollout cannot
+            # interleave with the host stream, so its draws come from the device Philox stream instead
+            import warnings
+            warnings.warn("PhantomEnv.rollout with exogenous='numpy' and no `exo` tensor: the customers' / publishers' "
+                          "draws come from the device RNG stream, not from np.random as in step(); pass exo=[T, B, n_exo] "
+                          "to replay recorded draws, or build the env with exogenous='device'", RuntimeWarning, stacklevel=2)
         traj = self._device().rollout(T, actions, exo, out)
         self._sync_host_state()
         return traj
