@@ -127,9 +127,10 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
 
   // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by threads [first, NT).
   //      One Philox block serves ticks 4q .. 4q + 3 of a shop: work items are (row quad jr, pair gl).
-  auto draws_impl = [&](int t0, int tc, int buf, int first, auto ALIGNED) __attribute__((always_inline)) {
+  auto draws_impl = [&](int t0, int tc, int buf, int first, auto ALIGNED, auto K6) __attribute__((always_inline)) {
     // ALIGNED: every env's chunk starts on a tick quad and tc is a multiple of 4 -> every row of a unit exists
-    constexpr bool aligned = decltype(ALIGNED)::value;
+    // K6: every shop has six customers (all six base-5 digits of y count)
+    constexpr bool aligned = decltype(ALIGNED)::value, k6 = decltype(K6)::value;
     if (tid < first) return;
     int* s_rd = s_rd0 + buf * items;
     float* s_act = s_act0 + buf * items;
@@ -146,24 +147,41 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
       const uint32_t tick_a = tick_base + (uint32_t)tla;                 // multiple of 4
       uint32_t w[4];
       rng_block(a.seed, genv, tick_a, s, 0, 0, w);
+      // the four words of the block -> four ticks.  The accept path is branch-free so that the four items' LDS lookups
+      // overlap; the redraw of a rejected word (probability 3.3e-6) is ONE cold branch after it
+      uint32_t y[4], aj[4];
+      bool rej = false;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
+      if (__builtin_expect(rej, 0)) {
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {
+          uint32_t y2, j2;
+          if (!rng_split(w[h], y2, j2)) y[h] = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj[h]);
+        }
+      }
       int i = aligned ? (int)__umul24(tla, G) + gl : tla * G + gl;
 #pragma unroll
       for (int h = 0; h < 4; ++h, i += G) {
         if (!aligned) { const int tl = tla + h; if (tl < 0 || tl >= tc) continue; }
-        uint32_t y, aj;
-        if (!rng_split(w[h], y, aj)) y = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj);     // 3.3e-6
-        if (a.K < 6) y -= __umul24((uint32_t)((float)y * a.inv_pK), a.pK);   // the first K base-5 digits: y mod 5^K
-        const uint32_t hi = (uint32_t)((float)y * 0.008f);               // y / 125, exact through f32
-        const int D = (int)s_ds[hi] + (int)s_ds[y - __umul24(125u, hi)]; // sum of the customers' order sizes, supply_chain.py:61-67
-        const float action = rng_j_to_action(aj);                        // random policy, [0, 100)
+        uint32_t yy = y[h];
+        if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);  // the first K base-5 digits: y mod 5^K
+        const uint32_t hi = (uint32_t)((float)yy * 0.008f);              // y / 125, exact through f32
+        const int D = (int)s_ds[hi] + (int)s_ds[yy - __umul24(125u, hi)];   // sum of the customers' order sizes, supply_chain.py:61-67
+        const float action = rng_j_to_action(aj[h]);                     // random policy, [0, 100)
         s_act[i] = action;
         s_rd[i] = (int)rintf(action) | (D << 8);                         // decode_action: int(round(action)), supply_chain.py:139
       }
     }
   };
   auto draws = [&](int t0, int tc, int buf, int first) __attribute__((always_inline)) {
-    if (!quad_extra && (tc & 3) == 0) draws_impl(t0, tc, buf, first, std::true_type{});
-    else draws_impl(t0, tc, buf, first, std::false_type{});
+    if (a.K == 6) {
+      if (!quad_extra && (tc & 3) == 0) draws_impl(t0, tc, buf, first, std::true_type{}, std::true_type{});
+      else draws_impl(t0, tc, buf, first, std::false_type{}, std::true_type{});
+    } else {
+      if (!quad_extra && (tc & 3) == 0) draws_impl(t0, tc, buf, first, std::true_type{}, std::false_type{});
+      else draws_impl(t0, tc, buf, first, std::false_type{}, std::false_type{});
+    }
   };
 
   // ---- the stock recurrence of chunk c (tc rows), one lane per pair ----------------------------------------------
@@ -191,12 +209,24 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
       x = (MINCAP) ? (end_ ? 0 : min(xn_, PHX_SHOP_MAX_STOCK)) : xn_;                                      \
     }
     if (tc == TC && !weird) {               // straight-line code, the chunk's operands fetched in one burst
+      // The episode reset costs the chain nothing: the tile word of the episode's last step is PATCHED to D = 255, R = 0
+      // before the burst (stock' = max(stock - 255, 0) + min(0, ...) = 0 for stock <= 100) and restored after the chain
+      // for the output phase.  Per step that leaves sub, max, sub, min, add (R and D are byte fields of the word) and one
+      // LDS store: every instruction of this wave waits ~8 cycles for a quarter-rate multiply of the draw waves to
+      // leave the VALU, priority or not, so the recurrence lasts as long as its instruction count.
+      int* rdw = s_rd0 + (c % 3) * items + tid;
+      int orig = 0;
+      if (ends) { orig = rdw[tend * G]; rdw[tend * G] = 0xFF00; }
       int rd[TC];
 #pragma unroll
-      for (int h = 0; h < TC; ++h) rd[h] = rdp[h * G];
+      for (int h = 0; h < TC; ++h) rd[h] = rdw[h * G];
 #pragma unroll
-      for (int h = 0; h < TC; ++h) FAST_STEP(h, rd[h], false)
-      fin_rd = rd[TC - 1];
+      for (int h = 0; h < TC; ++h) {
+        xb[h * G] = x; fin_xb = x;
+        x = max(x - ((rd[h] >> 8) & 255), 0) + min(rd[h] & 255, PHX_SHOP_MAX_STOCK - x);
+      }
+      if (ends) rdw[tend * G] = orig;
+      fin_rd = (ends && tend == TC - 1) ? orig : rd[TC - 1];
     } else {                                // a ragged last chunk, or an out-of-range stock at launch
       for (int h = 0; h < tc; ++h) { const int rdh = rdp[h * G]; FAST_STEP(h, rdh, true) fin_rd = rdh; }
     }
