@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-frag200", action="store_true",
+                    help="skip the informational T=200 launches (profiling: keeps per-kernel averages to T=100 launches)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -301,6 +303,8 @@ def main():
     # steps; informational -- the roofline object below stays on T = 100, the fragment `value` is measured with
     frag200 = None
     try:
+        if args.no_frag200:
+            raise RuntimeError("skipped (--no-frag200)")
         traj200 = dev.rollout(2 * T)
         for _ in range(5):
             dev.rollout(2 * T, out=traj200)

@@ -160,14 +160,14 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
           if (!rng_split(w[h], y2, j2)) y[h] = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj[h]);
         }
       }
-      int i = aligned ? (int)__umul24(tla, G) + gl : tla * G + gl;
+      int i = __mul24(tla, G) + gl;
 #pragma unroll
       for (int h = 0; h < 4; ++h, i += G) {
         if (!aligned) { const int tl = tla + h; if (tl < 0 || tl >= tc) continue; }
         uint32_t yy = y[h];
         if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);  // the first K base-5 digits: y mod 5^K
         const uint32_t hi = (uint32_t)((float)yy * 0.008f);              // y / 125, exact through f32
-        const int D = (int)s_ds[hi] + (int)s_ds[yy - __umul24(125u, hi)];   // sum of the customers' order sizes, supply_chain.py:61-67
+        const int D = (int)s_ds[hi] + (int)s_ds[__mul24((int)hi, -125) + (int)yy];   // digits of y / 125 and y % 125: the customers' order sizes summed, supply_chain.py:61-67
         const float action = rng_j_to_action(aj[h]);                     // random policy, [0, 100)
         s_act[i] = action;
         s_rd[i] = (int)rintf(action) | (D << 8);                         // decode_action: int(round(action)), supply_chain.py:139
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
     const uint32_t utotal = (uint32_t)total;
     const int G4 = G >> 2, nw = NT - first, n_units = tc * G4;
     const uint32_t PR = 3u * (uint32_t)G4;                              // 16-byte observation pieces per tile row
+    const uint32_t row_bytes = utotal * 12u;                            // bytes between tile rows of the observation plane
     const int lane = tid & 63;
     for (int ub = (tid - first) - lane; ub < n_units; ub += nw) {       // ub: the wave's first unit (uniform per wave)
       const int u = ub + lane;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
         const uint32_t q = q0 + (uint32_t)lane + 64u * (uint32_t)k;
         if (q < qn) {
           const uint32_t rr = __umulhi(q, a.mPR), pc = q - rr * PR;     // tile row and piece within the row
-          *(float4*)(p_obs + (size_t)(rr * (utotal * 12u) + pc * 16u)) = *(const float4*)(s_ostage + 4 * q);
+          *(float4*)(p_obs + (size_t)(rr * row_bytes + pc * 16u)) = *(const float4*)(s_ostage + 4 * q);
         }
       }
       if (u < n_units) {

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-run}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"; cd /tmp
-B="python $R/bench.py --no-cpu-baseline --no-other-configs"
+B="python $R/bench.py --no-cpu-baseline --no-other-configs --no-frag200"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $B --steps 20 --warmup 5 > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $B --steps 20 --warmup 5 --min-region-ms 5 > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $B --steps 20 --warmup 5 --min-region-ms 5 > $OUT/bench_write.log 2>&1
