@@ -391,7 +391,8 @@ class DeviceEnv:
         # is never cached, so repeated env.rollout(T) calls pin nothing (a T=100 SC64 fragment is
         # ~80 MB at B=4096).
         ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else None
-        key = (T,) + tuple(ptr(x) for x in out[:10]) + (ptr(actions), ptr(exo))
+        sig = lambda x: (x.data_ptr(), x.numel()) if hasattr(x, "data_ptr") else None     # address AND size: a buffer freed
+        key = (T,) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))           # and reallocated smaller misses
         cached = None if owned else self._rollout_io_cache.get(key)
         if cached is None:
             self._check_rollout_buffers(T, actions, exo, out)
