@@ -15,4 +15,4 @@ def run(name, S, K, B, fsm, n=150):
     print(f"{name:30s} {e0.elapsed_time(e1) / n * 1e3:8.2f} us/step", flush=True)
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 if which in ("sc64", "both"): run("SC64 B=4096 generic", 9, 6, 4096, False)
-if which in ("sc256", "both"): run("SC256-FSM B=8192 generic", 51, 4, 8192, True, n=60)
+if which in ("sc256", "both"): run("SC256-FSM B=8192 generic", 51, 4, 8192, True, n=90)
