@@ -41,7 +41,7 @@ enum {
 // block shape and constant-table offsets of the round-2 supply-chain rollout kernel (phx_sc_rollout.hip)
 #define PHX_FAST_TC 20          // steps per chunk (one Philox block serves 4 ticks: 5 row quads)
 struct ScFastPlan {
-  int32_t ok, epb, G, K, nt, norm;
+  int32_t ok, epb, G, K, nt, norm, whole_envs;
 };
 
 struct DevSpec {

@@ -36,7 +36,7 @@
 #include <vector>
 
 struct FastArgs {
-  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
+  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows, whole_envs;
   uint32_t pK; float inv_pK;        // 5^K and its f32 reciprocal (floor(y * inv) == y / 5^K for y < 5^6: tests/test_host_logic.py)
   uint32_t mG, mG4, mS, mPR;        // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4)  for i < 2^16
   int32_t norm;                     // the shops' common max_sales_per_step
@@ -61,8 +61,13 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
   const int tid = threadIdx.x, nS = a.S, G = a.G;
   const int64_t total = (int64_t)a.B * nS;
   const int bid = xcd_block(a.xcd_remap != 0);
-  const int64_t b_first = (int64_t)bid * a.epb;
-  const int64_t g_base = b_first * nS;
+  // the block's G consecutive (env, shop) pairs: whole envs where a multiple of 4 of them fits a block (a.whole_envs),
+  // otherwise a range of pairs that starts and ends inside envs -- shops never interact, an env's shops only share
+  // its step counter and tick, which every block that holds a part of the env walks identically
+  const int64_t g_base = (int64_t)bid * G;
+  const int64_t b_first = a.whole_envs ? (int64_t)bid * a.epb : g_base / nS;
+  const int r0 = (int)(g_base - b_first * nS);                          // the first pair's shop
+  const int n_env = a.whole_envs ? a.epb : (r0 + G - 1) / nS + 1;       // envs the block touches (<= a.epb)
 #ifdef PHX_TIMING
   unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define FTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tprev; tprev = now_; } while (0)
@@ -91,10 +96,11 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
   int x = 0, step = 0;                    // lane state of the recurrence (lane tid owns pair g_base + tid)
   {
     int tk = 0;
-    const uint32_t el = nS == 1 ? (uint32_t)tid : __umulhi((uint32_t)tid, a.mS);     // tid / S (the magic of 1 does not fit 32 bits)
+    const uint32_t pt = (uint32_t)(r0 + tid);
+    const uint32_t el = nS == 1 ? pt : __umulhi(pt, a.mS);               // (r0 + tid) / S (the magic of 1 does not fit 32 bits)
     if (tid < G) { x = a.stock[g_base + tid]; step = a.env_step[b_first + el]; }
-    if (tid < a.epb) tk = a.env_tick[b_first + tid];
-    if (tid < G) { s_pair[tid] = ((uint32_t)tid - el * (uint32_t)nS) | (el << 8); }
+    if (tid < n_env) tk = a.env_tick[b_first + tid];
+    if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); }
     if (tid < 125) s_ds[tid] = (uint8_t)(tid % 5 + (tid / 5) % 5 + tid / 25);
     if (tid <= PHX_SHOP_MAX_STOCK) {
       // f32 IEEE division == the reference's f64 quotient cast to f32 for |ints| < 2^24 (phx_dev.h: shop_obs_f32)
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
     if (tid <= 5 * a.K) s_tabn[tid] = (float)tid / (float)a.norm;
     if (tid < 2) s_flags[tid] = 0;
     __syncthreads();
-    if (tid < a.epb) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
+    if (tid < n_env) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
     if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
     __syncthreads();
   }
@@ -354,13 +360,31 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
       shop_obs(x, sales, missed, a.norm, ob);
       io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
     }
+    // (blocks of pair ranges: another block of the env may not have read these yet -- phx_sc_fast_env_kernel writes them)
     const uint32_t pr = s_pair[tid];
-    if ((pr & 255u) == 0u) {
+    if (a.whole_envs && (pr & 255u) == 0u) {
       const int bl = (int)(pr >> 8);
       a.env_step[b_first + bl] = step;
       a.env_tick[b_first + bl] = s_tick0[bl] + a.T;
     }
   }
+}
+
+// Step counter and tick of every env after the fragment, for launches whose blocks hold parts of envs: the walk of
+// `step` in the recurrence above, once per env, after the main kernel (stream order).
+__global__ void phx_sc_fast_env_kernel(const FastArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  int step = a.env_step[b];
+  for (int t0 = 0, c = 0; t0 < a.T; ++c) {
+    const int left = a.T - t0, tc = c == 0 ? a.first_rows : (left < PHX_FAST_TC ? left : PHX_FAST_TC);
+    const int tend = a.num_steps - 1 - step;
+    step += tc;
+    if (tend >= 0 && tend < tc) step -= a.num_steps;
+    t0 += tc;
+  }
+  a.env_step[b] = step;
+  a.env_tick[b] += a.T;
 }
 
 // ---- host: plan, blob, launcher -------------------------------------------------------------------------------------
@@ -376,9 +400,24 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
   int epb = 0;
   for (int cand = 4; cand * S <= 96 && cand <= 255; cand += 4) if (cand * S >= 32) { epb = cand; break; }
   if (!epb && 4 * S <= 96) epb = 4;
-  if (!epb || B % epb != 0 || ((int64_t)B * S) % 4 != 0) return false;
+  const int64_t total = (int64_t)B * S;
+  static const int g_env = getenv("PHX_ROLLOUT_G") ? atoi(getenv("PHX_ROLLOUT_G")) : 0;
+  if (epb && B % epb == 0 && total % 4 == 0 && !g_env) { p->epb = epb; p->G = epb * S; p->whole_envs = 1; }
+  else {
+    // wider envs (SC256: 51 shops): blocks of G consecutive (env, shop) pairs, G a multiple of 4 that divides B * S.
+    // 32 pairs make every tile row of a block whole 128-byte lines (SC256, B = 8192, T = 100: G = 32 201 us per launch,
+    // 64 225 us, 28 / 36 / 40 265 us, 96 317 us; the round-1 kernel 267 us)
+    int G = 0;
+    if (g_env) { if (g_env % 4 == 0 && g_env >= 4 && g_env <= 128 && total % g_env == 0) G = g_env; }
+    else {
+      static const int pref[] = {32, 64, 48, 40, 36, 44, 52, 56, 60, 28, 24, 68, 72, 76, 80, 84, 88, 92, 96};
+      for (int cand : pref) if (total % cand == 0) { G = cand; break; }
+    }
+    if (!G) return false;
+    p->G = G; p->epb = (G + S - 2) / S + 1; p->whole_envs = 0;       // epb: the most envs a block can touch
+  }
   if ((int64_t)PHX_FAST_TC * B * S * 12 >= ((int64_t)1 << 32)) return false;      // 32-bit store offsets within a chunk
-  p->epb = epb; p->G = epb * S; p->K = K_uniform;
+  p->K = K_uniform;
   const int p2w = (p->G + 63) / 64, p1w = ((PHX_FAST_TC / 4) * p->G + 63) / 64;     // draws of a chunk in one pass
   int want = 64 * (p2w + p1w);
   p->nt = want <= 256 ? 256 : (want <= 320 ? 320 : (want <= 384 ? 384 : 512));
@@ -389,7 +428,7 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
 hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const ScFastPlan& p = sp.sc_fast;
   FastArgs a;
-  a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
+  a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.whole_envs = p.whole_envs; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
   static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
   a.xcd_remap = remap_env >= 0 ? remap_env : 1;
   uint32_t pk = 1; for (int k = 0; k < p.K; ++k) pk *= 5u;
@@ -410,7 +449,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
 #ifdef PHX_TIMING
   { static unsigned long long* tbuf = nullptr; if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 8 * 8192 * sizeof(unsigned long long)); a.timing = tbuf;
     if (getenv("PHX_TIMING_DUMP")) { static int calls = 0; if (++calls == 20) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(8 * 8 * 8192); (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
-      const int wpb = p.nt / 64, nw = (sp.B / p.epb) * wpb; double sum[8] = {0}, w0[8] = {0}; for (int w = 0; w < nw; ++w) for (int q = 0; q < 8; ++q) { sum[q] += h[(size_t)w * 8 + q]; if (w % wpb == 0) w0[q] += h[(size_t)w * 8 + q]; }
+      const int wpb = p.nt / 64, nw = (int)(((int64_t)sp.B * sp.S) / p.G) * wpb; double sum[8] = {0}, w0[8] = {0}; for (int w = 0; w < nw; ++w) for (int q = 0; q < 8; ++q) { sum[q] += h[(size_t)w * 8 + q]; if (w % wpb == 0) w0[q] += h[(size_t)w * 8 + q]; }
       fprintf(stderr, "FAST_TIMING avg cycles per wave:  setup %.0f | draws %.0f | bar %.0f | P2 %.0f | bar %.0f | out %.0f | bar+setup-loads %.0f | P2 preload %.0f\n", sum[0]/nw, sum[1]/nw, sum[2]/nw, sum[3]/nw, sum[4]/nw, sum[5]/nw, sum[6]/nw, sum[7]/nw);
       fprintf(stderr, "FAST_TIMING wave0 of each block:  setup %.0f | draws %.0f | bar %.0f | P2 %.0f | bar %.0f | out %.0f | bar+setup-loads %.0f | P2 preload %.0f\n", w0[0]*wpb/nw, w0[1]*wpb/nw, w0[2]*wpb/nw, w0[3]*wpb/nw, w0[4]*wpb/nw, w0[5]*wpb/nw, w0[6]*wpb/nw, w0[7]*wpb/nw); } } }
 #endif
@@ -419,7 +458,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   // 2 episode-end rows + the observation staging tile (3 floats per item) + ticks + flags
   const size_t lds = (size_t)((p.G + 3) & ~3) * 4 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)items * 4 * (6 + 2 + 3) +
                      (size_t)((p.G + 3) & ~3) * 8 + (size_t)((p.epb + 3) & ~3) * 4 + 16;
-  const dim3 grid(sp.B / p.epb);
+  const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
   static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
   const int rec = ((p.G + 63) / 64) * 64;
   const int nt = (nt_env && nt_env >= rec + 64) ? nt_env : p.nt;
@@ -427,5 +466,6 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<384>), grid, dim3(384), lds, st, a);
   else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<320>), grid, dim3(320), lds, st, a);
   else hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<256>), grid, dim3(256), lds, st, a);
+  if (!p.whole_envs) hipLaunchKernelGGL(phx_sc_fast_env_kernel, dim3((sp.B + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

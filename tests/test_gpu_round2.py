@@ -311,10 +311,12 @@ def test_bench_collective_path_on_one_gpu():
 
 # ---- the round-2 rollout kernel (phx_sc_rollout.hip): its special cases against the oracle ---------------------
 @pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (9, 6, 64, 23), (3, 2, 48, 40), (12, 5, 16, 31), (1, 1, 64, 20),
-                                             (51, 4, 16, 100), (20, 3, 8, 57)])
+                                             (51, 4, 16, 100), (20, 3, 8, 57),
+                                             # blocks of pair ranges that start and end inside envs (S too wide for 4 whole envs)
+                                             (51, 4, 64, 100), (30, 6, 8, 25), (100, 2, 4, 40), (7, 3, 12, 30)])
 def test_fast_rollout_kernel_edge_cases_match_oracle(S, K, B, num_steps):
-    """device-RNG rollouts through the fast kernel where its plan applies (uniform 1..6 customers, whole envs per
-    block) and through the general kernel otherwise: fragments that start on ticks that are not multiples of 4
+    """device-RNG rollouts through the fast kernel where its plan applies (uniform 1..6 customers; whole envs per
+    block, or blocks of consecutive (env, shop) pairs for wide envs) and through the general kernel otherwise: fragments that start on ticks that are not multiples of 4
     (per-step launches first), fragment lengths that are no multiple of the chunk, several episode ends per
     fragment, stocks poked outside [0, 100] (the reference's arithmetic for a negative stock), state hand-over to
     per-step launches."""
