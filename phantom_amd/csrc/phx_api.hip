@@ -778,7 +778,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   }
   if (e->use_stk) {
     if (io->exo) return fail(PHX_EINVAL, "the market has no exogenous draws");
-    if (phx_stk_rollout_lds(e->d) > 60 * 1024) return fail(PHX_EUNSUPPORTED, "market too large for the LDS-resident rollout");
+    if (phx_stk_rollout_lds(e->d) > 60 * 1024 || e->d.A > 3 * 1024) return fail(PHX_EUNSUPPORTED, "market too large for the LDS-resident rollout");
     HIPCHK(phx_launch_stk_rollout(e->d, *io, (hipStream_t)stream)); return PHX_OK;
   }
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too

@@ -10,12 +10,18 @@
 // slots of the buyers are kept in compressed per-seller form (below).  Results are bit-identical to
 // the generic engine.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "phx_dev.h"
 
 #define STK_NT 256
-#ifndef STKR_NT
-#define STKR_NT 512    // rollout kernel: one block per env, ~2 agents per lane at 128 x 1024
+__host__ __device__ inline size_t g_stk_paid_off(int nSell) { return ((size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 15) & ~(size_t)15; }
+#ifdef PHX_TIMING
+__device__ unsigned long long g_stk_tm[8];
+#define STICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); stm[k] += now_ - sprev; sprev = now_; } while (0)
+#else
+#define STICK(k) do {} while (0)
 #endif
 
 // BuyerAgent.prices in compressed form.  Every Price a seller posts goes to ALL of its neighbours
@@ -40,6 +46,8 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   int* s_tx = (int*)(s_rev + nSell);                     // [nSell] seller.tx
   int* s_count = s_tx + nSell;                           // [nSell] orders received this step
   uint8_t* s_sent = (uint8_t*)(s_count + nSell);         // [nSell] seller broadcast a Price this step
+  double* s_paid = (double*)(smem + g_stk_paid_off(nSell));   // [nBuy] buyer.paid as decided this step
+  uint8_t* s_bought = (uint8_t*)(s_paid + nBuy);         // [nBuy] buyer.bought this step, 0xFF: the buyer did not act (state in the blob)
 
   const int t = fld<int32_t>(sp, F_ENV_STEP)[b] + 1;                         // env.py:252
   const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
   // off is not a neighbour this episode (sellers do not post to it, buyers do not consider it)
   const uint8_t* conn_b = nullptr;
   if (DYN) {                                             // the env's connectivity row, staged in LDS
-    uint8_t* s_conn = s_sent + ((nSell + 15) & ~15);
+    uint8_t* s_conn = s_bought + ((nBuy + 15) & ~15);
     const uint8_t* src = fld<uint8_t>(sp, F_NET_CONN_ON) + (int64_t)b * sp.n_conn;
     for (int i = tid; i < sp.n_conn; i += STK_NT) s_conn[i] = src[i];
     conn_b = s_conn;
@@ -64,6 +72,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     s_rev[k] = fld<double>(sp, F_SELLER_REVENUE)[sbase + k]; s_tx[k] = fld<int32_t>(sp, F_SELLER_TX)[sbase + k];
     s_count[k] = 0; s_sent[k] = 0;
   }
+  for (int k = tid; k < nBuy; k += STK_NT) s_bought[k] = 0xFF;
   __syncthreads();
 
   // ---- acting phase (_handle_acting_agents, env.py:320-336): decode_action of every acting agent.
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       }
       fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr] = bought;
       fld<double>(sp, F_BUYER_PAID)[bbase + kr] = paid;
+      s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;                     // read back by compute_reward below
     }
   }
   __syncthreads();
@@ -155,13 +165,17 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
         ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
       }
     }
-    uint8_t cv = rew_cache_v[a]; double cache = rew_cache[a];
+    // self._rewards[aid]: recomputed below for the rewarded group; read only where it is emitted as it stands
+    uint8_t cv = 0; double cache = 0.0;
     if (fl & 4) {                                                            // compute_reward -> self._rewards
       if (seller) cache = s_rev[kr];
-      else cache = fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr]
-                       ? __dsub_rn(sp.param_f[a * PHX_NPF], fld<double>(sp, F_BUYER_PAID)[bbase + kr]) : 0.0;
+      else {
+        int bought = s_bought[kr]; double paid = s_paid[kr];
+        if (bought == 0xFF) { bought = fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr]; paid = fld<double>(sp, F_BUYER_PAID)[bbase + kr]; }
+        cache = bought ? __dsub_rn(sp.param_f[a * PHX_NPF], paid) : 0.0;
+      }
       cv = 1; rew_cache[a] = cache; rew_cache_v[a] = 1;
-    }
+    } else if (terminal || ov) { cv = rew_cache_v[a]; cache = rew_cache[a]; }
     uint8_t rv = 0; double rw = 0.0;
     if (terminal) { rv = cv ? 1 : 2; rw = cv ? cache : 0.0; }                // stackelberg.py:180-187
     else if (ov && cv) { rv = 1; rw = cache; }                               // stackelberg.py:190-194
@@ -183,8 +197,21 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
 // acting agent's word of the tick (the stream the supply chain uses; its rank j in [0, 274877))
 // mapped onto its action space: seller price j / 274877, buyer buys iff j < 137438 (p = 1/2).
 // Auto-reset at the end of the terminal step (the caller's env.reset(), stackelberg.py:53-109).
-template <bool DYN>
-__global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
+//
+// A lane owns the same (up to) STKR_SLOTS agents for the whole fragment, a = tid + k * NT, with NT chosen so that
+// the slots are full (1 152 agents: 384 threads x 3): what is static per agent -- its record, both flag bytes, a
+// buyer's neighbour list (<= 8 seller ranks, packed u16) and value, a seller's degree -- is loaded into registers
+// once, and the agent's Philox block is kept for the four ticks it covers (an agent acts on two of them).  Measured
+// before (PHX_TIMING, 512 threads, everything looked up per step): 15.3 k cycles per step = acting 6.3 k (Philox per
+// acting agent and step) + booking 1.8 k + outputs 7.0 k (four dependent table loads per agent), a quarter of the
+// lanes idle in the third pass over the agents.
+#define STKR_SLOTS 3
+#ifndef STKR_W384
+#define STKR_W384 6
+#endif
+#define STKR_MINWAVES(NT) ((NT) == 384 ? STKR_W384 : ((NT) / 64 < 4 ? 4 : ((NT) / 64 > 8 ? 8 : (NT) / 64)))
+template <bool DYN, int NT>
+__global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int A = sp.A, B = sp.B;
@@ -196,8 +223,7 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
   double* s_paid = s_cache + A;                          // [nBuy]
   int* s_tx = (int*)(s_paid + nBuy);
   int* s_count = s_tx + nSell;
-  float* s_act = (float*)(s_count + nSell);              // [A] action taken this step (0: did not act)
-  uint8_t* s_sent = (uint8_t*)(s_act + A);
+  uint8_t* s_sent = (uint8_t*)(s_count + nSell);
   uint8_t* s_cv = s_sent + nSell;                        // [A] reward cache valid
   uint8_t* s_bought = s_cv + A;                          // [nBuy]
   uint8_t* s_conn = s_bought + nBuy;                     // [n_conn] StochasticNetwork: connection is in this episode's graph
@@ -206,68 +232,128 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
   const int64_t genv = sp.env_offset + b;
   uint32_t episode = dyn ? (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b] : 0u;
   int n_resets = 0;
-  if (dyn) for (int i = tid; i < sp.n_conn; i += STKR_NT) s_conn[i] = fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i];
+  if (dyn) for (int i = tid; i < sp.n_conn; i += NT) s_conn[i] = fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i];
 
-  for (int k = tid; k < nSell; k += STKR_NT) {
+  for (int k = tid; k < nSell; k += NT) {
     s_posted[k] = fld<double>(sp, F_SELLER_POSTED)[sbase + k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
     s_rev[k] = fld<double>(sp, F_SELLER_REVENUE)[sbase + k]; s_tx[k] = fld<int32_t>(sp, F_SELLER_TX)[sbase + k];
   }
-  for (int k = tid; k < nBuy; k += STKR_NT) {
+  for (int k = tid; k < nBuy; k += NT) {
     s_paid[k] = fld<double>(sp, F_BUYER_PAID)[bbase + k]; s_bought[k] = (uint8_t)fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + k];
   }
-  for (int a = tid; a < A; a += STKR_NT) {
+  for (int a = tid; a < A; a += NT) {
     s_cache[a] = fld<double>(sp, F_ENV_REW_CACHE)[abase + a]; s_cv[a] = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[abase + a];
   }
+  // the lane's agents: static data in registers.  rec = seller | flags(leaders' step) << 1 | flags(followers' step) << 4 |
+  // deg << 8 | kind_rank << 16; nbp: a buyer's neighbours (seller ranks, packed u16), for a seller nbp[0] = its degree;
+  // rw2 / rt2: the agent's word of tick rt2, kept from the Philox block of its previous acting tick
+  uint32_t rec[STKR_SLOTS], nbp[STKR_SLOTS][4], rw2[STKR_SLOTS], rt2[STKR_SLOTS];
+  double val[STKR_SLOTS];
+#pragma unroll
+  for (int k = 0; k < STKR_SLOTS; ++k) {
+    const int a = tid + k * NT;
+    rec[k] = 0; val[k] = 0.0; rw2[k] = 0; rt2[k] = 0xffffffffu;
+    nbp[k][0] = nbp[k][1] = nbp[k][2] = nbp[k][3] = 0;
+    if (a < A) {
+      const uint32_t r = sp.stk_rec[a];
+      const bool seller = (r & 255u) == PHX_KIND_SELLER;
+      rec[k] = (r & 0xffffff00u) | (seller ? 1u : 0u) | ((uint32_t)(sp.stk_flags[a] & 7) << 1) | ((uint32_t)(sp.stk_flags[(int64_t)A + a] & 7) << 4);
+      const int kr = (int)(r >> 16), deg = (int)((r >> 8) & 255u);
+      if (seller) nbp[k][0] = (uint32_t)(sp.row_ptr[a + 1] - sp.row_ptr[a]);                       // len(ctx.neighbour_ids)
+      else {
+        val[k] = sp.param_f[a * PHX_NPF];
+        if (!dyn && deg <= 8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < deg) nbp[k][j >> 1] |= (uint32_t)sp.stk_nbr[(int64_t)j * nBuy + kr] << ((j & 1) * 16);
+        }
+      }
+    }
+  }
+  for (int k = tid; k < nSell; k += NT) { s_count[k] = 0; s_sent[k] = 0; }    // per-step inbox counters: cleared again by the booking pass
   int step = fld<int32_t>(sp, F_ENV_STEP)[b];
   uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
   __syncthreads();
+#ifdef PHX_TIMING
+  unsigned long long stm[8] = {0}, sprev = __builtin_readcyclecounter();
+#endif
+
+  // a buyer's cheapest current neighbour: first minimum in neighbour order (price slots hold the sellers' posted
+  // prices); jr < 0: no neighbour this episode
+  auto cheapest = [&](int k, int kr, int deg, int& jr) __attribute__((always_inline)) {
+    double best = 0.0; jr = -1;
+    if (!dyn && deg <= 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < deg) {
+          const int l = (int)((nbp[k][j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+          const double v = s_posted[l];
+          if (j == 0 || v < best) { best = v; jr = l; }
+        }
+    } else {
+      const uint16_t* nb = sp.stk_nbr + kr;
+      for (int j = 0; j < deg; ++j) {
+        if (dyn && !s_conn[sp.stk_nbr_conn[(int64_t)j * nBuy + kr]]) continue;
+        const int l = nb[(int64_t)j * nBuy]; const double v = s_posted[l];
+        if (jr < 0 || v < best) { best = v; jr = l; }
+      }
+    }
+    return best;
+  };
 
   for (int t = 0; t < io.T; ++t) {
     const int tt = step + 1;                                                 // env.py:252
-    const int list = (tt & 1) ? 0 : 1;                                       // stackelberg.py:133-137
-    const uint8_t* flags = sp.stk_flags + (int64_t)list * A;
+    const int lsh = (tt & 1) ? 1 : 4;                                        // stackelberg.py:133-137: leaders on odd steps
     const int64_t row = ((int64_t)t * B + b) * A;
-    for (int k = tid; k < nSell; k += STKR_NT) { s_count[k] = 0; s_sent[k] = 0; }
-    __syncthreads();
+    // what derives from the packed words (ranks, LDS addresses, flags) is recomputed per step: hoisted out of the step
+    // loop it costs ~90 VGPRs and the occupancy with them
+#pragma unroll
+    for (int k = 0; k < STKR_SLOTS; ++k)
+      asm volatile("" : "+v"(rec[k]), "+v"(nbp[k][0]), "+v"(nbp[k][1]), "+v"(nbp[k][2]), "+v"(nbp[k][3]));
+    int ltid = tid;
+    asm volatile("" : "+v"(ltid));
     // ---- acting phase ---------------------------------------------------------------------------
-    for (int a = tid; a < A; a += STKR_NT) {
+    float act[STKR_SLOTS];
+#pragma unroll
+    for (int k = 0; k < STKR_SLOTS; ++k) {
+      const int a = ltid + k * NT;
       float action = 0.f;
-      if (flags[a] & 1) {
-        const uint32_t rec = sp.stk_rec[a];
-        const int kr = (int)(rec >> 16), deg = (int)((rec >> 8) & 255u);
-        const bool seller = (rec & 255u) == PHX_KIND_SELLER;
-        if (io.actions) action = io.actions[row + a];
-        else {
-          uint32_t aj;
-          rng_group_y(sp.seed, genv, tick, a, 0, 0, &aj);          // the agent's word of this tick: rank j
+      if (a < A && ((rec[k] >> lsh) & 1u)) {
+        const int kr = (int)(rec[k] >> 16), deg = (int)((rec[k] >> 8) & 255u);
+        const bool seller = (rec[k] & 1u) != 0;
+        if (io.actions) action = *(const float*)((const char*)(io.actions + row) + (size_t)((uint32_t)a * 4u));
+        else {                                                               // the agent's word of this tick: rank j
+          uint32_t word = rw2[k];
+          if (rt2[k] != tick) {                                              // not kept from the agent's previous acting tick
+            uint32_t w[4];
+            rng_block(sp.seed, genv, tick, a, 0, 0, w);
+            word = rng_pick(w, tick);
+            rw2[k] = rng_pick(w, tick + 2u);
+            rt2[k] = (tick & 2u) ? 0xffffffffu : tick + 2u;                  // the block covers ticks 4q .. 4q + 3
+          }
+          uint32_t y, aj;
+          if (!rng_split(word, y, aj)) rng_group_y(sp.seed, genv, tick, a, 0, 1, &aj);
           action = seller ? (float)aj * (1.0f / 274877.0f) : (aj < 137438u ? 1.0f : 0.0f);
         }
         if (seller) { s_price[kr] = (double)action; s_sent[kr] = 1; }
         else {
           int bought = 0; double paid = 0.0;
           if (action > 0.5f && deg > 0) {
-            const uint16_t* nb = sp.stk_nbr + kr;
-            int jr = -1; double best = 0.0;
-            if (!dyn) {
-              jr = nb[0]; best = s_posted[jr];
-              for (int k = 1; k < deg; ++k) { const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l]; if (v < best) { best = v; jr = l; } }
-            } else {
-              for (int k = 0; k < deg; ++k) {
-                if (!s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
-                const int l = nb[(int64_t)k * nBuy]; const double v = s_posted[l];
-                if (jr < 0 || v < best) { best = v; jr = l; }
-              }
-            }
+            int jr;
+            const double best = cheapest(k, kr, deg, jr);
             if (jr >= 0) { bought = 1; paid = best; atomicAdd(&s_count[jr], 1); }
           }
           s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;
         }
       }
-      s_act[a] = action;
+      act[k] = action;
+      __builtin_amdgcn_sched_barrier(0);
     }
+    STICK(0);
     __syncthreads();
+    STICK(1);
     // ---- pre_message_resolution + the single round --------------------------------------------------
-    for (int kr = tid; kr < nSell; kr += STKR_NT) {
+    for (int kr = tid; kr < nSell; kr += NT) {
       double rev = s_rev[kr]; int tx = s_tx[kr];
       if ((tt & 1) == 0) { rev = 0.0; tx = 0; }
       const int n = s_count[kr];
@@ -278,100 +364,100 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
       }
       s_rev[kr] = rev; s_tx[kr] = tx;
       if (s_sent[kr]) s_posted[kr] = s_price[kr];
+      s_count[kr] = 0; s_sent[kr] = 0;
     }
     __syncthreads();
+    STICK(2);
     // ---- obs / reward / flags -> trajectory row (stackelberg.py:142-196) -----------------------------
     const bool terminal = (tt == sp.num_steps);
     const bool last = (t == io.T - 1);
-    auto agent_out = [&](int a, float& ob0, float& ob1, float& rwf, uint8_t& ov, uint8_t& rv) {
-      const int fl = flags[a];
-      const uint32_t rec = sp.stk_rec[a];
-      const int kr = (int)(rec >> 16), deg = (int)((rec >> 8) & 255u);
-      const bool seller = (rec & 255u) == PHX_KIND_SELLER;
-      ob0 = 0.f; ob1 = 0.f; ov = 0;
-      if (fl & 2) {
+    char* const p_obs = (char*)(io.obs + row * 2);
+    char* const p_act = (char*)(io.action_out + row);
+    char* const p_rew = (char*)(io.reward + row);
+    char* const p_ter = (char*)(io.terminated + row);
+    char* const p_tru = (char*)(io.truncated + row);
+    char* const p_ov = (char*)(io.obs_valid + row);
+    char* const p_rv = (char*)(io.reward_valid + row);
+#pragma unroll
+    for (int k = 0; k < STKR_SLOTS; ++k) {
+      const int a = ltid + k * NT;
+      if (a >= A) continue;
+      const uint32_t fl = rec[k] >> lsh;                                     // 1 acts, 2 observes, 4 rewarded
+      const int kr = (int)(rec[k] >> 16), deg = (int)((rec[k] >> 8) & 255u);
+      const bool seller = (rec[k] & 1u) != 0;
+      float ob0 = 0.f, ob1 = 0.f; uint8_t ov = 0;
+      if (fl & 2u) {
         ov = 1;
         if (seller) {
-          int sd = sp.row_ptr[a + 1] - sp.row_ptr[a];
+          int sd = (int)nbp[k][0];
           if (dyn) { sd = 0; for (int e = sp.row_ptr[a]; e < sp.row_ptr[a + 1]; ++e) sd += s_conn[sp.col_conn[e]] ? 1 : 0; }
           ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
         } else {
-          const uint16_t* nb = sp.stk_nbr + kr;
-          double mn = 1.0;
-          if (!dyn) {
-            if (deg > 0) mn = s_posted[nb[0]];
-            for (int k = 1; k < deg; ++k) { const double v = s_posted[nb[(int64_t)k * nBuy]]; mn = v < mn ? v : mn; }
-          } else {
-            bool any = false;
-            for (int k = 0; k < deg; ++k) {
-              if (!s_conn[sp.stk_nbr_conn[(int64_t)k * nBuy + kr]]) continue;
-              const double v = s_posted[nb[(int64_t)k * nBuy]];
-              if (!any || v < mn) { mn = v; any = true; }
-            }
-          }
-          ob0 = (float)mn; ob1 = (float)sp.param_f[a * PHX_NPF];
+          int jr;
+          const double mn = cheapest(k, kr, deg, jr);                        // min over the price slots (none: 1.0)
+          ob0 = (float)(jr >= 0 ? mn : 1.0); ob1 = (float)val[k];
         }
       }
       uint8_t cv = s_cv[a]; double cache = s_cache[a];
-      if (fl & 4) {
-        cache = seller ? s_rev[kr] : (s_bought[kr] ? __dsub_rn(sp.param_f[a * PHX_NPF], s_paid[kr]) : 0.0);
+      if (fl & 4u) {
+        cache = seller ? s_rev[kr] : (s_bought[kr] ? __dsub_rn(val[k], s_paid[kr]) : 0.0);
         cv = 1; s_cache[a] = cache; s_cv[a] = 1;
       }
-      rv = 0; double rw = 0.0;
+      uint8_t rv = 0; double rw = 0.0;
       if (terminal) { rv = cv ? 1 : 2; rw = cv ? cache : 0.0; }
       else if (ov && cv) { rv = 1; rw = cache; }
-      rwf = (float)rw;
-    };
-    // (one agent per lane and iteration: packing four agents per lane for 16-byte stores was 30 %
-    //  slower -- the phase is bound by the dependent LDS lookups per agent, not by the stores)
-    for (int a = tid; a < A; a += STKR_NT) {
-      float ob0, ob1, rwf; uint8_t ov, rv;
-      agent_out(a, ob0, ob1, rwf, ov, rv);
-      const int64_t o = row + a;
-      *(float2*)(io.obs + o * 2) = make_float2(ob0, ob1);
-      io.action_out[o] = s_act[a];
-      io.reward[o] = rwf;
-      io.terminated[o] = 0; io.truncated[o] = terminal;
-      io.obs_valid[o] = ov; io.reward_valid[o] = rv;
+      // scalar row bases + 32-bit lane offsets: the stores take the SGPR-base + VGPR-offset form (per-slot 64-bit
+      // pointers kept across the step loop cost ~50 VGPRs)
+      const uint32_t ua = (uint32_t)a;
+      *(float2*)(p_obs + (size_t)(ua * 8u)) = make_float2(ob0, ob1);
+      *(float*)(p_act + (size_t)(ua * 4u)) = act[k];
+      *(float*)(p_rew + (size_t)(ua * 4u)) = (float)rw;
+      *(uint8_t*)(p_ter + (size_t)ua) = 0; *(uint8_t*)(p_tru + (size_t)ua) = terminal;
+      *(uint8_t*)(p_ov + (size_t)ua) = ov; *(uint8_t*)(p_rv + (size_t)ua) = rv;
       if (last && io.last_obs) {
         // the observation the next fragment starts from: after a terminal step, the reset's (the
         // leaders observe their reset state, stackelberg.py:95-109: a seller sees tx / deg = 0 and
         // price 0, a buyer among the leaders no prices yet -> 1.0, and its value)
         if (terminal) {
-          const bool lead_buyer = (sp.stk_flags[a] & 1) != 0 &&           // acts on the leaders' step
-                                  (sp.stk_rec[a] & 255u) != PHX_KIND_SELLER;
+          const bool lead_buyer = (rec[k] & 2u) != 0 && !seller;             // acts on the leaders' step
           ob0 = lead_buyer ? 1.0f : 0.f;
-          ob1 = lead_buyer ? (float)sp.param_f[a * PHX_NPF] : 0.f;
+          ob1 = lead_buyer ? (float)val[k] : 0.f;
         }
         *(float2*)(io.last_obs + (abase + a) * 2) = make_float2(ob0, ob1);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     step = tt; ++tick;
+    STICK(3);
     __syncthreads();
+    STICK(4);
     if (terminal) {                                                          // the caller's env.reset()
-      for (int k = tid; k < nSell; k += STKR_NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
-      for (int k = tid; k < nBuy; k += STKR_NT) { s_paid[k] = 0.0; s_bought[k] = 0; }
-      for (int a = tid; a < A; a += STKR_NT) s_cv[a] = 0;
+      for (int k = tid; k < nSell; k += NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
+      for (int k = tid; k < nBuy; k += NT) { s_paid[k] = 0.0; s_bought[k] = 0; }
+      for (int a = tid; a < A; a += NT) s_cv[a] = 0;
       if (dyn) {                                                             // resample_connectivity network.py:438-447
-        for (int i = tid; i < sp.n_conn; i += STKR_NT) s_conn[i] = (uint8_t)rng_connection(sp.seed, genv, episode, i, sp.conn_rate[i]);
+        for (int i = tid; i < sp.n_conn; i += NT) s_conn[i] = (uint8_t)rng_connection(sp.seed, genv, episode, i, sp.conn_rate[i]);
         ++episode; ++n_resets;
       }
       step = 0;
       __syncthreads();
     }
   }
+#ifdef PHX_TIMING
+  if (blockIdx.x < 64 && (tid & 63) == 0 && (tid >> 6) == 1) for (int q = 0; q < 8; ++q) atomicAdd(&g_stk_tm[q], stm[q]);
+#endif
   if (dyn && n_resets > 0) {
-    for (int i = tid; i < sp.n_conn; i += STKR_NT) fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i] = s_conn[i];
+    for (int i = tid; i < sp.n_conn; i += NT) fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i] = s_conn[i];
     if (tid == 0) fld<int32_t>(sp, F_ENV_EPISODE)[b] = (int32_t)episode;
   }
-  for (int k = tid; k < nSell; k += STKR_NT) {
+  for (int k = tid; k < nSell; k += NT) {
     fld<double>(sp, F_SELLER_POSTED)[sbase + k] = s_posted[k]; fld<double>(sp, F_SELLER_PRICE)[sbase + k] = s_price[k];
     fld<double>(sp, F_SELLER_REVENUE)[sbase + k] = s_rev[k]; fld<int32_t>(sp, F_SELLER_TX)[sbase + k] = s_tx[k];
   }
-  for (int k = tid; k < nBuy; k += STKR_NT) {
+  for (int k = tid; k < nBuy; k += NT) {
     fld<double>(sp, F_BUYER_PAID)[bbase + k] = s_paid[k]; fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + k] = s_bought[k];
   }
-  for (int a = tid; a < A; a += STKR_NT) {
+  for (int a = tid; a < A; a += NT) {
     fld<double>(sp, F_ENV_REW_CACHE)[abase + a] = s_cache[a]; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[abase + a] = s_cv[a];
   }
   if (tid == 0) { fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick; }
@@ -379,12 +465,34 @@ __global__ __launch_bounds__(STKR_NT) void phx_stk_rollout_kernel(const DevSpec 
 
 size_t phx_stk_rollout_lds(const DevSpec& sp) {
   const size_t nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER], A = sp.A;
-  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell + A) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32;
+  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32;
 }
 
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
-  if (sp.dynamic_graph) hipLaunchKernelGGL(phx_stk_rollout_kernel<true>, dim3(sp.B), dim3(STKR_NT), phx_stk_rollout_lds(sp), st, sp, io);
-  else hipLaunchKernelGGL(phx_stk_rollout_kernel<false>, dim3(sp.B), dim3(STKR_NT), phx_stk_rollout_lds(sp), st, sp, io);
+#ifdef PHX_TIMING
+  { static int calls = 0; if (getenv("PHX_TIMING_DUMP") && ++calls == 10) { (void)hipDeviceSynchronize(); unsigned long long h[8];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stk_tm), sizeof h); fprintf(stderr, "STK_TIMING cycles per step (wave 1 of blocks < 64): act %.0f | bar %.0f | book+bar %.0f | out %.0f | bar %.0f\n",
+      h[0] / (9.0 * 64 * io.T), h[1] / (9.0 * 64 * io.T), h[2] / (9.0 * 64 * io.T), h[3] / (9.0 * 64 * io.T), h[4] / (9.0 * 64 * io.T)); } }
+#endif
+  // threads per env: a block whose STKR_SLOTS passes cover the agents
+  static const int nt_env = getenv("PHX_STK_ROLLOUT_NT") ? atoi(getenv("PHX_STK_ROLLOUT_NT")) : 0;
+  // (1 152 agents: 384 threads with three full slots 35.4 us per step, 33.0 with the registers capped for 5 blocks per CU;
+  //  512 threads -- 32 waves per CU, a quarter of the lanes idle in the third slot -- 28.1: the step is a latency chain)
+  int nt = 1024;
+  for (int cand : {128, 256, 512, 1024}) if (STKR_SLOTS * cand >= sp.A) { nt = cand; break; }
+  if (nt_env && STKR_SLOTS * nt_env >= sp.A) nt = nt_env;
+  if (STKR_SLOTS * nt < sp.A) return hipErrorInvalidConfiguration;
+  const size_t lds = phx_stk_rollout_lds(sp);
+#define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp, io); \
+                                  else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp, io); } while (0)
+  switch (nt) {
+    case 128: PHX_LAUNCH_STKR(128); break;
+    case 256: PHX_LAUNCH_STKR(256); break;
+    case 384: PHX_LAUNCH_STKR(384); break;
+    case 512: PHX_LAUNCH_STKR(512); break;
+    default: PHX_LAUNCH_STKR(1024); break;
+  }
+#undef PHX_LAUNCH_STKR
   return hipGetLastError();
 }
 
@@ -405,7 +513,8 @@ __global__ __launch_bounds__(256) void phx_stk_materialise_kernel(const DevSpec 
 
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
-  const size_t lds = (size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 32 + (sp.dynamic_graph ? (size_t)sp.n_conn : 0);
+  const int nBuy = sp.kind_count[PHX_KIND_BUYER];
+  const size_t lds = g_stk_paid_off(nSell) + (size_t)nBuy * 8 + (((size_t)nBuy + 15) & ~(size_t)15) + 32 + (sp.dynamic_graph ? (size_t)sp.n_conn : 0);
   if (sp.dynamic_graph) hipLaunchKernelGGL(phx_stk_step_kernel<true>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   else hipLaunchKernelGGL(phx_stk_step_kernel<false>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   return hipGetLastError();
