@@ -71,6 +71,8 @@ struct Derived {
   std::vector<int32_t> stk_nbr_conn;
   std::vector<uint32_t> stk_rec;
   std::vector<uint8_t> stk_flags;
+  std::vector<uint32_t> stk_rec2, stk_agent;
+  bool stk_packed = false;
   // supertypes
   bool any_typed = false, device_sampling = false;
   std::vector<int32_t> type_src, shop_type_src;
@@ -267,6 +269,19 @@ static int derive(const phx_spec* sp, Derived& d) {
         d.stk_flags[(size_t)l * A + a] = (uint8_t)((d.act_mask[(size_t)l * A + a] ? 1 : 0) | (d.obs_mask[(size_t)l * A + a] ? 2 : 0) |
                                                    (d.rew_mask[(size_t)l * A + a] ? 4 : 0));
     }
+    // packed per-agent words of the batched-load kernels (phx_stk_fused.hip)
+    d.stk_packed = !d.dynamic_graph && d.buyer_dmax <= 8;
+    d.stk_rec2.assign(A, 0); d.stk_agent.assign((size_t)4 * A, 0);
+    if (d.stk_packed)
+      for (int a = 0; a < A; ++a) {
+        const bool seller = sp->kind[a] == PHX_KIND_SELLER;
+        const int deg = sp->row_ptr[a + 1] - sp->row_ptr[a];
+        d.stk_rec2[a] = (d.stk_rec[a] & 0xffffff00u) | (seller ? 1u : 0u) | ((uint32_t)(d.stk_flags[a] & 7) << 1) |
+                        ((uint32_t)(d.stk_flags[(size_t)A + a] & 7) << 4);
+        if (seller) d.stk_agent[(size_t)4 * a] = (uint32_t)deg;
+        else for (int j = 0; j < deg; ++j)
+          d.stk_agent[(size_t)4 * a + (j >> 1)] |= (uint32_t)d.kind_rank[sp->col[sp->row_ptr[a] + j]] << ((j & 1) * 16);
+      }
   }
   // ---- static digital-ads schedule? (phx_ads_fused.hip) -------------------------------------------------
   // the shipped env (digital_ads_market.py:525-596): one exchange, one publisher, N advertisers, every
@@ -528,6 +543,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.n_conn = spec->n_conn;
   UP(stk_nbr, der.stk_nbr.data(), der.stk_nbr.size()); UP(stk_nbr_conn, der.stk_nbr_conn.data(), der.stk_nbr_conn.size());
   UP(stk_rec, der.stk_rec.data(), der.stk_rec.size()); UP(stk_flags, der.stk_flags.data(), der.stk_flags.size());
+  UP(stk_rec2, der.stk_rec2.data(), der.stk_rec2.size()); UP(stk_agent, der.stk_agent.data(), der.stk_agent.size());
+  d.stk_packed = der.stk_packed ? 1 : 0;
   UP(sampler_kind, spec->sampler_kind, spec->n_samplers); UP(sampler_param, spec->sampler_param, 4 * spec->n_samplers);
   UP(type_src, der.type_src.data(), A);
   {                                                            // phx_generic_step_kernel's LDS table layout, packed

@@ -99,6 +99,10 @@ struct DevSpec {
   const int32_t* stk_nbr_conn;   // same shape: base connection of that slot (StochasticNetwork)
   const uint32_t* stk_rec;       // [A] kind | deg << 8 | kind_rank << 16
   const uint8_t*  stk_flags;     // [2][A] 1 acts, 2 observes, 4 rewarded in list 0 (leaders' step) / 1
+  // the same per agent in two words a lane loads without a dependent lookup (static graphs, buyers with <= 8 neighbours):
+  const uint32_t* stk_rec2;      // [A] seller | flags(list 0) << 1 | flags(list 1) << 4 | deg << 8 | kind_rank << 16
+  const uint32_t* stk_agent;     // [A][4] buyer: its neighbours' seller ranks, packed u16; seller: [0] = its degree
+  int32_t stk_packed;            // the two tables are valid
   // StochasticNetwork (network.py:340-453): per-env on/off byte per base connection
   int32_t n_conn;
   const double*  conn_rate;      // [n_conn]

@@ -16,6 +16,11 @@
 #include "phx_dev.h"
 
 #define STK_NT 256
+#define STKR_SLOTS 3
+#ifndef STKR_W384
+#define STKR_W384 6
+#endif
+#define STKR_MINWAVES(NT) ((NT) == 384 ? STKR_W384 : ((NT) / 64 < 4 ? 4 : ((NT) / 64 > 8 ? 8 : (NT) / 64)))
 __host__ __device__ inline size_t g_stk_paid_off(int nSell) { return ((size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 15) & ~(size_t)15; }
 #ifdef PHX_TIMING
 __device__ unsigned long long g_stk_tm[8];
@@ -73,7 +78,11 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     s_count[k] = 0; s_sent[k] = 0;
   }
   for (int k = tid; k < nBuy; k += STK_NT) s_bought[k] = 0xFF;
+#ifdef PHX_TIMING
+  unsigned long long stm[8] = {0}, sprev = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+  STICK(0);
 
   // ---- acting phase (_handle_acting_agents, env.py:320-336): decode_action of every acting agent.
   //      Sellers only record the new price (the Price messages land after the acting phase:
@@ -111,7 +120,9 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
       s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;                     // read back by compute_reward below
     }
   }
+  STICK(1);
   __syncthreads();
+  STICK(2);
   // ---- pre_message_resolution + the single round: sellers book their orders (one add per Order,
   //      in inbox order: all addends are the same f64); this step's Price messages land in every
   //      neighbour's slot, i.e. the seller's posted price changes -----------------------------------
@@ -129,7 +140,9 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     fld<int32_t>(sp, F_SELLER_TX)[sbase + kr] = tx;
     if (s_sent[kr]) { fld<double>(sp, F_SELLER_PRICE)[sbase + kr] = s_price[kr]; s_posted[kr] = s_price[kr]; posted_b[kr] = s_price[kr]; }
   }
+  STICK(3);
   __syncthreads();
+  STICK(4);
   // ---- obs / reward / done in ONE pass (stackelberg.py:142-196).  Neither kind terminates or
   //      truncates (agents.py:292-323), so "terminal" is the step count alone (env.py:312-318).
   const bool terminal = (t == sp.num_steps);
@@ -179,8 +192,187 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     uint8_t rv = 0; double rw = 0.0;
     if (terminal) { rv = cv ? 1 : 2; rw = cv ? cache : 0.0; }                // stackelberg.py:180-187
     else if (ov && cv) { rv = 1; rw = cache; }                               // stackelberg.py:190-194
+#ifdef STK_ABL_OUT
+    if (ob0 == 123.f && rw == 7.0) {
+#endif
     *(float2*)(io.obs + o * 2) = make_float2(ob0, ob1);
     io.reward[o] = rw;
+    io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = 1;
+    io.terminated[o] = 0; io.truncated[o] = 0;
+#ifdef STK_ABL_OUT
+    }
+#endif
+  }
+  STICK(5);
+  if (tid == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = t;
+    fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
+    io.all_terminated[b] = 0; io.all_truncated[b] = terminal;
+  }
+#ifdef PHX_TIMING
+  if (blockIdx.x < 64 && (tid & 63) == 0 && (tid >> 6) == 1) for (int q = 0; q < 8; ++q) atomicAdd(&g_stk_tm[q], stm[q]);
+#endif
+}
+
+// ---- the same step, loads batched.  Measured on the kernel above (PHX_TIMING, 128 x 1024, B = 4096): 34 k cycles per
+// block, 13 k in the acting pass and 19 k in the output pass -- per agent three to four DEPENDENT table lookups (flags ->
+// record -> neighbour slots -> action / cache), 4.5 agents per lane one after the other; removing the output stores
+// (half of the kernel's bytes) saved 9 of 57 us.  Here a lane owns (up to) STKR_SLOTS agents, a = tid + k * NT, and the
+// step is two load batches: (1) the env's step word, the sellers' state and, per slot, the packed record, the packed
+// neighbour list and the agent's value -- none depends on another; (2) once the step parity is known: the action of
+// the agents that act and the reward cache of those that emit it without recomputing it.  Barriers order LDS only, so
+// batch (2) and the state stores stay in flight across them.  Static graphs with <= 8 neighbours per buyer
+// (DevSpec::stk_packed); the kernel above takes the rest.
+__device__ __forceinline__ void stk_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_step_fast_kernel(const DevSpec sp, const phx_step_io io) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int A = sp.A;
+  const int nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER];
+  double* s_posted = (double*)smem;                      // [nSell] price every neighbour currently holds
+  double* s_price = s_posted + nSell;                    // [nSell] seller.price
+  double* s_rev = s_price + nSell;                       // [nSell] seller.revenue
+  int* s_tx = (int*)(s_rev + nSell);                     // [nSell] seller.tx
+  int* s_count = s_tx + nSell;                           // [nSell] orders received this step
+  uint8_t* s_sent = (uint8_t*)(s_count + nSell);         // [nSell] seller broadcast a Price this step
+  double* s_paid = (double*)(smem + g_stk_paid_off(nSell));   // [nBuy] buyer.paid as decided this step
+  uint8_t* s_bought = (uint8_t*)(s_paid + nBuy);         // [nBuy] buyer.bought this step, 0xFF: the buyer did not act
+  const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy, abase = (int64_t)b * A;
+
+  // ---- batch 1 ---------------------------------------------------------------------------------------------
+  const int t = fld<int32_t>(sp, F_ENV_STEP)[b] + 1;                         // env.py:252
+  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  uint32_t rec[STKR_SLOTS]; uint4 ag[STKR_SLOTS]; double val[STKR_SLOTS];
+#pragma unroll
+  for (int k = 0; k < STKR_SLOTS; ++k) {
+    const int a = tid + k * NT;
+    rec[k] = 0; ag[k] = make_uint4(0u, 0u, 0u, 0u); val[k] = 0.0;
+    if (a < A) { rec[k] = sp.stk_rec2[a]; ag[k] = *(const uint4*)(sp.stk_agent + 4 * a); val[k] = sp.param_f[a * PHX_NPF]; }
+  }
+  double* posted_b = fld<double>(sp, F_SELLER_POSTED) + sbase;
+  for (int k = tid; k < nSell; k += NT) {
+    s_posted[k] = posted_b[k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
+    s_rev[k] = fld<double>(sp, F_SELLER_REVENUE)[sbase + k]; s_tx[k] = fld<int32_t>(sp, F_SELLER_TX)[sbase + k];
+    s_count[k] = 0; s_sent[k] = 0;
+  }
+  for (int k = tid; k < nBuy; k += NT) s_bought[k] = 0xFF;
+  // ---- batch 2: what depends on the step's parity (stackelberg.py:133-137: leaders on odd steps) ---------------
+  const int lsh = (t & 1) ? 1 : 4;
+  const bool terminal = (t == sp.num_steps);
+  const float* actions_b = io.actions ? io.actions + abase : nullptr;
+  const uint8_t* av_b = io.action_valid ? io.action_valid + abase : nullptr;
+  const double* rew_cache = fld<double>(sp, F_ENV_REW_CACHE) + abase;
+  const uint8_t* rew_cache_v = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID) + abase;
+  float action[STKR_SLOTS]; uint8_t has[STKR_SLOTS], cv[STKR_SLOTS]; double cache[STKR_SLOTS];
+#pragma unroll
+  for (int k = 0; k < STKR_SLOTS; ++k) {
+    const int a = tid + k * NT;
+    const uint32_t fl = rec[k] >> lsh;                                       // 1 acts, 2 observes, 4 rewarded
+    action[k] = 0.f; has[k] = 0; cv[k] = 0; cache[k] = 0.0;
+    if (a < A) {
+      if ((fl & 1u) && actions_b) { action[k] = actions_b[a]; has[k] = av_b ? av_b[a] : 1; }   // aid in actions, env.py:330
+      // self._rewards[aid]: recomputed for the rewarded group, read only where it is emitted as it stands
+      if (!(fl & 4u) && (terminal || (fl & 2u))) { cv[k] = rew_cache_v[a]; cache[k] = rew_cache[a]; }
+    }
+  }
+  stk_lds_barrier();
+
+  auto cheapest = [&](int k, int deg, int& jr) __attribute__((always_inline)) {   // first minimum in neighbour order
+    const uint32_t w[4] = {ag[k].x, ag[k].y, ag[k].z, ag[k].w};
+    double best = 0.0; jr = -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < deg) {
+        const int l = (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+        const double v = s_posted[l];
+        if (j == 0 || v < best) { best = v; jr = l; }
+      }
+    return best;
+  };
+  // ---- acting phase (_handle_acting_agents, env.py:320-336) ----------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < STKR_SLOTS; ++k) {
+    const int a = tid + k * NT;
+    if (a >= A || !has[k]) continue;
+    const int kr = (int)(rec[k] >> 16), deg = (int)((rec[k] >> 8) & 255u);
+    if (rec[k] & 1u) { s_price[kr] = (double)action[k]; s_sent[kr] = 1; }
+    else {
+      int bought = 0; double paid = 0.0;
+      if (action[k] > 0.5f && deg > 0) {
+        int jr;
+        const double best = cheapest(k, deg, jr);
+        if (jr >= 0) { bought = 1; paid = best; atomicAdd(&s_count[jr], 1); }     // Order(1) -> that seller's inbox
+      }
+      fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr] = bought;
+      fld<double>(sp, F_BUYER_PAID)[bbase + kr] = paid;
+      s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;
+    }
+  }
+  stk_lds_barrier();
+  // ---- pre_message_resolution + the single round ------------------------------------------------------------------
+  for (int kr = tid; kr < nSell; kr += NT) {
+    double rev = s_rev[kr]; int tx = s_tx[kr];
+    if ((t & 1) == 0) { rev = 0.0; tx = 0; }                                 // start of a buying round
+    const int n = s_count[kr];
+    if (n > 0) {
+      const double amount = __dmul_rn(s_price[kr], 1.0);                     // price * vol, vol = 1
+      for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+      tx += n;
+    }
+    s_rev[kr] = rev; s_tx[kr] = tx;
+    fld<double>(sp, F_SELLER_REVENUE)[sbase + kr] = rev;
+    fld<int32_t>(sp, F_SELLER_TX)[sbase + kr] = tx;
+    if (s_sent[kr]) { fld<double>(sp, F_SELLER_PRICE)[sbase + kr] = s_price[kr]; s_posted[kr] = s_price[kr]; posted_b[kr] = s_price[kr]; }
+  }
+  stk_lds_barrier();
+  // ---- obs / reward / done in one pass (stackelberg.py:142-196) -----------------------------------------------------
+  char* const p_obs = (char*)(io.obs + abase * 2);
+  char* const p_rew = (char*)(io.reward + abase);
+  char* const p_cache = (char*)(fld<double>(sp, F_ENV_REW_CACHE) + abase);
+#pragma unroll
+  for (int k = 0; k < STKR_SLOTS; ++k) {
+    const int a = tid + k * NT;
+    if (a >= A) continue;
+    const uint32_t fl = rec[k] >> lsh;
+    const int kr = (int)(rec[k] >> 16), deg = (int)((rec[k] >> 8) & 255u);
+    const bool seller = (rec[k] & 1u) != 0;
+    float ob0 = 0.f, ob1 = 0.f; uint8_t ov = 0;
+    if (fl & 2u) {                                                           // encode_observation
+      ov = 1;
+      if (seller) {
+        const int sd = (int)ag[k].x;                                         // len(ctx.neighbour_ids)
+        ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
+      } else {
+        int jr;
+        const double mn = cheapest(k, deg, jr);                              // min over the price slots (none: 1.0)
+        ob0 = (float)(jr >= 0 ? mn : 1.0); ob1 = (float)val[k];
+      }
+    }
+    uint8_t cvk = cv[k]; double ck = cache[k];
+    if (fl & 4u) {                                                           // compute_reward -> self._rewards
+      if (seller) ck = s_rev[kr];
+      else {
+        int bought = s_bought[kr]; double paid = s_paid[kr];
+        if (bought == 0xFF) { bought = fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + kr]; paid = fld<double>(sp, F_BUYER_PAID)[bbase + kr]; }
+        ck = bought ? __dsub_rn(val[k], paid) : 0.0;
+      }
+      cvk = 1;
+      *(double*)(p_cache + (size_t)((uint32_t)a * 8u)) = ck;
+      fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[abase + a] = 1;
+    }
+    uint8_t rv = 0; double rw = 0.0;
+    if (terminal) { rv = cvk ? 1 : 2; rw = cvk ? ck : 0.0; }                 // stackelberg.py:180-187
+    else if (ov && cvk) { rv = 1; rw = ck; }                                 // stackelberg.py:190-194
+    const uint32_t ua = (uint32_t)a;
+    *(float2*)(p_obs + (size_t)(ua * 8u)) = make_float2(ob0, ob1);
+    *(double*)(p_rew + (size_t)(ua * 8u)) = rw;
+    const int64_t o = abase + a;
     io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = 1;
     io.terminated[o] = 0; io.truncated[o] = 0;
   }
@@ -205,11 +397,6 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
 // before (PHX_TIMING, 512 threads, everything looked up per step): 15.3 k cycles per step = acting 6.3 k (Philox per
 // acting agent and step) + booking 1.8 k + outputs 7.0 k (four dependent table loads per agent), a quarter of the
 // lanes idle in the third pass over the agents.
-#define STKR_SLOTS 3
-#ifndef STKR_W384
-#define STKR_W384 6
-#endif
-#define STKR_MINWAVES(NT) ((NT) == 384 ? STKR_W384 : ((NT) / 64 < 4 ? 4 : ((NT) / 64 > 8 ? 8 : (NT) / 64)))
 template <bool DYN, int NT>
 __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -512,9 +699,30 @@ __global__ __launch_bounds__(256) void phx_stk_materialise_kernel(const DevSpec 
 }
 
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
+#ifdef PHX_TIMING
+  { static int calls = 0; if (getenv("PHX_TIMING_DUMP") && ++calls == 101) { (void)hipDeviceSynchronize(); unsigned long long h[8];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stk_tm), sizeof h); const double n = 100.0 * 64;
+      fprintf(stderr, "STK_STEP_TIMING cycles (wave 1 of blocks < 64): loads+bar %.0f | act %.0f | bar %.0f | book %.0f | bar %.0f | out %.0f\n",
+              h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n); } }
+#endif
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
   const int nBuy = sp.kind_count[PHX_KIND_BUYER];
   const size_t lds = g_stk_paid_off(nSell) + (size_t)nBuy * 8 + (((size_t)nBuy + 15) & ~(size_t)15) + 32 + (sp.dynamic_graph ? (size_t)sp.n_conn : 0);
+  static const int fast_env = getenv("PHX_STK_STEP_FAST") ? atoi(getenv("PHX_STK_STEP_FAST")) : 1;
+  static const int nt_env = getenv("PHX_STK_STEP_NT") ? atoi(getenv("PHX_STK_STEP_NT")) : 0;
+  if (sp.stk_packed && fast_env && sp.A <= STKR_SLOTS * 1024) {
+    int nt = 1024;
+    for (int cand : {128, 256, 512, 1024}) if (STKR_SLOTS * cand >= sp.A) { nt = cand; break; }
+    if (nt_env && STKR_SLOTS * nt_env >= sp.A) nt = nt_env;
+    switch (nt) {
+      case 128: hipLaunchKernelGGL((phx_stk_step_fast_kernel<128>), dim3(sp.B), dim3(128), lds, st, sp, io); break;
+      case 256: hipLaunchKernelGGL((phx_stk_step_fast_kernel<256>), dim3(sp.B), dim3(256), lds, st, sp, io); break;
+      case 384: hipLaunchKernelGGL((phx_stk_step_fast_kernel<384>), dim3(sp.B), dim3(384), lds, st, sp, io); break;
+      case 512: hipLaunchKernelGGL((phx_stk_step_fast_kernel<512>), dim3(sp.B), dim3(512), lds, st, sp, io); break;
+      default: hipLaunchKernelGGL((phx_stk_step_fast_kernel<1024>), dim3(sp.B), dim3(1024), lds, st, sp, io); break;
+    }
+    return hipGetLastError();
+  }
   if (sp.dynamic_graph) hipLaunchKernelGGL(phx_stk_step_kernel<true>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   else hipLaunchKernelGGL(phx_stk_step_kernel<false>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   return hipGetLastError();
