@@ -598,6 +598,15 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   e->prices_compressed = der.stk_static;
   he = hipMalloc((void**)&e->inject_dev, sizeof(DevMsg) * PHX_MAX_INJECT);
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMalloc: %s", hipGetErrorString(he)); }
+  {                                   // the finished spec in device memory (DevSpec::self_dev)
+    void* p = nullptr;
+    he = hipMalloc(&p, sizeof(DevSpec));
+    if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMalloc: %s", hipGetErrorString(he)); }
+    e->dev_allocs.push_back(p);
+    d.self_dev = (const DevSpec*)p;
+    he = hipMemcpy(p, &d, sizeof(DevSpec), hipMemcpyHostToDevice);
+    if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMemcpy: %s", hipGetErrorString(he)); }
+  }
   // constructor state: zero blob, then Agent.reset() for every agent (env.py:122-124)
   he = hipMemset(state_blob, 0, (size_t)need);
   if (he != hipSuccess) { phx_destroy(e); return fail(PHX_EHIP, "hipMemset: %s", hipGetErrorString(he)); }

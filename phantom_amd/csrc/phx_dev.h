@@ -128,6 +128,7 @@ struct DevSpec {
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env
+  const DevSpec* self_dev;       // this struct in device memory (kernels that read it through the scalar cache instead of 300 SGPRs)
 };
 
 struct GenArgs {               // arguments of the generic engine kernel

@@ -634,8 +634,21 @@ __device__ __forceinline__ void reset_env(const DevSpec& sp, const int b, const 
   }
 }
 
+// The spec (device memory, DevSpec::self_dev) and the launch arguments (the kernarg segment) are read through the scalar
+// cache WHERE THEY ARE USED: both are constant-address-space pointers whose provenance is hidden from the compiler again
+// at every phase boundary (PHX_REFRESH), so no pointer lives in an SGPR across phases.  Passed and used by value, the
+// ~130 pointers of the two structs were loaded at entry and spilled: 321 spilled SGPRs, a fifth of the kernel's VALU
+// instructions were the v_readlane / v_writelane of that spilling (the engine is VALU-issue bound: 4 waves per SIMD).
+typedef const __attribute__((address_space(4))) char* phx_kptr_t;
+#define sp (*(const DevSpec*)spc)
+#define g (*(const GenArgs*)(kp + PHX_GENARGS_KERNARG_OFF))
+#define PHX_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
+#define PHX_GENARGS_KERNARG_OFF 8
 template <int NT, bool LDSQ, bool TABLDS>
-__global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, const GenArgs g) {
+__global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
+  phx_kptr_t spc = (phx_kptr_t)spp_;
+  phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  PHX_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   __shared__ int wave_sums[NT / 64];
@@ -643,9 +656,9 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
   __shared__ int s_hub[PHX_MAX_HUBS];
 #ifdef PHX_TIMING
   unsigned long long gtm[16] = {0}, gprev = __builtin_readcyclecounter();
-#define GTICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
+#define GTICK(k) do { PHX_REFRESH(); const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
 #else
-#define GTICK(k) do {} while (0)
+#define GTICK(k) PHX_REFRESH()
 #endif
 
   const int b = xcd_block(g.xcd_remap != 0), tid = threadIdx.x;
@@ -1033,6 +1046,9 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec sp, 
 #endif
 }
 
+#undef sp
+#undef g
+
 // ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------
 template <int NT>
 __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const uint8_t* mask,
@@ -1078,7 +1094,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   // round 2, after the factory's serial chain went message-parallel: SC256-FSM B=8192 199 / 165 / 149 us per step
   // (with the second queue gone -- 6 instead of 5 workgroups per CU -- 128 threads win again: 144 vs 177 us)
   int nt = nt_env ? nt_env : (sp.A <= 64 ? 64 : 128);
-#define PHX_LAUNCH_GENERIC(NT_, L_, T_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_>), dim3(sp.B), dim3(NT_), bytes, st, sp, g)
+#define PHX_LAUNCH_GENERIC(NT_, L_, T_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
   if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
   else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, true); else PHX_LAUNCH_GENERIC(256, true, true); }
   else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, false); else PHX_LAUNCH_GENERIC(256, true, false); }
