@@ -26,8 +26,6 @@
 #include "phx_epilogue.h"
 
 #define ERRKEY_NONE 0x7fffffff
-#define PHX_HUB_MIN 12        // batches longer than this are rank-sorted by the whole workgroup
-#define PHX_MAX_HUBS 32
 
 
 template <int NT>
@@ -437,7 +435,7 @@ __device__ __forceinline__ void adexchange_batch(const DevSpec& sp, const Topo& 
 // ---- the same reduction, by the whole workgroup ------------------------------------------------------
 // The single lane above is the critical path of an ads-market step (a 120-bid auction costs it ~10^6
 // cycles); here every thread takes batch positions k = tid, tid + NT, ...  Phase A (before the
-// receivers' lanes run): rank-sort the batch into send order, classify every message, count what each
+// receivers' lanes run; the batch is in send order already): classify every message, count what each
 // position sends and reduce the winner; phase B (after the block scan): write the messages.  Sends are
 // booked in position order, which is the reference's order unless an ImpressionRequest follows a Bid
 // in the batch -- then `mode[a]` = -1 and lane `a` runs the sequential adexchange_batch instead.
@@ -491,16 +489,6 @@ __device__ __forceinline__ void adx_coop_count(const DevSpec& sp, const Topo& tp
                                                int* seg, int c, int* cls, int* counts, DevMsg* resp, int* red, int* mode,
                                                int* errkey, int seq0) {
   const int tid = threadIdx.x;
-  if (c > 1) {                                                 // rank sort by send sequence number
-    for (int k = tid; k < c; k += NT) {
-      const int v = seg[k]; int r = 0;
-      for (int j = 0; j < c; ++j) r += seg[j] < v;
-      cls[r] = v;
-    }
-    __syncthreads();
-    for (int k = tid; k < c; k += NT) seg[k] = cls[k];
-    __syncthreads();
-  }
   int first_bid = 0x7fffffff, last_req = -1, best = -1;
   for (int k = tid; k < c; k += NT) {
     const DevMsg m = qc[seg[k]];
@@ -652,8 +640,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   __shared__ int wave_sums[NT / 64];
-  __shared__ int s_errkey, s_nterm, s_ntrunc, s_nhub;
-  __shared__ int s_hub[PHX_MAX_HUBS];
+  __shared__ int s_errkey, s_nterm, s_ntrunc;
 #ifdef PHX_TIMING
   unsigned long long gtm[16] = {0}, gprev = __builtin_readcyclecounter();
 #define GTICK(k) do { PHX_REFRESH(); const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
@@ -853,6 +840,18 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     for (int i = tid; i < n; i += NT) order[goff[qc[i].dst] + slot[i]] = i;
     __syncthreads();
     GTICK(9);
+    // ---- batches in send order.  The slots the atomics handed out are in ARRIVAL order, which is not deterministic:
+    //      message i takes the rank of its sequence number among its receiver's batch (c independent LDS reads per
+    //      message, whatever the batch length -- the factory of SC256 receives 51 requests, an exchange 120 bids; round 1
+    //      sorted short batches with a dependent insertion-sort chain in the receiver's lane and long ones hub by hub)
+    for (int i = tid; i < n; i += NT) {
+      const int d = qc[i].dst, base = goff[d], c = cnt[d];
+      int r = 0;
+      for (int j = 0; j < c; ++j) r += order[base + j] < i;
+      slot[base + r] = i;
+    }
+    __syncthreads();
+    { int* const t_ = order; order = slot; slot = t_; }          // order: the sorted batches; slot: scratch until the next round
     const bool has_adx = sp.n_adx > 0;
     for (int x = 0; x < sp.n_adx; ++x) {                       // exchanges: workgroup-wide batch reduction (phase A)
       const int a = sp.adx_idx[x];
@@ -860,39 +859,6 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
           adx_coop_count<NT>(sp, tp, x, a, live, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], resp + goff[a],
                              wave_sums, first, &s_errkey, seq_base + goff[a]);
     }
-    // ---- batches in send order.  A short batch is insertion-sorted by its receiver's lane; a long one (a hub: the
-    //      factory of SC256 receives 51 requests) is rank-sorted by the whole workgroup first
-    if (tid == 0) s_nhub = 0;
-    __syncthreads();
-    for (int a = tid; a < A; a += NT)
-      if (cnt[a] > PHX_HUB_MIN && !(has_adx && tp.kind[a] == PHX_KIND_ADEXCHANGE)) { const int k = atomicAdd(&s_nhub, 1); if (k < PHX_MAX_HUBS) s_hub[k] = a; }
-    __syncthreads();
-    const int n_hub = s_nhub < PHX_MAX_HUBS ? s_nhub : 0;      // more hubs than slots: their lanes sort (slow, correct)
-    for (int hx = 0; hx < n_hub; ++hx) {
-      const int a = s_hub[hx], c = cnt[a];
-      int* seg = order + goff[a];
-      int* tmp = slot + goff[a];                               // the round's slot[] entries of this segment are dead
-      for (int k = tid; k < c; k += NT) {
-        const int v = seg[k]; int r = 0;
-        for (int j = 0; j < c; ++j) r += seg[j] < v;
-        tmp[r] = v;
-      }
-      __syncthreads();
-      for (int k = tid; k < c; k += NT) seg[k] = tmp[k];
-      __syncthreads();
-    }
-    for (int a = tid; a < A; a += NT) {
-      const int c = cnt[a];
-      if (c < 2 || (n_hub > 0 && c > PHX_HUB_MIN)) continue;
-      if (has_adx && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;
-      int* seg = order + goff[a];
-      for (int x = 1; x < c; ++x) {                             // insertion sort by sequence number
-        const int v = seg[x]; int y = x - 1;
-        while (y >= 0 && seg[y] > v) { seg[y + 1] = seg[y]; --y; }
-        seg[y + 1] = v;
-      }
-    }
-    __syncthreads();
     if (sp.flags & PHX_F_SHUFFLE_BATCHES) {                     // np.random.shuffle(msgs), resolvers.py:150-151
       const uint16_t* sh = g.io.shuffle ? g.io.shuffle + (int64_t)b * 8 * Q + shuf_off : nullptr;
       for (int a = tid; a < A; a += NT) {
