@@ -181,14 +181,22 @@ struct Topo {
   const int32_t* buyer_off;
   const int32_t* col_conn;       // StochasticNetwork: base connection of each CSR entry, else NULL
   const uint8_t* conn_on;        // this env's row of net.conn_on (set by the kernel), else NULL
+  int kmax;                      // no agent kind above this one (a compile-time constant in the specialised kernels)
 };
+// kind of agent a.  With kmax a constant (phx_generic_step_kernel<.., KMAX>) the bound prunes every switch over kinds
+// to the cases that can occur: a supply-chain-only spec compiles none of the market / ads handlers.
+__device__ __forceinline__ int tkind(const Topo& tp, int a) {
+  const int k = tp.kind[a];
+  __builtin_assume(k <= tp.kmax);
+  return k;
+}
 // CSR entry k is an edge of this env's graph (always, for a static Network)
 __device__ __forceinline__ bool edge_on(const Topo& tp, int k) {
   return tp.conn_on == nullptr || tp.conn_on[tp.col_conn[k]] != 0;
 }
 __device__ __forceinline__ Topo topo_global(const DevSpec& sp) {
   Topo t;
-  t.col_conn = sp.col_conn; t.conn_on = nullptr;
+  t.col_conn = sp.col_conn; t.conn_on = nullptr; t.kmax = PHX_KIND_COUNT - 1;
   t.kind = sp.kind; t.param_i = sp.param_i; t.param_f = sp.param_f; t.row_ptr = sp.row_ptr; t.col = sp.col;
   t.strat_rank = sp.strat_rank; t.kind_rank = sp.kind_rank; t.exo_rank = sp.exo_rank; t.buyer_off = sp.buyer_off;
   return t;
@@ -236,8 +244,8 @@ __device__ __forceinline__ int dev_payload_check(const DevSpec& sp, const Topo& 
     int sk, rk, dec;
     dev_payload_types(type, sk, rk, dec);
     if (!dec) return PHX_ERR_PAYLOAD;
-    if (sk && tp.kind[src] != sk) return PHX_ERR_PAYLOAD;
-    if (rk && tp.kind[dst] != rk) return PHX_ERR_PAYLOAD;
+    if (sk && tkind(tp, src) != sk) return PHX_ERR_PAYLOAD;
+    if (rk && tkind(tp, dst) != rk) return PHX_ERR_PAYLOAD;
   }
   return 0;
 }
@@ -491,7 +499,7 @@ struct AgentRef {          // where one agent's state lives for env b
 
 __device__ __forceinline__ AgentRef agent_ref(const DevSpec& sp, const Topo& tp, int b, int a) {
   AgentRef r;
-  r.a = a; r.kind = tp.kind[a]; r.kr = tp.kind_rank[a];
+  r.a = a; r.kind = tkind(tp, a); r.kr = tp.kind_rank[a];
   r.base = (int64_t)b * sp.kind_count[r.kind] + r.kr;
   return r;
 }
@@ -610,11 +618,11 @@ __device__ __forceinline__ double dev_compute_reward(const DevSpec& sp, const To
 }
 
 __device__ __forceinline__ bool dev_is_terminated(const DevSpec& sp, const Topo& tp, int b, int a, int step) {
-  if (tp.kind[a] == PHX_KIND_MOCK_STRAT) return step == tp.param_i[a * PHX_NPI];          // tests/__init__.py:61-62
-  if (tp.kind[a] == PHX_KIND_ADVERTISER)                                                   // digital_ads_market.py:345-349
+  if (tkind(tp, a) == PHX_KIND_MOCK_STRAT) return step == tp.param_i[a * PHX_NPI];          // tests/__init__.py:61-62
+  if (tkind(tp, a) == PHX_KIND_ADVERTISER)                                                 // digital_ads_market.py:345-349
     return fld<double>(sp, F_ADV_LEFT)[(int64_t)b * sp.kind_count[PHX_KIND_ADVERTISER] + tp.kind_rank[a]] <= 0.0;
   return false;
 }
 __device__ __forceinline__ bool dev_is_truncated(const DevSpec& sp, const Topo& tp, int a, int step) {
-  return tp.kind[a] == PHX_KIND_MOCK_STRAT && step == tp.param_i[a * PHX_NPI];            // tests/__init__.py:64-65
+  return tkind(tp, a) == PHX_KIND_MOCK_STRAT && step == tp.param_i[a * PHX_NPI];            // tests/__init__.py:64-65
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ void set_errkey(int* errkey, int seq, int code) {
 
 // ---- acting phase: decode_action (env.py:330-331) / generate_messages (:332-333) -------------
 __device__ __forceinline__ int act_count(const DevSpec& sp, const Topo& tp, int b, int a, bool has_action, float action) {
-  switch (tp.kind[a]) {
+  switch (tkind(tp, a)) {
     case PHX_KIND_SHOP: return has_action ? 1 : 0;
     case PHX_KIND_CUSTOMER: return 1;
     case PHX_KIND_SELLER: {
@@ -384,7 +384,7 @@ __device__ __forceinline__ void adexchange_batch(const DevSpec& sp, const Topo& 
     int n = 0;
     for (int e = tp.row_ptr[a]; e < tp.row_ptr[a + 1]; ++e) {
       const int dst = tp.col[e];
-      if (tp.kind[dst] != PHX_KIND_ADVERTISER) continue;
+      if (tkind(tp, dst) != PHX_KIND_ADVERTISER) continue;
       const int sc = dev_send_check(sp, tp, a, dst, PHX_MSG_IMPRESSION_REQ);
       if (sc) { if (!emit) set_errkey(errkey, seq0 + k, sc); continue; }
       if (emit) {
@@ -579,10 +579,11 @@ __device__ __forceinline__ void adx_coop_emit(const DevSpec& sp, const Topo& tp,
 // Contains __syncthreads(): call it from uniform control flow.
 template <int NT>
 __device__ __forceinline__ void reset_env(const DevSpec& sp, const int b, const double* sampler_values, const uint8_t* conn_values,
-                                          float* obs, uint8_t* obs_valid) {
+                                          float* obs, uint8_t* obs_valid, const int kmax = PHX_KIND_COUNT - 1) {
   const int tid = threadIdx.x;
   const int A = sp.A, S = sp.S, D = sp.D;
-  const Topo tp = topo_env(sp, b);
+  Topo tp = topo_env(sp, b);
+  tp.kmax = kmax;
   if (sp.n_samplers > 0 || sp.n_conn > 0) {                             // env.py:211-218
     const uint32_t ep = (uint32_t)fld<int32_t>(sp, F_ENV_EPISODE)[b];
     if (sp.n_samplers > 0) {
@@ -632,7 +633,7 @@ typedef const __attribute__((address_space(4))) char* phx_kptr_t;
 #define g (*(const GenArgs*)(kp + PHX_GENARGS_KERNARG_OFF))
 #define PHX_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
 #define PHX_GENARGS_KERNARG_OFF 8
-template <int NT, bool LDSQ, bool TABLDS>
+template <int NT, bool LDSQ, bool TABLDS, int KMAX>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
   phx_kptr_t spc = (phx_kptr_t)spp_;
   phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   // queues: the round's messages, the responses by inbox position, and -- only where a handler still reads the old
   // queue while the next one is written (the exchanges' cooperative emission) -- a second queue to compact into;
   // otherwise the responses are compacted into the queue they answer (4.3 KB of LDS less per SC256 env)
-  const bool two_queues = sp.n_adx > 0;
+  const bool two_queues = KMAX >= PHX_KIND_ADEXCHANGE && sp.n_adx > 0;
   DevMsg* q0 = (DevMsg*)mem;
   DevMsg* q1 = two_queues ? q0 + Q : q0;
   DevMsg* resp = q0 + (two_queues ? 2 : 1) * Q;
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
   // static topology tables: LDS copies behind the queues (TABLDS) or the global arrays
   Topo tp = topo_env(sp, b);
+  tp.kmax = KMAX;
   if (TABLDS) {
     char* tb = smem + g.tab_off;
     const int nnz = sp.nnz;
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     // the policy of a launch-loop rollout, fused: every strategic agent's action of this tick (random policy = the
     // agent's word of the tick, rank j mapped onto the kind's action space), recorded in the trajectory whether or not it acts
     for (int s = tid; s < S; s += NT) {
-      const int a = sp.strat_idx[s], kind = tp.kind[a];
+      const int a = sp.strat_idx[s], kind = tkind(tp, a);
       bool acts = true;
       if (sp.env_type == PHX_ENV_STACKELBERG) acts = sp.act_mask[(int64_t)list * A + a] != 0;
       float action = 0.f;
@@ -852,8 +854,9 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     }
     __syncthreads();
     { int* const t_ = order; order = slot; slot = t_; }          // order: the sorted batches; slot: scratch until the next round
-    const bool has_adx = sp.n_adx > 0;
-    for (int x = 0; x < sp.n_adx; ++x) {                       // exchanges: workgroup-wide batch reduction (phase A)
+    const bool has_adx = KMAX >= PHX_KIND_ADEXCHANGE && sp.n_adx > 0;
+    const int n_adx = has_adx ? sp.n_adx : 0;
+    for (int x = 0; x < n_adx; ++x) {                          // exchanges: workgroup-wide batch reduction (phase A)
       const int a = sp.adx_idx[x];
       if (cnt[a] > 0)
           adx_coop_count<NT>(sp, tp, x, a, live, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], resp + goff[a],
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     for (int P = tid; P < n; P += NT) {
       const DevMsg m = qc[order[P]];
       const int a = m.dst;
-      if (!kind_stateless(tp.kind[a])) continue;
+      if (!kind_stateless(tkind(tp, a))) continue;
       AgentState none;
       deliver(a, P, m, none);
     }
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     for (int a = tid; a < A; a += NT) {
       const int c = cnt[a];
       if (c == 0) continue;
-      const int kind_a = tp.kind[a];
+      const int kind_a = tkind(tp, a);
       if (kind_stateless(kind_a)) continue;
       if (has_adx && kind_a == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;    // done by phase A
       int* seg = order + goff[a];
@@ -939,14 +942,14 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     else {
       for (int P = tid; P < n; P += NT)
         if (resp[P].type != 0) qn[scanbuf[P]] = resp[P];
-      for (int x = 0; x < sp.n_adx; ++x) {
+      for (int x = 0; x < n_adx; ++x) {
         const int a = sp.adx_idx[x];
         if (cnt[a] > 0 && first[a] != -1)
           adx_coop_emit<NT>(sp, tp, x, a, qc, order + goff[a], cnt[a], slot + goff[a], scanbuf + goff[a], qn, first[a]);
       }
       if (has_adx)
         for (int a = tid; a < A; a += NT)
-          if (cnt[a] > 0 && tp.kind[a] == PHX_KIND_ADEXCHANGE && first[a] == -1)
+          if (cnt[a] > 0 && tkind(tp, a) == PHX_KIND_ADEXCHANGE && first[a] == -1)
             adexchange_batch(sp, tp, a, qc, order + goff[a], cnt[a],
                              [&](int k) { const DevMsg m = qc[order[goff[a] + k]];
                                           return live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst)); },
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     }
     if (at | au) {                                             // the caller's env.reset(), same launch
       __syncthreads();
-      reset_env<NT>(sp, b, nullptr, nullptr, st.obs, st.obs_valid);
+      reset_env<NT>(sp, b, nullptr, nullptr, st.obs, st.obs_valid, KMAX);
     }
   }
 #ifdef PHX_TIMING
@@ -1060,10 +1063,17 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   // round 2, after the factory's serial chain went message-parallel: SC256-FSM B=8192 199 / 165 / 149 us per step
   // (with the second queue gone -- 6 instead of 5 workgroups per CU -- 128 threads win again: 144 vs 177 us)
   int nt = nt_env ? nt_env : (sp.A <= 64 ? 64 : 128);
-#define PHX_LAUNCH_GENERIC(NT_, L_, T_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
+  // a spec whose kinds are all supply-chain kinds (FACTORY / SHOP / CUSTOMER = 1..3) runs the instantiation that compiles
+  // only their handlers (fewer registers, no exchange / market code in the round loop)
+  int kmax = 0;
+  for (int k = 0; k < PHX_KIND_COUNT; ++k) if (sp.kind_count[k] > 0) kmax = k;
+  const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
+#define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
+#define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)
   if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
   else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, true); else PHX_LAUNCH_GENERIC(256, true, true); }
   else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, false); else PHX_LAUNCH_GENERIC(256, true, false); }
+#undef PHX_LAUNCH_GENERIC_K
 #undef PHX_LAUNCH_GENERIC
   return hipGetLastError();
 }
