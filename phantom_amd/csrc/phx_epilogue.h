@@ -6,7 +6,7 @@
 #include "phx_dev.h"
 
 // One workgroup per env.  `live` = agent has a context this step (NULL: every agent is live).
-// s_nterm / s_ntrunc: zero-initialised LDS counters.  Contains a __syncthreads().
+// s_nterm / s_ntrunc: zero-initialised LDS counters.  Contains a workgroup barrier.
 // `encode_obs(a, t, ob)` is the agent's encode_observation; the fused Stackelberg kernel passes one
 // that reads the buyers' prices from its LDS copy of seller.posted.
 template <int NT, typename ObsFn>
@@ -30,59 +30,61 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
   float* obs_cache = fld<float>(sp, F_ENV_OBS_CACHE) + (int64_t)b * S * D;
   uint8_t* obs_cache_v = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID) + (int64_t)b * S;
 
+  // One pass writes the step's outputs as they stand when the step is not the env's last (the reward an FSM / Stackelberg
+  // env emits is the cached one, read or just computed by this lane); only a terminal step -- once per episode -- takes
+  // the second pass that dumps the cached dicts.  (The second pass used to run every step and re-read from HBM what the
+  // first had just written, behind a full fence.)
   for (int s = tid; s < S; s += NT) {                          // env.py:273 / fsm.py:320 / stackelberg.py:150
     const int a = sp.strat_idx[s];
     const int64_t o = (int64_t)b * S + s;
+    const uint8_t term_old = term[s], trunc_old = trunc[s];
     uint8_t ov = 0, rv = 0, dv = 0, tm = 0, tr = 0;
     double rw = 0.0;
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
+    bool cached_now = false; double rc = 0.0;
     if (!live || live[a]) {                                    // env.py:274-275
       dv = 1;
       if (obs_mask[a]) ov = encode_obs(a, t, ob) ? 1 : 0;      // `if obs is not None` env.py:279-280
       if (sp.env_type == PHX_ENV_PLAIN) { if (ov) { rw = dev_compute_reward(sp, tp, b, a); rv = 1; } }   // env.py:283
-      else if (rew_mask[a]) { rew_cache[s] = dev_compute_reward(sp, tp, b, a); rew_cache_v[s] = 1; }
+      else if (rew_mask[a]) { rc = dev_compute_reward(sp, tp, b, a); cached_now = true; rew_cache[s] = rc; rew_cache_v[s] = 1; }
       tm = dev_is_terminated(sp, tp, b, a, t) ? 1 : 0;         // env.py:285-286
       tr = dev_is_truncated(sp, tp, a, t) ? 1 : 0;
       if (tm) term[s] = 1;                                     // :288-292
       if (tr) trunc[s] = 1;
     }
-    if (term[s]) atomicAdd(s_nterm, 1);
-    if (trunc[s]) atomicAdd(s_ntrunc, 1);
+    if (tm | term_old) atomicAdd(s_nterm, 1);
+    if (tr | trunc_old) atomicAdd(s_ntrunc, 1);
     if (sp.env_type == PHX_ENV_FSM && ov) {                    // self._observations.update, fsm.py:349
       for (int d = 0; d < D; ++d) obs_cache[s * D + d] = ob[d];
       obs_cache_v[s] = 1;
+    }
+    if (sp.env_type != PHX_ENV_PLAIN && ov) {                  // a non-terminal step's reward: the cached one
+      const bool cv = cached_now || rew_cache_v[s] != 0;
+      if (!cached_now && cv) rc = rew_cache[s];
+      if (sp.env_type == PHX_ENV_FSM) { rv = cv ? 1 : 2; rw = cv ? rc : 0.0; }          // fsm.py:378
+      else if (cv) { rv = 1; rw = rc; }                                                   // stackelberg.py:190-194
     }
     for (int d = 0; d < D; ++d) obs_b[s * D + d] = ob[d];
     io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = dv;
     io.terminated[o] = tm; io.truncated[o] = tr; io.reward[o] = rw;
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the two LDS counters: a barrier that leaves the stores in flight
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   const bool all_term = *s_nterm == S;                                        // env.py:308-310
   const bool all_trunc = (t == sp.num_steps) || *s_ntrunc == S;              // env.py:312-318
   const bool terminal = all_term || all_trunc;
-  if (sp.env_type != PHX_ENV_PLAIN) {
+  if (sp.env_type != PHX_ENV_PLAIN && terminal) {              // (uniform over the workgroup)
+    __syncthreads();                                           // this lane's stores above are re-read below
     for (int s = tid; s < S; s += NT) {
       const int64_t o = (int64_t)b * S + s;
-      const bool observed = io.obs_valid[o] != 0;
-      if (sp.env_type == PHX_ENV_FSM) {
-        if (terminal) {                                        // fsm.py:360-375: cached dicts of all agents
-          const uint8_t v = obs_cache_v[s];
-          io.obs_valid[o] = v;
-          for (int d = 0; d < D; ++d) obs_b[s * D + d] = v ? obs_cache[s * D + d] : 0.f;
-          io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
-          io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
-        } else if (observed) {                                 // fsm.py:378
-          io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
-          io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
-        }
-      } else {
-        if (terminal) {                                        // stackelberg.py:180-187
-          io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;
-          io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
-        } else if (observed && rew_cache_v[s]) {               // stackelberg.py:190-194
-          io.reward_valid[o] = 1; io.reward[o] = rew_cache[s];
-        }
+      if (sp.env_type == PHX_ENV_FSM) {                        // fsm.py:360-375: cached dicts of all agents
+        const uint8_t v = obs_cache_v[s];
+        io.obs_valid[o] = v;
+        for (int d = 0; d < D; ++d) obs_b[s * D + d] = v ? obs_cache[s * D + d] : 0.f;
       }
+      io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;             // fsm.py:360-375 / stackelberg.py:180-187
+      io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
     }
   }
   if (tid == 0) {
