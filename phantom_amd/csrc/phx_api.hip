@@ -574,6 +574,18 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.n_tabn = der.n_tabn; d.n_quot = der.n_quot; d.rew_smax = der.rew_smax;
 #undef UP
   d.max_cust = der.max_cust;
+  d.fsm_lean_K = 0; d.fsm_lean_norm = 0;
+  if (der.sc_static && spec->env_type == PHX_ENV_FSM && !der.any_typed && d.S > 0 && d.D == 3) {
+    // lean FSM rollout loop: every shop with the same 1..6 customers and normaliser, a shop's customers act all or none per stage
+    int Ku = der.shop_cust_ptr.size() > 1 ? der.shop_cust_ptr[1] - der.shop_cust_ptr[0] : -1;
+    bool ok = true;
+    for (int s2 = 0; s2 < d.S; ++s2) {
+      if (der.shop_cust_ptr[s2 + 1] - der.shop_cust_ptr[s2] != Ku) Ku = -1;
+      ok = ok && der.shop_norm[s2] == der.shop_norm[0];
+    }
+    for (size_t i = 0; i < der.sc_shop_flags.size(); ++i) ok = ok && (!(der.sc_shop_flags[i] & 2) || (der.sc_shop_flags[i] & 4));
+    if (ok && Ku >= 1 && Ku <= 6 && der.shop_norm[0] > 0) { d.fsm_lean_K = Ku; d.fsm_lean_norm = der.shop_norm[0]; }
+  }
   if (der.sc_static && spec->env_type == PHX_ENV_PLAIN && !der.any_typed && d.S > 0) {
     // fast rollout kernel (phx_sc_rollout.hip): every shop with the same 1..6 customers and the same normaliser
     int Ku = der.shop_cust_ptr.size() > 1 ? der.shop_cust_ptr[1] - der.shop_cust_ptr[0] : -1;

@@ -89,6 +89,7 @@ struct DevSpec {
   const uint8_t* sc_shop_flags;  // [n_lists][nS] 1 shop acts, 2 a customer acts, 4 every customer acts, 8 observes, 16 rewarded
   int32_t max_cust;              // max customers of one shop
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
+  int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
   // host-built lookup tables of the rollout kernel (exactly the values the formulas give):
   //   [0,101) f32 stock/100 ; [101, 101+n_tabn) f32 x/norm, n_quot valid entries (0 unless
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)

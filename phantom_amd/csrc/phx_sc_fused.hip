@@ -652,6 +652,116 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   }
 }
 
+// ---- the same loop for the common FSM supply chain, lean.  The kernel above keeps every case in its step loop (exogenous
+// and action replay, per-customer acting masks, more than six customers per shop, typed shops): ~180 instructions per
+// step and lane through a maze of branches, and with the stores removed the launch still takes 222 of 272 us (SC256-FSM,
+// B = 8192, T = 100) -- it is bound by its instruction count.  This variant serves device-RNG random-policy rollouts of
+// specs where every shop has the same 1..6 customers and normaliser and a shop's customers act all or none per stage
+// (DevSpec::fsm_lean_K): one Philox block per four ticks, the order sum as a digit sum of y mod 5^K, observations from
+// LDS tables (computed at setup: exactly the f32 quotients), stores through scalar row bases + 32-bit lane offsets.
+__global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const DevSpec sp, const phx_rollout_io io,
+                                                                       const int epb, const int remap, const uint32_t pK,
+                                                                       const float inv_pK) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const int nS = sp.S, nL = sp.n_lists, K = sp.fsm_lean_K;
+  float* s_tabs = (float*)s_raw;                           // [101] stock / 100
+  float* s_tabn = s_tabs + 104;                            // [5K + 1] x / norm
+  unsigned char* s_fl = (unsigned char*)(s_tabn + 32);     // [n_lists][S] sc_shop_flags
+  int* s_next = (int*)(s_fl + ((nL * nS + 3) & ~3));       // [n_lists] stage_next
+  for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) s_fl[idx] = sp.sc_shop_flags[idx];
+  for (int idx = threadIdx.x; idx < nL; idx += SC_NT) s_next[idx] = sp.stage_next[idx];
+  if (threadIdx.x <= PHX_SHOP_MAX_STOCK) s_tabs[threadIdx.x] = (float)threadIdx.x / (float)PHX_SHOP_MAX_STOCK;
+  if ((int)threadIdx.x <= 5 * K) s_tabn[threadIdx.x] = (float)threadIdx.x / (float)sp.fsm_lean_norm;
+  const int64_t total = (int64_t)sp.B * nS;
+  const int64_t b_first = (int64_t)xcd_block(remap != 0) * epb;
+  const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
+  const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
+  const int64_t g = b_first * nS + threadIdx.x;
+  const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
+  const int s = active ? (int)(threadIdx.x % nS) : 0;
+  int step = fld<int32_t>(sp, F_ENV_STEP)[b];
+  uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  int stage = fld<int32_t>(sp, F_ENV_STAGE)[b];
+  int prev_stage = fld<int32_t>(sp, F_ENV_PREV_STAGE)[b];
+  __syncthreads();          // tables staged; per-env words read before their shop-0 lane rewrites them
+  if (!active) return;
+
+  const float norm = (float)sp.fsm_lean_norm;
+  const int64_t genv = sp.env_offset + b;
+  ShopLane st;
+  st.stock = fld<int32_t>(sp, F_SHOP_STOCK)[g]; st.sales = fld<int32_t>(sp, F_SHOP_SALES)[g];
+  st.missed = fld<int32_t>(sp, F_SHOP_MISSED)[g]; st.delivered = fld<int32_t>(sp, F_SHOP_DELIVERED)[g];
+  double rc = fld<double>(sp, F_ENV_REW_CACHE)[g];                           // self._rewards[aid]
+  uint8_t rcv = fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g];
+  float oc[3] = {fld<float>(sp, F_ENV_OBS_CACHE)[g * 3], fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 1],
+                 fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + 2]};                // self._observations[aid]
+  uint8_t ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g];
+  float lo[3] = {0.f, 0.f, 0.f};
+  RngQuadCache rq; rq.q = 0xffffffffu;
+  const uint32_t lane_off = (uint32_t)threadIdx.x;                           // g = block base + lane: 32-bit offsets from scalar bases
+  const int64_t g0 = b_first * nS;
+
+  for (int t = 0; t < io.T; ++t) {
+    const int64_t row = (int64_t)t * total + g0;                             // uniform over the block
+    char* const p_obs = (char*)(io.obs + row * 3);
+    char* const p_act = (char*)(io.action_out + row);
+    char* const p_rew = (char*)(io.reward + row);
+    char* const p_ter = (char*)(io.terminated + row);
+    char* const p_tru = (char*)(io.truncated + row);
+    const int fl = s_fl[stage * nS + s];
+    const bool has_action = (fl & 1) != 0, any_order = (fl & 2) != 0;
+    rng_quad_block(rq, sp.seed, genv, tick, s);                              // one Philox block per four ticks
+    uint32_t y, aj;
+    if (!rng_split(rng_pick(rq.w, tick), y, aj)) y = rng_group_y(sp.seed, genv, tick, s, 0, 1, &aj);   // probability 3.3e-6
+    y -= __umul24((uint32_t)((float)y * inv_pK), pK);                        // the first K base-5 digits: the customers' orders
+    const int D = any_order ? rng_digit_sum6(y) : 0;
+    const float action = rng_j_to_action(aj);
+    sc_shop_step(st, has_action, action, any_order, D);
+    ++step; ++tick;
+    const bool all_trunc = (step == sp.num_steps);                           // env.py:312-318
+    float ob[3] = {0.f, 0.f, 0.f};
+    uint8_t ov = 0, rv = 0; double rw = 0.0;
+    const bool observes = (fl & 8) != 0;
+    if (observes) {                                                          // fsm.py:328-332,349
+      if ((unsigned)st.stock <= (unsigned)PHX_SHOP_MAX_STOCK && (unsigned)st.sales <= (unsigned)(5 * K) &&
+          (unsigned)st.missed <= (unsigned)(5 * K)) { ob[0] = s_tabs[st.stock]; ob[1] = s_tabn[st.sales]; ob[2] = s_tabn[st.missed]; }
+      else shop_obs_f32(st.stock, st.sales, st.missed, norm, ob);            // a stock the caller set outside [0, 100]
+      oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; ocv = 1;
+    }
+    if (fl & 16) { rc = shop_reward(st.sales, st.stock); rcv = 1; }          // fsm.py:334-335,350
+    if (all_trunc) {                                                         // fsm.py:360-375
+      ov = ocv; ob[0] = ocv ? oc[0] : 0.f; ob[1] = ocv ? oc[1] : 0.f; ob[2] = ocv ? oc[2] : 0.f;
+      rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
+    } else if (observes) {                                                   // fsm.py:378
+      ov = 1; rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
+    }
+    float* po = (float*)(p_obs + (size_t)(lane_off * 12u));
+    po[0] = ob[0]; po[1] = ob[1]; po[2] = ob[2];
+    *(float*)(p_act + (size_t)(lane_off * 4u)) = action;
+    *(float*)(p_rew + (size_t)(lane_off * 4u)) = (float)rw;
+    *(uint8_t*)(p_ter + (size_t)lane_off) = 0; *(uint8_t*)(p_tru + (size_t)lane_off) = all_trunc;
+    if (io.obs_valid) *(uint8_t*)((char*)(io.obs_valid + row) + (size_t)lane_off) = ov;
+    if (io.reward_valid) *(uint8_t*)((char*)(io.reward_valid + row) + (size_t)lane_off) = rv;
+    lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2];
+    prev_stage = stage; stage = s_next[stage];                               // fsm.py:355
+    if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
+      st.stock = 0; step = 0; stage = sp.initial_stage; rcv = 0;
+      lo[0] = lo[1] = lo[2] = 0.f;
+      if (s_fl[sp.initial_stage * nS + s] & 1) shop_obs_f32(st.stock, st.sales, st.missed, norm, lo);
+    }
+  }
+  fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock; fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
+  fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed; fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
+  fld<double>(sp, F_ENV_REW_CACHE)[g] = rc; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g] = rcv;
+  for (int d = 0; d < 3; ++d) fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + d] = oc[d];
+  fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g] = ocv;
+  if (io.last_obs) for (int d = 0; d < 3; ++d) io.last_obs[g * 3 + d] = lo[d];
+  if (s == 0) {
+    fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
+    fld<int32_t>(sp, F_ENV_STAGE)[b] = stage; fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = prev_stage;
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
@@ -674,6 +784,15 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
   const int epb = SC_NT / sp.S;
   static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
   const int remap = remap_env >= 0 ? remap_env : 1;
+  static const int lean_env = getenv("PHX_FSM_LEAN") ? atoi(getenv("PHX_FSM_LEAN")) : 1;
+  if (lean_env && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
+    uint32_t pk = 1; for (int k = 0; k < sp.fsm_lean_K; ++k) pk *= 5u;
+    static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
+    const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (size_t)sp.n_lists * 4 + 16;
+    hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, remap,
+                       pk, inv[sp.fsm_lean_K]);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
                      (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb, remap);
   return hipGetLastError();
