@@ -345,6 +345,39 @@ def test_fast_rollout_kernel_edge_cases_match_oracle(S, K, B, num_steps):
     assert (d.err == 0).all()
 
 
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (51, 4, 16, 100), (3, 2, 48, 7), (5, 1, 40, 33)])
+def test_fsm_lean_rollout_loop_edge_cases_match_oracle(S, K, B, num_steps):
+    """device-RNG rollouts of FSM supply chains whose shops all have the same 1..6 customers (the lean loop of
+    phx_sc_fused.hip; PHX_FSM_LEAN=0 selects the general one): fragments starting on ticks that are no multiple of 4 and in
+    either stage, several episode ends per fragment, caches carried across launches, stocks poked outside [0, 100] (the
+    observation tables do not cover them), hand-over to per-step launches."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, fsm=True, seed=5 + S, env_offset=77)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    assert d.dev.uses_fused
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S * 10 + K)
+    for t in range(3):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+    fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.stage", "env.step", "env.tick")
+    for T in (1, 6, 41, 100, 3):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, True)
+        for f in fields:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    st = rng.integers(-40, 160, (B, S)).astype(np.int32)
+    o.set_i32("shop.stock", st); d.set_i32("shop.stock", st)
+    for T in (12, 5):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, True)
+    a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+    o.step(a, None, None); d.step(a, None, None)
+    np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
+    np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward))
+    np.testing.assert_array_equal(d.obs_valid, o.obs_valid)
+    assert (d.err == 0).all()
+
+
 # ---- BatchResolver(shuffle_batches=True) on the device stream (resolvers.py:150-151) ----------------------------
 @pytest.mark.parametrize("fsm", [False, True])
 def test_shuffle_batches_device_stream_matches_oracle(fsm):
