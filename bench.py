@@ -101,26 +101,43 @@ def other_configs(device):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3                    # seconds per call
 
-    def add(name, agents, B, steps_per_call, sec, mode):
-        res.append({"config": name, "mode": mode, "agents": agents, "envs": B,
-                    "us_per_step": sec / steps_per_call * 1e6,
-                    "agent_steps_per_sec": agents * B * steps_per_call / sec})
+    def add(name, agents, B, steps_per_call, sec, mode, bytes_per_env_step=None):
+        r = {"config": name, "mode": mode, "agents": agents, "envs": B,
+             "us_per_step": sec / steps_per_call * 1e6,
+             "agent_steps_per_sec": agents * B * steps_per_call / sec}
+        if bytes_per_env_step:                                   # algorithmic HBM bytes against the 8 TB/s peak
+            gbps = bytes_per_env_step * B * steps_per_call / sec / 1e9
+            r["hbm"] = {"algorithmic_bytes_per_env_step": bytes_per_env_step, "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBS}
+        res.append(r)
 
     # config 3: SC256 (1 + 51 + 204 agents), 2-stage FSM, B = 8192
     env = ph.SupplyChainFSMEnv(n_shops=51, customers_per_shop=4, num_steps=100, batch_size=8192, seed=42,
                                exogenous="device", device=device)
     env.reset(); dev = env._device()
     tr = dev.rollout(100)
-    add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 3), "fused FSM rollout T=100")
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 10), "fused FSM rollout T=100",
+        bytes_per_env_step=24 * 51)                              # trajectory: obs 12 + action 4 + reward 4 + 4 flag bytes per shop
     acts = torch.rand(8192, 51, device=dev.device) * 100.0
-    add("SC256 FSM B=8192 (config 3)", 256, 8192, 1, timed(lambda: dev.step(acts), 100), "one launch per step")
+    # per env-step: S * (43 + K) + 6 with device-RNG orders (no exo term: S * 43 + 6), + stage and valid planes
+    step_bytes = 51 * 43 + 6 + 2 * 51 + 2
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 1, timed(lambda: dev.step(acts), 100), "one launch per step",
+        bytes_per_env_step=step_bytes)
+    try:                                                         # the same launches replayed from a hipGraph (DeviceEnv.step_graph)
+        a50 = (torch.rand(50, 8192, 51, device=dev.device) * 100.0).contiguous()
+        sg = dev.step_graph(a50)
+        add("SC256 FSM B=8192 (config 3)", 256, 8192, 50, timed(sg.replay, 6), "one launch per step, hipGraph of 50 steps",
+            bytes_per_env_step=step_bytes)
+        del sg, a50
+    except Exception as exc:                                     # graph capture is an optimisation, not the product path
+        res.append({"config": "SC256 FSM B=8192 (config 3)", "mode": "hipGraph", "error": str(exc)[:200]})
     del env, dev, tr, acts; torch.cuda.empty_cache()
     # config 4, one GPU's share: SC256 plain, B = 8192 per GPU, rollout T = 100
     env = ph.SupplyChainEnv(n_shops=51, customers_per_shop=4, num_steps=100, batch_size=8192, seed=42,
                             exogenous="device", device=device)
     env.reset(); dev = env._device()
     tr = dev.rollout(100)
-    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 3), "fused rollout T=100")
+    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 10), "fused rollout T=100",
+        bytes_per_env_step=22 * 51)
     del env, dev, tr; torch.cuda.empty_cache()
     # config 5: Stackelberg market 128 leaders / 1024 followers, B = 4096
     env = market_env(128, 1024, 8, 100, 4096, exogenous="device", device=device)
@@ -133,9 +150,13 @@ def other_configs(device):
 
     def one():
         dev.step(acts, valid[k[0] & 1]); k[0] += 1
-    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 1, timed(one, 40), "one launch per step")
+    # per env-step: outputs 21 B per agent, reward cache 9 B written by the rewarded half and read by the observing half,
+    # actions + valid 5 B per acting agent (half on average), seller state 56 B, bought / paid 12 B per buyer every other step
+    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 1, timed(one, 40), "one launch per step",
+        bytes_per_env_step=21 * S + 9 * S + 5 * S // 2 + 56 * 128 + 6 * 1024)
     tr = dev.rollout(20)
-    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 20, timed(lambda: dev.rollout(20, out=tr), 2), "fused rollout T=20")
+    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 20, timed(lambda: dev.rollout(20, out=tr), 4), "fused rollout T=20",
+        bytes_per_env_step=20 * S)
     del env, dev, tr
     torch.cuda.empty_cache()
     # not a BASELINE config: the reference's digital-ads example at its own size (the exchange's

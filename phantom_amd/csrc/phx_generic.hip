@@ -633,6 +633,7 @@ typedef const __attribute__((address_space(4))) char* phx_kptr_t;
 #define g (*(const GenArgs*)(kp + PHX_GENARGS_KERNARG_OFF))
 #define PHX_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
 #define PHX_GENARGS_KERNARG_OFF 8
+static_assert(alignof(GenArgs) == 8 && sizeof(const DevSpec*) == 8, "kernarg layout: (spec pointer, GenArgs at offset 8)");
 template <int NT, bool LDSQ, bool TABLDS, int KMAX>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
   phx_kptr_t spc = (phx_kptr_t)spp_;
