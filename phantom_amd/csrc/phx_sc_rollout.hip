@@ -53,11 +53,19 @@ __device__ __forceinline__ void fast_lds_barrier() {     // orders LDS traffic o
 }
 
 // four workgroups per CU must stay co-resident (B = 4096 is ONE round of 1 024 workgroups): NT / 64 waves per SIMD
+// The arguments are read from the kernarg segment through a constant-address-space pointer whose provenance is hidden from
+// the compiler again at every chunk iteration (FAST_REFRESH): scalar loads where a field is used.  Used by value, the block
+// was loaded at entry and kept: 67 spilled SGPRs, v_readlane / v_writelane traffic inside the chunk loop.
+typedef const __attribute__((address_space(4))) char* fast_kptr_t;
+#define a (*(const FastArgs*)kp)
+#define io (a.io)
+#define FAST_REFRESH() asm volatile("" : "+s"(kp))
 template <int NT>
-__global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const FastArgs a) {
+__global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const FastArgs a_) {
+  fast_kptr_t kp = (fast_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  FAST_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TC = PHX_FAST_TC;
-  const phx_rollout_io& io = a.io;
   const int tid = threadIdx.x, nS = a.S, G = a.G;
   const int64_t total = (int64_t)a.B * nS;
   const int bid = xcd_block(a.xcd_remap != 0);
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
   //      Draw tiles rotate over three buffers (draws(c + 2) overwrites what outputs(c - 1) read before the last
   //      barrier), stock tiles over two.  One call site per phase keeps the code small.
   for (int it = -2; it < n_chunks; ++it) {
+    FAST_REFRESH();
     const int co = it, cr = it + 1, cd = it + 2;
     if (tid < rec_threads && it > -2) {
       if (cr < n_chunks) recurrence(cr, rows_of(cr));
@@ -369,6 +378,10 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
     }
   }
 }
+
+#undef a
+#undef io
+#undef FAST_REFRESH
 
 // Step counter and tick of every env after the fragment, for launches whose blocks hold parts of envs: the walk of
 // `step` in the recurrence above, once per env, after the main kernel (stream order).
