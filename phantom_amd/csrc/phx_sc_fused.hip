@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   // are read by every lane of the env and rewritten by its shop-0 lane, so readers and writer
   // must sit in one workgroup with a barrier between the two.
   extern __shared__ __attribute__((aligned(16))) unsigned char s_exo[];
-  const int nS = sp.S, A = sp.A;
+  const int nS = sp.S;
   const int64_t b_first = (int64_t)xcd_block(stage_exo >= 0 && PHX_STEP_REMAP) * epb;
   const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
   const int lanes = (int)(b_end - b_first) * nS;
