@@ -661,13 +661,17 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
 // LDS tables (computed at setup: exactly the f32 quotients), stores through scalar row bases + 32-bit lane offsets.
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                        const int epb, const int remap, const uint32_t pK,
-                                                                       const float inv_pK) {
+                                                                       const float inv_pK, const int wide) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int nS = sp.S, nL = sp.n_lists, K = sp.fsm_lean_K;
   float* s_tabs = (float*)s_raw;                           // [101] stock / 100
   float* s_tabn = s_tabs + 104;                            // [5K + 1] x / norm
   unsigned char* s_fl = (unsigned char*)(s_tabn + 32);     // [n_lists][S] sc_shop_flags
   int* s_next = (int*)(s_fl + ((nL * nS + 3) & ~3));       // [n_lists] stage_next
+  // `wide` (blocks start on multiples of 4 pairs): a wave's 64 x 3 observation floats of a step leave as 48 consecutive
+  // 16-byte pieces through a wave-private LDS tile -- with its stores removed this loop takes 125 of 242 us, so the
+  // memory system's cost per store instruction (three 4-byte stores at a 12-byte lane stride) is what it pays for
+  float* s_ot = (float*)(s_next + ((nL + 3) & ~3)) + (threadIdx.x >> 6) * 192;
   for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) s_fl[idx] = sp.sc_shop_flags[idx];
   for (int idx = threadIdx.x; idx < nL; idx += SC_NT) s_next[idx] = sp.stage_next[idx];
   if (threadIdx.x <= PHX_SHOP_MAX_STOCK) s_tabs[threadIdx.x] = (float)threadIdx.x / (float)PHX_SHOP_MAX_STOCK;
@@ -700,6 +704,10 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
   RngQuadCache rq; rq.q = 0xffffffffu;
   const uint32_t lane_off = (uint32_t)threadIdx.x;                           // g = block base + lane: 32-bit offsets from scalar bases
   const int64_t g0 = b_first * nS;
+  const uint32_t wave_off = (uint32_t)threadIdx.x & ~63u;                    // pairs of the block before this wave
+  const int lanes_blk = (int)(b_end - b_first) * nS;
+  const int n_wave = lanes_blk - (int)wave_off < 64 ? lanes_blk - (int)wave_off : 64;   // active lanes of this wave (a multiple of 4 when wide)
+  const int n_pieces = (n_wave * 3) >> 2;
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t row = (int64_t)t * total + g0;                             // uniform over the block
@@ -735,8 +743,17 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
     } else if (observes) {                                                   // fsm.py:378
       ov = 1; rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
     }
-    float* po = (float*)(p_obs + (size_t)(lane_off * 12u));
-    po[0] = ob[0]; po[1] = ob[1]; po[2] = ob[2];
+    if (wide) {
+      const int lane = (int)(threadIdx.x & 63u);
+      s_ot[lane * 3 + 0] = ob[0]; s_ot[lane * 3 + 1] = ob[1]; s_ot[lane * 3 + 2] = ob[2];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // wave-private tile: no barrier
+      if (lane < n_pieces)
+        *(float4*)(p_obs + (size_t)(wave_off * 12u + (uint32_t)lane * 16u)) = *(const float4*)(s_ot + 4 * lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // read before the next step overwrites the tile
+    } else {
+      float* po = (float*)(p_obs + (size_t)(lane_off * 12u));
+      po[0] = ob[0]; po[1] = ob[1]; po[2] = ob[2];
+    }
     *(float*)(p_act + (size_t)(lane_off * 4u)) = action;
     *(float*)(p_rew + (size_t)(lane_off * 4u)) = (float)rw;
     *(uint8_t*)(p_ter + (size_t)lane_off) = 0; *(uint8_t*)(p_tru + (size_t)lane_off) = all_trunc;
@@ -788,9 +805,18 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
   if (lean_env && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
     uint32_t pk = 1; for (int k = 0; k < sp.fsm_lean_K; ++k) pk *= 5u;
     static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
-    const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (size_t)sp.n_lists * 4 + 16;
-    hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, remap,
-                       pk, inv[sp.fsm_lean_K]);
+    // blocks that start on multiples of 4 pairs (16-byte aligned observation rows): whole envs, a multiple of 4 of them
+    // unless the shop count is one itself
+    int epb_l = epb; int wide = 0;
+    static const int wide_env = getenv("PHX_FSM_WIDE") ? atoi(getenv("PHX_FSM_WIDE")) : 1;
+    if (wide_env && ((int64_t)sp.B * sp.S) % 4 == 0) {
+      if (sp.S % 4 == 0) wide = (sp.B % epb == 0);
+      else if ((SC_NT / sp.S) >= 4) { const int e4 = (SC_NT / sp.S) & ~3; if (sp.B % e4 == 0) { epb_l = e4; wide = 1; } }
+    }
+    const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (((size_t)sp.n_lists + 3) & ~(size_t)3) * 4 +
+                       (SC_NT / 64) * 192 * 4 + 16;
+    hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3((sp.B + epb_l - 1) / epb_l), dim3(SC_NT), lds, st, sp, io, epb_l, remap,
+                       pk, inv[sp.fsm_lean_K], wide);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
