@@ -250,6 +250,17 @@ __device__ __forceinline__ int dev_payload_check(const DevSpec& sp, const Topo& 
   }
   return 0;
 }
+// the same with both kinds known (a reply: the receiver's kind, and the sender's fetched with the message)
+__device__ __forceinline__ int dev_payload_check_kinds(const DevSpec& sp, int src_kind, int dst_kind, int type) {
+  if (!(sp.flags & PHX_F_NO_PAYLOAD_CHECKS)) {
+    int sk, rk, dec;
+    dev_payload_types(type, sk, rk, dec);
+    if (!dec) return PHX_ERR_PAYLOAD;
+    if (sk && src_kind != sk) return PHX_ERR_PAYLOAD;
+    if (rk && dst_kind != rk) return PHX_ERR_PAYLOAD;
+  }
+  return 0;
+}
 // Network.send checks (network.py:246-252, 297-331); returns PHX_ERR_* (0 = deliverable)
 __device__ __forceinline__ int dev_send_check(const DevSpec& sp, const Topo& tp, int src, int dst, int type) {
   if (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) && !dev_has_edge(sp, tp, src, dst)) return PHX_ERR_NETWORK;

@@ -28,6 +28,19 @@
 #define ERRKEY_NONE 0x7fffffff
 
 
+// inclusive scan over the 64 lanes of a wave with DPP row shifts / broadcasts: ~80 cycles against ~400 for the six
+// dependent ds_bpermute round trips of a __shfl_up ladder (tools/ubench/ub_dppscan.hip checks and times both)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 template <int NT>
 __device__ __forceinline__ int block_exscan(int* arr, int n, int* wave_sums) {
   // in-place exclusive scan of arr[0..n); returns the total.  All NT threads must call.
@@ -36,12 +49,7 @@ __device__ __forceinline__ int block_exscan(int* arr, int n, int* wave_sums) {
   const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
   int local = 0;
   for (int i = lo; i < hi; ++i) local += arr[i];
-  int incl = local;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if ((tid & 63) >= off) incl += v;
-  }
+  const int incl = wave_incl_scan(local);
   if ((tid & 63) == 63) wave_sums[tid >> 6] = incl;
   __syncthreads();
   int wave_off = 0, total = 0;
@@ -237,11 +245,10 @@ __device__ __forceinline__ bool kind_stateless(int kind) {
 
 // Agent.handle_message (agents.py:122-155): returns true and fills `resp` (dst/type/payload)
 // when the handler answers; sets `code` to PHX_ERR_UNKNOWN_MSG for an unhandled payload type.
-// `st`: the receiver's register-cached state (kind_state_cached kinds).
-__device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp, int b, int a, const DevMsg& m,
+// `st`: the receiver's register-cached state (kind_state_cached kinds); `r`: agent_ref of the receiver.
+__device__ __forceinline__ bool handle_message(const DevSpec& sp, const Topo& tp, int b, int a, const AgentRef& r, const DevMsg& m,
                                                int clock, const uint8_t* exo_b, uint32_t tick, DevMsg& resp, int& code,
                                                AgentState& st) {
-  const AgentRef r = agent_ref(sp, tp, b, a);
   const int32_t* pi = tp.param_i + a * PHX_NPI;
   resp.src = (uint16_t)a; resp.dst = m.src; resp.pad = 0; resp.type = 0;
   switch (r.kind) {
@@ -888,16 +895,17 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     // dropped: receiver not in contexts (resolvers.py:143-144), edge filter (:146-148), or a send that already
     // failed its checks (type 0).  The receive-side edge filter can only drop something when sends skipped the
     // edge check (ignore_connection_errors): every queued message already passed has_edge.
-    auto deliver = [&](int a, int P, const DevMsg& m, AgentState& st) {
+    // `r`, `live_a`: the receiver's agent_ref and context flag; `src_kind`: kind of the sender (for the payload whitelist of a reply)
+    auto deliver = [&](int a, const AgentRef& r, bool live_a, int P, const DevMsg& m, int src_kind, AgentState& st) __attribute__((always_inline)) {
       DevMsg out; out.type = 0;
-      if (live[a] && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
+      if (live_a && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
         int code = 0;
-        const bool answered = handle_message(sp, tp, b, a, m, clock + P, exo_b, tick, out, code, st);
+        const bool answered = handle_message(sp, tp, b, a, r, m, clock + P, exo_b, tick, out, code, st);
         if (code) set_errkey(&s_errkey, seq_base + P, code);
         if (answered) {                                         // network.send(receiver, sub_receiver, payload) :156-158
           // a reply to the sender travels the edge the delivered message came along (connections are undirected,
           // also per env on a StochasticNetwork): only the payload whitelist is left to check
-          const int sc = out.dst == m.src ? dev_payload_check(sp, tp, out.src, out.dst, out.type)
+          const int sc = out.dst == m.src ? dev_payload_check_kinds(sp, r.kind, src_kind, out.type)
                                           : dev_send_check(sp, tp, out.src, out.dst, out.type);
           if (sc) { set_errkey(&s_errkey, seq_base + P, sc); out.type = 0; }
         } else out.type = 0;
@@ -911,7 +919,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
       const int a = m.dst;
       if (!kind_stateless(tkind(tp, a))) continue;
       AgentState none;
-      deliver(a, P, m, none);
+      deliver(a, agent_ref(sp, tp, b, a), live[a] != 0, P, m, tkind(tp, m.src), none);
     }
     // every other receiver: one lane walks its batch, handled one message at a time (agents.py:96-120)
     for (int a = tid; a < A; a += NT) {
@@ -931,9 +939,23 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
       }
       const AgentRef r = agent_ref(sp, tp, b, a);
       const bool cached = kind_state_cached(kind_a);
+      const bool live_a = live[a] != 0;
+      const int base = goff[a];
       AgentState st;
       if (cached) load_state(sp, r, st);
-      for (int k = 0; k < c; ++k) deliver(a, goff[a] + k, qc[seg[k]], st);
+      // The batch is handled in order, four messages at a time: their queue entries and the senders' kinds are fetched
+      // first (independent LDS reads), the handlers then run on registers.  One message at a time cost ~1 000 cycles
+      // each -- index, entry, receiver's context flag / kind / rank and the sender's kind re-read behind every response
+      // store -- and the longest such chain (a shop's six orders) is what the round waits for.
+      for (int k0 = 0; k0 < c; k0 += 4) {
+        DevMsg mm[4]; int sk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mm[j] = qc[seg[k0 + j < c ? k0 + j : c - 1]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sk[j] = tkind(tp, mm[j].src);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k0 + j < c) deliver(a, r, live_a, base + k0 + j, mm[j], sk[j], st);
+      }
       if (cached) store_state(sp, r, st);
     }
     __syncthreads();
