@@ -250,7 +250,8 @@ typedef struct phx_step_io {
   const int32_t* next_stage;   /* [B] or NULL                                               */
 } phx_step_io;
 
-/* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end */
+/* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end.
+ * Every buffer must be 16-byte aligned (the kernels write 16-byte pieces); phx_rollout returns PHX_EINVAL otherwise. */
 typedef struct phx_rollout_io {
   int32_t T;
   const float*   actions;      /* [T][B][S] replayed policy, or NULL -> random U[0,100)     */

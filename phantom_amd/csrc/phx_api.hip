@@ -777,6 +777,12 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EINVAL, "bad rollout io");
   if ((io->msg_log || io->msg_count) && (e->d.trace_cap <= 0 || !io->msg_log || !io->msg_count))
     return fail(PHX_EINVAL, "rollout message log needs trace_cap > 0 and both msg_log and msg_count");
+  {                                   // the rollout kernels write 16-byte pieces
+    const void* bufs[] = {io->obs, io->action_out, io->reward, io->terminated, io->truncated, io->obs_valid, io->reward_valid,
+                          io->last_obs, io->actions, io->exo};
+    for (const void* p : bufs)
+      if (((uintptr_t)p & 15u) != 0) return fail(PHX_EINVAL, "phx_rollout: every buffer must be 16-byte aligned");
+  }
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   HIPCHK(use_device(e));

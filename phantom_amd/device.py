@@ -353,6 +353,8 @@ class DeviceEnv:
                 raise ValueError(f"rollout: `{name}` is required for this env")
             if x.dtype != dtype or x.device != self.device or not x.is_contiguous():
                 raise ValueError(f"rollout: `{name}` must be a contiguous {dtype} tensor on {self.device}")
+            if x.data_ptr() % 16:
+                raise ValueError(f"rollout: `{name}` must start on a 16-byte boundary (a view at an odd offset?)")
             if tuple(x.shape[1:]) != tuple(tail) or (lead is not None and x.shape[0] != lead) \
                     or (lead is None and x.shape[0] < T):
                 want = (lead if lead is not None else f">={T}",) + tuple(tail)

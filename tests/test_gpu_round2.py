@@ -151,6 +151,11 @@ def test_rollout_rejects_malformed_buffers():
         dev.rollout(5, actions=torch.zeros(4, 4, 3, device=dev.device))
     with pytest.raises(ValueError):
         dev.rollout(6, out=tr)
+    # a view that starts off a 16-byte boundary (the kernels write 16-byte pieces): rejected in Python and by the ABI
+    big = torch.zeros(tr.truncations.numel() + 16, dtype=torch.uint8, device=dev.device)
+    odd = big[3:3 + tr.truncations.numel()].view(tr.truncations.shape)
+    with pytest.raises(ValueError):
+        dev.rollout(5, out=tr._replace(truncations=odd))
     dev.rollout(5, out=tr)
     # repeated rollouts into internally allocated fragments pin nothing
     for _ in range(8):
