@@ -218,7 +218,8 @@ typedef struct phx_msg_rec {
 } phx_msg_rec;
 
 /* ---- step I/O: every pointer is a device pointer, NULL where noted --------------------
- * S = number of strategic agents (rank order = agent order), D = obs_dim (phx_obs_dim).   */
+ * S = number of strategic agents (rank order = agent order), D = obs_dim (phx_obs_dim).   
+ * Alignment: obs and actions 16 bytes, reward 8 bytes (PHX_EINVAL otherwise). */
 typedef struct phx_step_io {
   const float*   actions;      /* [B][S]    one float per strategic agent                   */
   const uint8_t* action_valid; /* [B][S] or NULL (= every strategic agent has an action);

@@ -688,6 +688,8 @@ static int check_step_io(const phx_env* e, const phx_step_io* io) {
   if (!io->obs || !io->obs_valid || !io->reward || !io->reward_valid || !io->terminated || !io->truncated ||
       !io->done_valid || !io->all_terminated || !io->all_truncated)
     return fail(PHX_EINVAL, "a required output pointer is NULL");
+  if ((((uintptr_t)io->obs | (uintptr_t)io->actions) & 15u) != 0 || ((uintptr_t)io->reward & 7u) != 0)
+    return fail(PHX_EINVAL, "phx_step: obs and actions must be 16-byte aligned, reward 8-byte aligned");
   if ((io->msg_log || io->msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
   if (io->shuffle && !(e->d.flags & PHX_F_SHUFFLE_BATCHES)) return fail(PHX_EINVAL, "shuffle given but the spec has no PHX_F_SHUFFLE_BATCHES");
   if (io->next_stage && e->d.env_type != PHX_ENV_FSM) return fail(PHX_EINVAL, "next_stage given but the env is not a FiniteStateMachineEnv");
