@@ -87,7 +87,7 @@ def main():
         d.rollout(T, out=traj)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / (4 * T) * 1e3
-    nbytes = sum(x.numel() * x.element_size() for x in traj if x is not None and x is not traj.last_obs)
+    nbytes = sum(x.numel() * x.element_size() for x in traj if hasattr(x, "numel") and x is not traj.last_obs)
     out.append(dict(config=f"STK 128x1024 B={B} rollout T={T}", engine="fused", agents=S, batch=B,
                     us_per_step_events=us, us_per_step_wall=us, agent_steps_per_s=S * B / (us * 1e-6),
                     trajectory_GBps=nbytes / T / (us * 1e-6) / 1e9))
