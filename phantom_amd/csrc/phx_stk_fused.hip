@@ -192,16 +192,10 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     uint8_t rv = 0; double rw = 0.0;
     if (terminal) { rv = cv ? 1 : 2; rw = cv ? cache : 0.0; }                // stackelberg.py:180-187
     else if (ov && cv) { rv = 1; rw = cache; }                               // stackelberg.py:190-194
-#ifdef STK_ABL_OUT
-    if (ob0 == 123.f && rw == 7.0) {
-#endif
     *(float2*)(io.obs + o * 2) = make_float2(ob0, ob1);
     io.reward[o] = rw;
     io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = 1;
     io.terminated[o] = 0; io.truncated[o] = 0;
-#ifdef STK_ABL_OUT
-    }
-#endif
   }
   STICK(5);
   if (tid == 0) {
