@@ -575,6 +575,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
 #undef UP
   d.max_cust = der.max_cust;
   d.fsm_lean_K = 0; d.fsm_lean_norm = 0;
+  std::vector<uint32_t> fsm_tab;             // position table of the time-parallel FSM rollout
   if (der.sc_static && spec->env_type == PHX_ENV_FSM && !der.any_typed && d.S > 0 && d.D == 3) {
     // lean FSM rollout loop: every shop with the same 1..6 customers and normaliser, a shop's customers act all or none per stage
     int Ku = der.shop_cust_ptr.size() > 1 ? der.shop_cust_ptr[1] - der.shop_cust_ptr[0] : -1;
@@ -585,6 +586,57 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     }
     for (size_t i = 0; i < der.sc_shop_flags.size(); ++i) ok = ok && (!(der.sc_shop_flags[i] & 2) || (der.sc_shop_flags[i] & 4));
     if (ok && Ku >= 1 && Ku <= 6 && der.shop_norm[0] > 0) { d.fsm_lean_K = Ku; d.fsm_lean_norm = der.shop_norm[0]; }
+    // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): additionally the stage's flags are the same for every shop, the
+    // env has no samplers, and along the handler-less chain from the initial stage every lookback the kernel serves from
+    // its tiles is at most PHX_FSM_LB steps.  The table holds, per episode position, the flags, the lookbacks and the stage.
+    memset(&d.fsm_fast, 0, sizeof d.fsm_fast);
+    bool fok = d.fsm_lean_K > 0 && spec->n_samplers == 0 && d.num_steps >= PHX_FAST_TC && d.num_steps <= 4096 && d.n_lists <= 255;
+    for (int l = 0; l < d.n_lists && fok; ++l)
+      for (int s2 = 1; s2 < d.S; ++s2) fok = fok && der.sc_shop_flags[(size_t)l * d.S + s2] == der.sc_shop_flags[(size_t)l * d.S];
+    if (fok) {
+      const int ns = d.num_steps, LB = PHX_FSM_LB;
+      std::vector<int> stage(ns), fl(ns);
+      int sg = spec->initial_stage;
+      for (int p = 0; p < ns; ++p) {
+        if (sg < 0 || sg >= d.n_lists) { fok = false; break; }
+        stage[p] = sg; fl[p] = der.sc_shop_flags[(size_t)sg * d.S];
+        sg = spec->stage_next[sg];
+      }
+      fsm_tab.assign(fok ? ns : 0, 0);
+      auto back_in_episode = [&](int p, int bit) { for (int k = 0; k <= p; ++k) if (fl[p - k] & bit) return k; return -1; };
+      auto back_cyclic = [&](int p, int bit, bool* same_episode) {
+        for (int k = 0; k <= LB; ++k) { const int q = p - k; if (fl[((q % ns) + ns) % ns] & bit) { *same_episode = q >= 0; return k; } }
+        *same_episode = false; return -1;
+      };
+      for (int p = 0; p < ns && fok; ++p) {
+        const int f = fl[p];
+        uint32_t w = (uint32_t)((f & 1) | ((f & 2) ? 2 : 0) | ((f & 8) ? 4 : 0) | ((f & 16) ? 8 : 0));
+        const bool emits = (f & 8) || p == ns - 1;               // the shop observes, or the episode ends: a reward is emitted
+        const int lr = back_in_episode(p, 16), lo = back_in_episode(p, 8);
+        if (emits && lr > LB) fok = false;
+        if (p == ns - 1 && lo != 0) fok = false;                   // the episode's last step observes (no dump of an older observation)
+        w |= (uint32_t)((lr < 0 || lr > LB) ? 7 : lr) << 4;
+        w |= (uint32_t)((lo < 0 || lo > LB) ? 7 : lo) << 8;
+        bool se = false, dummy = false;
+        const int cr = back_cyclic(p, 16, &se), co = back_cyclic(p, 8, &dummy), ca = back_cyclic(p, 1, &dummy);
+        if (cr < 0 || co < 0 || ca < 0) fok = false;               // the state left behind must be in reach from every position
+        w |= (uint32_t)(cr < 0 ? 7 : cr) << 12; w |= (uint32_t)(se ? 1 : 0) << 15;
+        w |= (uint32_t)(co < 0 ? 7 : co) << 16; w |= (uint32_t)(ca < 0 ? 7 : ca) << 20;
+        w |= (uint32_t)stage[p] << 24;
+        fsm_tab[p] = w;
+      }
+      ScFastPlan plan;
+      if (fok && phx_sc_fast_plan(d.B, d.S, d.fsm_lean_K, true, d.num_steps, &plan)) { plan.norm = d.fsm_lean_norm; d.fsm_fast = plan; }
+    }
+  }
+  d.fsm_pos_tab = nullptr; d.fsm_irregular = nullptr;
+  if (d.fsm_fast.ok) {
+    rc = upload(e, fsm_tab.data(), fsm_tab.size(), &d.fsm_pos_tab);
+    if (rc != PHX_OK) { phx_destroy(e); return rc; }
+    const int32_t zero = 0; const int32_t* flag = nullptr;
+    rc = upload(e, &zero, 1, &flag);
+    if (rc != PHX_OK) { phx_destroy(e); return rc; }
+    d.fsm_irregular = (int32_t*)flag;
   }
   if (der.sc_static && spec->env_type == PHX_ENV_PLAIN && !der.any_typed && d.S > 0) {
     // fast rollout kernel (phx_sc_rollout.hip): every shop with the same 1..6 customers and the same normaliser

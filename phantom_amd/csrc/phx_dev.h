@@ -39,6 +39,7 @@ enum {
 };
 
 // block shape and constant-table offsets of the round-2 supply-chain rollout kernel (phx_sc_rollout.hip)
+#define PHX_FSM_LB 3            // lookback (steps) the time-parallel FSM rollout serves from its tiles
 #define PHX_FAST_TC 20          // steps per chunk (one Philox block serves 4 ticks: 5 row quads)
 struct ScFastPlan {
   int32_t ok, epb, G, K, nt, norm, whole_envs;
@@ -90,6 +91,9 @@ struct DevSpec {
   int32_t max_cust;              // max customers of one shop
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
+  ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)
+  const uint32_t* fsm_pos_tab;   // [num_steps] flags / lookbacks / stage of every episode position (layout: phx_sc_rollout_fsm.hip)
+  int32_t* fsm_irregular;        // device word the launch uses to send envs off the tabulated stage chain to the general loop
   // host-built lookup tables of the rollout kernel (exactly the values the formulas give):
   //   [0,101) f32 stock/100 ; [101, 101+n_tabn) f32 x/norm, n_quot valid entries (0 unless
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)

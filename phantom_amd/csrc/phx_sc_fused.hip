@@ -15,6 +15,7 @@
 // shop's inbox -- is staged through LDS from 16-byte coalesced loads of the exo rows.
 // Results are bit-identical to the generic engine (tests/test_gpu_parity.py).
 #include "phx_dev.h"
+#include "phx_sc_fast.h"
 
 #ifndef PHX_STEP_REMAP
 #define PHX_STEP_REMAP 1     // XCD-aware env mapping: SC256-FSM B=8192 step 12.0 -> 10.9 us, SC64 B=65536 13.3 -> 12.7 us, neutral at B=4096 (graph replay)
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
 // LDS tables (computed at setup: exactly the f32 quotients), stores through scalar row bases + 32-bit lane offsets.
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                        const int epb, const int remap, const uint32_t pK,
-                                                                       const float inv_pK, const int wide) {
+                                                                       const float inv_pK, const int wide, const int32_t* only_if, const int32_t gen) {
+  if (only_if && *only_if != gen) return;   // the time-parallel kernel took this launch (phx_sc_rollout_fsm.hip)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int nS = sp.S, nL = sp.n_lists, K = sp.fsm_lean_K;
   float* s_tabs = (float*)s_raw;                           // [101] stock / 100
@@ -801,8 +803,15 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
   const int epb = SC_NT / sp.S;
   static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
   const int remap = remap_env >= 0 ? remap_env : 1;
+  // time-parallel kernel first where its plan applies; the lane-per-pair loop below then runs only if that kernel found
+  // an env off the tabulated stage chain (a stage a handler or the caller set) and left the launch alone
+  const int32_t* only_if = nullptr; int32_t gen = 0;
+  if (sp.fsm_fast.ok && sp.fsm_lean_K > 0) {
+    hipError_t fe = hipSuccess;
+    if (phx_launch_sc_rollout_fsmfast(sp, io, st, &fe, &gen)) { if (fe != hipSuccess) return fe; only_if = sp.fsm_irregular; }
+  }
   static const int lean_env = getenv("PHX_FSM_LEAN") ? atoi(getenv("PHX_FSM_LEAN")) : 1;
-  if (lean_env && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
+  if ((lean_env || only_if) && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
     uint32_t pk = 1; for (int k = 0; k < sp.fsm_lean_K; ++k) pk *= 5u;
     static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
     // blocks that start on multiples of 4 pairs (16-byte aligned observation rows): whole envs, a multiple of 4 of them
@@ -816,7 +825,7 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (((size_t)sp.n_lists + 3) & ~(size_t)3) * 4 +
                        (SC_NT / 64) * 192 * 4 + 16;
     hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3((sp.B + epb_l - 1) / epb_l), dim3(SC_NT), lds, st, sp, io, epb_l, remap,
-                       pk, inv[sp.fsm_lean_K], wide);
+                       pk, inv[sp.fsm_lean_K], wide, only_if, gen);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),

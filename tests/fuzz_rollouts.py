@@ -2,9 +2,12 @@
 -- whole-env and pair-range blocks of the time-parallel kernel, its round-1 fallback for ragged shops, the lean and the general
 FSM loop -- and the Stackelberg market) against the CPU oracle, bit-exact, on shapes and fragment lengths drawn from a seed.
 Used by tests/test_gpu_fuzz.py; `python tests/fuzz_rollouts.py LO HI` runs a sweep by hand."""
+import os
 import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from helpers import f32_bits, market_env, supply_chain_env
 from oracle import OracleEnv

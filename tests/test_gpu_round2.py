@@ -352,8 +352,9 @@ def test_fast_rollout_kernel_edge_cases_match_oracle(S, K, B, num_steps):
 
 @pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (51, 4, 16, 100), (3, 2, 48, 7), (5, 1, 40, 33)])
 def test_fsm_lean_rollout_loop_edge_cases_match_oracle(S, K, B, num_steps):
-    """device-RNG rollouts of FSM supply chains whose shops all have the same 1..6 customers (the lean loop of
-    phx_sc_fused.hip; PHX_FSM_LEAN=0 selects the general one): fragments starting on ticks that are no multiple of 4 and in
+    """device-RNG rollouts of FSM supply chains whose shops all have the same 1..6 customers (at these sizes the time-parallel
+    kernel of phx_sc_rollout_fsm.hip; PHX_FSM_FAST=0: the lean loop of phx_sc_fused.hip; PHX_FSM_LEAN=0: the general one):
+    fragments starting on ticks that are no multiple of 4 and in
     either stage, several episode ends per fragment, caches carried across launches, stocks poked outside [0, 100] (the
     observation tables do not cover them), hand-over to per-step launches."""
     env = supply_chain_env(S, [K] * S, num_steps, B, fsm=True, seed=5 + S, env_offset=77)
@@ -375,6 +376,16 @@ def test_fsm_lean_rollout_loop_edge_cases_match_oracle(S, K, B, num_steps):
     for T in (12, 5):
         ro, rd = o.rollout(T), d.rollout(T)
         _cmp_rollout(rd, ro, True)
+    # envs pushed off the handler-less stage chain (a stage a handler or the caller chose): the time-parallel kernel's
+    # position table does not describe them, its check sends the launch to the lane-per-pair loop
+    stg = o.get_i32("env.stage").copy()
+    stg[::2] = 1 - stg[::2]
+    o.set_i32("env.stage", stg); d.set_i32("env.stage", stg)
+    for T in (9, 30):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, True)
+        for f in fields:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after an off-chain stage, T={T}")
     a = rng.uniform(0, 100, (B, S)).astype(np.float32)
     o.step(a, None, None); d.step(a, None, None)
     np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
