@@ -45,13 +45,28 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """Compile every translation unit (in parallel: the kernels are independent files) and link the library."""
     if not force and not needs_build():
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    cc = hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="phx_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            cmd = [cc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [cc] + [f"--offload-arch={a}" for a in ARCHS] + ["-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     with open(ARCH_FILE, "w") as f:
         f.write(";".join(ARCHS) + "\n")
     return LIB
