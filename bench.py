@@ -7,13 +7,20 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one PhantomEnv.step() of every env instance of the batch.  The timed region runs the
-K-step region R times back to back (R chosen so that it lasts >= 50 ms; printed as "repeats") as
+K-step region R times back to back (R chosen so that it lasts >= 1 s; printed as "repeats") as
 fused on-device rollouts (phx_rollout, T=100 = one episode per launch; every step's observation,
 action, reward and done flags are written to the trajectory buffer in HBM) with inputs/state
 already resident in HBM, bracketed by barrier + synchronize, max over ranks.
 value = A * B_total * R * K / time  (agent-steps/s, whole job); ms_per_step = time / (R * K).
-`--gpus N` without a torchrun environment re-executes itself under torch.distributed.run.  The per-launch PhantomEnv.step
-mode (one kernel per step) is measured right after and reported under "per_step".
+The launches rotate over >= 4 trajectory buffers (> 256 MB in total, more than the Infinity Cache holds) so that the
+written bytes really reach HBM.  `--gpus N` without a torchrun environment re-executes itself under
+torch.distributed.run.  The per-launch PhantomEnv.step mode (one kernel per step) is measured right after and
+reported under "per_step".
+
+Multi-rank runs cannot fail silently: barrier / max-over-ranks go over a gloo control group (the step path has no
+collective, so `value` does not depend on RCCL at all), RCCL is brought up only for the rollout-collection
+sections, and a watchdog thread plus SIGTERM / exception handlers make rank 0 print the JSON line with whatever
+was measured, `rccl_ranks_seen` and an `error` field when a stage hangs, RCCL fails or the launcher tears the job down.
 
 Extra objects on the JSON line:
   roofline      dominant kernel (phx_sc_rollout_kernel): algorithmic HBM bytes per launch /
@@ -24,8 +31,17 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import signal
 import sys
 import time
+
+# SIGTERM is blocked before any library creates a thread (numpy's BLAS pool, torch): rank 0 takes it in a dedicated
+# sigwait thread (class Watch) so that the JSON line is printed even while the main thread is blocked in a C call.
+if __name__ == "__main__":
+    try:
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+    except (AttributeError, ValueError, OSError):
+        pass
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -82,7 +98,23 @@ def cpu_baseline(budget_s=12.0):
     return {"value": multi, "unit": "agent-steps/s", "cores": threads, "kind": "port",
             "sample": f"SC64, {Bn} envs x {Tn} steps on {threads} threads ({dtn:.1f} s); "
                       f"single core: {B} envs x {T1} steps ({dt1:.1f} s)",
-            "single_core_value": single, "host_cpu_count": cores}
+            "single_core_value": single, "host_cpu_count": cores, "nproc": cores, "cpu_model": cpu_model(),
+            # the reference's own Python PhantomEnv (SupplyChain agent classes, synthetic SC64) cannot
+            # travel to this box; measured once in the build container on 1 core of an 8-vCPU host
+            "interpreted_reference": {"env_steps_per_sec": 1060.0, "agent_steps_per_sec": 6.8e4, "cores": 1,
+                                      "where": "build container (NOT this box), reference Python PhantomEnv imported from "
+                                               "/root/reference, SURVEY section 6 / BASELINE.md section 2"}}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def other_configs(device):
@@ -186,16 +218,94 @@ def _free_port():
         return so.getsockname()[1]
 
 
-def self_spawn(n, argv):
+def self_spawn(n, argv, watchdog_s):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: re-exec this script under
-    torch.distributed.run, one rank per GPU over RCCL, and pass its output (rank 0's JSON line) through."""
+    torch.distributed.run, one rank per GPU over RCCL, and pass its output (rank 0's JSON line) through.
+    If the children die or hang without a JSON line, the parent prints the error line itself."""
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    raise SystemExit(subprocess.call(cmd, env=env))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    err = None
+    try:
+        out, _ = proc.communicate(timeout=watchdog_s + 120)
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group started above
+        except OSError:
+            pass
+        out, _ = proc.communicate()
+        err = f"launcher watchdog: no exit after {watchdog_s + 120:.0f} s"
+    sys.stdout.write(out or "")
+    has_line = any(l.startswith("{") and '"metric"' in l for l in (out or "").splitlines())
+    if not has_line:
+        print(json.dumps(error_line(n, err or f"ranks exited with code {proc.returncode} without a result line",
+                                    stage="self_spawn")), flush=True)
+    raise SystemExit(proc.returncode if proc.returncode is not None else 1)
+
+
+def error_line(n_gpus, error, stage=None, partial=None):
+    """the JSON line of a run that failed: same keys, value null (or what was measured before the failure)."""
+    out = {"metric": "agent_steps_per_sec", "value": None, "unit": "agent-steps/s", "n_gpus": n_gpus,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+           "rccl_ranks_seen": 0}
+    out.update(partial or {})
+    out["error"] = str(error)[:2000]
+    if stage is not None:
+        out["failed_stage"] = stage
+    return out
+
+
+class Watch:
+    """Rank 0's guarantee of ONE JSON line: `line` accumulates what has been measured; a failure (exception, a stage
+    over its deadline, SIGTERM from the launcher because another rank died) prints it with an `error` field."""
+
+    def __init__(self, n_gpus, rank, total_s):
+        import threading
+        self.n_gpus, self.rank, self.line = n_gpus, rank, {}
+        self.stage_name, self.deadline, self.total_deadline = "start", None, time.monotonic() + total_s
+        self.lock, self.printed = threading.Lock(), False
+        # SIGTERM (torchrun tears the job down when another rank dies) is taken by a dedicated sigwait thread: a Python
+        # signal handler would only run once the main thread returns from whatever C call it is blocked in (a gloo
+        # rendezvous, a device synchronize) -- i.e. possibly never before the launcher's SIGKILL.  The mask is set
+        # before any other thread exists, so every later thread (torch, gloo, RCCL) inherits it.
+        try:
+            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+            threading.Thread(target=self._wait_term, daemon=True).start()
+        except (AttributeError, ValueError, OSError):
+            pass
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def _wait_term(self):
+        signal.sigwait({signal.SIGTERM})
+        self.emit("SIGTERM from the launcher (another rank failed or the job was torn down)")
+        os._exit(143)
+
+    def stage(self, name, seconds):
+        self.stage_name, self.deadline = name, time.monotonic() + seconds
+
+    def emit(self, error=None):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+        if self.rank == 0:
+            line = self.line if error is None else error_line(self.n_gpus, error, self.stage_name, self.line)
+            print(json.dumps(line), flush=True)
+        elif error is not None:
+            print(f"[bench rank {self.rank}] {error} (stage {self.stage_name})", file=sys.stderr, flush=True)
+
+    def _run(self):
+        while not self.printed:
+            time.sleep(0.5)
+            now = time.monotonic()
+            if (self.deadline is not None and now > self.deadline) or now > self.total_deadline:
+                self.emit(f"watchdog: stage '{self.stage_name}' exceeded its deadline (hang in a collective, RCCL init or a kernel)")
+                os._exit(4)
 
 
 def main():
@@ -205,8 +315,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="sc64")
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's)")
-    ap.add_argument("--min-region-ms", type=float, default=50.0,
+    ap.add_argument("--min-region-ms", type=float, default=1000.0,
                     help="the K-step region is repeated back to back until the timed region lasts at least this long")
+    ap.add_argument("--buffers", type=int, default=0,
+                    help="trajectory buffers the launches rotate over (default: enough for > 320 MB, at least 4)")
+    ap.add_argument("--watchdog-s", type=float, default=900.0, help="overall deadline; a JSON line with `error` is printed when it passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -215,26 +328,54 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_spawn(args.gpus, sys.argv[1:])
+        try:
+            signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM})     # the launcher keeps the default disposition
+        except (AttributeError, ValueError, OSError):
+            pass
+        self_spawn(args.gpus, sys.argv[1:], args.watchdog_s)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    watch = Watch(args.gpus, rank, args.watchdog_s)
+    try:
+        run(args, rank, local_rank, world, watch)
+    except SystemExit:
+        raise
+    except BaseException as exc:                     # noqa: BLE001 -- the line must appear whatever happened
+        import traceback
+        traceback.print_exc()
+        watch.emit(f"{type(exc).__name__}: {exc}")
+        os._exit(1)
+    watch.emit()
+    sys.stdout.flush()
+    os._exit(0)      # process-group / communicator destructors have nothing left to do and can hang when a peer is gone
+
+
+def run(args, rank, local_rank, world, watch):
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the PhantomEnv.step() path has no CPU fallback")
+        raise RuntimeError("bench.py needs a GPU: the PhantomEnv.step() path has no CPU fallback")
+    if os.environ.get("PHX_BENCH_SHARE_GPU"):
+        # test hook: several ranks on the GPUs that exist (RCCL then refuses the duplicate device -- the failure path
+        # of the data plane -- while `value` over the gloo control plane stays valid)
+        local_rank %= max(1, torch.cuda.device_count())
+    if local_rank >= torch.cuda.device_count():
+        raise RuntimeError(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PHX_BENCH_FORCE_DIST"):
-        # one process per GPU over RCCL (backend "nccl" on ROCm); also taken with a single rank
-        # (torchrun with one process, or PHX_BENCH_FORCE_DIST=1) so that the collective path can be
-        # exercised on a 1-GPU box
+        # one process per GPU.  CONTROL plane (barrier, max over ranks) = gloo on CPU tensors: the step path has no
+        # collective, so `value` must not depend on RCCL coming up.  DATA plane (rollout collection) = RCCL (backend
+        # "nccl" on ROCm), created below only for the sections that exchange trajectories.  Also taken with a single
+        # rank (torchrun with one process, or PHX_BENCH_FORCE_DIST=1) so the path is exercised on a 1-GPU box.
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        watch.stage("init_process_group(gloo)", 180)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=170))
 
     import phantom_amd as ph
     global N_SHOPS, CUST_PER_SHOP, N_AGENTS
@@ -242,7 +383,10 @@ def main():
     N_AGENTS = 1 + N_SHOPS + N_SHOPS * CUST_PER_SHOP
     B, S, K, W = args.batch or default_batch, N_SHOPS, args.steps, args.warmup
     if K < 1:
-        raise SystemExit("--steps must be >= 1")
+        raise RuntimeError("--steps must be >= 1")
+    watch.line.update({"metric": "agent_steps_per_sec", "value": None, "unit": "agent-steps/s", "n_gpus": world,
+                       "steps": K, "warmup": W, "rccl_ranks_seen": 0})
+    watch.stage("create env", 180)
     # one process per GPU owns envs [rank*B, (rank+1)*B); the RNG is keyed by the GLOBAL env
     # index so results do not depend on the number of GPUs.  No collective inside a step.
     env = ph.SupplyChainEnv(n_shops=N_SHOPS, customers_per_shop=CUST_PER_SHOP, num_steps=NUM_STEPS,
@@ -252,11 +396,20 @@ def main():
     assert dev.uses_fused, "bench expects the fused supply-chain kernels"
     env.reset()
     T = NUM_STEPS
-    traj = dev.rollout(T)                                   # allocates the trajectory buffers once
+    # The launches rotate over several trajectory buffers whose total exceeds the 256 MB Infinity Cache, so that
+    # every fragment's bytes are really written to HBM (one 82 MB buffer rewritten in place could live in the cache)
+    frag_bytes = algorithmic_bytes_rollout(B, S, T)
+    n_buf = args.buffers if args.buffers > 0 else max(4, -(-(320 << 20) // frag_bytes))
+    trajs = [dev.rollout(T) for _ in range(n_buf)]           # allocates the trajectory buffers once
+    traj = trajs[0]
+    rot = [0]
 
-    def launches(n):                                        # n full-length fragments, back to back
+    def launches(n, bufs=None):                             # n full-length fragments, back to back
+        bufs = bufs or trajs
+        k = rot[0]
         for _ in range(n):
-            dev.rollout(T, out=traj)
+            dev.rollout(T, out=bufs[k % len(bufs)]); k += 1
+        rot[0] = k
 
     def sync_barrier():
         torch.cuda.synchronize()
@@ -267,26 +420,29 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([x], dtype=torch.float64)          # CPU tensor: the gloo control group
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
     # The env steps as a continuous stream (auto-reset at every episode end), issued as fragments of T = 100
-    # steps per launch.  A K-step region shorter than ~50 ms would time launch + sync latency, not the path
-    # (K = 20 is ONE 8 us slice): the region is therefore repeated R times back to back, R the smallest
+    # steps per launch.  A K-step region shorter than ~1 s would time launch + sync latency, not the path
+    # (K = 20 is ONE 8 us slice) and the driver's GPU-busy sampler would see an idle chip: the region is therefore
+    # repeated R times back to back, R the smallest
     # count that makes R*K a whole number of fragments and the timed region >= --min-region-ms; the line
     # reports steps = K, repeats = R and ms_per_step = elapsed / (R*K).  Warm-up: W steps rounded up to whole
     # fragments (at least 20 fragments, which also calibrates R -- identically on every rank).
     import math
+    watch.stage("warm-up + calibration", 240)
     n_warm = max(20, -(-W // T))
     launches(n_warm)
     sync_barrier()
-    t0 = time.perf_counter(); launches(20); torch.cuda.synchronize()
-    per_launch = max_over_ranks((time.perf_counter() - t0) / 20)
+    t0 = time.perf_counter(); launches(200); torch.cuda.synchronize()
+    per_launch = max_over_ranks((time.perf_counter() - t0) / 200)
     unit = T // math.gcd(K, T)                              # repeats per whole number of fragments
-    R = max(1, math.ceil(1.15 * args.min_region_ms * 1e-3 / per_launch * T / K))   # 15 % margin: the calibration loop is short
+    R = max(1, math.ceil(1.05 * args.min_region_ms * 1e-3 / per_launch * T / K))
     R = -(-R // unit) * unit
     n_launch = R * K // T
+    watch.stage("timed region", 120 + 20 * args.min_region_ms * 1e-3)
     sync_barrier()
     t0 = time.perf_counter()
     launches(n_launch)
@@ -295,20 +451,46 @@ def main():
     sync_barrier()                           # ... all ranks are; the job's time is the MAX over ranks
     elapsed = max_over_ranks(elapsed)
     value = N_AGENTS * B * world * (R * K) / elapsed
+    out = watch.line
+    out.update({
+        "metric": "agent_steps_per_sec", "value": value, "unit": "agent-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / (R * K) * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32", "data": "synthetic",
+        "config": {"workload": f"supply-chain {args.config.upper()} (1 factory + {N_SHOPS} shops + "
+                               f"{N_SHOPS * CUST_PER_SHOP} customers = {N_AGENTS} agents), "
+                               f"batch {B} envs per GPU, random actions U[0,100), device-RNG orders, "
+                               "fused on-device rollout T=100 with full trajectory written to HBM",
+                   "agents": N_AGENTS, "envs_per_gpu": B, "global_envs": B * world,
+                   "num_steps": NUM_STEPS, "mode": "phx_rollout", "sharding": f"env-batch x{world}, no step-time collective",
+                   "trajectory_buffers": f"{n_buf} x {frag_bytes / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)"},
+        "repeats": R, "timed_steps": R * K, "timed_launches": n_launch, "timed_region_ms": elapsed * 1e3,
+        "warmup_launches": n_warm,
+        "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} fragments of {T} steps; "
+                       "ms_per_step = timed_region_ms / (repeats * steps)",
+        "env_steps_per_sec": B * world * (R * K) / elapsed,
+        "control_plane": "gloo" if dist is not None else None,
+    })
 
     # ---- kernel-level timing for the roofline (HIP events on the launch stream) -------------
     # ONE event pair around >= 200 full-length launches (independent of K), divided by their number: the
     # average launch duration as the stream sees it, which is what the rocprofv3 kernel trace in profiles/
     # averages too (an event pair per launch would add ~2 us of marker packets to each interval).
-    n_full = 200
-    launches(10)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    launches(n_full)
-    ev1.record()
-    torch.cuda.synchronize()
-    launch_ms = ev0.elapsed_time(ev1) / n_full
-    alg = algorithmic_bytes_rollout(B, S, T)
+    watch.stage("roofline loop", 240)
+
+    def event_ms(n, bufs=None):
+        launches(10, bufs)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        launches(n, bufs)
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / n
+
+    n_full = 400
+    launch_ms = event_ms(n_full)                              # rotating over the buffers: HBM
+    same_ms = event_ms(n_full, [traj])                        # one buffer rewritten in place (round 2's loop): may sit in the Infinity Cache
+    alg = frag_bytes
     achieved = alg / (launch_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -326,139 +508,190 @@ def main():
     try:
         if args.no_frag200:
             raise RuntimeError("skipped (--no-frag200)")
-        traj200 = dev.rollout(2 * T)
-        for _ in range(5):
-            dev.rollout(2 * T, out=traj200)
+        t200 = [dev.rollout(2 * T) for _ in range(max(2, n_buf // 2))]
+        for k in range(5):
+            dev.rollout(2 * T, out=t200[k % len(t200)])
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
-        for _ in range(100):
-            dev.rollout(2 * T, out=traj200)
+        for k in range(100):
+            dev.rollout(2 * T, out=t200[k % len(t200)])
         g1.record(); torch.cuda.synchronize()
         ms200 = g0.elapsed_time(g1) / 100
         alg200 = algorithmic_bytes_rollout(B, S, 2 * T)
         frag200 = {"T": 2 * T, "launch_ms": ms200, "achieved": alg200 / (ms200 * 1e-3) / 1e9,
-                   "frac": alg200 / (ms200 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        del traj200
+                   "frac": alg200 / (ms200 * 1e-3) / 1e9 / HBM_PEAK_GBS, "buffers": len(t200)}
+        del t200
         dev.rollout(T, out=traj)                 # back to the 100-step fragment's buffers
     except Exception as e:                       # report, do not hide
         frag200 = {"error": str(e)}
-    # achievable write bandwidth of this box for a buffer of the trajectory's size (a plain fill)
-    fill_buf = torch.empty(alg // 4, dtype=torch.float32, device=dev.device)
-    for _ in range(3):
-        fill_buf.fill_(1.0)
+    # achievable write bandwidth of this box for buffers of the trajectory's size (a plain fill, same rotation)
+    fills = [torch.empty(alg // 4, dtype=torch.float32, device=dev.device) for _ in range(n_buf)]
+    for f in fills:
+        f.fill_(1.0)
     torch.cuda.synchronize()
     f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     f0.record()
-    for _ in range(20):
-        fill_buf.fill_(1.0)
+    for k in range(40):
+        fills[k % n_buf].fill_(1.0)
     f1.record(); torch.cuda.synchronize()
-    fill_gbs = alg / (f0.elapsed_time(f1) / 20 * 1e-3) / 1e9
-    del fill_buf
-    roofline = {"bound": "hbm", "kernel": "phx_sc_rollout_fast_kernel", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg,
-                "launch_ms": launch_ms, "launches_timed": n_full, "launch": f"T={T} steps x B={B} envs",
-                "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs,
-                "two_episodes_per_launch": frag200}
-
-    out = {
-        "metric": "agent_steps_per_sec", "value": value, "unit": "agent-steps/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / (R * K) * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "i32", "data": "synthetic",
-        "config": {"workload": f"supply-chain {args.config.upper()} (1 factory + {N_SHOPS} shops + "
-                               f"{N_SHOPS * CUST_PER_SHOP} customers = {N_AGENTS} agents), "
-                               f"batch {B} envs per GPU, random actions U[0,100), device-RNG orders, "
-                               "fused on-device rollout T=100 with full trajectory written to HBM",
-                   "agents": N_AGENTS, "envs_per_gpu": B, "global_envs": B * world,
-                   "num_steps": NUM_STEPS, "mode": "phx_rollout", "sharding": f"env-batch x{world}, no step-time collective"},
-        "repeats": R, "timed_steps": R * K, "timed_launches": n_launch, "timed_region_ms": elapsed * 1e3,
-        "warmup_launches": n_warm,
-        "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} fragments of {T} steps; "
-                       "ms_per_step = timed_region_ms / (repeats * steps)",
-        "env_steps_per_sec": B * world * (R * K) / elapsed,
-        "rccl_ranks_seen": (dist.get_world_size() if dist is not None else 0),
-        "roofline": roofline,
-    }
+    fill_gbs = alg / (f0.elapsed_time(f1) / 40 * 1e-3) / 1e9
+    del fills
+    out["roofline"] = {"bound": "hbm", "kernel": "phx_sc_rollout_fast_kernel", "achieved": achieved,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg,
+                       "launch_ms": launch_ms, "launches_timed": n_full, "launch": f"T={T} steps x B={B} envs",
+                       "buffers_rotated": n_buf,
+                       "same_buffer": {"launch_ms": same_ms, "frac": alg / (same_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "note": "every launch rewrites ONE 82 MB buffer (fits the 256 MB Infinity Cache): not the HBM figure"},
+                       "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs,
+                       "two_episodes_per_launch": frag200}
 
     # ---- per-launch PhantomEnv.step mode (one kernel launch per step) ---------------------------
     if not args.no_per_step:
-        ksteps = 1000
-        acts = torch.rand(ksteps, B, S, device=dev.device) * 100.0
-        env.reset()
-        for i in range(20):
-            dev.step(acts[i % ksteps])
-        sync_barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter(); e0.record()
-        for i in range(ksteps):
-            dev.step(acts[i])
-        e1.record()
-        sync_barrier()
-        dt = time.perf_counter() - t0
-        # kernel-only duration: the tight loop above is host bound, so the kernel time is taken from a
-        # second pass with per-launch events
-        evs = []
-        for i in range(200):
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); dev.step(acts[i % ksteps]); b_.record(); evs.append((a, b_))
-        torch.cuda.synchronize()
-        kms = float(np.median([a.elapsed_time(b_) for a, b_ in evs]))
-        alg_s = algorithmic_bytes_step(B, S, CUST_PER_SHOP, device_rng=True)
-        # the same per-step launches captured once into a hipGraph (DeviceEnv.step_graph: 100 steps per replay)
-        graph_us = None
+        watch.stage("per-step mode", 300)
         try:
-            sg = dev.step_graph(acts[:100])
-            for _ in range(3):
-                sg.replay()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(20):
-                sg.replay()
-            torch.cuda.synchronize()
-            graph_us = (time.perf_counter() - tg) / 2000 * 1e6
-        except Exception as e:                                   # report, do not hide
-            graph_us = f"capture failed: {e}"
-        out["per_step"] = {"value": N_AGENTS * B * world * ksteps / dt, "unit": "agent-steps/s",
-                           "steps": ksteps, "ms_per_step_wall": dt / ksteps * 1e3,
-                           "event_ms_per_launch": kms,
-                           "hipgraph_us_per_step": graph_us,
-                           "roofline": {"bound": "hbm", "kernel": "phx_sc_step_kernel",
-                                        "achieved": alg_s / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": alg_s / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "algorithmic_bytes_per_launch": alg_s,
-                                        "note": "event interval includes launch gaps; B=4096 is latency-bound"}}
+            out["per_step"] = bench_per_step(env, dev, B, S, world, sync_barrier)
+        except Exception as e:                   # report, do not hide
+            out["per_step"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- rollout collection exchange (BASELINE config 4's RCCL all-gather), outside `value` ------
     if dist is not None:
-        out["rollout_allgather"] = bench_collection(dist, dev, traj, T, B, world, rank, sync_barrier,
-                                                    max_over_ranks, N_AGENTS)
-        if args.config == "sc64":
-            # BASELINE config 4, one GPU's share: SC256 (1 + 51 + 204), B = 8192 per GPU, plain env, T = 100 fused
-            # rollouts; throughput with the trajectory all-gather excluded and included
-            del traj
-            torch.cuda.empty_cache()
-            out["config4_share"] = bench_config4(ph, dist, world, rank, local_rank, sync_barrier, max_over_ranks)
+        watch.stage("RCCL init (data plane)", 240)
+        nccl = None
+        try:
+            import datetime
+            nccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=600))
+            one = torch.ones(1, device=dev.device)
+            dist.all_reduce(one, group=nccl)
+            torch.cuda.synchronize()
+            out["rccl_ranks_seen"] = int(one.item())
+            out["rccl_env"] = {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_P2P_DISABLE", "HSA_ENABLE_IPC_MODE_LEGACY")
+                               if k in os.environ}
+        except Exception as e:
+            out["rccl_error"] = f"{type(e).__name__}: {e}"[:1500]
+            out["error"] = "RCCL did not come up: `value` (control plane over gloo) is valid, the rollout-collection sections were skipped"
+            nccl = None
+        if nccl is not None:
+            watch.stage("rollout_allgather", 300)
+            try:
+                out["rollout_allgather"] = bench_collection(dist, nccl, dev, traj, T, B, world, rank, sync_barrier,
+                                                            max_over_ranks, N_AGENTS)
+            except Exception as e:
+                out["rollout_allgather"] = {"error": f"{type(e).__name__}: {e}"[:1500]}
+                out["error"] = "rollout_allgather failed (see that section); `value` is valid"
+            if args.config == "sc64":
+                # BASELINE config 4, one GPU's share: SC256 (1 + 51 + 204), B = 8192 per GPU, plain env, T = 100 fused
+                # rollouts; throughput with the trajectory all-gather excluded and included
+                watch.stage("config4_share", 420)
+                del trajs[:]
+                traj = None
+                torch.cuda.empty_cache()
+                try:
+                    out["config4_share"] = bench_config4(ph, dist, nccl, world, rank, local_rank, sync_barrier, max_over_ranks)
+                except Exception as e:
+                    out["config4_share"] = {"error": f"{type(e).__name__}: {e}"[:1500]}
+                    out["error"] = "config4_share failed (see that section); `value` is valid"
 
     # ---- BASELINE.json configs 3-5 on this GPU (parity-test cases; reported for orientation only) ------
     if rank == 0 and world == 1 and args.config == "sc64" and not args.no_other_configs:
+        watch.stage("other configs", 420)
+        del trajs[:]
         traj = None
         torch.cuda.empty_cache()
-        out["other_configs"] = other_configs(f"cuda:{local_rank}")
+        try:
+            out["other_configs"] = other_configs(f"cuda:{local_rank}")
+        except Exception as e:
+            out["other_configs"] = {"error": f"{type(e).__name__}: {e}"[:1500]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        watch.stage("cpu baseline", 300)
         out["cpu_baseline"] = cpu_baseline()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    watch.stage("done", 60)
 
 
-def bench_collection(dist, dev, traj, T, B, world, rank, sync_barrier, max_over_ranks, n_agents):
+def bench_per_step(env, dev, B, S, world, sync_barrier):
+    ksteps = 1000
+    acts = torch.rand(ksteps, B, S, device=dev.device) * 100.0
+    env.reset()
+    for i in range(20):
+        dev.step(acts[i % ksteps])
+    sync_barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for i in range(ksteps):
+        dev.step(acts[i])
+    e1.record()
+    sync_barrier()
+    dt = time.perf_counter() - t0
+    # kernel-only duration: the tight loop above is host bound, so the kernel time is taken from a
+    # second pass with per-launch events
+    evs = []
+    for i in range(200):
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); dev.step(acts[i % ksteps]); b_.record(); evs.append((a, b_))
+    torch.cuda.synchronize()
+    kms = float(np.median([a.elapsed_time(b_) for a, b_ in evs]))
+    alg_s = algorithmic_bytes_step(B, S, CUST_PER_SHOP, device_rng=True)
+    # the same per-step launches captured once into a hipGraph (DeviceEnv.step_graph: 100 steps per replay)
+    graph_us = None
+    try:
+        sg = dev.step_graph(acts[:100])
+        for _ in range(3):
+            sg.replay()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(20):
+            sg.replay()
+        torch.cuda.synchronize()
+        graph_us = (time.perf_counter() - tg) / 2000 * 1e6
+    except Exception as e:                                   # report, do not hide
+        graph_us = f"capture failed: {e}"
+    res = {"value": N_AGENTS * B * world * ksteps / dt, "unit": "agent-steps/s",
+           "steps": ksteps, "ms_per_step_wall": dt / ksteps * 1e3,
+           "event_ms_per_launch": kms,
+           "hipgraph_us_per_step": graph_us,
+           "roofline": {"bound": "hbm", "kernel": "phx_sc_step_kernel",
+                        "achieved": alg_s / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg_s / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_s,
+                        "note": "event interval includes launch gaps; B=4096 is latency-bound"}}
+    try:
+        res["rllib_adapter"] = bench_rllib_adapter(env, B, S)
+    except Exception as e:                                   # report, do not hide
+        res["rllib_adapter"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+    return res
+
+
+def bench_rllib_adapter(env, B, S):
+    """the RLlib-facing vector-env path (phantom_amd/rllib.py): poll() + send_actions() per step at full batch,
+    with RLlib's MultiEnvDict signature and with the tensor fast path."""
+    from phantom_amd.rllib import BatchedBaseEnv
+    if not hasattr(BatchedBaseEnv, "send_action_tensor"):
+        return {"error": "adapter without the tensor fast path"}
+    be = BatchedBaseEnv(env)
+    res = {"envs": B}
+    acts = torch.rand(B, S, device=env._device().device) * 100.0
+    for mode, n in (("tensor", 50), ("multi_env_dict", 5)):
+        be.try_reset_all() if hasattr(be, "try_reset_all") else None
+        obs = be.poll()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            if mode == "tensor":
+                be.send_action_tensor(acts)
+            else:
+                be.send_actions(be.random_action_dict(obs[0]))
+            obs = be.poll()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        res[mode] = {"ms_per_step": dt * 1e3, "agent_steps_per_sec": N_AGENTS * B / dt, "steps": n}
+    return res
+
+
+def bench_collection(dist, group, dev, traj, T, B, world, rank, sync_barrier, max_over_ranks, n_agents):
     """rollout collection of one T-step fragment: ONE flat RCCL all-gather (payload without the
     all-zero `terminated` plane, `truncated` bit-packed), and the produce + collect pipeline."""
     from phantom_amd.distributed import TrajectoryGather, device_env_collector
-    tg = TrajectoryGather(dev, T)                          # one flat buffer; the gathered payload is its prefix
+    tg = TrajectoryGather(dev, T, group=group)             # one flat buffer; the gathered payload is its prefix
     dev.rollout(T, out=tg.traj)
     tg.gather(); sync_barrier()
     reps = 5
@@ -475,7 +708,7 @@ def bench_collection(dist, dev, traj, T, B, world, rank, sync_barrier, max_over_
            "payload": tg.describe(),
            "note": "one T=100 fragment, one all_gather_into_tensor over RCCL; not in `value`"}
     # produce + collect, pipelined: chunk c is gathered on a side stream while chunk c+1 rolls out
-    col = device_env_collector(dev, T)                     # chunking by bytes (auto_chunk)
+    col = device_env_collector(dev, T, group=group)        # chunking by bytes (auto_chunk)
     col.collect(); sync_barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -488,7 +721,7 @@ def bench_collection(dist, dev, traj, T, B, world, rank, sync_barrier, max_over_
     return res
 
 
-def bench_config4(ph, dist, world, rank, local_rank, sync_barrier, max_over_ranks):
+def bench_config4(ph, dist, group, world, rank, local_rank, sync_barrier, max_over_ranks):
     from phantom_amd.distributed import device_env_collector
     nS, nK, Bc, T = 51, 4, 8192, 100
     A = 1 + nS + nS * nK
@@ -511,7 +744,7 @@ def bench_config4(ph, dist, world, rank, local_rank, sync_barrier, max_over_rank
            "agent_steps_per_sec_gather_excluded": A * Bc * world * T / dt}
     del tr
     torch.cuda.empty_cache()
-    col = device_env_collector(dev, T, chunk=10)           # 10-step chunks (~92 MB per rank), SURVEY 8e (i)
+    col = device_env_collector(dev, T, chunk=10, group=group)   # 10-step chunks (~92 MB per rank), SURVEY 8e (i)
     col.collect(); sync_barrier()
     t0 = time.perf_counter()
     for _ in range(3):

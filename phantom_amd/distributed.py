@@ -42,28 +42,96 @@ def make_sharded_env(env_cls, global_batch: int, *args, seed: int = 0, **kwargs)
     return env_cls(*args, batch_size=sh.local_batch, seed=seed, env_offset=sh.env_offset, **kwargs), sh
 
 
-def all_gather_trajectory(traj, group=None, out=None):
-    """Gather a rollout fragment from every rank.
+def _staging_mode(tensor, group=None, staging: str = "auto") -> str:
+    """"device": the collective takes device tensors (RCCL, backend "nccl"); "host": device tensors are staged
+    through pinned host memory around a CPU collective (backend "gloo": two ranks that share ONE GPU -- RCCL
+    refuses several ranks per device -- or a box without a working RCCL); CPU tensors always go as they are."""
+    import torch.distributed as dist
+    if staging not in ("auto", "device", "host"):
+        raise ValueError(f"staging must be 'auto', 'device' or 'host', not {staging!r}")
+    if not tensor.is_cuda:
+        return "device"                                  # nothing to stage
+    if staging != "auto":
+        return staging
+    return "host" if dist.is_initialized() and dist.get_backend(group) == "gloo" else "device"
 
-    ``traj`` is a tuple of time-major tensors [T, B_local, ...] (device.Trajectory or any tuple).
-    Returns a tuple of tensors [world, T, B_local, ...]: the consumer indexes shards instead of
-    paying for a transpose to [T, B_global, ...] (global env = shard * B_local + local env).
-    Collectives are issued back to back on the caller's stream; RCCL picks ring vs. direct.
-    """
+
+class HostStage:
+    """Pinned host mirror of (send, gathered) byte buffers for host-staged collectives; allocated once."""
+
+    def __init__(self, nbytes: int, world: int):
+        import torch
+        self.send = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.recv = torch.empty(world * nbytes, dtype=torch.uint8, pin_memory=True)
+
+
+def all_gather_bytes(out, send, group=None, staging: str = "auto", stage: Optional[HostStage] = None):
+    """ONE all-gather of the byte buffer ``send`` [n] into ``out`` [world, n] (or [world * n]) on the current stream.
+
+    world 1: a copy.  Device staging: ``all_gather_into_tensor`` straight on the device buffers (RCCL over xGMI).
+    Host staging (see _staging_mode): D2H into pinned memory, the CPU collective, H2D -- the current stream is
+    synchronised from the host in between, so this path is for correctness runs, not for speed."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    outs = []
-    for k, x in enumerate(traj):
-        x = x.contiguous()
-        o = out[k] if out is not None else torch.empty((world,) + tuple(x.shape), dtype=x.dtype,
-                                                      device=x.device)
-        if world == 1:
-            o[0].copy_(x)
-        else:
-            dist.all_gather_into_tensor(o.view(world * x.shape[0], *x.shape[1:]), x, group=group)
-        outs.append(o)
-    return tuple(outs)
+    flat_out = out.view(-1)
+    if world == 1:
+        flat_out.copy_(send, non_blocking=True)
+        return out
+    if _staging_mode(send, group, staging) == "device":
+        dist.all_gather_into_tensor(flat_out, send, group=group)
+        return out
+    n = send.numel()
+    if stage is None or stage.send.numel() != n or stage.recv.numel() != world * n:
+        stage = HostStage(n, world)
+    stage.send.copy_(send, non_blocking=True)
+    torch.cuda.current_stream(send.device).synchronize()
+    dist.all_gather_into_tensor(stage.recv, stage.send, group=group)
+    flat_out.copy_(stage.recv, non_blocking=True)
+    torch.cuda.current_stream(send.device).synchronize()          # the pinned buffer may be reused right away
+    return out
+
+
+def all_gather_trajectory(traj, group=None, out=None, staging: str = "auto"):
+    """Gather a rollout fragment from every rank with ONE flat collective.
+
+    ``traj`` is a tuple of time-major tensors [T, B_local, ...] (device.Trajectory fields or any tuple; None
+    entries are skipped).  The fields are packed back to back (256-byte aligned sections) into one send buffer,
+    gathered with a single all_gather_into_tensor, and returned as views [world, T, B_local, ...] of the
+    gathered buffer: the consumer indexes shards instead of paying for a transpose to [T, B_global, ...]
+    (global env = shard * B_local + local env).  ``out``: a uint8 buffer [world, nbytes] from a previous call
+    (``result.flat``) to gather into.  For fragments that are produced for collection prefer
+    ``TrajectoryGather``: its fragment already lives in the send buffer (no packing copy) and the done flags
+    travel bit-packed."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    fields = [x.contiguous() for x in traj if x is not None]
+    offs, total = [], 0
+    for x in fields:
+        offs.append(total)
+        total += (x.numel() * x.element_size() + 255) & ~255
+    dev = fields[0].device
+    send = torch.empty(total, dtype=torch.uint8, device=dev)
+    for o, x in zip(offs, fields):
+        send[o:o + x.numel() * x.element_size()].copy_(x.view(-1).view(torch.uint8), non_blocking=True)
+    if out is None:
+        out = torch.empty((world, total), dtype=torch.uint8, device=dev)
+    elif tuple(out.shape) != (world, total) or out.dtype != torch.uint8:
+        raise ValueError(f"all_gather_trajectory: out must be a uint8 tensor [{world}, {total}]")
+    all_gather_bytes(out, send, group=group, staging=staging)
+    views = tuple(out[:, o:o + x.numel() * x.element_size()].view(x.dtype).view((world,) + tuple(x.shape))
+                  for o, x in zip(offs, fields))
+    return GatheredFields(views, out)
+
+
+class GatheredFields(tuple):
+    """tuple of gathered views [world, T, B_local, ...]; ``.flat`` is the one uint8 buffer [world, nbytes] behind them."""
+
+    def __new__(cls, views, flat):
+        self = super().__new__(cls, views)
+        self.flat = flat
+        return self
 
 
 class RolloutCollector:
@@ -85,7 +153,8 @@ class RolloutCollector:
     """
 
     def __init__(self, produce, like, T: int, chunk: int, group=None, n_buffers: int = 2,
-                 n_gathered: Optional[int] = None, before_gather=None, payload: str = "every field as is"):
+                 n_gathered: Optional[int] = None, before_gather=None, payload: str = "every field as is",
+                 staging: str = "auto"):
         """``n_gathered``: only the first n fields of ``like`` travel (they form a prefix of the staging
         buffer; the remaining fields are produced into the buffer's tail and stay local) -- used to leave
         out the u8 done planes once ``before_gather(bufs)`` (enqueued on the producing stream) has
@@ -106,6 +175,7 @@ class RolloutCollector:
         offs, total = [], 0
         n_gathered = len(like) if n_gathered is None else n_gathered
         self.before_gather, self.payload = before_gather, payload
+        self.staging, self._stage = staging, None
         for k, n in enumerate(nbytes):
             offs.append(total)
             total += (n + 255) & ~255
@@ -129,12 +199,10 @@ class RolloutCollector:
             self.ready = [torch.cuda.Event() for _ in range(n_buffers)]
 
     def _gather(self, c, k):
-        import torch.distributed as dist
         send = self._flat[k][:self.nbytes]
-        if self.world == 1:
-            self._out_flat[c, 0].copy_(send, non_blocking=True)
-        else:
-            dist.all_gather_into_tensor(self._out_flat[c].view(-1), send, group=self.group)
+        if self.world > 1 and self._stage is None and _staging_mode(send, self.group, self.staging) == "host":
+            self._stage = HostStage(self.nbytes, self.world)
+        all_gather_bytes(self._out_flat[c], send, group=self.group, staging=self.staging, stage=self._stage)
 
     def collect(self):
         """Run one fragment; returns ``self.out`` (valid on the caller's stream on return)."""
@@ -175,7 +243,7 @@ def auto_chunk(T: int, bytes_per_step: int, min_chunk_bytes: int = 128 << 20) ->
 
 
 def device_env_collector(dev, T: int, chunk: Optional[int] = None, group=None,
-                         n_buffers: int = 2, pack_flags: bool = True) -> RolloutCollector:
+                         n_buffers: int = 2, pack_flags: bool = True, staging: str = "auto") -> RolloutCollector:
     """RolloutCollector over a DeviceEnv: each chunk is one phx_rollout of ``chunk`` steps
     (default: auto_chunk on the fragment's bytes per step).  With ``pack_flags`` the gathered payload
     is obs | actions | rewards | [obs_valid | reward_valid] | bit-packed done flags (SURVEY 8e iii): the
@@ -203,7 +271,7 @@ def device_env_collector(dev, T: int, chunk: Optional[int] = None, group=None,
             m = (bufs[5], bufs[6]) if has_masks else (None, None)
             dev.rollout(tc, out=Trajectory(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], probe.last_obs, *m))
 
-        return RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers,
+        return RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers, staging=staging,
                                 payload="obs, actions, rewards f32; terminations, truncations u8 planes")
     # the packed flags of a chunk, shaped [chunk, bytes / chunk] so that every field has the chunk axis
     # first (padded to whole 64-bit words per plane and to a multiple of the chunk length)
@@ -229,7 +297,7 @@ def device_env_collector(dev, T: int, chunk: Optional[int] = None, group=None,
                        "phx_pack_flags")
 
     col = RolloutCollector(produce, fields, T, chunk, group=group, n_buffers=n_buffers, n_gathered=n_gathered,
-                           before_gather=before_gather,
+                           before_gather=before_gather, staging=staging,
                            payload="obs, actions, rewards f32" + (", obs_valid, reward_valid u8" if has_masks else "") +
                                    ", truncations bit-packed" + (", terminations bit-packed" if planes == 2
                                                                  else " (terminations: all zero for these kinds, not sent)"))
@@ -256,11 +324,11 @@ class TrajectoryGather:
     all_gather_into_tensor of that prefix on the current stream; ``unpack(r)`` returns rank r's
     fragment as a Trajectory of views (done planes re-expanded to u8)."""
 
-    def __init__(self, dev, T_or_traj, group=None):
+    def __init__(self, dev, T_or_traj, group=None, staging: str = "auto"):
         import torch
         import torch.distributed as dist
         from .device import Trajectory
-        self.dev, self.group = dev, group
+        self.dev, self.group, self.staging, self._stage = dev, group, staging, None
         self.traj = T_or_traj if isinstance(T_or_traj, Trajectory) else dev.alloc_trajectory(int(T_or_traj), flat=True)
         if self.traj.flat is None:
             raise ValueError("TrajectoryGather needs a fragment from alloc_trajectory(flat=True)")
@@ -285,10 +353,9 @@ class TrajectoryGather:
         import torch.distributed as dist
         self.dev.pack_done_flags(self.traj)
         send = self.traj.flat[:self.nbytes]
-        if self.world == 1:
-            self.out[0].copy_(send, non_blocking=True)
-        else:
-            dist.all_gather_into_tensor(self.out.view(-1), send, group=self.group)
+        if self.world > 1 and self._stage is None and _staging_mode(send, self.group, self.staging) == "host":
+            self._stage = HostStage(self.nbytes, self.world)
+        all_gather_bytes(self.out, send, group=self.group, staging=self.staging, stage=self._stage)
         return self.out
 
     def unpack(self, r: int):
