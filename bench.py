@@ -8,7 +8,7 @@
 
 A "step" is one PhantomEnv.step() of every env instance of the batch.  The timed region runs the
 K-step region R times back to back (R chosen so that it lasts >= 1 s; printed as "repeats") as
-fused on-device rollouts (phx_rollout, T=100 = one episode per launch; every step's observation,
+fused on-device rollouts (phx_rollout, T=400 = four episodes per launch by default; every step's observation,
 action, reward and done flags are written to the trajectory buffer in HBM) with inputs/state
 already resident in HBM, bracketed by barrier + synchronize, max over ranks.
 value = A * B_total * R * K / time  (agent-steps/s, whole job); ms_per_step = time / (R * K).
@@ -319,12 +319,16 @@ def main():
                     help="the K-step region is repeated back to back until the timed region lasts at least this long")
     ap.add_argument("--buffers", type=int, default=0,
                     help="trajectory buffers the launches rotate over (default: enough for > 320 MB, at least 4)")
+    ap.add_argument("--episodes-per-launch", type=int, default=4,
+                    help="episodes (of num_steps = 100 steps) per phx_rollout launch: a time-major T = 400 fragment is four "
+                         "consecutive T = 100 fragments in memory; start-up / drain and the launch gap are paid once per launch")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the library's default block shape (no env.autotune_rollout)")
     ap.add_argument("--watchdog-s", type=float, default=900.0, help="overall deadline; a JSON line with `error` is printed when it passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-frag200", action="store_true",
-                    help="skip the informational T=200 launches (profiling: keeps per-kernel averages to T=100 launches)")
+                    help="skip the informational one-episode-per-launch loop (profiling: keeps per-kernel averages to one launch shape)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -392,14 +396,20 @@ def run(args, rank, local_rank, world, watch):
     env = ph.SupplyChainEnv(n_shops=N_SHOPS, customers_per_shop=CUST_PER_SHOP, num_steps=NUM_STEPS,
                             batch_size=B, seed=42, env_offset=rank * B, exogenous="device",
                             device=f"cuda:{local_rank}")
+    T = NUM_STEPS * max(1, args.episodes_per_launch)        # steps per launch
+    tune = None
+    if not args.no_autotune:
+        # block shape of the rollout kernel picked on THIS box (every variant gives the same trajectories): outside
+        # the timed region, a few launches per candidate (PhantomEnv.autotune_rollout)
+        watch.stage("autotune", 180)
+        tune = env.autotune_rollout(T)
     dev = env._device()
     assert dev.uses_fused, "bench expects the fused supply-chain kernels"
     env.reset()
-    T = NUM_STEPS
     # The launches rotate over several trajectory buffers whose total exceeds the 256 MB Infinity Cache, so that
     # every fragment's bytes are really written to HBM (one 82 MB buffer rewritten in place could live in the cache)
     frag_bytes = algorithmic_bytes_rollout(B, S, T)
-    n_buf = args.buffers if args.buffers > 0 else max(4, -(-(320 << 20) // frag_bytes))
+    n_buf = args.buffers if args.buffers > 0 else max(2, -(-(320 << 20) // frag_bytes))
     trajs = [dev.rollout(T) for _ in range(n_buf)]           # allocates the trajectory buffers once
     traj = trajs[0]
     rot = [0]
@@ -460,10 +470,13 @@ def run(args, rank, local_rank, world, watch):
         "config": {"workload": f"supply-chain {args.config.upper()} (1 factory + {N_SHOPS} shops + "
                                f"{N_SHOPS * CUST_PER_SHOP} customers = {N_AGENTS} agents), "
                                f"batch {B} envs per GPU, random actions U[0,100), device-RNG orders, "
-                               "fused on-device rollout T=100 with full trajectory written to HBM",
+                               f"fused on-device rollouts of T={T} steps ({T // NUM_STEPS} episodes of {NUM_STEPS} steps) per launch "
+                               "with the full trajectory written to HBM",
                    "agents": N_AGENTS, "envs_per_gpu": B, "global_envs": B * world,
                    "num_steps": NUM_STEPS, "mode": "phx_rollout", "sharding": f"env-batch x{world}, no step-time collective",
-                   "trajectory_buffers": f"{n_buf} x {frag_bytes / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)"},
+                   "trajectory_buffers": f"{n_buf} x {frag_bytes / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)",
+                   "steps_per_launch": T, "episodes_per_launch": T // NUM_STEPS,
+                   "autotune": tune},
         "repeats": R, "timed_steps": R * K, "timed_launches": n_launch, "timed_region_ms": elapsed * 1e3,
         "warmup_launches": n_warm,
         "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} fragments of {T} steps; "
@@ -487,7 +500,7 @@ def run(args, rank, local_rank, world, watch):
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / n
 
-    n_full = 400
+    n_full = max(100, 400 * NUM_STEPS // T)
     launch_ms = event_ms(n_full)                              # rotating over the buffers: HBM
     same_ms = event_ms(n_full, [traj])                        # one buffer rewritten in place (round 2's loop): may sit in the Infinity Cache
     alg = frag_bytes
@@ -502,28 +515,28 @@ def run(args, rank, local_rank, world, watch):
                 str(rec.get("source", "see file")) + "); not re-measured by this run"
         except Exception:
             traffic = None
-    # the same kernel with two episodes per launch (T = 200): start-up and drain of a launch amortised over twice the
-    # steps; informational -- the roofline object below stays on T = 100, the fragment `value` is measured with
-    frag200 = None
+    # the same kernel with ONE episode per launch (T = 100, what rounds 1-2 reported): the launch gap, the block ramp and the
+    # two pipeline iterations before the first store are paid per 82 MB instead of per launch of T steps; informational
+    frag1 = None
     try:
-        if args.no_frag200:
-            raise RuntimeError("skipped (--no-frag200)")
-        t200 = [dev.rollout(2 * T) for _ in range(max(2, n_buf // 2))]
-        for k in range(5):
-            dev.rollout(2 * T, out=t200[k % len(t200)])
+        if args.no_frag200 or T == NUM_STEPS:
+            raise RuntimeError("skipped")
+        alg1 = algorithmic_bytes_rollout(B, S, NUM_STEPS)
+        t1 = [dev.rollout(NUM_STEPS) for _ in range(max(2, -(-(320 << 20) // alg1)))]
+        for k in range(10):
+            dev.rollout(NUM_STEPS, out=t1[k % len(t1)])
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
-        for k in range(100):
-            dev.rollout(2 * T, out=t200[k % len(t200)])
+        for k in range(400):
+            dev.rollout(NUM_STEPS, out=t1[k % len(t1)])
         g1.record(); torch.cuda.synchronize()
-        ms200 = g0.elapsed_time(g1) / 100
-        alg200 = algorithmic_bytes_rollout(B, S, 2 * T)
-        frag200 = {"T": 2 * T, "launch_ms": ms200, "achieved": alg200 / (ms200 * 1e-3) / 1e9,
-                   "frac": alg200 / (ms200 * 1e-3) / 1e9 / HBM_PEAK_GBS, "buffers": len(t200)}
-        del t200
-        dev.rollout(T, out=traj)                 # back to the 100-step fragment's buffers
+        ms1 = g0.elapsed_time(g1) / 400
+        frag1 = {"T": NUM_STEPS, "launch_ms": ms1, "achieved": alg1 / (ms1 * 1e-3) / 1e9,
+                 "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "buffers": len(t1)}
+        del t1
+        dev.rollout(T, out=traj)                 # back to the bench fragment's buffers
     except Exception as e:                       # report, do not hide
-        frag200 = {"error": str(e)}
+        frag1 = {"error": str(e)}
     # achievable write bandwidth of this box for buffers of the trajectory's size (a plain fill, same rotation)
     fills = [torch.empty(alg // 4, dtype=torch.float32, device=dev.device) for _ in range(n_buf)]
     for f in fills:
@@ -542,9 +555,10 @@ def run(args, rank, local_rank, world, watch):
                        "launch_ms": launch_ms, "launches_timed": n_full, "launch": f"T={T} steps x B={B} envs",
                        "buffers_rotated": n_buf,
                        "same_buffer": {"launch_ms": same_ms, "frac": alg / (same_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "note": "every launch rewrites ONE 82 MB buffer (fits the 256 MB Infinity Cache): not the HBM figure"},
+                                       "note": "every launch rewrites ONE buffer in place (a T = 100 fragment fits the 256 MB Infinity Cache): not the HBM figure"},
                        "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs,
-                       "two_episodes_per_launch": frag200}
+                       "ms_per_100_steps": launch_ms * NUM_STEPS / T,
+                       "one_episode_per_launch": frag1}
 
     # ---- per-launch PhantomEnv.step mode (one kernel launch per step) ---------------------------
     if not args.no_per_step:
@@ -574,7 +588,7 @@ def run(args, rank, local_rank, world, watch):
         if nccl is not None:
             watch.stage("rollout_allgather", 300)
             try:
-                out["rollout_allgather"] = bench_collection(dist, nccl, dev, traj, T, B, world, rank, sync_barrier,
+                out["rollout_allgather"] = bench_collection(dist, nccl, dev, traj, NUM_STEPS, B, world, rank, sync_barrier,
                                                             max_over_ranks, N_AGENTS)
             except Exception as e:
                 out["rollout_allgather"] = {"error": f"{type(e).__name__}: {e}"[:1500]}

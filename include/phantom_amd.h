@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 5
+#define PHX_ABI_VERSION 6
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -196,7 +196,27 @@ typedef struct phx_spec {
   /* ABI 5: FSM stages with handlers: stage_allowed[s][n] != 0 <=> n in FSMStage(s).next_stages (fsm.py:304);
    * NULL: only stage_next[s] is allowed (handler-less stages, fsm.py:281-292)                              */
   const uint8_t* stage_allowed; /* [n_stages][n_stages] or NULL                               */
+  /* ABI 6: kernel-variant selection, per env (0 = the library's choice).  Every variant computes the same results
+   * bit for bit; the fields exist so that each kernel can be selected -- and tested -- without process-wide
+   * environment switches.  A variant whose preconditions the env does not meet is ignored (the library's choice).  */
+  int32_t variant_rollout;      /* PHX_VR_*                                                   */
+  int32_t variant_block;        /* time-parallel rollout kernels: (env, shop) pairs per workgroup; 0 = auto,
+                                   PHX_VB_WHOLE_ENVS = whole envs per workgroup                */
+  int32_t variant_step;         /* PHX_VS_*                                                   */
+  int32_t variant_reserved;
 } phx_spec;
+
+/* phx_spec.variant_rollout: which kernel phx_rollout uses for a supply-chain env with a fused schedule */
+#define PHX_VR_AUTO          0
+#define PHX_VR_TIME_PARALLEL 1  /* plain env: phx_sc_rollout_fast_kernel; FSM env: phx_sc_rollout_fsmfast_kernel at any batch size */
+#define PHX_VR_LEAN          2  /* FSM env: phx_sc_rollout_fsm_lean_kernel, one lane per (env, shop) pair                        */
+#define PHX_VR_GENERAL       3  /* plain env: phx_sc_rollout_kernel, round 1, also serves replays; FSM env: phx_sc_rollout_fsm_kernel */
+#define PHX_VR_LAUNCH_LOOP   4  /* generic engine: one phx_generic_step_kernel launch per step                                    */
+#define PHX_VB_WHOLE_ENVS   (-1)
+/* phx_spec.variant_step */
+#define PHX_VS_AUTO          0
+#define PHX_VS_FUSED         1  /* the static-schedule kernel of the env's family (default where one applies)                      */
+#define PHX_VS_GENERIC       2  /* the message-passing engine (same as PHX_F_FORCE_GENERIC)                                       */
 
 typedef struct phx_env phx_env;   /* opaque */
 

@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -27,6 +27,10 @@ FLOAT_PAYLOAD_TYPES = (MSG_PRICE, MSG_CASH, MSG_REQUEST, MSG_RESPONSE, MSG_BID, 
 TAG_PYF, TAG_F32, TAG_F64 = 0, 1, 2      # PHX_TAG_*: numpy scalar kind of an ads-market float
 
 ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
+# phx_spec.variant_* (ABI 6)
+VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP = 0, 1, 2, 3, 4
+VB_WHOLE_ENVS = -1
+VS_AUTO, VS_FUSED, VS_GENERIC = 0, 1, 2
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES = 1, 2, 4, 8
@@ -57,6 +61,8 @@ class PhxSpec(C.Structure):
         ("type_src", C.c_void_p),
         ("n_conn", C.c_int32), ("conn_rate", C.c_void_p), ("col_conn", C.c_void_p),
         ("stage_allowed", C.c_void_p),
+        ("variant_rollout", C.c_int32), ("variant_block", C.c_int32), ("variant_step", C.c_int32),
+        ("variant_reserved", C.c_int32),
     ]
 
 

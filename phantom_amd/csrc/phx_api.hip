@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -78,6 +79,11 @@ struct Derived {
   std::vector<int32_t> type_src, shop_type_src;
   std::vector<double> shop_type_prm;
 };
+
+// phx_spec.variant_step == PHX_VS_GENERIC and variant_rollout == PHX_VR_LAUNCH_LOOP select the message-passing engine like PHX_F_FORCE_GENERIC
+static uint32_t eff_flags(const phx_spec* sp) {
+  return sp->flags | ((sp->variant_step == PHX_VS_GENERIC || sp->variant_rollout == PHX_VR_LAUNCH_LOOP) ? PHX_F_FORCE_GENERIC : 0u);
+}
 
 static int derive(const phx_spec* sp, Derived& d) {
   if (!sp) return fail(PHX_EINVAL, "null spec");
@@ -227,7 +233,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   // ---- static supply-chain schedule? (fused kernels) ------------------------------------------
   bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 &&
             d.kind_count[PHX_KIND_SHOP] <= 256 &&
-            !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
+            !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
             (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS) && !d.dynamic_graph;
   auto edge = [&](int u, int v) { for (int k = sp->row_ptr[u]; k < sp->row_ptr[u + 1]; ++k) if (sp->col[k] == v) return true; return false; };
   for (int a = 0; a < A && sc; ++a) {
@@ -239,7 +245,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   d.sc_static = sc;
   // ---- static Stackelberg-market schedule? (fused kernel) ----------------------------------------
   bool stk = sp->env_type == PHX_ENV_STACKELBERG && d.kind_count[PHX_KIND_SELLER] > 0 &&
-             !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
+             !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
              (sp->round_limit < 0 || sp->round_limit >= 1) && (!d.dynamic_graph || sp->n_samplers == 0);
   for (int a = 0; a < A && stk; ++a) {
     const int k = sp->kind[a];
@@ -289,7 +295,7 @@ static int derive(const phx_spec* sp, Derived& d) {
   {
     const int N = d.kind_count[PHX_KIND_ADVERTISER];
     bool ads = sp->env_type == PHX_ENV_FSM && sp->n_stages == 2 && N >= 1 && N <= 1024 && d.kind_count[PHX_KIND_PUBLISHER] == 1 &&
-               d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(sp->flags & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
+               d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
                (sp->round_limit < 0 || sp->round_limit >= 3) && (!d.dynamic_graph || (sp->flags & PHX_F_IGNORE_CONN_ERRORS)) && d.D == 3 &&
                sp->stage_next[0] == 1 && sp->stage_next[1] == 0;
     if (ads) {
@@ -397,6 +403,7 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_ENV_OBS_CACHE, "env.obs_cache", 3, 0, B, S, d.D, 0}, {F_ENV_OBS_CACHE_VALID, "env.obs_cache_valid", 2, 0, B, S, 1, 0},
     {F_ENV_SAMPLER, "env.sampler", 1, 0, B, sp->n_samplers, 1, 0}, {F_ENV_EPISODE, "env.episode", 0, 0, B, (sp->n_samplers > 0 || sp->n_conn > 0) ? 1 : 0, 1, 0},
     {F_NET_CONN_ON, "net.conn_on", 2, 0, B, sp->n_conn, 1, 0},
+    {F_ENV_ARRIVE, "env.arrive", 0, 0, B, d.sc_static ? 1 : 0, 1, 0},
     {F_SHOP_STOCK, "shop.stock", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_SALES, "shop.sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_MISSED, "shop.missed_sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
@@ -465,6 +472,7 @@ struct phx_env {
   int device = 0;
   bool use_fused = false, use_stk = false, use_ads = false, lds_ok = true;
   bool prices_compressed = false;   // buyer.prices is represented by seller.posted (fused Stackelberg kernel)
+  std::atomic<int32_t> fsm_gen{0};  // launch generation of the time-parallel FSM rollout (DevSpec::fsm_gen_host)
   DevMsg* inject_dev = nullptr;
   DevMsg inject_host[PHX_MAX_INJECT];
   int n_inject = 0;
@@ -516,6 +524,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.flags = spec->flags; d.queue_cap = spec->queue_cap; d.trace_cap = spec->trace_cap; d.scan_cap = der.scan_cap;
   d.n_lists = der.n_lists; d.initial_stage = spec->initial_stage; d.buyer_nnz = der.buyer_nnz; d.buyer_stride = der.kind_count[PHX_KIND_BUYER];
   d.seed = spec->seed; d.env_offset = spec->env_offset;
+  d.variant_rollout = spec->variant_rollout; d.variant_block = spec->variant_block; d.variant_step = spec->variant_step;
   memcpy(d.kind_count, der.kind_count, sizeof d.kind_count);
   const int A = der.A;
 #define UP(dst, ptr, n) do { rc = upload(e, ptr, (size_t)(n), &d.dst); if (rc != PHX_OK) { phx_destroy(e); return rc; } } while (0)
@@ -626,7 +635,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
         fsm_tab[p] = w;
       }
       ScFastPlan plan;
-      if (fok && phx_sc_fast_plan(d.B, d.S, d.fsm_lean_K, true, d.num_steps, &plan)) { plan.norm = d.fsm_lean_norm; d.fsm_fast = plan; }
+      if (fok && phx_sc_fast_plan(d.B, d.S, d.fsm_lean_K, true, d.num_steps, d.variant_block, false, &plan)) { plan.norm = d.fsm_lean_norm; d.fsm_fast = plan; }
     }
   }
   d.fsm_pos_tab = nullptr; d.fsm_irregular = nullptr;
@@ -637,6 +646,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     rc = upload(e, &zero, 1, &flag);
     if (rc != PHX_OK) { phx_destroy(e); return rc; }
     d.fsm_irregular = (int32_t*)flag;
+    d.fsm_gen_host = &e->fsm_gen;
   }
   if (der.sc_static && spec->env_type == PHX_ENV_PLAIN && !der.any_typed && d.S > 0) {
     // fast rollout kernel (phx_sc_rollout.hip): every shop with the same 1..6 customers and the same normaliser
@@ -647,7 +657,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       nu = nu && der.shop_norm[s2] == der.shop_norm[0];
     }
     ScFastPlan plan;
-    if (phx_sc_fast_plan(d.B, d.S, Ku, nu, d.num_steps, &plan)) {
+    if (phx_sc_fast_plan(d.B, d.S, Ku, nu, d.num_steps, d.variant_block, true, &plan)) {
       plan.norm = der.shop_norm[0];
       d.sc_fast = plan;
     }
@@ -881,7 +891,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   }
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
-  if (e->d.sc_fast.ok && !io->actions && !io->exo) { HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
+  if (e->d.sc_fast.ok && !io->actions && !io->exo && e->d.variant_rollout != PHX_VR_GENERAL) { HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
   return PHX_OK;
 }

@@ -35,6 +35,7 @@ enum {
   F_ADV_LEFT, F_ADV_BID, F_ADV_LEFT_TAG, F_ADV_BID_TAG, F_ADV_CLICKS, F_ADV_WINS, F_ADV_USER,
   F_ADV_TOT_CLICKS, F_ADV_TOT_REQUESTS, F_ADV_TOT_WINS, F_PUB_ADS_SEEN,
   F_WORKSPACE, F_ROLLOUT_SCRATCH,
+  F_ENV_ARRIVE,        // i32 [B]: blocks of a time-parallel rollout launch that have finished with the env (0 between launches)
   F_COUNT
 };
 
@@ -89,11 +90,13 @@ struct DevSpec {
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
   const uint8_t* sc_shop_flags;  // [n_lists][nS] 1 shop acts, 2 a customer acts, 4 every customer acts, 8 observes, 16 rewarded
   int32_t max_cust;              // max customers of one shop
+  int32_t variant_rollout, variant_block, variant_step;   // phx_spec.variant_* (0 = the library's choice)
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
   ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)
   const uint32_t* fsm_pos_tab;   // [num_steps] flags / lookbacks / stage of every episode position (layout: phx_sc_rollout_fsm.hip)
   int32_t* fsm_irregular;        // device word the launch uses to send envs off the tabulated stage chain to the general loop
+  void* fsm_gen_host;            // std::atomic<int32_t>* in the env's handle: launch generation written into fsm_irregular (per env, thread safe)
   // host-built lookup tables of the rollout kernel (exactly the values the formulas give):
   //   [0,101) f32 stock/100 ; [101, 101+n_tabn) f32 x/norm, n_quot valid entries (0 unless
   //   every shop has the same norm) ; then 101 f64 penalties 0.1*stock (8-byte aligned)

@@ -5,7 +5,10 @@
 #include "phx_dev.h"
 
 // decides whether an env shape takes the fast rollout kernel and with which block shape
-bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, ScFastPlan* p);
+// `block`: phx_spec.variant_block (0 auto, PHX_VB_WHOLE_ENVS, or pairs per workgroup); `aligned`: the auto choice prefers
+// workgroups of G consecutive (env, shop) pairs whose trajectory row segments are whole 64-byte pieces (G % 16 == 0) and a
+// grid that is a multiple of the 256 CUs, over whole envs per workgroup
+bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, bool aligned, ScFastPlan* p);
 hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): issues the launch and returns true when the plan applies; the caller then
 // issues the lane-per-pair loop guarded by DevSpec::fsm_irregular == *gen (it runs only if some env is off the tabulated stage chain)

@@ -806,12 +806,14 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
   // time-parallel kernel first where its plan applies; the lane-per-pair loop below then runs only if that kernel found
   // an env off the tabulated stage chain (a stage a handler or the caller set) and left the launch alone
   const int32_t* only_if = nullptr; int32_t gen = 0;
-  if (sp.fsm_fast.ok && sp.fsm_lean_K > 0) {
+  const int vr = sp.variant_rollout;      // phx_spec.variant_rollout: PHX_VR_TIME_PARALLEL / LEAN / GENERAL pick the kernel per env
+  if (sp.fsm_fast.ok && sp.fsm_lean_K > 0 && (vr == PHX_VR_AUTO || vr == PHX_VR_TIME_PARALLEL)) {
     hipError_t fe = hipSuccess;
     if (phx_launch_sc_rollout_fsmfast(sp, io, st, &fe, &gen)) { if (fe != hipSuccess) return fe; only_if = sp.fsm_irregular; }
   }
-  static const int lean_env = getenv("PHX_FSM_LEAN") ? atoi(getenv("PHX_FSM_LEAN")) : 1;
-  if ((lean_env || only_if) && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
+  static const int lean_env = getenv("PHX_FSM_LEAN") ? atoi(getenv("PHX_FSM_LEAN")) : 1;      // development default
+  const bool lean = vr == PHX_VR_LEAN || (vr != PHX_VR_GENERAL && lean_env);
+  if ((lean || only_if) && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
     uint32_t pk = 1; for (int k = 0; k < sp.fsm_lean_K; ++k) pk *= 5u;
     static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
     // blocks that start on multiples of 4 pairs (16-byte aligned observation rows): whole envs, a multiple of 4 of them

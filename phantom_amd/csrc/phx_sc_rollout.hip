@@ -42,7 +42,7 @@ struct FastArgs {
   int32_t norm;                     // the shops' common max_sales_per_step
   uint64_t seed; int64_t env_offset;
   unsigned long long* timing;       // PHX_TIMING builds only
-  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick;
+  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_arrive;
   phx_rollout_io io;
 };
 
@@ -160,7 +160,11 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
       if (!aligned && (tla + 3 < 0 || tla >= tc)) continue;
       const uint32_t tick_a = tick_base + (uint32_t)tla;                 // multiple of 4
       uint32_t w[4];
+#ifdef PHX_ABL_NODRAW
+      w[0] = tick_a * 2654435761u + (uint32_t)genv; w[1] = w[0] * 40503u + s; w[2] = w[1] ^ 0x9e3779b9u; w[3] = w[2] + w[0];   // dev ablation: no Philox
+#else
       rng_block(a.seed, genv, tick_a, s, 0, 0, w);
+#endif
       // the four words of the block -> four ticks.  The accept path is branch-free so that the four items' LDS lookups
       // overlap; the redraw of a rejected word (probability 3.3e-6) is ONE cold branch after it
       uint32_t y[4], aj[4];
@@ -316,6 +320,9 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
         st[0] = make_float4(o[0], o[1], o[2], o[3]); st[1] = make_float4(o[4], o[5], o[6], o[7]); st[2] = make_float4(o[8], o[9], o[10], o[11]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave's own pieces are in LDS (wave-private region: no barrier)
+#ifdef PHX_ABL_NOSTORE
+      if (a.norm != -12345) { if (u < n_units && vrw.x == 1.2345e30f) *(float4*)p_rew = vrw; continue; }   // dev ablation: everything but the stores
+#endif
       const uint32_t q0 = 3u * (uint32_t)ub, qn = 3u * (uint32_t)n_units;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -369,12 +376,22 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
       shop_obs(x, sales, missed, a.norm, ob);
       io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
     }
-    // (blocks of pair ranges: another block of the env may not have read these yet -- phx_sc_fast_env_kernel writes them)
     const uint32_t pr = s_pair[tid];
-    if (a.whole_envs && (pr & 255u) == 0u) {
-      const int bl = (int)(pr >> 8);
-      a.env_step[b_first + bl] = step;
-      a.env_tick[b_first + bl] = s_tick0[bl] + a.T;
+    const int bl = (int)(pr >> 8);
+    if (a.whole_envs) {
+      if ((pr & 255u) == 0u) { a.env_step[b_first + bl] = step; a.env_tick[b_first + bl] = s_tick0[bl] + a.T; }
+    } else if ((pr & 255u) == 0u || tid == 0) {
+      // Blocks of pair ranges: another block that holds a part of this env may not have read its step counter and
+      // tick yet (a block of a later round of the grid), so the block that FINISHES LAST with the env writes them:
+      // every block counts itself in after its own reads (they were consumed at setup), the one that completes the
+      // count -- the number of blocks whose pair range meets the env -- stores the new words and clears the counter
+      // (stream order makes both visible to the next launch).  No second launch, no co-residency assumption.
+      const int64_t b = b_first + bl, p0 = b * nS;
+      const int n_touch = (int)((p0 + nS - 1) / G - p0 / G) + 1;
+      if (n_touch == 1 || atomicAdd(&a.env_arrive[b], 1) + 1 == n_touch) {
+        a.env_step[b] = step; a.env_tick[b] = s_tick0[bl] + a.T;
+        if (n_touch > 1) a.env_arrive[b] = 0;
+      }
     }
   }
 }
@@ -383,52 +400,46 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
 #undef io
 #undef FAST_REFRESH
 
-// Step counter and tick of every env after the fragment, for launches whose blocks hold parts of envs: the walk of
-// `step` in the recurrence above, once per env, after the main kernel (stream order).
-__global__ void phx_sc_fast_env_kernel(const FastArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
-  int step = a.env_step[b];
-  for (int t0 = 0, c = 0; t0 < a.T; ++c) {
-    const int left = a.T - t0, tc = c == 0 ? a.first_rows : (left < PHX_FAST_TC ? left : PHX_FAST_TC);
-    const int tend = a.num_steps - 1 - step;
-    step += tc;
-    if (tend >= 0 && tend < tc) step -= a.num_steps;
-    t0 += tc;
-  }
-  a.env_step[b] = step;
-  a.env_tick[b] += a.T;
-}
-
 // ---- host: plan, blob, launcher -------------------------------------------------------------------------------------
 static uint32_t magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); }
 
-bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, ScFastPlan* p) {
+bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, bool aligned, ScFastPlan* p) {
   memset(p, 0, sizeof *p);
-  static const int off = getenv("PHX_ROLLOUT_FAST") ? atoi(getenv("PHX_ROLLOUT_FAST")) == 0 : 0;
-  if (off) return false;
+  static const int off = getenv("PHX_ROLLOUT_FAST") ? atoi(getenv("PHX_ROLLOUT_FAST")) == 0 : 0;     // development default only:
+  if (off) return false;                                                                               // per env: phx_spec.variant_rollout
   if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || num_steps < PHX_FAST_TC) return false;
-  // whole envs per block, a multiple of 4 of them so that every tile row is a whole number of 16-byte
-  // segments; ~32..64 pairs per block (one recurrence wave)
+  const int64_t total = (int64_t)B * S;
+  static const int g_env = getenv("PHX_ROLLOUT_G") ? atoi(getenv("PHX_ROLLOUT_G")) : 0;               // development default of variant_block
+  if (block == 0) block = g_env;
+  auto pairs_ok = [&](int G) { return G >= 4 && G <= 128 && G % 4 == 0 && total % G == 0 && (G + S - 2) / S + 1 <= 255; };
+  // (1) whole envs per block, a multiple of 4 of them so that every tile row is a whole number of 16-byte segments;
+  //     ~32..64 pairs per block (one recurrence wave)
   int epb = 0;
   for (int cand = 4; cand * S <= 96 && cand <= 255; cand += 4) if (cand * S >= 32) { epb = cand; break; }
   if (!epb && 4 * S <= 96) epb = 4;
-  const int64_t total = (int64_t)B * S;
-  static const int g_env = getenv("PHX_ROLLOUT_G") ? atoi(getenv("PHX_ROLLOUT_G")) : 0;
-  if (epb && B % epb == 0 && total % 4 == 0 && !g_env) { p->epb = epb; p->G = epb * S; p->whole_envs = 1; }
-  else {
-    // wider envs (SC256: 51 shops): blocks of G consecutive (env, shop) pairs, G a multiple of 4 that divides B * S.
-    // 32 pairs make every tile row of a block whole 128-byte lines (SC256, B = 8192, T = 100: G = 32 201 us per launch,
-    // 64 225 us, 28 / 36 / 40 265 us, 96 317 us; the round-1 kernel 267 us)
-    int G = 0;
-    if (g_env) { if (g_env % 4 == 0 && g_env >= 4 && g_env <= 128 && total % g_env == 0) G = g_env; }
-    else {
-      static const int pref[] = {32, 64, 48, 40, 36, 44, 52, 56, 60, 28, 24, 68, 72, 76, 80, 84, 88, 92, 96};
-      for (int cand : pref) if (total % cand == 0) { G = cand; break; }
+  const bool whole_ok = epb && B % epb == 0 && total % 4 == 0;
+  // (2) blocks of G CONSECUTIVE (env, shop) PAIRS that start and end inside envs.  With G % 16 == 0 every row segment a
+  //     block writes is a whole number of 64-byte pieces of the f32 planes (the memory-side write request): the lines at
+  //     block boundaries need no merging of partial writes in the L2.  Measured (tools/ubench/ub_store3.hip, the rollout
+  //     itself: DESIGN 3.3): on some MI355X boxes the partially written boundary lines of 36-pair blocks cost 1.6x
+  //     (T = 400, SC64, B = 4096: 118 vs 75-85 us per launch), on the others whole-env blocks are ~5 % faster; a grid that
+  //     is a multiple of the 256 CUs keeps the one-round launch balanced (SC64, B = 4096: 48 pairs -> 768 blocks = 3 per CU).
+  int G = 0;
+  if (block > 0 && pairs_ok(block)) G = block;
+  else if (block != PHX_VB_WHOLE_ENVS && (aligned || !whole_ok)) {
+    static const int pref16[] = {32, 48, 64, 16, 80, 96, 112, 128};
+    if (aligned) {
+      for (int cand : pref16) if (pairs_ok(cand) && (total / cand) % 256 == 0) { G = cand; break; }
+      if (!G) for (int cand : pref16) if (pairs_ok(cand)) { G = cand; break; }
     }
-    if (!G) return false;
-    p->G = G; p->epb = (G + S - 2) / S + 1; p->whole_envs = 0;       // epb: the most envs a block can touch
+    if (!G && !whole_ok) {
+      static const int pref[] = {32, 64, 48, 40, 36, 44, 52, 56, 60, 28, 24, 68, 72, 76, 80, 84, 88, 92, 96};
+      for (int cand : pref) if (pairs_ok(cand)) { G = cand; break; }
+    }
   }
+  if (G) { p->G = G; p->epb = (G + S - 2) / S + 1; p->whole_envs = 0; }       // epb: the most envs a block can touch
+  else if (whole_ok) { p->epb = epb; p->G = epb * S; p->whole_envs = 1; }
+  else return false;
   if ((int64_t)PHX_FAST_TC * B * S * 12 >= ((int64_t)1 << 32)) return false;      // 32-bit store offsets within a chunk
   p->K = K_uniform;
   const int p2w = (p->G + 63) / 64, p1w = ((PHX_FAST_TC / 4) * p->G + 63) / 64;     // draws of a chunk in one pass
@@ -456,7 +467,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   a.first_rows = first;
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
-  a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
+  a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
   a.io = io;
   a.timing = nullptr;
 #ifdef PHX_TIMING
@@ -479,6 +490,5 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<384>), grid, dim3(384), lds, st, a);
   else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<320>), grid, dim3(320), lds, st, a);
   else hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<256>), grid, dim3(256), lds, st, a);
-  if (!p.whole_envs) hipLaunchKernelGGL(phx_sc_fast_env_kernel, dim3((sp.B + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

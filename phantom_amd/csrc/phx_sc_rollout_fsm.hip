@@ -19,6 +19,7 @@
 #include "phx_dev.h"
 #include "phx_sc_fast.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -496,8 +497,8 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
   // 4 096 envs 40 / 60, x 16 384 120 / 85, x 65 536 501 / 464; 51 shops x 2 048 envs 104 / 77, x 4 096 191 / 119, x 8 192 330-370 /
   // 204-335.  The output phase costs twice the plain kernel's (own row + looked-back row per pair, silent and observing steps
   // mixed in every wave), so this kernel only wins where the loop's one lane per pair leaves the chip underfilled.
-  static const int force = getenv("PHX_FSM_FAST") ? atoi(getenv("PHX_FSM_FAST")) : 0;
-  if (force < 2 && (int64_t)sp.B * sp.S > 65536) return false;
+  static const int force = getenv("PHX_FSM_FAST") ? atoi(getenv("PHX_FSM_FAST")) : 0;             // development default
+  if (force < 2 && sp.variant_rollout != PHX_VR_TIME_PARALLEL && (int64_t)sp.B * sp.S > 65536) return false;
   FsmFastArgs a;
   memset(&a, 0, sizeof a);
   a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.whole_envs = p.whole_envs; a.K = p.K; a.T = io_.T; a.num_steps = sp.num_steps;
@@ -516,8 +517,14 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
   a.rew_cache = (double*)sp.f[F_ENV_REW_CACHE]; a.rew_cache_v = (uint8_t*)sp.f[F_ENV_REW_CACHE_VALID];
   a.obs_cache = (float*)sp.f[F_ENV_OBS_CACHE]; a.obs_cache_v = (uint8_t*)sp.f[F_ENV_OBS_CACHE_VALID];
   a.pos_tab = sp.fsm_pos_tab; a.irregular = sp.fsm_irregular;
-  static int32_t launch_gen = 0;
-  launch_gen = launch_gen == 0x7fffffff ? 1 : launch_gen + 1;
+  // the generation is per env (two envs, or two host threads, never share a counter) and is baked into the kernel
+  // arguments: a launch captured into a hipGraph would replay ONE generation for ever, so a capturing stream takes the
+  // lane-per-pair loop instead (same results)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+  std::atomic<int32_t>* gen_host = (std::atomic<int32_t>*)sp.fsm_gen_host;
+  int32_t launch_gen = gen_host->fetch_add(1) + 1;
+  if (launch_gen <= 0 || launch_gen == 0x7fffffff) { gen_host->store(1); launch_gen = 1; }
   a.gen = launch_gen; *gen_out = launch_gen;
   a.io = io_;
   a.timing = nullptr;

@@ -32,7 +32,7 @@ class PhantomEnv:
     def __init__(self, num_steps: int, network: Optional[Network] = None, env_supertype=None,
                  agent_supertypes=None, *, batch_size: int = 1, device=None, seed: int = 0,
                  env_offset: int = 0, exogenous: Optional[str] = None,
-                 force_generic: bool = False) -> None:
+                 force_generic: bool = False, variants: Optional[Dict] = None) -> None:
         self.network = network or Network()
         self.num_steps = num_steps
         self.batch_size = int(batch_size)
@@ -41,6 +41,9 @@ class PhantomEnv:
         self._device_name = device
         self._seed, self._env_offset = seed, env_offset
         self._force_generic = force_generic
+        #: kernel variants (phx_spec.variant_*): {"rollout": "time_parallel" | "lean" | "general" | "launch_loop",
+        #: "block": pairs per workgroup | "whole_envs", "step": "fused" | "generic"}; every variant gives the same results
+        self._variants = dict(variants or {})
         #: where CustomerAgent's np.random.randint(5) (supply_chain.py:64) comes from:
         #: "numpy" = the global legacy numpy stream consumed in the reference's order
         #: (bit-parity with the reference for the same np.random.seed); "device" = Philox
@@ -154,7 +157,7 @@ class PhantomEnv:
     def _compile(self) -> EnvSpec:
         return compile_spec(self.network, self.num_steps, self.batch_size, self._env_type,
                             seed=self._seed, env_offset=self._env_offset,
-                            force_generic=self._force_generic, samplers=self._samplers,
+                            force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
                             device_sampling=self._device_sampling)
 
     @property
@@ -364,6 +367,50 @@ class PhantomEnv:
         traj = self._device().rollout(T, actions, exo, out)
         self._sync_host_state()
         return traj
+
+    def autotune_rollout(self, T: int, candidates=None, launches: int = 12):
+        """Pick the fastest kernel variant for ``rollout(T)`` ON THIS GPU and rebuild the device env with it.
+
+        Every variant computes the same trajectories bit for bit (phx_spec.variant_*); which block shape is fastest
+        depends on the box -- whole-env workgroups win by ~5 % where the L2 merges the partially written boundary
+        lines, workgroups of 32 / 48 consecutive (env, shop) pairs (whole 64-byte pieces per row) win by up to 1.6x
+        where it does not.  Each candidate gets its own device env (same spec, own state blob) and is
+        timed over ``launches`` fragments into real-size trajectory buffers (rotated, so the bytes reach HBM).
+        Re-creates the device env: call before ``reset()``.  Returns {"chosen": variants, "us_per_launch": {...}}."""
+        import torch
+        from .device import DeviceEnv
+        from .spec import resolve_variants
+        if candidates is None:
+            # whole-env workgroups are NOT a default candidate: where they win it is by <= 5 %, and their partially written
+            # boundary lines make them sensitive to where the trajectory buffers land (up to 1.6x between two allocations
+            # of the same process), which a measurement on the tuning buffers cannot foresee
+            candidates = [{"block": 48}, {"block": 32}]
+        base = dict(self._variants)
+        results, best, best_t = {}, None, None
+        for cand in candidates:
+            v = dict(base); v.update(cand)
+            resolve_variants(v)
+            self._variants, self._spec, self._dev = v, None, None
+            dev = DeviceEnv(self.spec, self._device_name)
+            dev.reset()
+            one = dev.alloc_trajectory(T)
+            nbytes = sum(x.numel() * x.element_size() for x in one[:5])
+            bufs = [one] + [dev.alloc_trajectory(T) for _ in range(max(1, -(-(320 << 20) // max(nbytes, 1)) - 1))]
+            for k in range(3):
+                dev.rollout(T, out=bufs[k % len(bufs)])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(launches):
+                dev.rollout(T, out=bufs[k % len(bufs)])
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / launches * 1e3
+            results[str(cand)] = t
+            if best_t is None or t < best_t:
+                best, best_t = v, t
+            dev.close(); del dev, bufs, one
+        torch.cuda.empty_cache()
+        self._variants, self._spec, self._dev = best, None, None
+        return {"chosen": dict(best), "us_per_launch": results}
 
     def _sync_host_state(self):
         """host mirrors of the env clock (current_step, FSM stages) re-read from the device state."""

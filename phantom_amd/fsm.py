@@ -101,7 +101,7 @@ class FiniteStateMachineEnv(PhantomEnv):
         return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_FSM,
                             stages=self._stage_list, initial_stage=self._initial_stage,
                             seed=self._seed, env_offset=self._env_offset,
-                            force_generic=self._force_generic, samplers=self._samplers,
+                            force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
                             device_sampling=self._device_sampling)
 
     @property

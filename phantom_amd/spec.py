@@ -50,6 +50,8 @@ class EnvSpec:
     # StochasticNetwork: base connections (row_ptr/col then describe the base graph)
     conn_rate: Optional[np.ndarray] = None        # f64 [n_conn]
     col_conn: Optional[np.ndarray] = None         # i32 [nnz]
+    # kernel variants (phx_spec.variant_*, ABI 6): {"rollout": name | int, "block": pairs | "whole_envs", "step": name | int}
+    variants: Dict = field(default_factory=dict)
 
     # ---- derived ------------------------------------------------------------------------
     @property
@@ -162,7 +164,32 @@ class EnvSpec:
         s.n_conn = self.n_conn
         s.conn_rate = ptr(self.conn_rate, np.float64) if self.n_conn else None
         s.col_conn = ptr(self.col_conn, np.int32) if self.n_conn else None
+        s.variant_rollout, s.variant_block, s.variant_step = resolve_variants(self.variants)
         return s, keep
+
+
+VARIANT_ROLLOUT = {"auto": _abi.VR_AUTO, "time_parallel": _abi.VR_TIME_PARALLEL, "lean": _abi.VR_LEAN,
+                   "general": _abi.VR_GENERAL, "launch_loop": _abi.VR_LAUNCH_LOOP}
+VARIANT_STEP = {"auto": _abi.VS_AUTO, "fused": _abi.VS_FUSED, "generic": _abi.VS_GENERIC}
+
+
+def resolve_variants(variants) -> tuple:
+    """(variant_rollout, variant_block, variant_step) of phx_spec from the host-side dict; unknown names raise."""
+    v = dict(variants or {})
+    unknown = set(v) - {"rollout", "block", "step"}
+    if unknown:
+        raise ValueError(f"unknown kernel-variant keys {sorted(unknown)} (rollout, block, step)")
+
+    def pick(table, x, what):
+        if isinstance(x, str):
+            if x not in table:
+                raise ValueError(f"unknown {what} variant {x!r}; one of {sorted(table)}")
+            return table[x]
+        return int(x or 0)
+
+    blk = v.get("block", 0)
+    blk = _abi.VB_WHOLE_ENVS if blk == "whole_envs" else int(blk or 0)
+    return pick(VARIANT_ROLLOUT, v.get("rollout", 0), "rollout"), blk, pick(VARIANT_STEP, v.get("step", 0), "step")
 
 
 def _max_emissions(kind: int, deg: int) -> int:
@@ -182,7 +209,7 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                  leaders: Optional[Sequence] = None, followers: Optional[Sequence] = None,
                  seed: int = 0, env_offset: int = 0, force_generic: bool = False,
                  extra_queue: int = 16, samplers: Optional[Sequence] = None,
-                 device_sampling: bool = False) -> EnvSpec:
+                 device_sampling: bool = False, variants: Optional[Dict] = None) -> EnvSpec:
     from .agents import Agent, StrategicAgent, check_device_executable
     agent_ids = list(network.agents.keys())
     A = len(agent_ids)
@@ -261,6 +288,8 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                    row_ptr=row_ptr, col=col_arr, batch=int(batch_size), num_steps=int(num_steps),
                    round_limit=round_limit, env_type=env_type, flags=flags, queue_cap=queue_cap,
                    trace_cap=int(trace_cap), seed=int(seed), env_offset=int(env_offset))
+    resolve_variants(variants)                              # validates the names
+    spec.variants = dict(variants or {})
 
     if env_type == _abi.ENV_FSM:
         stage_ids = [s.id for s in stages]

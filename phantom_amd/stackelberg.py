@@ -27,5 +27,5 @@ class StackelbergEnv(PhantomEnv):
         return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_STACKELBERG,
                             leaders=self.leader_agents, followers=self.follower_agents,
                             seed=self._seed, env_offset=self._env_offset,
-                            force_generic=self._force_generic, samplers=self._samplers,
+                            force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
                             device_sampling=self._device_sampling)

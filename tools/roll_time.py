@@ -13,25 +13,34 @@ ap.add_argument("--shops", type=int, default=9); ap.add_argument("--cust", type=
 ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--T", type=int, default=100)
 ap.add_argument("--n", type=int, default=200); ap.add_argument("--fsm", action="store_true")
 ap.add_argument("--tag", default="")
+ap.add_argument("--bufs", type=int, default=0, help="trajectory buffers rotated over (0: enough for > 320 MB)")
+ap.add_argument("--block", default="0", help="variants['block']: pairs per workgroup, whole_envs, or 0 = auto")
+ap.add_argument("--rollout", default="auto", help="variants['rollout']")
+ap.add_argument("--tblock", type=int, default=0, help="phx_rollout_io.t_block (0 / 1: time-major)")
 a = ap.parse_args()
 cls = ph.SupplyChainFSMEnv if a.fsm else ph.SupplyChainEnv
-env = cls(n_shops=a.shops, customers_per_shop=a.cust, num_steps=100, batch_size=a.batch, seed=42, exogenous="device")
+blk = a.block if a.block == "whole_envs" else int(a.block)
+env = cls(n_shops=a.shops, customers_per_shop=a.cust, num_steps=100, batch_size=a.batch, seed=42, exogenous="device",
+          variants={"block": blk, "rollout": a.rollout})
 env.reset(); dev = env._device()
-tr = dev.rollout(a.T)
+S = a.shops
+alg = a.batch * a.T * 22 * S + a.batch * (S * 32 + 16)
+nb = a.bufs or max(2, -(-(320 << 20) // alg))
+kw = {"t_block": a.tblock} if a.tblock else {}
+trs = [dev.alloc_trajectory(a.T, **kw) for _ in range(nb)]
+tr = dev.rollout(a.T, out=trs[0])
 torch.cuda.synchronize()
 h = hashlib.sha1()
 for x in (tr.observations, tr.actions, tr.rewards, tr.truncations):
     h.update(x.cpu().numpy().tobytes())
-for _ in range(20):
-    dev.rollout(a.T, out=tr)
+for i in range(20):
+    dev.rollout(a.T, out=trs[i % nb])
 best = 1e9
 for rep in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(a.n):
-        dev.rollout(a.T, out=tr)
+    for i in range(a.n):
+        dev.rollout(a.T, out=trs[i % nb])
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / a.n * 1e3)
-S = a.shops
-alg = a.batch * a.T * 22 * S + a.batch * (S * 32 + 16)
-print(f"{a.tag:28s} {best:8.2f} us/launch  {alg / best / 1e3 / 8000:.3f} of 8 TB/s  sha {h.hexdigest()[:12]}", flush=True)
+print(f"{a.tag:28s} T={a.T:5d} bufs={nb:2d} {best:8.2f} us/launch  {best * 100 / a.T:7.2f} us/100 steps  {alg / best / 1e3 / 8000:.3f} of 8 TB/s  sha {h.hexdigest()[:12]}", flush=True)
