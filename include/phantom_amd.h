@@ -296,6 +296,9 @@ typedef struct phx_rollout_io {
 /* ---- entry points ---------------------------------------------------------------------- */
 int         phx_abi_version(void);
 const char* phx_last_error(void);
+/* names of the kernels the calling thread's last phx_step / phx_rollout / phx_resolve launched, joined by '+'
+ * (kernel-variant tests: phx_spec.variant_*) */
+const char* phx_last_kernel(void);
 
 /* sizes derived from the spec, so the caller (torch) can own every buffer */
 int64_t phx_state_nbytes(const phx_spec* spec);

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
 template <bool ROLLOUT>
 static hipError_t ads_launch(const DevSpec& sp, const AdsArgs& a, hipStream_t st) {
   const int n = sp.S;
+  phx_note_kernel(ROLLOUT ? "phx_ads_kernel[rollout]" : "phx_ads_kernel[step]");
 #define PHX_ADS(NT_) hipLaunchKernelGGL((phx_ads_kernel<NT_, ROLLOUT>), dim3(sp.B), dim3(NT_), 0, st, sp, a)
   if (n <= 64) PHX_ADS(64); else if (n <= 128) PHX_ADS(128); else if (n <= 256) PHX_ADS(256);
   else if (n <= 512) PHX_ADS(512); else PHX_ADS(1024);

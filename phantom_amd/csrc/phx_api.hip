@@ -489,10 +489,20 @@ static int upload(phx_env* e, const T* host, size_t n, const T** out) {
   return PHX_OK;
 }
 
+static thread_local char g_kernels[384] = "";
+static void note_reset() { g_kernels[0] = 0; }
+void phx_note_kernel(const char* name) {
+  const size_t n = strlen(g_kernels), m = strlen(name);
+  if (strstr(g_kernels, name) || n + m + 2 >= sizeof g_kernels) return;
+  if (n) { g_kernels[n] = '+'; memcpy(g_kernels + n + 1, name, m + 1); } else memcpy(g_kernels, name, m + 1);
+}
+
 extern "C" {
 
 int phx_abi_version(void) { return PHX_ABI_VERSION; }
 const char* phx_last_error(void) { return g_err; }
+
+const char* phx_last_kernel(void) { return g_kernels; }
 
 int64_t phx_state_nbytes(const phx_spec* spec) {
   Derived d; if (derive(spec, d) != PHX_OK) return -1;
@@ -765,6 +775,7 @@ static int upload_inject(phx_env* e, hipStream_t st) {
 }
 
 int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
+  note_reset();
   if (!e) return fail(PHX_EINVAL, "null env");
   HIPCHK(use_device(e));
   int rc = check_step_io(e, io);
@@ -814,6 +825,7 @@ int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) {
 }
 
 int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count, void* stream) {
+  note_reset();
   if (!e) return fail(PHX_EINVAL, "null env");
   if ((msg_log || msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
   HIPCHK(use_device(e));
@@ -834,6 +846,7 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 }
 
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
+  note_reset();
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
   if (e->d.env_type != PHX_ENV_PLAIN && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");

@@ -139,6 +139,9 @@ struct DevSpec {
   const DevSpec* self_dev;       // this struct in device memory (kernels that read it through the scalar cache instead of 300 SGPRs)
 };
 
+// names of the kernels the calling thread's last phx_step / phx_rollout / phx_resolve launched (phx_last_kernel, tests)
+void phx_note_kernel(const char* name);
+
 struct GenArgs {               // arguments of the generic engine kernel
   phx_step_io io;
   const DevMsg* inject;         // device copy of host-injected messages (same for every env)

@@ -1091,6 +1091,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   int kmax = 0;
   for (int k = 0; k < PHX_KIND_COUNT; ++k) if (sp.kind_count[k] > 0) kmax = k;
   const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
+  phx_note_kernel("phx_generic_step_kernel");
 #define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)
   if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }

@@ -793,6 +793,7 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
   const int64_t bytes = (int64_t)epb * sp.n_exo + 32;
   const int stage = (io.exo && bytes <= SC_STAGE_MAX) ? 1 : 0;
   const size_t lds = stage ? (size_t)bytes : 0;
+  phx_note_kernel("phx_sc_step_kernel");
   if (nt == 64) hipLaunchKernelGGL((phx_sc_step_kernel<64>), dim3(blocks), dim3(64), lds, st, sp, io, epb, stage);
   else if (nt == 128) hipLaunchKernelGGL((phx_sc_step_kernel<128>), dim3(blocks), dim3(128), lds, st, sp, io, epb, stage);
   else hipLaunchKernelGGL((phx_sc_step_kernel<256>), dim3(blocks), dim3(256), lds, st, sp, io, epb, stage);
@@ -826,10 +827,12 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     }
     const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (((size_t)sp.n_lists + 3) & ~(size_t)3) * 4 +
                        (SC_NT / 64) * 192 * 4 + 16;
+    phx_note_kernel(only_if ? "phx_sc_rollout_fsm_lean_kernel[if off-chain]" : "phx_sc_rollout_fsm_lean_kernel");
     hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3((sp.B + epb_l - 1) / epb_l), dim3(SC_NT), lds, st, sp, io, epb_l, remap,
                        pk, inv[sp.fsm_lean_K], wide, only_if, gen);
     return hipGetLastError();
   }
+  phx_note_kernel("phx_sc_rollout_fsm_kernel");
   hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
                      (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb, remap);
   return hipGetLastError();
@@ -911,6 +914,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
     else nt = big ? 512 : 256;
   }
   if (nt_env) nt = nt_env;
+  phx_note_kernel("phx_sc_rollout_kernel");
 #define PHX_LAUNCH_ROLLOUT(NT_)                                                                              \
   do {                                                                                                        \
     if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, true>), grid, dim3(NT_), lds, st, a);  \

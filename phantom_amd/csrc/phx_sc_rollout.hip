@@ -486,6 +486,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
   const int rec = ((p.G + 63) / 64) * 64;
   const int nt = (nt_env && nt_env >= rec + 64) ? nt_env : p.nt;
+  phx_note_kernel(p.whole_envs ? "phx_sc_rollout_fast_kernel[whole_envs]" : "phx_sc_rollout_fast_kernel[pairs]");
   if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<512>), grid, dim3(512), lds, st, a);
   else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<384>), grid, dim3(384), lds, st, a);
   else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<320>), grid, dim3(320), lds, st, a);

@@ -543,6 +543,7 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
                      sp.num_steps, a.gen, sp.B, sp.fsm_irregular);
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
   const int nt = p.nt;
+  phx_note_kernel(p.whole_envs ? "phx_sc_rollout_fsmfast_kernel[whole_envs]" : "phx_sc_rollout_fsmfast_kernel[pairs]");
   if (nt == 512) hipLaunchKernelGGL((phx_sc_rollout_fsmfast_kernel<512>), grid, dim3(512), lds, st, a);
   else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fsmfast_kernel<384>), grid, dim3(384), lds, st, a);
   else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fsmfast_kernel<320>), grid, dim3(320), lds, st, a);

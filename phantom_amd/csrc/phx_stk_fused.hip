@@ -664,6 +664,7 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
   if (nt_env && STKR_SLOTS * nt_env >= sp.A) nt = nt_env;
   if (STKR_SLOTS * nt < sp.A) return hipErrorInvalidConfiguration;
   const size_t lds = phx_stk_rollout_lds(sp);
+  phx_note_kernel("phx_stk_rollout_kernel");
 #define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp, io); \
                                   else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp, io); } while (0)
   switch (nt) {
@@ -708,6 +709,7 @@ hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStre
     int nt = 1024;
     for (int cand : {128, 256, 512, 1024}) if (STKR_SLOTS * cand >= sp.A) { nt = cand; break; }
     if (nt_env && STKR_SLOTS * nt_env >= sp.A) nt = nt_env;
+    phx_note_kernel("phx_stk_step_fast_kernel");
     switch (nt) {
       case 128: hipLaunchKernelGGL((phx_stk_step_fast_kernel<128>), dim3(sp.B), dim3(128), lds, st, sp, io); break;
       case 256: hipLaunchKernelGGL((phx_stk_step_fast_kernel<256>), dim3(sp.B), dim3(256), lds, st, sp, io); break;
@@ -717,6 +719,7 @@ hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStre
     }
     return hipGetLastError();
   }
+  phx_note_kernel("phx_stk_step_kernel");
   if (sp.dynamic_graph) hipLaunchKernelGGL(phx_stk_step_kernel<true>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   else hipLaunchKernelGGL(phx_stk_step_kernel<false>, dim3(sp.B), dim3(STK_NT), lds, st, sp, io);
   return hipGetLastError();

@@ -144,6 +144,10 @@ class DeviceEnv:
     def _err(self) -> str:
         return (self.lib.phx_last_error() or b"").decode()
 
+    def last_kernel(self) -> str:
+        """names of the kernels this thread's last step / rollout / resolve call launched, joined by '+'"""
+        return (self.lib.phx_last_kernel() or b"").decode()
+
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 

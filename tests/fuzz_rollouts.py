@@ -32,7 +32,12 @@ def run_rollout_case(case):
         Ks = [K] * S if rng.random() < 0.8 else [int(rng.integers(1, 9)) for _ in range(S)]
         B = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 20, 32, 48, 64]))
         ns = int(rng.choice([1, 2, 5, 19, 20, 21, 40, 57, 100]))
-        env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)))
+        # a kernel variant drawn from the seed (phx_spec.variant_*; ignored where its preconditions do not hold)
+        vrng = np.random.default_rng(case + 10_000_019)
+        variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general"])),
+                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36][int(vrng.integers(0, 8))]}
+        env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
+                               variants=variants)
         fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")
         amax, valid = 100.0, fsm
     else:

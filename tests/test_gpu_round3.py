@@ -115,3 +115,140 @@ def test_bench_forced_collective_path_matches_the_plain_run():
     assert abs(a["value"] - b["value"]) / a["value"] < 0.35          # two processes, two buffer placements
     assert b["rollout_allgather"]["bytes_per_rank"] < b["rollout_allgather"]["raw_trajectory_bytes_per_rank"]
     assert b["config4_share"]["agent_steps_per_sec_gather_included"] > 0
+
+
+# ---- every rollout kernel variant against the oracle at small sizes (VERDICT r2 item 5) -----------------------------
+def _cmp_rollout(rd, ro, valid_planes):
+    for k in ("obs", "actions", "rewards", "last_obs"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    for k in ("truncated", "terminated") + (("obs_valid", "reward_valid") if valid_planes else ()):
+        np.testing.assert_array_equal(rd[k], ro[k], err_msg=k)
+
+
+PLAIN_VARIANTS = [
+    ({"block": "whole_envs"}, "phx_sc_rollout_fast_kernel[whole_envs]"),
+    ({"block": 32}, "phx_sc_rollout_fast_kernel[pairs]"),
+    ({"block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
+    ({"block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
+    ({}, "phx_sc_rollout_fast_kernel"),
+    ({"rollout": "general"}, "phx_sc_rollout_kernel"),
+    ({"rollout": "launch_loop"}, "phx_generic_step_kernel"),
+]
+
+
+@pytest.mark.parametrize("variants,kernel", PLAIN_VARIANTS, ids=[str(v) for v, _ in PLAIN_VARIANTS])
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (9, 6, 32, 23), (3, 2, 48, 40), (51, 4, 16, 100), (7, 3, 96, 30)])
+def test_plain_rollout_variants_match_oracle(S, K, B, num_steps, variants, kernel):
+    """phx_spec.variant_rollout / variant_block select the kernel PER ENV: the time-parallel kernel with whole-env
+    workgroups and with workgroups of 16 / 32 / 48 consecutive (env, shop) pairs (the last block of an env's pair
+    range is the one that writes its step counter: the last-arriver count), the round-1 kernel and the generic
+    engine's launch loop -- unaligned ticks, ragged fragment lengths, several episode ends per fragment, poked stocks,
+    hand-over to per-step launches -- all bit-equal to the oracle."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, seed=11 + S, env_offset=1000, variants=variants)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S * 100 + K)
+    for t in range(3):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+    used = set()
+    for T in (1, 7, 20, 41, 100, 3, 200):
+        ro, rd = o.rollout(T), d.rollout(T)
+        used.add(d.dev.last_kernel())
+        _cmp_rollout(rd, ro, False)
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    if "env.arrive" in d.dev.field_names():
+        assert int(d.dev.field("env.arrive").abs().sum()) == 0      # the arrival counters are back at zero
+    st = rng.integers(-40, 160, (B, S)).astype(np.int32)
+    o.set_i32("shop.stock", st); d.set_i32("shop.stock", st)
+    for T in (20, 9):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, False)
+    a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+    o.step(a, None, None); d.step(a, None, None)
+    np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
+    np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward))
+    assert (d.err == 0).all()
+    # the requested kernel ran wherever its preconditions hold (the plan refuses e.g. 48 pairs when B * S % 48 != 0)
+    total = B * S
+    blk = variants.get("block")
+    applicable = not isinstance(blk, int) or (total % blk == 0 and (blk + S - 2) // S + 1 <= 255)
+    if blk == "whole_envs":
+        epb = next((c for c in range(4, 256, 4) if c * S <= 96 and c * S >= 32), 4 if 4 * S <= 96 else 0)
+        applicable = bool(epb) and B % epb == 0
+    if applicable:
+        assert any(kernel in u for u in used), (kernel, used)
+
+
+FSM_VARIANTS = [
+    ({"rollout": "time_parallel"}, "phx_sc_rollout_fsmfast_kernel"),
+    ({"rollout": "time_parallel", "block": 32}, "phx_sc_rollout_fsmfast_kernel[pairs]"),
+    ({"rollout": "lean"}, "phx_sc_rollout_fsm_lean_kernel"),
+    ({"rollout": "general"}, "phx_sc_rollout_fsm_kernel"),
+    ({"rollout": "launch_loop"}, "phx_generic_step_kernel"),
+]
+
+
+@pytest.mark.parametrize("variants,kernel", FSM_VARIANTS, ids=[str(v) for v, _ in FSM_VARIANTS])
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (51, 4, 16, 100), (3, 2, 48, 7), (5, 1, 40, 33)])
+def test_fsm_rollout_variants_match_oracle(S, K, B, num_steps, variants, kernel):
+    """the three FSM rollout kernels (time-parallel, lean lane-per-pair loop, general loop) and the launch loop, selected
+    per env, on the edge cases of round 2's lean-loop test: fragments starting in either stage and on unaligned ticks,
+    several episode ends, caches carried across launches, poked stocks, envs pushed off the stage chain."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, fsm=True, seed=5 + S, env_offset=77, variants=variants)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S * 10 + K)
+    for t in range(3):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+    fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.stage", "env.step", "env.tick")
+    used = set()
+    for T in (1, 6, 41, 100, 3):
+        ro, rd = o.rollout(T), d.rollout(T)
+        used.add(d.dev.last_kernel())
+        _cmp_rollout(rd, ro, True)
+        for f in fields:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    st = rng.integers(-40, 160, (B, S)).astype(np.int32)
+    o.set_i32("shop.stock", st); d.set_i32("shop.stock", st)
+    for T in (12, 5):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, True)
+    stg = o.get_i32("env.stage").copy()
+    stg[::2] = 1 - stg[::2]
+    o.set_i32("env.stage", stg); d.set_i32("env.stage", stg)
+    for T in (9, 30):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, True)
+        for f in fields:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after an off-chain stage, T={T}")
+    assert (d.err == 0).all()
+    # (the time-parallel FSM kernel's plan needs num_steps >= 20 and <= 40 KB of LDS: 51-shop envs take 48-pair blocks that exceed it)
+    # and a position table whose lookbacks fit; the SC64 shape meets every precondition)
+    tp_ok = (S, K, num_steps) == (9, 6, 100)
+    if variants["rollout"] != "time_parallel" or tp_ok:
+        assert any(kernel in u for u in used), (kernel, used)
+
+
+def test_config2_full_size_per_step_matches_oracle():
+    """BASELINE configs[1] in the drop-in env.step() mode: SC64, B = 4096, twelve phx_step launches of the fused step
+    kernel (device-RNG orders, random actions) against the oracle on every host core -- obs f32 / rewards f64 by bit
+    pattern, flags, state (VERDICT r2 weak #1: the oracle comparison stopped at B <= 192)."""
+    B, S = 4096, 9
+    env = supply_chain_env(S, [6] * S, 100, B, seed=42)
+    o, d = OracleEnv(env.spec, threads=NCPU), _dev(env.spec)
+    assert d.dev.uses_fused
+    o.reset(); d.reset()
+    rng = np.random.default_rng(1234)
+    for t in range(12):
+        a = (rng.random((B, S), dtype=np.float32) * 100.0).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+        assert "phx_sc_step_kernel" in d.dev.last_kernel()
+        np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs), err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d.truncated, o.truncated); np.testing.assert_array_equal(d.terminated, o.terminated)
+    for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
+    assert (d.err == 0).all()
