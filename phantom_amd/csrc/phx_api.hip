@@ -887,6 +887,14 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     sio.err = io->err;
     GenArgs g; memset(&g, 0, sizeof g); g.io = sio; g.inject = e->inject_dev; g.n_inject = 0; g.resolve_only = 0; g.timing = nullptr;
     g.roll = *io; g.roll_actions_in = io->actions; g.roll_actions = (float*)(base + gs.actions);
+    if (e->d.variant_rollout != PHX_VR_LAUNCH_LOOP) {
+      // ONE launch: the kernel loops over the T steps itself (GenArgs::roll_T) -- queues, staged tables and the env's
+      // workgroup stay resident; policy, trajectory row, the caller's reset and the last observation are in the loop
+      sio.exo = io->exo; sio.msg_log = io->msg_log; sio.msg_count = io->msg_count;
+      g.io = sio; g.roll_t = 0; g.roll_T = io->T;
+      HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
+      return PHX_OK;
+    }
     for (int t = 0; t < io->T; ++t) {            // one launch per step: policy + step + trajectory row + the caller's reset
       sio.exo = io->exo ? io->exo + (int64_t)t * e->d.B * e->d.n_exo : nullptr;
       sio.msg_log = io->msg_log ? io->msg_log + (int64_t)t * e->d.B * e->d.trace_cap : nullptr;   // rollout.py:369-373

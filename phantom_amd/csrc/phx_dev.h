@@ -153,6 +153,8 @@ struct GenArgs {               // arguments of the generic engine kernel
   // launch-loop rollout (phx_rollout on the generic engine): the policy, the trajectory row of step roll_t and
   // the caller's reset at an episode end are fused into the step kernel (roll_t < 0: a plain phx_step)
   int32_t roll_t;
+  int32_t roll_T;               // > 0: the kernel itself loops over steps roll_t .. roll_t + roll_T - 1 (queues, tables and the env's
+                                // workgroup stay resident; io.exo / io.msg_log / io.msg_count are then [T][B][..] bases); 0: one step
   const float* roll_actions_in; // [T][B][S] replayed policy or NULL -> random policy
   float* roll_actions;          // [B][S] scratch the acting phase reads (= io.actions)
   phx_rollout_io roll;

@@ -676,12 +676,6 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   int* goff = first + A;
   uint8_t* live = (uint8_t*)(goff + A);
 
-  // the env's scalar words first: their round trip overlaps the table copy below
-  const bool full = !g.resolve_only;
-  const int step_in = fld<int32_t>(sp, F_ENV_STEP)[b];
-  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-  const int clock0 = fld<int32_t>(sp, F_ENV_CLOCK)[b];
-  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
   // static topology tables: LDS copies behind the queues (TABLDS) or the global arrays
   Topo tp = topo_env(sp, b);
   tp.kmax = KMAX;
@@ -708,6 +702,19 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
   uint8_t* trunc = fld<uint8_t>(sp, F_ENV_TRUNC) + (int64_t)b * S;
 
+  // ---- the T-step loop of a rollout launch (GenArgs::roll_T > 0: rollout.py:300-363 for this env instance with the queues,
+  //      the staged tables and the workgroup resident; the env's words and agent state stay in the blob, L2-hot) ----------
+  const int n_steps = g.roll_T > 0 ? g.roll_T : 1;
+  for (int it = 0; it < n_steps; ++it) {
+  PHX_REFRESH();
+  const int roll_t = g.roll_t >= 0 ? g.roll_t + it : -1;       // trajectory row of this step (-1: a plain phx_step)
+  const int64_t step_env = (g.roll_T > 0 ? (int64_t)it * sp.B : 0) + b;   // row of the per-step [T][B][..] inputs / logs
+  // the env's scalar words (a later step reads what the previous one's epilogue / reset wrote: same workgroup, one L1)
+  const bool full = !g.resolve_only;
+  const int step_in = fld<int32_t>(sp, F_ENV_STEP)[b];
+  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
+  const int clock0 = fld<int32_t>(sp, F_ENV_CLOCK)[b];
+  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
   const int t = full ? step_in + 1 : step_in;                  // env.py:252
   int list = 0;                                                // which acting list / mask row
   if (sp.env_type == PHX_ENV_FSM) list = cur_stage;                          // fsm.py:276
@@ -719,8 +726,8 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     const int s = tp.strat_rank[a];
     live[a] = (g.resolve_only || s < 0) ? 1 : !(term[s] | trunc[s]);
   }
-  if (g.roll_t >= 0) {
-    // the policy of a launch-loop rollout, fused: every strategic agent's action of this tick (random policy = the
+  if (roll_t >= 0) {
+    // the policy of a rollout, fused: every strategic agent's action of this tick (random policy = the
     // agent's word of the tick, rank j mapped onto the kind's action space), recorded in the trajectory whether or not it acts
     for (int s = tid; s < S; s += NT) {
       const int a = sp.strat_idx[s], kind = tkind(tp, a);
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
       if (sp.env_type == PHX_ENV_STACKELBERG) acts = sp.act_mask[(int64_t)list * A + a] != 0;
       float action = 0.f;
       if (acts) {
-        if (g.roll_actions_in) action = g.roll_actions_in[((int64_t)g.roll_t * sp.B + b) * S + s];
+        if (g.roll_actions_in) action = g.roll_actions_in[((int64_t)roll_t * sp.B + b) * S + s];
         else {
           uint32_t j;
           rng_group_y(sp.seed, sp.env_offset + b, tick, s, 0, 0, &j);
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
         }
       }
       g.roll_actions[(int64_t)b * S + s] = action;
-      g.roll.action_out[((int64_t)g.roll_t * sp.B + b) * S + s] = action;
+      g.roll.action_out[((int64_t)roll_t * sp.B + b) * S + s] = action;
     }
   }
   __syncthreads();
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   const int n_items = g.n_inject + n_act;
   const float* actions_b = g.io.actions ? g.io.actions + (int64_t)b * S : nullptr;
   const uint8_t* av_b = g.io.action_valid ? g.io.action_valid + (int64_t)b * S : nullptr;
-  const uint8_t* exo_b = g.io.exo ? g.io.exo + (int64_t)b * sp.n_exo : nullptr;
+  const uint8_t* exo_b = g.io.exo ? g.io.exo + step_env * sp.n_exo : nullptr;
 
   // per-item message counts -> exclusive scan -> queue offsets (scanbuf holds scan_cap >= n_items)
   for (int it = tid; it < n_items; it += NT) {
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   if (full)
     for (int a = tid; a < A; a += NT) if (live[a]) pre_resolution(sp, tp, b, a, t);
 
-  phx_msg_rec* log_b = g.io.msg_log ? g.io.msg_log + (int64_t)b * sp.trace_cap : nullptr;
+  phx_msg_rec* log_b = g.io.msg_log ? g.io.msg_log + step_env * sp.trace_cap : nullptr;
   if (log_b)                                                    // Resolver.push tracking, resolvers.py:41-42
     for (int i = tid; i < n; i += NT)
       if (i < sp.trace_cap) {
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
 
   if (tid == 0) {
     fld<int32_t>(sp, F_ENV_CLOCK)[b] = clock;
-    if (g.io.msg_count) g.io.msg_count[b] = log_n;
+    if (g.io.msg_count) g.io.msg_count[step_env] = log_n;
     if (g.io.err && g.io.err[b] == 0 && s_errkey != ERRKEY_NONE) g.io.err[b] = s_errkey & 15;
   }
   if (g.resolve_only) return;
@@ -1015,12 +1022,12 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   GTICK(13);
   strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc, next_in);
   GTICK(14);
-  if (g.roll_t >= 0) {                                         // the step's outputs -> trajectory row roll_t
+  if (roll_t >= 0) {                                           // the step's outputs -> trajectory row roll_t
     __syncthreads();
     const phx_step_io& st = g.io; const phx_rollout_io& io = g.roll;
     const uint8_t at = st.all_terminated[b], au = st.all_truncated[b];
     for (int s = tid; s < S; s += NT) {
-      const int64_t i = (int64_t)b * S + s, o = ((int64_t)g.roll_t * sp.B + b) * S + s;
+      const int64_t i = (int64_t)b * S + s, o = ((int64_t)roll_t * sp.B + b) * S + s;
       for (int d = 0; d < sp.D; ++d) io.obs[o * sp.D + d] = st.obs[i * sp.D + d];
       io.reward[o] = (float)st.reward[i];
       io.terminated[o] = (uint8_t)(st.terminated[i] | at);
@@ -1032,7 +1039,13 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
       __syncthreads();
       reset_env<NT>(sp, b, nullptr, nullptr, st.obs, st.obs_valid, KMAX);
     }
+    if (g.roll_T > 0 && it == n_steps - 1 && io.last_obs) {    // the observation after the fragment (after a reset: the reset's)
+      __syncthreads();
+      for (int k = tid; k < S * sp.D; k += NT) io.last_obs[(int64_t)b * S * sp.D + k] = st.obs[(int64_t)b * S * sp.D + k];
+    }
   }
+  __syncthreads();                                             // the next step reads the words and the state this one wrote
+  }   // steps of the launch
 #ifdef PHX_TIMING
   if (g.timing && threadIdx.x == 0 && blockIdx.x < 64) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
 #endif
@@ -1091,7 +1104,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   int kmax = 0;
   for (int k = 0; k < PHX_KIND_COUNT; ++k) if (sp.kind_count[k] > 0) kmax = k;
   const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
-  phx_note_kernel("phx_generic_step_kernel");
+  phx_note_kernel(g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel");
 #define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)
   if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }

@@ -1,18 +1,43 @@
-import os, sys, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Time the generic message-passing engine (force_generic) on the two supply-chain shapes VERDICT names: per phx_step launch,
+and per step of a phx_rollout (T-step loop in the kernel vs the one-launch-per-step loop).
+    python tools/gen_time.py [sc64|sc256|both] [--roll-only]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from helpers import supply_chain_env
-def run(name, S, K, B, fsm, n=150):
-    env = supply_chain_env(S, [K] * S, 100, B, fsm=fsm, force_generic=True, seed=1, exogenous="device")
-    d = env._device(); env.reset()
-    acts = [torch.rand(B, S, device="cuda") * 100 for _ in range(4)]
-    for i in range(20): d.step(acts[i % 4])
-    torch.cuda.synchronize()
+
+
+def ev(fn, n):
+    fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for i in range(n): d.step(acts[i % 4])
+    for _ in range(n):
+        fn()
     e1.record(); torch.cuda.synchronize()
-    print(f"{name:30s} {e0.elapsed_time(e1) / n * 1e3:8.2f} us/step", flush=True)
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def run(name, S, K, B, fsm, n=150, T=50, roll_only=False):
+    if not roll_only:
+        env = supply_chain_env(S, [K] * S, 100, B, fsm=fsm, force_generic=True, seed=1, exogenous="device")
+        d = env._device(); env.reset()
+        acts = [torch.rand(B, S, device="cuda") * 100 for _ in range(4)]
+        k = [0]
+        def one():
+            d.step(acts[k[0] % 4]); k[0] += 1
+        print(f"{name:28s} phx_step                     {ev(one, n):8.2f} us/step   [{d.last_kernel()}]", flush=True)
+        del env, d
+    for var in ("auto", "launch_loop"):
+        env = supply_chain_env(S, [K] * S, 100, B, fsm=fsm, force_generic=True, seed=1, exogenous="device", variants={"rollout": var})
+        d = env._device(); env.reset()
+        tr = d.rollout(T)
+        us = ev(lambda: d.rollout(T, out=tr), 4)
+        print(f"{name:28s} phx_rollout T={T:3d} {var:12s} {us / T:8.2f} us/step   [{d.last_kernel()}]", flush=True)
+        del env, d, tr
+
+
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
-if which in ("sc64", "both"): run("SC64 B=4096 generic", 9, 6, 4096, False)
-if which in ("sc256", "both"): run("SC256-FSM B=8192 generic", 51, 4, 8192, True, n=90)
+ro = "--roll-only" in sys.argv
+if which in ("sc64", "both"): run("SC64 B=4096 generic", 9, 6, 4096, False, roll_only=ro)
+if which in ("sc256", "both"): run("SC256-FSM B=8192 generic", 51, 4, 8192, True, n=90, roll_only=ro)
