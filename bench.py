@@ -685,19 +685,28 @@ def bench_rllib_adapter(env, B, S):
     be = BatchedBaseEnv(env)
     res = {"envs": B}
     acts = torch.rand(B, S, device=env._device().device) * 100.0
-    for mode, n in (("tensor", 50), ("multi_env_dict", 5)):
-        be.try_reset_all() if hasattr(be, "try_reset_all") else None
+    ids = sorted(be.get_agent_ids())
+    for mode, n in (("tensor", 50), ("multi_env_dict", 5), ("multi_env_dict_rows_read", 3)):
+        env.reset()
+        be._pending = None
         obs = be.poll()
         t0 = time.perf_counter()
         for _ in range(n):
-            if mode == "tensor":
+            if mode == "tensor":                 # [B, S] tensor in, one D2H copy out, lazy MultiEnvDicts (nothing read)
                 be.send_action_tensor(acts)
-            else:
-                be.send_actions(be.random_action_dict(obs[0]))
+            else:                                # RLlib's MultiEnvDict in: B x S python entries converted once
+                be.send_actions({b: {aid: 50.0 for aid in ids} for b in range(B)})
             obs = be.poll()
+            if mode == "multi_env_dict_rows_read":   # and every env's observation / reward row materialised, as a sampler would
+                for b in range(B):
+                    row, rw = obs[0][b], obs[1][b]
+                    for aid in ids:
+                        row[aid], rw.get(aid)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         res[mode] = {"ms_per_step": dt * 1e3, "agent_steps_per_sec": N_AGENTS * B / dt, "steps": n}
+    res["note"] = ("poll() + send per step at full batch through phantom_amd.rllib.BatchedBaseEnv: tensor = send_action_tensor; "
+                   "multi_env_dict = RLlib's send_actions(MultiEnvDict); rows_read also reads every (env, agent) entry back")
     return res
 
 

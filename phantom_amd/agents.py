@@ -8,6 +8,7 @@ read back lazily through attribute access (so ``env["SHOP"].stock`` and
 ``SimpleAgentMetric("SHOP", "stock")``-style reflection keep working, metrics.py:230-231).
 """
 from dataclasses import dataclass
+import numpy as np
 from typing import Dict, Optional, Tuple
 
 from . import _abi
@@ -150,6 +151,20 @@ class Box:
 
     def __repr__(self):
         return f"Box({self.low}, {self.high}, {self.shape})"
+
+    def sample(self):
+        """uniform over [low, high) where both are finite, else a standard normal shifted to the finite bound
+        (gym.spaces.Box.sample's rule, with numpy's global stream)."""
+        lo, hi = float(self.low), float(self.high)
+        if np.isfinite(lo) and np.isfinite(hi):
+            return np.random.uniform(lo, hi, self.shape).astype(self.dtype)
+        base = lo if np.isfinite(lo) else (hi if np.isfinite(hi) else 0.0)
+        x = np.abs(np.random.normal(size=self.shape)) if np.isfinite(lo) else np.random.normal(size=self.shape)
+        return (base + (x if np.isfinite(lo) or not np.isfinite(hi) else -np.abs(x))).astype(self.dtype)
+
+    def contains(self, x) -> bool:
+        x = np.asarray(x)
+        return x.shape == self.shape and bool((x >= self.low).all() and (x <= self.high).all())
 
 
 # --------------------------------------------------------------------------------------

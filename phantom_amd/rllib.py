@@ -1,9 +1,12 @@
 """Caller-side adapters: what RLlib-facing code of the reference touches on an env
 (phantom/utils/rllib/wrapper.py:10-57, train.py:185-187,294-297, rollout.py:300-363).
 
-``ray`` is not a dependency: these classes are duck-typed to the interfaces RLlib calls
-(`MultiAgentEnv.step/reset`, `BaseEnv.poll/send_actions/try_reset/get_sub_environments`), and
-parity with ray[rllib]==2.7.1 itself is unpinned (ray is absent from the build image).
+``ray`` is not a dependency.  When ``ray.rllib`` is importable ``RLlibEnvWrapper`` subclasses its ``MultiAgentEnv`` and
+``BatchedBaseEnv`` its ``BaseEnv`` (so ``isinstance`` checks in RLlib's env runners pass); otherwise the same
+classes stand on ``object``.  Method names, arities and keyword names follow ray[rllib]==2.7.1 (the reference's pin,
+pyproject.toml) -- ``tests/rllib_stub.py`` transcribes them and ``tests/test_rllib_conformance.py`` checks both
+classes against that transcript and drives them with an RLlib-style sampling loop.  Parity with ray itself stays
+unpinned (ray is absent from the build image).
 """
 from collections.abc import Mapping
 from typing import Any, Dict, Optional, Tuple
@@ -12,8 +15,26 @@ import numpy as np
 
 from .message import AgentID
 
+try:                                        # pragma: no cover - ray is absent from the build image
+    from ray.rllib import MultiAgentEnv as _MultiAgentEnvBase
+    from ray.rllib.env.base_env import BaseEnv as _BaseEnvBase
+except Exception:                           # noqa: BLE001
+    _MultiAgentEnvBase = object
+    _BaseEnvBase = object
 
-class RLlibEnvWrapper:
+
+def _space_dict(spaces: Dict):
+    """gym.spaces.Dict as in wrapper.py:23-35 when gymnasium is importable, else the plain dict."""
+    try:                                    # pragma: no cover - gymnasium is absent from the build image
+        import gymnasium as gym
+        if all(isinstance(v, gym.Space) for v in spaces.values()):
+            return gym.spaces.Dict(spaces)
+    except Exception:                       # noqa: BLE001
+        pass
+    return spaces
+
+
+class RLlibEnvWrapper(_MultiAgentEnvBase):
     """wrapper.py:10-57: pass-through ``step`` / ``reset`` + attribute delegation.  With
     ``batch_size == 1`` the wrapped env returns exactly the reference's dict shapes."""
 
@@ -21,8 +42,11 @@ class RLlibEnvWrapper:
         self.env = env
         self.env.reset()
         self._agent_ids = self.env.strategic_agent_ids
-        self.action_space = {aid: env.agents[aid].action_space for aid in self._agent_ids}
-        self.observation_space = {aid: env.agents[aid].observation_space for aid in self._agent_ids}
+        self.action_space = _space_dict({aid: env.agents[aid].action_space for aid in self._agent_ids})
+        self.observation_space = _space_dict({aid: env.agents[aid].observation_space for aid in self._agent_ids})
+        if _MultiAgentEnvBase is not object:                # wrapper.py:37 -- after the spaces, as the reference does
+            super().__init__()
+        self._agent_ids = self.env.strategic_agent_ids
 
     def get_agent_ids(self):
         return set(self._agent_ids)
@@ -34,10 +58,18 @@ class RLlibEnvWrapper:
               ) -> Tuple[Dict[AgentID, Any], Dict[str, Any]]:
         return self.env.reset(seed, options)
 
+    def to_base_env(self, make_env=None, num_envs: int = 1, remote_envs: bool = False,
+                    remote_env_batch_wait_ms: int = 0, restart_failed_sub_environments: bool = False):
+        """what RLlib's env runners call to vectorise an env (convert_to_base_env): instead of RLlib's python list of
+        sub-envs, the wrapped env's own batch IS the vector env (``batch_size`` instances, one launch per step)."""
+        return BatchedBaseEnv(self.env)
+
     def is_terminated(self):
         return self.env.is_terminated()
 
     def __getattr__(self, name: str) -> Any:
+        if name == "env":                                   # not yet set (unpickling / failed __init__): no recursion
+            raise AttributeError(name)
         return getattr(self.env, name)
 
     def __getitem__(self, agent_id: AgentID):
@@ -45,6 +77,21 @@ class RLlibEnvWrapper:
 
     def __str__(self):
         return f"<{type(self).__name__}{self.env}>"
+
+
+def register_env(name: str, env_class, registry=None):
+    """train.py:185-187: ``ray.tune.registry.register_env(env_class.__name__, lambda config:
+    RLlibEnvWrapper(env_class(**config)))``.  ``registry``: anything with ``register_env(name, creator)``
+    (default: ray.tune.registry when importable).  Returns the creator."""
+    creator = lambda config: RLlibEnvWrapper(env_class(**config))      # noqa: E731
+    if registry is None:
+        try:                                # pragma: no cover
+            import ray.tune.registry as registry
+        except Exception:                   # noqa: BLE001
+            registry = None
+    if registry is not None:
+        registry.register_env(name, creator)
+    return creator
 
 
 class _EnvRow(Mapping):
@@ -121,24 +168,108 @@ class SubEnvView:
         return getattr(self._env, name)
 
 
-class BatchedBaseEnv:
-    """BaseEnv-shaped poll / send_actions over one batched device env: the list-of-envs loop of
-    rollout.py:361-363 becomes one launch; results are lazy per-env mappings."""
+class _Rows(Mapping):
+    """MultiEnvDict {env_id: row} over batched arrays: ONE object per poll() result; the per-env row views are built when
+    an env id is read (5 dicts of B entries + 5 B row objects per step were ~20 k python objects at B = 4096)."""
+
+    def __init__(self, n: int, make_row):
+        self._n, self._make = n, make_row
+
+    def __getitem__(self, b):
+        b = int(b)
+        if not 0 <= b < self._n:
+            raise KeyError(b)
+        return self._make(b)
+
+    def __iter__(self):
+        return iter(range(self._n))
+
+    def __len__(self):
+        return self._n
+
+
+class BatchedBaseEnv(_BaseEnvBase):
+    """ray.rllib.env.base_env.BaseEnv over ONE batched device env: the list-of-envs loop of rollout.py:361-363 (and of
+    RLlib's vector env) becomes one launch.
+
+    * ``poll()`` -> (obs, rewards, terminateds, truncateds, infos, off_policy_actions), each a MultiEnvDict
+      ``{env_id: {agent_id: value}}`` (lazy mappings; ``"__all__"`` in the done dicts);
+    * ``send_actions(action_dict)`` takes RLlib's MultiEnvDict ``{env_id: {agent_id: action}}`` and converts it ONCE into
+      the f32 [B, S] action tensor + the u8 [B, S] "agent has an action" mask (env.py:330);
+    * ``send_action_tensor(actions, action_valid=None)`` is the tensor fast path (no python per env);
+    * ``try_reset(env_id=None, *, seed=None, options=None)`` -> (obs MultiEnvDict, infos MultiEnvDict)."""
 
     def __init__(self, env) -> None:
         self.env = env
         self._ids = env.strategic_agent_ids
+        self._col = {aid: s for s, aid in enumerate(self._ids)}
         self._pending = None
         self._first = True
 
+    # ---- BaseEnv surface -----------------------------------------------------------------------------------------
     @property
     def num_envs(self) -> int:
         return self.env.batch_size
 
-    def get_sub_environments(self):
-        return [SubEnvView(self.env, b) for b in range(self.env.batch_size)]
+    @property
+    def envs(self):
+        """``base_env.envs[0]`` of RLlibMetricLogger.on_episode_step (train.py:294-297)."""
+        return self.get_sub_environments()
 
-    def try_reset(self, env_id: Optional[int] = None):
+    @property
+    def observation_space(self):
+        return _space_dict({aid: self.env.agents[aid].observation_space for aid in self._ids})
+
+    @property
+    def action_space(self):
+        return _space_dict({aid: self.env.agents[aid].action_space for aid in self._ids})
+
+    def get_agent_ids(self):
+        return set(self._ids)
+
+    def get_sub_environments(self, as_dict: bool = False):
+        B = self.env.batch_size
+        if as_dict:
+            return {b: SubEnvView(self.env, b) for b in range(B)}
+        return [SubEnvView(self.env, b) for b in range(B)]
+
+    def try_render(self, env_id: Optional[int] = None) -> None:
+        return None
+
+    def to_base_env(self, make_env=None, num_envs: int = 1, remote_envs: bool = False,
+                    remote_env_batch_wait_ms: int = 0, restart_failed_sub_environments: bool = False):
+        return self
+
+    def action_space_sample(self, agent_id: Optional[list] = None):
+        ids = self._ids if agent_id is None else [a for a in self._ids if a in agent_id]
+        return {b: {aid: self.env.agents[aid].action_space.sample() for aid in ids} for b in range(self.env.batch_size)}
+
+    def observation_space_sample(self, agent_id: Optional[list] = None):
+        ids = self._ids if agent_id is None else [a for a in self._ids if a in agent_id]
+        return {b: {aid: self.env.agents[aid].observation_space.sample() for aid in ids} for b in range(self.env.batch_size)}
+
+    def observation_space_contains(self, x) -> bool:
+        return all(self.env.agents[aid].observation_space.contains(v) for row in x.values() for aid, v in row.items())
+
+    def action_space_contains(self, x) -> bool:
+        return all(self.env.agents[aid].action_space.contains(np.asarray(v, dtype=np.float32).reshape(
+            self.env.agents[aid].action_space.shape)) for row in x.values() for aid, v in row.items())
+
+    def last(self):
+        """the most recent poll() result again (BaseEnv.last); None before the first poll"""
+        return getattr(self, "_last", None)
+
+    def stop(self) -> None:
+        dev = getattr(self.env, "_dev", None)
+        if dev is not None:
+            dev.close()
+
+    def try_restart(self, env_id: Optional[int] = None) -> None:
+        """RLlib calls this after a sub-env fault; the device env has no per-instance process to restart: reset it."""
+        self.try_reset(env_id)
+
+    def try_reset(self, env_id: Optional[int] = None, *, seed: Optional[int] = None,
+                  options: Optional[Dict[str, Any]] = None):
         mask = None
         if env_id is not None:
             mask = np.zeros(self.env.batch_size, dtype=np.uint8)
@@ -148,26 +279,50 @@ class BatchedBaseEnv:
         obs, valid = dev.reset(mask, sampler_values, conn_on)
         self.env._host_reset(mask)
         o, v = obs.cpu().numpy(), valid.cpu().numpy()
-        rows = {b: _EnvRow(self._ids, o, v, b) for b in
-                (range(self.env.batch_size) if env_id is None else [env_id])}
-        return rows, {b: {} for b in rows}
+        ids = self._ids
+        if env_id is None:
+            B = self.env.batch_size
+            return _Rows(B, lambda b: _EnvRow(ids, o, v, b)), _Rows(B, lambda b: {})
+        return {env_id: _EnvRow(ids, o, v, env_id)}, {env_id: {}}
 
-    def send_actions(self, action_tensor) -> None:
-        """actions for every env instance as one f32 [B, S] tensor (device or host)."""
+    def send_actions(self, action_dict) -> None:
+        """RLlib's signature: ``action_dict`` is a MultiEnvDict {env_id: {agent_id: action}}; an agent missing from an
+        env's dict did not act (``aid in actions``, env.py:330).  Converted once into the [B, S] tensors."""
+        if not isinstance(action_dict, Mapping):
+            raise TypeError("send_actions takes RLlib's MultiEnvDict {env_id: {agent_id: action}}; "
+                            "for a [B, S] action tensor use send_action_tensor()")
+        import torch
+        B, S = self.env.batch_size, len(self._ids)
+        act = np.zeros((B, S), dtype=np.float32)
+        valid = np.zeros((B, S), dtype=np.uint8)
+        col = self._col
+        for b, row in action_dict.items():
+            for aid, a in row.items():
+                s = col[aid]
+                act[b, s] = a if np.isscalar(a) else np.asarray(a, dtype=np.float32).reshape(-1)[0]
+                valid[b, s] = 1
+        dev = self.env._device()
+        self._pending = self.env.step_tensors(torch.from_numpy(act).to(dev.device),
+                                              torch.from_numpy(valid).to(dev.device))
+
+    def send_action_tensor(self, action_tensor, action_valid=None) -> None:
+        """the fast path: actions of every env instance as one f32 [B, S] tensor (device or host)."""
         import torch
         dev = self.env._device()
         a = torch.as_tensor(action_tensor, dtype=torch.float32).to(dev.device).contiguous()
-        self._pending = self.env.step_tensors(a)
+        if action_valid is not None:
+            action_valid = torch.as_tensor(action_valid, dtype=torch.uint8).to(dev.device).contiguous()
+        self._pending = self.env.step_tensors(a, action_valid)
 
     def poll(self):
+        B = self.env.batch_size
+        ids = self._ids
         if self._pending is None:
             rows, infos = self.try_reset()
-            B = self.env.batch_size
-            empty = {b: {} for b in range(B)}
-            return rows, empty, {b: {"__all__": False} for b in range(B)}, \
-                {b: {"__all__": False} for b in range(B)}, infos, {}
+            self._last = (rows, _Rows(B, lambda b: {}), _Rows(B, lambda b: {"__all__": False}),
+                          _Rows(B, lambda b: {"__all__": False}), infos, _Rows(B, lambda b: {}))
+            return self._last
         self._pending = None
-        B = self.env.batch_size
         h = self.env._device().pull_step()                         # one device-to-host copy; copies: the
         h = {k: v.copy() for k, v in h.items()}                    # rows outlive the next step
         obs, ov = h["obs"], h["obs_valid"]
@@ -175,9 +330,10 @@ class BatchedBaseEnv:
         term, trunc = h["terminated"].astype(bool), h["truncated"].astype(bool)
         dv = h["done_valid"]
         at, au = h["all_terminated"].astype(bool), h["all_truncated"].astype(bool)
-        obs_d = {b: _EnvRow(self._ids, obs, ov, b) for b in range(B)}
-        rew_d = {b: _EnvRow(self._ids, rew, rv, b, scalar=True) for b in range(B)}
-        term_d = {b: _EnvRow(self._ids, term, dv, b, {"__all__": bool(at[b])}, scalar=True) for b in range(B)}
-        trunc_d = {b: _EnvRow(self._ids, trunc, dv, b, {"__all__": bool(au[b])}, scalar=True) for b in range(B)}
-        info_d = {b: _InfoRow(self._ids, ov, b) for b in range(B)}       # infos[aid] = {} (agents.py:301-306)
-        return obs_d, rew_d, term_d, trunc_d, info_d, {}
+        self._last = (_Rows(B, lambda b: _EnvRow(ids, obs, ov, b)),
+                _Rows(B, lambda b: _EnvRow(ids, rew, rv, b, scalar=True)),
+                _Rows(B, lambda b: _EnvRow(ids, term, dv, b, {"__all__": bool(at[b])}, scalar=True)),
+                _Rows(B, lambda b: _EnvRow(ids, trunc, dv, b, {"__all__": bool(au[b])}, scalar=True)),
+                _Rows(B, lambda b: _InfoRow(ids, ov, b)),          # infos[aid] = {} (agents.py:301-306)
+                _Rows(B, lambda b: {}))
+        return self._last

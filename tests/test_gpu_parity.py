@@ -404,7 +404,7 @@ def test_metrics_and_rllib_adapters():
     rng = np.random.RandomState(0)
     for t in range(5):
         a = rng.uniform(0, 100, (B, S)).astype(np.float32)
-        base.send_actions(a)
+        base.send_action_tensor(a)
         obs, rew, term, trunc, infos, _ = base.poll()
         o.step(a, None, None)
         for b in (0, B - 1):

@@ -1,0 +1,131 @@
+"""RLlib-facing conformance of phantom_amd.rllib.  CPU part: names / arities / keyword names of
+RLlibEnvWrapper and BatchedBaseEnv against the ray[rllib]==2.7.1 transcript in tests/rllib_stub.py and against the call
+shapes the reference makes (wrapper.py:10-57, train.py:185-187,294-297, rollout.py:300-389).  GPU part: an RLlib-style
+sampling loop (poll -> policy -> send_actions(MultiEnvDict)) and the reference's own evaluation loop (_rollout_task_fn)
+driven against the oracle."""
+import inspect
+
+import numpy as np
+import pytest
+
+import phantom_amd as ph
+from phantom_amd.rllib import BatchedBaseEnv, RLlibEnvWrapper, register_env
+
+import rllib_stub as stub
+
+
+@pytest.mark.parametrize("cls,table", [(BatchedBaseEnv, stub.BASE_ENV), (RLlibEnvWrapper, stub.MULTI_AGENT_ENV)])
+def test_method_names_and_signatures_follow_the_transcript(cls, table):
+    for name, sig in table.items():
+        assert hasattr(cls, name), f"{cls.__name__}.{name} is missing"
+        problems = stub.accepts_like(getattr(cls, name), sig)
+        assert not problems, f"{cls.__name__}.{name}: {problems}"
+    if cls is BatchedBaseEnv:
+        for prop in stub.BASE_ENV_PROPERTIES:
+            assert isinstance(inspect.getattr_static(cls, prop), property), prop
+
+
+def test_the_references_call_shapes_bind():
+    for name, args, kwargs in stub.REFERENCE_CALLS_WRAPPER:
+        assert stub.binds(getattr(RLlibEnvWrapper, name), (None,) + args, kwargs), (name, args, kwargs)
+    for name, args, kwargs in stub.REFERENCE_CALLS_BASE_ENV:
+        assert stub.binds(getattr(BatchedBaseEnv, name), (None,) + args, kwargs), (name, args, kwargs)
+    # RLlib's signature only: a tensor is NOT a MultiEnvDict
+    be = BatchedBaseEnv.__new__(BatchedBaseEnv)
+    with pytest.raises(TypeError):
+        BatchedBaseEnv.send_actions(be, np.zeros((2, 3), np.float32))
+
+
+def test_register_env_creator_matches_train_py():
+    """train.py:185-187: register_env(env_class.__name__, lambda config: RLlibEnvWrapper(env_class(**config)))"""
+    seen = {}
+
+    class Registry:
+        @staticmethod
+        def register_env(name, creator):
+            seen[name] = creator
+
+    creator = register_env("SupplyChainEnv", ph.SupplyChainEnv, registry=Registry)
+    assert seen["SupplyChainEnv"] is creator and callable(creator)
+    assert inspect.signature(creator).parameters.keys() == {"config"}
+
+
+def test_wrapper_subclasses_multi_agent_env_when_ray_is_importable():
+    try:
+        from ray.rllib import MultiAgentEnv
+    except Exception:
+        assert RLlibEnvWrapper.__mro__[1] is object          # ray absent: same class on `object`
+        return
+    assert issubclass(RLlibEnvWrapper, MultiAgentEnv)        # pragma: no cover
+
+
+# ---- GPU: an RLlib-style sampler and the reference's evaluation loop against the oracle ----------------------------
+@pytest.mark.gpu
+def test_env_runner_style_loop_with_multi_env_dicts_matches_oracle():
+    from helpers import supply_chain_env
+    from oracle import OracleEnv
+    B, S, K, NS = 12, 3, 2, 6
+    env = supply_chain_env(S, [K] * S, NS, B, seed=9, exogenous="device")
+    o = OracleEnv(env.spec)
+    base = RLlibEnvWrapper(env).to_base_env(num_envs=B)
+    assert isinstance(base, BatchedBaseEnv) and base.num_envs == B and base.get_agent_ids() == {"SHOP0", "SHOP1", "SHOP2"}
+    o.reset()
+    rng = np.random.RandomState(1)
+    obs, rew, term, trunc, infos, off = base.poll()              # first poll: reset observations
+    assert len(obs) == B and set(obs.keys()) == set(range(B)) and off[0] == {}
+    for t in range(2 * NS + 1):
+        # "policy": one action per (env, agent) that has an observation; SHOP1 of env 3 sits every third step out
+        actions = {b: {aid: [float(rng.uniform(0, 100))] for aid in obs[b] if not (b == 3 and aid == "SHOP1" and t % 3 == 0)}
+                   for b in obs}
+        assert base.action_space_contains(actions)
+        base.send_actions(actions)
+        a = np.zeros((B, S), np.float32); av = np.zeros((B, S), np.uint8)
+        for b, row in actions.items():
+            for aid, v in row.items():
+                a[b, int(aid[4:])] = v[0]; av[b, int(aid[4:])] = 1
+        o.step(a, av, None)
+        obs, rew, term, trunc, infos, off = base.poll()
+        assert base.last()[0] is obs
+        for b in range(B):
+            assert set(obs[b]) == {f"SHOP{s}" for s in range(S) if o.obs_valid[b, s]}
+            for s in range(S):
+                if o.obs_valid[b, s]:
+                    np.testing.assert_array_equal(obs[b][f"SHOP{s}"], o.obs[b, s])
+                    assert rew[b][f"SHOP{s}"] == o.reward[b, s] and infos[b][f"SHOP{s}"] == {}
+            assert trunc[b]["__all__"] == bool(o.all_truncated[b]) and term[b]["__all__"] == bool(o.all_terminated[b])
+        done = [b for b in range(B) if trunc[b]["__all__"] or term[b]["__all__"]]
+        if done:                                                  # RLlib resets finished sub-envs one by one
+            m = np.zeros(B, np.uint8); m[done] = 1
+            oo, ov = o.reset(mask=m)
+            for b in done:
+                r_obs, r_info = base.try_reset(b, seed=None, options=None)
+                assert list(r_obs) == [b] and r_info == {b: {}}
+                np.testing.assert_array_equal(r_obs[b]["SHOP0"], oo[b, 0])
+            # the observations the policy sees next: the reset observations for the envs just reset
+            cur, cur_v = o.obs.copy(), o.obs_valid.copy()
+            cur[done], cur_v[done] = oo[done], ov[done]
+            obs = {b: {f"SHOP{s}": cur[b, s] for s in range(S) if cur_v[b, s]} for b in range(B)}
+    sub = base.envs[0]                                            # RLlibMetricLogger.on_episode_step: base_env.envs[0]
+    assert sub.agents["SHOP1"].stock == int(o.get_i32("shop.stock")[0, 1])
+    assert isinstance(base.get_sub_environments(as_dict=True), dict)
+    base.stop()
+
+
+@pytest.mark.gpu
+def test_reference_rollout_task_loop_runs_on_the_wrapper():
+    """rollout.py:300-389 transcribed: vec_envs -> reset(seed=...) -> per step {agent: [obs per env]} -> actions ->
+    env.step(actions) per env -> Step fields; with batch_size = 1 envs behind RLlibEnvWrapper (the reference's shapes)."""
+    np.random.seed(0)
+    vec_envs = [RLlibEnvWrapper(ph.SupplyChainEnv()) for _ in range(3)]
+    vec_observations = [env.reset(seed=i)[0] for i, env in enumerate(vec_envs)]
+    assert all(set(o) == {"SHOP"} for o in vec_observations)
+    for i in range(vec_envs[0].num_steps):
+        dict_observations = {k: [dic[k] for dic in vec_observations] for k in vec_observations[0]}
+        actions = {aid: [np.array([10.0 + i], np.float32) for _ in vec_obs] for aid, vec_obs in dict_observations.items()}
+        vec_actions = [dict(zip(actions, t)) for t in zip(*actions.values())]
+        vec_steps = [env.step(a) for env, a in zip(vec_envs, vec_actions)]
+        for st in vec_steps:
+            assert set(st.rewards) <= {"SHOP"} and "__all__" in st.truncations and isinstance(st.infos, dict)
+        vec_observations = [st.observations for st in vec_steps]
+    assert all(st.truncations["__all__"] for st in vec_steps)
+    assert vec_envs[0]["SHOP"].stock == vec_envs[0].env.agents["SHOP"].stock       # wrapper.__getitem__
