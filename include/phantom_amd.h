@@ -204,6 +204,12 @@ typedef struct phx_spec {
                                    PHX_VB_WHOLE_ENVS = whole envs per workgroup                */
   int32_t variant_step;         /* PHX_VS_*                                                   */
   int32_t variant_reserved;
+  /* ABI 6: stage handlers that decide from the clock and the current stage alone (fsm.py:294-307), tabulated by the
+   * host at spec-compile time: stage_tab[s * (num_steps + 1) + t] = the stage the handler of stage s returns when the
+   * clock reads t (1 .. num_steps; the clock is incremented before the handler runs, fsm.py:268); rows of handler-less
+   * stages hold stage_next[s].  NULL: no tabulated handler.  With a table the device takes every transition itself --
+   * phx_step (phx_step_io.next_stage == NULL) and phx_rollout alike; every entry must be allowed by stage_allowed.   */
+  const int32_t* stage_tab;
 } phx_spec;
 
 /* phx_spec.variant_rollout: which kernel phx_rollout uses for a supply-chain env with a fused schedule */

@@ -844,7 +844,7 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
                          uint8_t* terminated, uint8_t* truncated, uint8_t* done_valid,
                          uint8_t* all_term, uint8_t* all_trunc) {
   const int A = E->A, S = E->S, D = E->D;
-  const int next_in = e->next_in; e->next_in = -1;                    /* a stage handler's return value, this step only */
+  int next_in = e->next_in; e->next_in = -1;                    /* a stage handler's return value, this step only */
   e->step += 1;                                                       /* env.py:252 */
   e->exo_b = exo_b;
 
@@ -890,6 +890,9 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
 
   if (E->s.env_type == PHX_ENV_FSM) {
     next_stage = E->s.stage_next[cur_stage];                          /* no handler: next_stages[0]  fsm.py:281-292 */
+    /* a handler that decides from (stage, clock) alone, tabulated by the host: what env_handler() returns now, :294-302 */
+    if (next_in == -1 && E->s.stage_tab && e->step >= 0 && e->step <= E->s.num_steps)
+      next_in = E->s.stage_tab[(size_t)cur_stage * (E->s.num_steps + 1) + e->step];
     if (next_in >= 0 || next_in == -2) {                              /* env_handler() returned a stage  :294-302 */
       int ok = next_in >= 0 && next_in < E->s.n_stages &&
                (E->s.stage_allowed ? E->s.stage_allowed[(size_t)cur_stage * E->s.n_stages + next_in] != 0
@@ -1024,7 +1027,8 @@ phxo_env* phxo_create(const phx_spec* sp) {
     E->s.stage_rewarded_all = (const uint8_t*)dup_arr(sp->stage_rewarded_all, ns);
     E->s.stage_next = (const int32_t*)dup_arr(sp->stage_next, sizeof(int32_t) * ns);
     E->s.stage_allowed = sp->stage_allowed ? (const uint8_t*)dup_arr(sp->stage_allowed, (size_t)ns * ns) : NULL;
-  } else E->s.stage_allowed = NULL;
+    E->s.stage_tab = sp->stage_tab ? (const int32_t*)dup_arr(sp->stage_tab, sizeof(int32_t) * (size_t)ns * (sp->num_steps + 1)) : NULL;
+  } else { E->s.stage_allowed = NULL; E->s.stage_tab = NULL; }
   if (sp->env_type == PHX_ENV_STACKELBERG) {
     E->s.leaders = (const int32_t*)dup_arr(sp->leaders, sizeof(int32_t) * (sp->n_leaders ? sp->n_leaders : 1));
     E->s.followers = (const int32_t*)dup_arr(sp->followers, sizeof(int32_t) * (sp->n_followers ? sp->n_followers : 1));
@@ -1095,7 +1099,7 @@ void phxo_destroy(phxo_env* E) {
   free((void*)E->s.conn_rate); free((void*)E->s.col_conn);
   if (E->s.env_type == PHX_ENV_FSM) {
     free((void*)E->s.stage_act_ptr); free((void*)E->s.stage_act_idx);
-    free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next);
+    free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next); free((void*)E->s.stage_tab);
   }
   if (E->s.env_type == PHX_ENV_STACKELBERG) { free((void*)E->s.leaders); free((void*)E->s.followers); }
   free(E);

@@ -63,6 +63,7 @@ class PhxSpec(C.Structure):
         ("stage_allowed", C.c_void_p),
         ("variant_rollout", C.c_int32), ("variant_block", C.c_int32), ("variant_step", C.c_int32),
         ("variant_reserved", C.c_int32),
+        ("stage_tab", C.c_void_p),
     ]
 
 

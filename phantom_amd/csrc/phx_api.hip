@@ -57,6 +57,7 @@ struct Derived {
   std::vector<int32_t> strat_rank, strat_idx, kind_rank, exo_rank, buyer_off;
   std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
   std::vector<uint8_t> stage_allowed, stage_rew_all;
+  std::vector<int32_t> stage_tab;
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
   bool sc_static = false, stk_static = false, ads_static = false;
@@ -195,6 +196,15 @@ static int derive(const phx_spec* sp, Derived& d) {
     for (int st = 0; st < ns; ++st)
       for (int nx = 0; nx < ns; ++nx)
         d.stage_allowed[(size_t)st * ns + nx] = sp->stage_allowed ? (sp->stage_allowed[(size_t)st * ns + nx] != 0) : (nx == sp->stage_next[st]);
+    if (sp->stage_tab) {                                                      // tabulated clock / stage handlers (ABI 6)
+      d.stage_tab.assign(sp->stage_tab, sp->stage_tab + (size_t)ns * (sp->num_steps + 1));
+      for (int st = 0; st < ns; ++st)
+        for (int t = 0; t <= sp->num_steps; ++t) {
+          const int nx = d.stage_tab[(size_t)st * (sp->num_steps + 1) + t];
+          if (nx < 0 || nx >= ns || !d.stage_allowed[(size_t)st * ns + nx])
+            return fail(PHX_EINVAL, "stage_tab[%d][%d] = %d is not one of the stage's next_stages (fsm.py:304-307)", st, t, nx);
+        }
+    }
     d.obs_mask.assign((size_t)ns * A, 0); d.rew_mask.assign((size_t)ns * A, 0);
     for (int st = 0; st < ns; ++st) {
       const int nx = sp->stage_next[st];
@@ -297,7 +307,7 @@ static int derive(const phx_spec* sp, Derived& d) {
     bool ads = sp->env_type == PHX_ENV_FSM && sp->n_stages == 2 && N >= 1 && N <= 1024 && d.kind_count[PHX_KIND_PUBLISHER] == 1 &&
                d.kind_count[PHX_KIND_ADEXCHANGE] == 1 && A == N + 2 && !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
                (sp->round_limit < 0 || sp->round_limit >= 3) && (!d.dynamic_graph || (sp->flags & PHX_F_IGNORE_CONN_ERRORS)) && d.D == 3 &&
-               sp->stage_next[0] == 1 && sp->stage_next[1] == 0;
+               sp->stage_next[0] == 1 && sp->stage_next[1] == 0 && !sp->stage_tab;
     if (ads) {
       for (int a = 0; a < A; ++a) { if (sp->kind[a] == PHX_KIND_PUBLISHER) d.ads_pub = a; if (sp->kind[a] == PHX_KIND_ADEXCHANGE) d.ads_adx = a; }
       const int pub = d.ads_pub, adx = d.ads_adx;
@@ -547,6 +557,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(obs_mask, der.obs_mask.data(), der.obs_mask.size()); UP(rew_mask, der.rew_mask.data(), der.rew_mask.size());
   UP(stage_next, der.stage_next.data(), der.stage_next.size());
   UP(stage_allowed, der.stage_allowed.data(), der.stage_allowed.size());
+  d.stage_tab = nullptr;
+  if (!der.stage_tab.empty()) UP(stage_tab, der.stage_tab.data(), der.stage_tab.size());
   UP(stage_rew_all, der.stage_rew_all.data(), der.stage_rew_all.size());
   UP(reset_obs_idx, der.reset_obs_idx.data(), der.reset_obs_idx.size());
   d.n_reset_obs = (int)der.reset_obs_idx.size();
@@ -604,7 +616,9 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       ok = ok && der.shop_norm[s2] == der.shop_norm[0];
     }
     for (size_t i = 0; i < der.sc_shop_flags.size(); ++i) ok = ok && (!(der.sc_shop_flags[i] & 2) || (der.sc_shop_flags[i] & 4));
-    if (ok && Ku >= 1 && Ku <= 6 && der.shop_norm[0] > 0) { d.fsm_lean_K = Ku; d.fsm_lean_norm = der.shop_norm[0]; }
+    // (tabulated handlers: the general lane-per-pair loop looks every transition up; the lean loop and the time-parallel
+    //  kernel are built on the handler-less stage chain)
+    if (ok && Ku >= 1 && Ku <= 6 && der.shop_norm[0] > 0 && !spec->stage_tab) { d.fsm_lean_K = Ku; d.fsm_lean_norm = der.shop_norm[0]; }
     // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): additionally the stage's flags are the same for every shop, the
     // env has no samplers, and along the handler-less chain from the initial stage every lookback the kernel serves from
     // its tiles is at most PHX_FSM_LB steps.  The table holds, per episode position, the flags, the lookbacks and the stage.

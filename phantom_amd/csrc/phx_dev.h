@@ -77,6 +77,7 @@ struct DevSpec {
   const uint8_t* rew_mask;       // [n_lists][A] who is rewarded
   const int32_t* stage_next;     // [n_lists]  (FSM)
   const uint8_t* stage_allowed;  // [n_lists][n_lists] FSMStage.next_stages as a matrix (handler-chosen transitions), or NULL
+  const int32_t* stage_tab;      // [n_lists][num_steps + 1] tabulated clock / stage handlers (phx_spec.stage_tab), or NULL
   const uint8_t* stage_rew_all;  // [n_lists] rewarded_agents is None (every strategic agent observes, fsm.py:315-317)
   const int32_t* reset_obs_ptr;  // agents that observe at reset: CSR with a single row
   const int32_t* reset_obs_idx;

@@ -1002,8 +1002,9 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   if (n > 0 && tid == 0) set_errkey(&s_errkey, seq_base + 1, PHX_ERR_ROUND_LIMIT);   // resolvers.py:160-163
   // a stage handler's return value (fsm.py:294-307), decided by the host: must be one of the stage's next_stages
   int next_in = -1;
-  if (full && sp.env_type == PHX_ENV_FSM && g.io.next_stage) {
-    next_in = g.io.next_stage[b];
+  if (full && sp.env_type == PHX_ENV_FSM && (g.io.next_stage || sp.stage_tab)) {
+    // the host's handler call for this step, or the tabulated handler's value at (stage, clock) -- validated at phx_create
+    next_in = g.io.next_stage ? g.io.next_stage[b] : sp.stage_tab[(int64_t)cur_stage * (sp.num_steps + 1) + (t <= sp.num_steps ? t : sp.num_steps)];
     if (next_in < 0 || next_in >= sp.n_lists || !sp.stage_allowed[(int64_t)cur_stage * sp.n_lists + next_in]) {
       if (tid == 0) set_errkey(&s_errkey, seq_base + 2, PHX_ERR_FSM_TRANSITION);     // FSMRuntimeError, after the resolution
       next_in = -1;

@@ -106,6 +106,17 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   const uint32_t tick = tick0;
 
   if (sp.env_type == PHX_ENV_FSM) fl = sp.sc_shop_flags[(int64_t)list * nS + s];
+  // the stage after this step: next_stages[0], or what a tabulated clock / stage handler returns (fsm.py:281-302); the
+  // agents acting in THAT stage observe (fsm.py:320) unless rewarded_agents is None (every strategic agent, :315-317)
+  int next_stage = 0;
+  if (sp.env_type == PHX_ENV_FSM) {
+    next_stage = sp.stage_next[cur_stage];
+    if (sp.stage_tab) {
+      next_stage = sp.stage_tab[(int64_t)cur_stage * (sp.num_steps + 1) + (t <= sp.num_steps ? t : sp.num_steps)];
+      const bool obs_next = sp.stage_rew_all[cur_stage] || (sp.sc_shop_flags[(int64_t)next_stage * nS + s] & 1);
+      fl = (fl & ~8) | (obs_next ? 8 : 0);
+    }
+  }
   const bool shop_acts = (fl & 1) != 0;
   const bool has_action = shop_acts && av_in;
   const float action = has_action ? action_in : 0.0f;
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
     fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)(tick + 1);
     if (sp.env_type == PHX_ENV_FSM) {                                         // fsm.py:355
       fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = cur_stage;
-      fld<int32_t>(sp, F_ENV_STAGE)[b] = sp.stage_next[cur_stage];
+      fld<int32_t>(sp, F_ENV_STAGE)[b] = next_stage;
     }
     io.all_terminated[b] = 0; io.all_truncated[b] = all_trunc;
   }
@@ -581,7 +592,12 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t o = (int64_t)t * total + g;
-    const int fl = s_fl[stage * nS + s];
+    int fl = s_fl[stage * nS + s];
+    int next_stage = sp.stage_next[stage];
+    if (sp.stage_tab) {                                        // a tabulated clock / stage handler's choice, fsm.py:294-302,320
+      next_stage = sp.stage_tab[(int64_t)stage * (sp.num_steps + 1) + (step + 1 <= sp.num_steps ? step + 1 : sp.num_steps)];
+      fl = (fl & ~8) | ((sp.stage_rew_all[stage] || (s_fl[next_stage * nS + s] & 1)) ? 8 : 0);
+    }
     const bool has_action = (fl & 1) != 0, any_order = (fl & 2) != 0;
     const uint8_t* cact = sp.shop_cust_act + (int64_t)stage * sp.n_exo;
     int D = 0; uint32_t aj = 0;
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     if (io.obs_valid) io.obs_valid[o] = ov;
     if (io.reward_valid) io.reward_valid[o] = rv;
     lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2]; lo[3] = ob[3];
-    prev_stage = stage; stage = sp.stage_next[stage];                        // fsm.py:355
+    prev_stage = stage; stage = next_stage;                                  // fsm.py:355
     if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
       st.stock = 0; step = 0; stage = sp.initial_stage; rcv = 0;
       if (tsrc >= 0) {                                                       // env.py:211-212, agents.py:167-168

@@ -31,18 +31,35 @@ class FSMRuntimeError(Exception):
     """fsm.py:19-23"""
 
 
+def state_independent(handler_fn):
+    """Declare a stage handler (fsm.py:294-307) that decides from the CLOCK and the CURRENT STAGE alone -- it may read
+    ``env.current_step`` / ``env.current_stage`` / ``env.num_steps`` and call ``env.resolve_network()``, nothing of the
+    agents' state.  Such a handler is tabulated once per (stage, clock value) when the env's spec is compiled
+    (phx_spec.stage_tab) and the device takes every transition itself: ``step`` needs no host callback and fused
+    ``rollout`` launches work.  Use as a decorator under ``@FSMStage(...)`` or on the function passed as ``handler=``."""
+    setattr(handler_fn, "_phx_state_independent", True)
+    return handler_fn
+
+
 class FSMStage:
-    """fsm.py:26-63"""
+    """fsm.py:26-63.  ``handler_state_independent``: see ``state_independent`` (same declaration as a flag)."""
 
     def __init__(self, stage_id: StageID, acting_agents: Sequence[AgentID],
                  rewarded_agents: Optional[Sequence[AgentID]] = None,
                  next_stages: Optional[Sequence[StageID]] = None,
-                 handler: Optional[Callable[[], StageID]] = None) -> None:
+                 handler: Optional[Callable[[], StageID]] = None,
+                 handler_state_independent: bool = False) -> None:
         self.id = stage_id
         self.acting_agents = acting_agents
         self.rewarded_agents = rewarded_agents
         self.next_stages = next_stages or []
         self.handler = handler
+        self.handler_state_independent = bool(handler_state_independent)
+
+    def is_tabulated(self) -> bool:
+        h = self.handler
+        return h is not None and (self.handler_state_independent or getattr(h, "_phx_state_independent", False)
+                                  or getattr(getattr(h, "__func__", None), "_phx_state_independent", False))
 
     def __call__(self, handler_fn):
         setattr(handler_fn, "_decorator", self)
@@ -55,7 +72,11 @@ class FiniteStateMachineEnv(PhantomEnv):
 
     def __init__(self, num_steps: int, network: Network, initial_stage: StageID,
                  env_supertype=None, agent_supertypes=None,
-                 stages: Optional[Sequence[FSMStage]] = None, **device_kwargs) -> None:
+                 stages: Optional[Sequence[FSMStage]] = None, allow_host_handlers: bool = False,
+                 **device_kwargs) -> None:
+        """``allow_host_handlers``: silence the warning about stage handlers that are NOT declared state-independent
+        (they run on the host BEFORE the device step and therefore see the agents' state before the step's acting and
+        resolution phase, fsm.py:275-302 runs them after it)."""
         super().__init__(num_steps, network, env_supertype, agent_supertypes, **device_kwargs)
         self._initial_stage = initial_stage
         self._stages: Dict[StageID, FSMStage] = {}
@@ -90,15 +111,71 @@ class FiniteStateMachineEnv(PhantomEnv):
         # Stage HANDLERS (fsm.py:294-307) are Python: they are called on the host, once per step and stage, BEFORE the
         # launch; the stage they return goes to the device as a per-env input column (phx_step_io.next_stage).  The
         # device step always resolves the network, so `self.resolve_network()` inside a handler is a no-op marker.
-        self._has_handlers = any(stage.handler is not None for stage in self._stages.values())
+        # Handlers DECLARED state-independent (``state_independent`` / ``handler_state_independent=True``) are tabulated
+        # per (stage, clock value) at spec-compile time instead and run nowhere at step time (phx_spec.stage_tab).
+        self._host_handlers = [s for s in self._stages.values() if s.handler is not None and not s.is_tabulated()]
+        self._tab_handlers = [s for s in self._stages.values() if s.is_tabulated()]
+        self._has_handlers = bool(self._host_handlers)
+        if self._host_handlers and not allow_host_handlers:
+            import warnings
+            warnings.warn(
+                "FiniteStateMachineEnv: the handler(s) of stage(s) " + ", ".join(repr(s.id) for s in self._host_handlers) +
+                " run on the host BEFORE the device step (the reference calls them after the acting phase and lets them "
+                "resolve the network, fsm.py:275-302): a handler that inspects agent state sees the PREVIOUS step's state, "
+                "and it is called once per stage for the whole batch.  Handlers that decide from the clock / the stage "
+                "alone are exact -- declare them with @phantom_amd.state_independent (or FSMStage(handler_state_independent="
+                "True)) to have them tabulated and to enable fused rollouts; pass allow_host_handlers=True to silence this.",
+                RuntimeWarning, stacklevel=3)
+        self._stage_tab = None
         self._in_handler = False
         self._chosen_next = None
         self._stage_list = list(self._stages.values())
         self._stage_index = {s.id: i for i, s in enumerate(self._stage_list)}
         self._h_stage[:] = self._stage_index[initial_stage]
 
+    def _tabulate_handlers(self):
+        """stage_tab[s][t] = index of the stage the handler of stage s returns when the clock reads t (t = 1 .. num_steps:
+        the clock is incremented before the handler runs, fsm.py:268); handler-less rows hold next_stages[0].  The
+        handler is called with the env's host mirrors set to (stage s, clock t) and ``resolve_network()`` as a no-op."""
+        if not self._tab_handlers:
+            return None
+        if self._host_handlers:
+            raise NotImplementedError("an env mixes tabulated (state-independent) and host-called stage handlers: declare "
+                                      "every handler state-independent or none")
+        ns, T = len(self._stage_list), int(self.num_steps)
+        tab = np.zeros((ns, T + 1), dtype=np.int32)
+        keep = (self._h_step.copy(), self._h_stage.copy())
+        try:
+            for si, stage in enumerate(self._stage_list):
+                if not stage.is_tabulated():
+                    tab[si, :] = self._stage_index[stage.next_stages[0]]
+                    continue
+                for t in range(1, T + 1):
+                    self._h_step[:] = t
+                    self._h_stage[:] = si
+                    self._in_handler = True
+                    try:                                                     # bound method vs decorator form, fsm.py:294-302
+                        ret = stage.handler() if hasattr(stage.handler, "__self__") else stage.handler(self)
+                    finally:
+                        self._in_handler = False
+                    if not (isinstance(ret, str) or np.isscalar(ret)):
+                        vals = list(ret)
+                        if any(v != vals[0] for v in vals):
+                            raise FSMRuntimeError(f"state-independent handler of '{stage.id}' returned different stages for "
+                                                  f"different env instances at clock {t}")
+                        ret = vals[0]
+                    if ret not in stage.next_stages:                         # fsm.py:304-307
+                        raise FSMRuntimeError(
+                            f"FiniteStateMachineEnv attempted invalid transition from '{stage.id}' to {ret}")
+                    tab[si, t] = self._stage_index[ret]
+                tab[si, 0] = tab[si, 1]
+        finally:
+            self._h_step[:], self._h_stage[:] = keep
+        return tab
+
     def _compile(self):
-        return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_FSM,
+        self._stage_tab = self._tabulate_handlers()
+        return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_FSM, stage_tab=self._stage_tab,
                             stages=self._stage_list, initial_stage=self._initial_stage,
                             seed=self._seed, env_offset=self._env_offset,
                             force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
@@ -188,12 +265,18 @@ class FiniteStateMachineEnv(PhantomEnv):
     def rollout(self, *args, **kwargs):
         if self._has_handlers:
             raise NotImplementedError("stage handlers are Python callables evaluated per step on the host: a fused "
-                                      "on-device rollout cannot call them (use step / step_tensors)")
+                                      "on-device rollout cannot call them (use step / step_tensors), unless they are "
+                                      "declared state-independent (@phantom_amd.state_independent) and tabulated")
         return super().rollout(*args, **kwargs)
 
     def _host_advance(self):
         self._h_step += 1
         nxt = np.asarray([self._stage_index[s.next_stages[0]] if s.next_stages else 0 for s in self._stage_list])
         self.previous_stage_idx = self._h_stage.copy()                   # fsm.py:355
-        self._h_stage = nxt[self._h_stage] if self._chosen_next is None else self._chosen_next.copy()
+        if self._chosen_next is not None:
+            self._h_stage = self._chosen_next.copy()
+        elif self._stage_tab is not None:                                # the device looked the transition up (stage, clock)
+            self._h_stage = self._stage_tab[self._h_stage, np.minimum(self._h_step, self.num_steps)].astype(np.int64)
+        else:
+            self._h_stage = nxt[self._h_stage]
         self._chosen_next = None

@@ -40,6 +40,7 @@ class EnvSpec:
     stage_rewarded_all: Optional[np.ndarray] = None
     stage_next: Optional[np.ndarray] = None
     stage_allowed: Optional[np.ndarray] = None     # u8 [n_stages][n_stages]: FSMStage.next_stages as a matrix
+    stage_tab: Optional[np.ndarray] = None         # i32 [n_stages][num_steps + 1]: tabulated clock / stage handlers (or None)
     # Stackelberg
     leaders: Optional[np.ndarray] = None
     followers: Optional[np.ndarray] = None
@@ -165,6 +166,7 @@ class EnvSpec:
         s.conn_rate = ptr(self.conn_rate, np.float64) if self.n_conn else None
         s.col_conn = ptr(self.col_conn, np.int32) if self.n_conn else None
         s.variant_rollout, s.variant_block, s.variant_step = resolve_variants(self.variants)
+        s.stage_tab = ptr(self.stage_tab, np.int32) if self.stage_tab is not None else None
         return s, keep
 
 
@@ -209,7 +211,8 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                  leaders: Optional[Sequence] = None, followers: Optional[Sequence] = None,
                  seed: int = 0, env_offset: int = 0, force_generic: bool = False,
                  extra_queue: int = 16, samplers: Optional[Sequence] = None,
-                 device_sampling: bool = False, variants: Optional[Dict] = None) -> EnvSpec:
+                 device_sampling: bool = False, variants: Optional[Dict] = None,
+                 stage_tab: Optional[np.ndarray] = None) -> EnvSpec:
     from .agents import Agent, StrategicAgent, check_device_executable
     agent_ids = list(network.agents.keys())
     A = len(agent_ids)
@@ -316,6 +319,11 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         spec.stage_act_idx = np.asarray(idx, dtype=np.int32)
         spec.stage_rewarded, spec.stage_rewarded_all, spec.stage_next = rewarded, rewarded_all, nxt
         spec.stage_allowed = allowed
+        if stage_tab is not None:
+            tab = np.ascontiguousarray(stage_tab, dtype=np.int32)
+            if tab.shape != (len(stages), int(num_steps) + 1):
+                raise ValueError(f"stage_tab must have shape ({len(stages)}, {int(num_steps) + 1})")
+            spec.stage_tab = tab
     elif env_type == _abi.ENV_STACKELBERG:
         spec.leaders = np.asarray([index_of(a) for a in leaders], dtype=np.int32)
         spec.followers = np.asarray([index_of(a) for a in followers], dtype=np.int32)

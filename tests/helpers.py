@@ -49,17 +49,23 @@ def golden_restock_handler(env):
     return np.where(step % 3 == 0, "RESTOCK", "SELL").tolist() if step.ndim else ("RESTOCK" if step % 3 == 0 else "SELL")
 
 
-def handler_kw(g):
-    return {"restock_handler": golden_restock_handler} if "next_stage" in g else {}
+def handler_kw(g, tabulated=False):
+    """``tabulated``: the same handler DECLARED state-independent (phantom_amd.state_independent): it is evaluated once per
+    (stage, clock value) at spec-compile time (phx_spec.stage_tab) and never called at step time"""
+    if "next_stage" not in g:
+        return {}
+    if tabulated:
+        return {"restock_handler": ph.state_independent(lambda env: golden_restock_handler(env))}
+    return {"restock_handler": golden_restock_handler, "allow_host_handlers": True}
 
 
-def env_from_golden(g, batch=None, tracking=False, **kw):
+def env_from_golden(g, batch=None, tracking=False, tabulated_handlers=False, **kw):
     if "type_src" in g:
         kw.update(typed=True, agent_supertypes=typed_supertypes(g))
     return supply_chain_env(int(g["n_shops"]), g["ks"], int(g["num_steps"]),
                             batch or len(g["seeds"]), fsm=bool(g["fsm"]),
                             norm_customers=int(g["norm_customers"]), tracking=tracking,
-                            shuffle="shuffle" in g, **kw, **handler_kw(g))
+                            shuffle="shuffle" in g, **kw, **handler_kw(g, tabulated_handlers))
 
 
 def market_topology(L, Fw, d):

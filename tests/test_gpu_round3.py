@@ -252,3 +252,93 @@ def test_config2_full_size_per_step_matches_oracle():
     for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
         np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
     assert (d.err == 0).all()
+
+
+# ---- table-driven stage handlers in fused rollouts (fsm.py:294-307) --------------------------------
+def test_tabulated_stage_handler_fused_step_and_rollout_reproduce_the_reference_golden():
+    """golden `sc_fsm_handler` = the REFERENCE running a RESTOCK handler that restocks twice on every third step.  Declared
+    state-independent (phantom_amd.state_independent) the handler is tabulated per (stage, clock) at spec-compile time;
+    the FUSED kernels then take every transition themselves: (1) per-step launches of phx_sc_step_kernel with no host
+    callback, (2) ONE fused phx_rollout launch replaying the golden's actions and draws -- stage sequence, key sets,
+    observations (f32 bits), rewards and stock equal the reference's."""
+    import torch
+    from helpers import env_from_golden, golden
+    g = golden("sc_fsm_handler")
+    T, B = int(g["T"]), len(g["seeds"])
+    env = env_from_golden(g, exogenous="device", tabulated_handlers=True)
+    dev = env._device()
+    assert not env._has_handlers and env.spec.stage_tab is not None and dev.uses_fused
+    for t in range(T):                                             # (1) fused per-step launches
+        if g["reset_before"][t].any():
+            env.reset()
+        a = torch.from_numpy(g["actions"][t]).to(dev.device)
+        x = torch.from_numpy(g["exo"][t]).to(dev.device)
+        env.step_tensors(a, None, x, check_errors=True)
+        assert "phx_sc_step_kernel" in dev.last_kernel()
+        np.testing.assert_array_equal(np.atleast_1d(env._h_stage), g["next_stage"][t], err_msg=f"host stage after t={t}")
+        np.testing.assert_array_equal(dev.field("env.stage")[:, 0].cpu().numpy(), g["next_stage"][t])
+        np.testing.assert_array_equal(dev.obs_valid.cpu().numpy(), g["obs_valid"][t], err_msg=f"obs_valid t={t}")
+        np.testing.assert_array_equal(dev.reward_valid.cpu().numpy(), g["reward_valid"][t], err_msg=f"reward_valid t={t}")
+        ov = g["obs_valid"][t].astype(bool)
+        np.testing.assert_array_equal(f32_bits(dev.obs.cpu().numpy()[ov]), f32_bits(g["obs"][t][ov]))
+        rv = g["reward_valid"][t] == 1
+        np.testing.assert_array_equal(f64_bits(dev.reward.cpu().numpy()[rv]), f64_bits(g["reward"][t][rv]))
+        np.testing.assert_array_equal(dev.field("shop.stock").cpu().numpy(), g["stock"][t])
+    # (2) one fused rollout per episode stretch of the golden (the golden resets where its episodes end: auto-reset does too)
+    env2 = env_from_golden(g, exogenous="device", tabulated_handlers=True)
+    d2 = env2._device()
+    env2.reset()
+    resets = [t for t in range(T) if g["reset_before"][t].any()]
+    assert resets[0] == 0 and all((r % int(g["num_steps"])) == 0 for r in resets), "golden episodes end at num_steps"
+    acts = torch.from_numpy(np.ascontiguousarray(g["actions"])).to(d2.device)
+    exo = torch.from_numpy(np.ascontiguousarray(g["exo"])).to(d2.device)
+    tr = env2.rollout(T, actions=acts, exo=exo)
+    assert "phx_sc_rollout_fsm_kernel" in d2.last_kernel()
+    ovd, rvd = tr.obs_valid.cpu().numpy(), tr.reward_valid.cpu().numpy()
+    np.testing.assert_array_equal(ovd, g["obs_valid"][:T])
+    np.testing.assert_array_equal(rvd, g["reward_valid"][:T])
+    ov = g["obs_valid"][:T].astype(bool)
+    np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()[ov]), f32_bits(g["obs"][:T][ov]))
+    rv = g["reward_valid"][:T] == 1
+    np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()[rv]), f32_bits(g["reward"][:T][rv].astype(np.float32)))
+    np.testing.assert_array_equal(tr.truncations.cpu().numpy()[..., 0], g["all_truncated"][:T].astype(np.uint8))
+
+
+@pytest.mark.parametrize("variants", [{}, {"rollout": "launch_loop"}, {"step": "generic"}], ids=str)
+def test_tabulated_stage_handlers_random_tables_match_oracle(variants):
+    """random (stage, clock) -> next-stage tables on a 3-stage FSM supply chain: fused step kernel, general FSM rollout
+    kernel and the generic engine (per step and with the T-step loop in the kernel) against the oracle."""
+    rng = np.random.default_rng(5)
+    S, K, B, NS = 5, 3, 24, 17
+    net_env = supply_chain_env(S, [K] * S, NS, B, fsm=True, seed=3)            # only for the agent ids
+    shops = [a for a in net_env.agents if str(a).startswith("SHOP")]
+    custs = [a for a in net_env.agents if str(a).startswith("CUST")]
+    table = {(s, t): rng.integers(0, 3) for s in range(3) for t in range(NS + 1)}
+    names = ["A", "B", "C"]
+
+    def handler_for(si):
+        return ph.state_independent(lambda env: names[int(table[(si, int(np.atleast_1d(env.current_step)[0]))])])
+
+    stages = [ph.FSMStage("A", acting_agents=shops, rewarded_agents=shops, next_stages=names, handler=handler_for(0)),
+              ph.FSMStage("B", acting_agents=custs, rewarded_agents=[], next_stages=names, handler=handler_for(1)),
+              ph.FSMStage("C", acting_agents=shops + custs, rewarded_agents=None, next_stages=names, handler=handler_for(2))]
+    from phantom_amd.supply_chain import build_network
+    env = ph.FiniteStateMachineEnv(NS, build_network(S, [K] * S, ph.BatchResolver(), False), "A", stages=stages,
+                                   batch_size=B, seed=3, exogenous="device", variants=variants)
+    assert env.spec.stage_tab is not None
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    for t in range(5):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+        np.testing.assert_array_equal(d.obs_valid, o.obs_valid)
+        np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs))
+        np.testing.assert_array_equal(d.reward_valid, o.reward_valid)
+        np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward))
+        np.testing.assert_array_equal(d.get_i32("env.stage"), o.get_i32("env.stage"))
+    for T in (3, 40, 17):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, True)
+        for f in ("shop.stock", "env.stage", "env.step", "env.tick"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    assert (d.err == 0).all()

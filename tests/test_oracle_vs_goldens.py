@@ -12,11 +12,15 @@ SC_CASES = ["sc7_fixed20", "sc7_mixed", "sc64", "sc_ragged", "sc256_fsm", "sc_fs
             "sc_typed", "sc_typed_fsm"]
 
 
-def replay_supply_chain(g, make_runner):
-    """drive a runner (oracle or device adapter) with the golden inputs and compare outputs."""
+def replay_supply_chain(g, make_runner, tabulated_handlers=False):
+    """drive a runner (oracle or device adapter) with the golden inputs and compare outputs.  ``tabulated_handlers``: the
+    golden's stage handler is declared state-independent and travels as phx_spec.stage_tab instead of a per-step
+    next_stage column."""
     T, B = int(g["T"]), len(g["seeds"])
     typed = "type_src" in g
-    env = env_from_golden(g, tracking=int(g["n_logs"]) > 0)
+    env = env_from_golden(g, tracking=int(g["n_logs"]) > 0, tabulated_handlers=tabulated_handlers)
+    if tabulated_handlers:
+        assert env.spec.stage_tab is not None and env.spec.stage_tab.shape == (2, int(g["num_steps"]) + 1)
     run = make_runner(env.spec)
     assert run.D == (4 if typed else 3)
     for t in range(T):
@@ -39,7 +43,7 @@ def replay_supply_chain(g, make_runner):
             assert n <= cap
             sh[:, :n] = g["shuffle"][t][:, :n]
             run.step(g["actions"][t], None, exo, sh)
-        elif "next_stage" in g:            # the stage the reference's handler returned (fsm.py:294-302), per env
+        elif "next_stage" in g and not tabulated_handlers:   # the stage the reference's handler returned (fsm.py:294-302), per env
             run.step(g["actions"][t], None, exo, next_stage=g["next_stage"][t])
         else:
             run.step(g["actions"][t], None, exo)
@@ -82,6 +86,13 @@ def test_shuffle_goldens_are_not_the_identity():
 @pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES + HANDLER_CASES)
 def test_oracle_supply_chain_matches_reference(name):
     replay_supply_chain(golden(name), lambda spec: OracleEnv(spec))
+
+
+@pytest.mark.parametrize("name", HANDLER_CASES)
+def test_oracle_tabulated_stage_handler_matches_reference(name):
+    """the reference's handler decides from the clock: declared state-independent it is tabulated per (stage, clock) at
+    spec-compile time (phx_spec.stage_tab) and the oracle takes the transitions itself -- same golden, no next_stage input"""
+    replay_supply_chain(golden(name), lambda spec: OracleEnv(spec), tabulated_handlers=True)
 
 
 def replay_market(g, make_runner, tracking=True):
