@@ -464,7 +464,11 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     out.push_back(w);
   }
   // step-shaped scratch of the launch-loop rollout (envs without a fused rollout kernel)
-  if (!d.sc_static && !d.stk_static) {       // (the fused ads kernels keep it: injected sends fall back to the loop)
+  // (a market too large for the LDS-resident rollout kernel falls back to the generic engine's loop as well)
+  const int64_t stk_nS = d.kind_count[PHX_KIND_SELLER], stk_nB = d.kind_count[PHX_KIND_BUYER];
+  const bool stk_big = d.stk_static && (d.A > 3 * 1024 ||
+                                        8 * (3 * stk_nS + d.A + stk_nB) + 9 * stk_nS + d.A + stk_nB + sp->n_conn + 32 > 60 * 1024);
+  if ((!d.sc_static && !d.stk_static) || stk_big) {       // (the fused ads kernels keep it: injected sends fall back to the loop)
     const int64_t n = gen_rollout_scratch_bytes(B, S, d.D);
     FieldDef r = {F_ROLLOUT_SCRATCH, "rollout.scratch", 2, 0, 1, n, 1, off};
     off += n;
@@ -774,8 +778,10 @@ static int check_step_io(const phx_env* e, const phx_step_io* io) {
   if (!io->obs || !io->obs_valid || !io->reward || !io->reward_valid || !io->terminated || !io->truncated ||
       !io->done_valid || !io->all_terminated || !io->all_truncated)
     return fail(PHX_EINVAL, "a required output pointer is NULL");
-  if ((((uintptr_t)io->obs | (uintptr_t)io->actions) & 15u) != 0 || ((uintptr_t)io->reward & 7u) != 0)
-    return fail(PHX_EINVAL, "phx_step: obs and actions must be 16-byte aligned, reward 8-byte aligned");
+  // obs rows leave as 16-byte pieces, rewards as f64; the actions are read one f32 per strategic agent by every step
+  // kernel, so a row slice actions[t] of a [n, B, S] tensor is fine whatever B * S is
+  if (((uintptr_t)io->obs & 15u) != 0 || ((uintptr_t)io->reward & 7u) != 0 || ((uintptr_t)io->actions & 3u) != 0)
+    return fail(PHX_EINVAL, "phx_step: obs must be 16-byte aligned, reward 8-byte aligned, actions 4-byte aligned");
   if ((io->msg_log || io->msg_count) && e->d.trace_cap <= 0) return fail(PHX_EINVAL, "msg_log given but trace_cap == 0");
   if (io->shuffle && !(e->d.flags & PHX_F_SHUFFLE_BATCHES)) return fail(PHX_EINVAL, "shuffle given but the spec has no PHX_F_SHUFFLE_BATCHES");
   if (io->next_stage && e->d.env_type != PHX_ENV_FSM) return fail(PHX_EINVAL, "next_stage given but the env is not a FiniteStateMachineEnv");
@@ -881,6 +887,12 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     if (!io->obs_valid || !io->reward_valid) return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");
     HIPCHK(phx_launch_ads_rollout(e->d, *io, (hipStream_t)stream));
     return PHX_OK;
+  }
+  if (e->use_stk && e->prices_compressed && (phx_stk_rollout_lds(e->d) > 60 * 1024 || e->d.A > 3 * 1024) && e->d.f[F_ROLLOUT_SCRATCH]) {
+    // a market too large for the LDS-resident rollout kernel: materialise the price table and roll out on the generic
+    // engine (the env stays there, like after a host-injected message)
+    HIPCHK(phx_launch_stk_materialise(e->d, (hipStream_t)stream));
+    e->prices_compressed = false; e->use_stk = false;
   }
   if (!e->use_fused && !(e->use_stk && e->prices_compressed)) {
     // Launch loop for every other env (any topology of the device kinds, tracking off): per step ONE

@@ -342,3 +342,71 @@ def test_tabulated_stage_handlers_random_tables_match_oracle(variants):
         for f in ("shop.stock", "env.stage", "env.step", "env.tick"):
             np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
     assert (d.err == 0).all()
+
+
+# ---- ADVICE r2 ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,S,K", [(1, 3, 2), (3, 1, 4), (5, 51, 1)])
+def test_step_accepts_action_rows_at_any_4_byte_offset(B, S, K):
+    """a row slice actions[t] of a [n, B, S] tensor starts on a 16-byte boundary only when B * S is a
+    multiple of 4; no step kernel vector-loads actions, so phx_step / DeviceEnv.step_graph must take such rows."""
+    import torch
+    n = 6
+    env = supply_chain_env(S, [K] * S, 50, B, seed=8)
+    o, d = OracleEnv(env.spec), _dev(env.spec)
+    o.reset(); d.reset()
+    dev = d.dev
+    acts = (torch.rand(n, B, S, device=dev.device) * 100.0).contiguous()
+    assert (B * S) % 4 != 0 and acts[1].data_ptr() % 16 != 0
+    for t in range(n):
+        dev.step(acts[t])                                    # row slices straight into phx_step
+        o.step(acts[t].cpu().numpy(), None, None)
+    np.testing.assert_array_equal(dev.field("shop.stock").cpu().numpy(), o.get_i32("shop.stock"))
+    g = dev.step_graph(acts)                                 # and captured: step i reads actions[i]
+    g.replay(); torch.cuda.synchronize()
+    for t in range(n):
+        o.step(acts[t].cpu().numpy(), None, None)
+    np.testing.assert_array_equal(dev.field("shop.stock").cpu().numpy(), o.get_i32("shop.stock"))
+    np.testing.assert_array_equal(f32_bits(dev.obs.cpu().numpy()), f32_bits(o.obs))
+    env2 = supply_chain_env(S, [K] * S, 50, B, seed=8, exogenous="device")
+    env2.reset()
+    env2.step_tensors(acts[1])                               # the Python surface with a row slice
+
+
+def test_market_too_large_for_the_lds_rollout_falls_back_to_the_generic_loop():
+    """a market with more than 3072 agents does not fit phx_stk_rollout_kernel's three agent slots per
+    lane; phx_rollout materialises the price table and rolls out on the generic engine instead of returning an error."""
+    from helpers import market_env
+    L, Fw, B = 40, 3100, 2
+    env = market_env(L, Fw, 2, 6, B, seed=4)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    assert d.dev.uses_fused
+    o.reset(); d.reset()
+    rng = np.random.default_rng(2)
+    S = L + Fw
+    a = rng.random((B, S), dtype=np.float32); av = np.zeros((B, S), np.uint8); av[:, :L] = 1
+    o.step(a, av, None); d.step(a, av, None)                 # a fused market step first (compressed price slots)
+    ro, rd = o.rollout(5), d.rollout(5)
+    assert "phx_generic_step_kernel" in d.dev.last_kernel()
+    _cmp_rollout(rd, ro, True)
+    assert (d.err == 0).all()
+
+
+def test_never_terminates_agrees_with_the_device_for_every_strategic_kind():
+    """DeviceEnv.never_terminates() decides whether the `terminations` plane travels in a rollout
+    collection; it must agree with what the device's is_terminated can return.  For every env family: if
+    never_terminates() then no rollout ever sets a termination flag."""
+    import phantom_amd as ph
+    from helpers import market_env
+    envs = [supply_chain_env(3, [2] * 3, 5, 4, seed=1), supply_chain_env(3, [2] * 3, 5, 4, fsm=True, seed=1),
+            market_env(4, 8, 2, 6, 4, seed=1, exogenous="device"),
+            ph.DigitalAdsEnv(num_steps=6, num_agents_theme={"travel": 2, "tech": 2}, batch_size=4, seed=3,
+                             agent_supertypes={f"ADV_{i + 1}": ph.AdvertiserAgent.Supertype(budget=0.3) for i in range(4)})]
+    seen_terminating = False
+    for env in envs:
+        d = _dev(env.spec); d.reset()
+        r = d.rollout(30)
+        if d.dev.never_terminates():
+            assert int(r["terminated"].sum()) == 0
+        else:
+            seen_terminating = seen_terminating or int(r["terminated"].sum()) > 0
+    assert seen_terminating                                   # the ads market's advertisers do run out of budget
