@@ -408,6 +408,9 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   uint8_t* s_cv = s_sent + nSell;                        // [A] reward cache valid
   uint8_t* s_bought = s_cv + A;                          // [nBuy]
   uint8_t* s_conn = s_bought + nBuy;                     // [n_conn] StochasticNetwork: connection is in this episode's graph
+  // (Measured and dropped, round 3: the row's four u8 planes staged in LDS and stored as 16-byte pieces after the step's last
+  //  barrier instead of one byte store per lane and plane -- 12 fewer store instructions per lane and step, but one more
+  //  dependent stage on a step that is a latency chain: 26.9 -> 29.0 us per step at 128 x 1024, B = 4096.)
   constexpr bool dyn = DYN;
   const int64_t sbase = (int64_t)b * nSell, bbase = (int64_t)b * nBuy, abase = (int64_t)b * A;
   const int64_t genv = sp.env_offset + b;
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
     STICK(0);
-    __syncthreads();
+    stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
     STICK(1);
     // ---- pre_message_resolution + the single round --------------------------------------------------
     for (int kr = tid; kr < nSell; kr += NT) {
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       if (s_sent[kr]) s_posted[kr] = s_price[kr];
       s_count[kr] = 0; s_sent[kr] = 0;
     }
-    __syncthreads();
+    stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
     STICK(2);
     // ---- obs / reward / flags -> trajectory row (stackelberg.py:142-196) -----------------------------
     const bool terminal = (tt == sp.num_steps);
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     }
     step = tt; ++tick;
     STICK(3);
-    __syncthreads();
+    stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
     STICK(4);
     if (terminal) {                                                          // the caller's env.reset()
       for (int k = tid; k < nSell; k += NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
         ++episode; ++n_resets;
       }
       step = 0;
-      __syncthreads();
+      stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
     }
   }
 #ifdef PHX_TIMING
