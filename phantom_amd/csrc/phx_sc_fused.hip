@@ -678,7 +678,15 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
 // LDS tables (computed at setup: exactly the f32 quotients), stores through scalar row bases + 32-bit lane offsets.
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                        const int epb, const int remap, const uint32_t pK,
-                                                                       const float inv_pK, const int wide, const int32_t* only_if, const int32_t gen) {
+                                                                       const float inv_pK, const int wide, const int32_t* only_if, const int32_t gen,
+                                                                       const int pairs) {
+  // `pairs`: a block owns SC_NT CONSECUTIVE (env, shop) PAIRS instead of `epb` whole envs.  Every row segment a block writes
+  // is then whole 128-byte lines of the f32 planes and whole 64-byte pieces of the u8 planes, every lane is active (4 envs
+  // of 51 shops filled 204 of 256), and the launch no longer depends on WHERE the trajectory buffers lie: the partially
+  // written lines at whole-env block boundaries (816-byte segments at SC256) have to be merged in the L2 before they are
+  // evicted, which works or fails with the planes' physical placement -- config 3's two modes, 206-232 vs ~335 us per 100
+  // steps.  An env's words are then written by the block that finishes LAST with it (env.arrive, as in
+  // phx_sc_rollout_fast_kernel): another block of the env may not have read them yet.
   if (only_if && *only_if != gen) return;   // the time-parallel kernel took this launch (phx_sc_rollout_fsm.hip)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int nS = sp.S, nL = sp.n_lists, K = sp.fsm_lean_K;
@@ -695,12 +703,14 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
   if (threadIdx.x <= PHX_SHOP_MAX_STOCK) s_tabs[threadIdx.x] = (float)threadIdx.x / (float)PHX_SHOP_MAX_STOCK;
   if ((int)threadIdx.x <= 5 * K) s_tabn[threadIdx.x] = (float)threadIdx.x / (float)sp.fsm_lean_norm;
   const int64_t total = (int64_t)sp.B * nS;
-  const int64_t b_first = (int64_t)xcd_block(remap != 0) * epb;
+  const int64_t blk = xcd_block(remap != 0);
+  const int64_t b_first = pairs ? (blk * SC_NT) / nS : blk * epb;
   const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
-  const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
-  const int64_t g = b_first * nS + threadIdx.x;
-  const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
-  const int s = active ? (int)(threadIdx.x % nS) : 0;
+  const int64_t g0 = pairs ? blk * SC_NT : b_first * nS;                     // the block's first pair
+  const int64_t g = g0 + threadIdx.x;
+  const bool active = pairs ? g < total : (int)threadIdx.x < (int)(b_end - b_first) * nS;
+  const int b = active ? (pairs ? (int)(g / nS) : (int)(b_first + threadIdx.x / nS)) : (int)b_first;
+  const int s = active ? (pairs ? (int)(g - (int64_t)b * nS) : (int)(threadIdx.x % nS)) : 0;
   int step = fld<int32_t>(sp, F_ENV_STEP)[b];
   uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
   int stage = fld<int32_t>(sp, F_ENV_STAGE)[b];
@@ -721,9 +731,8 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
   float lo[3] = {0.f, 0.f, 0.f};
   RngQuadCache rq; rq.q = 0xffffffffu;
   const uint32_t lane_off = (uint32_t)threadIdx.x;                           // g = block base + lane: 32-bit offsets from scalar bases
-  const int64_t g0 = b_first * nS;
   const uint32_t wave_off = (uint32_t)threadIdx.x & ~63u;                    // pairs of the block before this wave
-  const int lanes_blk = (int)(b_end - b_first) * nS;
+  const int lanes_blk = pairs ? (int)((total - g0) < SC_NT ? (total - g0) : SC_NT) : (int)(b_end - b_first) * nS;
   const int n_wave = lanes_blk - (int)wave_off < 64 ? lanes_blk - (int)wave_off : 64;   // active lanes of this wave (a multiple of 4 when wide)
   const int n_pieces = (n_wave * 3) >> 2;
 
@@ -791,7 +800,17 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
   for (int d = 0; d < 3; ++d) fld<float>(sp, F_ENV_OBS_CACHE)[g * 3 + d] = oc[d];
   fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g] = ocv;
   if (io.last_obs) for (int d = 0; d < 3; ++d) io.last_obs[g * 3 + d] = lo[d];
-  if (s == 0) {
+  bool writes_env = (s == 0);
+  if (pairs) {                               // the env's first lane IN THIS BLOCK counts the block in; the last block to arrive writes
+    writes_env = false;
+    if (s == 0 || threadIdx.x == 0) {
+      const int64_t p0 = (int64_t)b * nS;
+      const int n_touch = (int)((p0 + nS - 1) / SC_NT - p0 / SC_NT) + 1;
+      int32_t* arrive = fld<int32_t>(sp, F_ENV_ARRIVE) + b;
+      if (n_touch == 1 || atomicAdd(arrive, 1) + 1 == n_touch) { writes_env = true; if (n_touch > 1) *arrive = 0; }
+    }
+  }
+  if (writes_env) {
     fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick;
     fld<int32_t>(sp, F_ENV_STAGE)[b] = stage; fld<int32_t>(sp, F_ENV_PREV_STAGE)[b] = prev_stage;
   }
@@ -844,8 +863,14 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (((size_t)sp.n_lists + 3) & ~(size_t)3) * 4 +
                        (SC_NT / 64) * 192 * 4 + 16;
     phx_note_kernel(only_if ? "phx_sc_rollout_fsm_lean_kernel[if off-chain]" : "phx_sc_rollout_fsm_lean_kernel");
-    hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3((sp.B + epb_l - 1) / epb_l), dim3(SC_NT), lds, st, sp, io, epb_l, remap,
-                       pk, inv[sp.fsm_lean_K], wide, only_if, gen);
+    // blocks of SC_NT consecutive pairs (whole lines per row segment, every lane active) unless the spec asks for whole envs
+    // or the pair count is no multiple of 4 (the observation pieces of a wave)
+    const int64_t total = (int64_t)sp.B * sp.S;
+    const int pairs = (sp.variant_block != PHX_VB_WHOLE_ENVS && total % 4 == 0 && sp.f[F_ENV_ARRIVE]) ? 1 : 0;
+    const unsigned grid = pairs ? (unsigned)((total + SC_NT - 1) / SC_NT) : (unsigned)((sp.B + epb_l - 1) / epb_l);
+    if (pairs) wide = 1;
+    hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3(grid), dim3(SC_NT), lds, st, sp, io, epb_l, remap,
+                       pk, inv[sp.fsm_lean_K], wide, only_if, gen, pairs);
     return hipGetLastError();
   }
   phx_note_kernel("phx_sc_rollout_fsm_kernel");
