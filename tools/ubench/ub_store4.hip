@@ -13,7 +13,9 @@
 #endif
 #define B 4096
 #define S 9
+#ifndef TC
 #define TC 20
+#endif
 #define G 32
 static __device__ __forceinline__ int xcd_block() {
   const unsigned n = gridDim.x, x = blockIdx.x & 7u, q = n >> 3, rem = n & 7u;
