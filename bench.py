@@ -354,7 +354,9 @@ def main():
         os._exit(1)
     watch.emit()
     sys.stdout.flush()
-    os._exit(0)      # process-group / communicator destructors have nothing left to do and can hang when a peer is gone
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PHX_BENCH_FORCE_DIST"):
+        os._exit(0)  # process-group / communicator destructors have nothing left to do and can hang when a peer is gone
+    # (a single process returns normally: a profiler attached to it -- rocprofv3 -- writes its output at interpreter exit)
 
 
 def run(args, rank, local_rank, world, watch):

@@ -408,6 +408,10 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   uint8_t* s_cv = s_sent + nSell;                        // [A] reward cache valid
   uint8_t* s_bought = s_cv + A;                          // [nBuy]
   uint8_t* s_conn = s_bought + nBuy;                     // [n_conn] StochasticNetwork: connection is in this episode's graph
+  // the buyers' values in LDS, not in a register pair per slot: with 64 VGPRs (8 waves per SIMD: the step is a latency
+  // chain) the 512-thread instantiation spilled 10 VGPRs to scratch -- 0.54 GB of FETCH_SIZE per T = 50 launch at
+  // 128 x 1024, B = 4096 (profiles/r03a), and a scratch reload on the step's critical path
+  double* s_val = (double*)(((uintptr_t)(s_conn + (DYN ? sp.n_conn : 0)) + 7) & ~(uintptr_t)7);   // [nBuy]
   // (Measured and dropped, round 3: the row's four u8 planes staged in LDS and stored as 16-byte pieces after the step's last
   //  barrier instead of one byte store per lane and plane -- 12 fewer store instructions per lane and step, but one more
   //  dependent stage on a step that is a latency chain: 26.9 -> 29.0 us per step at 128 x 1024, B = 4096.)
@@ -432,11 +436,10 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   // deg << 8 | kind_rank << 16; nbp: a buyer's neighbours (seller ranks, packed u16), for a seller nbp[0] = its degree;
   // rw2 / rt2: the agent's word of tick rt2, kept from the Philox block of its previous acting tick
   uint32_t rec[STKR_SLOTS], nbp[STKR_SLOTS][4], rw2[STKR_SLOTS], rt2[STKR_SLOTS];
-  double val[STKR_SLOTS];
 #pragma unroll
   for (int k = 0; k < STKR_SLOTS; ++k) {
     const int a = tid + k * NT;
-    rec[k] = 0; val[k] = 0.0; rw2[k] = 0; rt2[k] = 0xffffffffu;
+    rec[k] = 0; rw2[k] = 0; rt2[k] = 0xffffffffu;
     nbp[k][0] = nbp[k][1] = nbp[k][2] = nbp[k][3] = 0;
     if (a < A) {
       const uint32_t r = sp.stk_rec[a];
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       const int kr = (int)(r >> 16), deg = (int)((r >> 8) & 255u);
       if (seller) nbp[k][0] = (uint32_t)(sp.row_ptr[a + 1] - sp.row_ptr[a]);                       // len(ctx.neighbour_ids)
       else {
-        val[k] = sp.param_f[a * PHX_NPF];
+        s_val[kr] = sp.param_f[a * PHX_NPF];
         if (!dyn && deg <= 8) {
 #pragma unroll
           for (int j = 0; j < 8; ++j)
@@ -579,12 +582,12 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
         } else {
           int jr;
           const double mn = cheapest(k, kr, deg, jr);                        // min over the price slots (none: 1.0)
-          ob0 = (float)(jr >= 0 ? mn : 1.0); ob1 = (float)val[k];
+          ob0 = (float)(jr >= 0 ? mn : 1.0); ob1 = (float)s_val[kr];
         }
       }
       uint8_t cv = s_cv[a]; double cache = s_cache[a];
       if (fl & 4u) {
-        cache = seller ? s_rev[kr] : (s_bought[kr] ? __dsub_rn(val[k], s_paid[kr]) : 0.0);
+        cache = seller ? s_rev[kr] : (s_bought[kr] ? __dsub_rn(s_val[kr], s_paid[kr]) : 0.0);
         cv = 1; s_cache[a] = cache; s_cv[a] = 1;
       }
       uint8_t rv = 0; double rw = 0.0;
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
         if (terminal) {
           const bool lead_buyer = (rec[k] & 2u) != 0 && !seller;             // acts on the leaders' step
           ob0 = lead_buyer ? 1.0f : 0.f;
-          ob1 = lead_buyer ? (float)val[k] : 0.f;
+          ob1 = lead_buyer ? (float)s_val[kr] : 0.f;
         }
         *(float2*)(io.last_obs + (abase + a) * 2) = make_float2(ob0, ob1);
       }
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
 
 size_t phx_stk_rollout_lds(const DevSpec& sp) {
   const size_t nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER], A = sp.A;
-  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32;
+  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32 + 8 + 8 * nBuy;   // + the buyers' values
 }
 
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
