@@ -514,9 +514,10 @@ def run(args, rank, local_rank, world, watch):
     if os.path.exists(pmc) and args.config == "sc64" and B == BATCH:
         try:
             rec = json.load(open(pmc)).get("phx_sc_rollout_fast_kernel", {})
-            traffic = rec.get("hbm_bytes_per_launch")
-            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command: " + \
-                str(rec.get("source", "see file")) + "); not re-measured by this run"
+            if int(rec.get("steps_per_launch", NUM_STEPS)) == T:             # the counters were taken on this launch shape
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command: " + \
+                    str(rec.get("source", "see file")) + "); not re-measured by this run"
         except Exception:
             traffic = None
     # the same kernel with ONE episode per launch (T = 100, what rounds 1-2 reported): the launch gap, the block ramp and the
