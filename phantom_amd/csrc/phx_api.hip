@@ -477,6 +477,81 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
   return std::max<int64_t>(off, 256);
 }
 
+// ---- static round schedule of the generic engine --------------------------------------------
+// For specs whose message flow cannot drop or add a message -- static Network, no ignore_connection_errors, no shuffle, only
+// the supply-chain kinds (every send and every reply is unconditional: supply_chain.py:40-45,55-67,98-122,136-142) and the mock
+// kinds that never send -- the rounds of a step in which every agent has a context and every acting ShopAgent an action are the
+// same for every env and every step: which message sits where in which inbox (resolvers.py:128-158 -- receivers in first-arrival
+// order, batches in send order, replies in handling order).  Simulated here per acting list; the kernel checks the premise per env
+// and step and otherwise runs its atomics / scan / rank sort as before.
+struct StaticSched { std::vector<int32_t> blob, off; };
+static void build_static_schedule(const phx_spec* sp, const Derived& d, StaticSched& out) {
+  const int A = d.A;
+  out.blob.clear(); out.off.assign(d.n_lists, -1);
+  if ((sp->flags & (PHX_F_SHUFFLE_BATCHES | PHX_F_IGNORE_CONN_ERRORS)) || d.dynamic_graph) return;
+  for (int a = 0; a < A; ++a) {
+    const int k = sp->kind[a];
+    if (k != PHX_KIND_FACTORY && k != PHX_KIND_SHOP && k != PHX_KIND_CUSTOMER && k != PHX_KIND_MOCK_STRAT && k != PHX_KIND_MOCK_AGENT) return;
+  }
+  auto edge = [&](int u, int v) { for (int e = sp->row_ptr[u]; e < sp->row_ptr[u + 1]; ++e) if (sp->col[e] == v) return true; return false; };
+  auto payload_ok = [&](int src, int dst, int type) {
+    if (sp->flags & PHX_F_NO_PAYLOAD_CHECKS) return true;
+    int sk = 0, rk = 0;
+    switch (type) {
+      case PHX_MSG_ORDER_REQUEST: sk = PHX_KIND_CUSTOMER; rk = PHX_KIND_SHOP; break;
+      case PHX_MSG_ORDER_RESPONSE: sk = PHX_KIND_SHOP; rk = PHX_KIND_CUSTOMER; break;
+      case PHX_MSG_STOCK_REQUEST: sk = PHX_KIND_SHOP; rk = PHX_KIND_FACTORY; break;
+      case PHX_MSG_STOCK_RESPONSE: sk = PHX_KIND_FACTORY; rk = PHX_KIND_SHOP; break;
+      default: return false;
+    }
+    return sp->kind[src] == sk && sp->kind[dst] == rk;
+  };
+  struct M { int src, dst, type; };
+  for (int l = 0; l < d.n_lists; ++l) {
+    std::vector<M> q;
+    bool ok = true;
+    for (int k = d.act_ptr[l]; k < d.act_ptr[l + 1] && ok; ++k) {
+      const int a = d.act_idx[k], kind = sp->kind[a], dst = sp->param_i[a * PHX_NPI];
+      if (kind == PHX_KIND_SHOP || kind == PHX_KIND_CUSTOMER) {
+        const int type = kind == PHX_KIND_SHOP ? PHX_MSG_STOCK_REQUEST : PHX_MSG_ORDER_REQUEST;
+        ok = dst >= 0 && dst < A && edge(a, dst) && payload_ok(a, dst, type);
+        q.push_back({a, dst, type});
+      }
+    }
+    if (!ok || (int)q.size() > sp->queue_cap) continue;
+    std::vector<int32_t> rec(1 + PHX_SCHED_MAX_ROUNDS, 0);
+    int R = 0;
+    while (!q.empty() && ok) {
+      if (R == PHX_SCHED_MAX_ROUNDS || (sp->round_limit >= 0 && R >= sp->round_limit)) { ok = false; break; }
+      const int n = (int)q.size();
+      std::vector<int32_t> cnt(A, 0), first(A, 0x7fffffff), goff(A, 0), order(n, 0), fill(A, 0);
+      for (int i = 0; i < n; ++i) { cnt[q[i].dst]++; first[q[i].dst] = std::min(first[q[i].dst], i); }
+      int run = 0;
+      for (int i = 0; i < n; ++i) if (first[q[i].dst] == i) { goff[q[i].dst] = run; run += cnt[q[i].dst]; }   // dict order of receivers
+      for (int i = 0; i < n; ++i) order[goff[q[i].dst] + fill[q[i].dst]++] = i;                               // batches in send order
+      std::vector<M> nq;
+      for (int P = 0; P < n && ok; ++P) {                       // replies in handling order
+        const M m = q[order[P]];
+        const int rk = sp->kind[m.dst];
+        if (rk == PHX_KIND_FACTORY && m.type == PHX_MSG_STOCK_REQUEST) {
+          ok = payload_ok(m.dst, m.src, PHX_MSG_STOCK_RESPONSE); nq.push_back({m.dst, m.src, PHX_MSG_STOCK_RESPONSE});
+        } else if (rk == PHX_KIND_SHOP && m.type == PHX_MSG_ORDER_REQUEST) {
+          ok = payload_ok(m.dst, m.src, PHX_MSG_ORDER_RESPONSE); nq.push_back({m.dst, m.src, PHX_MSG_ORDER_RESPONSE});
+        } else if ((rk == PHX_KIND_SHOP && m.type == PHX_MSG_STOCK_RESPONSE) || (rk == PHX_KIND_CUSTOMER && m.type == PHX_MSG_ORDER_RESPONSE)) {
+        } else ok = false;                                        // no handler: the dynamic path reports it
+      }
+      if ((int)nq.size() > sp->queue_cap) ok = false;
+      rec[1 + R] = n;
+      rec.insert(rec.end(), cnt.begin(), cnt.end()); rec.insert(rec.end(), goff.begin(), goff.end()); rec.insert(rec.end(), order.begin(), order.end());
+      ++R; q.swap(nq);
+    }
+    if (!ok) continue;
+    rec[0] = R;
+    out.off[l] = (int32_t)out.blob.size();
+    out.blob.insert(out.blob.end(), rec.begin(), rec.end());
+  }
+}
+
 // ---- handle ----------------------------------------------------------------------------------------------
 struct phx_env {
   DevSpec d;
@@ -563,6 +638,12 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(stage_allowed, der.stage_allowed.data(), der.stage_allowed.size());
   d.stage_tab = nullptr;
   if (!der.stage_tab.empty()) UP(stage_tab, der.stage_tab.data(), der.stage_tab.size());
+  d.sched = nullptr; d.sched_off = nullptr;
+  if (!der.sc_static && !der.stk_static && !der.ads_static) {      // specs the generic engine serves
+    StaticSched ss;
+    build_static_schedule(spec, der, ss);
+    if (!ss.blob.empty()) { UP(sched, ss.blob.data(), ss.blob.size()); UP(sched_off, ss.off.data(), ss.off.size()); }
+  }
   UP(stage_rew_all, der.stage_rew_all.data(), der.stage_rew_all.size());
   UP(reset_obs_idx, der.reset_obs_idx.data(), der.reset_obs_idx.size());
   d.n_reset_obs = (int)der.reset_obs_idx.size();

@@ -40,6 +40,7 @@ enum {
 };
 
 // block shape and constant-table offsets of the round-2 supply-chain rollout kernel (phx_sc_rollout.hip)
+#define PHX_SCHED_MAX_ROUNDS 8   // rounds a precomputed schedule of the generic engine may hold (DevSpec::sched)
 #define PHX_FSM_LB 3            // lookback (steps) the time-parallel FSM rollout serves from its tiles
 #define PHX_FAST_TC 20          // steps per chunk (one Philox block serves 4 ticks: 5 row quads)
 struct ScFastPlan {
@@ -78,6 +79,12 @@ struct DevSpec {
   const int32_t* stage_next;     // [n_lists]  (FSM)
   const uint8_t* stage_allowed;  // [n_lists][n_lists] FSMStage.next_stages as a matrix (handler-chosen transitions), or NULL
   const int32_t* stage_tab;      // [n_lists][num_steps + 1] tabulated clock / stage handlers (phx_spec.stage_tab), or NULL
+  // generic engine, drop-out-free supply-chain specs: the round schedule of a step in which every agent is live and every acting
+  // strategic agent has an action, simulated once at phx_create (phx_api.hip: build_static_schedule).  sched + sched_off[list]:
+  // [R, n_0 .. n_7] then per round { cnt[A], goff[A], order[n_r] } = inbox sizes, inbox offsets in first-arrival (dict) order and the
+  // queue index of every inbox position in send order -- what the per-round LDS atomics, block scan and rank sort compute.
+  const int32_t* sched;          // or NULL
+  const int32_t* sched_off;      // [n_lists] offset of the list's schedule in `sched`, -1: this list is not static
   const uint8_t* stage_rew_all;  // [n_lists] rewarded_agents is None (every strategic agent observes, fsm.py:315-317)
   const int32_t* reset_obs_ptr;  // agents that observe at reset: CSR with a single row
   const int32_t* reset_obs_idx;

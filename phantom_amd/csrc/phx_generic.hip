@@ -649,7 +649,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   __shared__ int wave_sums[NT / 64];
-  __shared__ int s_errkey, s_nterm, s_ntrunc;
+  __shared__ int s_errkey, s_nterm, s_ntrunc, s_dyn;
 #ifdef PHX_TIMING
   unsigned long long gtm[16] = {0}, gprev = __builtin_readcyclecounter();
 #define GTICK(k) do { PHX_REFRESH(); const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
@@ -720,11 +720,17 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   if (sp.env_type == PHX_ENV_FSM) list = cur_stage;                          // fsm.py:276
   else if (sp.env_type == PHX_ENV_STACKELBERG) list = (t & 1) ? 0 : 1;       // stackelberg.py:133-137
 
-  if (tid == 0) { s_errkey = ERRKEY_NONE; s_nterm = 0; s_ntrunc = 0; }
+  if (tid == 0) { s_errkey = ERRKEY_NONE; s_nterm = 0; s_ntrunc = 0; s_dyn = 0; }
+  // the list's precomputed round schedule (DevSpec::sched), valid for this step only if every agent has a context and every
+  // acting supply-chain agent sends its message (s_dyn records a violation); injected sends and bare resolves are dynamic
+  const int32_t* sch = nullptr;
+  if (sp.sched && full && g.n_inject == 0) { const int so = sp.sched_off[list]; if (so >= 0) sch = sp.sched + so; }
+  __syncthreads();
   // _make_ctxs (env.py:338-348): contexts only for agents that are not done
   for (int a = tid; a < A; a += NT) {
     const int s = tp.strat_rank[a];
     live[a] = (g.resolve_only || s < 0) ? 1 : !(term[s] | trunc[s]);
+    if (sch && !live[a]) s_dyn = 1;
   }
   if (roll_t >= 0) {
     // the policy of a rollout, fused: every strategic agent's action of this tick (random policy = the
@@ -771,6 +777,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
         const int s = tp.strat_rank[a];
         const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);        // aid in actions, env.py:330
         c = act_count(sp, tp, b, a, has, has ? actions_b[s] : 0.0f);
+        if (sch && c == 0) { const int ka = tkind(tp, a); if (ka == PHX_KIND_SHOP || ka == PHX_KIND_CUSTOMER) s_dyn = 1; }   // a shop without an action
       }
     }
     scanbuf[it] = c;
@@ -829,7 +836,20 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   // ---- BatchResolver.resolve round loop (resolvers.py:128-163) ---------------------------------
   DevMsg* qc = q0; DevMsg* qn = q1;
   int round = 0;
+  const bool use_sched = sch != nullptr && s_dyn == 0;      // (uniform: s_dyn was last written before the barriers above)
+  const int sch_R = use_sched ? sch[0] : 0;
+  int sch_pos = 1 + PHX_SCHED_MAX_ROUNDS;                    // offset of the current round's tables in the schedule
   while (n > 0 && (sp.round_limit < 0 || round < sp.round_limit) && round < PHX_MAX_ROUNDS) {
+    const int* ord;                                          // inbox position -> queue index, batches in send order
+    if (use_sched && round < sch_R && n == sch[1 + round]) {
+      // static round: inbox sizes, offsets (receivers in first-arrival order) and batch order come from the table
+      const int32_t* rt = sch + sch_pos;
+      for (int a = tid; a < A; a += NT) { cnt[a] = rt[a]; goff[a] = rt[A + a]; }
+      ord = rt + 2 * A;
+      sch_pos += 2 * A + n;
+      __syncthreads();
+      GTICK(9);
+    } else {
     for (int a = tid; a < A; a += NT) { cnt[a] = 0; first[a] = 0x7fffffff; }
     __syncthreads();
     GTICK(5);
@@ -869,6 +889,8 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     }
     __syncthreads();
     { int* const t_ = order; order = slot; slot = t_; }          // order: the sorted batches; slot: scratch until the next round
+    ord = order;
+    }   // dynamic round
     const bool has_adx = KMAX >= PHX_KIND_ADEXCHANGE && sp.n_adx > 0;
     const int n_adx = has_adx ? sp.n_adx : 0;
     for (int x = 0; x < n_adx; ++x) {                          // exchanges: workgroup-wide batch reduction (phase A)
@@ -922,7 +944,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     };
     // receivers without state (factory, customer, ...): one lane per MESSAGE -- the handlers of a batch commute
     for (int P = tid; P < n; P += NT) {
-      const DevMsg m = qc[order[P]];
+      const DevMsg m = qc[ord[P]];
       const int a = m.dst;
       if (!kind_stateless(tkind(tp, a))) continue;
       AgentState none;
@@ -935,7 +957,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
       const int kind_a = tkind(tp, a);
       if (kind_stateless(kind_a)) continue;
       if (has_adx && kind_a == PHX_KIND_ADEXCHANGE && first[a] != -1) continue;    // done by phase A
-      int* seg = order + goff[a];
+      const int* seg = ord + goff[a];
       if (kind_a == PHX_KIND_ADEXCHANGE) {                      // overrides handle_batch: count now, emit after the scan
         for (int k = 0; k < c; ++k) resp[goff[a] + k].type = 0;
         adexchange_batch(sp, tp, a, qc, seg, c,
