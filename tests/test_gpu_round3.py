@@ -410,3 +410,20 @@ def test_never_terminates_agrees_with_the_device_for_every_strategic_kind():
         else:
             seen_terminating = seen_terminating or int(r["terminated"].sum()) > 0
     assert seen_terminating                                   # the ads market's advertisers do run out of budget
+
+
+def test_autotune_rollout_picks_a_candidate_and_keeps_the_trajectories():
+    """PhantomEnv.autotune_rollout times the candidate block shapes on this GPU and rebuilds the device env with the
+    fastest; whatever it picks, the trajectories are the oracle's."""
+    env = supply_chain_env(9, [6] * 9, 100, 256, seed=21, env_offset=64, exogenous="device")
+    res = env.autotune_rollout(100, candidates=[{"block": "whole_envs"}, {"block": 48}, {"block": 32}], launches=3)
+    assert res["chosen"]["block"] in ("whole_envs", 48, 32) and len(res["us_per_launch"]) == 3
+    assert env.spec.variants["block"] == res["chosen"]["block"]
+    o = OracleEnv(env.spec, threads=4)
+    o.reset(); env.reset()
+    tr = env.rollout(100)
+    ro = o.rollout(100)
+    np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
+    np.testing.assert_array_equal(tr.truncations.cpu().numpy(), ro["truncated"])
+    assert "phx_sc_rollout_fast_kernel" in env._device().last_kernel()
