@@ -615,6 +615,7 @@ __device__ __forceinline__ void reset_env(const DevSpec& sp, const int b, const 
     if (obs) for (int d = 0; d < D; ++d) obs[((int64_t)b * S + s) * D + d] = 0.f;
   }
   if (tid == 0) {
+    if (sp.f[F_ENV_ARRIVE]) fld<int32_t>(sp, F_ENV_ARRIVE)[b] = 0;      // (arrival counter of the pair-range rollout kernels: 0 between launches)
     fld<int32_t>(sp, F_ENV_STEP)[b] = 0;                                // env.py:209
     if (sp.env_type == PHX_ENV_FSM) fld<int32_t>(sp, F_ENV_STAGE)[b] = sp.initial_stage;   // fsm.py:217
   }
