@@ -208,6 +208,12 @@ class FiniteStateMachineEnv(PhantomEnv):
         return [spec.index_of(aid) for aid in st.acting_agents
                 if spec.kind[spec.index_of(aid)] == _abi.KIND_CUSTOMER]
 
+    def _acting_customer_groups(self):
+        stages = np.unique(self._h_stage)
+        if len(stages) != 1:
+            return None
+        return [(slice(None), self._acting_customers(0))]
+
     def _host_reset(self, mask=None):
         sel = slice(None) if mask is None else np.asarray(mask, dtype=bool)
         self._h_step[sel] = 0

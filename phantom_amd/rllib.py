@@ -79,6 +79,39 @@ class RLlibEnvWrapper(_MultiAgentEnvBase):
         return f"<{type(self).__name__}{self.env}>"
 
 
+try:                                        # pragma: no cover
+    from ray.rllib.algorithms.callbacks import DefaultCallbacks as _CallbacksBase
+except Exception:                           # noqa: BLE001
+    _CallbacksBase = object
+
+
+class RLlibMetricLogger(_CallbacksBase):
+    """train.py:283-306: the RLlib callback that logs Phantom metrics -- ``episode.user_data[metric_id]`` collects one value
+    per step from ``base_env.envs[0]`` (with the batched env: instance 0 of the batch, a SubEnvView), ``on_episode_end``
+    reduces them into ``episode.custom_metrics``."""
+
+    def __init__(self, metrics) -> None:
+        if _CallbacksBase is not object:
+            super().__init__()
+        self.metrics = metrics
+
+    def on_episode_start(self, *, episode, **kwargs) -> None:
+        for metric_id in self.metrics.keys():
+            episode.user_data[metric_id] = []
+
+    def on_episode_step(self, *, base_env, episode, **kwargs) -> None:
+        from .metrics import logging_helper
+        env = base_env.envs[0]
+        logging_helper(env, self.metrics, episode.user_data)
+
+    def on_episode_end(self, *, episode, **kwargs) -> None:
+        for metric_id, metric in self.metrics.items():
+            episode.custom_metrics[metric_id] = metric.reduce(episode.user_data[metric_id], mode="train")
+
+    def __call__(self) -> "RLlibMetricLogger":
+        return self
+
+
 def register_env(name: str, env_class, registry=None):
     """train.py:185-187: ``ray.tune.registry.register_env(env_class.__name__, lambda config:
     RLlibEnvWrapper(env_class(**config)))``.  ``registry``: anything with ``register_env(name, creator)``
@@ -160,6 +193,11 @@ class SubEnvView:
     def current_step(self):
         s = self._env.current_step
         return int(s[self._b]) if isinstance(s, np.ndarray) else s
+
+    @property
+    def current_stage(self):
+        s = getattr(self._env, "current_stage", None)
+        return s[self._b] if isinstance(s, (list, tuple, np.ndarray)) else s
 
     def __getitem__(self, agent_id):
         return self.agents[agent_id]

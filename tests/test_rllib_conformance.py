@@ -107,6 +107,20 @@ def test_env_runner_style_loop_with_multi_env_dicts_matches_oracle():
             obs = {b: {f"SHOP{s}": cur[b, s] for s in range(S) if cur_v[b, s]} for b in range(B)}
     sub = base.envs[0]                                            # RLlibMetricLogger.on_episode_step: base_env.envs[0]
     assert sub.agents["SHOP1"].stock == int(o.get_i32("shop.stock")[0, 1])
+    # train.py:283-306: the metric-logging callback against a stand-in for RLlib's Episode
+    from phantom_amd.metrics import SimpleAgentMetric
+    from phantom_amd.rllib import RLlibMetricLogger
+
+    class Episode:
+        def __init__(self):
+            self.user_data, self.custom_metrics = {}, {}
+
+    cb = RLlibMetricLogger({"SHOP1/stock": SimpleAgentMetric("SHOP1", "stock", "mean")})()
+    ep = Episode()
+    cb.on_episode_start(episode=ep)
+    cb.on_episode_step(base_env=base, episode=ep)
+    cb.on_episode_end(episode=ep)
+    assert ep.custom_metrics["SHOP1/stock"] == float(o.get_i32("shop.stock")[0, 1])
     assert isinstance(base.get_sub_environments(as_dict=True), dict)
     base.stop()
 
@@ -129,3 +143,14 @@ def test_reference_rollout_task_loop_runs_on_the_wrapper():
         vec_observations = [st.observations for st in vec_steps]
     assert all(st.truncations["__all__"] for st in vec_steps)
     assert vec_envs[0]["SHOP"].stock == vec_envs[0].env.agents["SHOP"].stock       # wrapper.__getitem__
+
+
+def test_metric_logger_has_the_callback_surface():
+    """train.py:283-306: on_episode_start / on_episode_step / on_episode_end with keyword-only arguments, callable returning itself"""
+    from phantom_amd.rllib import RLlibMetricLogger
+    cb = RLlibMetricLogger({})
+    assert cb() is cb
+    for name, kw in (("on_episode_start", {"episode"}), ("on_episode_step", {"base_env", "episode"}), ("on_episode_end", {"episode"})):
+        params = inspect.signature(getattr(RLlibMetricLogger, name)).parameters
+        assert kw <= {k for k, p in params.items() if p.kind == inspect.Parameter.KEYWORD_ONLY}
+        assert any(p.kind == inspect.Parameter.VAR_KEYWORD for p in params.values())
