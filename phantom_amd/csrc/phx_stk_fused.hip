@@ -392,7 +392,17 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_step_fast_kerne
 // acting agent and step) + booking 1.8 k + outputs 7.0 k (four dependent table loads per agent), a quarter of the
 // lanes idle in the third pass over the agents.
 template <bool DYN, int NT>
-__global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(const DevSpec sp, const phx_rollout_io io) {
+__global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(const DevSpec* __restrict__ spp_, const phx_rollout_io io_) {
+  // The spec (device memory, DevSpec::self_dev) and the rollout arguments (kernarg) are read through the scalar cache where they
+  // are used: constant-address-space pointers whose provenance is hidden again at every step (STKR_REFRESH).  By value the two
+  // structs cost 126 spilled SGPRs (v_readlane / v_writelane inside the step loop).
+  typedef const __attribute__((address_space(4))) char* stk_kptr_t;
+  stk_kptr_t spc = (stk_kptr_t)spp_;
+  stk_kptr_t kp = (stk_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+#define sp (*(const DevSpec*)spc)
+#define io (*(const phx_rollout_io*)(kp + 8))
+#define STKR_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
+  STKR_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int A = sp.A, B = sp.B;
@@ -489,6 +499,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   };
 
   for (int t = 0; t < io.T; ++t) {
+    STKR_REFRESH();
     const int tt = step + 1;                                                 // env.py:252
     const int lsh = (tt & 1) ? 1 : 4;                                        // stackelberg.py:133-137: leaders on odd steps
     const int64_t row = ((int64_t)t * B + b) * A;
@@ -649,6 +660,9 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   }
   if (tid == 0) { fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick; }
 }
+#undef sp
+#undef io
+#undef STKR_REFRESH
 
 size_t phx_stk_rollout_lds(const DevSpec& sp) {
   const size_t nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER], A = sp.A;
@@ -671,8 +685,8 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
   if (STKR_SLOTS * nt < sp.A) return hipErrorInvalidConfiguration;
   const size_t lds = phx_stk_rollout_lds(sp);
   phx_note_kernel("phx_stk_rollout_kernel");
-#define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp, io); \
-                                  else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp, io); } while (0)
+#define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
+                                  else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); } while (0)
   switch (nt) {
     case 128: PHX_LAUNCH_STKR(128); break;
     case 256: PHX_LAUNCH_STKR(256); break;
