@@ -1,0 +1,139 @@
+/*
+ * phx_cpu_abi.c -- the CPU restatement behind the product's OWN symbols ("exports the identical symbols").
+ * TEST INFRASTRUCTURE ONLY, like the rest of oracle/ (see phx_oracle.h).
+ *
+ * Builds oracle/libphantom_cpu.so = phx_oracle.c + this file: every entry point of include/phantom_amd.h, same names and
+ * signatures, HOST pointers instead of device pointers, `stream` ignored, `device` ignored.  The ctypes stub of
+ * INTEGRATION.md section 2 (phantom_amd/_abi.py: bind_signatures) drives it unchanged; tests/test_cpu_abi.py does, and replays
+ * the reference's goldens through it.  The product never loads this library: phantom_amd/_abi.py binds
+ * phantom_amd/_lib/libphantom_amd.so only and fails loudly without it.
+ *
+ * Differences that follow from keeping the sequential restatement's state inside the handle:
+ *   - the caller's state blob is not used (phx_state_nbytes returns a token size, phx_n_fields 0: no zero-copy field views);
+ *     state is reached by name through phx_get_state / phx_set_state;
+ *   - phx_uses_fused is 0, phx_last_kernel names the restatement, phx_sync_fields is a no-op.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "phx_oracle.h"
+
+struct phx_env { phxo_env* o; int B, A, nnz, n_conn, n_samplers, trace_cap; };
+
+int phx_abi_version(void) { return PHX_ABI_VERSION; }
+const char* phx_last_error(void) { return phxo_last_error(); }
+const char* phx_last_kernel(void) { return "cpu restatement (oracle/phx_oracle.c)"; }
+
+int64_t phx_state_nbytes(const phx_spec* spec) { return (spec && spec->abi_version == PHX_ABI_VERSION) ? 256 : -1; }
+
+static int spec_query(const phx_spec* spec, int (*fn)(const phxo_env*)) {
+  phxo_env* o = phxo_create(spec);
+  if (!o) return -1;
+  const int v = fn(o);
+  phxo_destroy(o);
+  return v;
+}
+int phx_obs_dim(const phx_spec* spec) { return spec_query(spec, phxo_obs_dim); }
+int phx_n_strategic(const phx_spec* spec) { return spec_query(spec, phxo_n_strategic); }
+int phx_n_exo(const phx_spec* spec) { return spec_query(spec, phxo_n_exo); }
+
+int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state_nbytes, phx_env** out) {
+  (void)device; (void)state_blob; (void)state_nbytes;
+  if (!spec || !out) return PHX_EINVAL;
+  phxo_env* o = phxo_create(spec);
+  if (!o) return PHX_EINVAL;
+  phx_env* e = (phx_env*)calloc(1, sizeof *e);
+  e->o = o; e->B = spec->batch; e->A = spec->n_agents; e->nnz = spec->row_ptr ? spec->row_ptr[spec->n_agents] : 0;
+  e->n_conn = spec->n_conn; e->n_samplers = spec->n_samplers; e->trace_cap = spec->trace_cap;
+  phxo_reset(o, NULL, NULL, NULL, NULL, NULL);          /* phx_create runs the initial reset (include/phantom_amd.h) */
+  *out = e;
+  return PHX_OK;
+}
+void phx_destroy(phx_env* e) { if (e) { phxo_destroy(e->o); free(e); } }
+int phx_n_fields(const phx_env* e) { (void)e; return 0; }
+int phx_field_info(const phx_env* e, int index, phx_field* out) { (void)e; (void)index; (void)out; return PHX_EINVAL; }
+int phx_uses_fused(const phx_env* e) { (void)e; return 0; }
+int phx_sync_fields(phx_env* e, void* stream) { (void)e; (void)stream; return PHX_OK; }
+
+int phx_reset(phx_env* e, const uint8_t* reset_mask, const double* sampler_values, const uint8_t* conn_on, float* obs,
+              uint8_t* obs_valid, void* stream) {
+  (void)stream;
+  if (!e) return PHX_EINVAL;
+  phxo_reset(e->o, reset_mask, sampler_values, conn_on, obs, obs_valid);
+  return PHX_OK;
+}
+int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
+  (void)stream;
+  if (!e || !io) return PHX_EINVAL;
+  phxo_step(e->o, io);
+  return PHX_OK;
+}
+int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) { if (!e) return PHX_EINVAL; phxo_inject(e->o, msgs, n); return PHX_OK; }
+int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count, void* stream) {
+  (void)stream;
+  if (!e) return PHX_EINVAL;
+  phxo_resolve(e->o, err, msg_log, msg_count);
+  return PHX_OK;
+}
+int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
+  (void)stream;
+  if (!e || !io || io->T <= 0) return PHX_EINVAL;
+  phxo_rollout(e->o, io);
+  return PHX_OK;
+}
+
+/* copying state access by field name: the restatement knows a field as i32, f64 or u8 */
+static size_t scratch_elems(const phx_env* e) {
+  size_t per = (size_t)(e->A > e->nnz ? e->A : e->nnz);
+  if ((size_t)e->n_conn > per) per = (size_t)e->n_conn;
+  if ((size_t)e->n_samplers > per) per = (size_t)e->n_samplers;
+  return (size_t)e->B * (per + 1) * 3;
+}
+int64_t phx_get_state(phx_env* e, const char* field, void* buf, int64_t buf_nbytes, void* stream) {
+  (void)stream;
+  if (!e || !field || !buf) return PHX_EINVAL;
+  const size_t n = scratch_elems(e);
+  void* tmp = malloc(n * 8);
+  int64_t got, esz = 4;
+  got = phxo_get_i32(e->o, field, (int32_t*)tmp);
+  if (got < 0) { got = phxo_get_f64(e->o, field, (double*)tmp); esz = 8; }
+  if (got < 0) { got = phxo_get_u8(e->o, field, (uint8_t*)tmp); esz = 1; }
+  int64_t rc = PHX_EINVAL;
+  if (got >= 0 && got * esz <= buf_nbytes) { memcpy(buf, tmp, (size_t)(got * esz)); rc = got * esz; }
+  free(tmp);
+  return rc;
+}
+int64_t phx_set_state(phx_env* e, const char* field, const void* buf, int64_t buf_nbytes, void* stream) {
+  (void)stream;
+  if (!e || !field || !buf) return PHX_EINVAL;
+  const size_t n = scratch_elems(e);
+  int32_t* tmp = (int32_t*)malloc(n * 4);
+  const int64_t have = phxo_get_i32(e->o, field, tmp);      /* the field's element count */
+  free(tmp);
+  if (have < 0 || have * 4 != buf_nbytes) return PHX_EINVAL;
+  return phxo_set_i32(e->o, field, (const int32_t*)buf) < 0 ? PHX_EINVAL : buf_nbytes;
+}
+int phx_trace(phx_env* e, const phx_msg_rec* msg_log, const int32_t* msg_count, int b, phx_msg_rec* out, int cap, void* stream) {
+  (void)stream;
+  if (!e || !msg_log || !msg_count || (cap > 0 && !out) || b < 0 || b >= e->B) return PHX_EINVAL;
+  int n = msg_count[b];
+  if (n > e->trace_cap) n = e->trace_cap;
+  const int m = n < cap ? n : cap;
+  if (m > 0) memcpy(out, msg_log + (size_t)b * e->trace_cap, (size_t)m * sizeof(phx_msg_rec));
+  return n;
+}
+int phx_pack_flags(const uint8_t* src, uint64_t* dst, int64_t n, void* stream) {
+  (void)stream;
+  if (!src || !dst || n < 0) return PHX_EINVAL;
+  const int64_t words = (n + 63) / 64;
+  memset(dst, 0, (size_t)words * 8);
+  for (int64_t i = 0; i < n; ++i) if (src[i]) dst[i >> 6] |= (uint64_t)1 << (i & 63);
+  return PHX_OK;
+}
+int phx_unpack_flags(const uint64_t* src, uint8_t* dst, int64_t n, void* stream) {
+  (void)stream;
+  if (!src || !dst || n < 0) return PHX_EINVAL;
+  for (int64_t i = 0; i < n; ++i) dst[i] = (uint8_t)((src[i >> 6] >> (i & 63)) & 1u);
+  return PHX_OK;
+}

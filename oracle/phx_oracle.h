@@ -8,7 +8,8 @@
  * reference's own known-answer tests (tests/test_oracle_reference_kats.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
- * library -- as the checker / the timed CPU baseline, never as the product path.  The
+ * library (and libphantom_cpu.so, the same restatement behind the product's phx_* symbols: phx_cpu_abi.c)
+ * -- as the checker / the timed CPU baseline, never as the product path.  The
  * product (phantom_amd/csrc, libphantom_amd.so) shares NO algorithm code with this file;
  * the two only share the type definitions in include/phantom_amd.h.
  */

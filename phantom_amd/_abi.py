@@ -130,20 +130,10 @@ def _check_arch(torch):
             f"PHX_OFFLOAD_ARCH='{arch}' (the kernels are tuned for gfx950 / MI355X only)")
 
 
-def load_library():
-    """Load libphantom_amd.so (built in-tree by ``phantom_amd.build``); never falls back."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run "
-            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback).")
-    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Import it FIRST so that this
-    # library's NEEDED libamdhip64.so.7 resolves to the already-loaded runtime: two HIP runtimes
-    # in one process do not share devices/streams ("no ROCm-capable device is detected").
-    import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+def bind_signatures(lib):
+    """restype / argtypes of every entry point of include/phantom_amd.h on a loaded library (the ctypes stub of
+    INTEGRATION.md section 2).  Used for libphantom_amd.so here and, unchanged, for the CPU restatement behind the same
+    symbols in tests (oracle/libphantom_cpu.so: host pointers)."""
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.phx_abi_version.restype = i32
     lib.phx_last_kernel.restype = C.c_char_p
@@ -185,6 +175,24 @@ def load_library():
     lib.phx_pack_flags.argtypes = [vp, vp, i64, vp]
     lib.phx_unpack_flags.restype = i32
     lib.phx_unpack_flags.argtypes = [vp, vp, i64, vp]
+    return lib
+
+
+def load_library():
+    """Load libphantom_amd.so (built in-tree by ``phantom_amd.build``); never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback).")
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Import it FIRST so that this
+    # library's NEEDED libamdhip64.so.7 resolves to the already-loaded runtime: two HIP runtimes
+    # in one process do not share devices/streams ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    bind_signatures(lib)
     if lib.phx_abi_version() != ABI_VERSION:
         raise RuntimeError("libphantom_amd.so ABI version mismatch")
     _check_arch(torch)

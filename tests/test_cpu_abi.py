@@ -1,0 +1,137 @@
+"""CPU: the restatement behind the product's OWN symbols (oracle/libphantom_cpu.so, SURVEY 8b / 8d "exports the identical
+symbols").  The ctypes stub a Phantom maintainer would add (phantom_amd/_abi.py: bind_signatures -- INTEGRATION.md section 2)
+is applied UNCHANGED to that library; the reference's goldens are replayed through phx_create / phx_reset / phx_step with host
+numpy buffers, and phx_rollout / phx_get_state / phx_set_state / phx_trace / phx_pack_flags are exercised through the same
+signatures.  Test infrastructure: the product never loads this library."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import env_from_golden, f32_bits, f64_bits, golden, supply_chain_env
+from phantom_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU_LIB = os.path.join(ROOT, "oracle", "libphantom_cpu.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libphantom_cpu.so"])
+    return _abi.bind_signatures(C.CDLL(CPU_LIB))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class CpuAbiRunner:
+    """the same calls DeviceEnv makes, with host numpy buffers"""
+
+    def __init__(self, lib, spec):
+        self.lib, self.spec = lib, spec
+        self.cs, self._keep = spec.to_ctypes()
+        cs = C.byref(self.cs)
+        self.B, self.S = spec.batch, lib.phx_n_strategic(cs)
+        self.D, self.n_exo = lib.phx_obs_dim(cs), lib.phx_n_exo(cs)
+        n = lib.phx_state_nbytes(cs)
+        assert n > 0
+        self.blob = np.zeros(n, np.uint8)
+        h = C.c_void_p()
+        assert lib.phx_create(cs, 0, _p(self.blob), n, C.byref(h)) == 0, lib.phx_last_error()
+        self.h = h
+        B, S, D = self.B, max(self.S, 1), self.D
+        self.obs = np.zeros((B, S, D), np.float32); self.reward = np.zeros((B, S), np.float64)
+        self.obs_valid = np.zeros((B, S), np.uint8); self.reward_valid = np.zeros((B, S), np.uint8)
+        self.terminated = np.zeros((B, S), np.uint8); self.truncated = np.zeros((B, S), np.uint8)
+        self.done_valid = np.zeros((B, S), np.uint8)
+        self.all_terminated = np.zeros(B, np.uint8); self.all_truncated = np.zeros(B, np.uint8)
+        self.err = np.zeros(B, np.int32)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.phx_destroy(self.h)
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        assert self.lib.phx_reset(self.h, _p(m), None, None, _p(self.obs), _p(self.obs_valid), None) == 0
+        return self.obs.copy(), self.obs_valid.copy()
+
+    def step(self, actions, exo=None):
+        io = _abi.PhxStepIO()
+        self._a = np.ascontiguousarray(actions, np.float32)
+        self._x = None if exo is None else np.ascontiguousarray(exo, np.uint8)
+        io.actions, io.exo = _p(self._a), _p(self._x)
+        io.obs, io.obs_valid, io.reward, io.reward_valid = _p(self.obs), _p(self.obs_valid), _p(self.reward), _p(self.reward_valid)
+        io.terminated, io.truncated, io.done_valid = _p(self.terminated), _p(self.truncated), _p(self.done_valid)
+        io.all_terminated, io.all_truncated, io.err = _p(self.all_terminated), _p(self.all_truncated), _p(self.err)
+        assert self.lib.phx_step(self.h, C.byref(io), None) == 0
+
+    def get_i32(self, field, shape):
+        out = np.zeros(shape, np.int32)
+        assert self.lib.phx_get_state(self.h, field.encode(), _p(out), out.nbytes, None) == out.nbytes
+        return out
+
+
+def test_every_declared_symbol_is_exported_with_the_products_signatures(lib):
+    for name in _abi.EXPORTS:
+        assert hasattr(lib, name), name
+    assert lib.phx_abi_version() == _abi.ABI_VERSION and b"restatement" in lib.phx_last_kernel()
+
+
+@pytest.mark.parametrize("name", ["sc7_fixed20", "sc64", "sc256_fsm"])
+def test_reference_goldens_through_the_identical_stub(lib, name):
+    g = golden(name)
+    T = int(g["T"])
+    env = env_from_golden(g)
+    run = CpuAbiRunner(lib, env.spec)
+    for t in range(T):
+        rb = g["reset_before"][t]
+        if rb.any():
+            obs, valid = run.reset(rb)
+            m = rb.astype(bool)
+            np.testing.assert_array_equal(valid[m], g["reset_obs_valid"][t][m])
+        run.step(g["actions"][t], g["exo"][t])
+        assert (run.err == 0).all()
+        S = run.S
+        np.testing.assert_array_equal(run.get_i32("shop.stock", (run.B, S)), g["stock"][t], err_msg=f"stock t={t}")
+        np.testing.assert_array_equal(run.obs_valid, g["obs_valid"][t])
+        ov = g["obs_valid"][t].astype(bool)
+        np.testing.assert_array_equal(f32_bits(run.obs[ov]), f32_bits(g["obs"][t][ov]), err_msg=f"obs t={t}")
+        rv = g["reward_valid"][t] == 1
+        np.testing.assert_array_equal(f64_bits(run.reward[rv]), f64_bits(g["reward"][t][rv]))
+        np.testing.assert_array_equal(run.all_truncated, g["all_truncated"][t])
+
+
+def test_rollout_state_trace_and_flag_packing_through_the_abi(lib):
+    B, S, T = 6, 3, 25
+    env = supply_chain_env(S, [2] * S, 10, B, seed=5, tracking=True, force_generic=True)
+    run = CpuAbiRunner(lib, env.spec)
+    run.reset()
+    io = _abi.PhxRolloutIO()
+    io.T = T
+    bufs = dict(obs=np.zeros((T, B, S, 3), np.float32), act=np.zeros((T, B, S), np.float32), rew=np.zeros((T, B, S), np.float32),
+                ter=np.zeros((T, B, S), np.uint8), tru=np.zeros((T, B, S), np.uint8), last=np.zeros((B, S, 3), np.float32),
+                log=np.zeros((T, B, env.spec.trace_cap, 16), np.uint8), cnt=np.zeros((T, B), np.int32))
+    io.obs, io.action_out, io.reward, io.terminated, io.truncated = (_p(bufs[k]) for k in ("obs", "act", "rew", "ter", "tru"))
+    io.last_obs, io.err, io.msg_log, io.msg_count = _p(bufs["last"]), _p(run.err), _p(bufs["log"]), _p(bufs["cnt"])
+    assert lib.phx_rollout(run.h, C.byref(io), None) == 0
+    assert bufs["tru"].sum() == 2 * B * S and (bufs["cnt"] > 0).all()
+    stock = run.get_i32("shop.stock", (B, S))
+    assert ((stock >= 0) & (stock <= 100)).all()
+    new = ((np.arange(B * S, dtype=np.int32).reshape(B, S) * 7) % 90).astype(np.int32)
+    assert lib.phx_set_state(run.h, b"shop.stock", _p(new), new.nbytes, None) == new.nbytes
+    np.testing.assert_array_equal(run.get_i32("shop.stock", (B, S)), new)
+    assert lib.phx_get_state(run.h, b"no.such.field", _p(new), new.nbytes, None) < 0
+    recs = (_abi.PhxMsgRec * env.spec.trace_cap)()
+    n = lib.phx_trace(run.h, _p(bufs["log"][T - 1]), _p(bufs["cnt"][T - 1]), 2, recs, env.spec.trace_cap, None)
+    assert n == int(bufs["cnt"][T - 1, 2]) and recs[0].type != 0
+    x = (np.random.default_rng(0).random(1003) < 0.3).astype(np.uint8) * 5
+    packed = np.zeros((1003 + 63) // 64, np.uint64)
+    assert lib.phx_pack_flags(_p(x), _p(packed), x.size, None) == 0
+    np.testing.assert_array_equal(packed.view(np.uint8)[:126], np.packbits(x != 0, bitorder="little"))
+    back = np.zeros(1003, np.uint8)
+    assert lib.phx_unpack_flags(_p(packed), _p(back), x.size, None) == 0
+    np.testing.assert_array_equal(back, (x != 0).astype(np.uint8))
