@@ -542,6 +542,25 @@ def run(args, rank, local_rank, world, watch):
         dev.rollout(T, out=traj)                 # back to the bench fragment's buffers
     except Exception as e:                       # report, do not hide
         frag1 = {"error": str(e)}
+    # the same launches WITHOUT the `terminations` plane (all zero: ShopAgent never terminates; phx_rollout_io.terminated = NULL):
+    # 21 instead of 22 bytes per shop-step.  Informational: `value` and `roofline` above write the full 22-byte record.
+    no_term = None
+    try:
+        tn = [dev.alloc_trajectory(T, terminations=False) for _ in range(n_buf)]
+        for k in range(4):
+            dev.rollout(T, out=tn[k % n_buf])
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for k in range(n_full):
+            dev.rollout(T, out=tn[k % n_buf])
+        g1.record(); torch.cuda.synchronize()
+        msn = g0.elapsed_time(g1) / n_full
+        algn = alg - B * T * S
+        no_term = {"launch_ms": msn, "algorithmic_bytes_per_launch": algn, "achieved": algn / (msn * 1e-3) / 1e9,
+                   "frac": algn / (msn * 1e-3) / 1e9 / HBM_PEAK_GBS, "agent_steps_per_sec": N_AGENTS * B * T / (msn * 1e-3)}
+        del tn
+    except Exception as e:                       # report, do not hide
+        no_term = {"error": str(e)[:300]}
     # achievable write bandwidth of this box for buffers of the trajectory's size (a plain fill, same rotation)
     fills = [torch.empty(alg // 4, dtype=torch.float32, device=dev.device) for _ in range(n_buf)]
     for f in fills:
@@ -563,7 +582,7 @@ def run(args, rank, local_rank, world, watch):
                                        "note": "every launch rewrites ONE buffer in place (a T = 100 fragment fits the 256 MB Infinity Cache): not the HBM figure"},
                        "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs,
                        "ms_per_100_steps": launch_ms * NUM_STEPS / T,
-                       "one_episode_per_launch": frag1}
+                       "one_episode_per_launch": frag1, "without_terminations_plane": no_term}
 
     # ---- per-launch PhantomEnv.step mode (one kernel launch per step) ---------------------------
     if not args.no_per_step:

@@ -286,7 +286,8 @@ typedef struct phx_rollout_io {
   float*    obs;               /* [T][B][S][D]  post-step observation                       */
   float*    action_out;        /* [T][B][S]     action taken                                */
   float*    reward;            /* [T][B][S]     f64 reward rounded to f32                   */
-  uint8_t*  terminated;        /* [T][B][S]                                                 */
+  uint8_t*  terminated;        /* [T][B][S]; may be NULL where the plane is all zero and the serving kernel can omit it
+                                  (plain supply-chain env on the time-parallel rollout kernel), PHX_EINVAL otherwise */
   uint8_t*  truncated;         /* [T][B][S]     per-agent flag OR'ed with __all__ truncation */
   uint8_t*  obs_valid;         /* [T][B][S] or NULL: 1 <=> aid in step.observations (FSM envs) */
   uint8_t*  reward_valid;      /* [T][B][S] or NULL: 0 absent, 1 value, 2 None (FSM envs)      */

@@ -274,6 +274,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
     char* const p_act = (char*)(io.action_out + row0);
     char* const p_tru = (char*)(io.truncated + row0);
     char* const p_ter = (char*)(io.terminated + row0);
+    const bool wr_ter = io.terminated != nullptr;           // NULL: the caller does not want the all-zero plane (ShopAgent never terminates)
     const uint32_t utotal = (uint32_t)total;
     const int G4 = G >> 2, nw = NT - first, n_units = tc * G4;
     const uint32_t PR = 3u * (uint32_t)G4;                              // 16-byte observation pieces per tile row
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
         *(float4*)(p_rew + (size_t)(eo * 4u)) = vrw;
         *(float4*)(p_act + (size_t)(eo * 4u)) = va;
         *(uint32_t*)(p_tru + (size_t)eo) = tr;
-        *(uint32_t*)(p_ter + (size_t)eo) = 0u;
+        if (wr_ter) *(uint32_t*)(p_ter + (size_t)eo) = 0u;
       }
     }
   };

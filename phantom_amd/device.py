@@ -303,7 +303,8 @@ class DeviceEnv:
         k = self.spec.kind[self.spec.strategic_idx] if self.S else np.zeros(0, np.uint8)
         return bool(np.isin(k, (_abi.KIND_SHOP, _abi.KIND_SELLER, _abi.KIND_BUYER)).all())
 
-    def alloc_trajectory(self, T: int, record_messages: bool = False, flat: bool = False) -> Trajectory:
+    def alloc_trajectory(self, T: int, record_messages: bool = False, flat: bool = False,
+                         terminations: bool = True) -> Trajectory:
         """Uninitialised device buffers for a T-step fragment (time-major).  ``record_messages``:
         also the per-step ordered message log (rollout.py:369-373, needs enable_tracking).
         ``flat``: every plane is a 256-byte aligned section of ONE buffer, ordered so that what a
@@ -338,8 +339,10 @@ class DeviceEnv:
             return Trajectory(v["observations"], v["actions"], v["rewards"], v["terminations"], v["truncations"],
                               v["last_obs"], v.get("obs_valid"), v.get("reward_valid"), None, None,
                               buf, v["packed_flags"], gather_nbytes)
+        # terminations=False: no `terminations` plane (it is all zero for kinds that never terminate; phx_rollout accepts
+        # the omission where the serving kernel can leave the plane out and returns an error otherwise)
         return Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
-                          e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8),
+                          e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8) if terminations else None,
                           e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),
                           e(T, B, S, dtype=torch.uint8) if fsm else None,
                           e(T, B, S, dtype=torch.uint8) if fsm else None,
@@ -373,7 +376,8 @@ class DeviceEnv:
         need("out.observations", out.observations, torch.float32, (B, S, D))
         need("out.actions", out.actions, torch.float32, (B, S))
         need("out.rewards", out.rewards, torch.float32, (B, S))
-        need("out.terminations", out.terminations, torch.uint8, (B, S))
+        if out.terminations is not None:                   # None: the all-zero plane left out (the library decides whether it can be)
+            need("out.terminations", out.terminations, torch.uint8, (B, S))
         need("out.truncations", out.truncations, torch.uint8, (B, S))
         need("out.last_obs", out.last_obs, torch.float32, (S, D), lead=B)
         if self._needs_valid_planes():

@@ -427,3 +427,27 @@ def test_autotune_rollout_picks_a_candidate_and_keeps_the_trajectories():
     np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
     np.testing.assert_array_equal(tr.truncations.cpu().numpy(), ro["truncated"])
     assert "phx_sc_rollout_fast_kernel" in env._device().last_kernel()
+
+
+def test_rollout_without_the_all_zero_terminations_plane():
+    """phx_rollout_io.terminated may be NULL on the time-parallel supply-chain kernel (ShopAgent never terminates): every other
+    plane equals the oracle's; envs / kernels that cannot leave the plane out refuse loudly."""
+    env = supply_chain_env(9, [6] * 9, 100, 64, seed=17)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    dev = d.dev
+    tr = dev.alloc_trajectory(130, terminations=False)
+    assert tr.terminations is None
+    dev.rollout(130, out=tr)
+    ro = o.rollout(130)
+    np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
+    np.testing.assert_array_equal(f32_bits(tr.actions.cpu().numpy()), f32_bits(ro["actions"]))
+    np.testing.assert_array_equal(tr.truncations.cpu().numpy(), ro["truncated"])
+    assert int(ro["terminated"].sum()) == 0
+    envf = supply_chain_env(9, [6] * 9, 100, 64, fsm=True, seed=17)
+    df = _dev(envf.spec); df.reset()
+    trf = df.dev.alloc_trajectory(10, terminations=False)
+    from phantom_amd.device import DeviceError
+    with pytest.raises(DeviceError):
+        df.dev.rollout(10, out=trf)
