@@ -336,8 +336,12 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
       if (u < n_units) {
         *(float4*)(p_rew + (size_t)(eo * 4u)) = vrw;
         *(float4*)(p_act + (size_t)(eo * 4u)) = va;
+#ifndef PHX_ABL_NOFLAGS
         *(uint32_t*)(p_tru + (size_t)eo) = tr;
         if (wr_ter) *(uint32_t*)(p_ter + (size_t)eo) = 0u;
+#else
+        if (a.norm == -12345) *(uint32_t*)(p_tru + (size_t)eo) = tr;     // dev ablation: neither flag plane is stored
+#endif
       }
     }
   };
