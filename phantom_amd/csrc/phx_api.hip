@@ -509,17 +509,20 @@ static void build_static_schedule(const phx_spec* sp, const Derived& d, StaticSc
   struct M { int src, dst, type; };
   for (int l = 0; l < d.n_lists; ++l) {
     std::vector<M> q;
+    std::vector<int32_t> act_off;                                // queue offset of each acting item's message, -1: sends nothing
     bool ok = true;
     for (int k = d.act_ptr[l]; k < d.act_ptr[l + 1] && ok; ++k) {
       const int a = d.act_idx[k], kind = sp->kind[a], dst = sp->param_i[a * PHX_NPI];
       if (kind == PHX_KIND_SHOP || kind == PHX_KIND_CUSTOMER) {
         const int type = kind == PHX_KIND_SHOP ? PHX_MSG_STOCK_REQUEST : PHX_MSG_ORDER_REQUEST;
         ok = dst >= 0 && dst < A && edge(a, dst) && payload_ok(a, dst, type);
+        act_off.push_back((int32_t)q.size());
         q.push_back({a, dst, type});
-      }
+      } else act_off.push_back(-1);
     }
     if (!ok || (int)q.size() > sp->queue_cap) continue;
     std::vector<int32_t> rec(1 + PHX_SCHED_MAX_ROUNDS, 0);
+    rec.insert(rec.end(), act_off.begin(), act_off.end());
     int R = 0;
     while (!q.empty() && ok) {
       if (R == PHX_SCHED_MAX_ROUNDS || (sp->round_limit >= 0 && R >= sp->round_limit)) { ok = false; break; }
@@ -530,19 +533,21 @@ static void build_static_schedule(const phx_spec* sp, const Derived& d, StaticSc
       for (int i = 0; i < n; ++i) if (first[q[i].dst] == i) { goff[q[i].dst] = run; run += cnt[q[i].dst]; }   // dict order of receivers
       for (int i = 0; i < n; ++i) order[goff[q[i].dst] + fill[q[i].dst]++] = i;                               // batches in send order
       std::vector<M> nq;
+      std::vector<int32_t> next_off(n, -1);                       // where the reply to inbox position P goes in the next queue
       for (int P = 0; P < n && ok; ++P) {                       // replies in handling order
         const M m = q[order[P]];
         const int rk = sp->kind[m.dst];
         if (rk == PHX_KIND_FACTORY && m.type == PHX_MSG_STOCK_REQUEST) {
-          ok = payload_ok(m.dst, m.src, PHX_MSG_STOCK_RESPONSE); nq.push_back({m.dst, m.src, PHX_MSG_STOCK_RESPONSE});
+          ok = payload_ok(m.dst, m.src, PHX_MSG_STOCK_RESPONSE); next_off[P] = (int32_t)nq.size(); nq.push_back({m.dst, m.src, PHX_MSG_STOCK_RESPONSE});
         } else if (rk == PHX_KIND_SHOP && m.type == PHX_MSG_ORDER_REQUEST) {
-          ok = payload_ok(m.dst, m.src, PHX_MSG_ORDER_RESPONSE); nq.push_back({m.dst, m.src, PHX_MSG_ORDER_RESPONSE});
+          ok = payload_ok(m.dst, m.src, PHX_MSG_ORDER_RESPONSE); next_off[P] = (int32_t)nq.size(); nq.push_back({m.dst, m.src, PHX_MSG_ORDER_RESPONSE});
         } else if ((rk == PHX_KIND_SHOP && m.type == PHX_MSG_STOCK_RESPONSE) || (rk == PHX_KIND_CUSTOMER && m.type == PHX_MSG_ORDER_RESPONSE)) {
         } else ok = false;                                        // no handler: the dynamic path reports it
       }
       if ((int)nq.size() > sp->queue_cap) ok = false;
       rec[1 + R] = n;
       rec.insert(rec.end(), cnt.begin(), cnt.end()); rec.insert(rec.end(), goff.begin(), goff.end()); rec.insert(rec.end(), order.begin(), order.end());
+      rec.insert(rec.end(), next_off.begin(), next_off.end());
       ++R; q.swap(nq);
     }
     if (!ok) continue;

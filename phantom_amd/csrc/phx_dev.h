@@ -81,8 +81,10 @@ struct DevSpec {
   const int32_t* stage_tab;      // [n_lists][num_steps + 1] tabulated clock / stage handlers (phx_spec.stage_tab), or NULL
   // generic engine, drop-out-free supply-chain specs: the round schedule of a step in which every agent is live and every acting
   // strategic agent has an action, simulated once at phx_create (phx_api.hip: build_static_schedule).  sched + sched_off[list]:
-  // [R, n_0 .. n_7] then per round { cnt[A], goff[A], order[n_r] } = inbox sizes, inbox offsets in first-arrival (dict) order and the
-  // queue index of every inbox position in send order -- what the per-round LDS atomics, block scan and rank sort compute.
+  // [R, n_0 .. n_7], act_off[acting items] (queue offset of the item's message or -1), then per round { cnt[A], goff[A], order[n_r],
+  // next_off[n_r] } = inbox sizes, inbox offsets in first-arrival (dict) order, the queue index of every inbox position in send
+  // order, and where the reply to that position goes in the next queue (-1: none) -- what the acting phase's counts and scan and
+  // the per-round LDS atomics, block scans and rank sort compute.
   const int32_t* sched;          // or NULL
   const int32_t* sched_off;      // [n_lists] offset of the list's schedule in `sched`, -1: this list is not static
   const uint8_t* stage_rew_all;  // [n_lists] rewarded_agents is None (every strategic agent observes, fsm.py:315-317)

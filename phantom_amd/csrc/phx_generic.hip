@@ -731,7 +731,13 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   for (int a = tid; a < A; a += NT) {
     const int s = tp.strat_rank[a];
     live[a] = (g.resolve_only || s < 0) ? 1 : !(term[s] | trunc[s]);
-    if (sch && !live[a]) s_dyn = 1;
+    if (sch) {
+      if (!live[a]) s_dyn = 1;
+      else if (s >= 0 && tkind(tp, a) == PHX_KIND_SHOP && sp.act_mask[(int64_t)list * A + a]) {     // an acting shop without an action
+        const bool has = g.roll_t >= 0 || (g.io.actions && (!g.io.action_valid || g.io.action_valid[(int64_t)b * S + s]));
+        if (!has) s_dyn = 1;
+      }
+    }
   }
   if (roll_t >= 0) {
     // the policy of a rollout, fused: every strategic agent's action of this tick (random policy = the
@@ -765,6 +771,22 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   const uint8_t* av_b = g.io.action_valid ? g.io.action_valid + (int64_t)b * S : nullptr;
   const uint8_t* exo_b = g.io.exo ? g.io.exo + step_env * sp.n_exo : nullptr;
 
+  const bool use_sched = sch != nullptr && __builtin_amdgcn_readfirstlane(s_dyn) == 0;   // uniform: s_dyn was last written before the barrier above
+  int n;
+  if (use_sched) {
+    // scheduled step: every acting item's queue offset is in the table and every send passed its checks at phx_create
+    const int32_t* act_off = sch + 1 + PHX_SCHED_MAX_ROUNDS;
+    for (int it = tid; it < n_act; it += NT) {
+      const int off = act_off[it];
+      const int a = act_list[it], s = tp.strat_rank[a];
+      const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);            // aid in actions, env.py:330
+      // (an item without a message still decodes its action: the mock agents count decode_action calls)
+      act_emit(sp, tp, b, a, has, has ? actions_b[s] : 0.0f, exo_b, tick, q0 + (off < 0 ? 0 : off));
+    }
+    n = sch[1];
+    __syncthreads();
+    GTICK(3);
+  } else {
   // per-item message counts -> exclusive scan -> queue offsets (scanbuf holds scan_cap >= n_items)
   for (int it = tid; it < n_items; it += NT) {
     int c = 0;
@@ -778,14 +800,13 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
         const int s = tp.strat_rank[a];
         const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);        // aid in actions, env.py:330
         c = act_count(sp, tp, b, a, has, has ? actions_b[s] : 0.0f);
-        if (sch && c == 0) { const int ka = tkind(tp, a); if (ka == PHX_KIND_SHOP || ka == PHX_KIND_CUSTOMER) s_dyn = 1; }   // a shop without an action
       }
     }
     scanbuf[it] = c;
   }
   __syncthreads();
   GTICK(1);
-  int n = block_exscan<NT>(scanbuf, n_items, wave_sums);
+  n = block_exscan<NT>(scanbuf, n_items, wave_sums);
   if (n > Q) { if (tid == 0) set_errkey(&s_errkey, n_items, PHX_ERR_QUEUE_FULL); n = 0; }
   else {
     for (int it = tid; it < n_items; it += NT) {
@@ -815,6 +836,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   }
   __syncthreads();
   GTICK(3);
+  }   // dynamic acting phase
 
   // pre_message_resolution for every live agent (env.py:170-173)
   if (full)
@@ -837,17 +859,20 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   // ---- BatchResolver.resolve round loop (resolvers.py:128-163) ---------------------------------
   DevMsg* qc = q0; DevMsg* qn = q1;
   int round = 0;
-  const bool use_sched = sch != nullptr && s_dyn == 0;      // (uniform: s_dyn was last written before the barriers above)
   const int sch_R = use_sched ? sch[0] : 0;
-  int sch_pos = 1 + PHX_SCHED_MAX_ROUNDS;                    // offset of the current round's tables in the schedule
+  int sch_pos = 1 + PHX_SCHED_MAX_ROUNDS + n_act;            // offset of the current round's tables in the schedule
   while (n > 0 && (sp.round_limit < 0 || round < sp.round_limit) && round < PHX_MAX_ROUNDS) {
     const int* ord;                                          // inbox position -> queue index, batches in send order
-    if (use_sched && round < sch_R && n == sch[1 + round]) {
+    const int32_t* next_off = nullptr;                       // scheduled round: where the reply to each inbox position goes
+    // (n is the same in every lane; readfirstlane tells the compiler so: the branches below hold barriers and scalar loads)
+    const bool sched_round = use_sched && round < sch_R && __builtin_amdgcn_readfirstlane(n) == sch[1 + round];
+    if (sched_round) {
       // static round: inbox sizes, offsets (receivers in first-arrival order) and batch order come from the table
       const int32_t* rt = sch + sch_pos;
       for (int a = tid; a < A; a += NT) { cnt[a] = rt[a]; goff[a] = rt[A + a]; }
       ord = rt + 2 * A;
-      sch_pos += 2 * A + n;
+      next_off = ord + n;
+      sch_pos += 2 * A + 2 * n;
       __syncthreads();
       GTICK(9);
     } else {
@@ -928,7 +953,11 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     // `r`, `live_a`: the receiver's agent_ref and context flag; `src_kind`: kind of the sender (for the payload whitelist of a reply)
     auto deliver = [&](int a, const AgentRef& r, bool live_a, int P, const DevMsg& m, int src_kind, AgentState& st) __attribute__((always_inline)) {
       DevMsg out; out.type = 0;
-      if (live_a && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
+      if (sched_round) {                                        // scheduled round: every check was made at phx_create
+        int code = 0;
+        if (!handle_message(sp, tp, b, a, r, m, clock + P, exo_b, tick, out, code, st)) out.type = 0;
+        if (code) set_errkey(&s_errkey, seq_base + P, code);
+      } else if (live_a && m.type != 0 && (!(sp.flags & PHX_F_IGNORE_CONN_ERRORS) || dev_has_edge(sp, tp, m.src, m.dst))) {
         int code = 0;
         const bool answered = handle_message(sp, tp, b, a, r, m, clock + P, exo_b, tick, out, code, st);
         if (code) set_errkey(&s_errkey, seq_base + P, code);
@@ -941,7 +970,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
         } else out.type = 0;
       }
       resp[P] = out;
-      scanbuf[P] = out.type != 0;
+      if (!sched_round) scanbuf[P] = out.type != 0;
     };
     // receivers without state (factory, customer, ...): one lane per MESSAGE -- the handlers of a batch commute
     for (int P = tid; P < n; P += NT) {
@@ -990,11 +1019,16 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     }
     __syncthreads();
     GTICK(10);
-    int n_next = block_exscan<NT>(scanbuf, n, wave_sums);
+    int n_next;
+    if (sched_round) {                                          // scheduled round: the replies' offsets are static (no scan)
+      n_next = round + 1 < sch_R ? sch[2 + round] : 0;
+      for (int P = tid; P < n; P += NT) { const int off = next_off[P]; if (off >= 0) qn[off] = resp[P]; }
+    } else n_next = block_exscan<NT>(scanbuf, n, wave_sums);
     if (n_next > Q) { if (tid == 0) set_errkey(&s_errkey, seq_base + n, PHX_ERR_QUEUE_FULL); n_next = 0; }
     else {
-      for (int P = tid; P < n; P += NT)
-        if (resp[P].type != 0) qn[scanbuf[P]] = resp[P];
+      if (!sched_round)
+        for (int P = tid; P < n; P += NT)
+          if (resp[P].type != 0) qn[scanbuf[P]] = resp[P];
       for (int x = 0; x < n_adx; ++x) {
         const int a = sp.adx_idx[x];
         if (cnt[a] > 0 && first[a] != -1)
