@@ -652,8 +652,11 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   __shared__ int wave_sums[NT / 64];
   __shared__ int s_errkey, s_nterm, s_ntrunc, s_dyn;
 #ifdef PHX_TIMING
-  unsigned long long gtm[16] = {0}, gprev = __builtin_readcyclecounter();
-#define GTICK(k) do { PHX_REFRESH(); const unsigned long long now_ = __builtin_readcyclecounter(); gtm[k] += now_ - gprev; gprev = now_; } while (0)
+  __shared__ unsigned long long gtm[17];
+  if (threadIdx.x < 17) gtm[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) gtm[16] = wall_clock64();
+#define GTICK(k) do { PHX_REFRESH(); if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); gtm[k] += now_ - gtm[16]; gtm[16] = now_; } } while (0)
 #else
 #define GTICK(k) PHX_REFRESH()
 #endif
