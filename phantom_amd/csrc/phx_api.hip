@@ -15,7 +15,7 @@
 #include "phx_dev.h"
 
 
-size_t phx_generic_queue_bytes(int A, int Q, int scan_cap, int n_adx);
+size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx);
 size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
@@ -455,7 +455,7 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
   // workspace of the generic engine when its queues do not fit LDS
   int n_adx_spec = 0;
   for (int a = 0; a < d.A; ++a) n_adx_spec += sp->kind[a] == PHX_KIND_ADEXCHANGE;
-  const size_t qb = phx_generic_queue_bytes(d.A, sp->queue_cap, d.scan_cap, n_adx_spec);
+  const size_t qb = phx_generic_queue_bytes(d.A, d.S, sp->queue_cap, d.scan_cap, n_adx_spec);
   *ws_stride = 0;
   if (qb > (size_t)GENERIC_LDS_LIMIT) {
     *ws_stride = ((int64_t)qb + 255) & ~(int64_t)255;
@@ -584,6 +584,21 @@ static int upload(phx_env* e, const T* host, size_t n, const T** out) {
 }
 
 static thread_local char g_kernels[384] = "";
+#ifdef PHX_TIMING
+// development builds: phase timers of the generic engine (10 ns ticks of thread 0, first 64 workgroups), dumped every PHX_TIMING_DUMP env-steps
+static unsigned long long* phx_gen_timing(int steps) {
+  static unsigned long long* tb = nullptr; static long done = 0, next = 0;
+  if (!tb) { (void)hipMalloc((void**)&tb, 16 * 8); (void)hipMemset(tb, 0, 16 * 8); next = getenv("PHX_TIMING_DUMP") ? atol(getenv("PHX_TIMING_DUMP")) : 0; }
+  if (next > 0 && done >= next) {
+    (void)hipDeviceSynchronize(); unsigned long long h[16]; (void)hipMemcpy(h, tb, sizeof h, hipMemcpyDeviceToHost); (void)hipMemset(tb, 0, 16 * 8);
+    const double n = (double)done * 64; double tot = 0; fprintf(stderr, "PHX_GTIMING ns/step:");
+    for (int q = 0; q < 16; ++q) { fprintf(stderr, " %d:%.0f", q, h[q] * 10.0 / n); tot += h[q] * 10.0 / n; }
+    fprintf(stderr, "  total %.0f\n", tot); done = 0;
+  }
+  done += steps;
+  return tb;
+}
+#endif
 static void note_reset() { g_kernels[0] = 0; }
 void phx_note_kernel(const char* name) {
   const size_t n = strlen(g_kernels), m = strlen(name);
@@ -905,11 +920,7 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   }
   GenArgs g; memset(&g, 0, sizeof g); g.io = *io; g.inject = e->inject_dev; g.n_inject = e->n_inject; g.resolve_only = 0; g.timing = nullptr; g.roll_t = -1;
 #ifdef PHX_TIMING
-  { static unsigned long long* tb = nullptr; static int calls = 0;
-    if (!tb) { (void)hipMalloc((void**)&tb, 16 * 8); (void)hipMemset(tb, 0, 16 * 8); }
-    g.timing = tb;
-    if (getenv("PHX_TIMING_DUMP") && ++calls == 100) { (void)hipDeviceSynchronize(); unsigned long long h[16]; (void)hipMemcpy(h, tb, sizeof h, hipMemcpyDeviceToHost);
-      const double n = 99.0 * 64; fprintf(stderr, "PHX_GTIMING cycles/block:"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %d:%.0f", q, h[q] / n); fprintf(stderr, "\n"); } }
+  g.timing = phx_gen_timing(1);
 #endif
   rc = upload_inject(e, st);
   if (rc != PHX_OK) return rc;
@@ -1009,6 +1020,9 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
       // workgroup stay resident; policy, trajectory row, the caller's reset and the last observation are in the loop
       sio.exo = io->exo; sio.msg_log = io->msg_log; sio.msg_count = io->msg_count;
       g.io = sio; g.roll_t = 0; g.roll_T = io->T;
+#ifdef PHX_TIMING
+      g.timing = phx_gen_timing(io->T);
+#endif
       HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
       return PHX_OK;
     }

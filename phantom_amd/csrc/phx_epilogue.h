@@ -6,14 +6,17 @@
 #include "phx_dev.h"
 
 // One workgroup per env.  `live` = agent has a context this step (NULL: every agent is live).
+// `roll` (a rollout's step, S <= NT): the step's outputs also go to the trajectory row at element offset row_o = (t_row * B + b) * S
+// straight from the lane's registers (rollout.py:361-389; the flags with the env's __all__ ORed in, as the copy loop of the caller
+// does otherwise); returns true when the row has been written.
 // s_nterm / s_ntrunc: zero-initialised LDS counters.  Contains a workgroup barrier.
 // `encode_obs(a, t, ob)` is the agent's encode_observation; the fused Stackelberg kernel passes one
 // that reads the buyers' prices from its LDS copy of seller.posted.
 template <int NT, typename ObsFn>
-__device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
+__device__ __forceinline__ bool strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
                                                    int list, int cur_stage, uint32_t tick,
                                                    const uint8_t* live, int* s_nterm, int* s_ntrunc, ObsFn encode_obs,
-                                                   int next_in = -1) {
+                                                   int next_in = -1, const phx_rollout_io* roll = nullptr, int64_t row_o = 0, int* all_flags = nullptr) {
   const int tid = threadIdx.x;
   const int A = sp.A, S = sp.S, D = sp.D;
   uint8_t* term = fld<uint8_t>(sp, F_ENV_TERM) + (int64_t)b * S;
@@ -34,6 +37,8 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
   // env emits is the cached one, read or just computed by this lane); only a terminal step -- once per episode -- takes
   // the second pass that dumps the cached dicts.  (The second pass used to run every step and re-read from HBM what the
   // first had just written, behind a full fence.)
+  const bool row = roll != nullptr && S <= NT;                 // one strategic agent per lane: its outputs stay in registers
+  float k_ob[4] = {0.f, 0.f, 0.f, 0.f}; double k_rw = 0.0; uint8_t k_ov = 0, k_rv = 0, k_tm = 0, k_tr = 0;
   for (int s = tid; s < S; s += NT) {                          // env.py:273 / fsm.py:320 / stackelberg.py:150
     const int a = sp.strat_idx[s];
     const int64_t o = (int64_t)b * S + s;
@@ -67,6 +72,7 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
     for (int d = 0; d < D; ++d) obs_b[s * D + d] = ob[d];
     io.obs_valid[o] = ov; io.reward_valid[o] = rv; io.done_valid[o] = dv;
     io.terminated[o] = tm; io.truncated[o] = tr; io.reward[o] = rw;
+    if (row) { for (int d = 0; d < 4; ++d) k_ob[d] = ob[d]; k_rw = rw; k_ov = ov; k_rv = rv; k_tm = tm; k_tr = tr; }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the two LDS counters: a barrier that leaves the stores in flight
   __builtin_amdgcn_s_barrier();
@@ -74,6 +80,7 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
   const bool all_term = *s_nterm == S;                                        // env.py:308-310
   const bool all_trunc = (t == sp.num_steps) || *s_ntrunc == S;              // env.py:312-318
   const bool terminal = all_term || all_trunc;
+  if (all_flags) *all_flags = (all_term ? 1 : 0) | (all_trunc ? 2 : 0) | (next_stage << 8);       // (+ the stage the env enters)
   if (sp.env_type != PHX_ENV_PLAIN && terminal) {              // (uniform over the workgroup)
     __syncthreads();                                           // this lane's stores above are re-read below
     for (int s = tid; s < S; s += NT) {
@@ -82,10 +89,23 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
         const uint8_t v = obs_cache_v[s];
         io.obs_valid[o] = v;
         for (int d = 0; d < D; ++d) obs_b[s * D + d] = v ? obs_cache[s * D + d] : 0.f;
+        if (row) { k_ov = v; for (int d = 0; d < D && d < 4; ++d) k_ob[d] = v ? obs_cache[s * D + d] : 0.f; }
       }
-      io.reward_valid[o] = rew_cache_v[s] ? 1 : 2;             // fsm.py:360-375 / stackelberg.py:180-187
-      io.reward[o] = rew_cache_v[s] ? rew_cache[s] : 0.0;
+      const uint8_t cv = rew_cache_v[s];
+      const double rc = cv ? rew_cache[s] : 0.0;
+      io.reward_valid[o] = cv ? 1 : 2;                         // fsm.py:360-375 / stackelberg.py:180-187
+      io.reward[o] = rc;
+      if (row) { k_rv = cv ? 1 : 2; k_rw = rc; }
     }
+  }
+  if (row && tid < S) {                                        // the trajectory row, rollout.py:361-389
+    const int64_t o = row_o + tid;
+    for (int d = 0; d < D && d < 4; ++d) roll->obs[o * D + d] = k_ob[d];
+    roll->reward[o] = (float)k_rw;
+    if (roll->terminated) roll->terminated[o] = (uint8_t)(k_tm | (all_term ? 1 : 0));
+    roll->truncated[o] = (uint8_t)(k_tr | (all_trunc ? 1 : 0));
+    if (roll->obs_valid) roll->obs_valid[o] = k_ov;
+    if (roll->reward_valid) roll->reward_valid[o] = k_rv;
   }
   if (tid == 0) {
     fld<int32_t>(sp, F_ENV_STEP)[b] = t;
@@ -96,12 +116,14 @@ __device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo
     }
     io.all_terminated[b] = all_term; io.all_truncated[b] = all_trunc;
   }
+  return row;
 }
 
 template <int NT>
-__device__ __forceinline__ void strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
+__device__ __forceinline__ bool strategic_epilogue(const DevSpec& sp, const Topo& tp, const phx_step_io& io, int b, int t,
                                                    int list, int cur_stage, uint32_t tick,
-                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc, int next_in = -1) {
-  strategic_epilogue<NT>(sp, tp, io, b, t, list, cur_stage, tick, live, s_nterm, s_ntrunc,
-                         [&](int a, int tt, float* ob) { return dev_encode_obs(sp, tp, b, a, tt, ob); }, next_in);
+                                                   const uint8_t* live, int* s_nterm, int* s_ntrunc, int next_in = -1,
+                                                   const phx_rollout_io* roll = nullptr, int64_t row_o = 0, int* all_flags = nullptr) {
+  return strategic_epilogue<NT>(sp, tp, io, b, t, list, cur_stage, tick, live, s_nterm, s_ntrunc,
+                         [&](int a, int tt, float* ob) { return dev_encode_obs(sp, tp, b, a, tt, ob); }, next_in, roll, row_o, all_flags);
 }

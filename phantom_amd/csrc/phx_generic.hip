@@ -642,7 +642,9 @@ typedef const __attribute__((address_space(4))) char* phx_kptr_t;
 #define PHX_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
 #define PHX_GENARGS_KERNARG_OFF 8
 static_assert(alignof(GenArgs) == 8 && sizeof(const DevSpec*) == 8, "kernarg layout: (spec pointer, GenArgs at offset 8)");
-template <int NT, bool LDSQ, bool TABLDS, int KMAX>
+// ROLL: the instantiation phx_rollout launches (policy, trajectory row, the caller's reset and the T-step loop compiled in);
+// phx_step / phx_resolve run the one without that code
+template <int NT, bool LDSQ, bool TABLDS, int KMAX, bool ROLL>
 __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
   phx_kptr_t spc = (phx_kptr_t)spp_;
   phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -708,17 +710,24 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
 
   // ---- the T-step loop of a rollout launch (GenArgs::roll_T > 0: rollout.py:300-363 for this env instance with the queues,
   //      the staged tables and the workgroup resident; the env's words and agent state stay in the blob, L2-hot) ----------
-  const int n_steps = g.roll_T > 0 ? g.roll_T : 1;
+  const int n_steps = ROLL && g.roll_T > 0 ? g.roll_T : 1;
+  // the env's scalar words: read once through the scalar cache (written by an earlier launch), then kept in registers from
+  // one step of the loop to the next (a reset inside the loop sets step = 0 and the initial stage, nothing else)
+  typedef const __attribute__((address_space(4))) int32_t* phx_ki32_t;
+  int w_step = ((phx_ki32_t)(uintptr_t)fld<int32_t>(sp, F_ENV_STEP))[b];
+  int w_tick = ((phx_ki32_t)(uintptr_t)fld<int32_t>(sp, F_ENV_TICK))[b];
+  int w_clock = ((phx_ki32_t)(uintptr_t)fld<int32_t>(sp, F_ENV_CLOCK))[b];
+  int w_stage = (sp.env_type == PHX_ENV_FSM) ? ((phx_ki32_t)(uintptr_t)fld<int32_t>(sp, F_ENV_STAGE))[b] : 0;
   for (int it = 0; it < n_steps; ++it) {
   PHX_REFRESH();
-  const int roll_t = g.roll_t >= 0 ? g.roll_t + it : -1;       // trajectory row of this step (-1: a plain phx_step)
-  const int64_t step_env = (g.roll_T > 0 ? (int64_t)it * sp.B : 0) + b;   // row of the per-step [T][B][..] inputs / logs
+  const int roll_t = ROLL && g.roll_t >= 0 ? g.roll_t + it : -1;       // trajectory row of this step (-1: a plain phx_step)
+  const int64_t step_env = (ROLL && g.roll_T > 0 ? (int64_t)it * sp.B : 0) + b;   // row of the per-step [T][B][..] inputs / logs
   // the env's scalar words (a later step reads what the previous one's epilogue / reset wrote: same workgroup, one L1)
   const bool full = !g.resolve_only;
-  const int step_in = fld<int32_t>(sp, F_ENV_STEP)[b];
-  const uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
-  const int clock0 = fld<int32_t>(sp, F_ENV_CLOCK)[b];
-  const int cur_stage = (sp.env_type == PHX_ENV_FSM) ? fld<int32_t>(sp, F_ENV_STAGE)[b] : 0;
+  const int step_in = w_step;
+  const uint32_t tick = (uint32_t)w_tick;
+  const int clock0 = w_clock;
+  const int cur_stage = w_stage;
   const int t = full ? step_in + 1 : step_in;                  // env.py:252
   int list = 0;                                                // which acting list / mask row
   if (sp.env_type == PHX_ENV_FSM) list = cur_stage;                          // fsm.py:276
@@ -737,12 +746,12 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     if (sch) {
       if (!live[a]) s_dyn = 1;
       else if (s >= 0 && tkind(tp, a) == PHX_KIND_SHOP && sp.act_mask[(int64_t)list * A + a]) {     // an acting shop without an action
-        const bool has = g.roll_t >= 0 || (g.io.actions && (!g.io.action_valid || g.io.action_valid[(int64_t)b * S + s]));
+        const bool has = (ROLL && g.roll_t >= 0) || (g.io.actions && (!g.io.action_valid || g.io.action_valid[(int64_t)b * S + s]));
         if (!has) s_dyn = 1;
       }
     }
   }
-  if (roll_t >= 0) {
+  if (ROLL && roll_t >= 0) {
     // the policy of a rollout, fused: every strategic agent's action of this tick (random policy = the
     // agent's word of the tick, rank j mapped onto the kind's action space), recorded in the trajectory whether or not it acts
     for (int s = tid; s < S; s += NT) {
@@ -872,7 +881,7 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
     if (sched_round) {
       // static round: inbox sizes, offsets (receivers in first-arrival order) and batch order come from the table
       const int32_t* rt = sch + sch_pos;
-      for (int a = tid; a < A; a += NT) { cnt[a] = rt[a]; goff[a] = rt[A + a]; }
+      for (int a = tid; a < A; a += NT) { const int c_ = rt[a], o_ = rt[A + a]; cnt[a] = c_; goff[a] = o_; }
       ord = rt + 2 * A;
       next_off = ord + n;
       sch_pos += 2 * A + 2 * n;
@@ -1081,24 +1090,31 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   if (g.resolve_only) return;
 
   GTICK(13);
-  strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc, next_in);
+  int all_flags = 0;
+  const bool row_done = strategic_epilogue<NT>(sp, tp, g.io, b, t, list, cur_stage, tick, live, &s_nterm, &s_ntrunc, next_in,
+                                               ROLL && roll_t >= 0 ? &g.roll : nullptr, ((int64_t)(roll_t >= 0 ? roll_t : 0) * sp.B + b) * S, &all_flags);
+  all_flags = __builtin_amdgcn_readfirstlane(all_flags);
   GTICK(14);
-  if (roll_t >= 0) {                                           // the step's outputs -> trajectory row roll_t
-    __syncthreads();
+  if (ROLL && roll_t >= 0) {                                   // the step's outputs -> trajectory row roll_t
     const phx_step_io& st = g.io; const phx_rollout_io& io = g.roll;
-    const uint8_t at = st.all_terminated[b], au = st.all_truncated[b];
-    for (int s = tid; s < S; s += NT) {
-      const int64_t i = (int64_t)b * S + s, o = ((int64_t)roll_t * sp.B + b) * S + s;
-      for (int d = 0; d < sp.D; ++d) io.obs[o * sp.D + d] = st.obs[i * sp.D + d];
-      io.reward[o] = (float)st.reward[i];
-      io.terminated[o] = (uint8_t)(st.terminated[i] | at);
-      io.truncated[o] = (uint8_t)(st.truncated[i] | au);
-      if (io.obs_valid) io.obs_valid[o] = st.obs_valid[i];
-      if (io.reward_valid) io.reward_valid[o] = st.reward_valid[i];
+    const uint8_t at = (uint8_t)(all_flags & 1), au = (uint8_t)((all_flags >> 1) & 1);
+    if (!row_done) {                                           // more strategic agents than lanes: copy what the epilogue stored
+      __syncthreads();
+      for (int s = tid; s < S; s += NT) {
+        const int64_t i = (int64_t)b * S + s, o = ((int64_t)roll_t * sp.B + b) * S + s;
+        for (int d = 0; d < sp.D; ++d) io.obs[o * sp.D + d] = st.obs[i * sp.D + d];
+        io.reward[o] = (float)st.reward[i];
+        if (io.terminated) io.terminated[o] = (uint8_t)(st.terminated[i] | at);
+        io.truncated[o] = (uint8_t)(st.truncated[i] | au);
+        if (io.obs_valid) io.obs_valid[o] = st.obs_valid[i];
+        if (io.reward_valid) io.reward_valid[o] = st.reward_valid[i];
+      }
     }
+    w_step = t; w_tick = (int)(tick + 1); w_clock = clock; w_stage = all_flags >> 8;
     if (at | au) {                                             // the caller's env.reset(), same launch
       __syncthreads();
       reset_env<NT>(sp, b, nullptr, nullptr, st.obs, st.obs_valid, KMAX);
+      w_step = 0; w_stage = sp.initial_stage;
     }
     if (g.roll_T > 0 && it == n_steps - 1 && io.last_obs) {    // the observation after the fragment (after a reset: the reset's)
       __syncthreads();
@@ -1126,7 +1142,7 @@ __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const u
 }
 
 // ---- launchers (called from phx_api.hip) -----------------------------------------------------
-size_t phx_generic_queue_bytes(int A, int Q, int scan_cap, int n_adx) {
+size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx) {
   return (size_t)Q * ((n_adx > 0 ? 3 : 2) * sizeof(DevMsg) + 2 * sizeof(int)) + (size_t)scan_cap * sizeof(int) +
          (size_t)A * 3 * sizeof(int) + (size_t)((A + 15) & ~15);
 }
@@ -1138,7 +1154,7 @@ size_t phx_generic_table_bytes(int A, int nnz) {
 
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
   GenArgs g = g_;
-  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.queue_cap, sp.scan_cap, sp.n_adx) + 15) & ~(size_t)15;
+  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, sp.n_adx) + 15) & ~(size_t)15;
   const size_t tab = phx_generic_table_bytes(sp.A, sp.nnz);
   static const int tablds_env = getenv("PHX_GENERIC_TABLDS") ? atoi(getenv("PHX_GENERIC_TABLDS")) : 1;
   // Staging the topology tables in LDS saves latency per lookup but costs occupancy: every workgroup of the CU holds its
@@ -1156,7 +1172,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   // SC64 B=4096 40 / 63 / 94 us per step, SC256-FSM B=8192 819 / 727 / 743 us.  (Keeping the env's
   // agent state in LDS for the step was measured too: no gain, the wave is instruction-bound --
   // about 6 000 instructions and 90 memory operations per env-step at SC64.)
-  static const int nt_env = getenv("PHX_GENERIC_NT") ? atoi(getenv("PHX_GENERIC_NT")) : 0;
+  static const int nt_env = getenv("PHX_GENERIC_NT") ? atoi(getenv("PHX_GENERIC_NT")) : 0;      // development: 64 or 128
   // round 2, after the factory's serial chain went message-parallel: SC256-FSM B=8192 199 / 165 / 149 us per step
   // (with the second queue gone -- 6 instead of 5 workgroups per CU -- 128 threads win again: 144 vs 177 us)
   int nt = nt_env ? nt_env : (sp.A <= 64 ? 64 : 128);
@@ -1166,12 +1182,15 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   for (int k = 0; k < PHX_KIND_COUNT; ++k) if (sp.kind_count[k] > 0) kmax = k;
   const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
   phx_note_kernel(g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel");
-#define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
+  const bool roll = g.roll_t >= 0;
+#define PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, R_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_, R_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
+#define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) do { if (roll) PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, true); else PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, false); } while (0)
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)
   if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
-  else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, true); else PHX_LAUNCH_GENERIC(256, true, true); }
-  else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else if (nt == 128) PHX_LAUNCH_GENERIC(128, true, false); else PHX_LAUNCH_GENERIC(256, true, false); }
+  else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else PHX_LAUNCH_GENERIC(128, true, true); }
+  else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else PHX_LAUNCH_GENERIC(128, true, false); }
 #undef PHX_LAUNCH_GENERIC_K
+#undef PHX_LAUNCH_GENERIC_R
 #undef PHX_LAUNCH_GENERIC
   return hipGetLastError();
 }
