@@ -15,7 +15,8 @@
 #include "phx_dev.h"
 
 
-size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx);
+size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx, bool lean = false);
+size_t phx_generic_lean_ws_bytes(int Q, int scan_cap);
 size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
@@ -401,6 +402,7 @@ struct FieldDef { int id; const char* name; int dtype; int kind; int64_t dim0, d
 
 static int64_t esize(int dtype) { return dtype == 1 ? 8 : (dtype == 2 ? 1 : 4); }
 
+static bool lean_lds_spec(const phx_spec* sp, const Derived& d);
 static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef>& out, int64_t* ws_stride) {
   const int64_t B = sp->batch, S = std::max(d.S, 1);
   auto kc = [&](int k) { return (int64_t)std::max(d.kind_count[k], 0); };
@@ -457,7 +459,13 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
   for (int a = 0; a < d.A; ++a) n_adx_spec += sp->kind[a] == PHX_KIND_ADEXCHANGE;
   const size_t qb = phx_generic_queue_bytes(d.A, d.S, sp->queue_cap, d.scan_cap, n_adx_spec);
   *ws_stride = 0;
-  if (qb > (size_t)GENERIC_LDS_LIMIT) {
+  if (lean_lds_spec(sp, d)) {
+    // scheduled two-wave supply chains: the sort / scan scratch of a DYNAMIC step lives here instead of LDS (phx_generic.hip, LEAN)
+    *ws_stride = ((int64_t)phx_generic_lean_ws_bytes(sp->queue_cap, d.scan_cap) + 255) & ~(int64_t)255;
+    FieldDef w = {F_WORKSPACE, "workspace", 2, 0, B, *ws_stride, 1, off};
+    off += B * *ws_stride;
+    out.push_back(w);
+  } else if (qb > (size_t)GENERIC_LDS_LIMIT) {
     *ws_stride = ((int64_t)qb + 255) & ~(int64_t)255;
     FieldDef w = {F_WORKSPACE, "workspace", 2, 0, B, *ws_stride, 1, off};
     off += B * *ws_stride;
@@ -555,6 +563,19 @@ static void build_static_schedule(const phx_spec* sp, const Derived& d, StaticSc
     out.off[l] = (int32_t)out.blob.size();
     out.blob.insert(out.blob.end(), rec.begin(), rec.end());
   }
+}
+
+// LEAN layout of the generic engine (phx_generic.hip): every acting list of a two-wave supply chain has a static schedule ->
+// the sort / scan scratch only a dynamic step needs (order, slot, scanbuf) moves from LDS to a per-env workspace in the blob
+static bool lean_lds_spec(const phx_spec* sp, const Derived& d) {
+  if (d.A <= 64 || d.A > 256) return false;
+  for (int a = 0; a < d.A; ++a) { const int k = sp->kind[a]; if (k != PHX_KIND_FACTORY && k != PHX_KIND_SHOP && k != PHX_KIND_CUSTOMER) return false; }
+  if (phx_generic_queue_bytes(d.A, d.S, sp->queue_cap, d.scan_cap, 0, true) > (size_t)GENERIC_LDS_LIMIT) return false;
+  StaticSched ss;
+  build_static_schedule(sp, d, ss);
+  if (ss.blob.empty()) return false;
+  for (int l = 0; l < d.n_lists; ++l) if (ss.off[l] < 0) return false;
+  return true;
 }
 
 // ---- handle ----------------------------------------------------------------------------------------------
@@ -793,7 +814,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   }
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
   d.ws_stride = ws_stride;
-  e->lds_ok = ws_stride == 0;
+  d.lean_lds = lean_lds_spec(spec, der) ? 1 : 0;
+  e->lds_ok = ws_stride == 0 || d.lean_lds;
   e->use_fused = der.sc_static;
   e->use_stk = der.stk_static;
   e->use_ads = der.ads_static;

@@ -146,6 +146,7 @@ struct DevSpec {
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env
+  int32_t lean_lds;              // generic engine: the dynamic steps' sort / scan scratch is in the workspace, not in LDS (LEAN)
   const DevSpec* self_dev;       // this struct in device memory (kernels that read it through the scalar cache instead of 300 SGPRs)
 };
 

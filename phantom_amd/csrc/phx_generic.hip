@@ -644,8 +644,14 @@ typedef const __attribute__((address_space(4))) char* phx_kptr_t;
 static_assert(alignof(GenArgs) == 8 && sizeof(const DevSpec*) == 8, "kernarg layout: (spec pointer, GenArgs at offset 8)");
 // ROLL: the instantiation phx_rollout launches (policy, trajectory row, the caller's reset and the T-step loop compiled in);
 // phx_step / phx_resolve run the one without that code
-template <int NT, bool LDSQ, bool TABLDS, int KMAX, bool ROLL>
-__global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
+#ifndef PHX_LEAN_WAVES
+#define PHX_LEAN_WAVES 6      // waves per SIMD the LEAN instantiations are compiled for (80 VGPRs: twelve two-wave workgroups per CU)
+#endif
+// LEAN (two-wave supply chains whose acting lists all have a static schedule): order / slot / scanbuf -- the scratch only a DYNAMIC
+// step sorts and scans in -- live in the env's workspace in the blob instead of LDS: 11.5 instead of 14.6 KB per SC256 env
+template <int NT, bool LDSQ, bool TABLDS, int KMAX, bool ROLL, bool LEAN>
+// (the supply-chain rollout instantiation of two-wave workgroups is held to 96 VGPRs: five waves per SIMD = the ten workgroups per CU the queues allow)
+__global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && KMAX <= PHX_KIND_CUSTOMER) ? 5 : 1)) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
   phx_kptr_t spc = (phx_kptr_t)spp_;
   phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   PHX_REFRESH();
@@ -674,10 +680,10 @@ __global__ __launch_bounds__(NT) void phx_generic_step_kernel(const DevSpec* __r
   DevMsg* q0 = (DevMsg*)mem;
   DevMsg* q1 = two_queues ? q0 + Q : q0;
   DevMsg* resp = q0 + (two_queues ? 2 : 1) * Q;
-  int* order = (int*)(resp + Q);
+  int* order = LEAN ? (int*)((char*)sp.f[F_WORKSPACE] + (int64_t)b * sp.ws_stride) : (int*)(resp + Q);
   int* slot = order + Q;
   int* scanbuf = slot + Q;
-  int* cnt = scanbuf + sp.scan_cap;
+  int* cnt = LEAN ? (int*)(resp + Q) : scanbuf + sp.scan_cap;
   int* first = cnt + A;
   int* goff = first + A;
   uint8_t* live = (uint8_t*)(goff + A);
@@ -1142,8 +1148,9 @@ __global__ __launch_bounds__(NT) void phx_reset_kernel(const DevSpec sp, const u
 }
 
 // ---- launchers (called from phx_api.hip) -----------------------------------------------------
-size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx) {
-  return (size_t)Q * ((n_adx > 0 ? 3 : 2) * sizeof(DevMsg) + 2 * sizeof(int)) + (size_t)scan_cap * sizeof(int) +
+size_t phx_generic_lean_ws_bytes(int Q, int scan_cap) { return ((size_t)2 * Q + scan_cap) * sizeof(int); }
+size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx, bool lean) {
+  return (size_t)Q * ((n_adx > 0 ? 3 : 2) * sizeof(DevMsg)) + (lean ? 0 : phx_generic_lean_ws_bytes(Q, scan_cap)) +
          (size_t)A * 3 * sizeof(int) + (size_t)((A + 15) & ~15);
 }
 
@@ -1154,13 +1161,14 @@ size_t phx_generic_table_bytes(int A, int nnz) {
 
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
   GenArgs g = g_;
-  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, sp.n_adx) + 15) & ~(size_t)15;
+  const bool lean = lds && sp.lean_lds != 0;
+  size_t bytes = (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, sp.n_adx, lean) + 15) & ~(size_t)15;
   const size_t tab = phx_generic_table_bytes(sp.A, sp.nnz);
   static const int tablds_env = getenv("PHX_GENERIC_TABLDS") ? atoi(getenv("PHX_GENERIC_TABLDS")) : 1;
   // Staging the topology tables in LDS saves latency per lookup but costs occupancy: every workgroup of the CU holds its
   // own copy.  Worth it only while queues + tables stay small (SC64: 6 KB); at SC256 (15.5 KB of queues + 10.5 KB of
   // tables = 6 workgroups per CU with them, 10 without) leaving them in global memory is 18 % faster (144 -> 118 us).
-  const bool tablds = lds && tablds_env && (tablds_env > 1 || bytes + tab <= 10 * 1024) && tab <= 24 * 1024 && bytes + tab <= 60 * 1024;
+  const bool tablds = lds && !lean && tablds_env && (tablds_env > 1 || bytes + tab <= 10 * 1024) && tab <= 24 * 1024 && bytes + tab <= 60 * 1024;
   g.tab_off = (int32_t)bytes;
   // one env per workgroup writes ~100-byte output segments: with consecutive envs on one XCD their shared cache
   // lines merge in one L2 (SC64 38.6 -> 37.1 us, SC256-FSM 352 -> 343 us per step)
@@ -1183,10 +1191,13 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
   phx_note_kernel(g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel");
   const bool roll = g.roll_t >= 0;
-#define PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, R_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_, R_>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
+#define PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, R_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_, R_, false>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
 #define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) do { if (roll) PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, true); else PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, false); } while (0)
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)
-  if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
+  if (lean) {                                                // (lean_lds_spec: supply-chain kinds only, 64 < A <= 256)
+    if (roll) hipLaunchKernelGGL((phx_generic_step_kernel<128, true, false, PHX_KIND_CUSTOMER, true, true>), dim3(sp.B), dim3(128), bytes, st, sp.self_dev, g);
+    else hipLaunchKernelGGL((phx_generic_step_kernel<128, true, false, PHX_KIND_CUSTOMER, false, true>), dim3(sp.B), dim3(128), bytes, st, sp.self_dev, g);
+  } else if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
   else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else PHX_LAUNCH_GENERIC(128, true, true); }
   else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else PHX_LAUNCH_GENERIC(128, true, false); }
 #undef PHX_LAUNCH_GENERIC_K

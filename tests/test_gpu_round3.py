@@ -451,3 +451,36 @@ def test_rollout_without_the_all_zero_terminations_plane():
     from phantom_amd.device import DeviceError
     with pytest.raises(DeviceError):
         df.dev.rollout(10, out=trf)
+
+
+# ---- the generic engine's LEAN layout (scheduled two-wave supply chains: the dynamic steps' sort / scan scratch in the blob) -----
+@pytest.mark.parametrize("fsm", [False, True])
+@pytest.mark.parametrize("S,K", [(20, 4), (51, 4), (13, 5)])
+def test_generic_engine_lean_layout_scheduled_and_dynamic_steps_match_oracle(S, K, fsm):
+    """Supply chains with 64 < A <= 256 agents on the generic engine keep order / slot / scanbuf in a per-env workspace of the state
+    blob (phx_generic.hip LEAN).  Steps with every action present follow the static schedule; a missing action or a done agent makes
+    the step dynamic (sort and scan through the workspace).  Both, interleaved, against the oracle -- per step and as rollouts."""
+    B = 48
+    env = supply_chain_env(S, [K] * S, 30, B, fsm=fsm, force_generic=True, seed=5 + S, env_offset=300)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    assert "workspace" in d.dev.field_names()
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S + K + fsm)
+    for t in range(70):                                         # two episode ends
+        a = rng.uniform(-20, 130, (B, S)).astype(np.float32)
+        valid = None if t % 3 == 0 else (rng.random((B, S)) < 0.85).astype(np.uint8)       # t % 3 == 0: scheduled steps
+        exo = rng.integers(0, 5, (B, S * K)).astype(np.uint8) if t % 2 else None
+        o.step(a, valid, exo); d.step(a, valid, exo)
+        np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs), err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d.truncated, o.truncated); np.testing.assert_array_equal(d.obs_valid, o.obs_valid)
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} t={t}")
+        done = (o.all_truncated | o.all_terminated).astype(np.uint8)
+        if done.any():
+            o.reset(done); d.reset(done)
+    assert "phx_generic_step_kernel" in d.dev.last_kernel()
+    for T in (1, 17, 45):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, fsm)
+    assert (d.err == 0).all()
