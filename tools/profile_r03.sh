@@ -35,6 +35,13 @@ timeout $T rocprofv3 --kernel-trace --stats -d $OUT/trace_gen -o trace -- $G > $
 echo "== kernel trace of tools/gen_time.py both" >> $OUT/summary.txt
 $SUM trace $OUT/trace_gen/trace_results.db 2>/dev/null | head -6 >> $OUT/summary.txt
 grep "us/step" $OUT/gen_trace.log >> $OUT/summary.txt
+for w in sc64 sc256; do
+  GS="python $R/tools/gen_step_only.py $w"
+  pmc sq_gen_$w SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -- $GS
+  pmc sq2_gen_$w SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES -- $GS
+  pmc sq3_gen_$w SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_BUSY_CYCLES -- $GS
+  pmc ic_gen_$w SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE -- $GS
+done
 # config 3 (SC256 FSM, B = 8192): pair-range lean loop vs whole-env blocks
 C3="python $R/tools/roll_time.py --fsm --shops 51 --cust 4 --batch 8192 --T 100 --n 6 --rollout lean"
 pmc w_c3 WRITE_SIZE -- $C3
