@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 6
+#define PHX_ABI_VERSION 7
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -144,6 +144,9 @@ typedef enum phx_msg_type {
                                         (Fisher-Yates, Philox block (env | draw / 4 << 48, tick, 0x10000000 | round << 16 |
                                         receiver), j = mulhi(word, i + 1)).  Always the generic engine.  Not with
                                         PHX_F_IGNORE_CONN_ERRORS or PHX_KIND_ADEXCHANGE (PHX_EUNSUPPORTED).        */
+#define PHX_F_MT19937           16u  /* ABI 7: every env instance carries its own legacy-numpy MT19937 stream in the state
+                                        blob ("env.mt_state" u32 [B][624], "env.mt_pos" i32 [B]): phx_mt_seed / phx_mt_draw
+                                        below.  2.5 KB per env instance.                                            */
 
 /*
  * Flat description of one env class: what the Python host compiles a
@@ -373,6 +376,27 @@ int64_t phx_set_state(phx_env* env, const char* field, const void* buf, int64_t 
  * reading phx_step_io.msg_log / msg_count directly.  Synchronises `stream`.                       */
 int  phx_trace(phx_env* env, const phx_msg_rec* msg_log, const int32_t* msg_count, int b,
                phx_msg_rec* out, int cap, void* stream);
+
+/* ---- ABI 7: the reference's own random stream, per env instance (PHX_F_MT19937) ---------------------------------
+ * CustomerAgent.generate_messages draws np.random.randint(CUSTOMER_MAX_ORDER_SIZE) from the process-global legacy
+ * MT19937 (examples/environments/supply_chain/supply_chain.py:64); a reference rollout worker runs ONE env on its own
+ * stream (utils/rllib/rollout.py:220-258, one process per rollout task).  With PHX_F_MT19937 env instance b of the
+ * batch carries that stream:
+ *   phx_mt_seed(env, seeds)     == np.random.seed(seeds[b]) in worker b   (init_genrand, numpy random/_mt19937 legacy
+ *                                  seeding of a 32-bit integer; `seeds` = B HOST words),
+ *   phx_mt_draw(env, exo, T)    == the T * n_exo calls of np.random.randint(5) worker b makes in T steps of a PLAIN env
+ *                                  whose customers all act every step, in the reference's call order (step, then the
+ *                                  customers in acting order = exogenous index): numpy's masked rejection, one 32-bit word
+ *                                  per attempt -- v = genrand_uint32() & 7 until v <= 4 (numpy 2.2 legacy RandomState.randint
+ *                                  -> _bounded_integers, use_masked; pinned by tests against numpy itself and against the
+ *                                  draws the REFERENCE consumed in the seeded golden runs, tests/golden/sc64.npz `exo`).
+ * `exo` is a DEVICE buffer u8 [T][B][n_exo], laid out like phx_rollout_io.exo / T stacked phx_step_io.exo: pass it on to
+ * phx_step / phx_rollout and instance b reproduces reference worker b's seeded run bit for bit, at any batch size,
+ * without a host loop.  The stream position persists in the blob between calls (phx_get_state / phx_set_state reach
+ * "env.mt_state" / "env.mt_pos").  PHX_EUNSUPPORTED for env types other than PHX_ENV_PLAIN, for specs without the flag and for
+ * specs whose customers do not all act in every step.                                                                 */
+int  phx_mt_seed(phx_env* env, const uint32_t* seeds, void* stream);
+int  phx_mt_draw(phx_env* env, uint8_t* exo, int T, void* stream);
 
 /* ---- rollout collection helpers (SURVEY 8e iii): done-flag planes bit-packed for the all-gather.
  * dst word w, bit j = (src[64 w + j] != 0), n = number of source bytes, dst = ceil(n / 64) words.   */

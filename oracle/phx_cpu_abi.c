@@ -19,7 +19,7 @@
 
 #include "phx_oracle.h"
 
-struct phx_env { phxo_env* o; int B, A, nnz, n_conn, n_samplers, trace_cap; };
+struct phx_env { phxo_env* o; int B, A, nnz, n_conn, n_samplers, trace_cap, n_exo, env_type; uint32_t flags; uint32_t* mt; int32_t* mt_pos; };
 
 int phx_abi_version(void) { return PHX_ABI_VERSION; }
 const char* phx_last_error(void) { return phxo_last_error(); }
@@ -46,11 +46,13 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   phx_env* e = (phx_env*)calloc(1, sizeof *e);
   e->o = o; e->B = spec->batch; e->A = spec->n_agents; e->nnz = spec->row_ptr ? spec->row_ptr[spec->n_agents] : 0;
   e->n_conn = spec->n_conn; e->n_samplers = spec->n_samplers; e->trace_cap = spec->trace_cap;
+  e->n_exo = phxo_n_exo(o); e->env_type = spec->env_type; e->flags = spec->flags;
+  if (spec->flags & PHX_F_MT19937) { e->mt = (uint32_t*)calloc((size_t)spec->batch * 624, 4); e->mt_pos = (int32_t*)calloc((size_t)spec->batch, 4); }
   phxo_reset(o, NULL, NULL, NULL, NULL, NULL);          /* phx_create runs the initial reset (include/phantom_amd.h) */
   *out = e;
   return PHX_OK;
 }
-void phx_destroy(phx_env* e) { if (e) { phxo_destroy(e->o); free(e); } }
+void phx_destroy(phx_env* e) { if (e) { phxo_destroy(e->o); free(e->mt); free(e->mt_pos); free(e); } }
 int phx_n_fields(const phx_env* e) { (void)e; return 0; }
 int phx_field_info(const phx_env* e, int index, phx_field* out) { (void)e; (void)index; (void)out; return PHX_EINVAL; }
 int phx_uses_fused(const phx_env* e) { (void)e; return 0; }
@@ -137,3 +139,45 @@ int phx_unpack_flags(const uint64_t* src, uint8_t* dst, int64_t n, void* stream)
   for (int64_t i = 0; i < n; ++i) dst[i] = (uint8_t)((src[i >> 6] >> (i & 63)) & 1u);
   return PHX_OK;
 }
+
+/* ---- ABI 7: per-env legacy-numpy MT19937 streams, the sequential statement (numpy random/src/mt19937/mt19937.c: mt19937_seed,
+ * mt19937_gen, mt19937_next; _bounded_integers buffered_bounded_masked_uint32 for np.random.randint(5), supply_chain.py:64) ---- */
+static uint32_t mt_next(uint32_t* mt, int32_t* pos) {
+  if (*pos >= 624) {
+    int k;
+    uint32_t y;
+    for (k = 0; k < 624 - 397; ++k) { y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+    for (; k < 623; ++k) { y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu); mt[k] = mt[k - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+    y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu); mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    *pos = 0;
+  }
+  uint32_t y = mt[(*pos)++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return y;
+}
+int phx_mt_seed(phx_env* e, const uint32_t* seeds, void* stream) {
+  (void)stream;
+  if (!e || !seeds) return PHX_EINVAL;
+  if (!e->mt) return PHX_EUNSUPPORTED;
+  for (int b = 0; b < e->B; ++b) {
+    uint32_t* mt = e->mt + (size_t)b * 624;
+    mt[0] = seeds[b];
+    for (uint32_t i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i;
+    e->mt_pos[b] = 624;
+  }
+  return PHX_OK;
+}
+int phx_mt_draw(phx_env* e, uint8_t* exo, int T, void* stream) {
+  (void)stream;
+  if (!e || !exo || T < 1) return PHX_EINVAL;
+  if (!e->mt || e->env_type != PHX_ENV_PLAIN || e->n_exo < 1) return PHX_EUNSUPPORTED;
+  for (int b = 0; b < e->B; ++b)
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < e->n_exo; ++j) {
+        uint32_t v;
+        do v = mt_next(e->mt + (size_t)b * 624, e->mt_pos + b) & 7u; while (v > 4u);
+        exo[((size_t)t * e->B + b) * e->n_exo + j] = (uint8_t)v;
+      }
+  return PHX_OK;
+}
+

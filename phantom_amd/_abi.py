@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -33,7 +33,7 @@ VB_WHOLE_ENVS = -1
 VS_AUTO, VS_FUSED, VS_GENERIC = 0, 1, 2
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
-F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES = 1, 2, 4, 8
+F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES, F_MT19937 = 1, 2, 4, 8, 16
 
 (ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL,
  ERR_CONTEXT, ERR_FSM_TRANSITION) = range(8)
@@ -106,7 +106,7 @@ EXPORTS = ("phx_abi_version", "phx_last_error", "phx_last_kernel", "phx_state_nb
            "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",
            "phx_field_info", "phx_uses_fused", "phx_sync_fields", "phx_reset", "phx_step", "phx_inject",
            "phx_resolve", "phx_rollout", "phx_get_state", "phx_set_state", "phx_trace",
-           "phx_pack_flags", "phx_unpack_flags")
+           "phx_pack_flags", "phx_unpack_flags", "phx_mt_seed", "phx_mt_draw")
 
 
 def built_archs():
@@ -175,6 +175,10 @@ def bind_signatures(lib):
     lib.phx_pack_flags.argtypes = [vp, vp, i64, vp]
     lib.phx_unpack_flags.restype = i32
     lib.phx_unpack_flags.argtypes = [vp, vp, i64, vp]
+    lib.phx_mt_seed.restype = i32
+    lib.phx_mt_seed.argtypes = [vp, vp, vp]
+    lib.phx_mt_draw.restype = i32
+    lib.phx_mt_draw.argtypes = [vp, vp, i32, vp]
     return lib
 
 

@@ -416,6 +416,8 @@ static int64_t layout(const phx_spec* sp, const Derived& d, std::vector<FieldDef
     {F_ENV_SAMPLER, "env.sampler", 1, 0, B, sp->n_samplers, 1, 0}, {F_ENV_EPISODE, "env.episode", 0, 0, B, (sp->n_samplers > 0 || sp->n_conn > 0) ? 1 : 0, 1, 0},
     {F_NET_CONN_ON, "net.conn_on", 2, 0, B, sp->n_conn, 1, 0},
     {F_ENV_ARRIVE, "env.arrive", 0, 0, B, d.sc_static ? 1 : 0, 1, 0},
+    {F_ENV_MT_STATE, "env.mt_state", 0, 0, B, (sp->flags & PHX_F_MT19937) ? 624 : 0, 1, 0},
+    {F_ENV_MT_POS, "env.mt_pos", 0, 0, B, (sp->flags & PHX_F_MT19937) ? 1 : 0, 1, 0},
     {F_SHOP_STOCK, "shop.stock", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_SALES, "shop.sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
     {F_SHOP_MISSED, "shop.missed_sales", 0, PHX_KIND_SHOP, B, kc(PHX_KIND_SHOP), 1, 0},
@@ -1150,6 +1152,117 @@ int phx_unpack_flags(const uint64_t* src, uint8_t* dst, int64_t n, void* stream)
   if (n < 0 || (n > 0 && (!src || !dst))) return fail(PHX_EINVAL, "bad argument");
   if (n == 0) return PHX_OK;
   hipLaunchKernelGGL(phx_unpack_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  HIPCHK(hipGetLastError());
+  return PHX_OK;
+}
+
+// ---- ABI 7: per-env legacy-numpy MT19937 streams (PHX_F_MT19937; supply_chain.py:64's np.random.randint(5)) -----------------
+// np.random.seed(seed) of a 32-bit integer = init_genrand (numpy random/src/mt19937/mt19937.c: mt19937_seed): one lane per env
+__global__ __launch_bounds__(256) void phx_mt_seed_kernel(const uint32_t* __restrict__ seeds, uint32_t* __restrict__ state,
+                                                          int32_t* __restrict__ pos, const int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  uint32_t* mt = state + (int64_t)b * 624;
+  uint32_t x = seeds[b];
+  mt[0] = x;
+  for (uint32_t i = 1; i < 624; ++i) { x = 1812433253u * (x ^ (x >> 30)) + i; mt[i] = x; }
+  pos[b] = 624;                                               // the first draw regenerates
+}
+// One wave per env: the state is staged in LDS, regenerated 64 words at a time (word k of the next state needs the OLD words k and
+// k + 1 and, k < 227, the old word k + 397, otherwise the NEW word k - 227: chunks of 64 in order have them all), and 64 words per
+// pass are tempered, masked (& 7) and rejected (> 4) with the accepted ones compacted by a ballot -- the words a sequence of
+// np.random.randint(5) calls would consume, in order; the pass that reaches the last wanted draw consumes up to ITS word only.
+__global__ __launch_bounds__(64) void phx_mt_draw_kernel(uint32_t* __restrict__ state, int32_t* __restrict__ pos, uint8_t* __restrict__ exo,
+                                                         const int B, const int n_exo, const int T) {
+  __shared__ uint32_t mt[624];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  uint32_t* gs = state + (int64_t)b * 624;
+  for (int i = lane; i < 624; i += 64) mt[i] = gs[i];
+  int p = pos[b];
+  __syncthreads();
+  const int64_t need = (int64_t)T * n_exo;
+  int64_t have = 0;
+  while (have < need) {
+    if (p >= 624) {                                           // genrand's regeneration (mt19937_gen)
+      for (int c = 0; c < 624; c += 64) {
+        const int k = c + lane;
+        uint32_t y = 0, src = 0;
+        if (k < 624) {
+          y = (mt[k] & 0x80000000u) | (mt[k == 623 ? 0 : k + 1] & 0x7fffffffu);
+          src = k < 227 ? mt[k + 397] : mt[k - 227];
+        }
+        __syncthreads();
+        if (k < 624) mt[k] = src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        __syncthreads();
+      }
+      p = 0;
+    }
+    const int len = 624 - p < 64 ? 624 - p : 64;
+    uint32_t y = lane < len ? mt[p + lane] : 0u;
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    const uint32_t v = y & 7u;                                // mask of rng = 4 (buffered_bounded_masked_uint32)
+    const bool acc = lane < len && v <= 4u;
+    const uint64_t m = __ballot(acc);
+    const int before = __popcll(m & ((1ull << lane) - 1ull)), total = __popcll(m);
+    const int64_t left = need - have;
+    if (acc && before < left) {
+      const int64_t idx = have + before, t = idx / n_exo, j = idx - t * n_exo;
+      exo[(t * B + b) * n_exo + j] = (uint8_t)v;
+    }
+    if (total <= left) { have += total; p += len; }
+    else {                                                    // the last wanted draw is inside this pass: stop behind its word
+      const uint64_t last = __ballot(acc && before == (int)left - 1);
+      p += __ffsll((long long)last);                          // 1-based lane of that word = words consumed
+      have = need;
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < 624; i += 64) gs[i] = mt[i];
+  if (lane == 0) pos[b] = p;
+}
+
+static int mt_check(phx_env* e) {
+  if (!e) return fail(PHX_EINVAL, "null env");
+  if (!e->d.f[F_ENV_MT_STATE]) return fail(PHX_EUNSUPPORTED, "the spec was compiled without PHX_F_MT19937");
+  return PHX_OK;
+}
+int phx_mt_seed(phx_env* e, const uint32_t* seeds, void* stream) {
+  int rc = mt_check(e);
+  if (rc != PHX_OK) return rc;
+  if (!seeds) return fail(PHX_EINVAL, "seeds is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* dseeds = nullptr;
+  HIPCHK(hipMalloc((void**)&dseeds, sizeof(uint32_t) * e->d.B));
+  hipError_t he = hipMemcpyAsync(dseeds, seeds, sizeof(uint32_t) * e->d.B, hipMemcpyHostToDevice, st);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(phx_mt_seed_kernel, dim3((e->d.B + 255) / 256), dim3(256), 0, st, dseeds, (uint32_t*)e->d.f[F_ENV_MT_STATE],
+                       (int32_t*)e->d.f[F_ENV_MT_POS], e->d.B);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipStreamSynchronize(st);        // `seeds` is the caller's host memory, the staging buffer is ours
+  (void)hipFree(dseeds);
+  HIPCHK(he);
+  return PHX_OK;
+}
+int phx_mt_draw(phx_env* e, uint8_t* exo, int T, void* stream) {
+  int rc = mt_check(e);
+  if (rc != PHX_OK) return rc;
+  if (!exo || T < 1) return fail(PHX_EINVAL, "bad argument");
+  if (e->d.env_type != PHX_ENV_PLAIN) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: PHX_ENV_PLAIN only (the customers of a stage-dependent acting list draw a stage-dependent number of words)");
+  if (e->d.n_exo < 1) return fail(PHX_EUNSUPPORTED, "the env has no exogenous draws");
+  // the (one) acting list must make the draws in exogenous-index order: every drawing agent acts, in index order, no publisher
+  // (its binomial draws depend on the auction)
+  if (e->der.kind_count[PHX_KIND_PUBLISHER] > 0) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: PublisherAgent draws depend on the auction");
+  int next = 0;
+  for (int k = e->der.act_ptr[0]; k < e->der.act_ptr[1]; ++k) {
+    const int r = e->der.exo_rank[e->der.act_idx[k]];
+    if (r < 0) continue;
+    if (r != next) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: the acting order is not the exogenous-index order");
+    ++next;
+  }
+  if (next != e->d.n_exo) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: every CustomerAgent must act in every step");
+  hipLaunchKernelGGL(phx_mt_draw_kernel, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, (uint32_t*)e->d.f[F_ENV_MT_STATE],
+                     (int32_t*)e->d.f[F_ENV_MT_POS], exo, e->d.B, e->d.n_exo, T);
   HIPCHK(hipGetLastError());
   return PHX_OK;
 }

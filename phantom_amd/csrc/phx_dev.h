@@ -36,6 +36,8 @@ enum {
   F_ADV_TOT_CLICKS, F_ADV_TOT_REQUESTS, F_ADV_TOT_WINS, F_PUB_ADS_SEEN,
   F_WORKSPACE, F_ROLLOUT_SCRATCH,
   F_ENV_ARRIVE,        // i32 [B]: blocks of a time-parallel rollout launch that have finished with the env (0 between launches)
+  F_ENV_MT_STATE,      // u32 [B][624]: the env instance's legacy-numpy MT19937 state (PHX_F_MT19937: phx_mt_seed / phx_mt_draw)
+  F_ENV_MT_POS,        // i32 [B]: index of the next word of that state (624: regenerate first)
   F_COUNT
 };
 

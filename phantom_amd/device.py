@@ -425,6 +425,25 @@ class DeviceEnv:
             self._check(rc, "phx_rollout")
         return out
 
+    # ---- per-env legacy-numpy MT19937 streams (ABI 7, PHX_F_MT19937) -------------------------------------------------
+    def mt_seed(self, seeds):
+        """``np.random.seed(seeds[b])`` for the stream of env instance b (32-bit integers)."""
+        s = np.ascontiguousarray(np.asarray(seeds).astype(np.uint32)).reshape(-1)
+        if s.size != self.B:
+            raise ValueError(f"mt_seed: {s.size} seeds for {self.B} env instances")
+        self._check(self.lib.phx_mt_seed(self.handle, s.ctypes.data, self._stream()), "phx_mt_seed")
+
+    def mt_draw(self, T: int = 1, out=None):
+        """The T * n_exo ``np.random.randint(5)`` calls each instance's reference worker makes in T steps, from the instance's own
+        stream: u8 [T, B, n_exo] on the device, the layout phx_step (row t) and phx_rollout replay."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty((T, self.B, self.n_exo), dtype=torch.uint8, device=self.device)
+        elif out.dtype != torch.uint8 or tuple(out.shape) != (T, self.B, self.n_exo) or not out.is_contiguous():
+            raise ValueError("mt_draw: `out` must be a contiguous u8 [T, B, n_exo] tensor on the env's device")
+        self._check(self.lib.phx_mt_draw(self.handle, out.data_ptr(), int(T), self._stream()), "phx_mt_draw")
+        return out
+
     def pack_done_flags(self, traj: Trajectory):
         """bit-pack the done planes of a flat fragment into its ``packed_flags`` section (SURVEY 8e iii):
         word w, bit j = truncations.flat[64 w + j] != 0; a second block of words holds `terminations` unless

@@ -46,8 +46,12 @@ class PhantomEnv:
         self._variants = dict(variants or {})
         #: where CustomerAgent's np.random.randint(5) (supply_chain.py:64) comes from:
         #: "numpy" = the global legacy numpy stream consumed in the reference's order
-        #: (bit-parity with the reference for the same np.random.seed); "device" = Philox
+        #: (bit-parity with the reference for the same np.random.seed); "device" = Philox;
+        #: "mt19937" = every env instance draws from its OWN legacy-numpy MT19937 stream on the device (seed_streams):
+        #: instance b reproduces the reference worker that ran np.random.seed(seeds[b]), at any batch size
         self.exogenous = exogenous or ("numpy" if self.batch_size == 1 else "device")
+        if self.exogenous not in ("numpy", "device", "mt19937"):
+            raise ValueError(f"exogenous={self.exogenous!r}: 'numpy', 'device' or 'mt19937'")
         self._dev = None
         self._spec: Optional[EnvSpec] = None
         self._h_step = np.zeros(self.batch_size, dtype=np.int64)
@@ -158,7 +162,19 @@ class PhantomEnv:
         return compile_spec(self.network, self.num_steps, self.batch_size, self._env_type,
                             seed=self._seed, env_offset=self._env_offset,
                             force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
-                            device_sampling=self._device_sampling)
+                            device_sampling=self._device_sampling, mt19937=self.exogenous == "mt19937")
+
+    def seed_streams(self, seeds) -> None:
+        """``exogenous="mt19937"``: ``np.random.seed(seeds[b])`` for env instance b's stream (the reference seeds the process-global
+        stream of a rollout worker the same way; ``env.reset(seed=...)`` does not touch it, env.py:185-237).  A scalar seeds
+        instance b with ``seed + b``."""
+        if self.exogenous != "mt19937":
+            raise ValueError("seed_streams needs exogenous='mt19937'")
+        s = np.asarray(seeds)
+        if s.ndim == 0:
+            s = (int(s) + np.arange(self.batch_size, dtype=np.int64)) & 0xFFFFFFFF
+        self._device().mt_seed(s)
+        self._streams_seeded = True
 
     @property
     def spec(self) -> EnvSpec:
@@ -240,6 +256,9 @@ class PhantomEnv:
         reference envs stepped in a loop would consume it (rollout.py:361-363)."""
         import torch
         spec = self.spec
+        if spec.n_exo > 0 and self.exogenous == "mt19937":
+            self._need_streams()
+            return self._device().mt_draw(1)[0]
         if spec.n_exo == 0 or self.exogenous != "numpy":
             return None
         if (spec.kind == _abi.KIND_PUBLISHER).any():
@@ -267,6 +286,10 @@ class PhantomEnv:
                     draws = np.random.randint(5, size=len(acting))
                     exo[b, [self._exo_rank[a] for a in acting]] = draws
         return torch.from_numpy(exo).to(self._device().device)
+
+    def _need_streams(self):
+        if not getattr(self, "_streams_seeded", False):
+            raise RuntimeError("exogenous='mt19937': call env.seed_streams(seeds) first (np.random.seed of every instance's stream)")
 
     def _acting_customer_groups(self):
         """[(env selector, acting customers)] when the instances fall into groups with a common acting list; None = unknown"""
@@ -378,6 +401,9 @@ class PhantomEnv:
             warnings.warn("PhantomEnv.rollout with exogenous='numpy' and no `exo` tensor: the customers' / publishers' "
                           "draws come from the device RNG stream, not from np.random as in step(); pass exo=[T, B, n_exo] "
                           "to replay recorded draws, or build the env with exogenous='device'", RuntimeWarning, stacklevel=2)
+        if exo is None and self.exogenous == "mt19937" and self.spec.n_exo > 0:
+            self._need_streams()
+            exo = self._device().mt_draw(T)                     # the draws of the T steps from every instance's own stream
         traj = self._device().rollout(T, actions, exo, out)
         self._sync_host_state()
         return traj

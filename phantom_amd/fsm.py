@@ -179,7 +179,7 @@ class FiniteStateMachineEnv(PhantomEnv):
                             stages=self._stage_list, initial_stage=self._initial_stage,
                             seed=self._seed, env_offset=self._env_offset,
                             force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
-                            device_sampling=self._device_sampling)
+                            device_sampling=self._device_sampling, mt19937=self.exogenous == "mt19937")
 
     @property
     def initial_stage(self) -> StageID:

@@ -212,7 +212,7 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                  seed: int = 0, env_offset: int = 0, force_generic: bool = False,
                  extra_queue: int = 16, samplers: Optional[Sequence] = None,
                  device_sampling: bool = False, variants: Optional[Dict] = None,
-                 stage_tab: Optional[np.ndarray] = None) -> EnvSpec:
+                 stage_tab: Optional[np.ndarray] = None, mt19937: bool = False) -> EnvSpec:
     from .agents import Agent, StrategicAgent, check_device_executable
     agent_ids = list(network.agents.keys())
     A = len(agent_ids)
@@ -280,6 +280,9 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
         if network.ignore_connection_errors:
             raise NotImplementedError("shuffle_batches with ignore_connection_errors is not supported on the device")
         flags |= _abi.F_SHUFFLE_BATCHES
+
+    if mt19937:                                                           # per-env legacy-numpy streams in the blob (ABI 7)
+        flags |= _abi.F_MT19937
 
     deg = np.diff(row_ptr)
     queue_cap = int(sum(_max_emissions(int(kind[a]), int(deg[a])) for a in range(A))) + extra_queue

@@ -28,4 +28,4 @@ class StackelbergEnv(PhantomEnv):
                             leaders=self.leader_agents, followers=self.follower_agents,
                             seed=self._seed, env_offset=self._env_offset,
                             force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
-                            device_sampling=self._device_sampling)
+                            device_sampling=self._device_sampling, mt19937=self.exogenous == "mt19937")

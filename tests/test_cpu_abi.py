@@ -135,3 +135,30 @@ def test_rollout_state_trace_and_flag_packing_through_the_abi(lib):
     back = np.zeros(1003, np.uint8)
     assert lib.phx_unpack_flags(_p(packed), _p(back), x.size, None) == 0
     np.testing.assert_array_equal(back, (x != 0).astype(np.uint8))
+
+
+# ---- ABI 7: per-env legacy-numpy MT19937 streams -----------------------------------------------------------------
+def test_mt19937_streams_equal_numpy_and_the_draws_the_reference_consumed(lib):
+    """phx_mt_seed / phx_mt_draw (sequential statement in oracle/phx_cpu_abi.c) against numpy itself -- np.random.seed(s) followed by
+    np.random.randint(5) calls, continued over several phx_mt_draw calls and over state regenerations -- and against the
+    draws the REFERENCE's CustomerAgents consumed in the seeded golden run sc64 (tests/golden/gen_goldens.py: one env alone on the
+    global stream after np.random.seed(seeds[b]))."""
+    g = golden("sc64")
+    seeds = [int(s) for s in g["seeds"]]
+    env = supply_chain_env(9, [6] * 9, 100, len(seeds), exogenous="mt19937")
+    r = CpuAbiRunner(lib, env.spec)
+    s32 = np.asarray(seeds, np.uint32)
+    assert lib.phx_mt_seed(r.h, _p(s32), None) == 0
+    T = g["exo"].shape[0]
+    got = np.zeros((T, len(seeds), 54), np.uint8)
+    for t0, t1 in ((0, 1), (1, 2), (2, 40), (40, T)):           # several calls: the stream position persists
+        part = np.zeros((t1 - t0, len(seeds), 54), np.uint8)
+        assert lib.phx_mt_draw(r.h, _p(part), t1 - t0, None) == 0
+        got[t0:t1] = part
+    for b, s in enumerate(seeds):
+        want = np.random.RandomState(s).randint(5, size=T * 54).astype(np.uint8).reshape(T, 54)
+        np.testing.assert_array_equal(got[:, b], want, err_msg=f"numpy stream of seed {s}")
+    np.testing.assert_array_equal(got, g["exo"])                # what the reference consumed
+    # a spec without the flag refuses; so does an FSM env (stage-dependent number of draws)
+    r2 = CpuAbiRunner(lib, supply_chain_env(2, [3, 3], 10, 2).spec)
+    assert lib.phx_mt_draw(r2.h, _p(np.zeros((1, 2, 6), np.uint8)), 1, None) == -2        # PHX_EUNSUPPORTED

@@ -484,3 +484,63 @@ def test_generic_engine_lean_layout_scheduled_and_dynamic_steps_match_oracle(S, 
         ro, rd = o.rollout(T), d.rollout(T)
         _cmp_rollout(rd, ro, fsm)
     assert (d.err == 0).all()
+
+
+# ---- ABI 7: per-env legacy-numpy MT19937 streams on the device (VERDICT r2 missing #5) ------------------------------------------
+def test_mt19937_streams_reproduce_the_seeded_reference_run():
+    """golden sc64 = four REFERENCE envs, each alone on the global numpy stream after np.random.seed(seeds[b]).  With
+    exogenous="mt19937" and seed_streams(seeds) the device draws every instance's orders from its own MT19937: the draws equal the
+    ones the reference's CustomerAgents consumed (supply_chain.py:64) and the run -- obs, rewards, stock, done flags -- equals the
+    golden, with no exogenous input replayed from the host."""
+    from helpers import golden
+    g = golden("sc64")
+    seeds = [int(s) for s in g["seeds"]]
+    B, T = len(seeds), int(g["actions"].shape[0])
+    env = supply_chain_env(9, [6] * 9, 100, B, exogenous="mt19937")
+    d = _dev(env.spec)
+    assert {"env.mt_state", "env.mt_pos"} <= set(d.dev.field_names())
+    d.reset(); d.dev.mt_seed(seeds)
+    for t in range(T):
+        if t > 0 and g["reset_before"][t].any():
+            d.reset(g["reset_before"][t])
+        exo = d.dev.mt_draw(1)[0].cpu().numpy()
+        np.testing.assert_array_equal(exo, g["exo"][t], err_msg=f"draws t={t}")
+        d.step(g["actions"][t], None, exo)
+        np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(g["obs"][t]), err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(g["reward"][t]), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(d.get_i32("shop.stock"), g["stock"][t], err_msg=f"stock t={t}")
+        np.testing.assert_array_equal(d.truncated, g["truncated"][t])
+    assert (d.err == 0).all()
+
+
+def test_mt19937_streams_equal_numpy_at_scale_and_feed_the_fused_rollout():
+    """B = 4096 instances, one numpy stream each: phx_mt_draw over several calls (state regenerations inside and between them)
+    equals np.random.RandomState(seed_b).randint(5, ...) for EVERY instance, and PhantomEnv.rollout in this mode equals the
+    oracle replaying those draws."""
+    B, S, K = 4096, 9, 6
+    env = supply_chain_env(S, [K] * S, 100, B, exogenous="mt19937", seed=3)
+    with pytest.raises(RuntimeError):
+        env.rollout(5)                                          # streams not seeded yet
+    seeds = (np.arange(B, dtype=np.uint64) * 2654435761 + 12345) % (1 << 32)
+    env.reset(); env.seed_streams(seeds)
+    dev = env._device()
+    n = S * K
+    chunks = [dev.mt_draw(T).cpu().numpy() for T in (1, 2, 130, 7)]
+    got = np.concatenate(chunks, axis=0)                        # [140, B, n]
+    for b in range(B):
+        want = np.random.RandomState(int(seeds[b])).randint(5, size=got.shape[0] * n).astype(np.uint8).reshape(-1, n)
+        if not np.array_equal(got[:, b], want):
+            raise AssertionError(f"instance {b} (seed {int(seeds[b])}) leaves numpy's stream")
+    # the same streams, continued, through the env surface: the rollout consumes the next 60 steps' draws
+    o = OracleEnv(env.spec, threads=NCPU); o.reset()
+    tr = env.rollout(60)
+    exo = np.stack([np.random.RandomState(int(seeds[b])).randint(5, size=200 * n).astype(np.uint8).reshape(200, n)[140:200] for b in range(B)], axis=1)
+    ro = o.rollout(60, actions=tr.actions.cpu().numpy(), exo=exo)
+    np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
+    # an FSM env draws a stage-dependent number of words per step: refused loudly
+    envf = supply_chain_env(3, [2] * 3, 10, 4, fsm=True, exogenous="mt19937")
+    envf.reset(); envf.seed_streams(7)
+    from phantom_amd.device import DeviceError
+    with pytest.raises(DeviceError):
+        envf._device().mt_draw(1)
