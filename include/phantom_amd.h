@@ -384,17 +384,20 @@ int  phx_trace(phx_env* env, const phx_msg_rec* msg_log, const int32_t* msg_coun
  * batch carries that stream:
  *   phx_mt_seed(env, seeds)     == np.random.seed(seeds[b]) in worker b   (init_genrand, numpy random/_mt19937 legacy
  *                                  seeding of a 32-bit integer; `seeds` = B HOST words),
- *   phx_mt_draw(env, exo, T)    == the T * n_exo calls of np.random.randint(5) worker b makes in T steps of a PLAIN env
- *                                  whose customers all act every step, in the reference's call order (step, then the
- *                                  customers in acting order = exogenous index): numpy's masked rejection, one 32-bit word
- *                                  per attempt -- v = genrand_uint32() & 7 until v <= 4 (numpy 2.2 legacy RandomState.randint
- *                                  -> _bounded_integers, use_masked; pinned by tests against numpy itself and against the
- *                                  draws the REFERENCE consumed in the seeded golden runs, tests/golden/sc64.npz `exo`).
- * `exo` is a DEVICE buffer u8 [T][B][n_exo], laid out like phx_rollout_io.exo / T stacked phx_step_io.exo: pass it on to
- * phx_step / phx_rollout and instance b reproduces reference worker b's seeded run bit for bit, at any batch size,
- * without a host loop.  The stream position persists in the blob between calls (phx_get_state / phx_set_state reach
- * "env.mt_state" / "env.mt_pos").  PHX_EUNSUPPORTED for env types other than PHX_ENV_PLAIN, for specs without the flag and for
- * specs whose customers do not all act in every step.                                                                 */
+ *   phx_mt_draw(env, exo, T)    == the np.random.randint(5) calls worker b makes in the next T steps, in the reference's call order:
+ *                                  step by step, the CustomerAgents of the step's acting list in acting order (a PLAIN env: all of
+ *                                  them; a FiniteStateMachineEnv: those of the env's stage, fsm.py:276-279 -- the stages are walked
+ *                                  forward from the env's current step / stage words along phx_spec.stage_next / stage_tab with the
+ *                                  reset at the episode's end, as phx_rollout walks them); numpy's masked rejection, one 32-bit
+ *                                  word per attempt -- v = genrand_uint32() & 7 until v <= 4 (numpy 2.2 legacy RandomState.randint
+ *                                  -> _bounded_integers, use_masked; pinned by tests against numpy itself and against the draws the
+ *                                  REFERENCE consumed in the seeded golden runs, tests/golden/{sc64,sc_fsm_small,sc256_fsm}.npz `exo`).
+ * `exo` is a DEVICE buffer u8 [T][B][n_exo], laid out like phx_rollout_io.exo / T stacked phx_step_io.exo (entries of customers that
+ * do not act in a step are 0): pass it on to phx_step / phx_rollout and instance b reproduces reference worker b's seeded run bit for
+ * bit, at any batch size, without a host loop.  The stream position persists in the blob between calls (phx_get_state /
+ * phx_set_state reach "env.mt_state" / "env.mt_pos").  PHX_EUNSUPPORTED for specs without the flag, for env types other than
+ * PHX_ENV_PLAIN / PHX_ENV_FSM and for specs with a PublisherAgent (its binomial draws depend on the auction's outcome).  With stage
+ * handlers called by the host (phx_step_io.next_stage) draw one step at a time: the walk follows stage_next / stage_tab.       */
 int  phx_mt_seed(phx_env* env, const uint32_t* seeds, void* stream);
 int  phx_mt_draw(phx_env* env, uint8_t* exo, int T, void* stream);
 

@@ -19,7 +19,9 @@
 
 #include "phx_oracle.h"
 
-struct phx_env { phxo_env* o; int B, A, nnz, n_conn, n_samplers, trace_cap, n_exo, env_type; uint32_t flags; uint32_t* mt; int32_t* mt_pos; };
+struct phx_env { phxo_env* o; int B, A, nnz, n_conn, n_samplers, trace_cap, n_exo, env_type; uint32_t flags; uint32_t* mt; int32_t* mt_pos;
+                 /* ABI 7: per acting list the exogenous indices of its drawing agents in acting order; the FSM's transitions */
+                 int n_lists, num_steps, initial_stage, has_publisher; int32_t *mt_ptr, *mt_rank, *stage_next, *stage_tab; };
 
 int phx_abi_version(void) { return PHX_ABI_VERSION; }
 const char* phx_last_error(void) { return phxo_last_error(); }
@@ -47,12 +49,31 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   e->o = o; e->B = spec->batch; e->A = spec->n_agents; e->nnz = spec->row_ptr ? spec->row_ptr[spec->n_agents] : 0;
   e->n_conn = spec->n_conn; e->n_samplers = spec->n_samplers; e->trace_cap = spec->trace_cap;
   e->n_exo = phxo_n_exo(o); e->env_type = spec->env_type; e->flags = spec->flags;
-  if (spec->flags & PHX_F_MT19937) { e->mt = (uint32_t*)calloc((size_t)spec->batch * 624, 4); e->mt_pos = (int32_t*)calloc((size_t)spec->batch, 4); }
+  if (spec->flags & PHX_F_MT19937) {
+    e->mt = (uint32_t*)calloc((size_t)spec->batch * 624, 4); e->mt_pos = (int32_t*)calloc((size_t)spec->batch, 4);
+    const int A = spec->n_agents, fsm = spec->env_type == PHX_ENV_FSM;
+    int32_t* rank = (int32_t*)malloc(sizeof(int32_t) * (size_t)A);     /* exogenous index: one per CustomerAgent, agent order */
+    int nx = 0;
+    for (int a = 0; a < A; ++a) { rank[a] = spec->kind[a] == PHX_KIND_CUSTOMER ? nx++ : -1; if (spec->kind[a] == PHX_KIND_PUBLISHER) e->has_publisher = 1; }
+    e->n_lists = fsm ? spec->n_stages : 1; e->num_steps = spec->num_steps; e->initial_stage = spec->initial_stage;
+    e->mt_ptr = (int32_t*)calloc((size_t)e->n_lists + 1, 4); e->mt_rank = (int32_t*)calloc((size_t)e->n_lists * (size_t)A + 1, 4);
+    int n = 0;
+    for (int l = 0; l < e->n_lists; ++l) {
+      if (fsm) { for (int k = spec->stage_act_ptr[l]; k < spec->stage_act_ptr[l + 1]; ++k) if (rank[spec->stage_act_idx[k]] >= 0) e->mt_rank[n++] = rank[spec->stage_act_idx[k]]; }
+      else for (int a = 0; a < A; ++a) if (rank[a] >= 0) e->mt_rank[n++] = rank[a];       /* env.py:320-336: every agent, insertion order */
+      e->mt_ptr[l + 1] = n;
+    }
+    if (fsm) {
+      e->stage_next = (int32_t*)malloc(sizeof(int32_t) * (size_t)e->n_lists); memcpy(e->stage_next, spec->stage_next, sizeof(int32_t) * (size_t)e->n_lists);
+      if (spec->stage_tab) { const size_t m = (size_t)e->n_lists * (size_t)(spec->num_steps + 1); e->stage_tab = (int32_t*)malloc(4 * m); memcpy(e->stage_tab, spec->stage_tab, 4 * m); }
+    }
+    free(rank);
+  }
   phxo_reset(o, NULL, NULL, NULL, NULL, NULL);          /* phx_create runs the initial reset (include/phantom_amd.h) */
   *out = e;
   return PHX_OK;
 }
-void phx_destroy(phx_env* e) { if (e) { phxo_destroy(e->o); free(e->mt); free(e->mt_pos); free(e); } }
+void phx_destroy(phx_env* e) { if (e) { phxo_destroy(e->o); free(e->mt); free(e->mt_pos); free(e->mt_ptr); free(e->mt_rank); free(e->stage_next); free(e->stage_tab); free(e); } }
 int phx_n_fields(const phx_env* e) { (void)e; return 0; }
 int phx_field_info(const phx_env* e, int index, phx_field* out) { (void)e; (void)index; (void)out; return PHX_EINVAL; }
 int phx_uses_fused(const phx_env* e) { (void)e; return 0; }
@@ -170,14 +191,30 @@ int phx_mt_seed(phx_env* e, const uint32_t* seeds, void* stream) {
 int phx_mt_draw(phx_env* e, uint8_t* exo, int T, void* stream) {
   (void)stream;
   if (!e || !exo || T < 1) return PHX_EINVAL;
-  if (!e->mt || e->env_type != PHX_ENV_PLAIN || e->n_exo < 1) return PHX_EUNSUPPORTED;
-  for (int b = 0; b < e->B; ++b)
-    for (int t = 0; t < T; ++t)
-      for (int j = 0; j < e->n_exo; ++j) {
+  if (!e->mt || (e->env_type != PHX_ENV_PLAIN && e->env_type != PHX_ENV_FSM) || e->n_exo < 1 || e->has_publisher) return PHX_EUNSUPPORTED;
+  const int fsm = e->env_type == PHX_ENV_FSM;
+  int32_t* step0 = NULL; int32_t* stage0 = NULL;
+  if (fsm) {
+    step0 = (int32_t*)malloc(4 * (size_t)e->B); stage0 = (int32_t*)malloc(4 * (size_t)e->B);
+    phxo_get_i32(e->o, "env.step", step0); phxo_get_i32(e->o, "env.stage", stage0);
+  }
+  memset(exo, 0, (size_t)T * (size_t)e->B * (size_t)e->n_exo);            /* customers that do not act draw nothing */
+  for (int b = 0; b < e->B; ++b) {
+    int step = fsm ? step0[b] : 0, stage = fsm ? stage0[b] : 0;
+    for (int t = 0; t < T; ++t) {
+      for (int k = e->mt_ptr[stage]; k < e->mt_ptr[stage + 1]; ++k) {    /* the step's CustomerAgents, acting order (supply_chain.py:64) */
         uint32_t v;
         do v = mt_next(e->mt + (size_t)b * 624, e->mt_pos + b) & 7u; while (v > 4u);
-        exo[((size_t)t * e->B + b) * e->n_exo + j] = (uint8_t)v;
+        exo[((size_t)t * e->B + b) * e->n_exo + e->mt_rank[k]] = (uint8_t)v;
       }
+      if (fsm) {                                                           /* fsm.py:281-307; the rollout's reset at the episode end */
+        const int tn = step + 1;
+        stage = e->stage_tab ? e->stage_tab[(size_t)stage * (size_t)(e->num_steps + 1) + (size_t)(tn <= e->num_steps ? tn : e->num_steps)] : e->stage_next[stage];
+        step = tn;
+        if (step >= e->num_steps) { step = 0; stage = e->initial_stage; }
+      }
+    }
+  }
+  free(step0); free(stage0);
   return PHX_OK;
 }
-

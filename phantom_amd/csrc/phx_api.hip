@@ -678,6 +678,14 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(act_mask, der.act_mask.data(), der.act_mask.size());
   UP(obs_mask, der.obs_mask.data(), der.obs_mask.size()); UP(rew_mask, der.rew_mask.data(), der.rew_mask.size());
   UP(stage_next, der.stage_next.data(), der.stage_next.size());
+  if (spec->flags & PHX_F_MT19937) {                            // the draw sequence of every acting list (phx_mt_draw)
+    std::vector<int32_t> mp = {0}, mr;
+    for (int l = 0; l < der.n_lists; ++l) {
+      for (int k = der.act_ptr[l]; k < der.act_ptr[l + 1]; ++k) { const int r = der.exo_rank[der.act_idx[k]]; if (r >= 0) mr.push_back(r); }
+      mp.push_back((int32_t)mr.size());
+    }
+    UP(mt_ptr, mp.data(), mp.size()); UP(mt_rank, mr.data(), mr.size());
+  }
   UP(stage_allowed, der.stage_allowed.data(), der.stage_allowed.size());
   d.stage_tab = nullptr;
   if (!der.stage_tab.empty()) UP(stage_tab, der.stage_tab.data(), der.stage_tab.size());
@@ -1171,54 +1179,67 @@ __global__ __launch_bounds__(256) void phx_mt_seed_kernel(const uint32_t* __rest
 // One wave per env: the state is staged in LDS, regenerated 64 words at a time (word k of the next state needs the OLD words k and
 // k + 1 and, k < 227, the old word k + 397, otherwise the NEW word k - 227: chunks of 64 in order have them all), and 64 words per
 // pass are tempered, masked (& 7) and rejected (> 4) with the accepted ones compacted by a ballot -- the words a sequence of
-// np.random.randint(5) calls would consume, in order; the pass that reaches the last wanted draw consumes up to ITS word only.
-__global__ __launch_bounds__(64) void phx_mt_draw_kernel(uint32_t* __restrict__ state, int32_t* __restrict__ pos, uint8_t* __restrict__ exo,
-                                                         const int B, const int n_exo, const int T) {
+// np.random.randint(5) calls would consume, in order; the pass that reaches a step's last draw consumes up to ITS word only.
+// Step by step: the drawing agents of a step are those of the env's acting list (FSM: of its stage, which is walked forward from
+// the env's words along stage_next / stage_tab with the reset at the episode's end, as phx_rollout walks it).
+struct MtArgs {
+  uint32_t* state; int32_t* pos; uint8_t* exo;
+  const int32_t *mt_ptr, *mt_rank, *stage_next, *stage_tab, *env_step, *env_stage;
+  int32_t B, n_exo, T, fsm, num_steps, initial_stage;
+};
+__global__ __launch_bounds__(64) void phx_mt_draw_kernel(const MtArgs a) {
   __shared__ uint32_t mt[624];
   const int b = blockIdx.x, lane = threadIdx.x;
-  uint32_t* gs = state + (int64_t)b * 624;
+  uint32_t* gs = a.state + (int64_t)b * 624;
   for (int i = lane; i < 624; i += 64) mt[i] = gs[i];
-  int p = pos[b];
+  int p = a.pos[b];
+  int step = a.fsm ? a.env_step[b] : 0, stage = a.fsm ? a.env_stage[b] : 0;
   __syncthreads();
-  const int64_t need = (int64_t)T * n_exo;
-  int64_t have = 0;
-  while (have < need) {
-    if (p >= 624) {                                           // genrand's regeneration (mt19937_gen)
-      for (int c = 0; c < 624; c += 64) {
-        const int k = c + lane;
-        uint32_t y = 0, src = 0;
-        if (k < 624) {
-          y = (mt[k] & 0x80000000u) | (mt[k == 623 ? 0 : k + 1] & 0x7fffffffu);
-          src = k < 227 ? mt[k + 397] : mt[k - 227];
+  for (int t = 0; t < a.T; ++t) {
+    const int base = a.mt_ptr[stage], need = a.mt_ptr[stage + 1] - base;
+    uint8_t* row = a.exo + ((int64_t)t * a.B + b) * a.n_exo;
+    int have = 0;
+    while (have < need) {
+      if (p >= 624) {                                         // genrand's regeneration (mt19937_gen)
+        for (int c = 0; c < 624; c += 64) {
+          const int k = c + lane;
+          uint32_t y = 0, src = 0;
+          if (k < 624) {
+            y = (mt[k] & 0x80000000u) | (mt[k == 623 ? 0 : k + 1] & 0x7fffffffu);
+            src = k < 227 ? mt[k + 397] : mt[k - 227];
+          }
+          __syncthreads();
+          if (k < 624) mt[k] = src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+          __syncthreads();
         }
-        __syncthreads();
-        if (k < 624) mt[k] = src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        __syncthreads();
+        p = 0;
       }
-      p = 0;
+      const int len = 624 - p < 64 ? 624 - p : 64;
+      uint32_t y = lane < len ? mt[p + lane] : 0u;
+      y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+      const uint32_t v = y & 7u;                              // mask of rng = 4 (buffered_bounded_masked_uint32)
+      const bool acc = lane < len && v <= 4u;
+      const uint64_t m = __ballot(acc);
+      const int before = __popcll(m & ((1ull << lane) - 1ull)), total = __popcll(m);
+      const int left = need - have;
+      if (acc && before < left) row[a.mt_rank[base + have + before]] = (uint8_t)v;
+      if (total <= left) { have += total; p += len; }
+      else {                                                  // the step's last draw is inside this pass: stop behind its word
+        const uint64_t last = __ballot(acc && before == left - 1);
+        p += __ffsll((long long)last);                        // 1-based lane of that word = words consumed
+        have = need;
+      }
     }
-    const int len = 624 - p < 64 ? 624 - p : 64;
-    uint32_t y = lane < len ? mt[p + lane] : 0u;
-    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-    const uint32_t v = y & 7u;                                // mask of rng = 4 (buffered_bounded_masked_uint32)
-    const bool acc = lane < len && v <= 4u;
-    const uint64_t m = __ballot(acc);
-    const int before = __popcll(m & ((1ull << lane) - 1ull)), total = __popcll(m);
-    const int64_t left = need - have;
-    if (acc && before < left) {
-      const int64_t idx = have + before, t = idx / n_exo, j = idx - t * n_exo;
-      exo[(t * B + b) * n_exo + j] = (uint8_t)v;
-    }
-    if (total <= left) { have += total; p += len; }
-    else {                                                    // the last wanted draw is inside this pass: stop behind its word
-      const uint64_t last = __ballot(acc && before == (int)left - 1);
-      p += __ffsll((long long)last);                          // 1-based lane of that word = words consumed
-      have = need;
+    if (a.fsm) {                                              // fsm.py:281-307 / the auto-reset of a rollout (fsm.py:217)
+      const int tn = step + 1;
+      stage = a.stage_tab ? a.stage_tab[(int64_t)stage * (a.num_steps + 1) + (tn <= a.num_steps ? tn : a.num_steps)] : a.stage_next[stage];
+      step = tn;
+      if (step >= a.num_steps) { step = 0; stage = a.initial_stage; }
     }
   }
   __syncthreads();
   for (int i = lane; i < 624; i += 64) gs[i] = mt[i];
-  if (lane == 0) pos[b] = p;
+  if (lane == 0) a.pos[b] = p;
 }
 
 static int mt_check(phx_env* e) {
@@ -1248,21 +1269,21 @@ int phx_mt_draw(phx_env* e, uint8_t* exo, int T, void* stream) {
   int rc = mt_check(e);
   if (rc != PHX_OK) return rc;
   if (!exo || T < 1) return fail(PHX_EINVAL, "bad argument");
-  if (e->d.env_type != PHX_ENV_PLAIN) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: PHX_ENV_PLAIN only (the customers of a stage-dependent acting list draw a stage-dependent number of words)");
+  if (e->d.env_type != PHX_ENV_PLAIN && e->d.env_type != PHX_ENV_FSM) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: PHX_ENV_PLAIN and PHX_ENV_FSM only");
   if (e->d.n_exo < 1) return fail(PHX_EUNSUPPORTED, "the env has no exogenous draws");
-  // the (one) acting list must make the draws in exogenous-index order: every drawing agent acts, in index order, no publisher
-  // (its binomial draws depend on the auction)
+  // (a publisher's binomial draws depend on the auction's outcome: they cannot be drawn ahead of the step)
   if (e->der.kind_count[PHX_KIND_PUBLISHER] > 0) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: PublisherAgent draws depend on the auction");
-  int next = 0;
-  for (int k = e->der.act_ptr[0]; k < e->der.act_ptr[1]; ++k) {
-    const int r = e->der.exo_rank[e->der.act_idx[k]];
-    if (r < 0) continue;
-    if (r != next) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: the acting order is not the exogenous-index order");
-    ++next;
-  }
-  if (next != e->d.n_exo) return fail(PHX_EUNSUPPORTED, "phx_mt_draw: every CustomerAgent must act in every step");
-  hipLaunchKernelGGL(phx_mt_draw_kernel, dim3(e->d.B), dim3(64), 0, (hipStream_t)stream, (uint32_t*)e->d.f[F_ENV_MT_STATE],
-                     (int32_t*)e->d.f[F_ENV_MT_POS], exo, e->d.B, e->d.n_exo, T);
+  hipStream_t st = (hipStream_t)stream;
+  bool all = e->d.n_lists == 1;                                // every drawing agent draws in every step: no entry is left unwritten
+  if (all) all = e->der.act_ptr.size() >= 2 && [&] { int n = 0; for (int k = e->der.act_ptr[0]; k < e->der.act_ptr[1]; ++k) n += e->der.exo_rank[e->der.act_idx[k]] >= 0; return n == e->d.n_exo; }();
+  if (!all) HIPCHK(hipMemsetAsync(exo, 0, (size_t)T * e->d.B * e->d.n_exo, st));    // customers that do not act draw nothing
+  MtArgs a;
+  a.state = (uint32_t*)e->d.f[F_ENV_MT_STATE]; a.pos = (int32_t*)e->d.f[F_ENV_MT_POS]; a.exo = exo;
+  a.mt_ptr = e->d.mt_ptr; a.mt_rank = e->d.mt_rank; a.stage_next = e->d.stage_next; a.stage_tab = e->d.stage_tab;
+  a.env_step = (const int32_t*)e->d.f[F_ENV_STEP]; a.env_stage = (const int32_t*)e->d.f[F_ENV_STAGE];
+  a.B = e->d.B; a.n_exo = e->d.n_exo; a.T = T; a.fsm = e->d.env_type == PHX_ENV_FSM ? 1 : 0;
+  a.num_steps = e->d.num_steps; a.initial_stage = e->d.initial_stage;
+  hipLaunchKernelGGL(phx_mt_draw_kernel, dim3(e->d.B), dim3(64), 0, st, a);
   HIPCHK(hipGetLastError());
   return PHX_OK;
 }

@@ -81,6 +81,8 @@ struct DevSpec {
   const int32_t* stage_next;     // [n_lists]  (FSM)
   const uint8_t* stage_allowed;  // [n_lists][n_lists] FSMStage.next_stages as a matrix (handler-chosen transitions), or NULL
   const int32_t* stage_tab;      // [n_lists][num_steps + 1] tabulated clock / stage handlers (phx_spec.stage_tab), or NULL
+  const int32_t* mt_ptr;         // PHX_F_MT19937: [n_lists + 1] / the exogenous indices of a list's drawing agents in acting order
+  const int32_t* mt_rank;        //   (the order in which the reference's CustomerAgents call np.random.randint in a step of that list)
   // generic engine, drop-out-free supply-chain specs: the round schedule of a step in which every agent is live and every acting
   // strategic agent has an action, simulated once at phx_create (phx_api.hip: build_static_schedule).  sched + sched_off[list]:
   // [R, n_0 .. n_7], act_off[acting items] (queue offset of the item's message or -1), then per round { cnt[A], goff[A], order[n_r],

@@ -159,6 +159,35 @@ def test_mt19937_streams_equal_numpy_and_the_draws_the_reference_consumed(lib):
         want = np.random.RandomState(s).randint(5, size=T * 54).astype(np.uint8).reshape(T, 54)
         np.testing.assert_array_equal(got[:, b], want, err_msg=f"numpy stream of seed {s}")
     np.testing.assert_array_equal(got, g["exo"])                # what the reference consumed
-    # a spec without the flag refuses; so does an FSM env (stage-dependent number of draws)
+    # a spec without the flag refuses
     r2 = CpuAbiRunner(lib, supply_chain_env(2, [3, 3], 10, 2).spec)
     assert lib.phx_mt_draw(r2.h, _p(np.zeros((1, 2, 6), np.uint8)), 1, None) == -2        # PHX_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["sc_fsm_small", "sc256_fsm"])
+def test_mt19937_streams_on_an_fsm_env_draw_for_the_stage_s_customers_only(lib, name):
+    """FSM supply chains: only the customers of the env's stage call np.random.randint (fsm.py:276-279 -> supply_chain.py:64).
+    Draws made step by step beside the steps equal the ones the REFERENCE consumed in the seeded golden run, the run itself
+    equals the golden, and ONE phx_mt_draw(T) -- which walks the stages forward itself -- equals the step-by-step draws."""
+    g = golden(name)
+    seeds = np.asarray([int(s) for s in g["seeds"]], np.uint32)
+    B, T, n = len(seeds), int(g["actions"].shape[0]), int(g["exo"].shape[2])
+    r = CpuAbiRunner(lib, env_from_golden(g, exogenous="mt19937").spec)
+    assert lib.phx_mt_seed(r.h, _p(seeds), None) == 0
+    r.reset()
+    for t in range(T):
+        if t > 0 and g["reset_before"][t].any():
+            r.reset(g["reset_before"][t])
+        exo = np.zeros((1, B, n), np.uint8)
+        assert lib.phx_mt_draw(r.h, _p(exo), 1, None) == 0
+        np.testing.assert_array_equal(exo[0], g["exo"][t], err_msg=f"draws t={t}")
+        r.step(g["actions"][t], exo[0])
+        np.testing.assert_array_equal(r.get_i32("shop.stock", (B, int(g["n_shops"]))), g["stock"][t], err_msg=f"stock t={t}")
+    # one call for the whole run from a fresh env: the stage walk (and the reset at the episode's end) is the kernel's own
+    if not g["reset_before"][1:].any() or int(g["num_steps"]) > 0:
+        r2 = CpuAbiRunner(lib, env_from_golden(g, exogenous="mt19937").spec)
+        assert lib.phx_mt_seed(r2.h, _p(seeds), None) == 0
+        r2.reset()
+        allx = np.zeros((T, B, n), np.uint8)
+        assert lib.phx_mt_draw(r2.h, _p(allx), T, None) == 0
+        np.testing.assert_array_equal(allx, g["exo"])

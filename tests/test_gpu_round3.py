@@ -538,9 +538,44 @@ def test_mt19937_streams_equal_numpy_at_scale_and_feed_the_fused_rollout():
     ro = o.rollout(60, actions=tr.actions.cpu().numpy(), exo=exo)
     np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]))
     np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
-    # an FSM env draws a stage-dependent number of words per step: refused loudly
-    envf = supply_chain_env(3, [2] * 3, 10, 4, fsm=True, exogenous="mt19937")
-    envf.reset(); envf.seed_streams(7)
-    from phantom_amd.device import DeviceError
-    with pytest.raises(DeviceError):
-        envf._device().mt_draw(1)
+
+
+@pytest.mark.parametrize("name", ["sc_fsm_small", "sc256_fsm"])
+def test_mt19937_streams_on_an_fsm_env_reproduce_the_seeded_reference_run(name):
+    """FSM supply chains: only the customers of the env's stage call np.random.randint.  Step by step the device draws equal what
+    the REFERENCE consumed in the seeded golden run and the run equals the golden; ONE phx_mt_draw(T), which walks the stages (and the
+    reset at the episode's end) itself, gives the same draws; and at B = 512 a fused FSM rollout fed by phx_mt_draw(T) equals the
+    same env stepped with per-step draws."""
+    from helpers import env_from_golden, golden
+    g = golden(name)
+    seeds = [int(s) for s in g["seeds"]]
+    B, T = len(seeds), int(g["actions"].shape[0])
+    d = _dev(env_from_golden(g, exogenous="mt19937").spec)
+    d.reset(); d.dev.mt_seed(seeds)
+    for t in range(T):
+        if t > 0 and g["reset_before"][t].any():
+            d.reset(g["reset_before"][t])
+        exo = d.dev.mt_draw(1)[0].cpu().numpy()
+        np.testing.assert_array_equal(exo, g["exo"][t], err_msg=f"draws t={t}")
+        d.step(g["actions"][t], None, exo)
+        np.testing.assert_array_equal(d.get_i32("shop.stock"), g["stock"][t], err_msg=f"stock t={t}")
+        np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(g["obs"][t]), err_msg=f"obs t={t}")
+    d2 = _dev(env_from_golden(g, exogenous="mt19937").spec)
+    d2.reset(); d2.dev.mt_seed(seeds)
+    np.testing.assert_array_equal(d2.dev.mt_draw(T).cpu().numpy(), g["exo"])
+    # at scale, through the env surface: rollout(T) draws the T steps' words in one call
+    S, K, Bb, Tr = int(g["n_shops"]), [int(k) for k in g["ks"]], 512, 2 * int(g["num_steps"]) + 3
+    ea = supply_chain_env(S, K, int(g["num_steps"]), Bb, fsm=True, exogenous="mt19937", seed=9)
+    eb = supply_chain_env(S, K, int(g["num_steps"]), Bb, fsm=True, exogenous="mt19937", seed=9)
+    for e in (ea, eb):
+        e.reset(); e.seed_streams(1000)
+    tr = ea.rollout(Tr)
+    db = eb._device()
+    acts = tr.actions
+    for t in range(Tr):
+        exo = db.mt_draw(1)[0]
+        out = db.step(acts[t].contiguous(), None, exo)
+        np.testing.assert_array_equal(f32_bits(out.observations.cpu().numpy()), f32_bits(tr.observations[t].cpu().numpy()), err_msg=f"obs t={t}")
+        done = (db.all_truncated | db.all_terminated)
+        if bool(done.any()):
+            db.reset(done)
