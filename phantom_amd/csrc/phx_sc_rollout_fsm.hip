@@ -33,7 +33,7 @@ struct FsmFastArgs {
   uint32_t mG, mG4, mS, mPR, mNS;   // ceil(2^32 / d) magics: G, G / 4, S, 3 G / 4, num_steps   (i < 2^16)
   int32_t norm;
   uint64_t seed; int64_t env_offset;
-  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_stage, *env_prev_stage;
+  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_stage, *env_prev_stage, *env_arrive;
   double* rew_cache; uint8_t* rew_cache_v; float* obs_cache; uint8_t* obs_cache_v;
   const uint32_t* pos_tab;          // [num_steps] see phx_api.hip: build_fsm_fast
   const int32_t* irregular;         // device word: == gen -> some env is off the tabulated stage chain, this kernel does nothing
@@ -452,37 +452,26 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fsmfast_kernel(con
       a.obs_cache_v[g] = 1;
     }
     const uint32_t pr = s_pair[tid];
-    if (a.whole_envs && (pr & 255u) == 0u) {
+    if ((pr & 255u) == 0u || (!a.whole_envs && tid == 0)) {
+      // the env's words: by the block itself when it holds whole envs; with blocks of pair ranges by the block that FINISHES LAST
+      // with the env (another block that holds a part of it may not have read them yet): every block counts itself in after its
+      // own reads, the one that completes the count stores the words and clears the counter (phx_sc_rollout.hip, same rule)
       const int bl = (int)(pr >> 8);
-      a.env_step[b_first + bl] = step;
-      a.env_tick[b_first + bl] = s_tick0[bl] + a.T;
-      a.env_stage[b_first + bl] = (int)(s_pos[step] >> 24);             // step < num_steps: the stage the next step runs in
-      a.env_prev_stage[b_first + bl] = (int)(wl >> 24);
+      const int64_t b = b_first + bl, p0 = b * nS;
+      const int n_touch = a.whole_envs ? 1 : (int)((p0 + nS - 1) / G - p0 / G) + 1;
+      if (n_touch == 1 || atomicAdd(&a.env_arrive[b], 1) + 1 == n_touch) {
+        a.env_step[b] = step;
+        a.env_tick[b] = s_tick0[bl] + a.T;
+        a.env_stage[b] = (int)(s_pos[step] >> 24);                      // step < num_steps: the stage the next step runs in
+        a.env_prev_stage[b] = (int)(wl >> 24);
+        if (n_touch > 1) a.env_arrive[b] = 0;
+      }
     }
   }
 }
 #undef a
 #undef io
 #undef FSM_REFRESH
-
-// env words after the fragment for launches whose blocks hold parts of envs (see phx_sc_fast_env_kernel)
-__global__ void phx_sc_fsmfast_env_kernel(const FsmFastArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B || *a.irregular == a.gen) return;
-  int step = a.env_step[b];
-  for (int t0 = 0, c = 0; t0 < a.T; ++c) {
-    const int left = a.T - t0, tc = c == 0 ? a.first_rows : (left < PHX_FAST_TC ? left : PHX_FAST_TC);
-    const int tend = a.num_steps - 1 - step;
-    step += tc;
-    if (tend >= 0 && tend < tc) step -= a.num_steps;
-    t0 += tc;
-  }
-  int pl = step - 1; if (pl < 0) pl += a.num_steps;
-  a.env_step[b] = step;
-  a.env_tick[b] += a.T;
-  a.env_stage[b] = (int)(a.pos_tab[step] >> 24);
-  a.env_prev_stage[b] = (int)(a.pos_tab[pl] >> 24);
-}
 
 static uint32_t fsm_magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); }
 
@@ -513,7 +502,7 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
-  a.env_stage = (int32_t*)sp.f[F_ENV_STAGE]; a.env_prev_stage = (int32_t*)sp.f[F_ENV_PREV_STAGE];
+  a.env_stage = (int32_t*)sp.f[F_ENV_STAGE]; a.env_prev_stage = (int32_t*)sp.f[F_ENV_PREV_STAGE]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
   a.rew_cache = (double*)sp.f[F_ENV_REW_CACHE]; a.rew_cache_v = (uint8_t*)sp.f[F_ENV_REW_CACHE_VALID];
   a.obs_cache = (float*)sp.f[F_ENV_OBS_CACHE]; a.obs_cache_v = (uint8_t*)sp.f[F_ENV_OBS_CACHE_VALID];
   a.pos_tab = sp.fsm_pos_tab; a.irregular = sp.fsm_irregular;
@@ -539,6 +528,7 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
   const size_t lds = (size_t)G4p * 4 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)items * 4 * (6 + 2 + 3) + (size_t)G4p * 4 * 4 +
                      (size_t)3 * FSM_LB * G4p * 8 + (size_t)G4p * 4 * 5 + (size_t)((sp.num_steps + 3) & ~3) * 4 + (size_t)epb4 * 8 + 32;
   if (lds > 40 * 1024) return false;
+  if (!p.whole_envs && !a.env_arrive) return false;           // blocks of pair ranges need the per-env arrival counter
   hipLaunchKernelGGL(phx_fsm_regular_check_kernel, dim3((sp.B + 255) / 256), dim3(256), 0, st, a.env_step, a.env_stage, a.pos_tab,
                      sp.num_steps, a.gen, sp.B, sp.fsm_irregular);
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
@@ -548,7 +538,6 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
   else if (nt == 384) hipLaunchKernelGGL((phx_sc_rollout_fsmfast_kernel<384>), grid, dim3(384), lds, st, a);
   else if (nt == 320) hipLaunchKernelGGL((phx_sc_rollout_fsmfast_kernel<320>), grid, dim3(320), lds, st, a);
   else hipLaunchKernelGGL((phx_sc_rollout_fsmfast_kernel<256>), grid, dim3(256), lds, st, a);
-  if (!p.whole_envs) hipLaunchKernelGGL(phx_sc_fsmfast_env_kernel, dim3((sp.B + 255) / 256), dim3(256), 0, st, a);
   *err = hipGetLastError();
   return true;
 }
