@@ -69,6 +69,18 @@ class StepGraph:
         return self.out
 
 
+class RolloutGraph:
+    """Consecutive ``phx_rollout`` fragments captured ONCE into a hipGraph (DeviceEnv.rollout_graph): ``replay()`` enqueues them on
+    the current stream; fragment i of a replay lands in ``trajectories[i]`` (rewritten by every replay)."""
+
+    def __init__(self, graph, trajectories, T):
+        self.graph, self.trajectories, self.T = graph, trajectories, T
+
+    def replay(self):
+        self.graph.replay()
+        return self.trajectories
+
+
 class DeviceEnv:
     def __init__(self, spec: EnvSpec, device=None):
         torch = _torch()
@@ -497,6 +509,25 @@ class DeviceEnv:
                 out = self.step(a, action_valid)
         torch.cuda.synchronize(self.device)
         return StepGraph(g, actions, self._step_out, n)
+
+    def rollout_graph(self, T: int, trajectories):
+        """Capture one ``phx_rollout`` of T steps per buffer of ``trajectories`` (from ``alloc_trajectory(T)``), in order, into a
+        hipGraph: a collection loop that consumes fragment after fragment replays the graph instead of paying a host launch per
+        fragment (the gap between dependent launches drops from the host's cadence to the graph's).  The env advances
+        ``len(trajectories) * T`` steps per replay, exactly as the same sequence of ``rollout`` calls would."""
+        torch = _torch()
+        trajectories = list(trajectories)
+        if not trajectories:
+            raise ValueError("rollout_graph needs at least one trajectory buffer")
+        for tr in trajectories:
+            self._check_rollout_buffers(T, None, None, tr)
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(self.device)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(g, stream=side):          # stream capture records the launches, it does not run them
+            for tr in trajectories:
+                self.rollout(T, out=tr)
+        torch.cuda.synchronize(self.device)
+        return RolloutGraph(g, trajectories, T)
 
     def inject(self, messages: List[Message]):
         if not messages:

@@ -579,3 +579,23 @@ def test_mt19937_streams_on_an_fsm_env_reproduce_the_seeded_reference_run(name):
         done = (db.all_truncated | db.all_terminated)
         if bool(done.any()):
             db.reset(done)
+
+
+def test_rollout_graph_replays_the_same_fragments_as_rollout_calls():
+    """DeviceEnv.rollout_graph: consecutive phx_rollout fragments captured once into a hipGraph; two replays give the fragments that
+    the same sequence of rollout() calls gives (the time-parallel kernel, and the generic engine's T-step loop)."""
+    for kw in ({}, {"force_generic": True}):
+        ea = supply_chain_env(9, [6] * 9, 100, 64, seed=21, **kw)
+        eb = supply_chain_env(9, [6] * 9, 100, 64, seed=21, **kw)
+        for e in (ea, eb):
+            e.reset()
+        da, db = ea._device(), eb._device()
+        bufs = [db.alloc_trajectory(37) for _ in range(3)]
+        g = db.rollout_graph(37, bufs)
+        for rep in range(2):
+            g.replay()
+            for i in range(3):
+                tr = da.rollout(37)
+                np.testing.assert_array_equal(f32_bits(bufs[i].observations.cpu().numpy()), f32_bits(tr.observations.cpu().numpy()), err_msg=f"{kw} replay {rep} fragment {i}")
+                np.testing.assert_array_equal(f32_bits(bufs[i].rewards.cpu().numpy()), f32_bits(tr.rewards.cpu().numpy()))
+                np.testing.assert_array_equal(bufs[i].truncations.cpu().numpy(), tr.truncations.cpu().numpy())
