@@ -301,7 +301,16 @@ typedef struct phx_rollout_io {
    * generic engine's launch loop); both NULL = not recorded.                               */
   phx_msg_rec* msg_log;        /* [T][B][trace_cap] or NULL                                 */
   int32_t*  msg_count;         /* [T][B] or NULL                                            */
+  /* ABI 7, opt-in RECORD layout: [T][B][S] records of PHX_TRAJ_RECORD_BYTES = 24 bytes
+   *   { float obs[3]; float action; float reward; uint8_t terminated, truncated, pad[2]; }
+   * instead of the five planes obs / action_out / reward / terminated / truncated, which must then be NULL.  The same values
+   * (time-major, one record per (step, env instance, strategic agent)); a workgroup of the time-parallel supply-chain kernel
+   * writes ONE run of whole cache lines per step instead of seven narrow runs (0.59-0.66 against 0.46-0.59 of the
+   * peak for the store pattern alone), at 24 instead of 22 bytes per agent-step.  Served by the time-parallel supply-chain
+   * rollout only (plain env, obs dim 3, device RNG and policy): PHX_EUNSUPPORTED elsewhere.  NULL = the planes.             */
+  void*     records;
 } phx_rollout_io;
+#define PHX_TRAJ_RECORD_BYTES 24
 
 /* ---- entry points ---------------------------------------------------------------------- */
 int         phx_abi_version(void);

@@ -92,7 +92,7 @@ class PhxStepIO(C.Structure):
 class PhxRolloutIO(C.Structure):
     _fields_ = [("T", C.c_int32)] + [(n, C.c_void_p) for n in (
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
-        "reward_valid", "last_obs", "err", "msg_log", "msg_count")]
+        "reward_valid", "last_obs", "err", "msg_log", "msg_count", "records")]
 
 
 assert C.sizeof(PhxMsgRec) == 16

@@ -999,6 +999,19 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
   if (e->d.env_type != PHX_ENV_PLAIN && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
+  if (io->records) {                  // opt-in record layout: the time-parallel supply-chain kernel only
+    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated)
+      return fail(PHX_EINVAL, "phx_rollout: with `records` the five planes must be NULL");
+    if (io->T <= 0 || ((uintptr_t)io->records & 15u) || ((uintptr_t)io->last_obs & 15u)) return fail(PHX_EINVAL, "bad rollout io");
+    if (!(e->use_fused && e->d.env_type == PHX_ENV_PLAIN && !e->d.any_typed && e->d.D == 3 && e->d.sc_fast.ok && !io->actions && !io->exo &&
+          !io->msg_log && !io->msg_count && e->d.variant_rollout != PHX_VR_GENERAL && e->d.variant_rollout != PHX_VR_LAUNCH_LOOP))
+      return fail(PHX_EUNSUPPORTED, "phx_rollout: the record layout is served by the time-parallel supply-chain rollout only");
+    if ((int64_t)20 * e->d.B * e->d.S * PHX_TRAJ_RECORD_BYTES >= ((int64_t)1 << 32))       // 32-bit offsets within a chunk of rows
+      return fail(PHX_EUNSUPPORTED, "phx_rollout: batch too large for the record layout");
+    HIPCHK(use_device(e));
+    HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
+    return PHX_OK;
+  }
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
   // `terminated` may be NULL where the plane would be all zero AND the kernel that serves the launch can leave it out: the

@@ -51,6 +51,8 @@ class Trajectory(NamedTuple):
     flat: "object" = None           # u8 [nbytes]: the one buffer every plane above is a section of (alloc_trajectory(flat=True))
     packed_flags: "object" = None   # u8 view of `flat`: bit-packed done flags for rollout collection (pack_done_flags)
     gather_nbytes: int = 0          # prefix of `flat` a learner needs from every rank (distributed.TrajectoryGather)
+    records: "object" = None        # u8 [T, B, S, 24]: the RECORD layout (alloc_trajectory(records=True)); observations /
+                                    # actions / rewards / terminations / truncations are then strided VIEWS of it
 
 
 class DeviceError(RuntimeError):
@@ -316,7 +318,7 @@ class DeviceEnv:
         return bool(np.isin(k, (_abi.KIND_SHOP, _abi.KIND_SELLER, _abi.KIND_BUYER)).all())
 
     def alloc_trajectory(self, T: int, record_messages: bool = False, flat: bool = False,
-                         terminations: bool = True) -> Trajectory:
+                         terminations: bool = True, records: bool = False) -> Trajectory:
         """Uninitialised device buffers for a T-step fragment (time-major).  ``record_messages``:
         also the per-step ordered message log (rollout.py:369-373, needs enable_tracking).
         ``flat``: every plane is a 256-byte aligned section of ONE buffer, ordered so that what a
@@ -328,6 +330,16 @@ class DeviceEnv:
         fsm = self._needs_valid_planes()
         if record_messages and self.spec.trace_cap <= 0:
             raise DeviceError("record_messages needs BatchResolver(enable_tracking=True)")
+        if records:
+            # phx_rollout_io.records: ONE buffer of 24-byte records {obs[3], action, reward, terminated, truncated, pad, pad} per
+            # (step, env instance, strategic agent); the usual fields are strided views of it (zero-copy: `.contiguous()` where a
+            # consumer needs a dense plane).  Served by the time-parallel supply-chain rollout only (phx_rollout refuses otherwise).
+            if flat or record_messages or fsm or D != 3:
+                raise DeviceError("alloc_trajectory(records=True): plain envs with 3-float observations only, not with flat / record_messages")
+            rec = e(T, B, S, 24, dtype=torch.uint8)
+            f = rec.view(torch.float32)                                # [T, B, S, 6]
+            return Trajectory(f[..., 0:3], f[..., 3], f[..., 4], rec[..., 20], rec[..., 21], e(B, S, D, dtype=torch.float32),
+                              records=rec)
         if flat:
             n = T * B * S
             words = (n + 63) // 64
@@ -385,6 +397,10 @@ class DeviceEnv:
             need("actions", actions, torch.float32, (B, S), lead=T)
         if exo is not None:
             need("exo", exo, torch.uint8, (B, self.n_exo), lead=T)
+        if out.records is not None:                        # record layout: one buffer; the plane fields are views of it
+            need("out.records", out.records, torch.uint8, (B, S, 24))
+            need("out.last_obs", out.last_obs, torch.float32, (S, D), lead=B)
+            return
         need("out.observations", out.observations, torch.float32, (B, S, D))
         need("out.actions", out.actions, torch.float32, (B, S))
         need("out.rewards", out.rewards, torch.float32, (B, S))
@@ -421,8 +437,11 @@ class DeviceEnv:
             io = _abi.PhxRolloutIO()
             io.T = T
             io.actions, io.exo = ptr(actions), ptr(exo)
-            io.obs, io.action_out, io.reward = ptr(out.observations), ptr(out.actions), ptr(out.rewards)
-            io.terminated, io.truncated = ptr(out.terminations), ptr(out.truncations)
+            if out.records is not None:
+                io.records = ptr(out.records)              # (the five planes stay NULL)
+            else:
+                io.obs, io.action_out, io.reward = ptr(out.observations), ptr(out.actions), ptr(out.rewards)
+                io.terminated, io.truncated = ptr(out.terminations), ptr(out.truncations)
             io.last_obs = ptr(out.last_obs)
             io.obs_valid, io.reward_valid = ptr(out.obs_valid), ptr(out.reward_valid)
             io.msg_log, io.msg_count = ptr(out.msg_log), ptr(out.msg_count)

@@ -599,3 +599,53 @@ def test_rollout_graph_replays_the_same_fragments_as_rollout_calls():
                 np.testing.assert_array_equal(f32_bits(bufs[i].observations.cpu().numpy()), f32_bits(tr.observations.cpu().numpy()), err_msg=f"{kw} replay {rep} fragment {i}")
                 np.testing.assert_array_equal(f32_bits(bufs[i].rewards.cpu().numpy()), f32_bits(tr.rewards.cpu().numpy()))
                 np.testing.assert_array_equal(bufs[i].truncations.cpu().numpy(), tr.truncations.cpu().numpy())
+
+
+# ---- the RECORD layout of a trajectory (phx_rollout_io.records; VERDICT r2 item 2a: an opt-in layout with an indexer) ------------
+@pytest.mark.parametrize("variants", [{}, {"block": 32}, {"block": 16}, {"block": "whole_envs"}], ids=str)
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (9, 6, 32, 23), (3, 2, 48, 40), (51, 4, 16, 100), (7, 3, 96, 30)])
+def test_record_layout_rollouts_match_oracle(S, K, B, num_steps, variants):
+    """alloc_trajectory(records=True): the time-parallel kernel writes one 24-byte record per (step, env, shop) -- obs[3], action,
+    reward, terminated, truncated, 2 pad bytes -- and the usual Trajectory fields are strided views of that buffer.  Ragged
+    fragment lengths, several episode ends per fragment, unaligned ticks, poked stocks: every view equals the oracle's plane, and
+    the env's state after the fragment equals the oracle's.  Envs / kernels that cannot serve the layout refuse."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, seed=31 + S, env_offset=500, variants=variants)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S * 10 + K)
+    for t in range(3):                                         # ticks no multiple of 4
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+    dev = d.dev
+    if variants.get("block") == "whole_envs" and not any(c * S <= 96 and c * S >= 32 and B % c == 0 for c in range(4, 256, 4)):
+        pytest.skip("no whole-env workgroup shape for this env: the time-parallel kernel does not apply")
+    for T in (1, 7, 20, 41, 100, 3, 200):
+        tr = dev.alloc_trajectory(T, records=True)
+        tr.records.fill_(0xA5)
+        dev.rollout(T, out=tr)
+        assert "records" in dev.last_kernel(), dev.last_kernel()
+        ro = o.rollout(T)
+        np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]), err_msg=f"obs T={T}")
+        np.testing.assert_array_equal(f32_bits(tr.actions.cpu().numpy()), f32_bits(ro["actions"]), err_msg=f"actions T={T}")
+        np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]), err_msg=f"rewards T={T}")
+        np.testing.assert_array_equal(tr.truncations.cpu().numpy(), ro["truncated"]); np.testing.assert_array_equal(tr.terminations.cpu().numpy(), ro["terminated"])
+        np.testing.assert_array_equal(f32_bits(tr.last_obs.cpu().numpy()), f32_bits(ro["last_obs"]))
+        assert int(tr.records[..., 22:].max()) == 0            # the pad bytes are written (zero), not left behind
+        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    st = rng.integers(-40, 160, (B, S)).astype(np.int32)
+    o.set_i32("shop.stock", st); d.set_i32("shop.stock", st)
+    tr = dev.alloc_trajectory(20, records=True); dev.rollout(20, out=tr); ro = o.rollout(20)
+    np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
+
+
+def test_record_layout_is_refused_where_no_kernel_serves_it():
+    from phantom_amd.device import DeviceError
+    envf = supply_chain_env(9, [6] * 9, 100, 16, fsm=True)
+    with pytest.raises(DeviceError):
+        _dev(envf.spec).dev.alloc_trajectory(10, records=True)
+    envg = supply_chain_env(9, [6] * 9, 100, 16, force_generic=True)
+    dg = _dev(envg.spec); dg.reset()
+    with pytest.raises(DeviceError):
+        dg.dev.rollout(10, out=dg.dev.alloc_trajectory(10, records=True))
