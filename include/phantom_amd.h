@@ -206,7 +206,9 @@ typedef struct phx_spec {
   int32_t variant_block;        /* time-parallel rollout kernels: (env, shop) pairs per workgroup; 0 = auto,
                                    PHX_VB_WHOLE_ENVS = whole envs per workgroup                */
   int32_t variant_step;         /* PHX_VS_*                                                   */
-  int32_t variant_reserved;
+  int32_t variant_flags;        /* ABI 7, time-parallel supply-chain rollout: PHX_VF_DENSE = the kernel stores every word of the flag planes;
+                                   PHX_VF_SPARSE = a streaming fill zeroes them and the kernel stores the non-zero words only (0 = auto:
+                                   sparse for fragments of >= 2^20 agent-steps)                                                    */
   /* ABI 6: stage handlers that decide from the clock and the current stage alone (fsm.py:294-307), tabulated by the
    * host at spec-compile time: stage_tab[s * (num_steps + 1) + t] = the stage the handler of stage s returns when the
    * clock reads t (1 .. num_steps; the clock is incremented before the handler runs, fsm.py:268); rows of handler-less
@@ -226,6 +228,8 @@ typedef struct phx_spec {
 #define PHX_VS_AUTO          0
 #define PHX_VS_FUSED         1  /* the static-schedule kernel of the env's family (default where one applies)                      */
 #define PHX_VS_GENERIC       2  /* the message-passing engine (same as PHX_F_FORCE_GENERIC)                                       */
+#define PHX_VF_DENSE         1
+#define PHX_VF_SPARSE        2
 
 typedef struct phx_env phx_env;   /* opaque */
 

@@ -62,7 +62,7 @@ class PhxSpec(C.Structure):
         ("n_conn", C.c_int32), ("conn_rate", C.c_void_p), ("col_conn", C.c_void_p),
         ("stage_allowed", C.c_void_p),
         ("variant_rollout", C.c_int32), ("variant_block", C.c_int32), ("variant_step", C.c_int32),
-        ("variant_reserved", C.c_int32),
+        ("variant_flags", C.c_int32),
         ("stage_tab", C.c_void_p),
     ]
 

@@ -666,7 +666,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.flags = spec->flags; d.queue_cap = spec->queue_cap; d.trace_cap = spec->trace_cap; d.scan_cap = der.scan_cap;
   d.n_lists = der.n_lists; d.initial_stage = spec->initial_stage; d.buyer_nnz = der.buyer_nnz; d.buyer_stride = der.kind_count[PHX_KIND_BUYER];
   d.seed = spec->seed; d.env_offset = spec->env_offset;
-  d.variant_rollout = spec->variant_rollout; d.variant_block = spec->variant_block; d.variant_step = spec->variant_step;
+  d.variant_rollout = spec->variant_rollout; d.variant_block = spec->variant_block; d.variant_step = spec->variant_step; d.variant_flags = spec->variant_flags;
   memcpy(d.kind_count, der.kind_count, sizeof d.kind_count);
   const int A = der.A;
 #define UP(dst, ptr, n) do { rc = upload(e, ptr, (size_t)(n), &d.dst); if (rc != PHX_OK) { phx_destroy(e); return rc; } } while (0)

@@ -104,7 +104,7 @@ struct DevSpec {
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
   const uint8_t* sc_shop_flags;  // [n_lists][nS] 1 shop acts, 2 a customer acts, 4 every customer acts, 8 observes, 16 rewarded
   int32_t max_cust;              // max customers of one shop
-  int32_t variant_rollout, variant_block, variant_step;   // phx_spec.variant_* (0 = the library's choice)
+  int32_t variant_rollout, variant_block, variant_step, variant_flags;   // phx_spec.variant_* (0 = the library's choice)
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
   ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)

@@ -37,6 +37,7 @@
 
 struct FastArgs {
   int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows, whole_envs;
+  int32_t flags_sparse;             // the flag planes were zero-filled before the launch: only the non-zero words are stored
   uint32_t pK; float inv_pK;        // 5^K and its f32 reciprocal (floor(y * inv) == y / 5^K for y < 5^6: tests/test_host_logic.py)
   uint32_t mG, mG4, mS, mPR;        // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4)  for i < 2^16
   int32_t norm;                     // the shops' common max_sales_per_step
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
     char* const p_tru = (char*)(io.truncated + row0);
     char* const p_ter = (char*)(io.terminated + row0);
     const bool wr_ter = io.terminated != nullptr;           // NULL: the caller does not want the all-zero plane (ShopAgent never terminates)
+    const bool flags_sparse = a.flags_sparse != 0;
     const uint32_t utotal = (uint32_t)total;
     const int G4 = G >> 2, nw = NT - first, n_units = tc * G4;
     const uint32_t PR = 3u * (uint32_t)G4;                              // 16-byte observation pieces per tile row
@@ -406,8 +408,11 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const 
         *(float4*)(p_rew + (size_t)(eo * 4u)) = vrw;
         *(float4*)(p_act + (size_t)(eo * 4u)) = va;
 #ifndef PHX_ABL_NOFLAGS
-        *(uint32_t*)(p_tru + (size_t)eo) = tr;
-        if (wr_ter) *(uint32_t*)(p_ter + (size_t)eo) = 0u;
+        if (flags_sparse) { if (tr) *(uint32_t*)(p_tru + (size_t)eo) = tr; }       // (an episode's last row: one row in num_steps)
+        else {
+          *(uint32_t*)(p_tru + (size_t)eo) = tr;
+          if (wr_ter) *(uint32_t*)(p_ter + (size_t)eo) = 0u;
+        }
 #else
         if (a.norm == -12345) *(uint32_t*)(p_tru + (size_t)eo) = tr;     // dev ablation: neither flag plane is stored
 #endif
@@ -556,6 +561,23 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   // 2 episode-end rows + the observation staging tile (3 floats per item) + ticks + flags
   const size_t lds = (size_t)((p.G + 3) & ~3) * 4 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)items * 4 * (6 + 2 + 3) +
                      (size_t)((p.G + 3) & ~3) * 8 + (size_t)((p.epb + 3) & ~3) * 4 + 16;
+  // The flag planes are 2 of the record's 22 bytes but a workgroup's share of a row is 32-48 bytes of each -- partial 64-byte
+  // write requests unless a neighbour's share reaches the L2 in time to merge; in the store pattern alone they cost a quarter to
+  // a third of the launch (tools/ubench/ub_store9.hip: 84-89 us with them, 54-62 without).  They are all zero except the
+  // episodes' last rows: a streaming fill (whole lines, ~5 us per T = 400 fragment) writes the zeros, the kernel the exceptions.
+  static const int sparse_env = getenv("PHX_ROLLOUT_SPARSE_FLAGS") ? atoi(getenv("PHX_ROLLOUT_SPARSE_FLAGS")) : 1;      // development
+  const int64_t n_flag = (int64_t)io.T * sp.B * sp.S;
+  a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 20)))) ? 1 : 0;
+  if (a.flags_sparse) {
+    phx_note_kernel("hipMemsetAsync[flag planes]");
+    hipError_t me;
+    if (io.terminated && io.terminated == io.truncated + n_flag) me = hipMemsetAsync(io.truncated, 0, (size_t)(2 * n_flag), st);
+    else {
+      me = hipMemsetAsync(io.truncated, 0, (size_t)n_flag, st);
+      if (me == hipSuccess && io.terminated) me = hipMemsetAsync(io.terminated, 0, (size_t)n_flag, st);
+    }
+    if (me != hipSuccess) return me;
+  }
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
   static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
   const int rec = ((p.G + 63) / 64) * 64;

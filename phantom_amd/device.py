@@ -365,9 +365,16 @@ class DeviceEnv:
                               buf, v["packed_flags"], gather_nbytes)
         # terminations=False: no `terminations` plane (it is all zero for kinds that never terminate; phx_rollout accepts
         # the omission where the serving kernel can leave the plane out and returns an error otherwise)
+        # (truncations directly followed by terminations: where the library zero-fills the flag planes before a rollout kernel
+        #  that only stores the non-zero flags, ONE fill covers both)
+        if terminations and (T * B * S) % 256 == 0:
+            flags = e(2, T, B, S, dtype=torch.uint8)
+            trunc, term = flags[0], flags[1]
+        else:
+            trunc, term = e(T, B, S, dtype=torch.uint8), (e(T, B, S, dtype=torch.uint8) if terminations else None)
         return Trajectory(e(T, B, S, D, dtype=torch.float32), e(T, B, S, dtype=torch.float32),
-                          e(T, B, S, dtype=torch.float32), e(T, B, S, dtype=torch.uint8) if terminations else None,
-                          e(T, B, S, dtype=torch.uint8), e(B, S, D, dtype=torch.float32),
+                          e(T, B, S, dtype=torch.float32), term,
+                          trunc, e(B, S, D, dtype=torch.float32),
                           e(T, B, S, dtype=torch.uint8) if fsm else None,
                           e(T, B, S, dtype=torch.uint8) if fsm else None,
                           e(T, B, self.spec.trace_cap, 16, dtype=torch.uint8) if record_messages else None,

@@ -35,7 +35,8 @@ def run_rollout_case(case):
         # a kernel variant drawn from the seed (phx_spec.variant_*; ignored where its preconditions do not hold)
         vrng = np.random.default_rng(case + 10_000_019)
         variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general"])),
-                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36][int(vrng.integers(0, 8))]}
+                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36][int(vrng.integers(0, 8))],
+                    "flags": ["auto", "dense", "sparse", "sparse"][int(vrng.integers(0, 4))]}
         env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
                                variants=variants)
         fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")
