@@ -208,7 +208,7 @@ typedef struct phx_spec {
   int32_t variant_step;         /* PHX_VS_*                                                   */
   int32_t variant_flags;        /* ABI 7, time-parallel supply-chain rollout: PHX_VF_DENSE = the kernel stores every word of the flag planes;
                                    PHX_VF_SPARSE = a streaming fill zeroes them and the kernel stores the non-zero words only (0 = auto:
-                                   sparse for fragments of >= 2^20 agent-steps)                                                    */
+                                   sparse for fragments of >= 2^23 agent-steps)                                                    */
   /* ABI 6: stage handlers that decide from the clock and the current stage alone (fsm.py:294-307), tabulated by the
    * host at spec-compile time: stage_tab[s * (num_steps + 1) + t] = the stage the handler of stage s returns when the
    * clock reads t (1 .. num_steps; the clock is incremented before the handler runs, fsm.py:268); rows of handler-less

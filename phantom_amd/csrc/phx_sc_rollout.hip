@@ -567,7 +567,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   // episodes' last rows: a streaming fill (whole lines, ~5 us per T = 400 fragment) writes the zeros, the kernel the exceptions.
   static const int sparse_env = getenv("PHX_ROLLOUT_SPARSE_FLAGS") ? atoi(getenv("PHX_ROLLOUT_SPARSE_FLAGS")) : 1;      // development
   const int64_t n_flag = (int64_t)io.T * sp.B * sp.S;
-  a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 20)))) ? 1 : 0;
+  a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 23)))) ? 1 : 0;
   if (a.flags_sparse) {
     phx_note_kernel("hipMemsetAsync[flag planes]");
     hipError_t me;
