@@ -131,8 +131,8 @@ PLAIN_VARIANTS = [
     ({"block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({}, "phx_sc_rollout_fast_kernel"),
-    ({"flags": "sparse"}, "hipMemsetAsync[flag planes]+phx_sc_rollout_fast_kernel"),
-    ({"flags": "sparse", "block": 32}, "hipMemsetAsync[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
+    ({"flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),            # (in-kernel fill, or hipMemsetAsync where a plane has a ragged end)
+    ({"flags": "sparse", "block": 32}, "[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
     ({"flags": "dense", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"rollout": "general"}, "phx_sc_rollout_kernel"),
     ({"rollout": "launch_loop"}, "phx_generic_step_kernel"),
