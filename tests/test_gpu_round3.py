@@ -131,7 +131,7 @@ PLAIN_VARIANTS = [
     ({"block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({}, "phx_sc_rollout_fast_kernel"),
-    ({"flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),            # (in-kernel fill, or hipMemsetAsync where a plane has a ragged end)
+    ({"flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),            # (hipMemsetAsync of the flag planes, then the kernel)
     ({"flags": "sparse", "block": 32}, "[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
     ({"flags": "dense", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"rollout": "general"}, "phx_sc_rollout_kernel"),
