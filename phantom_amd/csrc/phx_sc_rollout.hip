@@ -528,6 +528,22 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
   return true;
 }
 
+// zeros for the flag planes: one 16-byte store per thread, short-lived workgroups, the tail byte by byte.  (A kernel of our own, not
+// hipMemsetAsync: as fast, and a memset NODE captured into a hipGraph did not zero the planes on replay with this runtime --
+// test_rollout_graph_replays_the_same_fragments_as_rollout_calls.)
+__global__ __launch_bounds__(256) void phx_zero_fill_kernel(uint8_t* __restrict__ p, const int64_t n16, const int tail) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) ((float4*)p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < tail) p[n16 * 16 + i] = 0;
+}
+static hipError_t zero_fill(void* p, int64_t nbytes, hipStream_t st) {
+  if (((uintptr_t)p) & 15u) return hipErrorInvalidValue;              // (phx_rollout checks the planes' alignment)
+  const int64_t n16 = nbytes >> 4;
+  const int64_t threads = n16 > 16 ? n16 : 16;
+  hipLaunchKernelGGL(phx_zero_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (uint8_t*)p, n16, (int)(nbytes & 15));
+  return hipGetLastError();
+}
+
 hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const ScFastPlan& p = sp.sc_fast;
   FastArgs a;
@@ -569,12 +585,12 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   const int64_t n_flag = (int64_t)io.T * sp.B * sp.S;
   a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 23)))) ? 1 : 0;
   if (a.flags_sparse) {
-    phx_note_kernel("hipMemsetAsync[flag planes]");
+    phx_note_kernel("phx_zero_fill_kernel[flag planes]");
     hipError_t me;
-    if (io.terminated && io.terminated == io.truncated + n_flag) me = hipMemsetAsync(io.truncated, 0, (size_t)(2 * n_flag), st);
+    if (io.terminated && io.terminated == io.truncated + n_flag) me = zero_fill(io.truncated, 2 * n_flag, st);
     else {
-      me = hipMemsetAsync(io.truncated, 0, (size_t)n_flag, st);
-      if (me == hipSuccess && io.terminated) me = hipMemsetAsync(io.terminated, 0, (size_t)n_flag, st);
+      me = zero_fill(io.truncated, n_flag, st);
+      if (me == hipSuccess && io.terminated) me = zero_fill(io.terminated, n_flag, st);
     }
     if (me != hipSuccess) return me;
   }

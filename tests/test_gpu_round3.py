@@ -131,7 +131,7 @@ PLAIN_VARIANTS = [
     ({"block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({}, "phx_sc_rollout_fast_kernel"),
-    ({"flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),            # (hipMemsetAsync of the flag planes, then the kernel)
+    ({"flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),            # (the streaming fill of the flag planes, then the kernel)
     ({"flags": "sparse", "block": 32}, "[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
     ({"flags": "dense", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"rollout": "general"}, "phx_sc_rollout_kernel"),
@@ -587,7 +587,7 @@ def test_mt19937_streams_on_an_fsm_env_reproduce_the_seeded_reference_run(name):
 def test_rollout_graph_replays_the_same_fragments_as_rollout_calls():
     """DeviceEnv.rollout_graph: consecutive phx_rollout fragments captured once into a hipGraph; two replays give the fragments that
     the same sequence of rollout() calls gives (the time-parallel kernel, and the generic engine's T-step loop)."""
-    for kw in ({}, {"force_generic": True}):
+    for kw in ({}, {"force_generic": True}, {"variants": {"flags": "sparse"}}):      # (sparse: the fill kernel inside the capture)
         ea = supply_chain_env(9, [6] * 9, 100, 64, seed=21, **kw)
         eb = supply_chain_env(9, [6] * 9, 100, 64, seed=21, **kw)
         for e in (ea, eb):
