@@ -652,3 +652,26 @@ def test_record_layout_is_refused_where_no_kernel_serves_it():
     dg = _dev(envg.spec); dg.reset()
     with pytest.raises(DeviceError):
         dg.dev.rollout(10, out=dg.dev.alloc_trajectory(10, records=True))
+
+
+def test_bench_shape_fragment_sparse_flags_equal_dense_and_oracle_rows():
+    """The bench's launch shape (SC64, B = 4096, T = 400: the flag planes go out as one fill + the non-zero words by default) against
+    the same env with the kernel storing every flag word -- every plane bit-equal -- and the first and last episodes' rows against
+    the oracle."""
+    import torch
+    B, S, T = 4096, 9, 400
+    ea = supply_chain_env(S, [6] * S, 100, B, seed=42)                       # auto: sparse at this size
+    eb = supply_chain_env(S, [6] * S, 100, B, seed=42, variants={"flags": "dense"})
+    for e in (ea, eb):
+        e.reset()
+    ta = ea._device().rollout(T)
+    assert "phx_zero_fill_kernel[flag planes]" in ea._device().last_kernel()      # (the calling thread's LAST call)
+    tb = eb._device().rollout(T)
+    assert "fill" not in eb._device().last_kernel()
+    for name, x, y in zip(ta._fields[:6], ta[:6], tb[:6]):
+        assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8)), name
+    assert int(ta.truncations.sum()) == 4 * B * S and int(ta.terminations.sum()) == 0
+    o = OracleEnv(ea.spec, threads=NCPU); o.reset()
+    ro = o.rollout(100)
+    np.testing.assert_array_equal(f32_bits(ta.observations[:100].cpu().numpy()), f32_bits(ro["obs"]))
+    np.testing.assert_array_equal(ta.truncations[:100].cpu().numpy(), ro["truncated"])
