@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(256) void phx_mt_seed_kernel(const uint32_t* __rest
 struct MtArgs {
   uint32_t* state; int32_t* pos; uint8_t* exo;
   const int32_t *mt_ptr, *mt_rank, *stage_next, *stage_tab, *env_step, *env_stage;
-  int32_t B, n_exo, T, fsm, num_steps, initial_stage;
+  int32_t B, n_exo, T, fsm, num_steps, initial_stage, zero_rows;
 };
 __global__ __launch_bounds__(64) void phx_mt_draw_kernel(const MtArgs a) {
   __shared__ uint32_t mt[624];
@@ -1211,6 +1211,10 @@ __global__ __launch_bounds__(64) void phx_mt_draw_kernel(const MtArgs a) {
   for (int t = 0; t < a.T; ++t) {
     const int base = a.mt_ptr[stage], need = a.mt_ptr[stage + 1] - base;
     uint8_t* row = a.exo + ((int64_t)t * a.B + b) * a.n_exo;
+    if (a.zero_rows) {                                          // customers that do not act in this step draw nothing: their entries are 0
+      for (int j = lane; j < a.n_exo; j += 64) row[j] = 0;       // (one wave: these stores are issued before the draws' stores below)
+      __syncthreads();
+    }
     int have = 0;
     while (have < need) {
       if (p >= 624) {                                         // genrand's regeneration (mt19937_gen)
@@ -1289,13 +1293,12 @@ int phx_mt_draw(phx_env* e, uint8_t* exo, int T, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   bool all = e->d.n_lists == 1;                                // every drawing agent draws in every step: no entry is left unwritten
   if (all) all = e->der.act_ptr.size() >= 2 && [&] { int n = 0; for (int k = e->der.act_ptr[0]; k < e->der.act_ptr[1]; ++k) n += e->der.exo_rank[e->der.act_idx[k]] >= 0; return n == e->d.n_exo; }();
-  if (!all) HIPCHK(hipMemsetAsync(exo, 0, (size_t)T * e->d.B * e->d.n_exo, st));    // customers that do not act draw nothing
   MtArgs a;
   a.state = (uint32_t*)e->d.f[F_ENV_MT_STATE]; a.pos = (int32_t*)e->d.f[F_ENV_MT_POS]; a.exo = exo;
   a.mt_ptr = e->d.mt_ptr; a.mt_rank = e->d.mt_rank; a.stage_next = e->d.stage_next; a.stage_tab = e->d.stage_tab;
   a.env_step = (const int32_t*)e->d.f[F_ENV_STEP]; a.env_stage = (const int32_t*)e->d.f[F_ENV_STAGE];
   a.B = e->d.B; a.n_exo = e->d.n_exo; a.T = T; a.fsm = e->d.env_type == PHX_ENV_FSM ? 1 : 0;
-  a.num_steps = e->d.num_steps; a.initial_stage = e->d.initial_stage;
+  a.num_steps = e->d.num_steps; a.initial_stage = e->d.initial_stage; a.zero_rows = all ? 0 : 1;
   hipLaunchKernelGGL(phx_mt_draw_kernel, dim3(e->d.B), dim3(64), 0, st, a);
   HIPCHK(hipGetLastError());
   return PHX_OK;
