@@ -338,6 +338,10 @@ def main():
                     help="episodes (of num_steps = 100 steps) per phx_rollout launch: a time-major T = 400 fragment is four "
                          "consecutive T = 100 fragments in memory; start-up / drain and the launch gap are paid once per launch")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's default block shape (no env.autotune_rollout)")
+    ap.add_argument("--flag-pipeline", action="store_true",
+                    help="zero the NEXT buffer's flag planes on a side stream beside the current fragment (PHX_RH_FLAGS_ZEROED) instead of letting "
+                         "phx_rollout fill them in line -- measured SLOWER on MI355X (102 vs 80 us per T=400 launch: the cross-stream waits cost more "
+                         "than the 6 us fill they hide); kept for the comparison")
     ap.add_argument("--watchdog-s", type=float, default=900.0, help="overall deadline; a JSON line with `error` is printed when it passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
@@ -431,11 +435,34 @@ def run(args, rank, local_rank, world, watch):
     traj = trajs[0]
     rot = [0]
 
+    # Where the kernel stores only the non-zero flag words (phx_spec.variant_flags sparse: the default at this fragment size)
+    # phx_rollout zeroes the flag planes itself, in line, before the kernel.  --flag-pipeline: the zeros of the NEXT buffer's planes are
+    # written on a side stream while the current fragment is being written and phx_rollout is told so (PHX_RH_FLAGS_ZEROED) --
+    # measured slower (the cross-stream waits cost more than the fill they hide), kept for the comparison.
+    sparse = env._variants.get("flags", "auto") != "dense" and T * B * S >= (1 << 23)
+    use_pipe = sparse and args.flag_pipeline
+    side = torch.cuda.Stream(dev.device) if use_pipe else None
+    pipe_on = [use_pipe]
+
     def launches(n, bufs=None):                             # n full-length fragments, back to back
         bufs = bufs or trajs
         k = rot[0]
-        for _ in range(n):
-            dev.rollout(T, out=bufs[k % len(bufs)]); k += 1
+        if not pipe_on[0] or len(bufs) < 2:
+            for _ in range(n):
+                dev.rollout(T, out=bufs[k % len(bufs)]); k += 1
+        else:
+            main = torch.cuda.current_stream(dev.device)
+            dev.zero_flags(bufs[k % len(bufs)])             # the first buffer of the run: in line
+            for _ in range(n):
+                cur, nxt = bufs[k % len(bufs)], bufs[(k + 1) % len(bufs)]
+                e_prev, e_zero = torch.cuda.Event(), torch.cuda.Event()
+                e_prev.record(main)                         # everything that wrote `nxt` last (an earlier launch) is before this point
+                side.wait_event(e_prev)
+                with torch.cuda.stream(side):
+                    dev.zero_flags(nxt); e_zero.record(side)
+                dev.rollout(T, out=cur, flags_zeroed=True)
+                main.wait_event(e_zero)                     # the next launch needs `nxt` zeroed
+                k += 1
         rot[0] = k
 
     def sync_barrier():
@@ -493,7 +520,10 @@ def run(args, rank, local_rank, world, watch):
                    "num_steps": NUM_STEPS, "mode": "phx_rollout", "sharding": f"env-batch x{world}, no step-time collective",
                    "trajectory_buffers": f"{n_buf} x {frag_bytes / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)",
                    "steps_per_launch": T, "episodes_per_launch": T // NUM_STEPS,
-                   "autotune": tune},
+                   "autotune": tune,
+                   "flag_planes": ("zeros of the next buffer's terminated / truncated planes written on a side stream beside the current "
+                                   "fragment (PHX_RH_FLAGS_ZEROED), non-zero words by the kernel" if use_pipe else
+                                   ("zero-filled in line by phx_rollout, non-zero words by the kernel" if sparse else "every word stored by the kernel"))},
         "repeats": R, "timed_steps": R * K, "timed_launches": n_launch, "timed_region_ms": elapsed * 1e3,
         "warmup_launches": n_warm,
         "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} fragments of {T} steps; "
@@ -520,6 +550,11 @@ def run(args, rank, local_rank, world, watch):
     n_full = max(100, 400 * NUM_STEPS // T)
     launch_ms = event_ms(n_full)                              # rotating over the buffers: HBM
     same_ms = event_ms(n_full, [traj])                        # one buffer rewritten in place (round 2's loop): may sit in the Infinity Cache
+    inline_ms = None
+    if use_pipe:                                              # the same launches with phx_rollout zeroing the flag planes itself, in line
+        pipe_on[0] = False
+        inline_ms = event_ms(n_full)
+        pipe_on[0] = True
     alg = frag_bytes
     achieved = alg / (launch_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
@@ -596,6 +631,9 @@ def run(args, rank, local_rank, world, watch):
                        "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs,
                        "ms_per_100_steps": launch_ms * NUM_STEPS / T,
                        "one_episode_per_launch": frag1, "without_terminations_plane": no_term}
+    if inline_ms is not None:
+        out["roofline"]["flag_fill_in_line"] = {"launch_ms": inline_ms, "frac": alg / (inline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "note": "phx_rollout zeroes the flag planes itself before the kernel (no side stream, no hint): fill + kernel in series"}
 
     # ---- per-launch PhantomEnv.step mode (one kernel launch per step) ---------------------------
     if not args.no_per_step:

@@ -286,8 +286,12 @@ typedef struct phx_step_io {
 
 /* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end.
  * Every buffer must be 16-byte aligned (the kernels write 16-byte pieces); phx_rollout returns PHX_EINVAL otherwise. */
+#define PHX_RH_FLAGS_ZEROED 1   /* phx_rollout_io.hints: the caller has ALREADY zeroed `terminated` and `truncated` (e.g. on a side stream,
+                                   while the previous fragment was being written): where the serving kernel stores only the non-zero flag
+                                   words (phx_spec.variant_flags) its own fill is skipped; ignored by kernels that store every word */
 typedef struct phx_rollout_io {
   int32_t T;
+  int32_t hints;               /* ABI 7: PHX_RH_* (occupies what was padding: zero-initialised structs of older callers mean 0) */
   const float*   actions;      /* [T][B][S] replayed policy, or NULL -> random U[0,100)     */
   const uint8_t* exo;          /* [T][B][n_exo] or NULL -> device RNG                       */
   float*    obs;               /* [T][B][S][D]  post-step observation                       */

@@ -31,6 +31,7 @@ ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP = 0, 1, 2, 3, 4
 VB_WHOLE_ENVS = -1
 VS_AUTO, VS_FUSED, VS_GENERIC = 0, 1, 2
+RH_FLAGS_ZEROED = 1          # phx_rollout_io.hints
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES, F_MT19937 = 1, 2, 4, 8, 16
@@ -90,7 +91,7 @@ class PhxStepIO(C.Structure):
 
 
 class PhxRolloutIO(C.Structure):
-    _fields_ = [("T", C.c_int32)] + [(n, C.c_void_p) for n in (
+    _fields_ = [("T", C.c_int32), ("hints", C.c_int32)] + [(n, C.c_void_p) for n in (
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
         "reward_valid", "last_obs", "err", "msg_log", "msg_count", "records")]
 

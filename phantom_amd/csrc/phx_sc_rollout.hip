@@ -584,7 +584,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   static const int sparse_env = getenv("PHX_ROLLOUT_SPARSE_FLAGS") ? atoi(getenv("PHX_ROLLOUT_SPARSE_FLAGS")) : 1;      // development
   const int64_t n_flag = (int64_t)io.T * sp.B * sp.S;
   a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 23)))) ? 1 : 0;
-  if (a.flags_sparse) {
+  if (a.flags_sparse && !(io.hints & PHX_RH_FLAGS_ZEROED)) {          // (the caller may have zeroed them already, beside the previous fragment)
     phx_note_kernel("phx_zero_fill_kernel[flag planes]");
     hipError_t me;
     if (io.terminated && io.terminated == io.truncated + n_flag) me = zero_fill(io.truncated, 2 * n_flag, st);

@@ -427,7 +427,16 @@ class DeviceEnv:
             need("out.msg_count", out.msg_count, torch.int32, (B,))
             need("out.msg_log", out.msg_log, torch.uint8, (B, self.spec.trace_cap, 16))
 
-    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
+    def zero_flags(self, traj: Trajectory):
+        """Zero the ``terminations`` / ``truncations`` planes of a fragment on the CURRENT stream: a collection loop does this for the
+        next buffer on a side stream while the current fragment is written, and passes ``flags_zeroed=True`` to ``rollout``."""
+        traj.truncations.zero_()
+        if traj.terminations is not None:
+            traj.terminations.zero_()
+
+    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None, flags_zeroed: bool = False) -> Trajectory:
+        """``flags_zeroed``: the caller has already zeroed ``out``'s flag planes (``zero_flags``) -- where the serving kernel stores
+        only the non-zero flag words (phx_spec.variant_flags) its own fill is skipped; kernels that store every word ignore it."""
         owned = out is None
         if owned:
             out = self.alloc_trajectory(T)
@@ -437,12 +446,13 @@ class DeviceEnv:
         # ~80 MB at B=4096).
         ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else None
         sig = lambda x: (x.data_ptr(), x.numel()) if hasattr(x, "data_ptr") else None     # address AND size: a buffer freed
-        key = (T,) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))           # and reallocated smaller misses
+        key = (T, bool(flags_zeroed)) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))    # and reallocated smaller misses
         cached = None if owned else self._rollout_io_cache.get(key)
         if cached is None:
             self._check_rollout_buffers(T, actions, exo, out)
             io = _abi.PhxRolloutIO()
             io.T = T
+            io.hints = _abi.RH_FLAGS_ZEROED if (flags_zeroed and not owned) else 0
             io.actions, io.exo = ptr(actions), ptr(exo)
             if out.records is not None:
                 io.records = ptr(out.records)              # (the five planes stay NULL)

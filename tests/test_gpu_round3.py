@@ -675,3 +675,35 @@ def test_bench_shape_fragment_sparse_flags_equal_dense_and_oracle_rows():
     ro = o.rollout(100)
     np.testing.assert_array_equal(f32_bits(ta.observations[:100].cpu().numpy()), f32_bits(ro["obs"]))
     np.testing.assert_array_equal(ta.truncations[:100].cpu().numpy(), ro["truncated"])
+
+
+def test_rollout_with_flags_zeroed_by_the_caller_equals_the_in_line_fill():
+    """PHX_RH_FLAGS_ZEROED: a collection loop zeroes the next buffer's flag planes itself (DeviceEnv.zero_flags, e.g. on a side stream)
+    and phx_rollout skips its own fill; the fragments equal those of plain rollout calls.  Kernels that store every flag word ignore
+    the hint (a buffer full of garbage still comes out right)."""
+    import torch
+    for variants, T in (({"flags": "sparse"}, 57), ({"flags": "dense"}, 57), ({}, 300)):
+        ea = supply_chain_env(9, [6] * 9, 100, 64 if T < 100 else 4096, seed=5, variants=variants)
+        eb = supply_chain_env(9, [6] * 9, 100, 64 if T < 100 else 4096, seed=5, variants=variants)
+        for e in (ea, eb):
+            e.reset()
+        da, db = ea._device(), eb._device()
+        side = torch.cuda.Stream()
+        bufs = [db.alloc_trajectory(T) for _ in range(2)]
+        for b in bufs:
+            b.truncations.fill_(7); b.terminations.fill_(7)
+        main = torch.cuda.current_stream()
+        db.zero_flags(bufs[0])
+        for i in range(4):
+            cur, nxt = bufs[i % 2], bufs[(i + 1) % 2]
+            e0, e1 = torch.cuda.Event(), torch.cuda.Event()
+            e0.record(main); side.wait_event(e0)
+            with torch.cuda.stream(side):
+                if variants.get("flags") != "dense":
+                    db.zero_flags(nxt)
+                e1.record(side)
+            db.rollout(T, out=cur, flags_zeroed=True)
+            ref = da.rollout(T)
+            for name in ("observations", "rewards", "truncations", "terminations"):
+                assert torch.equal(getattr(cur, name), getattr(ref, name)), (variants, i, name)
+            main.wait_event(e1)
