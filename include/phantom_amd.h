@@ -228,6 +228,7 @@ typedef struct phx_spec {
 #define PHX_VS_AUTO          0
 #define PHX_VS_FUSED         1  /* the static-schedule kernel of the env's family (default where one applies)                      */
 #define PHX_VS_GENERIC       2  /* the message-passing engine (same as PHX_F_FORCE_GENERIC)                                       */
+/* phx_spec.variant_flags */
 #define PHX_VF_DENSE         1
 #define PHX_VF_SPARSE        2
 
