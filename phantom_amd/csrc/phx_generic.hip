@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   if (tid == 0) {
     fld<int32_t>(sp, F_ENV_CLOCK)[b] = clock;
     if (g.io.msg_count) g.io.msg_count[step_env] = log_n;
-    if (g.io.err && g.io.err[b] == 0 && s_errkey != ERRKEY_NONE) g.io.err[b] = s_errkey & 15;
+    if (g.io.err && s_errkey != ERRKEY_NONE && g.io.err[b] == 0) g.io.err[b] = s_errkey & 15;       // (the sticky word is read only when there is something to report)
   }
   if (g.resolve_only) return;
 
