@@ -28,7 +28,7 @@ TAG_PYF, TAG_F32, TAG_F64 = 0, 1, 2      # PHX_TAG_*: numpy scalar kind of an ad
 
 ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 # phx_spec.variant_* (ABI 6)
-VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP = 0, 1, 2, 3, 4
+VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP, VR_STORE_WAVES = 0, 1, 2, 3, 4, 5
 VB_WHOLE_ENVS = -1
 VS_AUTO, VS_FUSED, VS_GENERIC = 0, 1, 2
 RH_FLAGS_ZEROED = 1          # phx_rollout_io.hints

@@ -821,6 +821,14 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       plan.norm = der.shop_norm[0];
       d.sc_fast = plan;
     }
+    // round 4: the store-wave kernel serves the same envs (planes only) where a 16-pair-aligned workgroup shape exists;
+    // variant_rollout PHX_VR_TIME_PARALLEL keeps the round-3 kernel, PHX_VR_STORE_WAVES / PHX_VR_AUTO take this one
+    ScSwPlan sw;
+    if (d.sc_fast.ok && (d.variant_rollout == PHX_VR_AUTO || d.variant_rollout == PHX_VR_STORE_WAVES) &&
+        phx_sc_sw_plan(d.B, d.S, Ku, nu, d.num_steps, d.variant_block, &sw)) {
+      sw.norm = der.shop_norm[0];
+      d.sc_sw = sw;
+    }
   }
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
   d.ws_stride = ws_stride;
@@ -1088,7 +1096,11 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   }
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
-  if (e->d.sc_fast.ok && !io->actions && !io->exo && e->d.variant_rollout != PHX_VR_GENERAL) { HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
+  if (e->d.sc_fast.ok && !io->actions && !io->exo && e->d.variant_rollout != PHX_VR_GENERAL) {
+    if (e->d.sc_sw.ok) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
+    else HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
+    return PHX_OK;
+  }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));
   return PHX_OK;
 }

@@ -49,6 +49,11 @@ struct ScFastPlan {
   int32_t ok, epb, G, K, nt, norm, whole_envs;
 };
 
+// workgroup shape of the round-4 store-wave rollout kernel (phx_sc_rollout_sw.hip)
+struct ScSwPlan {
+  int32_t ok, epb, G, K, norm, tc, nt, n_rec, n_store, dtab_n, lds;
+};
+
 struct DevSpec {
   int32_t A, S, B, D, n_exo, nnz;
   int32_t num_steps, round_limit, env_type;
@@ -106,6 +111,7 @@ struct DevSpec {
   int32_t max_cust;              // max customers of one shop
   int32_t variant_rollout, variant_block, variant_step, variant_flags;   // phx_spec.variant_* (0 = the library's choice)
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
+  ScSwPlan sc_sw;                // store-wave rollout kernel (round 4): plan (ok == 0: not applicable)
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
   ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)
   const uint32_t* fsm_pos_tab;   // [num_steps] flags / lookbacks / stage of every episode position (layout: phx_sc_rollout_fsm.hip)
@@ -304,7 +310,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 #pragma unroll
   for (int r = 0; r < PHX_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    // three-way xor in ONE instruction (gfx950: v_bitop3_b32, truth table 0x96); the compiler emits two v_xor_b32 otherwise
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
     c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

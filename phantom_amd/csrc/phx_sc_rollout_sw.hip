@@ -1,0 +1,577 @@
+// phx_sc_rollout_sw.hip -- the time-parallel supply-chain rollout kernel, round-4 structure: DEDICATED STORE WAVES.
+//
+// Same path and the same trajectories as phx_sc_rollout_fast_kernel (phx_sc_rollout.hip): T consecutive PhantomEnv.step()
+// calls of a FACTORY / SHOP / CUSTOMER env (supply_chain.py:36-150, env.py:239-303) per launch, random policy and device-RNG
+// orders, auto-reset at episode end (the list-of-envs loop of utils/rllib/rollout.py:361-363).  What round 3 left on the
+// table (Weak #4): the worker waves of that kernel compute a chunk's outputs and store them themselves, a wave
+// stalled on store back-pressure computes nothing, and 44 bytes of LDS per item kept the workgroups narrow (48 pairs), which
+// is the slow end of the store pattern.  Measured before this file was written (tools/ubench/ub_store10.hip): a persistent
+// grid whose workgroups hand their finished chunk to a few waves that do nothing but `ds_read_b128 -> global_store_dwordx4`
+// (1 KB of consecutive 16-byte pieces per instruction) writes the trajectory at 0.82 of 8 TB/s with 144-pair workgroups (one
+// per CU, four store waves), dense flag planes included -- against 0.62-0.75 for the old pattern without the flag planes.
+// So here
+//   * a workgroup owns G consecutive (env, shop) pairs (G % 16 == 0; SC64, B = 4096: 144 pairs = one workgroup per CU) and
+//     walks the fragment in chunks of TC rows, one LDS-only barrier per chunk;
+//   * WORKER waves draw chunk c + 2 (one Philox block per (pair, tick quad); the order sum comes from ONE table lookup on
+//     y < 5^K, the action goes straight to HBM and never touches LDS) and compute the outputs of chunk c from 4 bytes of
+//     LDS per item (R | D << 8 and stock-before | stock-after << 8, both u16) into a staged tile laid out like the
+//     trajectory rows (observation [TC][3 G] f32, reward [TC][G] f32; the f32 reward comes from a [101][32] table of the
+//     f64 expression, computed at setup) -- they never issue a trajectory store except the 4-byte action;
+//   * RECURRENCE waves (one lane per pair) walk the stock chain of chunk c + 1 and store stock before AND after each step;
+//   * STORE waves stream the staged tile of chunk c - 1 to HBM and write the flag planes DENSELY (whole 16-byte pieces:
+//     no zero-fill launch before the kernel, no partial lines) from the per-pair episode-end rows of the chunk.
+// LDS: 10 bytes per item of tiles + 32 of staging (double-buffered) instead of 44 + nothing staged.
+#include "phx_dev.h"
+#include "phx_sc_fast.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+struct SwArgs {
+  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
+  int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
+  int32_t dtab_n;                       // 5^K entries of the order-sum table
+  int32_t alt_order;                    // every other worker wave draws before it computes outputs
+  int32_t store_inflight, store_sleep;  // store waves: stores in flight per wave (0 = unbounded), s_sleep 1 per store
+  uint32_t pK; float inv_pK;            // 5^K and its f32 reciprocal
+  uint32_t mG, mG4, mS, mPO, mPF;       // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4), i / (G / 16)   for i < 2^16
+  int32_t norm;
+  uint64_t seed; int64_t env_offset;
+  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_arrive;
+  unsigned long long* timing;           // PHX_TIMING builds only
+  phx_rollout_io io;
+};
+
+__device__ __forceinline__ void sw_lds_barrier() {       // orders LDS traffic only: the trajectory stores stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// LDS bytes of a workgroup (host and device agree through this one function)
+__host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_n) {
+  const size_t G4p = (size_t)((G + 3) & ~3), items = (size_t)TC * G;
+  return G4p * 4 + (size_t)((epb + 3) & ~3) * 4 + 16            // pair table, ticks, flags
+       + 101 * 32 * 4 + 32 * 32 * 4 + 401 * 8 * 4 + 128          // observation tables (32 copies), reward table (8 copies), digit sums of k < 125
+       + (size_t)((dtab_n + 15) & ~15)                           // order sums of y < 5^K
+       + items * 2 * 3 + items * 2 * 2                           // R | D tiles (3), stock tiles (2)
+       + (size_t)((G + 15) & ~15) * 3 + 16                       // episode-end rows (3) + pad
+       + G4p * 4                                                 // launch stocks (out-of-range stocks only)
+       + items * 16 * 2                                          // staged observation + reward, double-buffered
+       + items * 4 * 2;                                          // staged action (drawn one iteration before it is stored), double-buffered
+}
+
+typedef const __attribute__((address_space(4))) char* sw_kptr_t;
+#define a (*(const SwArgs*)kp)
+#define io (a.io)
+#define SW_REFRESH() asm volatile("" : "+s"(kp))
+
+template <int TC>
+__global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_) {
+  sw_kptr_t kp = (sw_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  SW_REFRESH();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, NT = blockDim.x, nS = a.S, G = a.G;
+  const int64_t total = (int64_t)a.B * nS;
+  const int bid = xcd_block(a.xcd_remap != 0);
+  const int64_t g_base = (int64_t)bid * G;
+  const int64_t b_first = g_base / nS;
+  const int r0 = (int)(g_base - b_first * nS);                          // the first pair's shop
+  const int n_env = (r0 + G - 1) / nS + 1;                              // envs the block touches (<= a.epb)
+
+  // ---- LDS carve (16-byte aligned sections; sw_lds_bytes) ---------------------------------------------------------
+  const int G4p = (G + 3) & ~3, G16p = (G + 15) & ~15, items = TC * G;
+  uint32_t* s_pair = (uint32_t*)smem;                                   // [G] shop | env_local << 8
+  int* s_tick0 = (int*)(s_pair + G4p);                                  // [epb]
+  int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
+  // The value tables are REPLICATED so that a lane's lookup lands in the lane's own LDS bank (ds_read_b32: 32 banks, lane
+  // groups of 32): entry v of copy c at dword v * 32 + c, lane l reads copy l & 31 -- no bank conflicts whatever the values.
+  // (One copy: ~3.5 distinct addresses per bank and lane group, and the output phase of nine waves was LDS-bound.)
+  float* s_tabs = (float*)(s_flags + 4);                                // [101][32] stock / 100        encode_observation,
+  float* s_tabn = s_tabs + 101 * 32;                                    // [32][32]  x / norm           supply_chain.py:124-134
+  // compute_reward (:147): f32(f64 sales - 0.1 * stock) depends on n = 10 * sales - stock only and equals the f32 quotient n / 10
+  // for every reachable (sales <= 30, stock <= 100) (tests/test_host_logic.py); 8 copies: lanes l, l + 8, .. share one
+  float* s_rtab = s_tabn + 32 * 32;                                     // [401][8]  f32(n / 10), n = 10 * sales - stock + 100
+  uint8_t* s_ds = (uint8_t*)(s_rtab + 401 * 8);                         // [125] base-5 digit sum of k < 5^3
+  uint8_t* s_dtab = s_ds + 128;                                         // [5^K] digit sum of y: the customers' order sizes summed
+  uint16_t* s_rd0 = (uint16_t*)(s_dtab + ((a.dtab_n + 15) & ~15));      // 3 x [TC][G]  R | D << 8                     (chunk c in c % 3)
+  uint16_t* s_xx0 = s_rd0 + 3 * items;                                  // 2 x [TC][G]  stock before | stock after << 8 (chunk c in c & 1)
+  uint8_t* s_ptend0 = (uint8_t*)(s_xx0 + 2 * items);                    // 3 x [G] chunk row that ends the pair's episode, or 255
+  int* s_x0w = (int*)(s_ptend0 + 3 * G16p + 16);                        // [G] stocks at launch (used when one is outside [0, 100])
+  float* s_out0 = (float*)(s_x0w + G4p);                                // 2 x { obs [TC][3 G], reward [TC][G] }   (chunk c in c & 1)
+  float* s_act0 = s_out0 + 8 * items;                                   // 2 x [TC][G] action, drawn at iteration c - 2, stored at c - 1 (chunk c in c & 1)
+
+  const int rec_threads = a.n_rec_waves << 6, store_first = rec_threads, work_first = rec_threads + (a.n_store_waves << 6);
+#ifdef PHX_TIMING
+  unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define STICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define STICK(k) do {} while (0)
+#endif
+
+  // ---- setup: the state loads are in flight while the tables are computed ------------------------------------------
+  int x = 0, step = 0;                    // lane state of the recurrence (lane tid owns pair g_base + tid)
+  {
+    int tk = 0;
+    const uint32_t pt = (uint32_t)(r0 + tid);
+    const uint32_t el = nS == 1 ? pt : __umulhi(pt, a.mS);               // (r0 + tid) / S
+    if (tid < G) { x = a.stock[g_base + tid]; step = a.env_step[b_first + el]; }
+    if (tid < n_env) tk = a.env_tick[b_first + tid];
+    if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
+    if (tid < 125) s_ds[tid] = (uint8_t)(tid % 5 + (tid / 5) % 5 + tid / 25);
+    for (int i = tid; i < 101 * 32; i += NT) s_tabs[i] = (float)(i >> 5) / (float)PHX_SHOP_MAX_STOCK;   // f32 IEEE division == the reference's f64 quotient cast to f32 (phx_dev.h: shop_obs_f32)
+    for (int i = tid; i < 32 * 32; i += NT) s_tabn[i] = (float)(i >> 5) / (float)a.norm;
+    for (int i = tid; i < 401 * 8; i += NT) {                            // f64 sales - 0.1 * stock, rounded once to f32 (shop_reward), by n
+      const int n = (i >> 3) - 100, sl = n >= 0 ? (n + 9) / 10 : 0, st = 10 * sl - n;       // a (sales, stock) pair with 10 * sales - stock == n
+      s_rtab[i] = (float)__dsub_rn((double)sl, __dmul_rn(0.1, (double)st));
+    }
+    if (tid < 4) s_flags[tid] = 0;
+    __syncthreads();
+    for (int w = tid; 4 * w < a.dtab_n; w += NT) {                       // order sums: four entries per word
+      uint32_t v = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t e = 4u * (uint32_t)w + (uint32_t)q, hi = (uint32_t)((float)e * 0.008f);     // e / 125, exact through f32 (e < 2^14)
+        v |= ((uint32_t)s_ds[hi < 125u ? hi : 0u] + (uint32_t)s_ds[(e - 125u * hi) < 125u ? e - 125u * hi : 0u]) << (8 * q);
+      }
+      ((uint32_t*)s_dtab)[w] = v;
+    }
+    if (tid < n_env) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
+    if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
+    __syncthreads();
+  }
+  STICK(0);
+  const int quad_extra = s_flags[0];      // chunk starts are not quad-aligned for every env: one more row quad
+  const bool weird = s_flags[1] != 0;     // a stock the caller set outside [0, 100] (any step brings it back into range)
+
+  const int first_rows = a.first_rows;
+  const int n_chunks = 1 + (a.T - first_rows + TC - 1) / TC;
+  auto start_of = [&](int c) { return c == 0 ? 0 : first_rows + (c - 1) * TC; };
+  auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c == 0 ? first_rows : (left < TC ? left : TC); };
+  const uint32_t utotal = (uint32_t)total;
+
+  // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by the worker waves.
+  //      One Philox block serves ticks 4q .. 4q + 3 of a shop: work items are (row quad jr, pair gl).  The action goes
+  //      straight to its plane (4 bytes per lane, 256 contiguous bytes per wave and row); R | D << 8 to the tile.
+  //      FIXED: the worker threads are a multiple of G, so a lane draws for the SAME pair in every item and every chunk --
+  //      shop, env and tick come from registers set once per launch instead of two dependent LDS lookups per item (an LDS
+  //      round trip is ~200 cycles in which the wave does nothing else: the draw phase had seven of them per item).
+  const int nwk = NT - work_first, wt = tid - work_first;               // worker threads, this thread's rank among them
+#ifdef SW_NO_FIXED_DRAWS
+  const bool draws_fixed = false;
+#else
+  const bool draws_fixed = (nwk % G) == 0;
+#endif
+  int dl_gl = 0, dl_jr0 = 0, dl_s = 0; uint32_t dl_tick0 = 0; int64_t dl_genv = 0;
+  if (wt >= 0) {
+    dl_jr0 = (int)__umulhi((uint32_t)wt, a.mG); dl_gl = wt - dl_jr0 * G;
+    const uint32_t pr = s_pair[dl_gl];
+    dl_s = (int)(pr & 255u);
+    dl_genv = a.env_offset + b_first + (int)(pr >> 8);
+    dl_tick0 = (uint32_t)s_tick0[pr >> 8];
+  }
+  auto draws_impl = [&](int t0, int tc, int buf, int buf2, auto ALIGNED, auto FIXED) __attribute__((always_inline)) {
+    constexpr bool aligned = decltype(ALIGNED)::value, fixed = decltype(FIXED)::value;
+    uint16_t* s_rd = s_rd0 + buf * items;
+    float* const s_act = s_act0 + (buf2) * items;
+    const int n_work = (((tc + 3) >> 2) + (aligned ? 0 : quad_extra)) * G;
+    const bool k6 = a.K == 6;
+    const int djr = fixed ? nwk / G : 0;
+    int jr = dl_jr0;
+    for (int iw = wt; iw < n_work; iw += nwk, jr += djr) {
+      int gl = dl_gl, s = dl_s; int64_t genv = dl_genv; uint32_t tick_base = dl_tick0 + (uint32_t)t0;
+      if (!fixed) {
+        jr = (int)__umulhi((uint32_t)iw, a.mG); gl = iw - (int)__umul24(jr, G);
+        const uint32_t pr = s_pair[gl];
+        s = (int)(pr & 255u);
+        genv = a.env_offset + b_first + (int)(pr >> 8);
+        tick_base = (uint32_t)s_tick0[pr >> 8] + (uint32_t)t0;
+      }
+      const int tla = 4 * jr - (aligned ? 0 : (int)(tick_base & 3u));
+      if (!aligned && (tla + 3 < 0 || tla >= tc)) continue;
+      const uint32_t tick_a = tick_base + (uint32_t)tla;                 // multiple of 4
+      uint32_t w[4];
+#ifdef PHX_ABL_NODRAW
+      w[0] = tick_a * 2654435761u + (uint32_t)genv; w[1] = w[0] * 40503u + s; w[2] = w[1] ^ 0x9e3779b9u; w[3] = w[2] + w[0];   // dev ablation: no Philox
+#else
+      rng_block(a.seed, genv, tick_a, s, 0, 0, w);
+#endif
+      uint32_t y[4], aj[4];
+      bool rej = false;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
+      if (__builtin_expect(rej, 0)) {                                    // probability 3.3e-6 per word: one cold branch
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {
+          uint32_t y2, j2;
+          if (!rng_split(w[h], y2, j2)) y[h] = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj[h]);
+        }
+      }
+      // the four order sums in ONE LDS round trip (the lookups are issued together, then the four items are finished)
+      int D[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        uint32_t yy = y[h];
+        if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);  // the first K base-5 digits: y mod 5^K
+        D[h] = (int)s_dtab[yy];                                          // the customers' order sizes summed, supply_chain.py:61-67
+      }
+      const int i = __mul24(tla, G) + gl;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if (!aligned) { const int tl = tla + h; if (tl < 0 || tl >= tc) continue; }
+        const float action = rng_j_to_action(aj[h]);                     // random policy, [0, 100)
+        s_rd[i + h * G] = (uint16_t)((int)rintf(action) | (D[h] << 8));  // decode_action: int(round(action)), supply_chain.py:139
+        s_act[i + h * G] = action;
+      }
+    }
+  };
+  auto draws = [&](int t0, int tc, int c) __attribute__((always_inline)) {
+    if (wt < 0) return;
+    if (!draws_fixed) draws_impl(t0, tc, c % 3, c & 1, std::false_type{}, std::false_type{});
+    else if (!quad_extra && (tc & 3) == 0) draws_impl(t0, tc, c % 3, c & 1, std::true_type{}, std::true_type{});
+    else draws_impl(t0, tc, c % 3, c & 1, std::false_type{}, std::true_type{});
+  };
+
+  // ---- the stock recurrence of chunk c (tc rows), one lane per pair ------------------------------------------------
+  //   stock' = max(stock - D, 0) + min(R, 100 - stock)      handle_order_request / handle_stock_response,
+  //   supply_chain.py:98-122 with decode_action's clamp :139; at the episode's last step the caller's env.reset() zeroes
+  //   the stock (ShopAgent.reset): the tile word of that step is PATCHED to D = 255, R = 0 before the burst read (stock'
+  //   = 0 for stock <= 100, no select on the chain) and restored after it.  Per step one u16 is stored: the stock before
+  //   the step and the stock after it; the episode's last row gets its true stock-after (what the last observation
+  //   shows) after the chain.
+  int fin_xb = 0, fin_rd = 0;             // the launch's last step: stock before it and its packed (R, D)
+  auto recurrence = [&](int c, int tc) __attribute__((always_inline)) {
+    const int tend = a.num_steps - 1 - step;                            // chunk row that ends the episode (one at most: TC <= num_steps)
+    const bool ends = tend >= 0 && tend < tc;
+    if (tid >= G) return;
+    __builtin_amdgcn_s_setprio(3);        // a dependent chain beside waves of Philox / output work: issue whenever ready
+    uint16_t* rdw = s_rd0 + (c % 3) * items + tid;
+    uint16_t* xx = s_xx0 + (c & 1) * items + tid;
+    s_ptend0[(c % 3) * G16p + tid] = (uint8_t)(ends ? tend : 255);
+    if (tc == TC && !(weird && c == 0)) {   // straight-line code, the chunk's operands fetched in one burst
+      int orig = 0;
+      if (ends) { orig = rdw[tend * G]; rdw[tend * G] = 0xFF00; }
+      int rd[TC];
+#pragma unroll
+      for (int h = 0; h < TC; ++h) rd[h] = rdw[h * G];
+#pragma unroll
+      for (int h = 0; h < TC; ++h) {
+        const int xn = max(x - (rd[h] >> 8), 0) + min(rd[h] & 255, PHX_SHOP_MAX_STOCK - x);
+        xx[h * G] = (uint16_t)(x | (xn << 8)); fin_xb = x;
+        x = xn;
+      }
+      fin_rd = rd[TC - 1];
+      if (ends) {                           // the true stock after the episode's last step (the chain carried the reset)
+        rdw[tend * G] = (uint16_t)orig;
+        const int xb = xx[tend * G] & 255;
+        const int xa = max(xb - (orig >> 8), 0) + min(orig & 255, PHX_SHOP_MAX_STOCK - xb);
+        xx[tend * G] = (uint16_t)(xb | (xa << 8));
+        if (tend == TC - 1) fin_rd = orig;
+      }
+    } else {                                // a ragged last chunk, or an out-of-range stock at launch (general form, capped)
+      for (int h = 0; h < tc; ++h) {
+        const int rdh = rdw[h * G];
+        const int xa = min(max(x - (rdh >> 8), 0) + min(rdh & 255, PHX_SHOP_MAX_STOCK - x), PHX_SHOP_MAX_STOCK);
+        xx[h * G] = (uint16_t)((x & 255) | (xa << 8)); fin_xb = x; fin_rd = rdh;
+        x = (ends && h == tend) ? 0 : xa;
+      }
+    }
+    step += tc;
+    if (ends) step -= a.num_steps;
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- outputs of chunk c into the staged tile, by the workers -------------------------------------------------------
+  // A work unit is 4 consecutive pairs of one tile row: 12 observation floats and 4 rewards, from the two u16 tiles and
+  // the tables; written to LDS in the layout of the trajectory rows (the store waves copy whole rows of pieces).  Where
+  // the worker threads are a multiple of G / 4, a lane keeps its column for the whole launch (no division per unit).
+  const int G4 = G >> 2;
+#ifdef SW_NO_FIXED_OUT
+  const bool out_fixed = false;
+#else
+  const bool out_fixed = (nwk % G4) == 0;
+#endif
+  const int ol_r0 = wt >= 0 ? (int)__umulhi((uint32_t)wt, a.mG4) : 0, ol_gl0 = wt >= 0 ? (wt - ol_r0 * G4) << 2 : 0;
+  auto outputs = [&](int c, int tc) __attribute__((always_inline)) {
+    if (wt < 0) return;
+    // typed views indexed in whole 8- / 16-byte elements from the (16-byte aligned) start of the LDS: the compiler then
+    // knows the alignment of every access (b64 reads, b128 writes) although the section offsets are run-time values
+    const uint2* const t_rd = (const uint2*)smem + (((int)((const char*)s_rd0 - smem) + (c % 3) * items * 2) >> 3);
+    const uint2* const t_xx = (const uint2*)smem + (((int)((const char*)s_xx0 - smem) + (c & 1) * items * 2) >> 3);
+    float4* const o_obs4 = (float4*)smem + (((int)((const char*)s_out0 - smem) >> 4) + (c & 1) * items);
+    float4* const o_rew4 = o_obs4 + 3 * (items >> 2);
+    const int n_units = tc * G4, dr = out_fixed ? nwk / G4 : 0;
+    const bool guard = weird && c == 0;
+    const uint32_t c32 = ((uint32_t)tid & 31u) << 2, c8 = ((uint32_t)tid & 7u) << 2;      // the lane's table copies (byte offsets)
+    const char* const t_s = (const char*)s_tabs; const char* const t_n = (const char*)s_tabn; const char* const t_r = (const char*)s_rtab;
+    int r = ol_r0;
+    for (int u = wt; u < n_units; u += nwk, r += dr) {
+      int gl0 = ol_gl0;
+      if (!out_fixed) { r = (int)__umulhi((uint32_t)u, a.mG4); gl0 = (u - (int)__umul24(r, G4)) << 2; }
+      const int j4 = (int)__umul24(r, G4) + (gl0 >> 2);                  // the unit's index: its four items start at 4 * j4
+      const uint2 vx = t_xx[j4], vr = t_rd[j4];
+      const uint32_t xw[4] = {vx.x & 0xffffu, vx.x >> 16, vx.y & 0xffffu, vx.y >> 16};
+      const uint32_t rw4[4] = {vr.x & 0xffffu, vr.x >> 16, vr.y & 0xffffu, vr.y >> 16};
+      float o[12], rw[4];
+      if (!guard) {
+        // sixteen table lookups in ONE LDS round trip: the addresses first, then the loads
+        uint32_t as_[4], an_[4], am_[4], ar_[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int x0 = (int)(xw[k] & 255u), xa = (int)(xw[k] >> 8), D = (int)(rw4[k] >> 8);
+          const int sales = min(x0, D), missed = D - sales;             // handle_order_request :105-122 (sales == x0 - max(x0 - D, 0))
+          as_[k] = ((uint32_t)xa << 7) | c32; an_[k] = ((uint32_t)sales << 7) | c32; am_[k] = ((uint32_t)missed << 7) | c32;
+          ar_[k] = ((uint32_t)(10 * sales - xa + 100) << 5) | c8;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[3 * k] = *(const float*)(t_s + as_[k]);                     // encode_observation :124-134
+          o[3 * k + 1] = *(const float*)(t_n + an_[k]);
+          o[3 * k + 2] = *(const float*)(t_n + am_[k]);
+          rw[k] = *(const float*)(t_r + ar_[k]);                        // compute_reward :147, rounded once to f32
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int x0 = (int)(xw[k] & 255u);
+          const int xa = (int)(xw[k] >> 8), D = (int)(rw4[k] >> 8);
+          if (r == 0) x0 = s_x0w[gl0 + k];                               // the launch's first row: the stock as the caller left it
+          const int sales = min(x0, D), missed = D - sales;
+          if ((unsigned)x0 <= (unsigned)PHX_SHOP_MAX_STOCK) {
+            o[3 * k] = s_tabs[xa << 5]; o[3 * k + 1] = s_tabn[sales << 5]; o[3 * k + 2] = s_tabn[missed << 5];
+            rw[k] = s_rtab[(10 * sales - xa + 100) << 3];
+          } else {                                                      // a stock the caller set outside [0, 100]: the formulas
+            float ob[3];
+            shop_obs_f32(xa, sales, missed, (float)a.norm, ob);
+            o[3 * k] = ob[0]; o[3 * k + 1] = ob[1]; o[3 * k + 2] = ob[2];
+            rw[k] = (float)shop_reward(sales, xa);
+          }
+        }
+      }
+      float4* so = o_obs4 + 3 * j4;
+      so[0] = make_float4(o[0], o[1], o[2], o[3]); so[1] = make_float4(o[4], o[5], o[6], o[7]); so[2] = make_float4(o[8], o[9], o[10], o[11]);
+      o_rew4[j4] = make_float4(rw[0], rw[1], rw[2], rw[3]);
+    }
+  };
+
+  // ---- the store waves: staged tile of chunk c -> trajectory rows, flag planes written densely ------------------------
+  // flat piece index q = row * P + piece over a staged tile, advancing by the store lanes per iteration: (piece, byte offset)
+  // are carried incrementally -- no multiply in the loop; each instruction writes 64 consecutive 16-byte pieces (1 KB)
+  const int nsl = a.n_store_waves << 6, sl = tid - store_first;
+  auto stream = [&](char* dst, const float* src, int tc, uint32_t P, uint32_t m, uint32_t rb) __attribute__((always_inline)) {
+    const uint32_t n = (uint32_t)tc * P, dq = (uint32_t)nsl;
+    const uint32_t dr = P == 1u ? dq : __umulhi(dq, m), dp = dq - dr * P;            // nsl = dr * P + dp
+    uint32_t q = (uint32_t)sl;
+    const uint32_t r0_ = P == 1u ? q : __umulhi(q, m);
+    uint32_t pc = q - r0_ * P, off = r0_ * rb + pc * 16u;
+    const uint32_t d_off = dr * rb + dp * 16u, wrap = rb - P * 16u;
+    for (; q < n; q += dq) {
+#ifndef PHX_ABL_NOSTORE
+      *(float4*)(dst + (size_t)off) = *(const float4*)(src + 4 * q);
+      // bound the stores this wave has in flight: a store that waits for room in the memory pipeline holds up the LDS / VMEM
+      // issue of the other waves of its SIMD pair (the workers' table lookups), so the store waves throttle themselves
+      switch (a.store_inflight) {
+        case 1: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: break;
+      }
+      for (int z = 0; z < a.store_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+#endif
+      pc += dp; off += d_off;
+      if (pc >= P) { pc -= P; off += wrap; }
+    }
+  };
+  auto store_actions = [&](int c, int t0, int tc) __attribute__((always_inline)) {      // chunk c's actions, staged by the draws one iteration ago
+    stream((char*)(io.action_out + ((int64_t)t0 * total + g_base)), s_act0 + (c & 1) * items, tc, (uint32_t)(G >> 2), a.mG4, utotal * 4u);
+  };
+  auto stores = [&](int c, int t0, int tc) __attribute__((always_inline)) {
+    const float* const o_obs = s_out0 + (c & 1) * (4 * items);
+    const float* const o_rew = o_obs + 3 * items;
+    const int64_t row0 = (int64_t)t0 * total + g_base;
+    const uint32_t PO = 3u * (uint32_t)(G >> 2), PR = (uint32_t)(G >> 2), PF = (uint32_t)(G >> 4);
+    stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, a.mPO, utotal * 12u);
+    stream((char*)(io.reward + row0), o_rew, tc, PR, a.mG4, utotal * 4u);
+#ifndef PHX_ABL_NOSTORE
+    {                                       // truncations["__all__"] (env.py:312-318) per shop; terminations are all zero (agents.py:292-323)
+      const uint8_t* pe = s_ptend0 + (c % 3) * G16p;
+      char* const p_tru = (char*)(io.truncated + row0);
+      char* const p_ter = io.terminated ? (char*)(io.terminated + row0) : nullptr;
+      const uint32_t n = (uint32_t)tc * PF;
+      for (uint32_t q = (uint32_t)sl; q < n; q += (uint32_t)nsl) {
+        const uint32_t rr = PF == 1u ? q : __umulhi(q, a.mPF), pc = q - rr * PF;     // (the magic of 1 does not fit 32 bits)
+        const uint4 e = *(const uint4*)(pe + 16u * pc);
+        const uint32_t rrrr = rr * 0x01010101u;
+        // bytes equal to rr -> 1 (exact zero-byte test of e ^ rrrr; rows are < 128, 255 = no episode end)
+        auto eq = [&](uint32_t w) { const uint32_t z = w ^ rrrr; return (~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu)) >> 7; };
+        const uint4 v = make_uint4(eq(e.x), eq(e.y), eq(e.z), eq(e.w));
+        *(uint4*)(p_tru + (size_t)(rr * utotal + pc * 16u)) = v;
+        if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#endif
+  };
+
+  // ---- schedule.  it = -2: the workers draw chunk 0;  it = -1: recurrence(0) beside draws(1);  it >= 0:
+  //        workers: outputs(it), draws(it + 2) | recurrence lanes: recurrence(it + 1) | store waves: stores(it - 1), actions(it + 1)    one barrier
+  for (int it = -2; it <= n_chunks; ++it) {
+    SW_REFRESH();
+    const int co = it, cr = it + 1, cd = it + 2, cs = it - 1;
+    if (tid >= work_first) {
+      // workers.  Every other worker wave draws first: the output phase is LDS traffic, the draws are VALU work -- both
+      // spread over the iteration.  One call site per phase keeps the code small.
+      const bool draw_first = a.alt_order && ((wt >> 6) & 1) != 0;
+#pragma unroll 1
+      for (int ph = 0; ph < 2; ++ph) {
+        if ((ph == 0) == draw_first) { if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd); STICK(1); }
+        else { if (co >= 0 && co < n_chunks) outputs(co, rows_of(co)); STICK(2); }
+      }
+    } else if (tid < rec_threads) {
+      if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
+      STICK(3);
+    } else {
+      if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
+      if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
+      STICK(4);
+    }
+    sw_lds_barrier(); STICK(5);
+  }
+#ifdef PHX_TIMING
+  if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = tm[q];
+#endif
+  // ---- state after the fragment -----------------------------------------------------------------------------------
+  if (tid < G) {
+    const int64_t g = g_base + tid;
+    const int R = fin_rd & 255, D = fin_rd >> 8;
+    const int xb = fin_xb;
+    const int sales = min(xb, D), missed = D - sales;
+    a.stock[g] = x; a.sales[g] = sales; a.missed[g] = missed; a.delivered[g] = min(R, PHX_SHOP_MAX_STOCK - xb);
+    if (io.last_obs) {
+      float ob[3];
+      shop_obs(x, sales, missed, a.norm, ob);
+      io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
+    }
+    const uint32_t pr = s_pair[tid];
+    const int bl = (int)(pr >> 8);
+    if ((pr & 255u) == 0u || tid == 0) {
+      // another block that holds a part of this env may not have read its step counter and tick yet: the block that
+      // FINISHES LAST with the env writes them (per-env arrival counter, as in phx_sc_rollout_fast_kernel)
+      const int64_t b = b_first + bl, p0 = b * nS;
+      const int n_touch = (int)((p0 + nS - 1) / G - p0 / G) + 1;
+      if (n_touch == 1 || atomicAdd(&a.env_arrive[b], 1) + 1 == n_touch) {
+        a.env_step[b] = step; a.env_tick[b] = s_tick0[bl] + a.T;
+        if (n_touch > 1) a.env_arrive[b] = 0;
+      }
+    }
+  }
+}
+
+#undef a
+#undef io
+#undef SW_REFRESH
+
+// ---- host: plan, launcher -------------------------------------------------------------------------------------------
+static uint32_t sw_magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); }
+static const size_t SW_LDS_MAX = 160 * 1024;
+
+// Decides whether an env shape takes the store-wave kernel and with which workgroup shape.  `block`: phx_spec.variant_block
+// (0 = auto; > 0: pairs per workgroup, taken when it is a multiple of 16 that divides B * S).
+bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, ScSwPlan* p) {
+  memset(p, 0, sizeof *p);
+  if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || block < 0) return false;
+  const int64_t total = (int64_t)B * S;
+  if (total >= ((int64_t)1 << 24)) return false;                                  // 24-bit multiplies on (row, pair) offsets
+  int dtab_n = 1; for (int k = 0; k < K_uniform; ++k) dtab_n *= 5;
+  static const int tc_env = getenv("PHX_SW_TC") ? atoi(getenv("PHX_SW_TC")) : 0;            // development default
+  static const int ns_env = getenv("PHX_SW_STORE_WAVES") ? atoi(getenv("PHX_SW_STORE_WAVES")) : 0;
+  static const int nw_env = getenv("PHX_SW_WORK_WAVES") ? atoi(getenv("PHX_SW_WORK_WAVES")) : 0;
+  auto epb_of = [&](int G) { return (G + S - 2) / S + 1; };                        // the most envs a block can touch
+  auto pairs_ok = [&](int G) { return G >= 16 && G <= 256 && G % 16 == 0 && total % G == 0 && epb_of(G) <= 255; };
+  auto tc_ok = [&](int G, int tc) {
+    return tc <= num_steps && (int64_t)tc * total * 12 < ((int64_t)1 << 32) && sw_lds_bytes(G, epb_of(G), tc, dtab_n) <= SW_LDS_MAX;
+  };
+  auto tc_for = [&](int G) {
+    if (tc_env == 16 || tc_env == 20) return tc_ok(G, tc_env) ? tc_env : 0;
+    return tc_ok(G, 20) ? 20 : (tc_ok(G, 16) ? 16 : 0);
+  };
+  int G = 0;
+  if (block > 0) { if (pairs_ok(block) && tc_for(block)) G = block; }
+  else {
+    // Wide workgroups write long row segments (tools/ubench/ub_store10.hip: 144 pairs 0.82 of 8 TB/s, 72 pairs 0.76, 48 pairs
+    // 0.74); a grid that fills whole rounds of the 256 CUs comes first.
+    double best = 0.0;
+    for (int cand = 192; cand >= 16; cand -= 16) {
+      if (!pairs_ok(cand) || !tc_for(cand)) continue;
+      const int64_t nblk = total / cand;
+      const size_t lds = sw_lds_bytes(cand, epb_of(cand), tc_for(cand), dtab_n);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(SW_LDS_MAX / lds, 2));
+      const int64_t slots = 256 * (int64_t)per_cu, rounds = (nblk + slots - 1) / slots;
+      const double eff = (double)nblk / (double)(rounds * slots);
+      const double shape = cand >= 128 ? 1.0 : cand >= 96 ? 0.95 : cand >= 64 ? 0.92 : cand >= 48 ? 0.9 : cand >= 32 ? 0.75 : 0.6;
+      if (eff * shape > best + 1e-9) { best = eff * shape; G = cand; }
+    }
+  }
+  if (!G) return false;
+  p->G = G; p->epb = epb_of(G); p->K = K_uniform; p->tc = tc_for(G); p->dtab_n = dtab_n;
+  p->n_rec = (G + 63) / 64;
+  p->n_store = ns_env > 0 ? ns_env : (G >= 96 ? 4 : (G >= 48 ? 2 : 1));
+  int work = nw_env > 0 ? nw_env : (p->tc * (G / 4) + 63) / 64;
+  if (work < 1) work = 1;
+  if (p->n_rec + p->n_store + work > 16) work = 16 - p->n_rec - p->n_store;
+  p->nt = 64 * (p->n_rec + p->n_store + work);
+  p->lds = (int32_t)sw_lds_bytes(G, p->epb, p->tc, dtab_n);
+  p->ok = 1;
+  return true;
+}
+
+hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  const ScSwPlan& p = sp.sc_sw;
+  SwArgs a; memset(&a, 0, sizeof a);
+  a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
+  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  a.xcd_remap = remap_env >= 0 ? remap_env : 1;
+  a.n_rec_waves = p.n_rec; a.n_store_waves = p.n_store; a.dtab_n = p.dtab_n;
+  static const int alt_env = getenv("PHX_SW_ALT") ? atoi(getenv("PHX_SW_ALT")) : 1;
+  a.alt_order = alt_env;
+  static const int sif_env = getenv("PHX_SW_INFLIGHT") ? atoi(getenv("PHX_SW_INFLIGHT")) : 0;
+  static const int ssl_env = getenv("PHX_SW_SLEEP") ? atoi(getenv("PHX_SW_SLEEP")) : 0;
+  a.store_inflight = sif_env; a.store_sleep = ssl_env;
+  static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
+  a.pK = (uint32_t)p.dtab_n; a.inv_pK = inv[p.K];
+  a.mG = sw_magic32(p.G); a.mG4 = sw_magic32(p.G / 4); a.mS = sw_magic32(sp.S); a.mPO = sw_magic32(3 * (p.G / 4)); a.mPF = sw_magic32(p.G / 16);
+  a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset;
+  a.first_rows = io.T <= p.tc ? io.T : p.tc;
+  a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
+  a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
+  a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
+  a.io = io;
+  const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
+#ifdef PHX_TIMING
+  { static unsigned long long* tbuf = nullptr; if (!tbuf) { (void)hipMalloc((void**)&tbuf, 8 * 16 * 8192 * sizeof(unsigned long long)); (void)hipMemset(tbuf, 0, 8 * 16 * 8192 * sizeof(unsigned long long)); } a.timing = grid.x <= 8192 ? tbuf : nullptr;
+    if (getenv("PHX_TIMING_DUMP")) { static int calls = 0; if (++calls == 20 && a.timing) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(8 * 16 * 8192); (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+      const char* role[3] = {"rec  ", "store", "work "}; const int nwv = p.nt / 64;
+      for (int r = 0; r < 3; ++r) { double sum[8] = {0}; int n = 0;
+        for (unsigned b = 0; b < grid.x; ++b) for (int w = 0; w < nwv; ++w) { const int rr = w < p.n_rec ? 0 : (w < p.n_rec + p.n_store ? 1 : 2); if (rr != r) continue; ++n; for (int q = 0; q < 8; ++q) sum[q] += (double)h[((size_t)b * 16 + w) * 8 + q]; }
+        fprintf(stderr, "SW_TIMING %s waves (%d): setup %.0f | draws %.0f | outputs %.0f | rec %.0f | stores %.0f | barrier %.0f   cycles per wave and launch\n", role[r], n, sum[0]/n, sum[1]/n, sum[2]/n, sum[3]/n, sum[4]/n, sum[5]/n); } } } }
+#endif
+  phx_note_kernel("phx_sc_rollout_sw_kernel");
+  // more than 64 KB of dynamic LDS needs the attribute (once per instantiation and device)
+  if (p.tc == 20) {
+    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev);
+    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; }
+    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<20>), grid, dim3(p.nt), (size_t)p.lds, st, a);
+  } else {
+    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev);
+    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; }
+    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<16>), grid, dim3(p.nt), (size_t)p.lds, st, a);
+  }
+  return hipGetLastError();
+}

@@ -126,14 +126,23 @@ def _cmp_rollout(rd, ro, valid_planes):
 
 
 PLAIN_VARIANTS = [
-    ({"block": "whole_envs"}, "phx_sc_rollout_fast_kernel[whole_envs]"),
-    ({"block": 32}, "phx_sc_rollout_fast_kernel[pairs]"),
-    ({"block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
-    ({"block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
-    ({}, "phx_sc_rollout_fast_kernel"),
-    ({"flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),            # (the streaming fill of the flag planes, then the kernel)
-    ({"flags": "sparse", "block": 32}, "[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
-    ({"flags": "dense", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
+    # the round-3 kernel (rollout="time_parallel") in every workgroup shape
+    ({"rollout": "time_parallel", "block": "whole_envs"}, "phx_sc_rollout_fast_kernel[whole_envs]"),
+    ({"rollout": "time_parallel", "block": 32}, "phx_sc_rollout_fast_kernel[pairs]"),
+    ({"rollout": "time_parallel", "block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
+    ({"rollout": "time_parallel", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
+    ({"rollout": "time_parallel"}, "phx_sc_rollout_fast_kernel"),
+    ({"rollout": "time_parallel", "flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),   # (the streaming fill of the flag planes, then the kernel)
+    ({"rollout": "time_parallel", "flags": "sparse", "block": 32}, "[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
+    ({"rollout": "time_parallel", "flags": "dense", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
+    # the round-4 store-wave kernel: the library's choice of workgroup, and 16 .. 144 pairs per workgroup
+    ({}, "phx_sc_rollout_"),
+    ({"rollout": "store_waves"}, "phx_sc_rollout_sw_kernel"),
+    ({"rollout": "store_waves", "block": 16}, "phx_sc_rollout_sw_kernel"),
+    ({"rollout": "store_waves", "block": 32}, "phx_sc_rollout_sw_kernel"),
+    ({"rollout": "store_waves", "block": 48}, "phx_sc_rollout_sw_kernel"),
+    ({"rollout": "store_waves", "block": 96}, "phx_sc_rollout_sw_kernel"),
+    ({"rollout": "store_waves", "block": 144}, "phx_sc_rollout_sw_kernel"),
     ({"rollout": "general"}, "phx_sc_rollout_kernel"),
     ({"rollout": "launch_loop"}, "phx_generic_step_kernel"),
 ]
@@ -177,6 +186,8 @@ def test_plain_rollout_variants_match_oracle(S, K, B, num_steps, variants, kerne
     total = B * S
     blk = variants.get("block")
     applicable = not isinstance(blk, int) or (total % blk == 0 and (blk + S - 2) // S + 1 <= 255)
+    if variants.get("rollout") == "store_waves":          # workgroups of a multiple of 16 pairs that divides B * S, chunk <= episode
+        applicable = num_steps >= 16 and (any(total % g == 0 for g in range(16, 257, 16)) if blk is None else (blk % 16 == 0 and total % blk == 0))
     if blk == "whole_envs":
         epb = next((c for c in range(4, 256, 4) if c * S <= 96 and c * S >= 32), 4 if 4 * S <= 96 else 0)
         applicable = bool(epb) and B % epb == 0

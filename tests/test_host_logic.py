@@ -482,3 +482,21 @@ def test_python_behaviour_on_a_device_kind_is_rejected():
         pass
     with pytest.raises(ph.UnsupportedAgentBehaviour):
         ph.compile_spec(net(Deeper), num_steps=3)
+
+
+def test_shop_reward_is_a_function_of_10_sales_minus_stock():
+    """phx_sc_rollout_sw_kernel tabulates compute_reward (supply_chain.py:144-147) by n = 10 * sales - stock: the f64 expression
+    sales - 0.1 * stock rounded once to f32 depends on n only over the reachable range, and equals the f32 quotient n / 10."""
+    by_n = {}
+    for sales in range(0, 31):
+        for stock in range(0, 101):
+            r = np.float32(np.float64(sales) - np.float64(0.1) * np.float64(stock))
+            n = 10 * sales - stock
+            assert by_n.setdefault(n, r.tobytes()) == r.tobytes(), (sales, stock)
+            assert r == np.float32(np.float32(n) / np.float32(10.0))
+    assert len(by_n) == 401
+    # the kernel fills entry n from ONE representative pair: sales = ceil(n / 10) (0 for n < 0), stock = 10 * sales - n
+    for n in range(-100, 301):
+        sl = (n + 9) // 10 if n >= 0 else 0
+        st = 10 * sl - n
+        assert 0 <= sl <= 30 and 0 <= st <= 100, n
