@@ -63,7 +63,7 @@ typedef const __attribute__((address_space(4))) char* fast_kptr_t;
 #define FAST_REFRESH() asm volatile("" : "+s"(kp))
 // REC: the trajectory goes out as 24-byte records (phx_rollout_io.records) instead of the five planes
 template <int NT, bool REC>
-__global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fast_kernel(const FastArgs a_) {
+__global__ __launch_bounds__(NT, (NT > 512 ? NT / 256 : NT / 64)) void phx_sc_rollout_fast_kernel(const FastArgs a_) {
   fast_kptr_t kp = (fast_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   FAST_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,7 +490,7 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
   const int64_t total = (int64_t)B * S;
   static const int g_env = getenv("PHX_ROLLOUT_G") ? atoi(getenv("PHX_ROLLOUT_G")) : 0;               // development default of variant_block
   if (block == 0) block = g_env;
-  auto pairs_ok = [&](int G) { return G >= 4 && G <= 128 && G % 4 == 0 && total % G == 0 && (G + S - 2) / S + 1 <= 255; };
+  auto pairs_ok = [&](int G) { return G >= 4 && G <= 192 && G % 4 == 0 && total % G == 0 && (G + S - 2) / S + 1 <= 255; };
   // (1) whole envs per block, a multiple of 4 of them so that every tile row is a whole number of 16-byte segments;
   //     ~32..64 pairs per block (one recurrence wave)
   int epb = 0;
@@ -523,7 +523,7 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
   p->K = K_uniform;
   const int p2w = (p->G + 63) / 64, p1w = ((PHX_FAST_TC / 4) * p->G + 63) / 64;     // draws of a chunk in one pass
   int want = 64 * (p2w + p1w);
-  p->nt = want <= 256 ? 256 : (want <= 320 ? 320 : (want <= 384 ? 384 : 512));
+  p->nt = want <= 256 ? 256 : (want <= 320 ? 320 : (want <= 384 ? 384 : (want <= 512 ? 512 : (want <= 768 ? 768 : 1024))));
   p->ok = 1;
   return true;
 }
@@ -602,7 +602,21 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
                              : (p.whole_envs ? "phx_sc_rollout_fast_kernel[whole_envs]" : "phx_sc_rollout_fast_kernel[pairs]"));
 #define PHX_LAUNCH_FAST(NT_) do { if (io.records) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<NT_, true>), grid, dim3(NT_), lds, st, a); \
                                  else hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<NT_, false>), grid, dim3(NT_), lds, st, a); } while (0)
-  if (nt == 512) PHX_LAUNCH_FAST(512);
+  if (lds > 64 * 1024) {               // more than 64 KB of dynamic LDS needs the attribute (wide workgroups)
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  if (nt == 1024) PHX_LAUNCH_FAST(1024);
+  else if (nt == 768) PHX_LAUNCH_FAST(768);
+  else if (nt == 512) PHX_LAUNCH_FAST(512);
   else if (nt == 384) PHX_LAUNCH_FAST(384);
   else if (nt == 320) PHX_LAUNCH_FAST(320);
   else PHX_LAUNCH_FAST(256);

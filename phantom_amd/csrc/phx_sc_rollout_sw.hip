@@ -36,6 +36,7 @@ struct SwArgs {
   int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
   int32_t dtab_n;                       // 5^K entries of the order-sum table
   int32_t alt_order;                    // every other worker wave draws before it computes outputs
+  int32_t alias_rows;                   // development only
   int32_t store_inflight, store_sleep;  // store waves: stores in flight per wave (0 = unbounded), s_sleep 1 per store
   uint32_t pK; float inv_pK;            // 5^K and its f32 reciprocal
   uint32_t mG, mG4, mS, mPO, mPF;       // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4), i / (G / 16)   for i < 2^16
@@ -57,7 +58,7 @@ __host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_
   const size_t G4p = (size_t)((G + 3) & ~3), items = (size_t)TC * G;
   return G4p * 4 + (size_t)((epb + 3) & ~3) * 4 + 16            // pair table, ticks, flags
        + 101 * 32 * 4 + 32 * 32 * 4 + 401 * 8 * 4 + 128          // observation tables (32 copies), reward table (8 copies), digit sums of k < 125
-       + (size_t)((dtab_n + 15) & ~15)                           // order sums of y < 5^K
+       + 15632                                                   // order sums of y < 5^K (5^6 reserved: the tables sit at fixed offsets)
        + items * 2 * 3 + items * 2 * 2                           // R | D tiles (3), stock tiles (2)
        + (size_t)((G + 15) & ~15) * 3 + 16                       // episode-end rows (3) + pad
        + G4p * 4                                                 // launch stocks (out-of-range stocks only)
@@ -70,12 +71,14 @@ typedef const __attribute__((address_space(4))) char* sw_kptr_t;
 #define io (a.io)
 #define SW_REFRESH() asm volatile("" : "+s"(kp))
 
-template <int TC>
+// GT > 0: the workgroup shape is a compile-time constant (GT pairs, NREC recurrence waves, NSTORE store waves): every
+// index computation on G folds, the kernel keeps fewer uniform values alive (the generic instantiation spills ~60 SGPRs).
+template <int TC, int GT, int NREC, int NSTORE, int NWORK>
 __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_) {
   sw_kptr_t kp = (sw_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   SW_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, NT = blockDim.x, nS = a.S, G = a.G;
+  const int tid = threadIdx.x, NT = GT ? 64 * (NREC + NSTORE + NWORK) : (int)blockDim.x, nS = a.S, G = GT ? GT : a.G;
   const int64_t total = (int64_t)a.B * nS;
   const int bid = xcd_block(a.xcd_remap != 0);
   const int64_t g_base = (int64_t)bid * G;
@@ -85,27 +88,32 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 
   // ---- LDS carve (16-byte aligned sections; sw_lds_bytes) ---------------------------------------------------------
   const int G4p = (G + 3) & ~3, G16p = (G + 15) & ~15, items = TC * G;
-  uint32_t* s_pair = (uint32_t*)smem;                                   // [G] shop | env_local << 8
-  int* s_tick0 = (int*)(s_pair + G4p);                                  // [epb]
-  int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
   // The value tables are REPLICATED so that a lane's lookup lands in the lane's own LDS bank (ds_read_b32: 32 banks, lane
   // groups of 32): entry v of copy c at dword v * 32 + c, lane l reads copy l & 31 -- no bank conflicts whatever the values.
-  // (One copy: ~3.5 distinct addresses per bank and lane group, and the output phase of nine waves was LDS-bound.)
-  float* s_tabs = (float*)(s_flags + 4);                                // [101][32] stock / 100        encode_observation,
+  float* s_tabs = (float*)smem;                                         // [101][32] stock / 100        encode_observation,
   float* s_tabn = s_tabs + 101 * 32;                                    // [32][32]  x / norm           supply_chain.py:124-134
   // compute_reward (:147): f32(f64 sales - 0.1 * stock) depends on n = 10 * sales - stock only and equals the f32 quotient n / 10
   // for every reachable (sales <= 30, stock <= 100) (tests/test_host_logic.py); 8 copies: lanes l, l + 8, .. share one
   float* s_rtab = s_tabn + 32 * 32;                                     // [401][8]  f32(n / 10), n = 10 * sales - stock + 100
   uint8_t* s_ds = (uint8_t*)(s_rtab + 401 * 8);                         // [125] base-5 digit sum of k < 5^3
-  uint8_t* s_dtab = s_ds + 128;                                         // [5^K] digit sum of y: the customers' order sizes summed
-  uint16_t* s_rd0 = (uint16_t*)(s_dtab + ((a.dtab_n + 15) & ~15));      // 3 x [TC][G]  R | D << 8                     (chunk c in c % 3)
+  uint8_t* s_dtab = s_ds + 128;                                         // [5^K <= 15625] digit sum of y: the customers' order sizes summed
+  uint32_t* s_pair = (uint32_t*)(s_dtab + 15632);                       // [G] shop | env_local << 8
+  int* s_tick0 = (int*)(s_pair + G4p);                                  // [epb]
+  int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
+  uint16_t* s_rd0 = (uint16_t*)(s_flags + 4);                           // 3 x [TC][G]  R | D << 8                     (chunk c in c % 3)
   uint16_t* s_xx0 = s_rd0 + 3 * items;                                  // 2 x [TC][G]  stock before | stock after << 8 (chunk c in c & 1)
   uint8_t* s_ptend0 = (uint8_t*)(s_xx0 + 2 * items);                    // 3 x [G] chunk row that ends the pair's episode, or 255
   int* s_x0w = (int*)(s_ptend0 + 3 * G16p + 16);                        // [G] stocks at launch (used when one is outside [0, 100])
   float* s_out0 = (float*)(s_x0w + G4p);                                // 2 x { obs [TC][3 G], reward [TC][G] }   (chunk c in c & 1)
   float* s_act0 = s_out0 + 8 * items;                                   // 2 x [TC][G] action, drawn at iteration c - 2, stored at c - 1 (chunk c in c & 1)
 
-  const int rec_threads = a.n_rec_waves << 6, store_first = rec_threads, work_first = rec_threads + (a.n_store_waves << 6);
+  // i / d for the block's divisors: a literal where the shape is compile-time, the host's magic otherwise (i < 2^16)
+  auto div_G = [&](uint32_t i) { return GT ? i / (uint32_t)(GT ? GT : 1) : __umulhi(i, a.mG); };
+  auto div_G4 = [&](uint32_t i) { return GT ? i / (uint32_t)(GT ? GT / 4 : 1) : __umulhi(i, a.mG4); };
+  auto div_PO = [&](uint32_t i) { return GT ? i / (uint32_t)(GT ? 3 * (GT / 4) : 1) : __umulhi(i, a.mPO); };
+  auto div_PF = [&](uint32_t i) { return GT ? i / (uint32_t)(GT ? GT / 16 : 1) : (a.mPF ? __umulhi(i, a.mPF) : i); };
+  const int n_store_waves = GT ? NSTORE : a.n_store_waves;
+  const int rec_threads = (GT ? NREC : a.n_rec_waves) << 6, store_first = rec_threads, work_first = rec_threads + (n_store_waves << 6);
 #ifdef PHX_TIMING
   unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define STICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tprev; tprev = now_; } while (0)
@@ -153,6 +161,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   auto start_of = [&](int c) { return c == 0 ? 0 : first_rows + (c - 1) * TC; };
   auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c == 0 ? first_rows : (left < TC ? left : TC); };
   const uint32_t utotal = (uint32_t)total;
+  const uint32_t rowmul = a.alias_rows ? 0u : 1u;            // development: every row written over row 0 (stores that never leave the L2)
 
   // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by the worker waves.
   //      One Philox block serves ticks 4q .. 4q + 3 of a shop: work items are (row quad jr, pair gl).  The action goes
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #endif
   int dl_gl = 0, dl_jr0 = 0, dl_s = 0; uint32_t dl_tick0 = 0; int64_t dl_genv = 0;
   if (wt >= 0) {
-    dl_jr0 = (int)__umulhi((uint32_t)wt, a.mG); dl_gl = wt - dl_jr0 * G;
+    dl_jr0 = (int)div_G((uint32_t)wt); dl_gl = wt - dl_jr0 * G;
     const uint32_t pr = s_pair[dl_gl];
     dl_s = (int)(pr & 255u);
     dl_genv = a.env_offset + b_first + (int)(pr >> 8);
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     for (int iw = wt; iw < n_work; iw += nwk, jr += djr) {
       int gl = dl_gl, s = dl_s; int64_t genv = dl_genv; uint32_t tick_base = dl_tick0 + (uint32_t)t0;
       if (!fixed) {
-        jr = (int)__umulhi((uint32_t)iw, a.mG); gl = iw - (int)__umul24(jr, G);
+        jr = (int)div_G((uint32_t)iw); gl = iw - (int)__umul24(jr, G);
         const uint32_t pr = s_pair[gl];
         s = (int)(pr & 255u);
         genv = a.env_offset + b_first + (int)(pr >> 8);
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #else
   const bool out_fixed = (nwk % G4) == 0;
 #endif
-  const int ol_r0 = wt >= 0 ? (int)__umulhi((uint32_t)wt, a.mG4) : 0, ol_gl0 = wt >= 0 ? (wt - ol_r0 * G4) << 2 : 0;
+  const int ol_r0 = wt >= 0 ? (int)div_G4((uint32_t)wt) : 0, ol_gl0 = wt >= 0 ? (wt - ol_r0 * G4) << 2 : 0;
   auto outputs = [&](int c, int tc) __attribute__((always_inline)) {
     if (wt < 0) return;
     // typed views indexed in whole 8- / 16-byte elements from the (16-byte aligned) start of the LDS: the compiler then
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     int r = ol_r0;
     for (int u = wt; u < n_units; u += nwk, r += dr) {
       int gl0 = ol_gl0;
-      if (!out_fixed) { r = (int)__umulhi((uint32_t)u, a.mG4); gl0 = (u - (int)__umul24(r, G4)) << 2; }
+      if (!out_fixed) { r = (int)div_G4((uint32_t)u); gl0 = (u - (int)__umul24(r, G4)) << 2; }
       const int j4 = (int)__umul24(r, G4) + (gl0 >> 2);                  // the unit's index: its four items start at 4 * j4
       const uint2 vx = t_xx[j4], vr = t_rd[j4];
       const uint32_t xw[4] = {vx.x & 0xffffu, vx.x >> 16, vx.y & 0xffffu, vx.y >> 16};
@@ -361,45 +370,43 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   // ---- the store waves: staged tile of chunk c -> trajectory rows, flag planes written densely ------------------------
   // flat piece index q = row * P + piece over a staged tile, advancing by the store lanes per iteration: (piece, byte offset)
   // are carried incrementally -- no multiply in the loop; each instruction writes 64 consecutive 16-byte pieces (1 KB)
-  const int nsl = a.n_store_waves << 6, sl = tid - store_first;
-  auto stream = [&](char* dst, const float* src, int tc, uint32_t P, uint32_t m, uint32_t rb) __attribute__((always_inline)) {
+  const int nsl = n_store_waves << 6, sl = tid - store_first;
+  auto stream = [&](char* dst, const float* src, int tc, uint32_t P, auto divP, uint32_t rb) __attribute__((always_inline)) {
     const uint32_t n = (uint32_t)tc * P, dq = (uint32_t)nsl;
-    const uint32_t dr = P == 1u ? dq : __umulhi(dq, m), dp = dq - dr * P;            // nsl = dr * P + dp
+    const uint32_t dr = divP(dq), dp = dq - dr * P;                                  // nsl = dr * P + dp
     uint32_t q = (uint32_t)sl;
-    const uint32_t r0_ = P == 1u ? q : __umulhi(q, m);
+    const uint32_t r0_ = divP(q);
     uint32_t pc = q - r0_ * P, off = r0_ * rb + pc * 16u;
     const uint32_t d_off = dr * rb + dp * 16u, wrap = rb - P * 16u;
-    for (; q < n; q += dq) {
+    const float4* sp = (const float4*)src + q;
+    // four pieces per trip: the LDS reads are issued together (one round trip), then the four stores
+    for (; q + 3u * dq < n; q += 4u * dq, sp += 4u * dq) {
+      const float4 v0 = sp[0], v1 = sp[dq], v2 = sp[2u * dq], v3 = sp[3u * dq];
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { o[k] = off; pc += dp; off += d_off; if (pc >= P) { pc -= P; off += wrap; } }
 #ifndef PHX_ABL_NOSTORE
-      *(float4*)(dst + (size_t)off) = *(const float4*)(src + 4 * q);
-      // bound the stores this wave has in flight: a store that waits for room in the memory pipeline holds up the LDS / VMEM
-      // issue of the other waves of its SIMD pair (the workers' table lookups), so the store waves throttle themselves
-      switch (a.store_inflight) {
-        case 1: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        default: break;
-      }
-      for (int z = 0; z < a.store_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+      *(float4*)(dst + (size_t)o[0]) = v0; *(float4*)(dst + (size_t)o[1]) = v1; *(float4*)(dst + (size_t)o[2]) = v2; *(float4*)(dst + (size_t)o[3]) = v3;
+#endif
+    }
+    for (; q < n; q += dq, sp += dq) {
+#ifndef PHX_ABL_NOSTORE
+      *(float4*)(dst + (size_t)off) = sp[0];
 #endif
       pc += dp; off += d_off;
       if (pc >= P) { pc -= P; off += wrap; }
     }
   };
   auto store_actions = [&](int c, int t0, int tc) __attribute__((always_inline)) {      // chunk c's actions, staged by the draws one iteration ago
-    stream((char*)(io.action_out + ((int64_t)t0 * total + g_base)), s_act0 + (c & 1) * items, tc, (uint32_t)(G >> 2), a.mG4, utotal * 4u);
+    stream((char*)(io.action_out + ((int64_t)(a.alias_rows ? 0 : t0) * total + g_base)), s_act0 + (c & 1) * items, tc, (uint32_t)(G >> 2), div_G4, utotal * 4u * rowmul);
   };
   auto stores = [&](int c, int t0, int tc) __attribute__((always_inline)) {
     const float* const o_obs = s_out0 + (c & 1) * (4 * items);
     const float* const o_rew = o_obs + 3 * items;
-    const int64_t row0 = (int64_t)t0 * total + g_base;
+    const int64_t row0 = (int64_t)(a.alias_rows ? 0 : t0) * total + g_base;
     const uint32_t PO = 3u * (uint32_t)(G >> 2), PR = (uint32_t)(G >> 2), PF = (uint32_t)(G >> 4);
-    stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, a.mPO, utotal * 12u);
-    stream((char*)(io.reward + row0), o_rew, tc, PR, a.mG4, utotal * 4u);
+    stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, div_PO, utotal * 12u * rowmul);
+    stream((char*)(io.reward + row0), o_rew, tc, PR, div_G4, utotal * 4u * rowmul);
 #ifndef PHX_ABL_NOSTORE
     {                                       // truncations["__all__"] (env.py:312-318) per shop; terminations are all zero (agents.py:292-323)
       const uint8_t* pe = s_ptend0 + (c % 3) * G16p;
@@ -407,14 +414,14 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       char* const p_ter = io.terminated ? (char*)(io.terminated + row0) : nullptr;
       const uint32_t n = (uint32_t)tc * PF;
       for (uint32_t q = (uint32_t)sl; q < n; q += (uint32_t)nsl) {
-        const uint32_t rr = PF == 1u ? q : __umulhi(q, a.mPF), pc = q - rr * PF;     // (the magic of 1 does not fit 32 bits)
+        const uint32_t rr = div_PF(q), pc = q - rr * PF;
         const uint4 e = *(const uint4*)(pe + 16u * pc);
         const uint32_t rrrr = rr * 0x01010101u;
         // bytes equal to rr -> 1 (exact zero-byte test of e ^ rrrr; rows are < 128, 255 = no episode end)
         auto eq = [&](uint32_t w) { const uint32_t z = w ^ rrrr; return (~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu)) >> 7; };
         const uint4 v = make_uint4(eq(e.x), eq(e.y), eq(e.z), eq(e.w));
-        *(uint4*)(p_tru + (size_t)(rr * utotal + pc * 16u)) = v;
-        if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
+        *(uint4*)(p_tru + (size_t)(rr * utotal * rowmul + pc * 16u)) = v;
+        if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal * rowmul + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
 #endif
@@ -544,9 +551,11 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   static const int sif_env = getenv("PHX_SW_INFLIGHT") ? atoi(getenv("PHX_SW_INFLIGHT")) : 0;
   static const int ssl_env = getenv("PHX_SW_SLEEP") ? atoi(getenv("PHX_SW_SLEEP")) : 0;
   a.store_inflight = sif_env; a.store_sleep = ssl_env;
+  static const int alias_env = getenv("PHX_SW_ALIAS_ROWS") ? atoi(getenv("PHX_SW_ALIAS_ROWS")) : 0;
+  a.alias_rows = alias_env;
   static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
   a.pK = (uint32_t)p.dtab_n; a.inv_pK = inv[p.K];
-  a.mG = sw_magic32(p.G); a.mG4 = sw_magic32(p.G / 4); a.mS = sw_magic32(sp.S); a.mPO = sw_magic32(3 * (p.G / 4)); a.mPF = sw_magic32(p.G / 16);
+  a.mG = sw_magic32(p.G); a.mG4 = sw_magic32(p.G / 4); a.mS = sw_magic32(sp.S); a.mPO = sw_magic32(3 * (p.G / 4)); a.mPF = p.G / 16 > 1 ? sw_magic32(p.G / 16) : 0;     // (the magic of 1 does not fit 32 bits: 0 = no division)
   a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset;
   a.first_rows = io.T <= p.tc ? io.T : p.tc;
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
@@ -564,14 +573,15 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
 #endif
   phx_note_kernel("phx_sc_rollout_sw_kernel");
   // more than 64 KB of dynamic LDS needs the attribute (once per instantiation and device)
-  if (p.tc == 20) {
-    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev);
-    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; }
-    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<20>), grid, dim3(p.nt), (size_t)p.lds, st, a);
-  } else {
-    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev);
-    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; }
-    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<16>), grid, dim3(p.nt), (size_t)p.lds, st, a);
-  }
+#define SW_LAUNCH(TC_, GT_, NREC_, NSTORE_, NWORK_) do { \
+    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev); \
+    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
+    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
+  static const int generic_env = getenv("PHX_SW_GENERIC") ? atoi(getenv("PHX_SW_GENERIC")) : 0;      // development: the run-time-shape instantiation
+  if (!generic_env && p.tc == 16 && p.G == 144 && p.n_rec == 3 && p.n_store == 4 && p.nt == 1024) SW_LAUNCH(16, 144, 3, 4, 9);
+  else if (!generic_env && p.tc == 16 && p.G == 144 && p.n_rec == 3 && p.n_store == 2 && p.nt == 896) SW_LAUNCH(16, 144, 3, 2, 9);
+  else if (p.tc == 20) SW_LAUNCH(20, 0, 0, 0, 0);
+  else SW_LAUNCH(16, 0, 0, 0, 0);
+#undef SW_LAUNCH
   return hipGetLastError();
 }
