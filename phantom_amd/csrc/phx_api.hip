@@ -825,9 +825,14 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     // variant_rollout PHX_VR_TIME_PARALLEL keeps the round-3 kernel, PHX_VR_STORE_WAVES / PHX_VR_AUTO take this one
     ScSwPlan sw;
     if (d.sc_fast.ok && (d.variant_rollout == PHX_VR_AUTO || d.variant_rollout == PHX_VR_STORE_WAVES) &&
-        phx_sc_sw_plan(d.B, d.S, Ku, nu, d.num_steps, d.variant_block, &sw)) {
+        phx_sc_sw_plan(d.B, d.S, Ku, nu, d.num_steps, d.variant_block, &sw) && (sw.specialised || d.variant_rollout == PHX_VR_STORE_WAVES)) {
       sw.norm = der.shop_norm[0];
-      d.sc_sw = sw;
+      std::vector<uint8_t> img;
+      phx_sc_sw_tables(sw.K, sw.norm, &img);
+      const uint8_t* dev_img = nullptr;
+      rc = upload(e, img.data(), img.size(), &dev_img);
+      if (rc != PHX_OK) { phx_destroy(e); return rc; }
+      d.sc_sw = sw; d.sc_sw_tables = dev_img;
     }
   }
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
@@ -1097,7 +1102,9 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   if (e->d.sc_fast.ok && !io->actions && !io->exo && e->d.variant_rollout != PHX_VR_GENERAL) {
-    if (e->d.sc_sw.ok) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
+    // the store-wave kernel where the caller asked for it, or (PHX_VR_AUTO) where a compile-time shape serves the env in one round of
+    // workgroups AND the fragment is long enough to amortise its deeper pipeline (T = 100: 24.4 us against 22.9; T = 400: 65 against 72-76)
+    if (e->d.sc_sw.ok && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 200)) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
     else HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
     return PHX_OK;
   }

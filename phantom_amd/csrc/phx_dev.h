@@ -52,6 +52,7 @@ struct ScFastPlan {
 // workgroup shape of the round-4 store-wave rollout kernel (phx_sc_rollout_sw.hip)
 struct ScSwPlan {
   int32_t ok, epb, G, K, norm, tc, nt, n_rec, n_store, dtab_n, lds;
+  int32_t specialised;           // a compile-time instantiation serves the shape (what PHX_VR_AUTO requires: the run-time-shape kernel is slower than round 3's)
 };
 
 struct DevSpec {
@@ -112,6 +113,7 @@ struct DevSpec {
   int32_t variant_rollout, variant_block, variant_step, variant_flags;   // phx_spec.variant_* (0 = the library's choice)
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   ScSwPlan sc_sw;                // store-wave rollout kernel (round 4): plan (ok == 0: not applicable)
+  const void* sc_sw_tables;      // its table image in device memory (phx_sc_sw_tables)
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
   ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)
   const uint32_t* fsm_pos_tab;   // [num_steps] flags / lookbacks / stage of every episode position (layout: phx_sc_rollout_fsm.hip)

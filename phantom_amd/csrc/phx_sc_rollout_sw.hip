@@ -36,14 +36,13 @@ struct SwArgs {
   int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
   int32_t dtab_n;                       // 5^K entries of the order-sum table
   int32_t alt_order;                    // every other worker wave draws before it computes outputs
-  int32_t alias_rows;                   // development only
-  int32_t store_inflight, store_sleep;  // store waves: stores in flight per wave (0 = unbounded), s_sleep 1 per store
   uint32_t pK; float inv_pK;            // 5^K and its f32 reciprocal
   uint32_t mG, mG4, mS, mPO, mPF;       // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4), i / (G / 16)   for i < 2^16
   int32_t norm;
   uint64_t seed; int64_t env_offset;
   int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_arrive;
   unsigned long long* timing;           // PHX_TIMING builds only
+  const float4* tables;                 // the host-built image of the table sections (phx_sc_sw_tables)
   phx_rollout_io io;
 };
 
@@ -65,6 +64,9 @@ __host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_
        + items * 16 * 2                                          // staged observation + reward, double-buffered
        + items * 4 * 2;                                          // staged action (drawn one iteration before it is stored), double-buffered
 }
+
+#define SW_TABLE_BYTES (101 * 32 * 4 + 32 * 32 * 4 + 401 * 8 * 4 + 128 + 15632)
+static_assert(SW_TABLE_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
 
 typedef const __attribute__((address_space(4))) char* sw_kptr_t;
 #define a (*(const SwArgs*)kp)
@@ -129,25 +131,24 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const uint32_t el = nS == 1 ? pt : __umulhi(pt, a.mS);               // (r0 + tid) / S
     if (tid < G) { x = a.stock[g_base + tid]; step = a.env_step[b_first + el]; }
     if (tid < n_env) tk = a.env_tick[b_first + tid];
-    if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
-    if (tid < 125) s_ds[tid] = (uint8_t)(tid % 5 + (tid / 5) % 5 + tid / 25);
-    for (int i = tid; i < 101 * 32; i += NT) s_tabs[i] = (float)(i >> 5) / (float)PHX_SHOP_MAX_STOCK;   // f32 IEEE division == the reference's f64 quotient cast to f32 (phx_dev.h: shop_obs_f32)
-    for (int i = tid; i < 32 * 32; i += NT) s_tabn[i] = (float)(i >> 5) / (float)a.norm;
-    for (int i = tid; i < 401 * 8; i += NT) {                            // f64 sales - 0.1 * stock, rounded once to f32 (shop_reward), by n
-      const int n = (i >> 3) - 100, sl = n >= 0 ? (n + 9) / 10 : 0, st = 10 * sl - n;       // a (sales, stock) pair with 10 * sales - stock == n
-      s_rtab[i] = (float)__dsub_rn((double)sl, __dmul_rn(0.1, (double)st));
-    }
-    if (tid < 4) s_flags[tid] = 0;
-    __syncthreads();
-    for (int w = tid; 4 * w < a.dtab_n; w += NT) {                       // order sums: four entries per word
-      uint32_t v = 0;
+    // the tables: a straight copy of the host-built image (L2-resident after the first workgroups), loads issued before anything waits
+    {
+      constexpr int NP = SW_TABLE_BYTES / 16;
+      float4* dstp = (float4*)smem;
+      constexpr int NV = 3;                                             // 1 024 threads: one pass
+      float4 v[NV];
+      for (int base = 0; base < NP; base += NV * NT) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t e = 4u * (uint32_t)w + (uint32_t)q, hi = (uint32_t)((float)e * 0.008f);     // e / 125, exact through f32 (e < 2^14)
-        v |= ((uint32_t)s_ds[hi < 125u ? hi : 0u] + (uint32_t)s_ds[(e - 125u * hi) < 125u ? e - 125u * hi : 0u]) << (8 * q);
+        for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) v[k] = a.tables[i]; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) dstp[i] = v[k]; }
       }
-      ((uint32_t*)s_dtab)[w] = v;
     }
+    if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
+    if (tid < 4) s_flags[tid] = 0;
+    STICK(6);
+    __syncthreads();
+    STICK(7);
     if (tid < n_env) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
     if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
     __syncthreads();
@@ -161,7 +162,6 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   auto start_of = [&](int c) { return c == 0 ? 0 : first_rows + (c - 1) * TC; };
   auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c == 0 ? first_rows : (left < TC ? left : TC); };
   const uint32_t utotal = (uint32_t)total;
-  const uint32_t rowmul = a.alias_rows ? 0u : 1u;            // development: every row written over row 0 (stores that never leave the L2)
 
   // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by the worker waves.
   //      One Philox block serves ticks 4q .. 4q + 3 of a shop: work items are (row quad jr, pair gl).  The action goes
@@ -398,15 +398,15 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     }
   };
   auto store_actions = [&](int c, int t0, int tc) __attribute__((always_inline)) {      // chunk c's actions, staged by the draws one iteration ago
-    stream((char*)(io.action_out + ((int64_t)(a.alias_rows ? 0 : t0) * total + g_base)), s_act0 + (c & 1) * items, tc, (uint32_t)(G >> 2), div_G4, utotal * 4u * rowmul);
+    stream((char*)(io.action_out + ((int64_t)t0 * total + g_base)), s_act0 + (c & 1) * items, tc, (uint32_t)(G >> 2), div_G4, utotal * 4u);
   };
   auto stores = [&](int c, int t0, int tc) __attribute__((always_inline)) {
     const float* const o_obs = s_out0 + (c & 1) * (4 * items);
     const float* const o_rew = o_obs + 3 * items;
-    const int64_t row0 = (int64_t)(a.alias_rows ? 0 : t0) * total + g_base;
+    const int64_t row0 = (int64_t)t0 * total + g_base;
     const uint32_t PO = 3u * (uint32_t)(G >> 2), PR = (uint32_t)(G >> 2), PF = (uint32_t)(G >> 4);
-    stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, div_PO, utotal * 12u * rowmul);
-    stream((char*)(io.reward + row0), o_rew, tc, PR, div_G4, utotal * 4u * rowmul);
+    stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, div_PO, utotal * 12u);
+    stream((char*)(io.reward + row0), o_rew, tc, PR, div_G4, utotal * 4u);
 #ifndef PHX_ABL_NOSTORE
     {                                       // truncations["__all__"] (env.py:312-318) per shop; terminations are all zero (agents.py:292-323)
       const uint8_t* pe = s_ptend0 + (c % 3) * G16p;
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         // bytes equal to rr -> 1 (exact zero-byte test of e ^ rrrr; rows are < 128, 255 = no episode end)
         auto eq = [&](uint32_t w) { const uint32_t z = w ^ rrrr; return (~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu)) >> 7; };
         const uint4 v = make_uint4(eq(e.x), eq(e.y), eq(e.z), eq(e.w));
-        *(uint4*)(p_tru + (size_t)(rr * utotal * rowmul + pc * 16u)) = v;
-        if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal * rowmul + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
+        *(uint4*)(p_tru + (size_t)(rr * utotal + pc * 16u)) = v;
+        if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
 #endif
@@ -485,7 +485,26 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #undef io
 #undef SW_REFRESH
 
-// ---- host: plan, launcher -------------------------------------------------------------------------------------------
+// ---- host: tables, plan, launcher -----------------------------------------------------------------------------------
+// The first 45 616 bytes of a workgroup's LDS: the replicated observation tables, the reward table, the digit sums.  Built ONCE per
+// env on the host with the same f32 / f64 operations (phx_create uploads it) -- computing them in every workgroup cost ~5 k
+// cycles of setup per launch.
+void phx_sc_sw_tables(int K, int norm, std::vector<uint8_t>* out) {
+  out->assign(SW_TABLE_BYTES, 0);
+  float* tabs = (float*)out->data(); float* tabn = tabs + 101 * 32; float* rtab = tabn + 32 * 32;
+  uint8_t* ds = (uint8_t*)(rtab + 401 * 8); uint8_t* dtab = ds + 128;
+  for (int i = 0; i < 101 * 32; ++i) tabs[i] = (float)(i >> 5) / (float)PHX_SHOP_MAX_STOCK;    // IEEE f32 division (shop_obs_f32)
+  for (int i = 0; i < 32 * 32; ++i) tabn[i] = (float)(i >> 5) / (float)norm;
+  for (int i = 0; i < 401 * 8; ++i) {
+    const int n = (i >> 3) - 100, sl = n >= 0 ? (n + 9) / 10 : 0, st = 10 * sl - n;               // a (sales, stock) pair with 10 * sales - stock == n
+    volatile double pen = 0.1 * (double)st;                                                      // product and difference rounded separately (shop_reward)
+    rtab[i] = (float)((double)sl - pen);
+  }
+  for (int k = 0; k < 125; ++k) ds[k] = (uint8_t)(k % 5 + (k / 5) % 5 + k / 25);
+  int n5 = 1; for (int k = 0; k < K; ++k) n5 *= 5;
+  for (int e = 0; e < n5; ++e) { int v = e, sum = 0; while (v) { sum += v % 5; v /= 5; } dtab[e] = (uint8_t)sum; }
+}
+
 static uint32_t sw_magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); }
 static const size_t SW_LDS_MAX = 160 * 1024;
 
@@ -507,6 +526,7 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   };
   auto tc_for = [&](int G) {
     if (tc_env == 16 || tc_env == 20) return tc_ok(G, tc_env) ? tc_env : 0;
+    if ((G == 144 || G == 96 || G == 48) && tc_ok(G, 16)) return 16;              // the shapes with a compile-time instantiation (16-row chunks)
     return tc_ok(G, 20) ? 20 : (tc_ok(G, 16) ? 16 : 0);
   };
   int G = 0;
@@ -535,6 +555,10 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   if (p->n_rec + p->n_store + work > 16) work = 16 - p->n_rec - p->n_store;
   p->nt = 64 * (p->n_rec + p->n_store + work);
   p->lds = (int32_t)sw_lds_bytes(G, p->epb, p->tc, dtab_n);
+  // one round of workgroups only: a workgroup per CU has nothing to hide its setup, pipeline fill and drain behind (~9 us per round)
+  p->specialised = (total / G <= 256 && p->tc == 16 && ((G == 144 && p->n_rec == 3 && work == 9 && (p->n_store == 4 || p->n_store == 2)) ||
+                                    (G == 96 && p->n_rec == 2 && work == 6 && (p->n_store == 4 || p->n_store == 2)) ||
+                                    (G == 48 && p->n_rec == 1 && work == 3 && p->n_store == 2))) ? 1 : 0;
   p->ok = 1;
   return true;
 }
@@ -548,11 +572,6 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.n_rec_waves = p.n_rec; a.n_store_waves = p.n_store; a.dtab_n = p.dtab_n;
   static const int alt_env = getenv("PHX_SW_ALT") ? atoi(getenv("PHX_SW_ALT")) : 1;
   a.alt_order = alt_env;
-  static const int sif_env = getenv("PHX_SW_INFLIGHT") ? atoi(getenv("PHX_SW_INFLIGHT")) : 0;
-  static const int ssl_env = getenv("PHX_SW_SLEEP") ? atoi(getenv("PHX_SW_SLEEP")) : 0;
-  a.store_inflight = sif_env; a.store_sleep = ssl_env;
-  static const int alias_env = getenv("PHX_SW_ALIAS_ROWS") ? atoi(getenv("PHX_SW_ALIAS_ROWS")) : 0;
-  a.alias_rows = alias_env;
   static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
   a.pK = (uint32_t)p.dtab_n; a.inv_pK = inv[p.K];
   a.mG = sw_magic32(p.G); a.mG4 = sw_magic32(p.G / 4); a.mS = sw_magic32(sp.S); a.mPO = sw_magic32(3 * (p.G / 4)); a.mPF = p.G / 16 > 1 ? sw_magic32(p.G / 16) : 0;     // (the magic of 1 does not fit 32 bits: 0 = no division)
@@ -561,6 +580,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
+  a.tables = (const float4*)sp.sc_sw_tables;
   a.io = io;
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
 #ifdef PHX_TIMING
@@ -569,7 +589,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
       const char* role[3] = {"rec  ", "store", "work "}; const int nwv = p.nt / 64;
       for (int r = 0; r < 3; ++r) { double sum[8] = {0}; int n = 0;
         for (unsigned b = 0; b < grid.x; ++b) for (int w = 0; w < nwv; ++w) { const int rr = w < p.n_rec ? 0 : (w < p.n_rec + p.n_store ? 1 : 2); if (rr != r) continue; ++n; for (int q = 0; q < 8; ++q) sum[q] += (double)h[((size_t)b * 16 + w) * 8 + q]; }
-        fprintf(stderr, "SW_TIMING %s waves (%d): setup %.0f | draws %.0f | outputs %.0f | rec %.0f | stores %.0f | barrier %.0f   cycles per wave and launch\n", role[r], n, sum[0]/n, sum[1]/n, sum[2]/n, sum[3]/n, sum[4]/n, sum[5]/n); } } } }
+        fprintf(stderr, "SW_TIMING %s waves (%d): setup %.0f (before 1st barrier %.0f, in it %.0f) | draws %.0f | outputs %.0f | rec %.0f | stores %.0f | barrier %.0f   cycles per wave and launch\n", role[r], n, sum[0]/n, sum[6]/n, sum[7]/n, sum[1]/n, sum[2]/n, sum[3]/n, sum[4]/n, sum[5]/n); } } } }
 #endif
   phx_note_kernel("phx_sc_rollout_sw_kernel");
   // more than 64 KB of dynamic LDS needs the attribute (once per instantiation and device)
@@ -578,10 +598,16 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
     if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
     hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
   static const int generic_env = getenv("PHX_SW_GENERIC") ? atoi(getenv("PHX_SW_GENERIC")) : 0;      // development: the run-time-shape instantiation
-  if (!generic_env && p.tc == 16 && p.G == 144 && p.n_rec == 3 && p.n_store == 4 && p.nt == 1024) SW_LAUNCH(16, 144, 3, 4, 9);
-  else if (!generic_env && p.tc == 16 && p.G == 144 && p.n_rec == 3 && p.n_store == 2 && p.nt == 896) SW_LAUNCH(16, 144, 3, 2, 9);
+  const int work = p.nt / 64 - p.n_rec - p.n_store;
+#define SW_SHAPE(G_, NREC_, NSTORE_, NWORK_) (p.tc == 16 && p.G == G_ && p.n_rec == NREC_ && p.n_store == NSTORE_ && work == NWORK_)
+  if (!generic_env && SW_SHAPE(144, 3, 4, 9)) SW_LAUNCH(16, 144, 3, 4, 9);
+  else if (!generic_env && SW_SHAPE(144, 3, 2, 9)) SW_LAUNCH(16, 144, 3, 2, 9);
+  else if (!generic_env && SW_SHAPE(96, 2, 4, 6)) SW_LAUNCH(16, 96, 2, 4, 6);
+  else if (!generic_env && SW_SHAPE(96, 2, 2, 6)) SW_LAUNCH(16, 96, 2, 2, 6);
+  else if (!generic_env && SW_SHAPE(48, 1, 2, 3)) SW_LAUNCH(16, 48, 1, 2, 3);
   else if (p.tc == 20) SW_LAUNCH(20, 0, 0, 0, 0);
   else SW_LAUNCH(16, 0, 0, 0, 0);
+#undef SW_SHAPE
 #undef SW_LAUNCH
   return hipGetLastError();
 }

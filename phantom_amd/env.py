@@ -421,14 +421,18 @@ class PhantomEnv:
         from .device import DeviceEnv
         from .spec import resolve_variants
         if candidates is None:
-            # whole-env workgroups are NOT a default candidate: where they win it is by <= 5 %, and their partially written
-            # boundary lines make them sensitive to where the trajectory buffers land (up to 1.6x between two allocations
-            # of the same process), which a measurement on the tuning buffers cannot foresee
-            # (the flag planes: a streaming fill + non-zero words only is the same 74-75 us on every box.  The kernel storing every
-            #  word -- {"flags": "dense"} -- is 65-78 us where the partial writes of neighbouring workgroups merge in the L2 and 79-99 us
-            #  where they do not, and WHICH it is depends on the buffers, not only on the box: as a candidate it won the tuning pass
-            #  with 69 us and then ran the timed region at 83.  Not a default candidate, like the whole-env workgroups.)
-            candidates = [{"block": 48}, {"block": 32}]
+            # Round 4: the store-wave kernel (one 144-pair workgroup per CU at SC64 / B = 4096, dense flag planes written by its
+            # store waves: 65 us per T = 400 fragment where the round-3 kernel takes 71-76) against round 3's kernel with its two
+            # workgroup shapes and -- new -- 144-pair workgroups.  Whole-env workgroups and {"flags": "dense"} on the round-3
+            # kernel are NOT default candidates: where they win it is by <= 5 %, and their partially written boundary lines make
+            # them sensitive to where the trajectory buffers land (up to 1.6x between two allocations of the same process).
+            candidates = [{"rollout": "store_waves"}, {"rollout": "time_parallel", "block": 144},
+                          {"rollout": "time_parallel", "block": 48}, {"rollout": "time_parallel", "block": 32}]
+        if self._dev is not None:
+            if getattr(self, "_h_step", None) is not None and np.any(self._h_step):
+                raise RuntimeError("autotune_rollout re-creates the device env: call it before reset() / step(), not on a stepped env")
+            self._dev.close()                                    # (the state blob of the env being replaced)
+            self._dev = None
         base = dict(self._variants)
         results, best, best_t = {}, None, None
         for cand in candidates:
@@ -440,6 +444,12 @@ class PhantomEnv:
             dev = DeviceEnv(self.spec, self._device_name)
             dev.reset()
             one = dev.alloc_trajectory(T)
+            dev.rollout(T, out=one)
+            want = {"store_waves": "phx_sc_rollout_sw_kernel", "time_parallel": "phx_sc_rollout_fast_kernel"}.get(str(v.get("rollout", "")))
+            if want and want not in dev.last_kernel():           # the plan refused the shape: not a candidate on this env
+                results[str(cand)] = None
+                dev.close(); del dev, one
+                continue
             nbytes = sum(x.numel() * x.element_size() for x in one[:5])
             bufs = [one] + [dev.alloc_trajectory(T) for _ in range(max(1, -(-(320 << 20) // max(nbytes, 1)) - 1))]
             for k in range(3):

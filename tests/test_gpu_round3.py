@@ -666,20 +666,32 @@ def test_record_layout_is_refused_where_no_kernel_serves_it():
 
 
 def test_bench_shape_fragment_sparse_flags_equal_dense_and_oracle_rows():
-    """The bench's launch shape (SC64, B = 4096, T = 400: the flag planes go out as one fill + the non-zero words by default) against
-    the same env with the kernel storing every flag word -- every plane bit-equal -- and the first and last episodes' rows against
-    the oracle."""
+    """The bench's launch shape (SC64, B = 4096, T = 400).  Round 3's kernel: the flag planes go out as one fill + the non-zero words by
+    default at this size, against the same kernel storing every flag word; round 4: the library's own choice for this shape is the
+    store-wave kernel (144 pairs per workgroup, one workgroup per CU, dense flags from its store waves) -- every plane of the three
+    bit-equal -- and the first episode's rows against the oracle."""
     import torch
     B, S, T = 4096, 9, 400
-    ea = supply_chain_env(S, [6] * S, 100, B, seed=42)                       # auto: sparse at this size
-    eb = supply_chain_env(S, [6] * S, 100, B, seed=42, variants={"flags": "dense"})
-    for e in (ea, eb):
+    ea = supply_chain_env(S, [6] * S, 100, B, seed=42, variants={"rollout": "time_parallel"})      # round-3 kernel: sparse at this size
+    eb = supply_chain_env(S, [6] * S, 100, B, seed=42, variants={"rollout": "time_parallel", "flags": "dense"})
+    ec = supply_chain_env(S, [6] * S, 100, B, seed=42)                                             # the library's choice
+    for e in (ea, eb, ec):
         e.reset()
     ta = ea._device().rollout(T)
     assert "phx_zero_fill_kernel[flag planes]" in ea._device().last_kernel()      # (the calling thread's LAST call)
     tb = eb._device().rollout(T)
     assert "fill" not in eb._device().last_kernel()
-    for name, x, y in zip(ta._fields[:6], ta[:6], tb[:6]):
+    tc = ec._device().rollout(T)
+    assert ec._device().last_kernel() == "phx_sc_rollout_sw_kernel"
+    for name, x, y, z in zip(ta._fields[:6], ta[:6], tb[:6], tc[:6]):
+        assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8)), name
+        assert torch.equal(x.contiguous().view(torch.uint8), z.contiguous().view(torch.uint8)), name
+    for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
+        assert torch.equal(ea._device().field(f), ec._device().field(f)), f
+    t1 = ec._device().rollout(100)                                     # a short fragment goes back to round 3's kernel, same stream of steps
+    assert "phx_sc_rollout_fast_kernel" in ec._device().last_kernel()
+    t1a = ea._device().rollout(100)
+    for name, x, y in zip(t1._fields[:6], t1[:6], t1a[:6]):
         assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8)), name
     assert int(ta.truncations.sum()) == 4 * B * S and int(ta.terminations.sum()) == 0
     o = OracleEnv(ea.spec, threads=NCPU); o.reset()
@@ -693,7 +705,7 @@ def test_rollout_with_flags_zeroed_by_the_caller_equals_the_in_line_fill():
     and phx_rollout skips its own fill; the fragments equal those of plain rollout calls.  Kernels that store every flag word ignore
     the hint (a buffer full of garbage still comes out right)."""
     import torch
-    for variants, T in (({"flags": "sparse"}, 57), ({"flags": "dense"}, 57), ({}, 300)):
+    for variants, T in (({"flags": "sparse"}, 57), ({"flags": "dense"}, 57), ({"rollout": "time_parallel"}, 300), ({}, 300)):
         ea = supply_chain_env(9, [6] * 9, 100, 64 if T < 100 else 4096, seed=5, variants=variants)
         eb = supply_chain_env(9, [6] * 9, 100, 64 if T < 100 else 4096, seed=5, variants=variants)
         for e in (ea, eb):
