@@ -804,10 +804,14 @@ def bench_rllib_adapter(env, B, S):
 def bench_collection(dist, group, dev, traj, T, B, world, rank, sync_barrier, max_over_ranks, n_agents):
     """rollout collection of one T-step fragment: ONE flat RCCL all-gather (payload without the
     all-zero `terminated` plane, `truncated` bit-packed), and the produce + collect pipeline."""
+    from phantom_amd import distributed as phd
     from phantom_amd.distributed import TrajectoryGather, device_env_collector
+    if world == 1:
+        os.environ["PHX_FORCE_COLLECTIVE"] = "1"           # a world of one rank still runs all_gather_into_tensor on the RCCL group (VERDICT r3 #4a)
     tg = TrajectoryGather(dev, T, group=group)             # one flat buffer; the gathered payload is its prefix
     dev.rollout(T, out=tg.traj)
     tg.gather(); sync_barrier()
+    mode = phd.LAST_MODE["mode"]                           # "copy" / "collective:nccl" / "host-staged:gloo": what the numbers below timed
     reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -819,8 +823,9 @@ def bench_collection(dist, group, dev, traj, T, B, world, rank, sync_barrier, ma
     res = {"ms": ag * 1e3, "bytes_per_rank": tg.nbytes, "raw_trajectory_bytes_per_rank": tg.raw_nbytes,
            "recv_GBps_per_rank": tg.nbytes * (world - 1) / ag / 1e9,
            "per_link_GBps_if_direct": tg.nbytes / ag / 1e9,
-           "payload": tg.describe(),
-           "note": "one T=100 fragment, one all_gather_into_tensor over RCCL; not in `value`"}
+           "payload": tg.describe(), "timed": mode,
+           "note": "one T=100 fragment, one all_gather_into_tensor (see `timed`: collective:nccl = RCCL on the device buffers, also with one "
+                   "rank; copy = a world-1 device copy; host-staged:gloo = through pinned memory); not in `value`"}
     # produce + collect, pipelined: chunk c is gathered on a side stream while chunk c+1 rolls out
     col = device_env_collector(dev, T, group=group)        # chunking by bytes (auto_chunk)
     col.collect(); sync_barrier()
@@ -868,6 +873,8 @@ def bench_config4(ph, dist, group, world, rank, local_rank, sync_barrier, max_ov
     res["rollout_plus_allgather_ms_per_fragment"] = pc * 1e3
     res["agent_steps_per_sec_gather_included"] = A * Bc * world * T / pc
     res["gather_bytes_per_rank"] = col.nbytes * col.n_chunks
+    from phantom_amd import distributed as phd
+    res["timed"] = phd.LAST_MODE["mode"]
     res["pipeline"] = f"{col.n_chunks} chunks of {col.chunk} steps on a side stream, payload: {col.payload}"
     return res
 

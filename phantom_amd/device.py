@@ -500,12 +500,16 @@ class DeviceEnv:
             raise ValueError("pack_done_flags needs a fragment from alloc_trajectory(flat=True)")
         n = traj.truncations.numel()
         words = (n + 63) // 64
-        pf = traj.packed_flags
-        self._check(self.lib.phx_pack_flags(traj.truncations.data_ptr(), pf.data_ptr(), n, self._stream()),
-                    "phx_pack_flags")
+        pf = traj.packed_flags.view(-1)
+        self.pack_flags(traj.truncations, pf)
         if pf.numel() >= 2 * words * 8:
-            self._check(self.lib.phx_pack_flags(traj.terminations.data_ptr(), pf.data_ptr() + words * 8, n,
-                                                self._stream()), "phx_pack_flags")
+            self.pack_flags(traj.terminations, pf[words * 8:])
+
+    def pack_flags(self, plane, dst):
+        """u8 plane [n] (any shape, contiguous) -> ceil(n / 64) little-endian 64-bit words at the start of the u8 tensor ``dst``:
+        word w, bit j = plane.flat[64 w + j] != 0.  One small launch on the current stream."""
+        n = plane.numel()
+        self._check(self.lib.phx_pack_flags(plane.data_ptr(), dst.data_ptr(), n, self._stream()), "phx_pack_flags")
 
     def unpack_flags(self, packed, n: int, out=None):
         """inverse of the packing above: u8 [n] (0 / 1) from ceil(n / 64) little-endian 64-bit words."""

@@ -117,6 +117,29 @@ def test_bench_forced_collective_path_matches_the_plain_run():
     assert b["config4_share"]["agent_steps_per_sec_gather_included"] > 0
 
 
+def test_rccl_collective_runs_with_one_rank_on_the_real_config4_buffers():
+    """VERDICT r3 #4a: `all_gather_into_tensor` on the RCCL ("nccl") group with the real uint8 device buffers of config 4's
+    per-GPU share (919 MB), forced although the world has ONE rank -- raw planes, the packed collection buffer and the
+    chunked side-stream collector; bytes equal."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_world1_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    r = json.loads(lines[-1])
+    assert r["ok"] and r["mode_raw"] == r["mode_gather"] == r["mode_pipeline"] == "collective:nccl", r
+    assert r["raw_bytes"] >= 8192 * 100 * 51 * 22 and r["gather_bytes"] < r["raw_bytes"]
+
+
+def test_bench_eight_ranks_sharing_one_gpu_print_one_line():
+    """VERDICT r3 #4c: `bench.py --gpus 8` with every rank on the one GPU of this box (PHX_BENCH_SHARE_GPU=1) and a small batch:
+    eight ranks spawn, the control plane (gloo) carries barrier and max-over-ranks, `value` is reported, ONE JSON line."""
+    p, r = _bench(["--gpus", "8", "--batch", "256", "--min-region-ms", "200", "--no-other-configs", "--no-cpu-baseline", "--no-per-step",
+                   "--no-frag200", "--steps", "20", "--warmup", "5"], {"PHX_BENCH_SHARE_GPU": "1"}, timeout=900)
+    assert r["n_gpus"] == 8 and r["value"] and r["value"] > 0, r
+    assert r["config"]["global_envs"] == 8 * 256
+    assert sum(1 for l in p.stdout.splitlines() if l.startswith("{")) == 1
+
+
 # ---- every rollout kernel variant against the oracle at small sizes (VERDICT r2 item 5) -----------------------------
 def _cmp_rollout(rd, ro, valid_planes):
     for k in ("obs", "actions", "rewards", "last_obs"):
