@@ -796,8 +796,35 @@ def bench_rllib_adapter(env, B, S):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         res[mode] = {"ms_per_step": dt * 1e3, "agent_steps_per_sec": N_AGENTS * B / dt, "steps": n}
+    # the floor of the rows_read loop itself: the same python (build the B x S action dict, read every obs / reward entry)
+    # against plain precomputed dicts -- no env, no adapter
+    plain_o = [{aid: None for aid in ids} for _ in range(B)]; plain_r = [{aid: 0.0 for aid in ids} for _ in range(B)]
+    t0 = time.perf_counter()
+    for _ in range(3):
+        _d = {b: {aid: 50.0 for aid in ids} for b in range(B)}
+        for b in range(B):
+            row, rw = plain_o[b], plain_r[b]
+            for aid in ids:
+                row[aid], rw.get(aid)
+    dt = (time.perf_counter() - t0) / 3
+    res["python_floor_of_rows_read_loop"] = {"ms_per_step": dt * 1e3, "agent_steps_per_sec": N_AGENTS * B / dt,
+                                             "note": "the measuring loop alone on plain dicts: what no adapter can go below"}
+    # the bulk exit: T = 100 steps per call as fused device rollouts, the fragment as per-policy SampleBatch column dicts
+    env.reset()
+    be.sample(NUM_STEPS)
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        sb = be.sample(NUM_STEPS)
+    dt = (time.perf_counter() - t0) / n
+    rows = sum(len(v["rewards"]) for v in sb.values())
+    res["bulk_sample_batches"] = {"ms_per_call": dt * 1e3, "steps_per_call": NUM_STEPS, "agent_steps_per_sec": N_AGENTS * B * NUM_STEPS / dt,
+                                  "strategic_rows_per_call": rows, "columns": sorted(next(iter(sb.values()))),
+                                  "note": "BatchedBaseEnv.sample(100): one episode per launch, transposed on the device, ONE pinned copy per column, "
+                                          "numpy views per policy (phantom_amd/rollout.py)"}
     res["note"] = ("poll() + send per step at full batch through phantom_amd.rllib.BatchedBaseEnv: tensor = send_action_tensor; "
-                   "multi_env_dict = RLlib's send_actions(MultiEnvDict); rows_read also reads every (env, agent) entry back")
+                   "multi_env_dict = RLlib's send_actions(MultiEnvDict); rows_read also reads every (env, agent) entry back "
+                   "(real dicts, built for all B instances in one vectorised pass on first access)")
     return res
 
 

@@ -299,9 +299,11 @@ class PhantomEnv:
     def _host_reset(self, mask=None):
         sel = slice(None) if mask is None else np.asarray(mask, dtype=bool)
         self._h_step[sel] = 0
+        self._obs_state = ("dev", None)                          # the strategic agents' current observation = the device's obs buffer
 
     def _host_advance(self):
         self._h_step += 1
+        self._obs_state = ("dev", None)
 
     def _step_extras(self) -> Dict[str, Any]:
         """extra per-step inputs of the device step decided on the host (FSM stage handlers)."""
@@ -406,7 +408,79 @@ class PhantomEnv:
             exo = self._device().mt_draw(T)                     # the draws of the T steps from every instance's own stream
         traj = self._device().rollout(T, actions, exo, out)
         self._sync_host_state()
+        self._obs_state = ("traj", traj.last_obs)               # what the strategic agents observe now (sample() starts from it)
         return traj
+
+    def sample(self, T: int, actions=None, exo=None):
+        """T steps of every env instance as fused device rollouts, brought to the host ONCE as a ``FragmentBatch``
+        (phantom_amd.rollout): agent-major arrays [B, S, T, ..] with the observation each policy acted on (``obs``: what
+        ``reset`` or the previous step returned) next to what the step returned (``new_obs``).  The bulk counterpart of the
+        reference's ``_rollout_task_fn`` loop (utils/rllib/rollout.py:300-408) and of an RLlib sampler's batch building.
+
+        The fragment is produced one episode piece per launch (a piece ends where the episode ends: the kernel's auto-reset
+        then leaves the NEXT episode's reset observation in ``last_obs``), transposed on the device and copied through pinned
+        host buffers.  Plain envs (every strategic agent observes every step); ``reset()`` first."""
+        import torch
+        from .rollout import FragmentBatch
+        dev = self._device()
+        if self.spec.env_type != _abi.ENV_PLAIN or dev._needs_valid_planes():
+            raise NotImplementedError("PhantomEnv.sample: plain envs only (FSM / Stackelberg dicts omit keys: use rollout() and "
+                                      "phantom_amd.rollout.fragment_from_arrays with the validity planes)")
+        if not (self._h_step == self._h_step[0]).all():
+            raise ValueError("sample() needs every env instance at the same step (after masked resets use rollout())")
+        cur = int(self._h_step[0])
+        cur_obs = self._cur_obs_tensor()
+        B, S, D, N = self.batch_size, self.spec.n_strategic, dev.D, self.num_steps
+        ep0 = getattr(self, "_episodes_done", 0)
+        new_obs = torch.empty((T, B, S, D), dtype=torch.float32, device=dev.device)
+        obs = torch.empty_like(new_obs)
+        act = torch.empty((T, B, S), dtype=torch.float32, device=dev.device)
+        rew = torch.empty_like(act)
+        term = torch.empty((T, B, S), dtype=torch.uint8, device=dev.device)
+        trunc = torch.empty_like(term)
+        t_in_ep = np.empty(T, dtype=np.int32); eps = np.empty(T, dtype=np.int64)
+        done, ep = 0, ep0
+        while done < T:
+            n = min(T - done, N - cur)
+            tr = self.rollout(n, None if actions is None else actions[done:done + n], None if exo is None else exo[done:done + n])
+            sl = slice(done, done + n)
+            new_obs[sl], act[sl], rew[sl], term[sl], trunc[sl] = tr.observations, tr.actions, tr.rewards, tr.terminations, tr.truncations
+            obs[done] = cur_obs
+            obs[done + 1:done + n] = tr.observations[:n - 1]
+            t_in_ep[sl] = np.arange(cur, cur + n); eps[sl] = ep
+            cur_obs = tr.last_obs
+            cur += n
+            if cur == N:
+                cur, ep = 0, ep + 1
+            done += n
+        self._episodes_done = ep
+        am = lambda x: x.permute(1, 2, 0, *range(3, x.dim())).contiguous()       # [T, B, S, ..] -> [B, S, T, ..] on the device
+        host = self._to_pinned({"obs": am(obs), "new_obs": am(new_obs), "actions": am(act), "rewards": am(rew),
+                                "terminateds": am(term), "truncateds": am(trunc)})
+        ids = [self.spec.agent_ids[a] for a in self.spec.strategic_idx]
+        return FragmentBatch(ids, host["obs"], host["new_obs"], host["actions"], host["rewards"], host["terminateds"].astype(bool),
+                             host["truncateds"].astype(bool), np.broadcast_to(t_in_ep, (B, T)).copy(),
+                             (eps[None, :] * B + np.arange(B)[:, None]).astype(np.int64),
+                             never_finishes_alone=dev.never_terminates())
+
+    def _cur_obs_tensor(self):
+        """the observation the strategic agents hold right now (what reset / the last step / the last rollout returned), on the device"""
+        kind, t = getattr(self, "_obs_state", ("dev", None))
+        return self._device().obs if kind == "dev" else t
+
+    def _to_pinned(self, tensors):
+        """device tensors -> numpy arrays through pinned host buffers (kept per name and shape), one synchronisation"""
+        import torch
+        pins = self.__dict__.setdefault("_pins", {})
+        out = {}
+        for k, x in tensors.items():
+            p = pins.get(k)
+            if p is None or p.shape != x.shape or p.dtype != x.dtype:
+                p = pins[k] = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+            p.copy_(x, non_blocking=True)
+            out[k] = p
+        torch.cuda.current_stream(self._device().device).synchronize()
+        return {k: v.numpy() for k, v in out.items()}
 
     def autotune_rollout(self, T: int, candidates=None, launches: int = 12):
         """Pick the fastest kernel variant for ``rollout(T)`` ON THIS GPU and rebuild the device env with it.

@@ -62,6 +62,10 @@ class RLlibEnvWrapper(_MultiAgentEnvBase):
                     remote_env_batch_wait_ms: int = 0, restart_failed_sub_environments: bool = False):
         """what RLlib's env runners call to vectorise an env (convert_to_base_env): instead of RLlib's python list of
         sub-envs, the wrapped env's own batch IS the vector env (``batch_size`` instances, one launch per step)."""
+        if num_envs not in (1, self.env.batch_size):
+            import warnings
+            warnings.warn(f"to_base_env(num_envs={num_envs}): the device env's batch_size ({self.env.batch_size}) is the number of "
+                          "env instances; RLlib's num_envs_per_worker is not used", RuntimeWarning, stacklevel=2)
         return BatchedBaseEnv(self.env)
 
     def is_terminated(self):
@@ -207,16 +211,22 @@ class SubEnvView:
 
 
 class _Rows(Mapping):
-    """MultiEnvDict {env_id: row} over batched arrays: ONE object per poll() result; the per-env row views are built when
-    an env id is read (5 dicts of B entries + 5 B row objects per step were ~20 k python objects at B = 4096)."""
+    """MultiEnvDict {env_id: row} over batched arrays: ONE object per poll() result.  A consumer that reads rows (an RLlib
+    sampler reads every one) gets REAL dicts, all B of them built in one vectorised pass on the first access (``make_all``:
+    C-level ``tolist`` / ``zip`` / ``dict`` -- ~1 us per env instead of a python object and an ``index`` call per entry);
+    envs whose dicts omit keys (FSM / Stackelberg validity masks) fall back to per-row views (``make_row``)."""
 
-    def __init__(self, n: int, make_row):
-        self._n, self._make = n, make_row
+    def __init__(self, n: int, make_row, make_all=None):
+        self._n, self._make, self._make_all, self._all = n, make_row, make_all, None
 
     def __getitem__(self, b):
         b = int(b)
         if not 0 <= b < self._n:
             raise KeyError(b)
+        if self._make_all is not None:
+            if self._all is None:
+                self._all = self._make_all()
+            return self._all[b]
         return self._make(b)
 
     def __iter__(self):
@@ -224,6 +234,32 @@ class _Rows(Mapping):
 
     def __len__(self):
         return self._n
+
+    def values(self):                                        # (one pass over the materialised rows, no per-key lookups)
+        if self._make_all is not None:
+            if self._all is None:
+                self._all = self._make_all()
+            return self._all
+        return [self._make(b) for b in range(self._n)]
+
+    def items(self):
+        return zip(range(self._n), self.values())
+
+
+def _rows_of_arrays(ids, arr):
+    """[{agent_id: arr[b, s]} for b]: one numpy row view per (env, agent), made by iterating the flattened array in C."""
+    S = len(ids)
+    flat = list(arr.reshape((-1,) + arr.shape[2:]))
+    return [dict(zip(ids, flat[k:k + S])) for k in range(0, len(flat), S)]
+
+
+def _rows_of_scalars(ids, arr, extra_key=None, extra=None):
+    """[{agent_id: python scalar} for b] (+ {extra_key: extra[b]}): ``tolist`` converts the whole array at once."""
+    rows = [dict(zip(ids, r)) for r in arr.tolist()]
+    if extra_key is not None:
+        for d, v in zip(rows, extra.tolist()):
+            d[extra_key] = v
+    return rows
 
 
 class BatchedBaseEnv(_BaseEnvBase):
@@ -301,6 +337,13 @@ class BatchedBaseEnv(_BaseEnvBase):
         dev = getattr(self.env, "_dev", None)
         if dev is not None:
             dev.close()
+            self.env._dev = None                                   # a later call (try_restart / try_reset after stop) rebuilds the device env
+
+    def sample(self, T: int, actions=None, exo=None, policy_mapping_fn=None):
+        """The bulk exit: T steps of every env instance in fused device rollouts and the fragment as per-policy ``SampleBatch``
+        column dicts (phantom_amd.rollout.FragmentBatch.to_sample_batches) -- no python object per (env, agent, step).
+        ``actions`` f32 [T, B, S] replays a policy's actions (None: the device's random policy)."""
+        return self.env.sample(T, actions, exo).to_sample_batches(policy_mapping_fn)
 
     def try_restart(self, env_id: Optional[int] = None) -> None:
         """RLlib calls this after a sub-env fault; the device env has no per-instance process to restart: reset it."""
@@ -320,6 +363,8 @@ class BatchedBaseEnv(_BaseEnvBase):
         ids = self._ids
         if env_id is None:
             B = self.env.batch_size
+            if bool(v.all()):
+                return _Rows(B, None, lambda: _rows_of_arrays(ids, o)), _Rows(B, lambda b: {})
             return _Rows(B, lambda b: _EnvRow(ids, o, v, b)), _Rows(B, lambda b: {})
         return {env_id: _EnvRow(ids, o, v, env_id)}, {env_id: {}}
 
@@ -331,14 +376,36 @@ class BatchedBaseEnv(_BaseEnvBase):
                             "for a [B, S] action tensor use send_action_tensor()")
         import torch
         B, S = self.env.batch_size, len(self._ids)
-        act = np.zeros((B, S), dtype=np.float32)
-        valid = np.zeros((B, S), dtype=np.uint8)
-        col = self._col
-        for b, row in action_dict.items():
-            for aid, a in row.items():
-                s = col[aid]
-                act[b, s] = a if np.isscalar(a) else np.asarray(a, dtype=np.float32).reshape(-1)[0]
-                valid[b, s] = 1
+        ids = self._ids
+        act = valid = None
+        if len(action_dict) == B:
+            # the common case -- every env instance, in env order, scalar (or 1-element) actions: ONE flat comprehension, missing
+            # agents marked by NaN (an action itself is never NaN: the spaces are bounded Boxes)
+            try:
+                nan = float("nan")
+                flat = np.array([row.get(aid, nan) for b in range(B) for row in (action_dict[b],) for aid in ids], dtype=np.float32)
+                act = flat.reshape(B, S)
+                valid = (~np.isnan(act)).astype(np.uint8)
+                act = np.nan_to_num(act, copy=False)
+            except (KeyError, TypeError, ValueError):
+                act = valid = None
+        if act is None:
+            act = np.zeros((B, S), dtype=np.float32)
+            valid = np.zeros((B, S), dtype=np.uint8)
+            col = self._col
+            for b, row in action_dict.items():
+                for aid, a in row.items():
+                    s = col[aid]
+                    act[b, s] = a if np.isscalar(a) else np.asarray(a, dtype=np.float32).reshape(-1)[0]
+                    valid[b, s] = 1
+        missing = B - len(action_dict)
+        if missing and not getattr(self, "_warned_partial", False):
+            # RLlib's BaseEnv steps only the env ids it was given; the device env steps its whole batch in lock-step (one launch):
+            # instances missing from ``action_dict`` advance one step with no agent acting
+            import warnings
+            warnings.warn(f"BatchedBaseEnv.send_actions: {missing} of {B} env instances have no entry in action_dict; the batched "
+                          "device env steps ALL instances in lock-step (those advance with no agent acting)", RuntimeWarning, stacklevel=2)
+            self._warned_partial = True
         dev = self.env._device()
         self._pending = self.env.step_tensors(torch.from_numpy(act).to(dev.device),
                                               torch.from_numpy(valid).to(dev.device))
@@ -368,6 +435,15 @@ class BatchedBaseEnv(_BaseEnvBase):
         term, trunc = h["terminated"].astype(bool), h["truncated"].astype(bool)
         dv = h["done_valid"]
         at, au = h["all_terminated"].astype(bool), h["all_truncated"].astype(bool)
+        full = bool(ov.all()) and bool(rv.all()) and bool(dv.all())       # plain envs: every strategic agent in every dict
+        if full:
+            self._last = (_Rows(B, None, lambda: _rows_of_arrays(ids, obs)),
+                          _Rows(B, None, lambda: _rows_of_scalars(ids, rew)),
+                          _Rows(B, None, lambda: _rows_of_scalars(ids, term, "__all__", at)),
+                          _Rows(B, None, lambda: _rows_of_scalars(ids, trunc, "__all__", au)),
+                          _Rows(B, None, lambda: [{aid: {} for aid in ids} for _ in range(B)]),     # infos[aid] = {} (agents.py:301-306)
+                          _Rows(B, lambda b: {}))
+            return self._last
         self._last = (_Rows(B, lambda b: _EnvRow(ids, obs, ov, b)),
                 _Rows(B, lambda b: _EnvRow(ids, rew, rv, b, scalar=True)),
                 _Rows(B, lambda b: _EnvRow(ids, term, dv, b, {"__all__": bool(at[b])}, scalar=True)),
