@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 7
+#define PHX_ABI_VERSION 8
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -365,6 +365,16 @@ int  phx_reset(phx_env* env, const uint8_t* reset_mask, const double* sampler_va
 
 /* one PhantomEnv.step for all B envs */
 int  phx_step(phx_env* env, const phx_step_io* io, void* stream);
+/* ABI 8: the two halves of a FiniteStateMachineEnv.step around a host-side stage handler that branches on agent state
+ * (fsm.py:275-307: the handler runs AFTER _handle_acting_agents, calls self.resolve_network(), then returns the next stage):
+ *   phx_step_begin -- the acting phase and resolve_network() (phx_step_io inputs; msg_log / msg_count / err outputs); the step
+ *                     counter, the tick and the stage are NOT advanced, no observation is written;
+ *   [the caller's handler reads the resolved state: phx_field_info views or phx_get_state]
+ *   phx_step_end   -- io->next_stage [B] (NULL: next_stages[0] / the tabulated handler) -> the transition, observations,
+ *                     rewards, done flags (every output of phx_step_io).
+ * begin followed by end equals ONE phx_step with the same next_stage.  Served by the message-passing engine. */
+int  phx_step_begin(phx_env* env, const phx_step_io* io, void* stream);
+int  phx_step_end(phx_env* env, const phx_step_io* io, void* stream);
 
 /* Network.send from outside a step (network.py:233-254; tests/network/ tests): queue n host
  * messages, the same for every env, delivered by the next phx_resolve / phx_step.          */

@@ -92,6 +92,18 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   phxo_step(e->o, io);
   return PHX_OK;
 }
+int phx_step_begin(phx_env* e, const phx_step_io* io, void* stream) {
+  (void)stream;
+  if (!e || !io) return PHX_EINVAL;
+  phxo_step_begin(e->o, io);
+  return PHX_OK;
+}
+int phx_step_end(phx_env* e, const phx_step_io* io, void* stream) {
+  (void)stream;
+  if (!e || !io) return PHX_EINVAL;
+  phxo_step_end(e->o, io);
+  return PHX_OK;
+}
 int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) { if (!e) return PHX_EINVAL; phxo_inject(e->o, msgs, n); return PHX_OK; }
 int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count, void* stream) {
   (void)stream;

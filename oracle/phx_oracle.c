@@ -82,6 +82,8 @@ typedef struct {
   const uint16_t* shuffle_b; /* this step's replayed shuffle permutations (NULL -> device RNG) */
   int shuf_pos;             /* queued messages of the step's earlier batches */
   int next_in;              /* stage chosen by the stage handler for the coming step (-1: none, -2: out of range) */
+  int phase;                /* 0: a whole step; 1: phxo_step_begin (acting + resolve_network, fsm.py:275-280 + the handler's
+                             * resolve); 2: phxo_step_end (the handler's stage -> transition, observations, rewards, :304-380) */
 } oenv;
 
 struct phxo_env {
@@ -845,6 +847,7 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
                          uint8_t* all_term, uint8_t* all_trunc) {
   const int A = E->A, S = E->S, D = E->D;
   int next_in = e->next_in; e->next_in = -1;                    /* a stage handler's return value, this step only */
+  const int phase = e->phase; e->phase = 0;
   e->step += 1;                                                       /* env.py:252 */
   e->exo_b = exo_b;
 
@@ -875,6 +878,7 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
   /* injected Network.send calls made before the step are already in the inbox */
   /* _handle_acting_agents env.py:320-336 */
   int n_iter = (E->s.env_type == PHX_ENV_PLAIN) ? A : n_act;
+  if (phase == 2) n_iter = 0;                                         /* phxo_step_end: acting and resolution happened in phxo_step_begin */
   for (int k = 0; k < n_iter; ++k) {
     int a = (E->s.env_type == PHX_ENV_PLAIN) ? k : act_list[k];
     if (!live[a]) continue;                                           /* :324-325 */
@@ -884,9 +888,12 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
   }
 
   /* resolve_network env.py:180-183 */
-  for (int a = 0; a < A; ++a) if (live[a]) agent_pre_resolution(E, e, a);     /* :170-173 */
-  batch_resolve(E, e, live);                                                   /* network.py:256-265 */
+  if (phase != 2) {
+    for (int a = 0; a < A; ++a) if (live[a]) agent_pre_resolution(E, e, a);   /* :170-173 */
+    batch_resolve(E, e, live);                                                 /* network.py:256-265 */
+  }
   /* post_message_resolution: no kind overrides it (agents.py:93-94) */
+  if (phase == 1) { e->step -= 1; return; }                           /* the host's stage handler runs now, on the resolved state (fsm.py:294-302) */
 
   if (E->s.env_type == PHX_ENV_FSM) {
     next_stage = E->s.stage_next[cur_stage];                          /* no handler: next_stages[0]  fsm.py:281-292 */
@@ -1138,18 +1145,26 @@ void phxo_inject(phxo_env* E, const phx_msg_rec* msgs, int n) {
   }
 }
 
-void phxo_step(phxo_env* E, const phx_step_io* io) {
+static void phxo_step_phase(phxo_env* E, const phx_step_io* io, int phase);
+void phxo_step(phxo_env* E, const phx_step_io* io) { phxo_step_phase(E, io, 0); }
+/* the two halves of a step around a host-side stage handler that reads agent state (fsm.py:275-307): begin = the acting phase and
+ * resolve_network(); end = the transition to io->next_stage and everything after it.  begin + end == phxo_step.             */
+void phxo_step_begin(phxo_env* E, const phx_step_io* io) { phxo_step_phase(E, io, 1); }
+void phxo_step_end(phxo_env* E, const phx_step_io* io) { phxo_step_phase(E, io, 2); }
+
+static void phxo_step_phase(phxo_env* E, const phx_step_io* io, int phase) {
   const int S = E->S, D = E->D;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int b = 0; b < E->B; ++b) {
     oenv* e = &E->env[b];
-    e->log = io->msg_log ? io->msg_log + (size_t)b * E->s.trace_cap : NULL;
+    e->log = (io->msg_log && phase != 2) ? io->msg_log + (size_t)b * E->s.trace_cap : NULL;
     e->log_cap = E->s.trace_cap;
     e->err = io->err ? io->err[b] : 0;
     e->log_n = 0; e->round = 0;
     e->shuffle_b = io->shuffle ? io->shuffle + (size_t)b * 8 * E->s.queue_cap : NULL;
-    e->next_in = io->next_stage ? (io->next_stage[b] >= 0 ? io->next_stage[b] : -2) : -1;
-    apply_injected(E, e);
+    e->next_in = (io->next_stage && phase != 1) ? (io->next_stage[b] >= 0 ? io->next_stage[b] : -2) : -1;
+    e->phase = phase;
+    if (phase != 2) apply_injected(E, e);
     uint8_t at = 0, au = 0;
     env_step_one(E, e, b, io->actions ? io->actions + (size_t)b * S : NULL,
                  io->action_valid ? io->action_valid + (size_t)b * S : NULL,
@@ -1158,11 +1173,11 @@ void phxo_step(phxo_env* E, const phx_step_io* io) {
                  io->reward + (size_t)b * S, io->reward_valid + (size_t)b * S,
                  io->terminated + (size_t)b * S, io->truncated + (size_t)b * S,
                  io->done_valid + (size_t)b * S, &at, &au);
-    io->all_terminated[b] = at; io->all_truncated[b] = au;
+    if (phase != 1) { io->all_terminated[b] = at; io->all_truncated[b] = au; }
     if (io->err) io->err[b] = e->err;
-    if (io->msg_count) io->msg_count[b] = e->log_n;
+    if (io->msg_count && phase != 2) io->msg_count[b] = e->log_n;
   }
-  E->n_injected = 0;
+  if (phase != 2) E->n_injected = 0;
 }
 
 void phxo_resolve(phxo_env* E, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count) {

@@ -38,6 +38,8 @@ int  phxo_n_exo(const phxo_env* e);
 void phxo_reset(phxo_env* e, const uint8_t* reset_mask, const double* sampler_values,
                 const uint8_t* conn_on, float* obs, uint8_t* obs_valid);
 void phxo_step(phxo_env* e, const phx_step_io* io);
+void phxo_step_begin(phxo_env* e, const phx_step_io* io);   /* acting phase + resolve_network (fsm.py:275-280) */
+void phxo_step_end(phxo_env* e, const phx_step_io* io);     /* io->next_stage -> transition, observations, rewards, done flags (fsm.py:304-380) */
 void phxo_inject(phxo_env* e, const phx_msg_rec* msgs, int n);
 void phxo_resolve(phxo_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_count);
 void phxo_rollout(phxo_env* e, const phx_rollout_io* io);

@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -105,7 +105,7 @@ LIB_PATH = os.environ.get("PHX_LIB_PATH") or os.path.join(LIB_DIR, "libphantom_a
 
 EXPORTS = ("phx_abi_version", "phx_last_error", "phx_last_kernel", "phx_state_nbytes", "phx_obs_dim",
            "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",
-           "phx_field_info", "phx_uses_fused", "phx_sync_fields", "phx_reset", "phx_step", "phx_inject",
+           "phx_field_info", "phx_uses_fused", "phx_sync_fields", "phx_reset", "phx_step", "phx_step_begin", "phx_step_end", "phx_inject",
            "phx_resolve", "phx_rollout", "phx_get_state", "phx_set_state", "phx_trace",
            "phx_pack_flags", "phx_unpack_flags", "phx_mt_seed", "phx_mt_draw")
 
@@ -158,8 +158,9 @@ def bind_signatures(lib):
     lib.phx_sync_fields.argtypes = [vp, vp]
     lib.phx_reset.restype = i32
     lib.phx_reset.argtypes = [vp, vp, vp, vp, vp, vp, vp]
-    lib.phx_step.restype = i32
-    lib.phx_step.argtypes = [vp, C.POINTER(PhxStepIO), vp]
+    for n in ("phx_step", "phx_step_begin", "phx_step_end"):
+        getattr(lib, n).restype = i32
+        getattr(lib, n).argtypes = [vp, C.POINTER(PhxStepIO), vp]
     lib.phx_inject.restype = i32
     lib.phx_inject.argtypes = [vp, C.POINTER(PhxMsgRec), i32]
     lib.phx_resolve.restype = i32

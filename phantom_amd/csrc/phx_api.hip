@@ -975,6 +975,36 @@ int phx_step(phx_env* e, const phx_step_io* io, void* stream) {
   return PHX_OK;
 }
 
+// The two halves of a step around a HOST-side stage handler that reads agent state (fsm.py:275-307): phx_step_begin runs the acting
+// phase and resolve_network() (message log included) and leaves the env's clock words alone; the caller's handler then looks at
+// the resolved state and picks the next stage; phx_step_end(io->next_stage) makes the transition and computes observations, rewards
+// and done flags.  begin + end == phx_step(io->next_stage).  Always the generic engine (the fused kernels do not split).
+static int step_half(phx_env* e, const phx_step_io* io, void* stream, int phase) {
+  note_reset();
+  if (!e) return fail(PHX_EINVAL, "null env");
+  HIPCHK(use_device(e));
+  int rc = check_step_io(e, io);
+  if (rc != PHX_OK) return rc;
+  if (phase == 2 && e->n_inject) return fail(PHX_EINVAL, "phx_step_end with injected messages pending (they belong to phx_step_begin)");
+  hipStream_t st = (hipStream_t)stream;
+  if (e->prices_compressed) {
+    HIPCHK(phx_launch_stk_materialise(e->d, st));
+    e->prices_compressed = false; e->use_stk = false;
+  }
+  GenArgs g; memset(&g, 0, sizeof g); g.io = *io; g.inject = e->inject_dev; g.n_inject = phase == 1 ? e->n_inject : 0;
+  g.resolve_only = 0; g.phase = phase; g.timing = nullptr; g.roll_t = -1;
+  if (phase == 1) {
+    rc = upload_inject(e, st);
+    if (rc != PHX_OK) return rc;
+    if (e->n_inject) HIPCHK(hipStreamSynchronize(st));
+    e->n_inject = 0;
+  }
+  HIPCHK(phx_launch_generic(e->d, g, e->lds_ok, st));
+  return PHX_OK;
+}
+int phx_step_begin(phx_env* e, const phx_step_io* io, void* stream) { return step_half(e, io, stream, 1); }
+int phx_step_end(phx_env* e, const phx_step_io* io, void* stream) { return step_half(e, io, stream, 2); }
+
 int phx_inject(phx_env* e, const phx_msg_rec* msgs, int n) {
   if (!e || (n > 0 && !msgs)) return fail(PHX_EINVAL, "null argument");
   if (e->n_inject + n > PHX_MAX_INJECT) return fail(PHX_ECAPACITY, "at most %d injected messages per resolve", PHX_MAX_INJECT);

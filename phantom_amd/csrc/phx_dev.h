@@ -170,6 +170,8 @@ struct GenArgs {               // arguments of the generic engine kernel
   const DevMsg* inject;         // device copy of host-injected messages (same for every env)
   int32_t n_inject;
   int32_t resolve_only;         // Network.resolve() alone: no clock tick, no acting, no epilogue
+  int32_t phase;                // 0: a whole step; 1: phx_step_begin (acting + resolve_network, no epilogue: a host-side stage handler
+                                // reads the resolved agent state next, fsm.py:294-302); 2: phx_step_end (transition + epilogue only)
   unsigned long long* timing;   // PHX_TIMING builds only
   int32_t tab_off;              // byte offset of the LDS-staged topology tables (generic engine)
   int32_t xcd_remap;            // XCD-aware workgroup -> env mapping (xcd_block)

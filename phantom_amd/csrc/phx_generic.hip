@@ -743,7 +743,7 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   // the list's precomputed round schedule (DevSpec::sched), valid for this step only if every agent has a context and every
   // acting supply-chain agent sends its message (s_dyn records a violation); injected sends and bare resolves are dynamic
   const int32_t* sch = nullptr;
-  if (sp.sched && full && g.n_inject == 0) { const int so = sp.sched_off[list]; if (so >= 0) sch = sp.sched + so; }
+  if (sp.sched && full && g.n_inject == 0 && g.phase == 0) { const int so = sp.sched_off[list]; if (so >= 0) sch = sp.sched + so; }
   __syncthreads();
   // _make_ctxs (env.py:338-348): contexts only for agents that are not done
   for (int a = tid; a < A; a += NT) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   GTICK(0);
 
   // ---- round-0 queue: host-injected sends, then the acting agents in list order -------------
-  const int n_act = full ? sp.act_ptr[list + 1] - sp.act_ptr[list] : 0;
+  const int n_act = (full && g.phase != 2) ? sp.act_ptr[list + 1] - sp.act_ptr[list] : 0;      // (phx_step_end: acting and resolution were phx_step_begin's)
   const int32_t* act_list = sp.act_idx + sp.act_ptr[list];
   const int n_items = g.n_inject + n_act;
   const float* actions_b = g.io.actions ? g.io.actions + (int64_t)b * S : nullptr;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   }   // dynamic acting phase
 
   // pre_message_resolution for every live agent (env.py:170-173)
-  if (full)
+  if (full && g.phase != 2)
     for (int a = tid; a < A; a += NT) if (live[a]) pre_resolution(sp, tp, b, a, t);
 
   phx_msg_rec* log_b = g.io.msg_log ? g.io.msg_log + step_env * sp.trace_cap : nullptr;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   if (n > 0 && tid == 0) set_errkey(&s_errkey, seq_base + 1, PHX_ERR_ROUND_LIMIT);   // resolvers.py:160-163
   // a stage handler's return value (fsm.py:294-307), decided by the host: must be one of the stage's next_stages
   int next_in = -1;
-  if (full && sp.env_type == PHX_ENV_FSM && (g.io.next_stage || sp.stage_tab)) {
+  if (full && g.phase != 1 && sp.env_type == PHX_ENV_FSM && (g.io.next_stage || sp.stage_tab)) {
     // the host's handler call for this step, or the tabulated handler's value at (stage, clock) -- validated at phx_create
     next_in = g.io.next_stage ? g.io.next_stage[b] : sp.stage_tab[(int64_t)cur_stage * (sp.num_steps + 1) + (t <= sp.num_steps ? t : sp.num_steps)];
     if (next_in < 0 || next_in >= sp.n_lists || !sp.stage_allowed[(int64_t)cur_stage * sp.n_lists + next_in]) {
@@ -1090,10 +1090,10 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
 
   if (tid == 0) {
     fld<int32_t>(sp, F_ENV_CLOCK)[b] = clock;
-    if (g.io.msg_count) g.io.msg_count[step_env] = log_n;
+    if (g.io.msg_count && g.phase != 2) g.io.msg_count[step_env] = log_n;
     if (g.io.err && s_errkey != ERRKEY_NONE && g.io.err[b] == 0) g.io.err[b] = s_errkey & 15;       // (the sticky word is read only when there is something to report)
   }
-  if (g.resolve_only) return;
+  if (g.resolve_only || g.phase == 1) return;      // (phx_step_begin stops here: the env's step counter and tick stay, the epilogue is phx_step_end's)
 
   GTICK(13);
   int all_flags = 0;

@@ -257,7 +257,29 @@ class DeviceEnv:
             self._fill_step_io(io)
         return self._step_io
 
-    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None) -> StepTensors:
+    def step_begin(self, actions, action_valid=None, exo=None, shuffle=None):
+        """phx_step_begin: the acting phase and resolve_network() of a step (fsm.py:275-280); agent state is the resolved one
+        afterwards, the env's clock words and the step outputs are untouched.  Followed by ``step_end``."""
+        return self.step(actions, action_valid, exo, shuffle, None, _entry="phx_step_begin")
+
+    def step_end(self, next_stage=None) -> StepTensors:
+        """phx_step_end: the transition to ``next_stage`` (int32 [B]; None: next_stages[0] / the tabulated handler) and the
+        step's observations, rewards and done flags (fsm.py:304-380)."""
+        torch = _torch()
+        io = self._step_io if self._step_io is not None else self._ensure_step_io()
+        if next_stage is not None:
+            if next_stage.dtype != torch.int32 or tuple(next_stage.shape) != (self.B,) or not next_stage.is_contiguous() \
+                    or next_stage.device != self.device:
+                raise ValueError(f"next_stage must be a contiguous int32 tensor [{self.B}] on {self.device}")
+            io.next_stage = next_stage.data_ptr()
+        else:
+            io.next_stage = None
+        rc = self.lib.phx_step_end(self.handle, self._step_io_ref, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            self._check(rc, "phx_step_end")
+        return self._step_out
+
+    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None, _entry="phx_step") -> StepTensors:
         torch = _torch()
         io = self._step_io
         if io is None:
@@ -290,10 +312,10 @@ class DeviceEnv:
             io.next_stage = next_stage.data_ptr()
         else:
             io.next_stage = None
-        rc = self.lib.phx_step(self.handle, self._step_io_ref,
-                               torch.cuda.current_stream(self.device).cuda_stream)
+        rc = getattr(self.lib, _entry)(self.handle, self._step_io_ref,
+                                       torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
-            self._check(rc, "phx_step")
+            self._check(rc, _entry)
         return self._step_out
 
     def pull_step(self) -> Dict[str, "object"]:

@@ -305,6 +305,10 @@ class PhantomEnv:
         self._h_step += 1
         self._obs_state = ("dev", None)
 
+    def _launch_step(self, dev, actions, action_valid, exo):
+        """one device step; FiniteStateMachineEnv splits it around host-side stage handlers (phx_step_begin / phx_step_end)"""
+        return dev.step(actions, action_valid, exo, **self._step_extras())
+
     def _step_extras(self) -> Dict[str, Any]:
         """extra per-step inputs of the device step decided on the host (FSM stage handlers)."""
         return {}
@@ -372,7 +376,7 @@ class PhantomEnv:
         dev = self._device()
         act, valid = self._actions_tensor(actions)
         exo = self._draw_exo()
-        dev.step(act, valid, exo, **self._step_extras())
+        self._launch_step(dev, act, valid, exo)
         self._host_advance()
         h = dev.pull_step()                                # one device-to-host copy for all outputs
         dev.raise_errors(self.network, err=h["err"])
@@ -387,7 +391,7 @@ class PhantomEnv:
         dev = self._device()
         if exo is None:
             exo = self._draw_exo()
-        out = dev.step(actions, action_valid, exo, **self._step_extras())
+        out = self._launch_step(dev, actions, action_valid, exo)
         self._host_advance()
         if check_errors:
             dev.raise_errors(self.network)

@@ -4,10 +4,12 @@ Stage masking -- which agents act, which observe (the next stage's acting agents
 are rewarded -- is compiled into per-stage tables and applied inside the step kernel with the
 reward cache / emit-on-observe semantics of fsm.py:309-380.  Handler-less stages (exactly one next
 stage, fsm.py:281-292) run entirely on the device.  Stage *handlers* (fsm.py:294-307) are Python
-callbacks: they are called on the host before the launch and the stage they return travels to the
-device as a per-env input column (phx_step_io.next_stage) -- exact for handlers that decide from the
-clock / the current stage (what the reference's own tests pin); a handler that inspects agent state
-sees the state BEFORE the step's acting phase, not after it.
+callbacks.  Declared state-independent they are tabulated per (stage, clock) and never run at step time.
+Otherwise the device step is split where the reference calls them (fsm.py:275-307): ``phx_step_begin``
+runs the acting phase and ``resolve_network()``, the handler is called on the host -- once per stage for
+the whole batch, agent attributes are [B] views of the RESOLVED state -- and the stages it returns travel
+to ``phx_step_end`` (phx_step_io.next_stage), which makes the transition and computes observations,
+rewards and done flags.
 """
 from typing import Any, Callable, Dict, Optional, Sequence, Tuple
 
@@ -74,9 +76,8 @@ class FiniteStateMachineEnv(PhantomEnv):
                  env_supertype=None, agent_supertypes=None,
                  stages: Optional[Sequence[FSMStage]] = None, allow_host_handlers: bool = False,
                  **device_kwargs) -> None:
-        """``allow_host_handlers``: silence the warning about stage handlers that are NOT declared state-independent
-        (they run on the host BEFORE the device step and therefore see the agents' state before the step's acting and
-        resolution phase, fsm.py:275-302 runs them after it)."""
+        """``allow_host_handlers``: accepted for round-3 callers (it silenced a warning about host-side handlers seeing the state
+        before the step; they now run between phx_step_begin and phx_step_end, where the reference runs them)."""
         super().__init__(num_steps, network, env_supertype, agent_supertypes, **device_kwargs)
         self._initial_stage = initial_stage
         self._stages: Dict[StageID, FSMStage] = {}
@@ -108,24 +109,16 @@ class FiniteStateMachineEnv(PhantomEnv):
                 raise FSMValidationError(
                     f"Stage '{stage.id}' without handler must have exactly one next stage "
                     f"(got {len(stage.next_stages)})")
-        # Stage HANDLERS (fsm.py:294-307) are Python: they are called on the host, once per step and stage, BEFORE the
-        # launch; the stage they return goes to the device as a per-env input column (phx_step_io.next_stage).  The
-        # device step always resolves the network, so `self.resolve_network()` inside a handler is a no-op marker.
-        # Handlers DECLARED state-independent (``state_independent`` / ``handler_state_independent=True``) are tabulated
-        # per (stage, clock value) at spec-compile time instead and run nowhere at step time (phx_spec.stage_tab).
+        # Stage HANDLERS (fsm.py:294-307) are Python.  Not declared state-independent, they are called on the host between the two
+        # halves of the device step -- after the acting phase and resolve_network() (phx_step_begin), before the transition
+        # (phx_step_end) -- exactly where fsm.py:275-307 calls them; `self.resolve_network()` inside a handler marks the
+        # resolution that phx_step_begin has already done.  One call per stage serves the whole batch: agent attributes are
+        # [B] arrays, the handler returns one stage or a sequence of B stages.  Handlers DECLARED state-independent
+        # (``state_independent`` / ``handler_state_independent=True``) are tabulated per (stage, clock value) at spec-compile
+        # time instead and run nowhere at step time (phx_spec.stage_tab): only those allow fused rollouts.
         self._host_handlers = [s for s in self._stages.values() if s.handler is not None and not s.is_tabulated()]
         self._tab_handlers = [s for s in self._stages.values() if s.is_tabulated()]
         self._has_handlers = bool(self._host_handlers)
-        if self._host_handlers and not allow_host_handlers:
-            import warnings
-            warnings.warn(
-                "FiniteStateMachineEnv: the handler(s) of stage(s) " + ", ".join(repr(s.id) for s in self._host_handlers) +
-                " run on the host BEFORE the device step (the reference calls them after the acting phase and lets them "
-                "resolve the network, fsm.py:275-302): a handler that inspects agent state sees the PREVIOUS step's state, "
-                "and it is called once per stage for the whole batch.  Handlers that decide from the clock / the stage "
-                "alone are exact -- declare them with @phantom_amd.state_independent (or FSMStage(handler_state_independent="
-                "True)) to have them tabulated and to enable fused rollouts; pass allow_host_handlers=True to silence this.",
-                RuntimeWarning, stacklevel=3)
         self._stage_tab = None
         self._in_handler = False
         self._chosen_next = None
@@ -232,11 +225,19 @@ class FiniteStateMachineEnv(PhantomEnv):
         raise NotImplementedError("message resolution is part of the device step (phx_step); "
                                   "use env.network.resolve() for host-driven resolves outside a step")
 
-    def _step_extras(self):
-        """call the current stages' handlers (fsm.py:294-302) and hand their return values to the device."""
-        self._chosen_next = None
+    def _launch_step(self, dev, actions, action_valid, exo):
         if not self._has_handlers:
-            return {}
+            return super()._launch_step(dev, actions, action_valid, exo)
+        dev.step_begin(actions, action_valid, exo)               # acting phase + resolve_network(), fsm.py:275-280
+        return dev.step_end(self._call_handlers()["next_stage"])  # the handlers' stages -> transition, observations, rewards
+
+    def _step_extras(self):
+        self._chosen_next = None
+        return {}
+
+    def _call_handlers(self):
+        """call the current stages' handlers (fsm.py:294-302) on the RESOLVED state and return their stages for the device."""
+        self._chosen_next = None
         import torch
         B = self.batch_size
         # what the reference's handler would see: the clock already incremented (fsm.py:268), the stage not yet

@@ -42,6 +42,17 @@ class DeviceRunner:
         self._pull()
         return self
 
+    def step_begin(self, actions, action_valid=None, exo=None, shuffle=None):
+        sh = None if shuffle is None else torch.from_numpy(np.ascontiguousarray(shuffle, np.uint16).view(np.int16)).to(self.dev.device)
+        self.dev.step_begin(self._t(actions, np.float32), self._t(action_valid, np.uint8), self._t(exo, np.uint8), sh)
+        self.err = self.dev.err.cpu().numpy()
+        return self
+
+    def step_end(self, next_stage=None):
+        self.dev.step_end(self._t(next_stage, np.int32))
+        self._pull()
+        return self
+
     def inject(self, messages):
         self._pending.extend(messages)
 

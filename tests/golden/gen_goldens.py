@@ -155,7 +155,7 @@ def build_ref_supply_chain(n_shops, ks, num_steps, norm_customers, tracking=Fals
             num_steps=num_steps, network=net, initial_stage="RESTOCK",
             stages=[ph.FSMStage("RESTOCK", acting_agents=shop_ids, rewarded_agents=shop_ids,
                                 next_stages=["SELL", "RESTOCK"] if handler else ["SELL"],
-                                handler=restock_handler if handler else None),
+                                handler=(restock_handler if handler is True else handler) if handler else None),
                     ph.FSMStage("SELL", acting_agents=flat_c, rewarded_agents=[],
                                 next_stages=["RESTOCK"])], **kw)
     else:

@@ -59,6 +59,13 @@ def handler_kw(g, tabulated=False):
     return {"restock_handler": golden_restock_handler, "allow_host_handlers": True}
 
 
+def golden_stock_handler(env, threshold=60):
+    """the RESTOCK handler of tests/golden/gen_goldens_fsm_state.py against the phantom_amd surface: agent attributes are [B] arrays"""
+    env.resolve_network()
+    total = sum(np.asarray(a.stock) for aid, a in env.agents.items() if str(aid).startswith("SHOP"))
+    return np.where(total < threshold, "RESTOCK", "SELL").tolist() if np.ndim(total) else ("RESTOCK" if total < threshold else "SELL")
+
+
 def env_from_golden(g, batch=None, tracking=False, tabulated_handlers=False, **kw):
     if "type_src" in g:
         kw.update(typed=True, agent_supertypes=typed_supertypes(g))

@@ -48,7 +48,8 @@ def lib():
         L.phxo_get_u8.argtypes = [vp, C.c_char_p, vp]
         L.phxo_rng_uniform.restype = C.c_double
         L.phxo_rng_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_int, vp]
-        L.phxo_step.argtypes = [vp, C.POINTER(_abi.PhxStepIO)]
+        for _n in ("phxo_step", "phxo_step_begin", "phxo_step_end"):
+            getattr(L, _n).argtypes = [vp, C.POINTER(_abi.PhxStepIO)]
         L.phxo_inject.argtypes = [vp, C.POINTER(_abi.PhxMsgRec), C.c_int]
         L.phxo_resolve.argtypes = [vp, vp, vp, vp]
         L.phxo_rollout.argtypes = [vp, C.POINTER(_abi.PhxRolloutIO)]
@@ -122,7 +123,15 @@ class OracleEnv:
         self.L.phxo_reset(self.h, _p(mask), _p(sampler_values), _p(conn_on), _p(self.obs), _p(self.obs_valid))
         return self.obs.copy(), self.obs_valid.copy()
 
-    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None):
+    def step_begin(self, actions, action_valid=None, exo=None, shuffle=None):
+        """phxo_step_begin: acting phase + resolve_network() (fsm.py:275-280); the outputs of the step are not touched"""
+        return self.step(actions, action_valid, exo, shuffle, None, _fn="phxo_step_begin")
+
+    def step_end(self, next_stage=None):
+        """phxo_step_end: the handler's stages -> transition, observations, rewards, done flags (fsm.py:304-380)"""
+        return self.step(None, None, None, None, next_stage, _fn="phxo_step_end")
+
+    def step(self, actions, action_valid=None, exo=None, shuffle=None, next_stage=None, _fn="phxo_step"):
         io = _abi.PhxStepIO()
         self._ns = np.ascontiguousarray(next_stage, np.int32) if next_stage is not None else None
         io.next_stage = _p(self._ns)
@@ -141,7 +150,7 @@ class OracleEnv:
         io.all_terminated, io.all_truncated = _p(self.all_terminated), _p(self.all_truncated)
         io.err = _p(self.err)
         io.msg_log, io.msg_count = _p(self.msg_log), _p(self.msg_count)
-        self.L.phxo_step(self.h, C.byref(io))
+        getattr(self.L, _fn)(self.h, C.byref(io))
         return self
 
     def inject(self, messages):

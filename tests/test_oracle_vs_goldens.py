@@ -12,7 +12,15 @@ SC_CASES = ["sc7_fixed20", "sc7_mixed", "sc64", "sc_ragged", "sc256_fsm", "sc_fs
             "sc_typed", "sc_typed_fsm"]
 
 
-def replay_supply_chain(g, make_runner, tabulated_handlers=False):
+def stock_handler_stage(run, threshold=60):
+    """the RESTOCK handler of tests/golden/gen_goldens_fsm_state.py on a runner's state: called AFTER the step's acting phase
+    and resolve_network() (fsm.py:294-302): restock again (stage 0) while the shops together hold fewer than 60 items"""
+    total = run.get_i32("shop.stock").sum(axis=1)
+    cur = run.get_i32("env.stage")[:, 0]
+    return np.where(cur == 0, np.where(total < threshold, 0, 1), 0).astype(np.int32)       # SELL's only next stage is RESTOCK
+
+
+def replay_supply_chain(g, make_runner, tabulated_handlers=False, state_handler=None):
     """drive a runner (oracle or device adapter) with the golden inputs and compare outputs.  ``tabulated_handlers``: the
     golden's stage handler is declared state-independent and travels as phx_spec.stage_tab instead of a per-step
     next_stage column."""
@@ -43,6 +51,12 @@ def replay_supply_chain(g, make_runner, tabulated_handlers=False):
             assert n <= cap
             sh[:, :n] = g["shuffle"][t][:, :n]
             run.step(g["actions"][t], None, exo, sh)
+        elif state_handler is not None:                      # a handler that reads agent state: the step in two halves around it
+            run.step_begin(g["actions"][t], None, exo)
+            assert (run.err == 0).all()
+            nxt = state_handler(run)
+            np.testing.assert_array_equal(nxt, g["next_stage"][t], err_msg=f"the handler's stage at t={t} (it must see the RESOLVED state)")
+            run.step_end(nxt)
         elif "next_stage" in g and not tabulated_handlers:   # the stage the reference's handler returned (fsm.py:294-302), per env
             run.step(g["actions"][t], None, exo, next_stage=g["next_stage"][t])
         else:
@@ -86,6 +100,17 @@ def test_shuffle_goldens_are_not_the_identity():
 @pytest.mark.parametrize("name", SC_CASES + SHUFFLE_CASES + HANDLER_CASES)
 def test_oracle_supply_chain_matches_reference(name):
     replay_supply_chain(golden(name), lambda spec: OracleEnv(spec))
+
+
+def test_oracle_state_dependent_stage_handler_between_the_two_halves_of_a_step():
+    """golden `sc_fsm_state_handler`: the REFERENCE running a RESTOCK handler that calls resolve_network() and then branches on
+    ShopAgent.stock.  phxo_step_begin (acting + resolution), the handler on the resolved state, phxo_step_end(next_stage):
+    stage sequence, stocks, observations and rewards equal the reference's; the same golden replayed with ONE step call per
+    step and the recorded stages gives the same outputs (begin + end == step)."""
+    g = golden("sc_fsm_state_handler")
+    assert (g["next_stage"][:2, 0] == [0, 1]).all() and (g["stage"][:3, 0] == [0, 0, 1]).all()      # RESTOCK twice, then SELL
+    replay_supply_chain(g, lambda spec: OracleEnv(spec), state_handler=stock_handler_stage)
+    replay_supply_chain(g, lambda spec: OracleEnv(spec))
 
 
 @pytest.mark.parametrize("name", HANDLER_CASES)
