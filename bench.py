@@ -338,10 +338,6 @@ def main():
                     help="episodes (of num_steps = 100 steps) per phx_rollout launch: a time-major T = 400 fragment is four "
                          "consecutive T = 100 fragments in memory; start-up / drain and the launch gap are paid once per launch")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's default block shape (no env.autotune_rollout)")
-    ap.add_argument("--flag-pipeline", action="store_true",
-                    help="zero the NEXT buffer's flag planes on a side stream beside the current fragment (PHX_RH_FLAGS_ZEROED) instead of letting "
-                         "phx_rollout fill them in line -- measured SLOWER on MI355X (102 vs 80 us per T=400 launch: the cross-stream waits cost more "
-                         "than the 6 us fill they hide); kept for the comparison")
     ap.add_argument("--watchdog-s", type=float, default=900.0, help="overall deadline; a JSON line with `error` is printed when it passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-step", action="store_true")
@@ -441,36 +437,19 @@ def run(args, rank, local_rank, world, watch):
     traj = trajs[0]
     rot = [0]
 
-    # Where the kernel stores only the non-zero flag words (phx_spec.variant_flags sparse: the default at this fragment size)
-    # phx_rollout zeroes the flag planes itself, in line, before the kernel.  --flag-pipeline: the zeros of the NEXT buffer's planes are
-    # written on a side stream while the current fragment is being written and phx_rollout is told so (PHX_RH_FLAGS_ZEROED) --
-    # measured slower (the cross-stream waits cost more than the fill they hide), kept for the comparison.
+    # The store-wave kernel (round 4) writes every flag word from its store waves; round 3's kernel, where it serves the launch,
+    # stores only the non-zero words after phx_rollout's own in-line fill (phx_spec.variant_flags sparse).
     served_by = dev.last_kernel()                              # what phx_rollout launched for the bench fragment (phx_last_kernel)
     store_waves = "phx_sc_rollout_sw_kernel" in served_by
     sparse = (not store_waves) and env._variants.get("flags", "auto") != "dense" and T * B * S >= (1 << 23)
-    use_pipe = sparse and args.flag_pipeline
-    side = torch.cuda.Stream(dev.device) if use_pipe else None
-    pipe_on = [use_pipe]
+    use_pipe = False                                          # (round 3's --flag-pipeline experiment was removed: measured slower)
+    pipe_on = [False]
 
     def launches(n, bufs=None):                             # n full-length fragments, back to back
         bufs = bufs or trajs
         k = rot[0]
-        if not pipe_on[0] or len(bufs) < 2:
-            for _ in range(n):
-                dev.rollout(T, out=bufs[k % len(bufs)]); k += 1
-        else:
-            main = torch.cuda.current_stream(dev.device)
-            dev.zero_flags(bufs[k % len(bufs)])             # the first buffer of the run: in line
-            for _ in range(n):
-                cur, nxt = bufs[k % len(bufs)], bufs[(k + 1) % len(bufs)]
-                e_prev, e_zero = torch.cuda.Event(), torch.cuda.Event()
-                e_prev.record(main)                         # everything that wrote `nxt` last (an earlier launch) is before this point
-                side.wait_event(e_prev)
-                with torch.cuda.stream(side):
-                    dev.zero_flags(nxt); e_zero.record(side)
-                dev.rollout(T, out=cur, flags_zeroed=True)
-                main.wait_event(e_zero)                     # the next launch needs `nxt` zeroed
-                k += 1
+        for _ in range(n):
+            dev.rollout(T, out=bufs[k % len(bufs)]); k += 1
         rot[0] = k
 
     def sync_barrier():
@@ -562,10 +541,6 @@ def run(args, rank, local_rank, world, watch):
     launch_ms = event_ms(n_full)                              # rotating over the buffers: HBM
     same_ms = event_ms(n_full, [traj])                        # one buffer rewritten in place (round 2's loop): may sit in the Infinity Cache
     inline_ms = None
-    if use_pipe:                                              # the same launches with phx_rollout zeroing the flag planes itself, in line
-        pipe_on[0] = False
-        inline_ms = event_ms(n_full)
-        pipe_on[0] = True
     alg = frag_bytes
     achieved = alg / (launch_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None

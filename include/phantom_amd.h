@@ -289,7 +289,8 @@ typedef struct phx_step_io {
 
 /* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end.
  * Every buffer must be 16-byte aligned (the kernels write 16-byte pieces); phx_rollout returns PHX_EINVAL otherwise. */
-#define PHX_RH_FLAGS_ZEROED 1   /* phx_rollout_io.hints: the caller has ALREADY zeroed `terminated` and `truncated` (e.g. on a side stream,
+#define PHX_RH_FLAGS_ZEROED 1   /* EXPERIMENTAL (round 3; measured slower: the cross-stream waits cost more than the fill they hide; the round-4
+                                   default kernel stores every flag word and ignores it).  phx_rollout_io.hints: the caller has ALREADY zeroed `terminated` and `truncated` (e.g. on a side stream,
                                    while the previous fragment was being written): where the serving kernel stores only the non-zero flag
                                    words (phx_spec.variant_flags) its own fill is skipped; ignored by kernels that store every word */
 typedef struct phx_rollout_io {
@@ -312,7 +313,8 @@ typedef struct phx_rollout_io {
    * generic engine's launch loop); both NULL = not recorded.                               */
   phx_msg_rec* msg_log;        /* [T][B][trace_cap] or NULL                                 */
   int32_t*  msg_count;         /* [T][B] or NULL                                            */
-  /* ABI 7, opt-in RECORD layout: [T][B][S] records of PHX_TRAJ_RECORD_BYTES = 24 bytes
+  /* ABI 7, EXPERIMENTAL opt-in RECORD layout (levels the boxes of round 3's kernel at 87 us per T = 400 fragment; the round-4
+   * store-wave kernel writes the planes in 61-66 us and does not serve it): [T][B][S] records of PHX_TRAJ_RECORD_BYTES = 24 bytes
    *   { float obs[3]; float action; float reward; uint8_t terminated, truncated, pad[2]; }
    * instead of the five planes obs / action_out / reward / terminated / truncated, which must then be NULL.  The same values
    * (time-major, one record per (step, env instance, strategic agent)); a workgroup of the time-parallel supply-chain kernel

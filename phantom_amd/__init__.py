@@ -27,6 +27,6 @@ from .message import Ads, AuctionResult, Bid, ImpressionRequest, ImpressionResul
 from . import samplers
 from .samplers import (LambdaSampler, NormalArraySampler, NormalSampler, Sampler,
                        UniformArraySampler, UniformFloatSampler, UniformIntSampler)
-from .views import AgentView, EnvView, FSMEnvView, View
+from .views import AgentView, Context, EnvView, FSMEnvView, View
 from . import ads_market, metrics, rllib
 from .distributed import all_gather_trajectory, make_sharded_env, shard_batch

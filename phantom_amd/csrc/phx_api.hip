@@ -631,6 +631,39 @@ void phx_note_kernel(const char* name) {
 
 extern "C" {
 
+// the development knobs: every PHX_* environment toggle of the library, read here and nowhere else (first use: phx_create)
+extern "C++" const DevKnobs& phx_knobs() {
+  static const DevKnobs knobs = [] {
+    DevKnobs k;
+    auto rd = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+    k.fsm_fast = rd("PHX_FSM_FAST", 0);
+    k.fsm_lean = rd("PHX_FSM_LEAN", 1);
+    k.fsm_wide = rd("PHX_FSM_WIDE", 1);
+    k.generic_nt = rd("PHX_GENERIC_NT", 0);
+    k.generic_remap = rd("PHX_GENERIC_REMAP", 1);
+    k.generic_tablds = rd("PHX_GENERIC_TABLDS", 1);
+    k.rollout_epb = rd("PHX_ROLLOUT_EPB", 0);
+    k.rollout_fast = rd("PHX_ROLLOUT_FAST", 0);
+    k.rollout_first = rd("PHX_ROLLOUT_FIRST", 0);
+    k.rollout_g = rd("PHX_ROLLOUT_G", 0);
+    k.rollout_ldskb = rd("PHX_ROLLOUT_LDSKB", 0);
+    k.rollout_nt = rd("PHX_ROLLOUT_NT", 0);
+    k.rollout_remap = rd("PHX_ROLLOUT_REMAP", -1);
+    k.rollout_sparse_flags = rd("PHX_ROLLOUT_SPARSE_FLAGS", 1);
+    k.step_nt = rd("PHX_STEP_NT", 0);
+    k.stk_rollout_nt = rd("PHX_STK_ROLLOUT_NT", 0);
+    k.stk_step_fast = rd("PHX_STK_STEP_FAST", 1);
+    k.stk_step_nt = rd("PHX_STK_STEP_NT", 0);
+    k.sw_alt = rd("PHX_SW_ALT", 1);
+    k.sw_generic = rd("PHX_SW_GENERIC", 0);
+    k.sw_store_waves = rd("PHX_SW_STORE_WAVES", 0);
+    k.sw_tc = rd("PHX_SW_TC", 0);
+    k.sw_work_waves = rd("PHX_SW_WORK_WAVES", 0);
+    return k;
+  }();
+  return knobs;
+}
+
 int phx_abi_version(void) { return PHX_ABI_VERSION; }
 const char* phx_last_error(void) { return g_err; }
 
@@ -648,6 +681,7 @@ int phx_n_exo(const phx_spec* spec) { Derived d; return derive(spec, d) == PHX_O
 int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state_nbytes, phx_env** out) {
   if (!out) return fail(PHX_EINVAL, "null out");
   *out = nullptr;
+  (void)phx_knobs();                                    // the development knobs are read here, once per process
   phx_env* e = new phx_env();
   int rc = derive(spec, e->der);
   if (rc != PHX_OK) { delete e; return rc; }

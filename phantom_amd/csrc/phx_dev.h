@@ -49,6 +49,36 @@ struct ScFastPlan {
   int32_t ok, epb, G, K, nt, norm, whole_envs;
 };
 
+// DEVELOPMENT knobs (A/B runs of kernel variants: tools/roll_time.py, tools/gen_time.py).  They are read from the environment in ONE
+// place, once per process, at the first phx_create (phx_knobs(), phx_api.hip); the plans and launchers take them from this table --
+// no getenv in a launcher.  Per-env, supported selection of kernels is phx_spec.variant_*.
+struct DevKnobs {
+  int fsm_fast;                // PHX_FSM_FAST (default 0)
+  int fsm_lean;                // PHX_FSM_LEAN (default 1)
+  int fsm_wide;                // PHX_FSM_WIDE (default 1)
+  int generic_nt;              // PHX_GENERIC_NT (default 0)
+  int generic_remap;           // PHX_GENERIC_REMAP (default 1)
+  int generic_tablds;          // PHX_GENERIC_TABLDS (default 1)
+  int rollout_epb;             // PHX_ROLLOUT_EPB (default 0)
+  int rollout_fast;            // PHX_ROLLOUT_FAST (default 0)
+  int rollout_first;           // PHX_ROLLOUT_FIRST (default 0)
+  int rollout_g;               // PHX_ROLLOUT_G (default 0)
+  int rollout_ldskb;           // PHX_ROLLOUT_LDSKB (default 0)
+  int rollout_nt;              // PHX_ROLLOUT_NT (default 0)
+  int rollout_remap;           // PHX_ROLLOUT_REMAP (default -1)
+  int rollout_sparse_flags;    // PHX_ROLLOUT_SPARSE_FLAGS (default 1)
+  int step_nt;                 // PHX_STEP_NT (default 0)
+  int stk_rollout_nt;          // PHX_STK_ROLLOUT_NT (default 0)
+  int stk_step_fast;           // PHX_STK_STEP_FAST (default 1)
+  int stk_step_nt;             // PHX_STK_STEP_NT (default 0)
+  int sw_alt;                  // PHX_SW_ALT (default 1)
+  int sw_generic;              // PHX_SW_GENERIC (default 0)
+  int sw_store_waves;          // PHX_SW_STORE_WAVES (default 0)
+  int sw_tc;                   // PHX_SW_TC (default 0)
+  int sw_work_waves;           // PHX_SW_WORK_WAVES (default 0)
+};
+const DevKnobs& phx_knobs();
+
 // workgroup shape of the round-4 store-wave rollout kernel (phx_sc_rollout_sw.hip)
 struct ScSwPlan {
   int32_t ok, epb, G, K, norm, tc, nt, n_rec, n_store, dtab_n, lds;

@@ -1164,7 +1164,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   const bool lean = lds && sp.lean_lds != 0;
   size_t bytes = (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, sp.n_adx, lean) + 15) & ~(size_t)15;
   const size_t tab = phx_generic_table_bytes(sp.A, sp.nnz);
-  static const int tablds_env = getenv("PHX_GENERIC_TABLDS") ? atoi(getenv("PHX_GENERIC_TABLDS")) : 1;
+  const int tablds_env = phx_knobs().generic_tablds;
   // Staging the topology tables in LDS saves latency per lookup but costs occupancy: every workgroup of the CU holds its
   // own copy.  Worth it only while queues + tables stay small (SC64: 6 KB); at SC256 (15.5 KB of queues + 10.5 KB of
   // tables = 6 workgroups per CU with them, 10 without) leaving them in global memory is 18 % faster (144 -> 118 us).
@@ -1172,7 +1172,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   g.tab_off = (int32_t)bytes;
   // one env per workgroup writes ~100-byte output segments: with consecutive envs on one XCD their shared cache
   // lines merge in one L2 (SC64 38.6 -> 37.1 us, SC256-FSM 352 -> 343 us per step)
-  static const int remap_env = getenv("PHX_GENERIC_REMAP") ? atoi(getenv("PHX_GENERIC_REMAP")) : 1;
+  const int remap_env = phx_knobs().generic_remap;
   g.xcd_remap = remap_env;
   if (tablds) bytes += tab;
   // threads per env: one wave while the agents fit it (the barriers of a single-wave workgroup are
@@ -1180,7 +1180,7 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   // SC64 B=4096 40 / 63 / 94 us per step, SC256-FSM B=8192 819 / 727 / 743 us.  (Keeping the env's
   // agent state in LDS for the step was measured too: no gain, the wave is instruction-bound --
   // about 6 000 instructions and 90 memory operations per env-step at SC64.)
-  static const int nt_env = getenv("PHX_GENERIC_NT") ? atoi(getenv("PHX_GENERIC_NT")) : 0;      // development: 64 or 128
+  const int nt_env = phx_knobs().generic_nt;      // development: 64 or 128
   // round 2, after the factory's serial chain went message-parallel: SC256-FSM B=8192 199 / 165 / 149 us per step
   // (with the second queue gone -- 6 instead of 5 workgroups per CU -- 128 threads win again: 144 vs 177 us)
   int nt = nt_env ? nt_env : (sp.A <= 64 ? 64 : 128);

@@ -821,7 +821,7 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
   // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
   // same (the per-launch mode is bound by the host's launch cadence); PHX_STEP_NT overrides.
   int nt = 256;
-  static const int force_nt = getenv("PHX_STEP_NT") ? atoi(getenv("PHX_STEP_NT")) : 0;
+  const int force_nt = phx_knobs().step_nt;
   if (force_nt == 64 || force_nt == 128 || force_nt == 256) nt = force_nt < sp.S ? 256 : force_nt;
   const int epb = nt / sp.S;
   const int blocks = (sp.B + epb - 1) / epb;
@@ -837,7 +837,7 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
 
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const int epb = SC_NT / sp.S;
-  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  const int remap_env = phx_knobs().rollout_remap;
   const int remap = remap_env >= 0 ? remap_env : 1;
   // time-parallel kernel first where its plan applies; the lane-per-pair loop below then runs only if that kernel found
   // an env off the tabulated stage chain (a stage a handler or the caller set) and left the launch alone
@@ -847,7 +847,7 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     hipError_t fe = hipSuccess;
     if (phx_launch_sc_rollout_fsmfast(sp, io, st, &fe, &gen)) { if (fe != hipSuccess) return fe; only_if = sp.fsm_irregular; }
   }
-  static const int lean_env = getenv("PHX_FSM_LEAN") ? atoi(getenv("PHX_FSM_LEAN")) : 1;      // development default
+  const int lean_env = phx_knobs().fsm_lean;      // development default
   const bool lean = vr == PHX_VR_LEAN || (vr != PHX_VR_GENERAL && lean_env);
   if ((lean || only_if) && sp.fsm_lean_K > 0 && sp.env_type == PHX_ENV_FSM && !io.actions && !io.exo && sp.n_samplers == 0) {
     uint32_t pk = 1; for (int k = 0; k < sp.fsm_lean_K; ++k) pk *= 5u;
@@ -855,7 +855,7 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     // blocks that start on multiples of 4 pairs (16-byte aligned observation rows): whole envs, a multiple of 4 of them
     // unless the shop count is one itself
     int epb_l = epb; int wide = 0;
-    static const int wide_env = getenv("PHX_FSM_WIDE") ? atoi(getenv("PHX_FSM_WIDE")) : 1;
+    const int wide_env = phx_knobs().fsm_wide;
     if (wide_env && ((int64_t)sp.B * sp.S) % 4 == 0) {
       if (sp.S % 4 == 0) wide = (sp.B % epb == 0);
       else if ((SC_NT / sp.S) >= 4) { const int e4 = (SC_NT / sp.S) & ~3; if (sp.B % e4 == 0) { epb_l = e4; wide = 1; } }
@@ -902,7 +902,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   // whole envs per block: a multiple of 4 so that G = epb * S makes every tile row a 16-byte
   // multiple; B = 4096, S = 9 -> epb 4, G 36, 1024 blocks of 256 threads
   int epb = 0;
-  static const int force_epb = getenv("PHX_ROLLOUT_EPB") ? atoi(getenv("PHX_ROLLOUT_EPB")) : 0;
+  const int force_epb = phx_knobs().rollout_epb;
   if (force_epb > 0 && force_epb * sp.S <= 256 && force_epb <= sp.B) epb = force_epb;
   // measured best on SC64 and SC256 up to ~100 k pairs: 256-thread blocks owning ~32..64 pairs;
   // beyond that (the chip is full either way) 512-thread blocks with twice the pairs win by ~5 %
@@ -912,7 +912,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   if (!epb) { epb = 256 / sp.S; if (epb > 4) epb &= ~3; if (epb < 1) epb = 1; if (epb > sp.B) epb = sp.B; }
   const int G = epb * sp.S;
   auto magic = [](int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); };
-  static const int ldskb_env = getenv("PHX_ROLLOUT_LDSKB") ? atoi(getenv("PHX_ROLLOUT_LDSKB")) : 0;
+  const int ldskb_env = phx_knobs().rollout_ldskb;
   const int ldskb = ldskb_env ? ldskb_env : (big ? 44 : 30);
   int TC = (ldskb * 1024) / (G * 32); if (TC < 1) TC = 1; if (TC > io.T) TC = io.T;   // 32 B of LDS per item (double-buffered tiles)
   while ((int64_t)TC * G * 3 >= 65536 && TC > 1) --TC;          // magic division range
@@ -938,13 +938,13 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
   // XCD-aware workgroup -> env mapping (xcd_block).  Measured, SC64, T = 100, back-to-back launches: HBM write
   // traffic 90.8 -> 80.8 MB per launch at B = 4096 (the algorithmic 82.3 MB); +1 % at B = 4096, +5 % at 16384,
   // +8 % at 65536.  PHX_ROLLOUT_REMAP = 0 identity, 1 contiguous eighths, n > 1 locality groups of n workgroups.
-  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  const int remap_env = phx_knobs().rollout_remap;
   a.xcd_remap = remap_env >= 0 ? remap_env : 1;
   const dim3 grid((sp.B + epb - 1) / epb);
   const bool replay = io.actions != nullptr || io.exo != nullptr;
   const int64_t total = (int64_t)sp.B * sp.S;
   const bool wide = (sp.B % epb == 0) && (G % 4 == 0) && (total % 4 == 0);
-  static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
+  const int nt_env = phx_knobs().rollout_nt;
   // block size: the waves that hold a recurrence lane + enough waves to take phase 1 (one work item
   // per row quad and pair) in a single pass, when that fits 512 threads
   int nt = 256;

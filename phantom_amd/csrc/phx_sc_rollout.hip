@@ -484,11 +484,11 @@ static uint32_t magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d
 
 bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, bool aligned, ScFastPlan* p) {
   memset(p, 0, sizeof *p);
-  static const int off = getenv("PHX_ROLLOUT_FAST") ? atoi(getenv("PHX_ROLLOUT_FAST")) == 0 : 0;     // development default only:
+  const int off = (phx_knobs().rollout_fast == 0);     // development default only:
   if (off) return false;                                                                               // per env: phx_spec.variant_rollout
   if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || num_steps < PHX_FAST_TC) return false;
   const int64_t total = (int64_t)B * S;
-  static const int g_env = getenv("PHX_ROLLOUT_G") ? atoi(getenv("PHX_ROLLOUT_G")) : 0;               // development default of variant_block
+  const int g_env = phx_knobs().rollout_g;               // development default of variant_block
   if (block == 0) block = g_env;
   auto pairs_ok = [&](int G) { return G >= 4 && G <= 192 && G % 4 == 0 && total % G == 0 && (G + S - 2) / S + 1 <= 255; };
   // (1) whole envs per block, a multiple of 4 of them so that every tile row is a whole number of 16-byte segments;
@@ -548,14 +548,14 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   const ScFastPlan& p = sp.sc_fast;
   FastArgs a;
   a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.whole_envs = p.whole_envs; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
-  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  const int remap_env = phx_knobs().rollout_remap;
   a.xcd_remap = remap_env >= 0 ? remap_env : 1;
   uint32_t pk = 1; for (int k = 0; k < p.K; ++k) pk *= 5u;
   static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
   a.pK = pk; a.inv_pK = inv[p.K];
   a.mG = magic32(p.G); a.mG4 = magic32(p.G / 4); a.mS = magic32(sp.S); a.mPR = magic32(3 * (p.G / 4));
   a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset;
-  static const int first_env = getenv("PHX_ROLLOUT_FIRST") ? atoi(getenv("PHX_ROLLOUT_FIRST")) : 0;
+  const int first_env = phx_knobs().rollout_first;
   int first = first_env > 0 ? first_env : PHX_FAST_TC;
   if (first > PHX_FAST_TC) first = PHX_FAST_TC;
   if (io.T <= PHX_FAST_TC) first = io.T;
@@ -581,7 +581,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   // write requests unless a neighbour's share reaches the L2 in time to merge; in the store pattern alone they cost a quarter to
   // a third of the launch (tools/ubench/ub_store9.hip: 84-89 us with them, 54-62 without).  They are all zero except the
   // episodes' last rows: a streaming fill (whole lines, ~5 us per T = 400 fragment) writes the zeros, the kernel the exceptions.
-  static const int sparse_env = getenv("PHX_ROLLOUT_SPARSE_FLAGS") ? atoi(getenv("PHX_ROLLOUT_SPARSE_FLAGS")) : 1;      // development
+  const int sparse_env = phx_knobs().rollout_sparse_flags;      // development
   const int64_t n_flag = (int64_t)io.T * sp.B * sp.S;
   a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 23)))) ? 1 : 0;
   if (a.flags_sparse && !(io.hints & PHX_RH_FLAGS_ZEROED)) {          // (the caller may have zeroed them already, beside the previous fragment)
@@ -595,7 +595,7 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
     if (me != hipSuccess) return me;
   }
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
-  static const int nt_env = getenv("PHX_ROLLOUT_NT") ? atoi(getenv("PHX_ROLLOUT_NT")) : 0;
+  const int nt_env = phx_knobs().rollout_nt;
   const int rec = ((p.G + 63) / 64) * 64;
   const int nt = (nt_env && nt_env >= rec + 64) ? nt_env : p.nt;
   phx_note_kernel(io.records ? (p.whole_envs ? "phx_sc_rollout_fast_kernel[whole_envs,records]" : "phx_sc_rollout_fast_kernel[pairs,records]")

@@ -479,14 +479,14 @@ static uint32_t fsm_magic32(int d) { return (uint32_t)((0x100000000ull + (uint64
 bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_, hipStream_t st, hipError_t* err, int32_t* gen_out) {
   *err = hipSuccess;
   const ScFastPlan& p = sp.fsm_fast;
-  static const int off = getenv("PHX_FSM_FAST") ? atoi(getenv("PHX_FSM_FAST")) == 0 : 0;
+  const int off = (phx_knobs().fsm_fast == 0);
   if (!p.ok || off || io_.actions || io_.exo || !io_.obs_valid || !io_.reward_valid) return false;
   if ((int64_t)io_.T + 2 * (int64_t)sp.num_steps >= 60000) return false;       // magic division of the position
   // Measured against the lane-per-pair loop (tools/roll_time.py --fsm, us per 100-step launch, this kernel / the loop): 9 shops x
   // 4 096 envs 40 / 60, x 16 384 120 / 85, x 65 536 501 / 464; 51 shops x 2 048 envs 104 / 77, x 4 096 191 / 119, x 8 192 330-370 /
   // 204-335.  The output phase costs twice the plain kernel's (own row + looked-back row per pair, silent and observing steps
   // mixed in every wave), so this kernel only wins where the loop's one lane per pair leaves the chip underfilled.
-  static const int force = getenv("PHX_FSM_FAST") ? atoi(getenv("PHX_FSM_FAST")) : 0;             // development default
+  const int force = phx_knobs().fsm_fast;             // development default
   if (force < 2 && sp.variant_rollout != PHX_VR_TIME_PARALLEL && (int64_t)sp.B * sp.S > 65536) return false;
   FsmFastArgs a;
   memset(&a, 0, sizeof a);

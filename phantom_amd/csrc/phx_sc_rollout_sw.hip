@@ -516,9 +516,9 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   const int64_t total = (int64_t)B * S;
   if (total >= ((int64_t)1 << 24)) return false;                                  // 24-bit multiplies on (row, pair) offsets
   int dtab_n = 1; for (int k = 0; k < K_uniform; ++k) dtab_n *= 5;
-  static const int tc_env = getenv("PHX_SW_TC") ? atoi(getenv("PHX_SW_TC")) : 0;            // development default
-  static const int ns_env = getenv("PHX_SW_STORE_WAVES") ? atoi(getenv("PHX_SW_STORE_WAVES")) : 0;
-  static const int nw_env = getenv("PHX_SW_WORK_WAVES") ? atoi(getenv("PHX_SW_WORK_WAVES")) : 0;
+  const int tc_env = phx_knobs().sw_tc;            // development default
+  const int ns_env = phx_knobs().sw_store_waves;
+  const int nw_env = phx_knobs().sw_work_waves;
   auto epb_of = [&](int G) { return (G + S - 2) / S + 1; };                        // the most envs a block can touch
   auto pairs_ok = [&](int G) { return G >= 16 && G <= 256 && G % 16 == 0 && total % G == 0 && epb_of(G) <= 255; };
   auto tc_ok = [&](int G, int tc) {
@@ -567,10 +567,10 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   const ScSwPlan& p = sp.sc_sw;
   SwArgs a; memset(&a, 0, sizeof a);
   a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
-  static const int remap_env = getenv("PHX_ROLLOUT_REMAP") ? atoi(getenv("PHX_ROLLOUT_REMAP")) : -1;
+  const int remap_env = phx_knobs().rollout_remap;
   a.xcd_remap = remap_env >= 0 ? remap_env : 1;
   a.n_rec_waves = p.n_rec; a.n_store_waves = p.n_store; a.dtab_n = p.dtab_n;
-  static const int alt_env = getenv("PHX_SW_ALT") ? atoi(getenv("PHX_SW_ALT")) : 1;
+  const int alt_env = phx_knobs().sw_alt;
   a.alt_order = alt_env;
   static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
   a.pK = (uint32_t)p.dtab_n; a.inv_pK = inv[p.K];
@@ -597,7 +597,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
     static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev); \
     if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
     hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
-  static const int generic_env = getenv("PHX_SW_GENERIC") ? atoi(getenv("PHX_SW_GENERIC")) : 0;      // development: the run-time-shape instantiation
+  const int generic_env = phx_knobs().sw_generic;      // development: the run-time-shape instantiation
   const int work = p.nt / 64 - p.n_rec - p.n_store;
 #define SW_SHAPE(G_, NREC_, NSTORE_, NWORK_) (p.tc == 16 && p.G == G_ && p.n_rec == NREC_ && p.n_store == NSTORE_ && work == NWORK_)
   if (!generic_env && SW_SHAPE(144, 3, 4, 9)) SW_LAUNCH(16, 144, 3, 4, 9);

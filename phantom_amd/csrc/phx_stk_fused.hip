@@ -676,7 +676,7 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
       h[0] / (9.0 * 64 * io.T), h[1] / (9.0 * 64 * io.T), h[2] / (9.0 * 64 * io.T), h[3] / (9.0 * 64 * io.T), h[4] / (9.0 * 64 * io.T)); } }
 #endif
   // threads per env: a block whose STKR_SLOTS passes cover the agents
-  static const int nt_env = getenv("PHX_STK_ROLLOUT_NT") ? atoi(getenv("PHX_STK_ROLLOUT_NT")) : 0;
+  const int nt_env = phx_knobs().stk_rollout_nt;
   // (1 152 agents: 384 threads with three full slots 35.4 us per step, 33.0 with the registers capped for 5 blocks per CU;
   //  512 threads -- 32 waves per CU, a quarter of the lanes idle in the third slot -- 28.1: the step is a latency chain)
   int nt = 1024;
@@ -723,8 +723,8 @@ hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStre
   const int nSell = sp.kind_count[PHX_KIND_SELLER];
   const int nBuy = sp.kind_count[PHX_KIND_BUYER];
   const size_t lds = g_stk_paid_off(nSell) + (size_t)nBuy * 8 + (((size_t)nBuy + 15) & ~(size_t)15) + 32 + (sp.dynamic_graph ? (size_t)sp.n_conn : 0);
-  static const int fast_env = getenv("PHX_STK_STEP_FAST") ? atoi(getenv("PHX_STK_STEP_FAST")) : 1;
-  static const int nt_env = getenv("PHX_STK_STEP_NT") ? atoi(getenv("PHX_STK_STEP_NT")) : 0;
+  const int fast_env = phx_knobs().stk_step_fast;
+  const int nt_env = phx_knobs().stk_step_nt;
   if (sp.stk_packed && fast_env && sp.A <= STKR_SLOTS * 1024) {
     int nt = 1024;
     for (int cand : {128, 256, 512, 1024}) if (STKR_SLOTS * cand >= sp.A) { nt = cand; break; }

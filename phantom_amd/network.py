@@ -77,18 +77,46 @@ class Network:
 
     def add_connections_with_adjmat(self, agent_ids: Sequence[AgentID],
                                     adjacency_matrix: np.ndarray) -> None:
-        num_nodes = adjacency_matrix.shape[0]
-        if len(agent_ids) != num_nodes:
-            raise ValueError("Number of agent IDs doesn't match adjacency matrix dimensions.")
-        if len(set(adjacency_matrix.shape)) != 1:
-            raise ValueError("Adjacency matrix must be square.")
-        if not (adjacency_matrix.transpose() == adjacency_matrix).all():
-            raise ValueError("Adjacency matrix must be symmetric.")
-        if not (np.abs(adjacency_matrix.diagonal() - 0.0) < 1e-5).all():
-            raise ValueError("Adjacency matrix must be hollow.")
-        for i, aid in enumerate(agent_ids):
-            self.add_connections_between(
-                [aid], [agent_ids[j] for j in range(num_nodes) if adjacency_matrix[i, j] > 0])
+        """network.py:140-177: connect agent_ids[i] -- agent_ids[j] wherever the (square, symmetric, hollow) matrix is positive.
+        The matrix is validated as a whole first (the reference's messages), then every row's neighbours are connected in
+        column order -- the insertion order the device's CSR adjacency keeps."""
+        m = np.asarray(adjacency_matrix)
+        n = len(agent_ids)
+        problems = ((m.shape[0] != n, "Number of agent IDs doesn't match adjacency matrix dimensions."),
+                    (m.ndim != 2 or m.shape[0] != m.shape[-1], "Adjacency matrix must be square."),
+                    (m.ndim == 2 and m.shape[0] == m.shape[-1] and not np.array_equal(m, m.T), "Adjacency matrix must be symmetric."),
+                    (m.ndim == 2 and bool((np.abs(np.diagonal(m)) >= 1e-5).any()), "Adjacency matrix must be hollow."))
+        for bad, message in problems:
+            if bad:
+                raise ValueError(message)
+        for i, j in zip(*np.nonzero(m > 0)):                   # row-major: row i's neighbours in column order
+            self.add_connection(agent_ids[int(i)], agent_ids[int(j)])
+
+    def subnet_for(self, agent_id: AgentID) -> "Network":
+        """network.py:186-206: the first-order ego network of ``agent_id`` -- the agent, its successors and predecessors
+        (the same set: connections are bidirectional), the connections among them, a reset copy of the resolver.  Host-side
+        object; it compiles to its own device env when stepped."""
+        import copy
+        if agent_id not in self.agents:
+            raise KeyError(agent_id)
+        keep = [agent_id] + [v for v in self._succ[agent_id] if v != agent_id]
+        keep += [u for u in self._succ if agent_id in self._succ[u] and u not in keep]
+        inside = set(keep)
+        sub = Network.__new__(Network)
+        Network.__init__(sub, resolver=copy.deepcopy(self.resolver), ignore_connection_errors=self.ignore_connection_errors,
+                         enforce_msg_payload_checks=self.enforce_msg_payload_checks)
+        sub.resolver.reset()
+        for aid in self.agents:                                # graph.subgraph keeps the parent's node order
+            if aid in inside:
+                sub.agents[aid] = self.agents[aid]
+                sub._succ[aid] = {v: None for v in self._succ[aid] if v in inside}
+        return sub
+
+    def context_for(self, agent_id: AgentID, env_view) -> "Context":
+        """network.py:208-222: the agent, the view each neighbour publishes to it (graph.neighbors order), the env view."""
+        from .views import Context
+        views = {nid: self.agents[nid].view(agent_id) for nid in self.neighbors(agent_id)}
+        return Context(self.agents[agent_id], views, env_view)
 
     def neighbors(self, agent_id: AgentID) -> List[AgentID]:
         """graph.neighbors(agent_id) order (network.py:219)."""

@@ -500,3 +500,24 @@ def test_shop_reward_is_a_function_of_10_sales_minus_stock():
         sl = (n + 9) // 10 if n >= 0 else 0
         st = 10 * sl - n
         assert 0 <= sl <= 30 and 0 <= st <= 100, n
+
+
+def test_network_subnet_for_context_for_and_adjacency_matrix():
+    """network.py:140-222 on the host surface: add_connections_with_adjmat (validation messages, neighbour order), subnet_for
+    (first-order ego network with a reset resolver copy), context_for (neighbour views in graph.neighbors order)."""
+    ids = ["A", "B", "C", "D"]
+    net = ph.Network([ph.Agent(i) for i in ids])
+    m = np.array([[0, 1, 1, 0], [1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 1, 0]])
+    net.add_connections_with_adjmat(ids, m)
+    assert net.neighbors("A") == ["B", "C"] and net.neighbors("C") == ["A", "D"] and net.neighbors("D") == ["C"]
+    for bad, msg in ((np.zeros((3, 3)), "doesn't match"), (np.zeros((4, 3)), "square"), (np.triu(np.ones((4, 4)), 1), "symmetric"),
+                     (np.eye(4), "hollow")):
+        with pytest.raises(ValueError, match=msg):
+            net.add_connections_with_adjmat(ids, bad)
+    sub = net.subnet_for("C")
+    assert list(sub.agents) == ["A", "C", "D"] and sub.agents["A"] is net.agents["A"]
+    assert sub.has_edge("A", "C") and sub.has_edge("D", "C") and not sub.has_edge("A", "B") and "B" not in sub.agents
+    assert sub.resolver is not net.resolver and type(sub.resolver) is type(net.resolver)
+    ctx = net.context_for("C", ph.EnvView(3, 0.3))
+    assert isinstance(ctx, ph.Context) and ctx.agent is net.agents["C"] and ctx.neighbour_ids == ["A", "D"]
+    assert ctx["A"] is None and "D" in ctx and "B" not in ctx and ctx.env_view.current_step == 3
