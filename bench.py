@@ -204,10 +204,16 @@ def other_configs(device):
                            agent_supertypes=st, batch_size=4096, seed=42, device=device)
     env.reset(); dev = env._device()
     acts = torch.rand(4096, 120, device=dev.device)
-    add("digital-ads market 122 agents B=4096 (SURVEY 8f-4)", 122, 4096, 1, timed(lambda: dev.step(acts), 40), "one launch per step")
+    # algorithmic bytes per env-step, N = 120 advertisers (the strategic agents), minimal layout: step outputs 25 B per
+    # advertiser (obs f32[3] 12 + reward f64 8 + 5 flag / validity bytes) + action f32 4; advertiser state touched per step: `left` f64
+    # read + written 16, `bid` f64 written 8, step clicks / wins / user i32 12, the served user's three total_* counters read +
+    # written 24 = 60; publisher + env words 14  =>  N * 89 + 14.  Rollout: the trajectory record, 24 B per advertiser-step
+    # (obs 12 + action 4 + reward 4 + terminated / truncated / obs_valid / reward_valid 4).
+    add("digital-ads market 122 agents B=4096 (SURVEY 8f-4)", 122, 4096, 1, timed(lambda: dev.step(acts), 40), "one launch per step",
+        bytes_per_env_step=120 * 89 + 14)
     tr = dev.rollout(40)
     add("digital-ads market 122 agents B=4096 (SURVEY 8f-4)", 122, 4096, 40, timed(lambda: dev.rollout(40, out=tr), 3),
-        "fused rollout T=40")
+        "fused rollout T=40", bytes_per_env_step=24 * 120)
     del env, dev, tr, acts
     torch.cuda.empty_cache()
     # the generic message-passing engine (LDS inboxes, static round schedule) on the two supply-chain shapes: what a topology
@@ -218,9 +224,13 @@ def other_configs(device):
         env.reset(); dev = env._device()
         acts = torch.rand(B_, S_, device=dev.device) * 100
         A_ = 1 + S_ + S_ * K_
-        add(f"{name}, generic engine (force_generic)", A_, B_, 1, timed(lambda: dev.step(acts), 60), "one launch per step")
+        fsm_ = cls is ph.SupplyChainFSMEnv
+        sb = S_ * 43 + 6 + ((2 * S_ + 2) if fsm_ else 0)             # SURVEY 8d, device-RNG orders (+ stage and validity planes)
+        add(f"{name}, generic engine (force_generic)", A_, B_, 1, timed(lambda: dev.step(acts), 60), "one launch per step",
+            bytes_per_env_step=sb)
         tr = dev.rollout(50)
-        add(f"{name}, generic engine (force_generic)", A_, B_, 50, timed(lambda: dev.rollout(50, out=tr), 4), "rollout T=50, T-step loop in the kernel")
+        add(f"{name}, generic engine (force_generic)", A_, B_, 50, timed(lambda: dev.rollout(50, out=tr), 4), "rollout T=50, T-step loop in the kernel",
+            bytes_per_env_step=(24 if fsm_ else 22) * S_)
         del env, dev, tr, acts
         torch.cuda.empty_cache()
     return res
@@ -739,7 +749,42 @@ def bench_per_step(env, dev, B, S, world, sync_barrier):
         res["rllib_adapter"] = bench_rllib_adapter(env, B, S)
     except Exception as e:                                   # report, do not hide
         res["rllib_adapter"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+    if world == 1:
+        try:
+            res["batch_sweep"] = bench_step_sweep(dev.device)
+        except Exception as e:                               # report, do not hide
+            res["batch_sweep"] = {"error": f"{type(e).__name__}: {e}"[:500]}
     return res
+
+
+def bench_step_sweep(device):
+    """phx_sc_step_kernel (one PhantomEnv.step per launch) at B = 4096 .. 262 144 env instances, replayed from a hipGraph of 50
+    launches so that the host's launch cadence is out of the picture: where the per-launch mode leaves the latency-bound
+    regime and what fraction of the 8 TB/s it settles at (VERDICT r3 Weak #7)."""
+    import phantom_amd as ph
+    rows = []
+    for Bs in (4096, 16384, 65536, 262144):
+        env = ph.SupplyChainEnv(n_shops=N_SHOPS, customers_per_shop=CUST_PER_SHOP, num_steps=NUM_STEPS, batch_size=Bs, seed=42,
+                                exogenous="device", device=str(device))
+        env.reset(); d = env._device()
+        a = (torch.rand(50, Bs, N_SHOPS, device=d.device) * 100.0).contiguous()
+        sg = d.step_graph(a)
+        for _ in range(3):
+            sg.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            sg.replay()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 500 * 1e3
+        alg = algorithmic_bytes_step(Bs, N_SHOPS, CUST_PER_SHOP, device_rng=True)
+        rows.append({"envs": Bs, "us_per_step": us, "agent_steps_per_sec": N_AGENTS * Bs / (us * 1e-6),
+                     "hbm": {"algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (us * 1e-6) / 1e9,
+                             "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}})
+        del sg, a, d, env
+        torch.cuda.empty_cache()
+    return {"mode": "phx_step per launch, hipGraph of 50 launches, SC64", "rows": rows}
 
 
 def bench_rllib_adapter(env, B, S):

@@ -636,14 +636,14 @@ extern "C++" const DevKnobs& phx_knobs() {
   static const DevKnobs knobs = [] {
     DevKnobs k;
     auto rd = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-    k.fsm_fast = rd("PHX_FSM_FAST", 0);
+    k.fsm_fast = rd("PHX_FSM_FAST", -1);             // -1: unset; 0 off; 2 forces it at any batch size
     k.fsm_lean = rd("PHX_FSM_LEAN", 1);
     k.fsm_wide = rd("PHX_FSM_WIDE", 1);
     k.generic_nt = rd("PHX_GENERIC_NT", 0);
     k.generic_remap = rd("PHX_GENERIC_REMAP", 1);
     k.generic_tablds = rd("PHX_GENERIC_TABLDS", 1);
     k.rollout_epb = rd("PHX_ROLLOUT_EPB", 0);
-    k.rollout_fast = rd("PHX_ROLLOUT_FAST", 0);
+    k.rollout_fast = rd("PHX_ROLLOUT_FAST", -1);     // -1: unset; 0 switches the kernel off
     k.rollout_first = rd("PHX_ROLLOUT_FIRST", 0);
     k.rollout_g = rd("PHX_ROLLOUT_G", 0);
     k.rollout_ldskb = rd("PHX_ROLLOUT_LDSKB", 0);

@@ -53,14 +53,14 @@ struct ScFastPlan {
 // place, once per process, at the first phx_create (phx_knobs(), phx_api.hip); the plans and launchers take them from this table --
 // no getenv in a launcher.  Per-env, supported selection of kernels is phx_spec.variant_*.
 struct DevKnobs {
-  int fsm_fast;                // PHX_FSM_FAST (default 0)
+  int fsm_fast;                // PHX_FSM_FAST (default -1 = unset; 0: off; 2: forced at any batch size)
   int fsm_lean;                // PHX_FSM_LEAN (default 1)
   int fsm_wide;                // PHX_FSM_WIDE (default 1)
   int generic_nt;              // PHX_GENERIC_NT (default 0)
   int generic_remap;           // PHX_GENERIC_REMAP (default 1)
   int generic_tablds;          // PHX_GENERIC_TABLDS (default 1)
   int rollout_epb;             // PHX_ROLLOUT_EPB (default 0)
-  int rollout_fast;            // PHX_ROLLOUT_FAST (default 0)
+  int rollout_fast;            // PHX_ROLLOUT_FAST (default -1 = unset; 0: off)
   int rollout_first;           // PHX_ROLLOUT_FIRST (default 0)
   int rollout_g;               // PHX_ROLLOUT_G (default 0)
   int rollout_ldskb;           // PHX_ROLLOUT_LDSKB (default 0)

@@ -543,6 +543,8 @@ class PhantomEnv:
                 best, best_t = v, t
             dev.close(); del dev, bufs, one
         torch.cuda.empty_cache()
+        if best is None:                                         # no candidate's kernel serves this env: keep the library's own choice
+            best = base
         self._variants, self._spec, self._dev = best, None, None
         return {"chosen": dict(best), "us_per_launch": results}
 

@@ -20,8 +20,9 @@ def _cmp(rd, ro, valid):
         np.testing.assert_array_equal(rd[k], ro[k], err_msg=k)
 
 
-def run_rollout_case(case):
-    """returns the number of env-steps compared"""
+def run_rollout_case(case, journal=None):
+    """returns the number of env-steps compared.  ``journal(text)``: called with the case's shape / variants before the first
+    launch and with the launched kernels' names after every rollout launch returns (before the host waits for it)."""
     from device_runner import DeviceRunner
     rng = np.random.default_rng(case)
     kind = int(rng.integers(0, 10))
@@ -34,20 +35,26 @@ def run_rollout_case(case):
         ns = int(rng.choice([1, 2, 5, 19, 20, 21, 40, 57, 100]))
         # a kernel variant drawn from the seed (phx_spec.variant_*; ignored where its preconditions do not hold)
         vrng = np.random.default_rng(case + 10_000_019)
-        variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general"])),
-                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36][int(vrng.integers(0, 8))],
+        variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general", "store_waves", "store_waves"])),
+                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36, 96, 144][int(vrng.integers(0, 10))],
                     "flags": ["auto", "dense", "sparse", "sparse"][int(vrng.integers(0, 4))]}
         env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
                                variants=variants)
         fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")
         amax, valid = 100.0, fsm
+        desc = f"sc S={S} Ks={Ks if len(set(Ks)) > 1 else Ks[0]} B={B} num_steps={ns} fsm={int(fsm)} variants={variants}"
     else:
         L = int(rng.choice([2, 4, 8, 16])); d = min(int(rng.choice([1, 2, 4])), L)
         Fw = int(rng.choice([4, 8, 32, 100])); B = int(rng.choice([1, 3, 8, 16])); ns = int(rng.choice([2, 7, 10, 33]))
         env = market_env(L, Fw, d, ns, B, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)))
         fields = ("env.step", "env.tick")
         amax, valid = 1.0, True
+        desc = f"market L={L} Fw={Fw} d={d} B={B} num_steps={ns}"
+    if journal:
+        journal(f"case {case}: {desc}")
     o, dv = OracleEnv(env.spec, threads=4), DeviceRunner(env.spec)
+    if journal:
+        dv.on_launch = lambda k: journal(f"case {case}: launched {k}")
     assert dv.dev.uses_fused
     o.reset(); dv.reset()
     for _ in range(int(rng.integers(0, 4))):                      # fragments that do not start on a tick quad / at a reset
@@ -55,7 +62,9 @@ def run_rollout_case(case):
         o.step(a, None, None); dv.step(a, None, None)
     n = 0
     for _ in range(int(rng.integers(1, 4))):
-        T = int(rng.choice([1, 2, 3, 7, 19, 20, 21, 39, 41, 64, 100, 130]))
+        T = int(rng.choice([1, 2, 3, 7, 19, 20, 21, 39, 41, 64, 100, 130, 200, 257]))
+        if journal:
+            journal(f"case {case}: rollout T={T}")
         ro, rd = o.rollout(T), dv.rollout(T)
         _cmp(rd, ro, valid)
         for f in fields:
@@ -65,7 +74,72 @@ def run_rollout_case(case):
     return n
 
 
+def _worker(lo, hi, journal_path):
+    """run cases lo .. hi - 1 in THIS process; every journal line is flushed and fsync-ed before the launch it announces"""
+    jf = open(journal_path, "a")
+
+    def journal(text):
+        jf.write(text + "\n"); jf.flush(); os.fsync(jf.fileno())
+    total = 0
+    for c in range(lo, hi):
+        total += run_rollout_case(c, journal)
+        journal(f"case {c}: ok")
+    journal(f"range {lo}..{hi}: ok, {total} env-steps compared")
+
+
+def campaign(lo, hi, journal_path, case_timeout_s=120.0, chunk=500):
+    """a campaign that can NAME a hang.  Cases run in child processes of `chunk` cases; the journal (fsync-ed
+    BEFORE each launch: case id, shape, variants, then the launched kernels' names) is watched from here; a child whose journal
+    does not move for `case_timeout_s` is killed (exactly that pid) and the last journal lines -- the hung case and its kernels --
+    are reported; the campaign then continues after that case.  Returns (cases passed, hangs [(case, lines)], failures)."""
+    import subprocess
+    import time
+    done, hangs, fails = 0, [], []
+    c = lo
+    while c < hi:
+        n = min(chunk, hi - c)
+        jp = f"{journal_path}.{c}"                            # one journal per child: removed when the child's range passed, kept otherwise
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(c), str(c + n), jp],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        last_size, last_move = -1, time.monotonic()
+        while p.poll() is None:
+            time.sleep(0.5)
+            size = os.path.getsize(jp) if os.path.exists(jp) else 0
+            if size != last_size:
+                last_size, last_move = size, time.monotonic()
+            elif time.monotonic() - last_move > case_timeout_s:
+                p.kill(); p.wait()
+                break
+        tail = open(jp).read().splitlines()[-6:] if os.path.exists(jp) else []
+        cur = None
+        for line in reversed(tail):
+            if line.startswith("case "):
+                cur = int(line.split()[1].rstrip(":")); break
+        if p.returncode == 0:
+            done += n; c += n
+            os.remove(jp)
+            with open(journal_path, "a") as sf:
+                sf.write(f"cases {c - n}..{c}: ok\n")
+        else:
+            passed = (cur - c) if cur is not None else 0
+            done += max(passed, 0)
+            (hangs if p.returncode in (-9, 137) else fails).append((cur, tail, (p.stdout.read() or "")[-1500:] if p.stdout else ""))
+            c = (cur + 1) if cur is not None else c + n          # carry on after the case that hung / failed
+    return done, hangs, fails
+
+
 if __name__ == "__main__":
-    lo, hi = int(sys.argv[1]), int(sys.argv[2])
-    total = sum(run_rollout_case(c) for c in range(lo, hi))
-    print(f"rollout cases {lo}..{hi}: ok, {total} env-steps compared")
+    if sys.argv[1] == "--worker":
+        _worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "--campaign":                           # python tests/fuzz_rollouts.py --campaign LO HI journal [timeout_s]
+        lo, hi, jp = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+        d, h, f = campaign(lo, hi, jp, float(sys.argv[5]) if len(sys.argv) > 5 else 120.0)
+        print(f"campaign {lo}..{hi}: {d} cases passed, {len(h)} hangs, {len(f)} failures")
+        for kind, items in (("HANG", h), ("FAIL", f)):
+            for cur, tail, out in items:
+                print(f"{kind} at case {cur}:\n  " + "\n  ".join(tail) + ("\n" + out if out else ""))
+        sys.exit(1 if (h or f) else 0)
+    else:
+        lo, hi = int(sys.argv[1]), int(sys.argv[2])
+        total = sum(run_rollout_case(c) for c in range(lo, hi))
+        print(f"rollout cases {lo}..{hi}: ok, {total} env-steps compared")
