@@ -570,6 +570,8 @@ static void build_static_schedule(const phx_spec* sp, const Derived& d, StaticSc
 // LEAN layout of the generic engine (phx_generic.hip): every acting list of a two-wave supply chain has a static schedule ->
 // the sort / scan scratch only a dynamic step needs (order, slot, scanbuf) moves from LDS to a per-env workspace in the blob
 static bool lean_lds_spec(const phx_spec* sp, const Derived& d) {
+  if (d.sc_static) return false;                 // the fused kernels serve this spec: the generic engine is its rare fallback (phx_inject / phx_resolve,
+                                                 // the split FSM step) and gets no schedule (DevSpec::sched) -- it keeps the plain layout
   if (d.A <= 64 || d.A > 256) return false;
   for (int a = 0; a < d.A; ++a) { const int k = sp->kind[a]; if (k != PHX_KIND_FACTORY && k != PHX_KIND_SHOP && k != PHX_KIND_CUSTOMER) return false; }
   if (phx_generic_queue_bytes(d.A, d.S, sp->queue_cap, d.scan_cap, 0, true) > (size_t)GENERIC_LDS_LIMIT) return false;

@@ -719,6 +719,9 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   const int n_steps = ROLL && g.roll_T > 0 ? g.roll_T : 1;
   // the env's scalar words: read once through the scalar cache (written by an earlier launch), then kept in registers from
   // one step of the loop to the next (a reset inside the loop sets step = 0 and the initial stage, nothing else)
+  // INVARIANT: these four words are written by this kernel only through w_step / w_tick / w_clock / w_stage below (the
+  // epilogue and reset_env store what those registers hold); a new in-kernel writer of env.step / tick / clock / stage must update the
+  // register copies too -- the scalar cache is NOT coherent with this launch's own vector stores.
   typedef const __attribute__((address_space(4))) int32_t* phx_ki32_t;
   int w_step = ((phx_ki32_t)(uintptr_t)fld<int32_t>(sp, F_ENV_STEP))[b];
   int w_tick = ((phx_ki32_t)(uintptr_t)fld<int32_t>(sp, F_ENV_TICK))[b];
@@ -799,6 +802,8 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
       const int a = act_list[it], s = tp.strat_rank[a];
       const bool has = s >= 0 && actions_b && (!av_b || av_b[s]);            // aid in actions, env.py:330
       // (an item without a message still decodes its action: the mock agents count decode_action calls)
+      // (off < 0: the schedule says this item sends nothing -- mock kinds that only count decode_action calls; q0 + 0 is then never written:
+      //  act_emit stores only when the kind emits, and a kind that emits has off >= 0 by construction of the schedule)
       act_emit(sp, tp, b, a, has, has ? actions_b[s] : 0.0f, exo_b, tick, q0 + (off < 0 ? 0 : off));
     }
     n = sch[1];

@@ -65,8 +65,14 @@ __host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_
        + items * 4 * 2;                                          // staged action (drawn one iteration before it is stored), double-buffered
 }
 
-#define SW_TABLE_BYTES (101 * 32 * 4 + 32 * 32 * 4 + 401 * 8 * 4 + 128 + 15632)
-static_assert(SW_TABLE_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
+// the host-built table image: BASE values of the three value tables (replicated per LDS bank inside the kernel), then the digit
+// sums and the order sums exactly as they sit in LDS
+#define SW_IMG_TABS 0                          /* f32 [104]: stock / 100                      */
+#define SW_IMG_TABN 104                        /* f32 [32]:  x / norm                         */
+#define SW_IMG_RTAB 136                        /* f32 [404]: f32(n / 10), n = index - 100     */
+#define SW_IMG_BASE_BYTES ((104 + 32 + 404) * 4)
+#define SW_TABLE_BYTES (SW_IMG_BASE_BYTES + 128 + 15632)
+static_assert(SW_IMG_BASE_BYTES % 16 == 0 && SW_TABLE_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
 
 typedef const __attribute__((address_space(4))) char* sw_kptr_t;
 #define a (*(const SwArgs*)kp)
@@ -131,17 +137,21 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const uint32_t el = nS == 1 ? pt : __umulhi(pt, a.mS);               // (r0 + tid) / S
     if (tid < G) { x = a.stock[g_base + tid]; step = a.env_step[b_first + el]; }
     if (tid < n_env) tk = a.env_tick[b_first + tid];
-    // the tables: a straight copy of the host-built image (L2-resident after the first workgroups), loads issued before anything waits
+    // the tables: the host-built image (17.9 KB, L2-resident after the first workgroups), loads issued before anything waits.  Digit
+    // and order sums go where they live; the base values of the three value tables go to a scratch area (the staging tile, unused
+    // until the first output phase) and are replicated per LDS bank after the barrier.  (The replicated tables as a 45.6 KB image
+    // cost every workgroup ~2.4 k more cycles of setup: ~11 bytes per cycle and CU when all 256 workgroups fetch at once.)
     {
-      constexpr int NP = SW_TABLE_BYTES / 16;
-      float4* dstp = (float4*)smem;
-      constexpr int NV = 3;                                             // 1 024 threads: one pass
+      constexpr int NP = SW_TABLE_BYTES / 16, NB = SW_IMG_BASE_BYTES / 16;
+      float4* const scratch = (float4*)s_out0;
+      float4* const sums = (float4*)s_ds;
+      constexpr int NV = 2;                                             // 1 024 threads: one pass
       float4 v[NV];
       for (int base = 0; base < NP; base += NV * NT) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) v[k] = a.tables[i]; }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) dstp[i] = v[k]; }
+        for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) { if (i < NB) scratch[i] = v[k]; else sums[i - NB] = v[k]; } }
       }
     }
     if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
@@ -149,6 +159,12 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     STICK(6);
     __syncthreads();
     STICK(7);
+    {
+      const float* const bv = (const float*)s_out0;                      // entry v of copy c at dword v * copies + c
+      for (int i = tid; i < 101 * 32; i += NT) s_tabs[i] = bv[SW_IMG_TABS + (i >> 5)];
+      for (int i = tid; i < 32 * 32; i += NT) s_tabn[i] = bv[SW_IMG_TABN + (i >> 5)];
+      for (int i = tid; i < 401 * 8; i += NT) s_rtab[i] = bv[SW_IMG_RTAB + (i >> 3)];
+    }
     if (tid < n_env) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
     if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
     __syncthreads();
@@ -486,19 +502,18 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #undef SW_REFRESH
 
 // ---- host: tables, plan, launcher -----------------------------------------------------------------------------------
-// The first 45 616 bytes of a workgroup's LDS: the replicated observation tables, the reward table, the digit sums.  Built ONCE per
-// env on the host with the same f32 / f64 operations (phx_create uploads it) -- computing them in every workgroup cost ~5 k
-// cycles of setup per launch.
+// The kernel's tables -- base values of the observation and reward tables, digit sums, order sums -- built ONCE per env on the host with
+// the same f32 / f64 operations (phx_create uploads the 17.9 KB image): computing them in every workgroup cost ~5 k cycles of setup.
 void phx_sc_sw_tables(int K, int norm, std::vector<uint8_t>* out) {
   out->assign(SW_TABLE_BYTES, 0);
-  float* tabs = (float*)out->data(); float* tabn = tabs + 101 * 32; float* rtab = tabn + 32 * 32;
-  uint8_t* ds = (uint8_t*)(rtab + 401 * 8); uint8_t* dtab = ds + 128;
-  for (int i = 0; i < 101 * 32; ++i) tabs[i] = (float)(i >> 5) / (float)PHX_SHOP_MAX_STOCK;    // IEEE f32 division (shop_obs_f32)
-  for (int i = 0; i < 32 * 32; ++i) tabn[i] = (float)(i >> 5) / (float)norm;
-  for (int i = 0; i < 401 * 8; ++i) {
-    const int n = (i >> 3) - 100, sl = n >= 0 ? (n + 9) / 10 : 0, st = 10 * sl - n;               // a (sales, stock) pair with 10 * sales - stock == n
+  float* base = (float*)out->data();
+  uint8_t* ds = out->data() + SW_IMG_BASE_BYTES; uint8_t* dtab = ds + 128;
+  for (int v = 0; v <= PHX_SHOP_MAX_STOCK; ++v) base[SW_IMG_TABS + v] = (float)v / (float)PHX_SHOP_MAX_STOCK;    // IEEE f32 division (shop_obs_f32)
+  for (int v = 0; v < 32; ++v) base[SW_IMG_TABN + v] = (float)v / (float)norm;
+  for (int i = 0; i < 401; ++i) {
+    const int n = i - 100, sl = n >= 0 ? (n + 9) / 10 : 0, st = 10 * sl - n;                    // a (sales, stock) pair with 10 * sales - stock == n
     volatile double pen = 0.1 * (double)st;                                                      // product and difference rounded separately (shop_reward)
-    rtab[i] = (float)((double)sl - pen);
+    base[SW_IMG_RTAB + i] = (float)((double)sl - pen);
   }
   for (int k = 0; k < 125; ++k) ds[k] = (uint8_t)(k % 5 + (k / 5) % 5 + k / 25);
   int n5 = 1; for (int k = 0; k < K; ++k) n5 *= 5;
