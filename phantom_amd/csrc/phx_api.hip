@@ -660,6 +660,7 @@ extern "C++" const DevKnobs& phx_knobs() {
     k.sw_generic = rd("PHX_SW_GENERIC", 0);
     k.sw_store_waves = rd("PHX_SW_STORE_WAVES", 0);
     k.sw_tc = rd("PHX_SW_TC", 0);
+    k.sw_small = rd("PHX_SW_SMALL", 4);
     k.sw_work_waves = rd("PHX_SW_WORK_WAVES", 0);
     return k;
   }();

@@ -75,6 +75,7 @@ struct DevKnobs {
   int sw_generic;              // PHX_SW_GENERIC (default 0)
   int sw_store_waves;          // PHX_SW_STORE_WAVES (default 0)
   int sw_tc;                   // PHX_SW_TC (default 0)
+  int sw_small;                // PHX_SW_SMALL: rows of the two short chunks at the head of a fragment (default 4; 0: none)
   int sw_work_waves;           // PHX_SW_WORK_WAVES (default 0)
 };
 const DevKnobs& phx_knobs();

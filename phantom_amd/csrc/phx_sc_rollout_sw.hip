@@ -32,7 +32,7 @@
 #include <vector>
 
 struct SwArgs {
-  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
+  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows, n_small;   // the first n_small chunks have first_rows rows each (a short pipeline fill), the others TC
   int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
   int32_t dtab_n;                       // 5^K entries of the order-sum table
   int32_t alt_order;                    // every other worker wave draws before it computes outputs
@@ -42,6 +42,7 @@ struct SwArgs {
   uint64_t seed; int64_t env_offset;
   int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_arrive;
   unsigned long long* timing;           // PHX_TIMING builds only
+  unsigned long long* rt; int32_t launch_idx;   // PHX_TIMING builds only: 100 MHz wall-clock stamps per workgroup and launch
   const float4* tables;                 // the host-built image of the table sections (phx_sc_sw_tables)
   phx_rollout_io io;
 };
@@ -75,6 +76,12 @@ __host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_
 static_assert(SW_IMG_BASE_BYTES % 16 == 0 && SW_TABLE_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
 
 typedef const __attribute__((address_space(4))) char* sw_kptr_t;
+#ifdef SW_NT_STORES      /* development A/B: trajectory stores that bypass the L2 */
+typedef float sw_f4v __attribute__((ext_vector_type(4)));
+#define SW_ST(p, v) do { const float4 v_ = (v); __builtin_nontemporal_store((sw_f4v){v_.x, v_.y, v_.z, v_.w}, (sw_f4v*)(p)); } while (0)
+#else
+#define SW_ST(p, v) (*(float4*)(p) = (v))
+#endif
 #define a (*(const SwArgs*)kp)
 #define io (a.io)
 #define SW_REFRESH() asm volatile("" : "+s"(kp))
@@ -124,6 +131,12 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   const int rec_threads = (GT ? NREC : a.n_rec_waves) << 6, store_first = rec_threads, work_first = rec_threads + (n_store_waves << 6);
 #ifdef PHX_TIMING
   unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+  unsigned long long rts[8]; rts[6] = rts[7] = 0; rts[0] = __builtin_amdgcn_s_memrealtime();
+#define RSTAMP(k) do { rts[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RSTAMP(k) do {} while (0)
+#endif
+#if defined(PHX_TIMING) && !defined(PHX_RT_ONLY)     /* PHX_RT_ONLY: the wall-clock stamps alone (six per workgroup: no perturbation to speak of) */
 #define STICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tprev; tprev = now_; } while (0)
 #else
 #define STICK(k) do {} while (0)
@@ -155,28 +168,45 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       }
     }
     if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
-    if (tid < 4) s_flags[tid] = 0;
+    if (tid < n_env) s_tick0[tid] = tk;
+    // launch-wide flags without a zeroing pass: the waves that can hold a pair or an env (the first four) publish theirs
+    {
+      const bool f0 = tid < n_env && (tk & 3) != 0;                                       // a tick that is not a multiple of 4
+      const bool f1 = tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK;              // a stock outside [0, 100]
+      const int wf = (__ballot(f0) != 0ull ? 1 : 0) | (__ballot(f1) != 0ull ? 2 : 0);
+      if ((tid & 63) == 0 && tid < 256) s_flags[tid >> 6] = wf;
+    }
     STICK(6);
     __syncthreads();
     STICK(7);
-    {
-      const float* const bv = (const float*)s_out0;                      // entry v of copy c at dword v * copies + c
-      for (int i = tid; i < 101 * 32; i += NT) s_tabs[i] = bv[SW_IMG_TABS + (i >> 5)];
-      for (int i = tid; i < 32 * 32; i += NT) s_tabn[i] = bv[SW_IMG_TABN + (i >> 5)];
-      for (int i = tid; i < 401 * 8; i += NT) s_rtab[i] = bv[SW_IMG_RTAB + (i >> 3)];
-    }
-    if (tid < n_env) { s_tick0[tid] = tk; if (tk & 3) s_flags[0] = 1; }
-    if (tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK) s_flags[1] = 1;
-    __syncthreads();
   }
-  STICK(0);
-  const int quad_extra = s_flags[0];      // chunk starts are not quad-aligned for every env: one more row quad
-  const bool weird = s_flags[1] != 0;     // a stock the caller set outside [0, 100] (any step brings it back into range)
+  STICK(0); RSTAMP(1);
+  int launch_flags = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (k * 64 < NT) launch_flags |= s_flags[k];
+  // the value tables, one copy per LDS bank: written during the loop's first iteration by the waves that have nothing else to do
+  // there (recurrence and store waves); the outputs first read them two barriers later
+  auto replicate_tables = [&](int t, int nthr) __attribute__((always_inline)) {
+    // entry v of copy c at dword v * copies + c: the copies of one entry are contiguous -- one 4-byte read, 16-byte writes
+    const float* const bv = (const float*)s_out0;
+    float4* const w32 = (float4*)s_tabs;                                 // s_tabs [101][32] and s_tabn [32][32] are adjacent: 133 entries x 8 pieces
+    float4* const w8 = (float4*)s_rtab;                                  // [401][8]: 2 pieces per entry
+    constexpr int N32 = (101 + 32) * 8, N8 = 401 * 2;
+    for (int i = t; i < N32 + N8; i += nthr) {
+      const bool wide = i < N32;
+      const int e = wide ? i >> 3 : (i - N32) >> 1;
+      const float v = bv[wide ? (e < 101 ? SW_IMG_TABS + e : SW_IMG_TABN + (e - 101)) : SW_IMG_RTAB + e];
+      (wide ? w32 + i : w8 + (i - N32))[0] = make_float4(v, v, v, v);
+    }
+  };
+  const int quad_extra = launch_flags & 1;      // chunk starts are not quad-aligned for every env: one more row quad
+  const bool weird = (launch_flags & 2) != 0;   // a stock the caller set outside [0, 100] (any step brings it back into range)
 
   const int first_rows = a.first_rows;
-  const int n_chunks = 1 + (a.T - first_rows + TC - 1) / TC;
-  auto start_of = [&](int c) { return c == 0 ? 0 : first_rows + (c - 1) * TC; };
-  auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c == 0 ? first_rows : (left < TC ? left : TC); };
+  const int n_small = a.n_small, small_rows = n_small * first_rows;
+  const int n_chunks = n_small + (a.T - small_rows + TC - 1) / TC;
+  auto start_of = [&](int c) { return c < n_small ? c * first_rows : small_rows + (c - n_small) * TC; };
+  auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c < n_small ? first_rows : (left < TC ? left : TC); };
   const uint32_t utotal = (uint32_t)total;
 
   // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by the worker waves.
@@ -323,6 +353,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   const int ol_r0 = wt >= 0 ? (int)div_G4((uint32_t)wt) : 0, ol_gl0 = wt >= 0 ? (wt - ol_r0 * G4) << 2 : 0;
   auto outputs = [&](int c, int tc) __attribute__((always_inline)) {
     if (wt < 0) return;
+#ifdef SW_ABL_DSKIP
+    if (((threadIdx.x >> 6) & 3) == 3) return;      // dev ablation (wrong results): the workers of the SIMD that has three of them skip the outputs
+#endif
     // typed views indexed in whole 8- / 16-byte elements from the (16-byte aligned) start of the LDS: the compiler then
     // knows the alignment of every access (b64 reads, b128 writes) although the section offsets are run-time values
     const uint2* const t_rd = (const uint2*)smem + (((int)((const char*)s_rd0 - smem) + (c % 3) * items * 2) >> 3);
@@ -402,12 +435,12 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #pragma unroll
       for (int k = 0; k < 4; ++k) { o[k] = off; pc += dp; off += d_off; if (pc >= P) { pc -= P; off += wrap; } }
 #ifndef PHX_ABL_NOSTORE
-      *(float4*)(dst + (size_t)o[0]) = v0; *(float4*)(dst + (size_t)o[1]) = v1; *(float4*)(dst + (size_t)o[2]) = v2; *(float4*)(dst + (size_t)o[3]) = v3;
+      SW_ST(dst + (size_t)o[0], v0); SW_ST(dst + (size_t)o[1], v1); SW_ST(dst + (size_t)o[2], v2); SW_ST(dst + (size_t)o[3], v3);
 #endif
     }
     for (; q < n; q += dq, sp += dq) {
 #ifndef PHX_ABL_NOSTORE
-      *(float4*)(dst + (size_t)off) = sp[0];
+      SW_ST(dst + (size_t)off, sp[0]);
 #endif
       pc += dp; off += d_off;
       if (pc >= P) { pc -= P; off += wrap; }
@@ -443,34 +476,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #endif
   };
 
-  // ---- schedule.  it = -2: the workers draw chunk 0;  it = -1: recurrence(0) beside draws(1);  it >= 0:
-  //        workers: outputs(it), draws(it + 2) | recurrence lanes: recurrence(it + 1) | store waves: stores(it - 1), actions(it + 1)    one barrier
-  for (int it = -2; it <= n_chunks; ++it) {
-    SW_REFRESH();
-    const int co = it, cr = it + 1, cd = it + 2, cs = it - 1;
-    if (tid >= work_first) {
-      // workers.  Every other worker wave draws first: the output phase is LDS traffic, the draws are VALU work -- both
-      // spread over the iteration.  One call site per phase keeps the code small.
-      const bool draw_first = a.alt_order && ((wt >> 6) & 1) != 0;
-#pragma unroll 1
-      for (int ph = 0; ph < 2; ++ph) {
-        if ((ph == 0) == draw_first) { if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd); STICK(1); }
-        else { if (co >= 0 && co < n_chunks) outputs(co, rows_of(co)); STICK(2); }
-      }
-    } else if (tid < rec_threads) {
-      if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
-      STICK(3);
-    } else {
-      if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
-      if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
-      STICK(4);
-    }
-    sw_lds_barrier(); STICK(5);
-  }
-#ifdef PHX_TIMING
-  if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = tm[q];
-#endif
-  // ---- state after the fragment -----------------------------------------------------------------------------------
+  // ---- state after the fragment: written by the recurrence lanes as soon as the last chunk's chain is done (iteration n_chunks - 1,
+  //      beside the last output phase), not after the drain: the arrival counter's round trip would otherwise end the launch
+  auto finish = [&]() __attribute__((always_inline)) {
   if (tid < G) {
     const int64_t g = g_base + tid;
     const int R = fin_rd & 255, D = fin_rd >> 8;
@@ -495,6 +503,50 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       }
     }
   }
+  };
+
+  // ---- schedule.  it = -2: the workers draw chunk 0;  it = -1: recurrence(0) beside draws(1);  it >= 0:
+  //        workers: outputs(it), draws(it + 2) | recurrence lanes: recurrence(it + 1) | store waves: stores(it - 1), actions(it + 1)    one barrier
+  for (int it = -2; it <= n_chunks; ++it) {
+    SW_REFRESH();
+    if (it == 1) RSTAMP(2);
+    if (it == -1) RSTAMP(6);
+    if (it == 0) RSTAMP(7);
+    if (it == n_chunks) RSTAMP(3);
+    const int co = it, cr = it + 1, cd = it + 2, cs = it - 1;
+    if (tid >= work_first) {
+      // workers.  Every other worker wave draws first: the output phase is LDS traffic, the draws are VALU work -- both
+      // spread over the iteration.  One call site per phase keeps the code small.
+      #ifndef SW_ALT_SHIFT
+#define SW_ALT_SHIFT 6
+#endif
+      const bool draw_first = a.alt_order && ((wt >> SW_ALT_SHIFT) & 1) != 0;
+#pragma unroll 1
+      for (int ph = 0; ph < 2; ++ph) {
+        if ((ph == 0) == draw_first) { if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd); STICK(1); }
+        else { if (co >= 0 && co < n_chunks) outputs(co, rows_of(co)); STICK(2); }
+      }
+    } else if (tid < rec_threads) {
+      if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
+      else if (it == -2) replicate_tables(tid, work_first);
+      else if (cr == n_chunks) finish();
+      STICK(3);
+    } else {
+      if (it == -2) replicate_tables(tid, work_first);
+      if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
+      if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
+      STICK(4);
+    }
+    sw_lds_barrier(); STICK(5);
+  }
+  RSTAMP(4);
+#ifdef PHX_TIMING
+  if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = tm[q];
+#endif
+#ifdef PHX_TIMING
+  RSTAMP(5);
+  if (a.rt && tid == 0) for (int q = 0; q < 8; ++q) a.rt[((int64_t)(a.launch_idx & 3) * 8192 + blockIdx.x) * 8 + q] = rts[q];
+#endif
 }
 
 #undef a
@@ -591,7 +643,11 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.pK = (uint32_t)p.dtab_n; a.inv_pK = inv[p.K];
   a.mG = sw_magic32(p.G); a.mG4 = sw_magic32(p.G / 4); a.mS = sw_magic32(sp.S); a.mPO = sw_magic32(3 * (p.G / 4)); a.mPF = p.G / 16 > 1 ? sw_magic32(p.G / 16) : 0;     // (the magic of 1 does not fit 32 bits: 0 = no division)
   a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset;
-  a.first_rows = io.T <= p.tc ? io.T : p.tc;
+  // Chunk geometry.  The first store leaves three iterations after the first draw: two short chunks at the head fill the pipeline in
+  // a quarter of the time (and leave a short ragged chunk at the tail, a shorter drain); fragments of a few chunks keep one geometry.
+  const int small = phx_knobs().sw_small;           // rows of a short head chunk (multiple of 4; 0: none)
+  if (small > 0 && small < p.tc && small % 4 == 0 && io.T >= 2 * small + p.tc) { a.first_rows = small; a.n_small = 2; }
+  else { a.first_rows = io.T <= p.tc ? io.T : p.tc; a.n_small = 1; }
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
@@ -600,6 +656,13 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
 #ifdef PHX_TIMING
   { static unsigned long long* tbuf = nullptr; if (!tbuf) { (void)hipMalloc((void**)&tbuf, 8 * 16 * 8192 * sizeof(unsigned long long)); (void)hipMemset(tbuf, 0, 8 * 16 * 8192 * sizeof(unsigned long long)); } a.timing = grid.x <= 8192 ? tbuf : nullptr;
+    { static unsigned long long* rbuf = nullptr; static int li = 0; if (!rbuf) (void)hipMalloc((void**)&rbuf, 4 * 8192 * 8 * sizeof(unsigned long long)); a.rt = grid.x <= 8192 ? rbuf : nullptr; a.launch_idx = li++;
+      if (getenv("PHX_TIMING_DUMP") && li == 44) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(4 * 8192 * 8); (void)hipMemcpy(h.data(), rbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        // launches 40..42 (slots 0..2): stamps in 10 ns ticks relative to the earliest entry of launch 40
+        unsigned long long base = ~0ull; for (unsigned b = 0; b < grid.x; ++b) base = std::min(base, h[((size_t)0 * 8192 + b) * 8]);
+        const char* nm[8] = {"entry", "setup done", "it 1 (first stores)", "it n_chunks (drain)", "loop done", "end", "it -1", "it 0"};
+        for (int l = 0; l < 3; ++l) for (int q : {0, 1, 6, 7, 2, 3, 4, 5}) { double mn = 1e30, mx = -1e30, sum = 0; for (unsigned b = 0; b < grid.x; ++b) { const double v = (double)(long long)(h[((size_t)l * 8192 + b) * 8 + q] - base) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+          fprintf(stderr, "SW_RT launch %d  %-22s min %8.2f  mean %8.2f  max %8.2f us\n", 40 + l, nm[q], mn, sum / grid.x, mx); } } }
     if (getenv("PHX_TIMING_DUMP")) { static int calls = 0; if (++calls == 20 && a.timing) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(8 * 16 * 8192); (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
       const char* role[3] = {"rec  ", "store", "work "}; const int nwv = p.nt / 64;
       for (int r = 0; r < 3; ++r) { double sum[8] = {0}; int n = 0;
