@@ -656,11 +656,9 @@ extern "C++" const DevKnobs& phx_knobs() {
     k.stk_rollout_nt = rd("PHX_STK_ROLLOUT_NT", 0);
     k.stk_step_fast = rd("PHX_STK_STEP_FAST", 1);
     k.stk_step_nt = rd("PHX_STK_STEP_NT", 0);
-    k.sw_alt = rd("PHX_SW_ALT", 1);
     k.sw_generic = rd("PHX_SW_GENERIC", 0);
     k.sw_store_waves = rd("PHX_SW_STORE_WAVES", 0);
     k.sw_tc = rd("PHX_SW_TC", 0);
-    k.sw_small = rd("PHX_SW_SMALL", 4);
     k.sw_work_waves = rd("PHX_SW_WORK_WAVES", 0);
     return k;
   }();

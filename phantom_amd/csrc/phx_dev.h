@@ -71,11 +71,9 @@ struct DevKnobs {
   int stk_rollout_nt;          // PHX_STK_ROLLOUT_NT (default 0)
   int stk_step_fast;           // PHX_STK_STEP_FAST (default 1)
   int stk_step_nt;             // PHX_STK_STEP_NT (default 0)
-  int sw_alt;                  // PHX_SW_ALT (default 1)
   int sw_generic;              // PHX_SW_GENERIC (default 0)
   int sw_store_waves;          // PHX_SW_STORE_WAVES (default 0)
   int sw_tc;                   // PHX_SW_TC (default 0)
-  int sw_small;                // PHX_SW_SMALL: rows of the two short chunks at the head of a fragment (default 4; 0: none)
   int sw_work_waves;           // PHX_SW_WORK_WAVES (default 0)
 };
 const DevKnobs& phx_knobs();

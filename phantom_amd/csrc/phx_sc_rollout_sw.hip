@@ -32,10 +32,9 @@
 #include <vector>
 
 struct SwArgs {
-  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows, n_small;   // the first n_small chunks have first_rows rows each (a short pipeline fill), the others TC
+  int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
   int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
   int32_t dtab_n;                       // 5^K entries of the order-sum table
-  int32_t alt_order;                    // every other worker wave draws before it computes outputs
   uint32_t pK; float inv_pK;            // 5^K and its f32 reciprocal
   uint32_t mG, mG4, mS, mPO, mPF;       // ceil(2^32 / d) magics: i / G, i / (G / 4), i / S, i / (3 G / 4), i / (G / 16)   for i < 2^16
   int32_t norm;
@@ -76,12 +75,11 @@ __host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_
 static_assert(SW_IMG_BASE_BYTES % 16 == 0 && SW_TABLE_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
 
 typedef const __attribute__((address_space(4))) char* sw_kptr_t;
-#ifdef SW_NT_STORES      /* development A/B: trajectory stores that bypass the L2 */
+// Trajectory stores are NON-TEMPORAL: a store wave writes whole 128-byte lines (64 consecutive 16-byte pieces per instruction), nothing
+// reads the fragment during the launch, and lines that bypass the L2 are not left to be written back at the end of the kernel
+// (measured: 1-2 us per T = 400 launch; round 2's kernel, whose lanes wrote partial lines, was twice as slow with such stores).
 typedef float sw_f4v __attribute__((ext_vector_type(4)));
-#define SW_ST(p, v) do { const float4 v_ = (v); __builtin_nontemporal_store((sw_f4v){v_.x, v_.y, v_.z, v_.w}, (sw_f4v*)(p)); } while (0)
-#else
-#define SW_ST(p, v) (*(float4*)(p) = (v))
-#endif
+__device__ __forceinline__ void sw_store16(char* p, const float4 v) { __builtin_nontemporal_store((sw_f4v){v.x, v.y, v.z, v.w}, (sw_f4v*)p); }
 #define a (*(const SwArgs*)kp)
 #define io (a.io)
 #define SW_REFRESH() asm volatile("" : "+s"(kp))
@@ -203,10 +201,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   const bool weird = (launch_flags & 2) != 0;   // a stock the caller set outside [0, 100] (any step brings it back into range)
 
   const int first_rows = a.first_rows;
-  const int n_small = a.n_small, small_rows = n_small * first_rows;
-  const int n_chunks = n_small + (a.T - small_rows + TC - 1) / TC;
-  auto start_of = [&](int c) { return c < n_small ? c * first_rows : small_rows + (c - n_small) * TC; };
-  auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c < n_small ? first_rows : (left < TC ? left : TC); };
+  // (two SHORT chunks at the head to fill the pipeline sooner were measured: every iteration costs ~1.2 us whatever its rows, +1-2 us)
+  const int n_chunks = 1 + (a.T - first_rows + TC - 1) / TC;
+  auto start_of = [&](int c) { return c == 0 ? 0 : first_rows + (c - 1) * TC; };
+  auto rows_of = [&](int c) { const int left = a.T - start_of(c); return c == 0 ? first_rows : (left < TC ? left : TC); };
   const uint32_t utotal = (uint32_t)total;
 
   // ---- draws of the chunk starting at step t0 (tc rows) into tile `buf`, by the worker waves.
@@ -353,9 +351,6 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   const int ol_r0 = wt >= 0 ? (int)div_G4((uint32_t)wt) : 0, ol_gl0 = wt >= 0 ? (wt - ol_r0 * G4) << 2 : 0;
   auto outputs = [&](int c, int tc) __attribute__((always_inline)) {
     if (wt < 0) return;
-#ifdef SW_ABL_DSKIP
-    if (((threadIdx.x >> 6) & 3) == 3) return;      // dev ablation (wrong results): the workers of the SIMD that has three of them skip the outputs
-#endif
     // typed views indexed in whole 8- / 16-byte elements from the (16-byte aligned) start of the LDS: the compiler then
     // knows the alignment of every access (b64 reads, b128 writes) although the section offsets are run-time values
     const uint2* const t_rd = (const uint2*)smem + (((int)((const char*)s_rd0 - smem) + (c % 3) * items * 2) >> 3);
@@ -428,19 +423,23 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     uint32_t pc = q - r0_ * P, off = r0_ * rb + pc * 16u;
     const uint32_t d_off = dr * rb + dp * 16u, wrap = rb - P * 16u;
     const float4* sp = (const float4*)src + q;
-    // four pieces per trip: the LDS reads are issued together (one round trip), then the four stores
-    for (; q + 3u * dq < n; q += 4u * dq, sp += 4u * dq) {
-      const float4 v0 = sp[0], v1 = sp[dq], v2 = sp[2u * dq], v3 = sp[3u * dq];
-      uint32_t o[4];
+    // SW_DEPTH pieces per trip: the LDS reads are issued together (one round trip), then the stores (6 or 8 per trip: no faster)
+    constexpr int SW_DEPTH = 4;
+    for (; q + (uint32_t)(SW_DEPTH - 1) * dq < n; q += (uint32_t)SW_DEPTH * dq, sp += (uint32_t)SW_DEPTH * dq) {
+      float4 v[SW_DEPTH];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { o[k] = off; pc += dp; off += d_off; if (pc >= P) { pc -= P; off += wrap; } }
+      for (int k = 0; k < SW_DEPTH; ++k) v[k] = sp[(uint32_t)k * dq];
+      uint32_t o[SW_DEPTH];
+#pragma unroll
+      for (int k = 0; k < SW_DEPTH; ++k) { o[k] = off; pc += dp; off += d_off; if (pc >= P) { pc -= P; off += wrap; } }
 #ifndef PHX_ABL_NOSTORE
-      SW_ST(dst + (size_t)o[0], v0); SW_ST(dst + (size_t)o[1], v1); SW_ST(dst + (size_t)o[2], v2); SW_ST(dst + (size_t)o[3], v3);
+#pragma unroll
+      for (int k = 0; k < SW_DEPTH; ++k) sw_store16(dst + (size_t)o[k], v[k]);
 #endif
     }
     for (; q < n; q += dq, sp += dq) {
 #ifndef PHX_ABL_NOSTORE
-      SW_ST(dst + (size_t)off, sp[0]);
+      sw_store16(dst + (size_t)off, sp[0]);
 #endif
       pc += dp; off += d_off;
       if (pc >= P) { pc -= P; off += wrap; }
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         // bytes equal to rr -> 1 (exact zero-byte test of e ^ rrrr; rows are < 128, 255 = no episode end)
         auto eq = [&](uint32_t w) { const uint32_t z = w ^ rrrr; return (~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu)) >> 7; };
         const uint4 v = make_uint4(eq(e.x), eq(e.y), eq(e.z), eq(e.w));
-        *(uint4*)(p_tru + (size_t)(rr * utotal + pc * 16u)) = v;
+        *(uint4*)(p_tru + (size_t)(rr * utotal + pc * 16u)) = v;      // (plain stores: a flag row of the block is G bytes, not whole lines)
         if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
@@ -509,23 +508,23 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   //        workers: outputs(it), draws(it + 2) | recurrence lanes: recurrence(it + 1) | store waves: stores(it - 1), actions(it + 1)    one barrier
   for (int it = -2; it <= n_chunks; ++it) {
     SW_REFRESH();
+#ifdef PHX_RT_FILL
+#define RSTAMP_WORK() do { if (it >= -2 && it <= 2) RSTAMP(it + 4); } while (0)      /* slots 2..6: own work of iterations -2..2 done (before the barrier) */
+    if (it == 3) RSTAMP(7);
+#else
+#define RSTAMP_WORK() do {} while (0)
     if (it == 1) RSTAMP(2);
     if (it == -1) RSTAMP(6);
     if (it == 0) RSTAMP(7);
     if (it == n_chunks) RSTAMP(3);
+#endif
     const int co = it, cr = it + 1, cd = it + 2, cs = it - 1;
     if (tid >= work_first) {
-      // workers.  Every other worker wave draws first: the output phase is LDS traffic, the draws are VALU work -- both
-      // spread over the iteration.  One call site per phase keeps the code small.
-      #ifndef SW_ALT_SHIFT
-#define SW_ALT_SHIFT 6
-#endif
-      const bool draw_first = a.alt_order && ((wt >> SW_ALT_SHIFT) & 1) != 0;
-#pragma unroll 1
-      for (int ph = 0; ph < 2; ++ph) {
-        if ((ph == 0) == draw_first) { if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd); STICK(1); }
-        else { if (co >= 0 && co < n_chunks) outputs(co, rows_of(co)); STICK(2); }
-      }
+      // workers (letting every other worker wave draw first, so that LDS-heavy and VALU-heavy phases overlap on a SIMD, changes nothing)
+      if (co >= 0 && co < n_chunks) outputs(co, rows_of(co));
+      STICK(2);
+      if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd);
+      STICK(1);
     } else if (tid < rec_threads) {
       if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
       else if (it == -2) replicate_tables(tid, work_first);
@@ -537,15 +536,23 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
       STICK(4);
     }
+    RSTAMP_WORK();
     sw_lds_barrier(); STICK(5);
   }
+#ifndef PHX_RT_FILL
   RSTAMP(4);
+#endif
 #ifdef PHX_TIMING
   if (a.timing && (tid & 63) == 0) for (int q = 0; q < 8; ++q) a.timing[((int64_t)blockIdx.x * 16 + (tid >> 6)) * 8 + q] = tm[q];
 #endif
 #ifdef PHX_TIMING
+#ifdef PHX_RT_FILL
+  { const int role = tid == 0 ? 0 : (tid == store_first ? 1 : (tid == work_first ? 2 : -1));
+    if (a.rt && role >= 0) for (int q = 0; q < 8; ++q) a.rt[((int64_t)(a.launch_idx & 3) * 8192 + blockIdx.x * 3 + role) * 8 + q] = rts[q]; }
+#else
   RSTAMP(5);
   if (a.rt && tid == 0) for (int q = 0; q < 8; ++q) a.rt[((int64_t)(a.launch_idx & 3) * 8192 + blockIdx.x) * 8 + q] = rts[q];
+#endif
 #endif
 }
 
@@ -637,17 +644,11 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   const int remap_env = phx_knobs().rollout_remap;
   a.xcd_remap = remap_env >= 0 ? remap_env : 1;
   a.n_rec_waves = p.n_rec; a.n_store_waves = p.n_store; a.dtab_n = p.dtab_n;
-  const int alt_env = phx_knobs().sw_alt;
-  a.alt_order = alt_env;
   static const float inv[7] = {1.0f, 0.2f, 0.04f, 0.008f, 0.0016f, 0.00032f, 0.000064f};
   a.pK = (uint32_t)p.dtab_n; a.inv_pK = inv[p.K];
   a.mG = sw_magic32(p.G); a.mG4 = sw_magic32(p.G / 4); a.mS = sw_magic32(sp.S); a.mPO = sw_magic32(3 * (p.G / 4)); a.mPF = p.G / 16 > 1 ? sw_magic32(p.G / 16) : 0;     // (the magic of 1 does not fit 32 bits: 0 = no division)
   a.norm = p.norm; a.seed = sp.seed; a.env_offset = sp.env_offset;
-  // Chunk geometry.  The first store leaves three iterations after the first draw: two short chunks at the head fill the pipeline in
-  // a quarter of the time (and leave a short ragged chunk at the tail, a shorter drain); fragments of a few chunks keep one geometry.
-  const int small = phx_knobs().sw_small;           // rows of a short head chunk (multiple of 4; 0: none)
-  if (small > 0 && small < p.tc && small % 4 == 0 && io.T >= 2 * small + p.tc) { a.first_rows = small; a.n_small = 2; }
-  else { a.first_rows = io.T <= p.tc ? io.T : p.tc; a.n_small = 1; }
+  a.first_rows = io.T <= p.tc ? io.T : p.tc;
   a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES];
   a.missed = (int32_t*)sp.f[F_SHOP_MISSED]; a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED];
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
@@ -656,13 +657,22 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
 #ifdef PHX_TIMING
   { static unsigned long long* tbuf = nullptr; if (!tbuf) { (void)hipMalloc((void**)&tbuf, 8 * 16 * 8192 * sizeof(unsigned long long)); (void)hipMemset(tbuf, 0, 8 * 16 * 8192 * sizeof(unsigned long long)); } a.timing = grid.x <= 8192 ? tbuf : nullptr;
-    { static unsigned long long* rbuf = nullptr; static int li = 0; if (!rbuf) (void)hipMalloc((void**)&rbuf, 4 * 8192 * 8 * sizeof(unsigned long long)); a.rt = grid.x <= 8192 ? rbuf : nullptr; a.launch_idx = li++;
+    { static unsigned long long* rbuf = nullptr; static int li = 0; if (!rbuf) (void)hipMalloc((void**)&rbuf, (4 * 8192 * 8) * sizeof(unsigned long long)); a.rt = grid.x <= 8192 ? rbuf : nullptr; a.launch_idx = li++;
       if (getenv("PHX_TIMING_DUMP") && li == 44) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(4 * 8192 * 8); (void)hipMemcpy(h.data(), rbuf, h.size() * 8, hipMemcpyDeviceToHost);
+#ifdef PHX_RT_FILL
+        { const char* rn[3] = {"rec", "store", "work"}; const char* nm2[8] = {"entry", "setup done", "it -2 work done", "it -1 work done", "it 0 work done", "it 1 work done", "it 2 work done", "it 3 starts"};
+          for (int r = 0; r < 3; ++r) for (int q = 1; q < 8; ++q) { double sum = 0, mx = 0; for (unsigned b = 0; b < grid.x; ++b) { const unsigned long long* e = &h[((size_t)1 * 8192 + b * 3 + r) * 8]; const double v = (double)(long long)(e[q] - e[0]) * 0.01; sum += v; mx = std::max(mx, v); }
+            fprintf(stderr, "SW_RTF launch 41 %-5s %-18s mean %7.2f max %7.2f us after the workgroup's entry\n", rn[r], nm2[q], sum / grid.x, mx); } }
+#endif
         // launches 40..42 (slots 0..2): stamps in 10 ns ticks relative to the earliest entry of launch 40
         unsigned long long base = ~0ull; for (unsigned b = 0; b < grid.x; ++b) base = std::min(base, h[((size_t)0 * 8192 + b) * 8]);
         const char* nm[8] = {"entry", "setup done", "it 1 (first stores)", "it n_chunks (drain)", "loop done", "end", "it -1", "it 0"};
         for (int l = 0; l < 3; ++l) for (int q : {0, 1, 6, 7, 2, 3, 4, 5}) { double mn = 1e30, mx = -1e30, sum = 0; for (unsigned b = 0; b < grid.x; ++b) { const double v = (double)(long long)(h[((size_t)l * 8192 + b) * 8 + q] - base) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
-          fprintf(stderr, "SW_RT launch %d  %-22s min %8.2f  mean %8.2f  max %8.2f us\n", 40 + l, nm[q], mn, sum / grid.x, mx); } } }
+          fprintf(stderr, "SW_RT launch %d  %-22s min %8.2f  mean %8.2f  max %8.2f us\n", 40 + l, nm[q], mn, sum / grid.x, mx); }
+        // launch 41 by XCD (workgroup b runs on XCD b % 8): entry and end, relative to the launch's earliest entry
+        { unsigned long long b1 = ~0ull; for (unsigned b = 0; b < grid.x; ++b) b1 = std::min(b1, h[((size_t)1 * 8192 + b) * 8]);
+          for (int xc = 0; xc < 8; ++xc) { double se = 0, sx = 0, mxx = 0, mnx = 1e30; int n = 0; for (unsigned b = xc; b < grid.x; b += 8) { const unsigned long long* e = &h[((size_t)1 * 8192 + b) * 8]; const double en = (double)(long long)(e[0] - b1) * 0.01, ex = (double)(long long)(e[5] - b1) * 0.01; se += en; sx += ex; mxx = std::max(mxx, ex); mnx = std::min(mnx, ex); ++n; }
+            fprintf(stderr, "SW_RT launch 41 XCD %d: entry mean %6.2f | end min %6.2f mean %6.2f max %6.2f us\n", xc, se / n, mnx, sx / n, mxx); } } } }
     if (getenv("PHX_TIMING_DUMP")) { static int calls = 0; if (++calls == 20 && a.timing) { (void)hipDeviceSynchronize(); std::vector<unsigned long long> h(8 * 16 * 8192); (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
       const char* role[3] = {"rec  ", "store", "work "}; const int nwv = p.nt / 64;
       for (int r = 0; r < 3; ++r) { double sum[8] = {0}; int n = 0;
