@@ -89,6 +89,10 @@ __device__ __forceinline__ void sw_store16(char* p, const float4 v) { __builtin_
 template <int TC, int GT, int NREC, int NSTORE, int NWORK>
 __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_) {
   sw_kptr_t kp = (sw_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  { uint32_t d0, d1, d2, d3, d4;          // every 64-byte line of the argument block into the scalar cache at once, not one miss per phase (setup 1.6 -> 1.2 us)
+    static_assert(sizeof(SwArgs) > 0x100 && sizeof(SwArgs) <= 0x180, "the offsets below cover the argument block line by line");
+    asm volatile("s_load_dword %0, %5, 0x0\n s_load_dword %1, %5, 0x40\n s_load_dword %2, %5, 0x80\n s_load_dword %3, %5, 0xc0\n s_load_dword %4, %5, 0x100\n s_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(kp) : "memory"); }
   SW_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, NT = GT ? 64 * (NREC + NSTORE + NWORK) : (int)blockDim.x, nS = a.S, G = GT ? GT : a.G;
@@ -156,14 +160,16 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       constexpr int NP = SW_TABLE_BYTES / 16, NB = SW_IMG_BASE_BYTES / 16;
       float4* const scratch = (float4*)s_out0;
       float4* const sums = (float4*)s_ds;
-      constexpr int NV = 2;                                             // 1 024 threads: one pass
-      float4 v[NV];
-      for (int base = 0; base < NP; base += NV * NT) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) v[k] = a.tables[i]; }
-#pragma unroll
-        for (int k = 0; k < NV; ++k) { const int i = base + k * NT + tid; if (i < NP) { if (i < NB) scratch[i] = v[k]; else sums[i - NB] = v[k]; } }
-      }
+      auto put = [&](int i, const float4 v) { if (i < NB) scratch[i] = v; else sums[i - NB] = v; };
+      // two named pieces per thread (1 024 threads: the whole image), both loads in flight before either is written; narrow
+      // workgroups loop over the rest.  (An indexed array of pieces here went through scratch memory, one load at a time.)
+      const int i0 = tid, i1 = tid + NT;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (i0 < NP) v0 = a.tables[i0];
+      if (i1 < NP) v1 = a.tables[i1];
+      if (i0 < NP) put(i0, v0);
+      if (i1 < NP) put(i1, v1);
+      for (int i = tid + 2 * NT; i < NP; i += NT) put(i, a.tables[i]);
     }
     if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
     if (tid < n_env) s_tick0[tid] = tk;
