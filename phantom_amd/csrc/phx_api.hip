@@ -1167,9 +1167,10 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   // typed shops (obs dim 4, per-env penalty weight) take the lane-per-pair kernel too
   if (e->d.env_type == PHX_ENV_FSM || e->d.any_typed) { HIPCHK(phx_launch_sc_rollout_fsm(e->d, *io, (hipStream_t)stream)); return PHX_OK; }
   if (e->d.sc_fast.ok && !io->actions && !io->exo && e->d.variant_rollout != PHX_VR_GENERAL) {
-    // the store-wave kernel where the caller asked for it, or (PHX_VR_AUTO) where a compile-time shape serves the env in one round of
-    // workgroups AND the fragment is long enough to amortise its deeper pipeline (T = 100: 24.4 us against 22.9; T = 400: 65 against 72-76)
-    if (e->d.sc_sw.ok && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 200)) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
+    // the store-wave kernel where the caller asked for it, or (PHX_VR_AUTO) where a compile-time shape serves the env and the fragment
+    // is longer than its pipeline fill (SC64, B = 4 096: T = 32 14.1 us either way, T = 50 14.7 against 16.4, T = 100 21.2 against
+    // 23.1, T = 400 57 against 72-76; several rounds of workgroups: B = 16 384 221 against 242; SC256, B = 8 192, T = 100: 195 against 204)
+    if (e->d.sc_sw.ok && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
     else HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
     return PHX_OK;
   }

@@ -606,7 +606,7 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   };
   auto tc_for = [&](int G) {
     if (tc_env == 16 || tc_env == 20) return tc_ok(G, tc_env) ? tc_env : 0;
-    if ((G == 144 || G == 96 || G == 48) && tc_ok(G, 16)) return 16;              // the shapes with a compile-time instantiation (16-row chunks)
+    if ((G == 144 || G == 128 || G == 96 || G == 48) && tc_ok(G, 16)) return 16;              // the shapes with a compile-time instantiation (16-row chunks)
     return tc_ok(G, 20) ? 20 : (tc_ok(G, 16) ? 16 : 0);
   };
   int G = 0;
@@ -635,8 +635,10 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   if (p->n_rec + p->n_store + work > 16) work = 16 - p->n_rec - p->n_store;
   p->nt = 64 * (p->n_rec + p->n_store + work);
   p->lds = (int32_t)sw_lds_bytes(G, p->epb, p->tc, dtab_n);
-  // one round of workgroups only: a workgroup per CU has nothing to hide its setup, pipeline fill and drain behind (~9 us per round)
-  p->specialised = (total / G <= 256 && p->tc == 16 && ((G == 144 && p->n_rec == 3 && work == 9 && (p->n_store == 4 || p->n_store == 2)) ||
+  // the shapes with a compile-time instantiation (any number of rounds of workgroups: a round of 144-pair workgroups costs the same
+  // whether it is the launch's only one or one of four -- B = 8 192 / 16 384: 113 / 221 us per T = 400 against 137 / 242)
+  p->specialised = (p->tc == 16 && ((G == 144 && p->n_rec == 3 && work == 9 && (p->n_store == 4 || p->n_store == 2)) ||
+                                    (G == 128 && p->n_rec == 2 && work == 8 && p->n_store == 4) ||
                                     (G == 96 && p->n_rec == 2 && work == 6 && (p->n_store == 4 || p->n_store == 2)) ||
                                     (G == 48 && p->n_rec == 1 && work == 3 && p->n_store == 2))) ? 1 : 0;
   p->ok = 1;
@@ -696,6 +698,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
 #define SW_SHAPE(G_, NREC_, NSTORE_, NWORK_) (p.tc == 16 && p.G == G_ && p.n_rec == NREC_ && p.n_store == NSTORE_ && work == NWORK_)
   if (!generic_env && SW_SHAPE(144, 3, 4, 9)) SW_LAUNCH(16, 144, 3, 4, 9);
   else if (!generic_env && SW_SHAPE(144, 3, 2, 9)) SW_LAUNCH(16, 144, 3, 2, 9);
+  else if (!generic_env && SW_SHAPE(128, 2, 4, 8)) SW_LAUNCH(16, 128, 2, 4, 8);
   else if (!generic_env && SW_SHAPE(96, 2, 4, 6)) SW_LAUNCH(16, 96, 2, 4, 6);
   else if (!generic_env && SW_SHAPE(96, 2, 2, 6)) SW_LAUNCH(16, 96, 2, 2, 6);
   else if (!generic_env && SW_SHAPE(48, 1, 2, 3)) SW_LAUNCH(16, 48, 1, 2, 3);
