@@ -149,6 +149,10 @@ def other_configs(device):
     tr = dev.rollout(100)
     add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 10), "fused FSM rollout T=100",
         bytes_per_env_step=24 * 51)                              # trajectory: obs 12 + action 4 + reward 4 + 4 flag bytes per shop
+    tr4 = dev.alloc_trajectory(400)                              # the headline's fragment length: start-up / drain paid once per 400 steps
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 5), "fused FSM rollout T=400",
+        bytes_per_env_step=24 * 51)
+    del tr4
     acts = torch.rand(8192, 51, device=dev.device) * 100.0
     # per env-step: S * (43 + K) + 6 with device-RNG orders (no exo term: S * 43 + 6), + stage and valid planes
     step_bytes = 51 * 43 + 6 + 2 * 51 + 2
@@ -170,7 +174,10 @@ def other_configs(device):
     tr = dev.rollout(100)
     add("SC256 B=8192 per GPU (config 4)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 10), "fused rollout T=100",
         bytes_per_env_step=22 * 51)
-    del env, dev, tr; torch.cuda.empty_cache()
+    tr4 = dev.alloc_trajectory(400)
+    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 5), "fused rollout T=400",
+        bytes_per_env_step=22 * 51)
+    del env, dev, tr, tr4; torch.cuda.empty_cache()
     # config 5: Stackelberg market 128 leaders / 1024 followers, B = 4096
     env = market_env(128, 1024, 8, 100, 4096, exogenous="device", device=device)
     env.reset(); dev = env._device()
