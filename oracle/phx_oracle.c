@@ -1321,6 +1321,7 @@ int64_t phxo_get_u8(const phxo_env* E, const char* field, uint8_t* out) {
 }
 int64_t phxo_set_i32(phxo_env* E, const char* field, const int32_t* in) {
   if (!strcmp(field, "env.tick")) { for (int b = 0; b < E->B; ++b) E->env[b].tick = (uint32_t)in[b]; return E->B; }
+  if (!strcmp(field, "env.step")) { for (int b = 0; b < E->B; ++b) E->env[b].step = in[b]; return E->B; }          /* tests: counters a caller moved */
   if (!strcmp(field, "env.episode")) { for (int b = 0; b < E->B; ++b) E->env[b].episode = in[b]; return E->B; }
   if (!strcmp(field, "env.stage")) { for (int b = 0; b < E->B; ++b) E->env[b].stage = in[b]; return E->B; }   /* tests: a stage off the default chain */
   const ofield* f = find_field(field);

@@ -1170,7 +1170,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     // the store-wave kernel where the caller asked for it, or (PHX_VR_AUTO) where a compile-time shape serves the env and the fragment
     // is longer than its pipeline fill (SC64, B = 4 096: T = 32 14.1 us either way, T = 50 14.7 against 16.4, T = 100 21.2 against
     // 23.1, T = 400 57 against 72-76; several rounds of workgroups: B = 16 384 221 against 242; SC256, B = 8 192, T = 100: 195 against 204)
-    if (e->d.sc_sw.ok && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
+    if (e->d.sc_sw.ok && io->T <= 0xFFFF && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
     else HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
     return PHX_OK;
   }

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
   uint16_t* s_rd0 = (uint16_t*)(s_flags + 4);                           // 3 x [TC][G]  R | D << 8                     (chunk c in c % 3)
   uint16_t* s_xx0 = s_rd0 + 3 * items;                                  // 2 x [TC][G]  stock before | stock after << 8 (chunk c in c & 1)
-  uint8_t* s_ptend0 = (uint8_t*)(s_xx0 + 2 * items);                    // 3 x [G] chunk row that ends the pair's episode, or 255
-  int* s_x0w = (int*)(s_ptend0 + 3 * G16p + 16);                        // [G] stocks at launch (used when one is outside [0, 100])
+  uint16_t* s_ftend = (uint16_t*)(s_xx0 + 2 * items);                   // [G] the row of the fragment that ends the pair's current episode (0xFFFF: none): the flag planes
+  int* s_x0w = (int*)((uint8_t*)s_ftend + 3 * G16p + 16);                        // [G] stocks at launch (used when one is outside [0, 100])
   float* s_out0 = (float*)(s_x0w + G4p);                                // 2 x { obs [TC][3 G], reward [TC][G] }   (chunk c in c & 1)
   float* s_act0 = s_out0 + 8 * items;                                   // 2 x [TC][G] action, drawn at iteration c - 2, stored at c - 1 (chunk c in c & 1)
 
@@ -171,13 +171,18 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       if (i1 < NP) put(i1, v1);
       for (int i = tid + 2 * NT; i < NP; i += NT) put(i, a.tables[i]);
     }
-    if (tid < G) { s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x; }
+    if (tid < G) {
+      s_pair[tid] = (pt - el * (uint32_t)nS) | (el << 8); s_x0w[tid] = x;
+      const int et = a.num_steps - 1 - step;
+      s_ftend[tid] = (uint16_t)((step < a.num_steps && et < 0xFFFF) ? et : 0xFFFF);      // (a counter >= num_steps never ends an episode: recurrence)
+    }
     if (tid < n_env) s_tick0[tid] = tk;
     // launch-wide flags without a zeroing pass: the waves that can hold a pair or an env (the first four) publish theirs
     {
       const bool f0 = tid < n_env && (tk & 3) != 0;                                       // a tick that is not a multiple of 4
       const bool f1 = tid < G && (unsigned)x > (unsigned)PHX_SHOP_MAX_STOCK;              // a stock outside [0, 100]
-      const int wf = (__ballot(f0) != 0ull ? 1 : 0) | (__ballot(f1) != 0ull ? 2 : 0);
+      const bool f2 = tid < G && step < 0;                                                // a step counter below zero
+      const int wf = (__ballot(f0) != 0ull ? 1 : 0) | (__ballot(f1) != 0ull ? 2 : 0) | (__ballot(f2) != 0ull ? 4 : 0);
       if ((tid & 63) == 0 && tid < 256) s_flags[tid >> 6] = wf;
     }
     STICK(6);
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   };
   const int quad_extra = launch_flags & 1;      // chunk starts are not quad-aligned for every env: one more row quad
   const bool weird = (launch_flags & 2) != 0;   // a stock the caller set outside [0, 100] (any step brings it back into range)
+  const bool neg_steps = (launch_flags & 4) != 0;   // a step counter the caller set below zero: its first episode end is num_steps - 1 - step rows away
 
   const int first_rows = a.first_rows;
   // (two SHORT chunks at the head to fill the pipeline sooner were measured: every iteration costs ~1.2 us whatever its rows, +1-2 us)
@@ -310,7 +316,6 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     __builtin_amdgcn_s_setprio(3);        // a dependent chain beside waves of Philox / output work: issue whenever ready
     uint16_t* rdw = s_rd0 + (c % 3) * items + tid;
     uint16_t* xx = s_xx0 + (c & 1) * items + tid;
-    s_ptend0[(c % 3) * G16p + tid] = (uint8_t)(ends ? tend : 255);
     if (tc == TC && !(weird && c == 0)) {   // straight-line code, the chunk's operands fetched in one burst
       int orig = 0;
       if (ends) { orig = rdw[tend * G]; rdw[tend * G] = 0xFF00; }
@@ -458,25 +463,44 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const float* const o_obs = s_out0 + (c & 1) * (4 * items);
     const float* const o_rew = o_obs + 3 * items;
     const int64_t row0 = (int64_t)t0 * total + g_base;
-    const uint32_t PO = 3u * (uint32_t)(G >> 2), PR = (uint32_t)(G >> 2), PF = (uint32_t)(G >> 4);
+    const uint32_t PO = 3u * (uint32_t)(G >> 2), PR = (uint32_t)(G >> 2);
     stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, div_PO, utotal * 12u);
     stream((char*)(io.reward + row0), o_rew, tc, PR, div_G4, utotal * 4u);
+  };
+
+  // ---- the flag planes, by the store waves while they have nothing to stream (iterations -2 .. 0: the pipeline fills, HBM is idle).
+  // truncations["__all__"] per shop (env.py:312-318) is a function of the env's step counter at launch and the row alone: row t ends a
+  // pair's episode <=> t == e + j num_steps, e = num_steps - 1 - step (s_ftend, set at setup); terminations are all zero
+  // (agents.py:292-323).  So the workgroup's G-byte segments of all T rows are written BEFORE the first chunk is streamed instead of
+  // with every chunk: on some boxes the two planes cost the steady state 8-10 us per launch (tools/ubench/ub_store10.hip, FLAGS 0 / 1).
+  auto flag_segments = [&](int part) __attribute__((always_inline)) {
 #ifndef PHX_ABL_NOSTORE
-    {                                       // truncations["__all__"] (env.py:312-318) per shop; terminations are all zero (agents.py:292-323)
-      const uint8_t* pe = s_ptend0 + (c % 3) * G16p;
-      char* const p_tru = (char*)(io.truncated + row0);
-      char* const p_ter = io.terminated ? (char*)(io.terminated + row0) : nullptr;
-      const uint32_t n = (uint32_t)tc * PF;
-      for (uint32_t q = (uint32_t)sl; q < n; q += (uint32_t)nsl) {
-        const uint32_t rr = div_PF(q), pc = q - rr * PF;
-        const uint4 e = *(const uint4*)(pe + 16u * pc);
-        const uint32_t rrrr = rr * 0x01010101u;
-        // bytes equal to rr -> 1 (exact zero-byte test of e ^ rrrr; rows are < 128, 255 = no episode end)
-        auto eq = [&](uint32_t w) { const uint32_t z = w ^ rrrr; return (~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu)) >> 7; };
-        const uint4 v = make_uint4(eq(e.x), eq(e.y), eq(e.z), eq(e.w));
-        *(uint4*)(p_tru + (size_t)(rr * utotal + pc * 16u)) = v;      // (plain stores: a flag row of the block is G bytes, not whole lines)
-        if (p_ter) *(uint4*)(p_ter + (size_t)(rr * utotal + pc * 16u)) = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t uT = (uint32_t)a.T, ns = (uint32_t)a.num_steps, PF = (uint32_t)(G >> 4);
+    const uint32_t r_lo = part == 0 ? 0u : (part == 1 ? (uT * 2u) / 5u : (uT * 13u) / 20u), r_hi = part == 0 ? (uT * 2u) / 5u : (part == 1 ? (uT * 13u) / 20u : uT);
+    const uint32_t n = (r_hi - r_lo) * PF;
+    const float inv_ns = 1.0f / (float)ns;
+    char* const p_tru = (char*)(io.truncated + g_base);
+    char* const p_ter = io.terminated ? (char*)(io.terminated + g_base) : nullptr;
+#pragma unroll 1
+    for (uint32_t f = (uint32_t)sl; f < n; f += (uint32_t)nsl) {
+      const uint32_t rr = div_PF(f), pc = f - rr * PF, t = r_lo + rr;
+      uint32_t x = t - (uint32_t)((float)t * inv_ns) * ns;                // t mod num_steps (t < 2^16: the f32 quotient is off by one at most)
+      if ((int)x < 0) x += ns;
+      if (x >= ns) x -= ns;
+      const uint4* const src = (const uint4*)(s_ftend + 16u * pc);
+      const uint4 ea = src[0], eb = src[1];
+      const uint32_t xx = x | (x << 16);
+      // two packed u16 -> two bytes: 1 where the half equals x
+      auto eq2 = [&](uint32_t w2) { const uint32_t z = w2 ^ xx; return ((z & 0xFFFFu) == 0u ? 1u : 0u) | ((z >> 16) == 0u ? 0x100u : 0u); };
+      uint4 v = make_uint4(eq2(ea.x) | (eq2(ea.y) << 16), eq2(ea.z) | (eq2(ea.w) << 16), eq2(eb.x) | (eq2(eb.y) << 16), eq2(eb.z) | (eq2(eb.w) << 16));
+      if (__builtin_expect(neg_steps, 0)) {                               // counters below zero: the general rule, byte by byte
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int b = 0; b < 16; ++b) { const uint32_t et = s_ftend[16u * pc + b]; if (et != 0xFFFFu && t >= et && (t - et) % ns == 0u) w[b >> 2] |= 1u << (8 * (b & 3)); }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
       }
+      const size_t off = (size_t)t * (size_t)utotal + (size_t)(pc * 16u);
+      *(uint4*)(p_tru + off) = v;                                          // (plain stores: a flag row of the block is G bytes, not whole lines)
+      if (p_ter) *(uint4*)(p_ter + off) = make_uint4(0u, 0u, 0u, 0u);
     }
 #endif
   };
@@ -538,6 +562,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       STICK(3);
     } else {
       if (it == -2) replicate_tables(tid, work_first);
+      if (it <= 0) flag_segments(it + 2);
       if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
       if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
       STICK(4);
@@ -592,7 +617,7 @@ static const size_t SW_LDS_MAX = 160 * 1024;
 // (0 = auto; > 0: pairs per workgroup, taken when it is a multiple of 16 that divides B * S).
 bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, ScSwPlan* p) {
   memset(p, 0, sizeof *p);
-  if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || block < 0) return false;
+  if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || block < 0 || num_steps >= 0xFFFF) return false;
   const int64_t total = (int64_t)B * S;
   if (total >= ((int64_t)1 << 24)) return false;                                  // 24-bit multiplies on (row, pair) offsets
   int dtab_n = 1; for (int k = 0; k < K_uniform; ++k) dtab_n *= 5;

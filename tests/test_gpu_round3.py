@@ -219,6 +219,30 @@ def test_plain_rollout_variants_match_oracle(S, K, B, num_steps, variants, kerne
         assert any(kernel in u for u in used), (kernel, used)
 
 
+@pytest.mark.parametrize("variants", [{"rollout": "store_waves"}, {"rollout": "store_waves", "block": 48}, {"rollout": "time_parallel"}],
+                         ids=["store_waves", "store_waves48", "time_parallel"])
+def test_rollout_with_step_counters_the_caller_moved(variants):
+    """The store-wave kernel writes the flag planes of the WHOLE fragment before it streams the first chunk, from the step counters it finds
+    at launch (row t ends a pair's episode <=> t == num_steps - 1 - step + j num_steps).  Counters a caller has moved -- ahead, behind,
+    below zero (the first end is further away), at or above num_steps (the episode never ends: env.py:298 tests equality) -- give the
+    oracle's trajectories all the same, also across several fragments and fragment lengths that are no multiple of anything."""
+    S, K, B, ns = 9, 6, 64, 23
+    env = supply_chain_env(S, [K] * S, ns, B, seed=5, env_offset=7, variants=variants)
+    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(99)
+    st = rng.integers(0, ns, B).astype(np.int32)
+    st[3], st[4], st[10], st[11], st[40] = -5, -40, ns, ns + 9, -1
+    o.set_i32("env.step", st); d.set_i32("env.step", st)
+    for T in (64, 41, 100, 7, 48):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp_rollout(rd, ro, False)
+        for f in ("shop.stock", "shop.sales", "env.step", "env.tick"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
+    if variants.get("block") != 48:
+        assert ("phx_sc_rollout_sw_kernel" if variants["rollout"] == "store_waves" else "phx_sc_rollout_fast_kernel") in d.dev.last_kernel()
+
+
 FSM_VARIANTS = [
     ({"rollout": "time_parallel"}, "phx_sc_rollout_fsmfast_kernel"),
     ({"rollout": "time_parallel", "block": 32}, "phx_sc_rollout_fsmfast_kernel[pairs]"),
