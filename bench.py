@@ -125,7 +125,9 @@ def other_configs(device):
     res = []
 
     def timed(fn, n):
-        fn(); torch.cuda.synchronize()
+        for _ in range(max(2, n // 4)):                          # (the first ~10 ms after idle run at ramping clocks: 63 against 53 us per SC64 launch)
+            fn()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
@@ -147,10 +149,10 @@ def other_configs(device):
                                exogenous="device", device=device)
     env.reset(); dev = env._device()
     tr = dev.rollout(100)
-    add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 10), "fused FSM rollout T=100",
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 40), "fused FSM rollout T=100",
         bytes_per_env_step=24 * 51)                              # trajectory: obs 12 + action 4 + reward 4 + 4 flag bytes per shop
     tr4 = dev.alloc_trajectory(400)                              # the headline's fragment length: start-up / drain paid once per 400 steps
-    add("SC256 FSM B=8192 (config 3)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 5), "fused FSM rollout T=400",
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 16), "fused FSM rollout T=400",
         bytes_per_env_step=24 * 51)
     del tr4
     acts = torch.rand(8192, 51, device=dev.device) * 100.0
@@ -172,10 +174,10 @@ def other_configs(device):
                             exogenous="device", device=device)
     env.reset(); dev = env._device()
     tr = dev.rollout(100)
-    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 10), "fused rollout T=100",
+    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 40), "fused rollout T=100",
         bytes_per_env_step=22 * 51)
     tr4 = dev.alloc_trajectory(400)
-    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 5), "fused rollout T=400",
+    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 16), "fused rollout T=400",
         bytes_per_env_step=22 * 51)
     del env, dev, tr, tr4; torch.cuda.empty_cache()
     # config 5: Stackelberg market 128 leaders / 1024 followers, B = 4096
