@@ -18,8 +18,9 @@
 //     trajectory rows (observation [TC][3 G] f32, reward [TC][G] f32; the f32 reward comes from a [101][32] table of the
 //     f64 expression, computed at setup) -- they never issue a trajectory store except the 4-byte action;
 //   * RECURRENCE waves (one lane per pair) walk the stock chain of chunk c + 1 and store stock before AND after each step;
-//   * STORE waves stream the staged tile of chunk c - 1 to HBM and write the flag planes DENSELY (whole 16-byte pieces:
-//     no zero-fill launch before the kernel, no partial lines) from the per-pair episode-end rows of the chunk.
+//   * STORE waves stream the staged tile of chunk c - 1 to HBM (non-temporal, whole 64-byte units); the flag planes of the WHOLE fragment
+//     they write before that, in the iterations in which the pipeline fills (dense 16-byte pieces, a closed form of the pairs' step
+//     counters at launch: no zero-fill launch before the kernel, no scattered flag stores in the steady state).
 // LDS: 10 bytes per item of tiles + 32 of staging (double-buffered) instead of 44 + nothing staged.
 #include "phx_dev.h"
 #include "phx_sc_fast.h"
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   uint8_t* s_dtab = s_ds + 128;                                         // [5^K <= 15625] digit sum of y: the customers' order sizes summed
   uint32_t* s_pair = (uint32_t*)(s_dtab + 15632);                       // [G] shop | env_local << 8
   int* s_tick0 = (int*)(s_pair + G4p);                                  // [epb]
-  int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [0] a tick is not a multiple of 4, [1] a stock outside [0, 100]
+  int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [4] per wave 0..3: bit 0 a tick is not a multiple of 4, 1 a stock outside [0, 100], 2 a step counter < 0
   uint16_t* s_rd0 = (uint16_t*)(s_flags + 4);                           // 3 x [TC][G]  R | D << 8                     (chunk c in c % 3)
   uint16_t* s_xx0 = s_rd0 + 3 * items;                                  // 2 x [TC][G]  stock before | stock after << 8 (chunk c in c & 1)
   uint16_t* s_ftend = (uint16_t*)(s_xx0 + 2 * items);                   // [G] the row of the fragment that ends the pair's current episode (0xFFFF: none): the flag planes
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     }
   };
 
-  // ---- the store waves: staged tile of chunk c -> trajectory rows, flag planes written densely ------------------------
+  // ---- the store waves: staged tile of chunk c -> trajectory rows ---------------------------------------------------------------
   // flat piece index q = row * P + piece over a staged tile, advancing by the store lanes per iteration: (piece, byte offset)
   // are carried incrementally -- no multiply in the loop; each instruction writes 64 consecutive 16-byte pieces (1 KB)
   const int nsl = n_store_waves << 6, sl = tid - store_first;
