@@ -13,10 +13,10 @@
 //   * a workgroup owns G consecutive (env, shop) pairs (G % 16 == 0; SC64, B = 4096: 144 pairs = one workgroup per CU) and
 //     walks the fragment in chunks of TC rows, one LDS-only barrier per chunk;
 //   * WORKER waves draw chunk c + 2 (one Philox block per (pair, tick quad); the order sum comes from ONE table lookup on
-//     y < 5^K, the action goes straight to HBM and never touches LDS) and compute the outputs of chunk c from 4 bytes of
+//     y < 5^K; the action is staged in LDS beside R | D) and compute the outputs of chunk c from 4 bytes of
 //     LDS per item (R | D << 8 and stock-before | stock-after << 8, both u16) into a staged tile laid out like the
-//     trajectory rows (observation [TC][3 G] f32, reward [TC][G] f32; the f32 reward comes from a [101][32] table of the
-//     f64 expression, computed at setup) -- they never issue a trajectory store except the 4-byte action;
+//     trajectory rows (observation [TC][3 G] f32, reward [TC][G] f32; the f32 reward comes from a table on 10 sales - stock
+//     of the f64 expression, built on the host) -- they never issue a trajectory store;
 //   * RECURRENCE waves (one lane per pair) walk the stock chain of chunk c + 1 and store stock before AND after each step;
 //   * STORE waves stream the staged tile of chunk c - 1 to HBM (non-temporal, whole 64-byte units); the flag planes of the WHOLE fragment
 //     they write before that, in the iterations in which the pipeline fills (dense 16-byte pieces, a closed form of the pairs' step
