@@ -36,7 +36,7 @@ def run_rollout_case(case, journal=None):
         # a kernel variant drawn from the seed (phx_spec.variant_*; ignored where its preconditions do not hold)
         vrng = np.random.default_rng(case + 10_000_019)
         variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general", "store_waves", "store_waves"])),
-                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36, 96, 144][int(vrng.integers(0, 10))],
+                    "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36, 96, 144, 128][int(vrng.integers(0, 11))],
                     "flags": ["auto", "dense", "sparse", "sparse"][int(vrng.integers(0, 4))]}
         env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
                                variants=variants)
@@ -60,6 +60,14 @@ def run_rollout_case(case, journal=None):
     for _ in range(int(rng.integers(0, 4))):                      # fragments that do not start on a tick quad / at a reset
         a = rng.uniform(0, amax, (B, env.spec.n_strategic)).astype(np.float32)
         o.step(a, None, None); dv.step(a, None, None)
+    if kind < 8 and not fsm and np.random.default_rng(case + 20_000_003).random() < 0.15:
+        # step counters a caller moved (round 4: the store-wave kernel derives the flag planes of a whole fragment from them):
+        # ahead, behind, below zero (the first episode end is further away), at or above num_steps (the episode never ends)
+        prng = np.random.default_rng(case + 20_000_003)
+        st = o.get_i32("env.step").copy()
+        for b in prng.integers(0, B, max(1, B // 3)):
+            st[b] = int(prng.integers(-30, ns + 10))
+        o.set_i32("env.step", st); dv.set_i32("env.step", st)
     n = 0
     for _ in range(int(rng.integers(1, 4))):
         T = int(rng.choice([1, 2, 3, 7, 19, 20, 21, 39, 41, 64, 100, 130, 200, 257]))
