@@ -30,7 +30,7 @@ ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 # phx_spec.variant_* (ABI 6)
 VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP, VR_STORE_WAVES = 0, 1, 2, 3, 4, 5
 VB_WHOLE_ENVS = -1
-VS_AUTO, VS_FUSED, VS_GENERIC = 0, 1, 2
+VS_AUTO, VS_FUSED, VS_GENERIC, VS_WIDE = 0, 1, 2, 3
 RH_FLAGS_ZEROED = 1          # phx_rollout_io.hints
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1

@@ -851,6 +851,10 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       if (der.shop_cust_ptr[s2 + 1] - der.shop_cust_ptr[s2] != Ku) Ku = -1;
       nu = nu && der.shop_norm[s2] == der.shop_norm[0];
     }
+    // four-pairs-per-thread step kernel (large batches): additionally every shop acts and every customer orders in the env's one list
+    bool all_act = d.n_lists == 1;
+    for (int s2 = 0; s2 < d.S && all_act; ++s2) all_act = (der.sc_shop_flags[s2] & 7) == 7;
+    if (all_act && Ku >= 1 && Ku <= 6 && nu && der.shop_norm[0] > 0 && d.D == 3 && ((int64_t)d.B * d.S) % 4 == 0) { d.sc_wide_K = Ku; d.sc_wide_norm = der.shop_norm[0]; }
     ScFastPlan plan;
     if (phx_sc_fast_plan(d.B, d.S, Ku, nu, d.num_steps, d.variant_block, true, &plan)) {
       plan.norm = der.shop_norm[0];

@@ -141,6 +141,7 @@ struct DevSpec {
   int32_t max_cust;              // max customers of one shop
   int32_t variant_rollout, variant_block, variant_step, variant_flags;   // phx_spec.variant_* (0 = the library's choice)
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
+  int32_t sc_wide_K, sc_wide_norm;   // phx_sc_step_wide_kernel: the shops' common customer count (0: the kernel does not apply) and normaliser
   ScSwPlan sc_sw;                // store-wave rollout kernel (round 4): plan (ok == 0: not applicable)
   const void* sc_sw_tables;      // its table image in device memory (phx_sc_sw_tables)
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser

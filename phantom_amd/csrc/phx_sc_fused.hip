@@ -203,6 +203,83 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
   }
 }
 
+// ---- the same step for LARGE batches of plain supply-chain envs: four consecutive (env, shop) pairs per thread ---------------------
+// phx_sc_step_kernel is one lane per pair, 4-byte loads and stores and five byte planes: at 2^18 envs of SC64 (2.4 M pairs, 103 MB per
+// step) it saturates at 0.36 of the HBM peak (this kernel: 0.45) -- 65 % of its wave cycles wait, 4.6 rounds of waves whose lives are two dependent
+// memory round trips.  Here a thread owns pairs 4u .. 4u + 3 of a block of whole envs (epb S pairs, a multiple of 4): state, actions
+// and masks arrive as 16-byte loads (all issued before the barrier that separates the env words' readers from their writers), four
+// Philox blocks are in flight per thread, and observation (48 B), reward (32 B), state (4 x 16 B) and the five flag planes (4 B each)
+// leave as whole 16- / 4-byte stores.  Plain env, every shop acts, every customer orders from the device stream, shops with one
+// customer count K <= 6 and one normaliser (DevSpec::sc_wide_K); anything else keeps phx_sc_step_kernel.  Same results bit for bit
+// (tests/test_gpu_round4.py); supply_chain.py:98-147, env.py:239-303.
+struct StepWideArgs {
+  int32_t B, S, K, num_steps, epb, norm;
+  uint32_t mS;                       // ceil(2^32 / S): i / S for i < 2^16
+  uint64_t seed; int64_t env_offset;
+  int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick;
+  const float* sc_tab; int32_t n_quot;      // DevSpec::sc_tab: [0, 101) stock / 100, [101, 101 + n_quot) x / norm (n_quot <= 64 here)
+  phx_step_io io;
+};
+
+__global__ __launch_bounds__(256) void phx_sc_step_wide_kernel(const StepWideArgs a) {
+  __shared__ float s_tab[101 + 64];
+  if ((int)threadIdx.x < 101 + a.n_quot) s_tab[threadIdx.x] = a.sc_tab[threadIdx.x];
+  const int64_t b_first = (int64_t)blockIdx.x * a.epb;
+  const int n_env = (int)((b_first + a.epb <= a.B) ? a.epb : a.B - b_first);
+  const int u = (int)threadIdx.x, n_units = (n_env * a.S) >> 2;
+  const bool active = u < n_units;
+  const int64_t g0 = b_first * a.S + 4 * (int64_t)u;                       // the thread's first pair (a multiple of 4)
+  int el[4], sh[4], step0[4]; uint32_t tick0[4];
+  int4 v_stock = make_int4(0, 0, 0, 0), v_deliv = v_stock;
+  float4 v_act = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t v_valid = 0x01010101u;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t rel = (uint32_t)(4 * u + k);
+      el[k] = a.S == 1 ? (int)rel : (int)__umulhi(rel, a.mS); sh[k] = (int)rel - el[k] * a.S;
+      step0[k] = a.env_step[b_first + el[k]]; tick0[k] = (uint32_t)a.env_tick[b_first + el[k]];
+    }
+    v_stock = *(const int4*)(a.stock + g0); v_deliv = *(const int4*)(a.delivered + g0);
+    if (a.io.actions) v_act = *(const float4*)(a.io.actions + g0);
+    if (a.io.action_valid) v_valid = *(const uint32_t*)(a.io.action_valid + g0);
+  }
+  __syncthreads();            // every thread has read its envs' words: the threads that hold an env's first shop rewrite them below
+  if (!active) return;
+  const int stock_in[4] = {v_stock.x, v_stock.y, v_stock.z, v_stock.w}, deliv_in[4] = {v_deliv.x, v_deliv.y, v_deliv.z, v_deliv.w};
+  const float act_in[4] = {v_act.x, v_act.y, v_act.z, v_act.w};
+  int o_stock[4], o_sales[4], o_missed[4], o_deliv[4];
+  float ob[12]; double rw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t b = b_first + el[k];
+    const bool has_action = ((v_valid >> (8 * k)) & 0xffu) != 0u;                                     // env.py:330 (no action tensor: actions of 0)
+    const int D = rng_shop_order_sum(a.seed, a.env_offset + b, tick0[k], sh[k], a.K, nullptr);      // supply_chain.py:61-67
+    ShopLane st; st.stock = stock_in[k]; st.delivered = deliv_in[k]; st.sales = 0; st.missed = 0;
+    sc_shop_step(st, has_action, has_action ? act_in[k] : 0.0f, true, D);      // (act_in is 0 without an action tensor)
+    o_stock[k] = st.stock; o_sales[k] = st.sales; o_missed[k] = st.missed; o_deliv[k] = st.delivered;
+    if ((unsigned)st.stock <= (unsigned)PHX_SHOP_MAX_STOCK && (unsigned)st.sales < (unsigned)a.n_quot && (unsigned)st.missed < (unsigned)a.n_quot) {   // encode_observation :124-134
+      ob[3 * k] = s_tab[st.stock]; ob[3 * k + 1] = s_tab[101 + st.sales]; ob[3 * k + 2] = s_tab[101 + st.missed];
+    } else shop_obs_f32(st.stock, st.sales, st.missed, (float)a.norm, ob + 3 * k);                   // a stock outside [0, 100] (the caller's, or an action below zero's)
+    rw[k] = shop_reward(st.sales, st.stock);                                                         // compute_reward :147
+    if (sh[k] == 0) {                                                                                // the env's words, env.py:252,297-298
+      const int t = step0[k] + 1;
+      a.env_step[b] = t; a.env_tick[b] = (int32_t)(tick0[k] + 1u);
+      a.io.all_terminated[b] = 0; a.io.all_truncated[b] = (uint8_t)(t == a.num_steps);
+    }
+  }
+  *(int4*)(a.stock + g0) = make_int4(o_stock[0], o_stock[1], o_stock[2], o_stock[3]);
+  *(int4*)(a.sales + g0) = make_int4(o_sales[0], o_sales[1], o_sales[2], o_sales[3]);
+  *(int4*)(a.missed + g0) = make_int4(o_missed[0], o_missed[1], o_missed[2], o_missed[3]);
+  *(int4*)(a.delivered + g0) = make_int4(o_deliv[0], o_deliv[1], o_deliv[2], o_deliv[3]);
+  float4* const po = (float4*)(a.io.obs + g0 * 3);
+  po[0] = make_float4(ob[0], ob[1], ob[2], ob[3]); po[1] = make_float4(ob[4], ob[5], ob[6], ob[7]); po[2] = make_float4(ob[8], ob[9], ob[10], ob[11]);
+  double2* const pr = (double2*)(a.io.reward + g0);
+  pr[0] = make_double2(rw[0], rw[1]); pr[1] = make_double2(rw[2], rw[3]);
+  *(uint32_t*)(a.io.obs_valid + g0) = 0x01010101u; *(uint32_t*)(a.io.reward_valid + g0) = 0x01010101u; *(uint32_t*)(a.io.done_valid + g0) = 0x01010101u;
+  *(uint32_t*)(a.io.terminated + g0) = 0u; *(uint32_t*)(a.io.truncated + g0) = 0u;
+}
+
 // ---- rollout: time-parallel.  The only sequential dependence of an episode is the stock
 // recurrence  stock' = min(stock - min(D, stock) + min(R, 100 - stock), 100)  (a dozen integer
 // ops); everything expensive -- the Philox draws, the divisions of the observation, the f64
@@ -820,6 +897,26 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
   // same (the per-launch mode is bound by the host's launch cadence); PHX_STEP_NT overrides.
+  // large plain batches: four pairs per thread (AUTO from 2^20 pairs per launch up -- SC64: B = 65 536 9.9 us either way, 131 072 19.6 -> 14.5,
+  // 262 144 35.6 -> 28.8; PHX_VS_WIDE forces it wherever it applies)
+  if (sp.sc_wide_K > 0 && sp.env_type == PHX_ENV_PLAIN && !io.exo && sp.S <= 1024 && sp.sc_tab &&
+      (sp.variant_step == PHX_VS_WIDE || (sp.variant_step == PHX_VS_AUTO && (int64_t)sp.B * sp.S >= (1 << 20)))) {
+    int epb = 1024 / sp.S;
+    while (epb > 1 && (epb * sp.S) % 4 != 0) --epb;
+    if ((epb * sp.S) % 4 == 0) {
+      StepWideArgs a = {};
+      a.B = sp.B; a.S = sp.S; a.K = sp.sc_wide_K; a.num_steps = sp.num_steps; a.epb = epb; a.norm = sp.sc_wide_norm;
+      a.mS = (uint32_t)((0x100000000ull + (uint64_t)sp.S - 1) / (uint64_t)sp.S);
+      a.seed = sp.seed; a.env_offset = sp.env_offset;
+      a.stock = (int32_t*)sp.f[F_SHOP_STOCK]; a.sales = (int32_t*)sp.f[F_SHOP_SALES]; a.missed = (int32_t*)sp.f[F_SHOP_MISSED];
+      a.delivered = (int32_t*)sp.f[F_SHOP_DELIVERED]; a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK];
+      a.sc_tab = sp.sc_tab; a.n_quot = sp.n_quot < 64 ? sp.n_quot : 64;
+      a.io = io;
+      phx_note_kernel("phx_sc_step_wide_kernel");
+      hipLaunchKernelGGL(phx_sc_step_wide_kernel, dim3((unsigned)((sp.B + epb - 1) / epb)), dim3(256), 0, st, a);
+      return hipGetLastError();
+    }
+  }
   int nt = 256;
   const int force_nt = phx_knobs().step_nt;
   if (force_nt == 64 || force_nt == 128 || force_nt == 256) nt = force_nt < sp.S ? 256 : force_nt;

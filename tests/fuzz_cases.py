@@ -44,6 +44,8 @@ def sc_case(rng, case):
     for c in custs:
         if rng.rand() < 0.99: net.add_connection(c.id, c.shop_id)
     kw = dict(batch_size=B, seed=int(rng.randint(1 << 30)), env_offset=int(rng.randint(1 << 20)), force_generic=force_generic)
+    if np.random.RandomState(case + 77_000_001).rand() < 0.5:      # round 4: the four-pairs-per-thread step kernel wherever it applies (plain env, one K)
+        kw["variants"] = {"step": "wide"}
     sup = None
     host_fed = False
     if typed:

@@ -95,3 +95,36 @@ def test_begin_plus_end_equals_one_step(kind):
         if (one.all_truncated | one.all_terminated).any():
             for r in (one, two, orc):
                 r.reset()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 7), (3, 2, 48, 5), (51, 4, 16, 9), (4, 4, 64, 3), (1, 3, 16, 4), (12, 1, 8, 6), (7, 5, 4, 5)])
+def test_wide_step_kernel_matches_oracle_and_the_lane_per_pair_kernel(S, K, B, num_steps):
+    """variants={"step": "wide"}: phx_sc_step_wide_kernel -- four (env, shop) pairs per thread, 16-byte accesses, what PHX_VS_AUTO takes from
+    2^20 pairs per launch up -- against the oracle AND against phx_sc_step_kernel on the same inputs: full and partial action dicts
+    (env.py:330), episode ends and the steps after them, the per-env words, the state a following rollout starts from."""
+    env_w = supply_chain_env(S, [K] * S, num_steps, B, seed=3 + S, env_offset=100, variants={"step": "wide"})
+    env_f = supply_chain_env(S, [K] * S, num_steps, B, seed=3 + S, env_offset=100, variants={"step": "fused"})
+    o, w, f = OracleEnv(env_w.spec, threads=4), DeviceRunner(env_w.spec), DeviceRunner(env_f.spec)
+    o.reset(); w.reset(); f.reset()
+    rng = np.random.default_rng(S * 7 + K)
+    fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")
+    for t in range(2 * num_steps + 3):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        valid = None if t % 3 else (rng.random((B, S)) < 0.7).astype(np.uint8)
+        o.step(a, valid, None)
+        w.step(a, valid, None); assert w.dev.last_kernel() == "phx_sc_step_wide_kernel"      # (the calling thread's LAST call)
+        f.step(a, valid, None); assert f.dev.last_kernel() == "phx_sc_step_kernel"
+        for d in (w, f):
+            np.testing.assert_array_equal(f32_bits(d.obs), f32_bits(o.obs), err_msg=f"obs, step {t}")
+            np.testing.assert_array_equal(f64_bits(d.reward), f64_bits(o.reward), err_msg=f"reward, step {t}")
+            for k in ("obs_valid", "reward_valid", "terminated", "truncated", "done_valid", "all_terminated", "all_truncated"):
+                np.testing.assert_array_equal(getattr(d, k), getattr(o, k), err_msg=f"{k}, step {t}")
+            for fl in fields:
+                np.testing.assert_array_equal(d.get_i32(fl), o.get_i32(fl), err_msg=f"{fl}, step {t}")
+        if o.all_truncated.any():                                # the caller's reset of the envs that ended (env.py:195-237)
+            m = o.all_truncated.astype(np.uint8)
+            o.reset(m); w.reset(m); f.reset(m)
+    ro, rw = o.rollout(11), w.rollout(11)
+    np.testing.assert_array_equal(f32_bits(rw["obs"]), f32_bits(ro["obs"]))
+    assert (w.err == 0).all()
