@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NT) void phx_sc_step_kernel(const DevSpec sp, const
 
 // ---- the same step for LARGE batches of plain supply-chain envs: four consecutive (env, shop) pairs per thread ---------------------
 // phx_sc_step_kernel is one lane per pair, 4-byte loads and stores and five byte planes: at 2^18 envs of SC64 (2.4 M pairs, 103 MB per
-// step) it saturates at 0.36 of the HBM peak (this kernel: 0.45) -- 65 % of its wave cycles wait, 4.6 rounds of waves whose lives are two dependent
+// step) it saturates at 0.36 of the HBM peak (this kernel: 0.52) -- 65 % of its wave cycles wait, 4.6 rounds of waves whose lives are two dependent
 // memory round trips.  Here a thread owns pairs 4u .. 4u + 3 of a block of whole envs (epb S pairs, a multiple of 4): state, actions
 // and masks arrive as 16-byte loads (all issued before the barrier that separates the env words' readers from their writers), four
 // Philox blocks are in flight per thread, and observation (48 B), reward (32 B), state (4 x 16 B) and the five flag planes (4 B each)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void phx_sc_step_wide_kernel(const StepWideArg
   const int u = (int)threadIdx.x, n_units = (n_env * a.S) >> 2;
   const bool active = u < n_units;
   const int64_t g0 = b_first * a.S + 4 * (int64_t)u;                       // the thread's first pair (a multiple of 4)
-  int el[4], sh[4], step0[4]; uint32_t tick0[4];
+  int el[4], sh[4]; uint32_t tick0[4];
   int4 v_stock = make_int4(0, 0, 0, 0), v_deliv = v_stock;
   float4 v_act = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t v_valid = 0x01010101u;
@@ -238,13 +238,27 @@ __global__ __launch_bounds__(256) void phx_sc_step_wide_kernel(const StepWideArg
     for (int k = 0; k < 4; ++k) {
       const uint32_t rel = (uint32_t)(4 * u + k);
       el[k] = a.S == 1 ? (int)rel : (int)__umulhi(rel, a.mS); sh[k] = (int)rel - el[k] * a.S;
-      step0[k] = a.env_step[b_first + el[k]]; tick0[k] = (uint32_t)a.env_tick[b_first + el[k]];
+      tick0[k] = (uint32_t)a.env_tick[b_first + el[k]];
     }
     v_stock = *(const int4*)(a.stock + g0); v_deliv = *(const int4*)(a.delivered + g0);
     if (a.io.actions) v_act = *(const float4*)(a.io.actions + g0);
     if (a.io.action_valid) v_valid = *(const uint32_t*)(a.io.action_valid + g0);
   }
-  __syncthreads();            // every thread has read its envs' words: the threads that hold an env's first shop rewrite them below
+  // the env words are rewritten by one thread per ENV (contiguous 4-byte stores; written from the lanes that hold an env's first shop they
+  // were 262 144 x 4 scattered sector writes per step at B = 2^18: 26 MB of 101)
+  int e_step[4], e_tick[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int e = (int)threadIdx.x + 256 * i; if (e < n_env) { e_step[i] = a.env_step[b_first + e]; e_tick[i] = a.env_tick[b_first + e]; } }
+  __syncthreads();            // every thread has read its envs' words
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = (int)threadIdx.x + 256 * i;
+    if (e < n_env) {                                                                                   // env.py:252,297-298
+      const int t = e_step[i] + 1;
+      a.env_step[b_first + e] = t; a.env_tick[b_first + e] = e_tick[i] + 1;
+      a.io.all_terminated[b_first + e] = 0; a.io.all_truncated[b_first + e] = (uint8_t)(t == a.num_steps);
+    }
+  }
   if (!active) return;
   const int stock_in[4] = {v_stock.x, v_stock.y, v_stock.z, v_stock.w}, deliv_in[4] = {v_deliv.x, v_deliv.y, v_deliv.z, v_deliv.w};
   const float act_in[4] = {v_act.x, v_act.y, v_act.z, v_act.w};
@@ -262,11 +276,6 @@ __global__ __launch_bounds__(256) void phx_sc_step_wide_kernel(const StepWideArg
       ob[3 * k] = s_tab[st.stock]; ob[3 * k + 1] = s_tab[101 + st.sales]; ob[3 * k + 2] = s_tab[101 + st.missed];
     } else shop_obs_f32(st.stock, st.sales, st.missed, (float)a.norm, ob + 3 * k);                   // a stock outside [0, 100] (the caller's, or an action below zero's)
     rw[k] = shop_reward(st.sales, st.stock);                                                         // compute_reward :147
-    if (sh[k] == 0) {                                                                                // the env's words, env.py:252,297-298
-      const int t = step0[k] + 1;
-      a.env_step[b] = t; a.env_tick[b] = (int32_t)(tick0[k] + 1u);
-      a.io.all_terminated[b] = 0; a.io.all_truncated[b] = (uint8_t)(t == a.num_steps);
-    }
   }
   *(int4*)(a.stock + g0) = make_int4(o_stock[0], o_stock[1], o_stock[2], o_stock[3]);
   *(int4*)(a.sales + g0) = make_int4(o_sales[0], o_sales[1], o_sales[2], o_sales[3]);
@@ -897,8 +906,8 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
   // same (the per-launch mode is bound by the host's launch cadence); PHX_STEP_NT overrides.
-  // large plain batches: four pairs per thread (AUTO from 2^20 pairs per launch up -- SC64: B = 65 536 9.9 us either way, 131 072 19.6 -> 14.5,
-  // 262 144 35.6 -> 28.8; PHX_VS_WIDE forces it wherever it applies)
+  // large plain batches: four pairs per thread (AUTO from 2^20 pairs per launch up -- SC64: B = 65 536 9.8 -> 9.6 us, 131 072 19.4 -> 14.3,
+  // 262 144 35.9 -> 24.9; PHX_VS_WIDE forces it wherever it applies)
   if (sp.sc_wide_K > 0 && sp.env_type == PHX_ENV_PLAIN && !io.exo && sp.S <= 1024 && sp.sc_tab &&
       (sp.variant_step == PHX_VS_WIDE || (sp.variant_step == PHX_VS_AUTO && (int64_t)sp.B * sp.S >= (1 << 20)))) {
     int epb = 1024 / sp.S;
