@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void phx_sc_step_wide_kernel(const StepWideArg
     if (a.io.action_valid) v_valid = *(const uint32_t*)(a.io.action_valid + g0);
   }
   // the env words are rewritten by one thread per ENV (contiguous 4-byte stores; written from the lanes that hold an env's first shop they
-  // were 262 144 x 4 scattered sector writes per step at B = 2^18: 26 MB of 101)
+  // were a million scattered 1- and 4-byte store requests per step at B = 2^18: 28.8 -> 24.9 us)
   int e_step[4], e_tick[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const int e = (int)threadIdx.x + 256 * i; if (e < n_env) { e_step[i] = a.env_step[b_first + e]; e_tick[i] = a.env_tick[b_first + e]; } }
