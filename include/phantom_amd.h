@@ -231,7 +231,7 @@ typedef struct phx_spec {
 #define PHX_VS_FUSED         1  /* the static-schedule kernel of the env's family (default where one applies)                      */
 #define PHX_VS_GENERIC       2  /* the message-passing engine (same as PHX_F_FORCE_GENERIC)                                       */
 #define PHX_VS_WIDE          3  /* plain supply chain, device-RNG orders: four (env, shop) pairs per thread, 16-byte accesses (AUTO
-                                   takes it from 2^20 pairs per launch up; smaller launches are latency-bound either way)          */
+                                   takes it from 2^19 pairs per launch up; smaller launches are latency-bound either way)          */
 /* phx_spec.variant_flags */
 #define PHX_VF_DENSE         1
 #define PHX_VF_SPARSE        2

@@ -906,10 +906,10 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   // whole envs per block (S <= 256 checked at create).  64-, 128- and 256-thread blocks time the
   // same (the per-launch mode is bound by the host's launch cadence); PHX_STEP_NT overrides.
-  // large plain batches: four pairs per thread (AUTO from 2^20 pairs per launch up -- SC64: B = 65 536 9.8 -> 9.6 us, 131 072 19.4 -> 14.3,
+  // large plain batches: four pairs per thread (AUTO from 2^19 pairs per launch up -- SC64: B = 65 536 9.8 -> 9.6 us, 131 072 19.4 -> 14.3,
   // 262 144 35.9 -> 24.9; PHX_VS_WIDE forces it wherever it applies)
   if (sp.sc_wide_K > 0 && sp.env_type == PHX_ENV_PLAIN && !io.exo && sp.S <= 1024 && sp.sc_tab &&
-      (sp.variant_step == PHX_VS_WIDE || (sp.variant_step == PHX_VS_AUTO && (int64_t)sp.B * sp.S >= (1 << 20)))) {
+      (sp.variant_step == PHX_VS_WIDE || (sp.variant_step == PHX_VS_AUTO && (int64_t)sp.B * sp.S >= (1 << 19)))) {
     int epb = 1024 / sp.S;
     while (epb > 1 && (epb * sp.S) % 4 != 0) --epb;
     if ((epb * sp.S) % 4 == 0) {

@@ -101,7 +101,7 @@ def test_begin_plus_end_equals_one_step(kind):
 @pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 7), (3, 2, 48, 5), (51, 4, 16, 9), (4, 4, 64, 3), (1, 3, 16, 4), (12, 1, 8, 6), (7, 5, 4, 5)])
 def test_wide_step_kernel_matches_oracle_and_the_lane_per_pair_kernel(S, K, B, num_steps):
     """variants={"step": "wide"}: phx_sc_step_wide_kernel -- four (env, shop) pairs per thread, 16-byte accesses, what PHX_VS_AUTO takes from
-    2^20 pairs per launch up -- against the oracle AND against phx_sc_step_kernel on the same inputs: full and partial action dicts
+    2^19 pairs per launch up -- against the oracle AND against phx_sc_step_kernel on the same inputs: full and partial action dicts
     (env.py:330), episode ends and the steps after them, the per-env words, the state a following rollout starts from."""
     env_w = supply_chain_env(S, [K] * S, num_steps, B, seed=3 + S, env_offset=100, variants={"step": "wide"})
     env_f = supply_chain_env(S, [K] * S, num_steps, B, seed=3 + S, env_offset=100, variants={"step": "fused"})
