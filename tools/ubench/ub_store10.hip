@@ -4,14 +4,16 @@
 // outputs) and write a staged tile to LDS, and NSW store waves stream the PREVIOUS chunk's staged tile (obs [TC][3G], reward [TC][G],
 // optionally action [TC][G]) out of LDS with 1 KB per store instruction (consecutive 16-byte pieces from consecutive lanes).  One
 // barrier per chunk, as in the kernel.  ACT_BY_WORKERS: the action plane is written by the workers as 4-byte stores per lane (what a
-// draw phase that never stages the action would do).  FLAGS: the store waves also write dense flag rows (G bytes per row and plane).
+// draw phase that never stages the action would do).  FLAGS 1: the store waves also write dense flag rows (G bytes per row and plane) with
+// every chunk; 2: the same bytes as whole 128-byte lines with one writer each; 3: whole ROWS of both planes (row t by workgroup t % blocks)
+// before the streaming starts.  Round 4's finding: on some boxes FLAGS 1 costs 8-10 us of a 57 us launch, 2 the same, 3 about 2.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 static constexpr int T = 400, N = 4096 * 9;
 struct Planes { char *obs, *act, *rew, *ter, *tru; };
 
-template <int G, int TC, int NT, int NSW, int VW, bool ACT_BY_WORKERS, bool FLAGS>
+template <int G, int TC, int NT, int NSW, int VW, bool ACT_BY_WORKERS, int FLAGS>
 __global__ __launch_bounds__(NT) void k(Planes P, int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PO = 3 * G / 4, PR = G / 4;                      // 16-byte pieces per row: obs, reward (= action)
@@ -22,6 +24,14 @@ __global__ __launch_bounds__(NT) void k(Planes P, int xcd) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   constexpr int NW = NT / 64, NWORK = NW - NSW;
   const size_t g0 = (size_t)id * G;
+  if (FLAGS == 3 && wave >= NWORK) {   // whole ROWS of the two flag planes, row t by workgroup t % blocks, before the streaming starts
+    const int sl0 = (wave - NWORK) * 64 + lane;
+    for (int t = id; t < T; t += (int)gridDim.x)
+      for (int q = sl0; q < N / 16; q += NSW * 64) {
+        *(float4*)(P.tru + (size_t)t * N + (size_t)q * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(P.ter + (size_t)t * N + (size_t)q * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
   for (int c = 0; c <= T / TC; ++c) {
     if (wave < NWORK) {
       if (c < T / TC) {
@@ -49,7 +59,15 @@ __global__ __launch_bounds__(NT) void k(Planes P, int xcd) {
         else if (i < TC * (PO + PR)) { const int k2 = i - TC * PO, r = k2 / PR, j = k2 - r * PR; *(float4*)(P.rew + (((size_t)cs * TC + r) * N + g0) * 4 + j * 16) = v; }
         else { const int k2 = i - TC * (PO + PR), r = k2 / PR, j = k2 - r * PR; *(float4*)(P.act + (((size_t)cs * TC + r) * N + g0) * 4 + j * 16) = v; }
       }
-      if (FLAGS) {
+      if (FLAGS == 3) {
+      } else if (FLAGS == 2) {        // whole 128-byte lines, one writer per line: [roundup(g0, 128), roundup(g0 + G, 128))
+        const int lo = (int)((g0 + 127) & ~(size_t)127), hi = (int)(((g0 + G + 127) & ~(size_t)127) < (size_t)N ? ((g0 + G + 127) & ~(size_t)127) : (size_t)N);
+        const int PFx = (hi - lo) >> 4;
+        for (int i = sl; i < 2 * TC * PFx; i += NSW * 64) {
+          const int pl = i >= TC * PFx, k2 = i - pl * TC * PFx, r = k2 / PFx, j = k2 - r * PFx;
+          *(float4*)((pl ? P.ter : P.tru) + ((size_t)cs * TC + r) * N + lo + j * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else if (FLAGS) {
         constexpr int PF = G / 16;
         for (int i = sl; i < 2 * TC * PF; i += NSW * 64) {
           const int pl = i >= TC * PF, k2 = i - pl * TC * PF, r = k2 / PF, j = k2 - r * PF;
@@ -74,7 +92,7 @@ static void alloc() {
   bufs.resize(2);
   for (auto& b : bufs) { hipMalloc(&b.obs, items * 12); hipMalloc(&b.act, items * 4); hipMalloc(&b.rew, items * 4); hipMalloc(&b.ter, items + 64); hipMalloc(&b.tru, items + 64); }
 }
-template <int G, int TC, int NT, int NSW, int VW, bool AW, bool FL> void run(int xcd = 1) {
+template <int G, int TC, int NT, int NSW, int VW, bool AW, int FL> void run(int xcd = 1) {
   const size_t items = (size_t)T * N, bytes = items * (FL ? 22 : 20);
   constexpr int ROWP = 3 * G / 4 + G / 4 + (AW ? 0 : G / 4);
   const size_t lds = 2 * (size_t)TC * ROWP * 16;
@@ -113,17 +131,18 @@ int main() {
   for (int rep = 0; rep < 2; ++rep) {
     run_fill();
     // stores only (VW = 0): the ceiling of the store-wave pattern, by shape
-    run<144, 20, 1024, 2, 0, false, false>(); run<144, 20, 1024, 4, 0, false, false>(); run<144, 20, 1024, 8, 0, false, false>(); run<144, 20, 1024, 1, 0, false, false>();
-    run<144, 10, 1024, 2, 0, false, false>(); run<144, 10, 1024, 4, 0, false, false>();
-    run<144, 20, 1024, 2, 0, true, false>(); run<144, 20, 1024, 4, 0, true, false>();
-    run<144, 20, 1024, 2, 0, false, true>(); run<144, 20, 1024, 4, 0, false, true>();
-    run<144, 20, 1024, 4, 0, false, false>(0);
-    run<48, 20, 384, 1, 0, false, false>(); run<48, 20, 384, 2, 0, false, false>(); run<48, 20, 384, 1, 0, true, false>(); run<48, 20, 384, 1, 0, false, true>();
-    run<96, 20, 512, 2, 0, false, false>(); run<72, 20, 512, 2, 0, false, false>();
+    run<144, 20, 1024, 2, 0, false, 0>(); run<144, 20, 1024, 4, 0, false, 0>(); run<144, 20, 1024, 8, 0, false, 0>(); run<144, 20, 1024, 1, 0, false, 0>();
+    run<144, 10, 1024, 2, 0, false, 0>(); run<144, 10, 1024, 4, 0, false, 0>();
+    run<144, 20, 1024, 2, 0, true, 0>(); run<144, 20, 1024, 4, 0, true, 0>();
+    run<144, 20, 1024, 2, 0, false, 1>(); run<144, 20, 1024, 4, 0, false, 1>(); run<144, 20, 1024, 4, 0, false, 2>();
+    run<144, 16, 1024, 4, 0, false, 0>(); run<144, 16, 1024, 4, 0, false, 1>(); run<144, 16, 1024, 4, 0, false, 2>(); run<144, 16, 1024, 4, 0, false, 3>();
+    run<144, 20, 1024, 4, 0, false, 0>(0);
+    run<48, 20, 384, 1, 0, false, 0>(); run<48, 20, 384, 2, 0, false, 0>(); run<48, 20, 384, 1, 0, true, 0>(); run<48, 20, 384, 1, 0, false, 1>();
+    run<96, 20, 512, 2, 0, false, 0>(); run<72, 20, 512, 2, 0, false, 0>();
     // with stand-in compute beside the stores (VW dependent ops per lane and chunk)
-    run<144, 20, 1024, 2, 400, false, false>(); run<144, 20, 1024, 2, 800, false, false>(); run<144, 20, 1024, 2, 1600, false, false>(); run<144, 20, 1024, 4, 800, false, false>();
-    run<144, 20, 1024, 2, 800, true, false>();
-    run<48, 20, 384, 1, 800, false, false>(); run<48, 20, 384, 1, 1600, false, false>();
+    run<144, 20, 1024, 2, 400, false, 0>(); run<144, 20, 1024, 2, 800, false, 0>(); run<144, 20, 1024, 2, 1600, false, 0>(); run<144, 20, 1024, 4, 800, false, 0>();
+    run<144, 20, 1024, 2, 800, true, 0>();
+    run<48, 20, 384, 1, 800, false, 0>(); run<48, 20, 384, 1, 1600, false, 0>();
   }
   return 0;
 }
