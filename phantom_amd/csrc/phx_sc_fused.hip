@@ -908,7 +908,10 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
   // same (the per-launch mode is bound by the host's launch cadence); PHX_STEP_NT overrides.
   // large plain batches: four pairs per thread (AUTO from 2^19 pairs per launch up -- SC64: B = 65 536 9.8 -> 9.6 us, 131 072 19.4 -> 14.3,
   // 262 144 35.9 -> 24.9; PHX_VS_WIDE forces it wherever it applies)
-  if (sp.sc_wide_K > 0 && sp.env_type == PHX_ENV_PLAIN && !io.exo && sp.S <= 1024 && sp.sc_tab &&
+  // (its 16- and 4-byte accesses want the caller's planes aligned like torch / hipMalloc allocations are; anything else: the lane-per-pair kernel)
+  const uintptr_t al16 = (uintptr_t)io.obs | (uintptr_t)io.reward | (uintptr_t)io.actions, al4 = (uintptr_t)io.obs_valid | (uintptr_t)io.reward_valid |
+                        (uintptr_t)io.done_valid | (uintptr_t)io.terminated | (uintptr_t)io.truncated | (uintptr_t)io.action_valid;
+  if (sp.sc_wide_K > 0 && sp.env_type == PHX_ENV_PLAIN && !io.exo && sp.S <= 1024 && sp.sc_tab && (al16 & 15) == 0 && (al4 & 3) == 0 &&
       (sp.variant_step == PHX_VS_WIDE || (sp.variant_step == PHX_VS_AUTO && (int64_t)sp.B * sp.S >= (1 << 19)))) {
     int epb = 1024 / sp.S;
     while (epb > 1 && (epb * sp.S) % 4 != 0) --epb;
