@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 8
+#define PHX_ABI_VERSION 9
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -281,11 +281,13 @@ typedef struct phx_step_io {
    * receiver-major order (receivers in first-arrival order), holds the batch-local index (send
    * order) of the message handled at that position.  shuffle_cap = 8 * queue_cap entries per env. */
   const uint16_t* shuffle;     /* [B][8 * queue_cap] or NULL                                */
-  /* FiniteStateMachineEnv stage HANDLERS (fsm.py:294-307): the stage a Python handler returned for each env, decided
-   * on the host before the launch (a handler that only looks at the clock / the stage is deterministic), or NULL ->
-   * next_stages[0] of the current stage.  Checked against phx_spec.stage_allowed; an invalid transition sets
-   * PHX_ERR_FSM_TRANSITION.  The agents acting in THAT stage are the ones that observe (fsm.py:320).  Runs on the
-   * generic engine.                                                                                           */
+  /* FiniteStateMachineEnv stage HANDLERS (fsm.py:294-307): the stage a Python handler returned for each env, or NULL ->
+   * the tabulated / device-evaluated handler of the current stage (phx_spec.stage_tab, phx_spec.stage_rule), else its
+   * next_stages[0].  A handler that reads agent state is called by the host where the reference calls it: BETWEEN
+   * phx_step_begin (acting phase + resolve_network) and phx_step_end, which takes this field; with ONE phx_step the
+   * values must have been decided before the launch (handlers that only look at the clock / the stage).  Checked against
+   * phx_spec.stage_allowed; an invalid transition sets PHX_ERR_FSM_TRANSITION.  The agents acting in THAT stage are the
+   * ones that observe (fsm.py:320).  Runs on the generic engine.                                                */
   const int32_t* next_stage;   /* [B] or NULL                                               */
 } phx_step_io;
 
@@ -295,6 +297,19 @@ typedef struct phx_step_io {
                                    default kernel stores every flag word and ignores it).  phx_rollout_io.hints: the caller has ALREADY zeroed `terminated` and `truncated` (e.g. on a side stream,
                                    while the previous fragment was being written): where the serving kernel stores only the non-zero flag
                                    words (phx_spec.variant_flags) its own fill is skipped; ignored by kernels that store every word */
+/* ABI 9: one trajectory fragment of a launch that writes SEVERAL (phx_rollout_io.frags): the planes of phx_rollout_io, each
+ * [frag_T][B][S](..) -- separate allocations, e.g. the buffers a learner takes one at a time.                              */
+#define PHX_MAX_FRAGMENTS 8
+typedef struct phx_rollout_frag {
+  float*    obs;               /* [frag_T][B][S][D]                                         */
+  float*    action_out;        /* [frag_T][B][S]                                            */
+  float*    reward;            /* [frag_T][B][S]                                            */
+  uint8_t*  terminated;        /* [frag_T][B][S] or NULL (all fragments alike), as phx_rollout_io.terminated */
+  uint8_t*  truncated;         /* [frag_T][B][S]                                            */
+  uint8_t*  obs_valid;         /* [frag_T][B][S] or NULL (FSM / Stackelberg / ads envs)     */
+  uint8_t*  reward_valid;      /* [frag_T][B][S] or NULL                                    */
+} phx_rollout_frag;
+
 typedef struct phx_rollout_io {
   int32_t T;
   int32_t hints;               /* ABI 7: PHX_RH_* (occupies what was padding: zero-initialised structs of older callers mean 0) */
@@ -324,6 +339,18 @@ typedef struct phx_rollout_io {
    * peak for the store pattern alone), at 24 instead of 22 bytes per agent-step.  Served by the time-parallel supply-chain
    * rollout only (plain env, obs dim 3, device RNG and policy): PHX_EUNSUPPORTED elsewhere.  NULL = the planes.             */
   void*     records;
+  /* ABI 9: a fragment LIST.  n_frag >= 2 (<= PHX_MAX_FRAGMENTS) and frags != NULL (a HOST array, read during the call): the launch
+   * advances the envs T steps as always and writes rows [f T / n_frag, (f + 1) T / n_frag) to frags[f] (T % n_frag == 0; obs,
+   * action_out, reward, terminated, truncated, obs_valid, reward_valid of the io itself must then be NULL; actions / exo / msg_log /
+   * msg_count stay [T][..]; last_obs is the observation after step T).  Why: the fixed cost of a rollout launch on this chip -- a
+   * pipeline to fill, a 160 KB workgroup to place on every CU, the kernel boundary -- is ~9 us against 12.5 us of streaming per 100
+   * steps of the BASELINE config: a consumer of 100-step fragments asks for k of them per call and gets the rate of one k x 100-step
+   * launch (the list-of-envs collection loop, utils/rllib/rollout.py:361-363, fills its buffers episode after episode in the same
+   * way).  The store-wave supply-chain kernel writes the list from ONE launch; every other env is served by n_frag consecutive
+   * launches inside the call (same results, no gain).  0 / 1 and NULL: the io's own planes.                                    */
+  int32_t   n_frag;
+  int32_t   reserved0;
+  const phx_rollout_frag* frags;
 } phx_rollout_io;
 #define PHX_TRAJ_RECORD_BYTES 24
 

@@ -132,6 +132,25 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     free(p.obs); free(p.action_out); free(p.reward); free(p.terminated); free(p.truncated);
     return PHX_OK;
   }
+  if (io->n_frag >= 2 || io->frags) {                    /* ABI 9, a fragment list: the same steps, the rows handed out fragment by fragment */
+    if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags || io->T % io->n_frag) return PHX_EINVAL;
+    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated || io->obs_valid || io->reward_valid) return PHX_EINVAL;
+    const int Tf = io->T / io->n_frag, S = phxo_n_strategic(e->o);
+    for (int f = 0; f < io->n_frag; ++f) {
+      const phx_rollout_frag* fr = &io->frags[f];
+      phx_rollout_io sub = *io;
+      sub.n_frag = 0; sub.frags = NULL; sub.T = Tf;
+      sub.obs = fr->obs; sub.action_out = fr->action_out; sub.reward = fr->reward; sub.terminated = fr->terminated; sub.truncated = fr->truncated;
+      sub.obs_valid = fr->obs_valid; sub.reward_valid = fr->reward_valid;
+      const int64_t row = (int64_t)f * Tf * e->B;
+      if (io->actions) sub.actions = io->actions + row * S;
+      if (io->exo) sub.exo = io->exo + row * phxo_n_exo(e->o);
+      if (io->msg_log) sub.msg_log = io->msg_log + row * e->trace_cap;
+      if (io->msg_count) sub.msg_count = io->msg_count + row;
+      phxo_rollout(e->o, &sub);
+    }
+    return PHX_OK;
+  }
   phxo_rollout(e->o, io);
   return PHX_OK;
 }

@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -93,7 +93,16 @@ class PhxStepIO(C.Structure):
 class PhxRolloutIO(C.Structure):
     _fields_ = [("T", C.c_int32), ("hints", C.c_int32)] + [(n, C.c_void_p) for n in (
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
-        "reward_valid", "last_obs", "err", "msg_log", "msg_count", "records")]
+        "reward_valid", "last_obs", "err", "msg_log", "msg_count", "records")] + [
+        ("n_frag", C.c_int32), ("reserved0", C.c_int32), ("frags", C.c_void_p)]
+
+
+class PhxRolloutFrag(C.Structure):
+    """one fragment of a fragment-list rollout (phx_rollout_io.frags, ABI 9)"""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "action_out", "reward", "terminated", "truncated", "obs_valid", "reward_valid")]
+
+
+MAX_FRAGMENTS = 8
 
 
 assert C.sizeof(PhxMsgRec) == 16

@@ -657,6 +657,7 @@ extern "C++" const DevKnobs& phx_knobs() {
     k.stk_step_fast = rd("PHX_STK_STEP_FAST", 1);
     k.stk_step_nt = rd("PHX_STK_STEP_NT", 0);
     k.sw_generic = rd("PHX_SW_GENERIC", 0);
+    k.sw_persist = rd("PHX_SW_PERSIST", 1);
     k.sw_store_waves = rd("PHX_SW_STORE_WAVES", 0);
     k.sw_tc = rd("PHX_SW_TC", 0);
     k.sw_work_waves = rd("PHX_SW_WORK_WAVES", 0);
@@ -1081,6 +1082,46 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
   if (e->d.env_type != PHX_ENV_PLAIN && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
+  if (io->n_frag >= 2 || io->frags) {   // ABI 9: a fragment list
+    if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags) return fail(PHX_EINVAL, "phx_rollout: a fragment list needs 2 .. %d fragments and `frags`", PHX_MAX_FRAGMENTS);
+    if (io->T <= 0 || io->T % io->n_frag) return fail(PHX_EINVAL, "phx_rollout: T must be a positive multiple of n_frag");
+    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated || io->obs_valid || io->reward_valid || io->records)
+      return fail(PHX_EINVAL, "phx_rollout: with a fragment list the io's own planes must be NULL");
+    const bool need_valid = e->d.env_type != PHX_ENV_PLAIN;
+    for (int f = 0; f < io->n_frag; ++f) {
+      const phx_rollout_frag& fr = io->frags[f];
+      if (!fr.obs || !fr.action_out || !fr.reward || !fr.truncated || (need_valid && (!fr.obs_valid || !fr.reward_valid)))
+        return fail(PHX_EINVAL, "phx_rollout: fragment %d lacks a required plane", f);
+      if ((fr.terminated != nullptr) != (io->frags[0].terminated != nullptr)) return fail(PHX_EINVAL, "phx_rollout: `terminated` must be given for every fragment or for none");
+      const void* bufs[] = {fr.obs, fr.action_out, fr.reward, fr.terminated, fr.truncated, fr.obs_valid, fr.reward_valid};
+      for (const void* p : bufs) if (((uintptr_t)p & 15u) != 0) return fail(PHX_EINVAL, "phx_rollout: every buffer must be 16-byte aligned");
+    }
+    if (((uintptr_t)io->last_obs & 15u) || ((uintptr_t)io->actions & 15u) || ((uintptr_t)io->exo & 15u)) return fail(PHX_EINVAL, "phx_rollout: every buffer must be 16-byte aligned");
+    const int Tf = io->T / io->n_frag;
+    // ONE launch where the store-wave supply-chain kernel serves the env (its store waves switch planes at the fragments' first rows) ...
+    if (e->use_fused && e->d.env_type == PHX_ENV_PLAIN && !e->d.any_typed && e->d.sc_fast.ok && e->d.sc_sw.ok && !io->actions && !io->exo && !io->msg_log && !io->msg_count &&
+        e->d.variant_rollout != PHX_VR_GENERAL && io->T <= 0xFFFF && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) {
+      HIPCHK(use_device(e));
+      HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
+      return PHX_OK;
+    }
+    // ... n_frag consecutive launches everywhere else
+    for (int f = 0; f < io->n_frag; ++f) {
+      const phx_rollout_frag& fr = io->frags[f];
+      phx_rollout_io sub = *io;
+      sub.n_frag = 0; sub.frags = nullptr; sub.T = Tf;
+      sub.obs = fr.obs; sub.action_out = fr.action_out; sub.reward = fr.reward; sub.terminated = fr.terminated; sub.truncated = fr.truncated;
+      sub.obs_valid = fr.obs_valid; sub.reward_valid = fr.reward_valid;
+      const int64_t row = (int64_t)f * Tf * e->d.B;
+      if (io->actions) sub.actions = io->actions + row * e->d.S;
+      if (io->exo) sub.exo = io->exo + row * e->d.n_exo;
+      if (io->msg_log) sub.msg_log = io->msg_log + row * e->d.trace_cap;
+      if (io->msg_count) sub.msg_count = io->msg_count + row;
+      const int rc = phx_rollout(e, &sub, stream);
+      if (rc != PHX_OK) return rc;
+    }
+    return PHX_OK;
+  }
   if (io->records) {                  // opt-in record layout: the time-parallel supply-chain kernel only
     if (io->obs || io->action_out || io->reward || io->terminated || io->truncated)
       return fail(PHX_EINVAL, "phx_rollout: with `records` the five planes must be NULL");

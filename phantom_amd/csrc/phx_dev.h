@@ -72,6 +72,7 @@ struct DevKnobs {
   int stk_step_fast;           // PHX_STK_STEP_FAST (default 1)
   int stk_step_nt;             // PHX_STK_STEP_NT (default 0)
   int sw_generic;              // PHX_SW_GENERIC (default 0)
+  int sw_persist;              // PHX_SW_PERSIST (default 1): the store-wave kernel's workgroups walk several pair groups (0: one workgroup per group)
   int sw_store_waves;          // PHX_SW_STORE_WAVES (default 0)
   int sw_tc;                   // PHX_SW_TC (default 0)
   int sw_work_waves;           // PHX_SW_WORK_WAVES (default 0)

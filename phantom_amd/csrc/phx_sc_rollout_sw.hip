@@ -26,12 +26,14 @@
 #include "phx_sc_fast.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
 
+struct SwFrag { float* obs; float* action_out; float* reward; uint8_t* terminated; uint8_t* truncated; };
 struct SwArgs {
   int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
   int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
@@ -45,6 +47,10 @@ struct SwArgs {
   unsigned long long* rt; int32_t launch_idx;   // PHX_TIMING builds only: 100 MHz wall-clock stamps per workgroup and launch
   const float4* tables;                 // the host-built image of the table sections (phx_sc_sw_tables)
   phx_rollout_io io;
+  // ---- (past the argument lines the kernel warms at entry) ----
+  int32_t n_groups;                     // pair groups of the launch (B S / G): workgroup w walks groups w, w + gridDim.x, .. one after the other
+  int32_t frag_T, n_frag;               // rows per trajectory fragment, fragments (frag_T * n_frag == T; one fragment: frag_T == T)
+  SwFrag frag[PHX_MAX_FRAGMENTS];       // row t of the launch is row t - f * frag_T of fragment f = t / frag_T
 };
 
 __device__ __forceinline__ void sw_lds_barrier() {       // orders LDS traffic only: the trajectory stores stay in flight
@@ -91,19 +97,13 @@ template <int TC, int GT, int NREC, int NSTORE, int NWORK>
 __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_) {
   sw_kptr_t kp = (sw_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   { uint32_t d0, d1, d2, d3, d4;          // every 64-byte line of the argument block into the scalar cache at once, not one miss per phase (setup 1.6 -> 1.2 us)
-    static_assert(sizeof(SwArgs) > 0x100 && sizeof(SwArgs) <= 0x180, "the offsets below cover the argument block line by line");
+    static_assert(offsetof(SwArgs, n_groups) > 0x100 && offsetof(SwArgs, n_groups) <= 0x140, "the offsets below cover the argument block line by line (the fragment table is read once per chunk)");
     asm volatile("s_load_dword %0, %5, 0x0\n s_load_dword %1, %5, 0x40\n s_load_dword %2, %5, 0x80\n s_load_dword %3, %5, 0xc0\n s_load_dword %4, %5, 0x100\n s_waitcnt lgkmcnt(0)"
                  : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(kp) : "memory"); }
   SW_REFRESH();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, NT = GT ? 64 * (NREC + NSTORE + NWORK) : (int)blockDim.x, nS = a.S, G = GT ? GT : a.G;
   const int64_t total = (int64_t)a.B * nS;
-  const int bid = xcd_block(a.xcd_remap != 0);
-  const int64_t g_base = (int64_t)bid * G;
-  const int64_t b_first = g_base / nS;
-  const int r0 = (int)(g_base - b_first * nS);                          // the first pair's shop
-  const int n_env = (r0 + G - 1) / nS + 1;                              // envs the block touches (<= a.epb)
-
   // ---- LDS carve (16-byte aligned sections; sw_lds_bytes) ---------------------------------------------------------
   const int G4p = (G + 3) & ~3, G16p = (G + 15) & ~15, items = TC * G;
   // The value tables are REPLICATED so that a lane's lookup lands in the lane's own LDS bank (ds_read_b32: 32 banks, lane
@@ -145,6 +145,18 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #define STICK(k) do {} while (0)
 #endif
 
+  // ---- the workgroup's pair groups, one after the other (a launch of more groups than resident workgroups: replacing a finished
+  //      1 024-thread, 160 KB workgroup by the next costs the CU 3-4 us -- tools/ubench/ub_anyorder.hip -- and the tables would be
+  //      staged again; round 4 launched one workgroup per group).  Virtual workgroup vb = blockIdx.x + k gridDim.x keeps the XCD of
+  //      blockIdx.x (gridDim.x % 8 == 0 or a single pass) and the XCD-contiguous ranges of xcd_block().
+  for (int vb = (int)blockIdx.x, pass = 0; vb < a.n_groups; vb += (int)gridDim.x, ++pass) {
+  int bid = vb;
+  if (a.xcd_remap) { const unsigned n = (unsigned)a.n_groups, xq = (unsigned)vb & 7u, q = n >> 3, rem = n & 7u; bid = (int)(xq * q + (xq < rem ? xq : rem) + ((unsigned)vb >> 3)); }
+  const int64_t g_base = (int64_t)bid * G;
+  const int64_t b_first = g_base / nS;
+  const int r0 = (int)(g_base - b_first * nS);                          // the first pair's shop
+  const int n_env = (r0 + G - 1) / nS + 1;                              // envs the block touches (<= a.epb)
+
   // ---- setup: the state loads are in flight while the tables are computed ------------------------------------------
   int x = 0, step = 0;                    // lane state of the recurrence (lane tid owns pair g_base + tid)
   {
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     // and order sums go where they live; the base values of the three value tables go to a scratch area (the staging tile, unused
     // until the first output phase) and are replicated per LDS bank after the barrier.  (The replicated tables as a 45.6 KB image
     // cost every workgroup ~2.4 k more cycles of setup: ~11 bytes per cycle and CU when all 256 workgroups fetch at once.)
-    {
+    if (pass == 0) {
       constexpr int NP = SW_TABLE_BYTES / 16, NB = SW_IMG_BASE_BYTES / 16;
       float4* const scratch = (float4*)s_out0;
       float4* const sums = (float4*)s_ds;
@@ -457,16 +469,33 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       if (pc >= P) { pc -= P; off += wrap; }
     }
   };
+  // Rows of the launch -> rows of the caller's fragments (phx_rollout_io.frags: row t is row t - f frag_T of fragment f = t / frag_T; a
+  // single fragment is the io's own planes).  The store waves visit the chunks in order: a cursor per plane group, no division; a chunk
+  // that straddles two fragments leaves in two runs.
+  const int Tf = a.frag_T;
+  int fs_f = 0, fs_lo = 0, fa_f = 0, fa_lo = 0;                          // cursors of stores() / store_actions(): fragment and its first row
+  auto runs = [&](int t0, int tc, int& f, int& lo, auto body) __attribute__((always_inline)) {
+    for (int r = 0; r < tc;) {
+      while (t0 + r >= lo + Tf) { lo += Tf; ++f; }
+      const int left = lo + Tf - (t0 + r), n = tc - r < left ? tc - r : left;
+      body(f, t0 + r - lo, r, n);                                        // fragment, first row in it, first row of the tile, rows
+      r += n;
+    }
+  };
   auto store_actions = [&](int c, int t0, int tc) __attribute__((always_inline)) {      // chunk c's actions, staged by the draws one iteration ago
-    stream((char*)(io.action_out + ((int64_t)t0 * total + g_base)), s_act0 + (c & 1) * items, tc, (uint32_t)(G >> 2), div_G4, utotal * 4u);
+    runs(t0, tc, fa_f, fa_lo, [&](int f, int tr, int r, int n) __attribute__((always_inline)) {
+      stream((char*)(a.frag[f].action_out + ((int64_t)tr * total + g_base)), s_act0 + (c & 1) * items + r * G, n, (uint32_t)(G >> 2), div_G4, utotal * 4u);
+    });
   };
   auto stores = [&](int c, int t0, int tc) __attribute__((always_inline)) {
     const float* const o_obs = s_out0 + (c & 1) * (4 * items);
     const float* const o_rew = o_obs + 3 * items;
-    const int64_t row0 = (int64_t)t0 * total + g_base;
     const uint32_t PO = 3u * (uint32_t)(G >> 2), PR = (uint32_t)(G >> 2);
-    stream((char*)(io.obs + row0 * 3), o_obs, tc, PO, div_PO, utotal * 12u);
-    stream((char*)(io.reward + row0), o_rew, tc, PR, div_G4, utotal * 4u);
+    runs(t0, tc, fs_f, fs_lo, [&](int f, int tr, int r, int n) __attribute__((always_inline)) {
+      const int64_t row0 = (int64_t)tr * total + g_base;
+      stream((char*)(a.frag[f].obs + row0 * 3), o_obs + r * (3 * G), n, PO, div_PO, utotal * 12u);
+      stream((char*)(a.frag[f].reward + row0), o_rew + r * G, n, PR, div_G4, utotal * 4u);
+    });
   };
 
   // ---- the flag planes, by the store waves while they have nothing to stream (iterations -2 .. 0: the pipeline fills, HBM is idle).
@@ -477,31 +506,37 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   auto flag_segments = [&](int part) __attribute__((always_inline)) {
 #ifndef PHX_ABL_NOSTORE
     const uint32_t uT = (uint32_t)a.T, ns = (uint32_t)a.num_steps, PF = (uint32_t)(G >> 4);
-    const uint32_t r_lo = part == 0 ? 0u : (part == 1 ? (uT * 2u) / 5u : (uT * 13u) / 20u), r_hi = part == 0 ? (uT * 2u) / 5u : (part == 1 ? (uT * 13u) / 20u : uT);
-    const uint32_t n = (r_hi - r_lo) * PF;
+    const uint32_t p_lo = part == 0 ? 0u : (part == 1 ? (uT * 2u) / 5u : (uT * 13u) / 20u), p_hi = part == 0 ? (uT * 2u) / 5u : (part == 1 ? (uT * 13u) / 20u : uT);
     const float inv_ns = 1.0f / (float)ns;
-    char* const p_tru = (char*)(io.truncated + g_base);
-    char* const p_ter = io.terminated ? (char*)(io.terminated + g_base) : nullptr;
 #pragma unroll 1
-    for (uint32_t f = (uint32_t)sl; f < n; f += (uint32_t)nsl) {
-      const uint32_t rr = div_PF(f), pc = f - rr * PF, t = r_lo + rr;
-      uint32_t x = t - (uint32_t)((float)t * inv_ns) * ns;                // t mod num_steps (t < 2^16: the f32 quotient is off by one at most)
-      if ((int)x < 0) x += ns;
-      if (x >= ns) x -= ns;
-      const uint4* const src = (const uint4*)(s_ftend + 16u * pc);
-      const uint4 ea = src[0], eb = src[1];
-      const uint32_t xx = x | (x << 16);
-      // two packed u16 -> two bytes: 1 where the half equals x
-      auto eq2 = [&](uint32_t w2) { const uint32_t z = w2 ^ xx; return ((z & 0xFFFFu) == 0u ? 1u : 0u) | ((z >> 16) == 0u ? 0x100u : 0u); };
-      uint4 v = make_uint4(eq2(ea.x) | (eq2(ea.y) << 16), eq2(ea.z) | (eq2(ea.w) << 16), eq2(eb.x) | (eq2(eb.y) << 16), eq2(eb.z) | (eq2(eb.w) << 16));
-      if (__builtin_expect(neg_steps, 0)) {                               // counters below zero: the general rule, byte by byte
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        for (int b = 0; b < 16; ++b) { const uint32_t et = s_ftend[16u * pc + b]; if (et != 0xFFFFu && t >= et && (t - et) % ns == 0u) w[b >> 2] |= 1u << (8 * (b & 3)); }
-        v = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int fr = 0; fr < a.n_frag; ++fr) {                                // the part's rows, fragment by fragment (one fragment: the whole part)
+      const uint32_t f_lo = (uint32_t)fr * (uint32_t)Tf, f_hi = f_lo + (uint32_t)Tf;
+      const uint32_t r_lo = p_lo > f_lo ? p_lo : f_lo, r_hi = p_hi < f_hi ? p_hi : f_hi;
+      if (r_hi <= r_lo) continue;
+      const uint32_t n = (r_hi - r_lo) * PF;
+      char* const p_tru = (char*)(a.frag[fr].truncated + g_base);
+      char* const p_ter = a.frag[fr].terminated ? (char*)(a.frag[fr].terminated + g_base) : nullptr;
+#pragma unroll 1
+      for (uint32_t f = (uint32_t)sl; f < n; f += (uint32_t)nsl) {
+        const uint32_t rr = div_PF(f), pc = f - rr * PF, t = r_lo + rr;
+        uint32_t x = t - (uint32_t)((float)t * inv_ns) * ns;                // t mod num_steps (t < 2^16: the f32 quotient is off by one at most)
+        if ((int)x < 0) x += ns;
+        if (x >= ns) x -= ns;
+        const uint4* const src = (const uint4*)(s_ftend + 16u * pc);
+        const uint4 ea = src[0], eb = src[1];
+        const uint32_t xx = x | (x << 16);
+        // two packed u16 -> two bytes: 1 where the half equals x
+        auto eq2 = [&](uint32_t w2) { const uint32_t z = w2 ^ xx; return ((z & 0xFFFFu) == 0u ? 1u : 0u) | ((z >> 16) == 0u ? 0x100u : 0u); };
+        uint4 v = make_uint4(eq2(ea.x) | (eq2(ea.y) << 16), eq2(ea.z) | (eq2(ea.w) << 16), eq2(eb.x) | (eq2(eb.y) << 16), eq2(eb.z) | (eq2(eb.w) << 16));
+        if (__builtin_expect(neg_steps, 0)) {                               // counters below zero: the general rule, byte by byte
+          uint32_t w[4] = {0u, 0u, 0u, 0u};
+          for (int b = 0; b < 16; ++b) { const uint32_t et = s_ftend[16u * pc + b]; if (et != 0xFFFFu && t >= et && (t - et) % ns == 0u) w[b >> 2] |= 1u << (8 * (b & 3)); }
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        const size_t off = (size_t)(t - f_lo) * (size_t)utotal + (size_t)(pc * 16u);
+        *(uint4*)(p_tru + off) = v;                                          // (plain stores: a flag row of the block is G bytes, not whole lines)
+        if (p_ter) *(uint4*)(p_ter + off) = make_uint4(0u, 0u, 0u, 0u);
       }
-      const size_t off = (size_t)t * (size_t)utotal + (size_t)(pc * 16u);
-      *(uint4*)(p_tru + off) = v;                                          // (plain stores: a flag row of the block is G bytes, not whole lines)
-      if (p_ter) *(uint4*)(p_ter + off) = make_uint4(0u, 0u, 0u, 0u);
     }
 #endif
   };
@@ -558,11 +593,11 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       STICK(1);
     } else if (tid < rec_threads) {
       if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
-      else if (it == -2) replicate_tables(tid, work_first);
+      else if (it == -2 && pass == 0) replicate_tables(tid, work_first);
       else if (cr == n_chunks) finish();
       STICK(3);
     } else {
-      if (it == -2) replicate_tables(tid, work_first);
+      if (it == -2 && pass == 0) replicate_tables(tid, work_first);
       if (it <= 0) flag_segments(it + 2);
       if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
       if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
@@ -571,6 +606,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     RSTAMP_WORK();
     sw_lds_barrier(); STICK(5);
   }
+  }   // pair groups of the workgroup
 #ifndef PHX_RT_FILL
   RSTAMP(4);
 #endif
@@ -688,7 +724,25 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
   a.tables = (const float4*)sp.sc_sw_tables;
   a.io = io;
-  const dim3 grid((unsigned)(((int64_t)sp.B * sp.S) / p.G));
+  // trajectory fragments: the caller's list (phx_rollout_io.frags, validated by phx_rollout) or the io's own planes as the only one
+  if (io.n_frag > 1) {
+    a.n_frag = io.n_frag; a.frag_T = io.T / io.n_frag;
+    for (int f = 0; f < io.n_frag; ++f) a.frag[f] = SwFrag{io.frags[f].obs, io.frags[f].action_out, io.frags[f].reward, io.frags[f].terminated, io.frags[f].truncated};
+  } else {
+    a.n_frag = 1; a.frag_T = io.T;
+    a.frag[0] = SwFrag{io.obs, io.action_out, io.reward, io.terminated, io.truncated};
+  }
+  // the grid: one workgroup per pair group up to what the chip holds at once, the rest of the groups are walked by the same workgroups
+  a.n_groups = (int32_t)(((int64_t)sp.B * sp.S) / p.G);
+  unsigned n_wg = (unsigned)a.n_groups;
+  if (phx_knobs().sw_persist) {
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(SW_LDS_MAX / (size_t)p.lds, (size_t)(2048 / p.nt)));
+    unsigned resident = (unsigned)n_cu * per_cu;
+    if (n_wg > resident) n_wg = resident >= 8 ? resident & ~7u : resident;        // (a multiple of 8: virtual workgroup vb stays on the XCD of vb % 8)
+  }
+  const dim3 grid(n_wg);
 #ifdef PHX_TIMING
   { static unsigned long long* tbuf = nullptr; if (!tbuf) { (void)hipMalloc((void**)&tbuf, 8 * 16 * 8192 * sizeof(unsigned long long)); (void)hipMemset(tbuf, 0, 8 * 16 * 8192 * sizeof(unsigned long long)); } a.timing = grid.x <= 8192 ? tbuf : nullptr;
     { static unsigned long long* rbuf = nullptr; static int li = 0; if (!rbuf) (void)hipMalloc((void**)&rbuf, (4 * 8192 * 8) * sizeof(unsigned long long)); a.rt = grid.x <= 8192 ? rbuf : nullptr; a.launch_idx = li++;

@@ -1,0 +1,218 @@
+"""Round 5 on the GPU: fragment lists (phx_rollout_io.frags, ABI 9), store-wave workgroups that walk several pair groups,
+the wide step kernel on multi-workgroup grids, PHX_VS_AUTO at the size where it picks the wide kernel, misaligned planes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import phantom_amd as ph
+from device_runner import DeviceRunner
+from helpers import f32_bits, f64_bits, market_env, supply_chain_env
+from oracle import OracleEnv
+
+pytestmark = pytest.mark.gpu
+NCPU = min(os.cpu_count() or 1, 128)
+STATE = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")
+
+
+def _planes(tr):
+    return dict(obs=tr.observations.cpu().numpy(), actions=tr.actions.cpu().numpy(), rewards=tr.rewards.cpu().numpy(),
+                terminated=None if tr.terminations is None else tr.terminations.cpu().numpy(), truncated=tr.truncations.cpu().numpy())
+
+
+def _assert_rows(got, ref, lo, hi, what):
+    for k in ("obs", "actions", "rewards"):
+        np.testing.assert_array_equal(f32_bits(got[k]), f32_bits(ref[k][lo:hi]), err_msg=f"{what}: {k}")
+    for k in ("terminated", "truncated"):
+        if got[k] is not None:
+            np.testing.assert_array_equal(got[k], ref[k][lo:hi], err_msg=f"{what}: {k}")
+
+
+@pytest.mark.parametrize("S,K,B,num_steps,Tf,k", [(9, 6, 64, 23, 25, 4), (9, 6, 64, 100, 100, 4), (9, 6, 32, 17, 5, 8), (3, 2, 48, 19, 23, 3), (4, 4, 64, 50, 21, 2), (51, 4, 128, 16, 20, 5)])
+def test_fragment_list_from_one_store_wave_launch_equals_the_oracle(S, K, B, num_steps, Tf, k):
+    """phx_rollout_io.frags: k fragments of Tf rows from ONE phx_sc_rollout_sw_kernel launch == rows [i Tf, (i + 1) Tf) of the oracle's
+    k Tf-step rollout (fragments shorter than a 16-row chunk, chunks that straddle two or three fragments, episode ends inside and at
+    fragment boundaries), the state after it, and a following plain rollout; twice in a row (the step counters carry over)."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, seed=11 + S, env_offset=5, variants={"rollout": "store_waves"})
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    dev = d.dev
+    for rep in range(2):
+        outs = [dev.alloc_trajectory(Tf) for _ in range(k)]
+        for t in outs:
+            for x in t[:6]:
+                x.fill_(3)                                       # garbage the launch has to overwrite
+        dev.rollout_fragments(Tf, outs)
+        assert dev.last_kernel() == "phx_sc_rollout_sw_kernel", dev.last_kernel()
+        ro = o.rollout(k * Tf)
+        for i, t in enumerate(outs):
+            _assert_rows(_planes(t), ro, i * Tf, (i + 1) * Tf, f"rep {rep} fragment {i}")
+        np.testing.assert_array_equal(f32_bits(outs[-1].last_obs.cpu().numpy()), f32_bits(ro["last_obs"]))
+        for f in STATE:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after rep {rep}")
+    rd, ro = d.rollout(17), o.rollout(17)
+    np.testing.assert_array_equal(f32_bits(rd["obs"]), f32_bits(ro["obs"]))
+    assert (d.err == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["sc_fsm", "market", "sc_generic", "sc_short"])
+def test_fragment_list_on_envs_other_kernels_serve_is_consecutive_launches(kind):
+    """Everywhere else the call runs one launch per fragment: FSM supply chain (validity planes per fragment), the Stackelberg market,
+    the generic engine, and a supply chain whose fragments are below the store-wave kernel's 40 steps -- each against the oracle."""
+    if kind == "market":
+        env = market_env(8, 24, 4, 10, 16)
+    else:
+        env = supply_chain_env(5, [3] * 5, 9, 16, fsm=kind == "sc_fsm", force_generic=kind == "sc_generic")
+    o, d = OracleEnv(env.spec, threads=4), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    Tf, k = (6, 3)
+    outs = [d.dev.alloc_trajectory(Tf) for _ in range(k)]
+    d.dev.rollout_fragments(Tf, outs)
+    assert "phx_sc_rollout_sw_kernel" not in d.dev.last_kernel()
+    ro = o.rollout(k * Tf)
+    for i, t in enumerate(outs):
+        got = _planes(t)
+        if t.obs_valid is not None:
+            ov, rv = t.obs_valid.cpu().numpy(), t.reward_valid.cpu().numpy()
+            np.testing.assert_array_equal(ov, ro["obs_valid"][i * Tf:(i + 1) * Tf]); np.testing.assert_array_equal(rv, ro["reward_valid"][i * Tf:(i + 1) * Tf])
+            m = ov.astype(bool)
+            np.testing.assert_array_equal(f32_bits(got["obs"][m]), f32_bits(ro["obs"][i * Tf:(i + 1) * Tf][m]))
+            m = rv == 1
+            np.testing.assert_array_equal(f32_bits(got["rewards"][m]), f32_bits(ro["rewards"][i * Tf:(i + 1) * Tf][m]))
+            np.testing.assert_array_equal(got["truncated"], ro["truncated"][i * Tf:(i + 1) * Tf])
+        else:
+            _assert_rows(got, ro, i * Tf, (i + 1) * Tf, f"{kind} fragment {i}")
+    np.testing.assert_array_equal(f32_bits(outs[-1].last_obs.cpu().numpy()), f32_bits(ro["last_obs"]))
+
+
+def test_fragment_list_argument_errors():
+    from phantom_amd.device import DeviceError
+    env = supply_chain_env(9, [6] * 9, 100, 64)
+    d = DeviceRunner(env.spec); d.reset()
+    dev = d.dev
+    with pytest.raises(ValueError):
+        dev.rollout_fragments(10, [dev.alloc_trajectory(10) for _ in range(9)])
+    a, b = dev.alloc_trajectory(50), dev.alloc_trajectory(50, terminations=False)
+    with pytest.raises(ValueError):
+        dev.rollout_fragments(50, [a, b])
+    with pytest.raises(ValueError):
+        dev.rollout_fragments(50, [a, dev.alloc_trajectory(49)])
+
+
+@pytest.mark.parametrize("S,K,B,T,block", [(9, 6, 8192, 48, 0), (3, 2, 4096 * 6, 40, 48), (51, 4, 1024, 41, 0)])
+def test_store_wave_workgroups_walking_several_pair_groups_match_the_oracle(S, K, B, T, block):
+    """More pair groups than the chip holds workgroups (SC64 at B = 8192: 512 groups of 144 pairs, 256 resident workgroups; 48-pair
+    groups; SC256's 128-pair groups): every workgroup walks its groups one after the other (tables staged once) -- every row of every
+    plane and the state after the launch against the oracle, and a second launch from that state."""
+    env = supply_chain_env(S, [K] * S, 30, B, seed=77, variants={"rollout": "store_waves", "block": block})
+    o, d = OracleEnv(env.spec, threads=NCPU), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    for rep in range(2):
+        rd = d.rollout(T)
+        assert d.dev.last_kernel() == "phx_sc_rollout_sw_kernel"
+        ro = o.rollout(T)
+        for k in ("obs", "actions", "rewards"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"{k} rep {rep}")
+        np.testing.assert_array_equal(rd["truncated"], ro["truncated"]); np.testing.assert_array_equal(rd["terminated"], ro["terminated"])
+        for f in STATE:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} rep {rep}")
+
+
+def test_bench_shape_all_400_rows_against_the_oracle():
+    """SC64, B = 4096, T = 400 from the library's own choice of kernel: every row of every plane against the oracle (round 4 compared
+    rows 0-99 with the oracle and the rest with round 3's kernel)."""
+    B, S, T = 4096, 9, 400
+    env = supply_chain_env(S, [6] * S, 100, B, seed=42)
+    o, d = OracleEnv(env.spec, threads=NCPU), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    tr = d.dev.rollout(T)
+    assert d.dev.last_kernel() == "phx_sc_rollout_sw_kernel"
+    ro = o.rollout(T)
+    _assert_rows(_planes(tr), ro, 0, T, "bench shape")
+    np.testing.assert_array_equal(f32_bits(tr.last_obs.cpu().numpy()), f32_bits(ro["last_obs"]))
+    for f in STATE:
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
+
+
+# ---- the four-pairs-per-thread step kernel on grids of several workgroups ------------------------------------------------
+@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 300, 5), (1, 3, 3000, 4), (51, 4, 44, 6), (9, 6, 1028, 3)])
+def test_wide_step_kernel_on_several_workgroups_with_a_partial_tail(S, K, B, num_steps):
+    """variants={"step": "wide"} with more (env, shop) pairs than one workgroup holds and a partial last workgroup: blockIdx > 0
+    indexing, the per-block env / shop split, the 4 x 256 env-word loop -- against the oracle and the lane-per-pair kernel."""
+    env_w = supply_chain_env(S, [K] * S, num_steps, B, seed=9 + S, env_offset=3, variants={"step": "wide"})
+    env_f = supply_chain_env(S, [K] * S, num_steps, B, seed=9 + S, env_offset=3, variants={"step": "fused"})
+    o, w, f = OracleEnv(env_w.spec, threads=8), DeviceRunner(env_w.spec), DeviceRunner(env_f.spec)
+    o.reset(); w.reset(); f.reset()
+    rng = np.random.default_rng(S + B)
+    for t in range(2 * num_steps + 2):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        valid = None if t % 3 else (rng.random((B, S)) < 0.7).astype(np.uint8)
+        o.step(a, valid, None)
+        w.step(a, valid, None); assert w.dev.last_kernel() == "phx_sc_step_wide_kernel"
+        f.step(a, valid, None); assert f.dev.last_kernel() == "phx_sc_step_kernel"
+        for dd in (w, f):
+            np.testing.assert_array_equal(f32_bits(dd.obs), f32_bits(o.obs), err_msg=f"obs, step {t}")
+            np.testing.assert_array_equal(f64_bits(dd.reward), f64_bits(o.reward), err_msg=f"reward, step {t}")
+            for k in ("obs_valid", "reward_valid", "terminated", "truncated", "done_valid", "all_terminated", "all_truncated"):
+                np.testing.assert_array_equal(getattr(dd, k), getattr(o, k), err_msg=f"{k}, step {t}")
+            for fl in STATE:
+                np.testing.assert_array_equal(dd.get_i32(fl), o.get_i32(fl), err_msg=f"{fl}, step {t}")
+        if o.all_truncated.any():
+            m = o.all_truncated.astype(np.uint8)
+            o.reset(m); w.reset(m); f.reset(m)
+    assert (w.err == 0).all()
+
+
+def test_vs_auto_takes_the_wide_step_kernel_at_65536_envs_and_matches():
+    """PHX_VS_AUTO at SC64, B = 65 536 (589 824 pairs >= 2^19): the library's own choice is phx_sc_step_wide_kernel -- against
+    variants={"step": "fused"} on the same inputs and against the oracle, over an episode end."""
+    S, K, B, num_steps = 9, 6, 65536, 3
+    env_a = supply_chain_env(S, [K] * S, num_steps, B, seed=2)
+    env_f = supply_chain_env(S, [K] * S, num_steps, B, seed=2, variants={"step": "fused"})
+    o, a_, f = OracleEnv(env_a.spec, threads=NCPU), DeviceRunner(env_a.spec), DeviceRunner(env_f.spec)
+    o.reset(); a_.reset(); f.reset()
+    rng = np.random.default_rng(0)
+    for t in range(num_steps + 2):
+        act = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(act, None, None)
+        a_.step(act, None, None); assert a_.dev.last_kernel() == "phx_sc_step_wide_kernel", a_.dev.last_kernel()
+        f.step(act, None, None); assert f.dev.last_kernel() == "phx_sc_step_kernel"
+        for dd in (a_, f):
+            np.testing.assert_array_equal(f32_bits(dd.obs), f32_bits(o.obs), err_msg=f"obs, step {t}")
+            np.testing.assert_array_equal(f64_bits(dd.reward), f64_bits(o.reward), err_msg=f"reward, step {t}")
+            np.testing.assert_array_equal(dd.truncated, o.truncated); np.testing.assert_array_equal(dd.all_truncated, o.all_truncated)
+            np.testing.assert_array_equal(dd.get_i32("shop.stock"), o.get_i32("shop.stock"))
+        if o.all_truncated.any():
+            m = o.all_truncated.astype(np.uint8)
+            o.reset(m); a_.reset(m); f.reset(m)
+
+
+def test_wide_step_kernel_declines_misaligned_planes():
+    """The wide kernel reads and writes 16-byte pieces: with an action plane (or an output plane) that starts 4 bytes off a 16-byte
+    boundary the launch falls back to phx_sc_step_kernel (commit aae3924) -- same results."""
+    import ctypes as C
+    import torch
+    S, K, B, num_steps = 9, 6, 64, 5
+    env = supply_chain_env(S, [K] * S, num_steps, B, seed=4, variants={"step": "wide"})
+    o, d = OracleEnv(env.spec, threads=4), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    dev = d.dev
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+    pad = torch.zeros(B * S + 4, dtype=torch.float32, device=dev.device)
+    pad[1:1 + B * S] = torch.from_numpy(a).to(dev.device).view(-1)
+    act = pad[1:1 + B * S].view(B, S)
+    assert act.data_ptr() % 16 == 4
+    dev.step(act)
+    assert dev.last_kernel() == "phx_sc_step_kernel", dev.last_kernel()
+    o.step(a, None, None)
+    np.testing.assert_array_equal(f32_bits(dev.obs.cpu().numpy()), f32_bits(o.obs))
+    np.testing.assert_array_equal(f64_bits(dev.reward.cpu().numpy()), f64_bits(o.reward))
+    a2 = rng.uniform(0, 100, (B, S)).astype(np.float32)
+    dev.step(torch.from_numpy(a2).to(dev.device))
+    assert dev.last_kernel() == "phx_sc_step_wide_kernel"
+    o.step(a2, None, None)
+    np.testing.assert_array_equal(f32_bits(dev.obs.cpu().numpy()), f32_bits(o.obs))

@@ -17,6 +17,7 @@ ap.add_argument("--bufs", type=int, default=0, help="trajectory buffers rotated 
 ap.add_argument("--block", default="0", help="variants['block']: pairs per workgroup, whole_envs, or 0 = auto")
 ap.add_argument("--rollout", default="auto", help="variants['rollout']")
 ap.add_argument("--tblock", type=int, default=0, help="phx_rollout_io.t_block (0 / 1: time-major)")
+ap.add_argument("--frags", type=int, default=1, help="fragments of T rows per call (phx_rollout_io.frags)")
 a = ap.parse_args()
 cls = ph.SupplyChainFSMEnv if a.fsm else ph.SupplyChainEnv
 blk = a.block if a.block == "whole_envs" else int(a.block)
@@ -33,14 +34,23 @@ torch.cuda.synchronize()
 h = hashlib.sha1()
 for x in (tr.observations, tr.actions, tr.rewards, tr.truncations):
     h.update(x.cpu().numpy().tobytes())
+k = a.frags
+if k > 1:                      # k fragments per call, the call's buffers rotated like single fragments
+    nb = max(nb, 2 * k) // k * k
+    trs = trs + [dev.alloc_trajectory(a.T) for _ in range(nb - len(trs))]
+    call = lambda i: dev.rollout_fragments(a.T, trs[(i * k) % nb:(i * k) % nb + k])
+else:
+    call = lambda i: dev.rollout(a.T, out=trs[i % nb])
 for i in range(20):
-    dev.rollout(a.T, out=trs[i % nb])
+    call(i)
 best = 1e9
 for rep in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(a.n):
-        dev.rollout(a.T, out=trs[i % nb])
+        call(i)
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / a.n * 1e3)
-print(f"{a.tag:28s} T={a.T:5d} bufs={nb:2d} {best:8.2f} us/launch  {best * 100 / a.T:7.2f} us/100 steps  {alg / best / 1e3 / 8000:.3f} of 8 TB/s  sha {h.hexdigest()[:12]}", flush=True)
+tot = a.T * k
+alg_call = a.batch * tot * 22 * S + a.batch * (S * 32 + 16)
+print(f"{a.tag:28s} T={a.T:5d} x{k} bufs={nb:2d} {best:8.2f} us/call  {best * 100 / tot:7.2f} us/100 steps  {alg_call / best / 1e3 / 8000:.3f} of 8 TB/s  sha {h.hexdigest()[:12]}  {dev.last_kernel()}", flush=True)
