@@ -106,6 +106,52 @@ def cpu_baseline(budget_s=12.0):
                                                "/root/reference, SURVEY section 6 / BASELINE.md section 2"}}
 
 
+def box_info():
+    """What can differ between two leases of "an MI355X" (VERDICT r4 #5): position in the node, serial, partition modes, firmware and
+    driver versions, clocks and power at the end of the run -- recorded beside the number so that the two kinds of box the rollout
+    kernel sees (53 vs 59-65 us per T = 400 launch at equal clocks and equal plain-fill rate) can be told apart over time."""
+    import glob
+    import re
+    import subprocess
+    info = {}
+
+    def sh(cmd):
+        try:
+            return subprocess.run(cmd, capture_output=True, text=True, timeout=20).stdout
+        except Exception:
+            return ""
+
+    st = sh(["amd-smi", "static", "--gpu", "0"]) or sh(["amd-smi", "static"])
+    for key in ("MARKET_NAME", "ASIC_SERIAL", "OAM_ID", "NUM_COMPUTE_UNITS", "PART_NUMBER", "BUILD_DATE", "SOCKET_POWER_LIMIT", "MODEL_NUMBER",
+                "PRODUCT_SERIAL", "COMPUTE_PARTITION", "MEMORY_PARTITION", "VRAM_VENDOR", "VRAM_SIZE", "BIT_WIDTH", "MAX_BANDWIDTH"):
+        m = re.search(r"^\s*" + key + r":\s*(.+)$", st, re.M)
+        if m:
+            info[key.lower()] = m.group(1).strip()
+    m = re.search(r"DRIVER:\s*\n\s*NAME:\s*(\S+)\s*\n\s*VERSION:\s*(.+)", st)
+    if m:
+        info["driver"] = (m.group(1) + " " + m.group(2).strip())[:120]
+    for name in ("current_memory_partition", "current_compute_partition", "vbios_version"):
+        for f in sorted(glob.glob(f"/sys/class/drm/card*/device/{name}"))[:1]:
+            try:
+                info[name] = open(f).read().strip()
+            except OSError:
+                pass
+    fw = sh(["rocm-smi", "--showfwinfo"])
+    info["firmware"] = {m.group(1).strip(): m.group(2).strip() for m in re.finditer(r"GPU\[0\]\s*:\s*(.+?) firmware version:\s*(\S+)", fw)}
+    met = sh(["amd-smi", "metric", "--gpu", "0", "--clock", "--power", "--temperature", "--ecc"])
+    for key, pat in (("gfx_clk", r"GFX_0:\s*\n\s*CLK:\s*(.+)"), ("mem_clk", r"MEM_0:\s*\n\s*CLK:\s*(.+)"), ("socket_power", r"SOCKET_POWER:\s*(.+)"),
+                     ("hotspot_temp", r"HOTSPOT:\s*(.+)"), ("mem_temp", r"\bMEM:\s*(\d.+)"), ("ecc_total_correctable", r"TOTAL_CORRECTABLE_COUNT:\s*(.+)")):
+        m = re.search(pat, met)
+        if m:
+            info[key] = m.group(1).strip()
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        info["torch"] = {"name": pr.name, "cus": pr.multi_processor_count, "total_memory": pr.total_memory, "torch": torch.__version__, "hip": torch.version.hip}
+    except Exception:
+        pass
+    return info
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -179,7 +225,10 @@ def other_configs(device):
     tr4 = dev.alloc_trajectory(400)
     add("SC256 B=8192 per GPU (config 4)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 16), "fused rollout T=400",
         bytes_per_env_step=22 * 51)
-    del env, dev, tr, tr4; torch.cuda.empty_cache()
+    fr = [dev.alloc_trajectory(100) for _ in range(4)]
+    add("SC256 B=8192 per GPU (config 4)", 256, 8192, 400, timed(lambda: dev.rollout_fragments(100, fr), 16),
+        "fused rollout, 4 fragments of T=100 per call (phx_rollout_io.frags)", bytes_per_env_step=22 * 51)
+    del env, dev, tr, tr4, fr; torch.cuda.empty_cache()
     # config 5: Stackelberg market 128 leaders / 1024 followers, B = 4096
     env = market_env(128, 1024, 8, 100, 4096, exogenous="device", device=device)
     env.reset(); dev = env._device()
@@ -353,9 +402,12 @@ def main():
                     help="the K-step region is repeated back to back until the timed region lasts at least this long")
     ap.add_argument("--buffers", type=int, default=0,
                     help="trajectory buffers the launches rotate over (default: enough for > 320 MB, at least 4)")
-    ap.add_argument("--episodes-per-launch", type=int, default=4,
-                    help="episodes (of num_steps = 100 steps) per phx_rollout launch: a time-major T = 400 fragment is four "
-                         "consecutive T = 100 fragments in memory; start-up / drain and the launch gap are paid once per launch")
+    ap.add_argument("--episodes-per-launch", type=int, default=1,
+                    help="episodes (of num_steps = 100 steps) per trajectory FRAGMENT (one buffer)")
+    ap.add_argument("--fragments-per-call", type=int, default=8,
+                    help="fragments per phx_rollout call (phx_rollout_io.frags, ABI 9): the consumer gets one-episode fragments in separate "
+                         "buffers, the pipeline fill, the placement of a 160 KB workgroup on every CU and the kernel boundary are paid once "
+                         "per call (round 4: ONE four-episode fragment per launch = --episodes-per-launch 4 --fragments-per-call 1)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the library's default block shape (no env.autotune_rollout)")
     ap.add_argument("--watchdog-s", type=float, default=900.0, help="overall deadline; a JSON line with `error` is printed when it passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -438,22 +490,27 @@ def run(args, rank, local_rank, world, watch):
     env = ph.SupplyChainEnv(n_shops=N_SHOPS, customers_per_shop=CUST_PER_SHOP, num_steps=NUM_STEPS,
                             batch_size=B, seed=42, env_offset=rank * B, exogenous="device",
                             device=f"cuda:{local_rank}")
-    T = NUM_STEPS * max(1, args.episodes_per_launch)        # steps per launch
+    NF = max(1, min(args.fragments_per_call, 8))            # fragments per call
+    TF = NUM_STEPS * max(1, args.episodes_per_launch)       # steps per fragment
+    T = TF * NF                                             # steps per launch
     tune = None
     if not args.no_autotune:
         # block shape of the rollout kernel picked on THIS box (every variant gives the same trajectories): outside
         # the timed region, a few launches per candidate (PhantomEnv.autotune_rollout)
         watch.stage("autotune", 180)
-        tune = env.autotune_rollout(T)
+        tune = env.autotune_rollout(min(T, 4 * NUM_STEPS))
     dev = env._device()
     assert dev.uses_fused, "bench expects the fused supply-chain kernels"
     env.reset()
     # The launches rotate over several trajectory buffers whose total exceeds the 256 MB Infinity Cache, so that
     # every fragment's bytes are really written to HBM (one 82 MB buffer rewritten in place could live in the cache)
-    frag_bytes = algorithmic_bytes_rollout(B, S, T)
-    n_buf = args.buffers if args.buffers > 0 else max(2, -(-(320 << 20) // frag_bytes))
-    trajs = [dev.rollout(T) for _ in range(n_buf)]           # allocates the trajectory buffers once
-    traj = trajs[0]
+    frag_bytes = algorithmic_bytes_rollout(B, S, T)          # per CALL (all its fragments)
+    n_buf = args.buffers if args.buffers > 0 else max(2, -(-(320 << 20) // frag_bytes))      # sets of NF fragment buffers
+    sets = [[dev.alloc_trajectory(TF) for _ in range(NF)] for _ in range(n_buf)]             # allocates the trajectory buffers once
+    for st_ in sets:
+        dev.rollout_fragments(TF, st_)
+    trajs = sets
+    traj = sets[0]
     rot = [0]
 
     # The store-wave kernel (round 4) writes every flag word from its store waves; round 3's kernel, where it serves the launch,
@@ -464,11 +521,11 @@ def run(args, rank, local_rank, world, watch):
     use_pipe = False                                          # (round 3's --flag-pipeline experiment was removed: measured slower)
     pipe_on = [False]
 
-    def launches(n, bufs=None):                             # n full-length fragments, back to back
+    def launches(n, bufs=None):                             # n calls of NF fragments each, back to back
         bufs = bufs or trajs
         k = rot[0]
         for _ in range(n):
-            dev.rollout(T, out=bufs[k % len(bufs)]); k += 1
+            dev.rollout_fragments(TF, bufs[k % len(bufs)]); k += 1
         rot[0] = k
 
     def sync_barrier():
@@ -520,12 +577,12 @@ def run(args, rank, local_rank, world, watch):
         "config": {"workload": f"supply-chain {args.config.upper()} (1 factory + {N_SHOPS} shops + "
                                f"{N_SHOPS * CUST_PER_SHOP} customers = {N_AGENTS} agents), "
                                f"batch {B} envs per GPU, random actions U[0,100), device-RNG orders, "
-                               f"fused on-device rollouts of T={T} steps ({T // NUM_STEPS} episodes of {NUM_STEPS} steps) per launch "
-                               "with the full trajectory written to HBM",
+                               f"fused on-device rollouts: {NF} fragment(s) of {TF} steps ({TF // NUM_STEPS} episode(s) of {NUM_STEPS} steps) each, "
+                               f"in separate buffers, per phx_rollout call (T={T} steps per launch) with the full trajectory written to HBM",
                    "agents": N_AGENTS, "envs_per_gpu": B, "global_envs": B * world,
                    "num_steps": NUM_STEPS, "mode": "phx_rollout", "sharding": f"env-batch x{world}, no step-time collective",
-                   "trajectory_buffers": f"{n_buf} x {frag_bytes / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)",
-                   "steps_per_launch": T, "episodes_per_launch": T // NUM_STEPS,
+                   "trajectory_buffers": f"{n_buf} sets x {NF} fragments x {frag_bytes / NF / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)",
+                   "steps_per_launch": T, "episodes_per_launch": T // NUM_STEPS, "fragments_per_call": NF, "steps_per_fragment": TF,
                    "autotune": tune,
                    "flag_planes": ("zeros of the next buffer's terminated / truncated planes written on a side stream beside the current "
                                    "fragment (PHX_RH_FLAGS_ZEROED), non-zero words by the kernel" if use_pipe else
@@ -535,7 +592,7 @@ def run(args, rank, local_rank, world, watch):
                    "served_by": served_by},
         "repeats": R, "timed_steps": R * K, "timed_launches": n_launch, "timed_region_ms": elapsed * 1e3,
         "warmup_launches": n_warm,
-        "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} fragments of {T} steps; "
+        "timing_note": f"the {K}-step region is run {R}x back to back as {n_launch} calls of {NF} x {TF} steps; "
                        "ms_per_step = timed_region_ms / (repeats * steps)",
         "env_steps_per_sec": B * world * (R * K) / elapsed,
         "control_plane": "gloo" if dist is not None else None,
@@ -556,7 +613,7 @@ def run(args, rank, local_rank, world, watch):
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / n
 
-    n_full = max(100, 400 * NUM_STEPS // T)
+    n_full = max(60, 400 * NUM_STEPS // T)
     launch_ms = event_ms(n_full)                              # rotating over the buffers: HBM
     same_ms = event_ms(n_full, [traj])                        # one buffer rewritten in place (round 2's loop): may sit in the Infinity Cache
     inline_ms = None
@@ -575,37 +632,41 @@ def run(args, rank, local_rank, world, watch):
             traffic = None
     # the same kernel with ONE episode per launch (T = 100, what rounds 1-2 reported): the launch gap, the block ramp and the
     # two pipeline iterations before the first store are paid per 82 MB instead of per launch of T steps; informational
-    frag1 = None
-    try:
-        if args.no_frag200 or T == NUM_STEPS:
-            raise RuntimeError("skipped")
-        alg1 = algorithmic_bytes_rollout(B, S, NUM_STEPS)
-        t1 = [dev.rollout(NUM_STEPS) for _ in range(max(2, -(-(320 << 20) // alg1)))]
+    def single_launch_shape(Tl, n):
+        """ONE fragment of Tl steps per launch (rounds 1-4's launch shapes), buffers rotated: what a caller pays who asks for one
+        fragment per call"""
+        algl = algorithmic_bytes_rollout(B, S, Tl)
+        tb = [dev.alloc_trajectory(Tl) for _ in range(max(2, -(-(320 << 20) // algl)))]
         for k in range(10):
-            dev.rollout(NUM_STEPS, out=t1[k % len(t1)])
+            dev.rollout(Tl, out=tb[k % len(tb)])
+        kern = dev.last_kernel()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
-        for k in range(400):
-            dev.rollout(NUM_STEPS, out=t1[k % len(t1)])
+        for k in range(n):
+            dev.rollout(Tl, out=tb[k % len(tb)])
         g1.record(); torch.cuda.synchronize()
-        ms1 = g0.elapsed_time(g1) / 400
-        frag1 = {"T": NUM_STEPS, "launch_ms": ms1, "achieved": alg1 / (ms1 * 1e-3) / 1e9,
-                 "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "buffers": len(t1)}
-        del t1
-        dev.rollout(T, out=traj)                 # back to the bench fragment's buffers
+        ms = g0.elapsed_time(g1) / n
+        return {"T": Tl, "launch_ms": ms, "achieved": algl / (ms * 1e-3) / 1e9, "frac": algl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "buffers": len(tb), "kernel": kern, "agent_steps_per_sec": N_AGENTS * B * Tl / (ms * 1e-3)}
+    frag1 = frag4 = None
+    try:
+        if args.no_frag200:
+            raise RuntimeError("skipped")
+        frag1 = single_launch_shape(NUM_STEPS, 400)
+        frag4 = single_launch_shape(4 * NUM_STEPS, 120)
     except Exception as e:                       # report, do not hide
-        frag1 = {"error": str(e)}
+        frag1 = frag1 or {"error": str(e)}
     # the same launches WITHOUT the `terminations` plane (all zero: ShopAgent never terminates; phx_rollout_io.terminated = NULL):
     # 21 instead of 22 bytes per shop-step.  Informational: `value` and `roofline` above write the full 22-byte record.
     no_term = None
     try:
-        tn = [dev.alloc_trajectory(T, terminations=False) for _ in range(n_buf)]
+        tn = [[dev.alloc_trajectory(TF, terminations=False) for _ in range(NF)] for _ in range(n_buf)]
         for k in range(4):
-            dev.rollout(T, out=tn[k % n_buf])
+            dev.rollout_fragments(TF, tn[k % n_buf])
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
         for k in range(n_full):
-            dev.rollout(T, out=tn[k % n_buf])
+            dev.rollout_fragments(TF, tn[k % n_buf])
         g1.record(); torch.cuda.synchronize()
         msn = g0.elapsed_time(g1) / n_full
         algn = alg - B * T * S
@@ -628,7 +689,11 @@ def run(args, rank, local_rank, world, watch):
     del fills
     # which kind of box this is (VERDICT r3 Weak #8): the same binary takes 65-69 us per T = 400 fragment on one MI355X and 5-8 % more on
     # another; the plain fill of the same bytes (below) and the tuning pass's per-candidate times tell them apart
-    box_class = "fast" if fill_gbs >= 6500.0 else ("typical" if fill_gbs >= 5800.0 else "slow")
+    # (round 4 derived the class from the fill rate, which is the same on both kinds; what separates them is how close the rollout's
+    #  store pattern gets to that fill: >= 0.88 of it on the boxes that sustain 52-54 us per T = 400 launch, 0.75-0.86 on the others)
+    ref = frag4 if (frag4 and "frac" in frag4) else None
+    fof = (ref["achieved"] / fill_gbs) if ref else achieved / fill_gbs
+    box_class = "fast" if fof >= 0.88 else "slow"
     out["roofline"] = {"bound": "hbm", "kernel": served_by, "achieved": achieved, "box_class": box_class,
                        "trace_equivalent": {"what": "kernel(s) of one phx_rollout call as a rocprofv3 kernel trace would sum them "
                                                     "(the event pair brackets back-to-back calls: launch gaps included)",
@@ -641,7 +706,13 @@ def run(args, rank, local_rank, world, watch):
                                        "note": "every launch rewrites ONE buffer in place (a T = 100 fragment fits the 256 MB Infinity Cache): not the HBM figure"},
                        "measured_fill_GBps_same_bytes": fill_gbs, "frac_of_measured_fill": achieved / fill_gbs,
                        "ms_per_100_steps": launch_ms * NUM_STEPS / T,
-                       "one_episode_per_launch": frag1, "without_terminations_plane": no_term}
+                       "one_episode_per_launch": frag1, "four_episodes_one_fragment_per_launch": frag4,
+                       "box_class_from": {"frac_of_measured_fill_at_T400_single_launch": fof, "rule": ">= 0.88: fast, else slow"},
+                       "without_terminations_plane": no_term}
+    try:
+        out["box"] = box_info()
+    except Exception as e:                       # informational
+        out["box"] = {"error": str(e)[:200]}
     if inline_ms is not None:
         out["roofline"]["flag_fill_in_line"] = {"launch_ms": inline_ms, "frac": alg / (inline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "note": "phx_rollout zeroes the flag planes itself before the kernel (no side stream, no hint): fill + kernel in series"}
@@ -758,12 +829,83 @@ def bench_per_step(env, dev, B, S, world, sync_barrier):
         res["rllib_adapter"] = bench_rllib_adapter(env, B, S)
     except Exception as e:                                   # report, do not hide
         res["rllib_adapter"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+    try:
+        res["on_policy"] = bench_on_policy(env, dev, B, S)
+    except Exception as e:                                   # report, do not hide
+        res["on_policy"] = {"error": f"{type(e).__name__}: {e}"[:500]}
     if world == 1:
         try:
             res["batch_sweep"] = bench_step_sweep(dev.device)
         except Exception as e:                               # report, do not hide
             res["batch_sweep"] = {"error": f"{type(e).__name__}: {e}"[:500]}
     return res
+
+
+def bench_on_policy(env, dev, B, S):
+    """A LEARNED policy in the loop (utils/rllib/rollout.py:300-363 calls the policy for every agent at every step): a small torch MLP
+    maps the step's observations to the next actions between the per-step launches; reset, the T = 100 act / step iterations and the
+    copies of every step's observation, action, reward and done flags into a time-major trajectory are captured ONCE in a hipGraph and
+    replayed.  What one launch per step plus inference costs next to the random-policy fused rollout."""
+    T = NUM_STEPS
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1)).to(dev.device)
+    for p_ in mlp.parameters():
+        p_.requires_grad_(False)
+    obs = torch.empty(T, B, S, 3, device=dev.device); act = torch.empty(T, B, S, device=dev.device)
+    rew = torch.empty(T, B, S, device=dev.device); tru = torch.empty(T, B, S, dtype=torch.uint8, device=dev.device)
+
+    def episode():
+        o, _ = dev.reset()
+        for i in range(T):
+            torch.mul(torch.sigmoid(mlp(o).squeeze(-1)), 100.0, out=act[i])
+            st = dev.step(act[i])
+            obs[i].copy_(st.observations); rew[i].copy_(st.rewards); tru[i].copy_(st.truncations)
+            o = st.observations
+
+    dev._ensure_step_io()
+    episode(); torch.cuda.synchronize()                       # eager once (also warms the GEMM heuristics), then captured
+    eager0 = time.perf_counter(); episode(); torch.cuda.synchronize(); eager = time.perf_counter() - eager0
+    g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(dev.device)
+    with torch.cuda.graph(g, stream=side):
+        episode()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    assert int(tru[T - 1].sum()) == B * S and int(tru[:T - 1].sum()) == 0      # one whole episode per replay
+    # policy-only and env-only shares: the same graph without the step launches / without the MLP
+    def timed_graph(body):
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg, stream=side):
+            body()
+        torch.cuda.synchronize(); gg.replay(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            gg.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n
+    o0 = dev.obs
+
+    def pol_only():
+        for i in range(T):
+            torch.mul(torch.sigmoid(mlp(o0).squeeze(-1)), 100.0, out=act[i])
+
+    def env_only():
+        dev.reset()
+        for i in range(T):
+            dev.step(act[i])
+    tp, te = timed_graph(pol_only), timed_graph(env_only)
+    return {"policy": "MLP 3-32-1 (tanh, sigmoid x 100) on every (env, shop) observation, torch fp32", "steps_per_replay": T,
+            "us_per_step": dt / T * 1e6, "agent_steps_per_sec": N_AGENTS * B * T / dt,
+            "us_per_step_policy_alone": tp / T * 1e6, "us_per_step_env_launches_alone": te / T * 1e6,
+            "us_per_step_eager": eager / T * 1e6, "trajectory": "obs / action / reward / truncated copied per step into [T, B, S, ..] buffers inside the graph",
+            "note": "one phx_step launch per step with the policy's kernels between the launches (hipGraph of one episode incl. reset)"}
 
 
 def bench_step_sweep(device):

@@ -191,3 +191,38 @@ def test_mt19937_streams_on_an_fsm_env_draw_for_the_stage_s_customers_only(lib, 
         allx = np.zeros((T, B, n), np.uint8)
         assert lib.phx_mt_draw(r2.h, _p(allx), T, None) == 0
         np.testing.assert_array_equal(allx, g["exo"])
+
+
+def test_fragment_list_through_the_abi_equals_one_long_rollout(lib):
+    """ABI 9, phx_rollout_io.frags: k fragments of Tf rows == rows [i Tf, (i + 1) Tf) of ONE k Tf-step rollout from the same state;
+    malformed lists are refused."""
+    B, S, Tf, k = 5, 3, 7, 3
+    env = supply_chain_env(S, [2] * S, 10, B, seed=8)
+    one, lst = CpuAbiRunner(lib, env.spec), CpuAbiRunner(lib, env.spec)
+    one.reset(); lst.reset()
+    T = Tf * k
+    mk = lambda n: dict(obs=np.zeros((n, B, S, 3), np.float32), act=np.zeros((n, B, S), np.float32), rew=np.zeros((n, B, S), np.float32),
+                        ter=np.full((n, B, S), 9, np.uint8), tru=np.full((n, B, S), 9, np.uint8))
+    whole, last_a, last_b = mk(T), np.zeros((B, S, 3), np.float32), np.zeros((B, S, 3), np.float32)
+    io = _abi.PhxRolloutIO()
+    io.T = T
+    io.obs, io.action_out, io.reward, io.terminated, io.truncated = (_p(whole[n]) for n in ("obs", "act", "rew", "ter", "tru"))
+    io.last_obs, io.err = _p(last_a), _p(one.err)
+    assert lib.phx_rollout(one.h, C.byref(io), None) == 0
+    parts = [mk(Tf) for _ in range(k)]
+    arr = (_abi.PhxRolloutFrag * k)()
+    for i, p in enumerate(parts):
+        arr[i].obs, arr[i].action_out, arr[i].reward, arr[i].terminated, arr[i].truncated = (_p(p[n]) for n in ("obs", "act", "rew", "ter", "tru"))
+    io2 = _abi.PhxRolloutIO()
+    io2.T, io2.n_frag, io2.frags = T, k, C.cast(arr, C.c_void_p)
+    io2.last_obs, io2.err = _p(last_b), _p(lst.err)
+    assert lib.phx_rollout(lst.h, C.byref(io2), None) == 0
+    for i, p in enumerate(parts):
+        for n in ("obs", "act", "rew", "ter", "tru"):
+            np.testing.assert_array_equal(p[n].view(np.uint8), whole[n][i * Tf:(i + 1) * Tf].view(np.uint8), err_msg=f"fragment {i} {n}")
+    np.testing.assert_array_equal(f32_bits(last_a), f32_bits(last_b))
+    np.testing.assert_array_equal(one.get_i32("shop.stock", (B, S)), lst.get_i32("shop.stock", (B, S)))
+    io2.T = T + 1                                              # not a multiple of n_frag
+    assert lib.phx_rollout(lst.h, C.byref(io2), None) < 0
+    io2.T, io2.obs = T, _p(whole["obs"])                       # the io's own planes beside a list
+    assert lib.phx_rollout(lst.h, C.byref(io2), None) < 0
