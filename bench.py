@@ -859,7 +859,8 @@ def bench_on_policy(env, dev, B, S):
         for i in range(T):
             torch.mul(torch.sigmoid(mlp(o).squeeze(-1)), 100.0, out=act[i])
             st = dev.step(act[i])
-            obs[i].copy_(st.observations); rew[i].copy_(st.rewards); tru[i].copy_(st.truncations)
+            obs[i].copy_(st.observations); rew[i].copy_(st.rewards)
+            torch.maximum(st.truncations, st.all_truncated[:, None], out=tru[i])      # per-agent flag OR truncations["__all__"], as phx_rollout records it
             o = st.observations
 
     dev._ensure_step_io()

@@ -1080,7 +1080,7 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   note_reset();
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
-  if (e->d.env_type != PHX_ENV_PLAIN && (!io->obs_valid || !io->reward_valid))
+  if (e->d.env_type != PHX_ENV_PLAIN && !(io->n_frag >= 2 || io->frags) && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
   if (io->n_frag >= 2 || io->frags) {   // ABI 9: a fragment list
     if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags) return fail(PHX_EINVAL, "phx_rollout: a fragment list needs 2 .. %d fragments and `frags`", PHX_MAX_FRAGMENTS);
