@@ -346,7 +346,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   for (int r = 0; r < PHX_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     // three-way xor in ONE instruction (gfx950: v_bitop3_b32, truth table 0x96); the compiler emits two v_xor_b32 otherwise
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)      /* PHX_OFFLOAD_ARCH builds for other CDNA parts: no v_bitop3_b32 */
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+#else
     const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+#endif
     c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

@@ -50,6 +50,11 @@ struct SwArgs {
   // ---- (past the argument lines the kernel warms at entry) ----
   int32_t n_groups;                     // pair groups of the launch (B S / G): workgroup w walks groups w, w + gridDim.x, .. one after the other
   int32_t frag_T, n_frag;               // rows per trajectory fragment, fragments (frag_T * n_frag == T; one fragment: frag_T == T)
+  // replayed inputs (REPLAY instantiations): io.actions [T][B][S] and / or io.exo [T][B][n_exo]
+  int32_t n_exo, guard_gen;             // exogenous columns per env; this launch's number for `guard`
+  const int32_t* exo_first;             // [S] exogenous column of each shop's first customer (its K customers' columns are consecutive)
+  const int32_t* guard;                 // device word: == guard_gen -> a replayed action rounds below zero (the pre-scan of this call found
+                                        // one): the stock would leave [0, 100], this kernel does nothing and round 1's kernel serves the call
   SwFrag frag[PHX_MAX_FRAGMENTS];       // row t of the launch is row t - f * frag_T of fragment f = t / frag_T
 };
 
@@ -93,7 +98,10 @@ __device__ __forceinline__ void sw_store16(char* p, const float4 v) { __builtin_
 
 // GT > 0: the workgroup shape is a compile-time constant (GT pairs, NREC recurrence waves, NSTORE store waves): every
 // index computation on G folds, the kernel keeps fewer uniform values alive (the generic instantiation spills ~60 SGPRs).
-template <int TC, int GT, int NREC, int NSTORE, int NWORK>
+// REPLAY: the policy's actions and / or the customers' order sizes come from HBM (phx_rollout_io.actions / exo: a recorded policy,
+// the reference's own numpy stream -- phx_mt_draw) instead of the Philox block: the draw phase loads them (4 S and S K more bytes
+// read per env-step) and the rest of the pipeline is the same.
+template <int TC, int GT, int NREC, int NSTORE, int NWORK, bool REPLAY>
 __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_) {
   sw_kptr_t kp = (sw_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   { uint32_t d0, d1, d2, d3, d4;          // every 64-byte line of the argument block into the scalar cache at once, not one miss per phase (setup 1.6 -> 1.2 us)
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     asm volatile("s_load_dword %0, %5, 0x0\n s_load_dword %1, %5, 0x40\n s_load_dword %2, %5, 0x80\n s_load_dword %3, %5, 0xc0\n s_load_dword %4, %5, 0x100\n s_waitcnt lgkmcnt(0)"
                  : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(kp) : "memory"); }
   SW_REFRESH();
+  if (REPLAY && a.guard && *a.guard == a.guard_gen) return;             // (uniform) an action outside the kernel's domain: round 1's kernel takes the call
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, NT = GT ? 64 * (NREC + NSTORE + NWORK) : (int)blockDim.x, nS = a.S, G = GT ? GT : a.G;
   const int64_t total = (int64_t)a.B * nS;
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   const bool draws_fixed = (nwk % G) == 0;
 #endif
   int dl_gl = 0, dl_jr0 = 0, dl_s = 0; uint32_t dl_tick0 = 0; int64_t dl_genv = 0;
+  const bool rp_act = REPLAY && io.actions != nullptr, rp_exo = REPLAY && io.exo != nullptr;
   if (wt >= 0) {
     dl_jr0 = (int)div_G((uint32_t)wt); dl_gl = wt - dl_jr0 * G;
     const uint32_t pr = s_pair[dl_gl];
@@ -272,13 +282,38 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       const int tla = 4 * jr - (aligned ? 0 : (int)(tick_base & 3u));
       if (!aligned && (tla + 3 < 0 || tla >= tc)) continue;
       const uint32_t tick_a = tick_base + (uint32_t)tla;                 // multiple of 4
-      uint32_t w[4];
+      // replayed inputs first: their loads are in flight while the Philox block (if one is needed) is computed
+      float av[4] = {0.f, 0.f, 0.f, 0.f};
+      int Dx[4] = {0, 0, 0, 0};
+      if (REPLAY) {
+        const int64_t pair = g_base + gl;
+        if (rp_act) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) { const int tl = tla + h; if (aligned || (tl >= 0 && tl < tc)) av[h] = io.actions[(int64_t)(t0 + tl) * total + pair]; }
+        }
+        if (rp_exo) {
+          const int64_t b = genv - a.env_offset;
+          const int K_ = a.K, e0 = a.exo_first[s];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int tl = tla + h;
+            if (aligned || (tl >= 0 && tl < tc)) {
+              const uint8_t* row = io.exo + ((int64_t)(t0 + tl) * a.B + b) * a.n_exo + e0;
+              int d = 0;
+              for (int k = 0; k < K_; ++k) d += (int)row[k];            // CustomerAgent.generate_messages: the recorded np.random.randint(5) draws, supply_chain.py:61-67
+              Dx[h] = d;
+            }
+          }
+        }
+      }
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      uint32_t y[4] = {0u, 0u, 0u, 0u}, aj[4] = {0u, 0u, 0u, 0u};
+      if (!(rp_act && rp_exo)) {
 #ifdef PHX_ABL_NODRAW
       w[0] = tick_a * 2654435761u + (uint32_t)genv; w[1] = w[0] * 40503u + s; w[2] = w[1] ^ 0x9e3779b9u; w[3] = w[2] + w[0];   // dev ablation: no Philox
 #else
       rng_block(a.seed, genv, tick_a, s, 0, 0, w);
 #endif
-      uint32_t y[4], aj[4];
       bool rej = false;
 #pragma unroll
       for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
@@ -289,20 +324,24 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
           if (!rng_split(w[h], y2, j2)) y[h] = rng_group_y(a.seed, genv, tick_a + (uint32_t)h, s, 0, 1, &aj[h]);
         }
       }
+      }
       // the four order sums in ONE LDS round trip (the lookups are issued together, then the four items are finished)
       int D[4];
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         uint32_t yy = y[h];
         if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);  // the first K base-5 digits: y mod 5^K
-        D[h] = (int)s_dtab[yy];                                          // the customers' order sizes summed, supply_chain.py:61-67
+        D[h] = rp_exo ? Dx[h] : (int)s_dtab[yy];                         // the customers' order sizes summed, supply_chain.py:61-67
       }
       const int i = __mul24(tla, G) + gl;
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         if (!aligned) { const int tl = tla + h; if (tl < 0 || tl >= tc) continue; }
-        const float action = rng_j_to_action(aj[h]);                     // random policy, [0, 100)
-        s_rd[i + h * G] = (uint16_t)((int)rintf(action) | (D[h] << 8));  // decode_action: int(round(action)), supply_chain.py:139
+        const float action = rp_act ? av[h] : rng_j_to_action(aj[h]);    // the replayed policy, or the random one: [0, 100)
+        // decode_action: int(round(action)), supply_chain.py:139.  A replayed action >= -0.5 (the call's pre-scan) rounds to R >= 0 and
+        // min(R, 100 - stock) is the same for every R >= 100: 255 stands for all of them in the tile's byte
+        const int Rq = rp_act ? (int)fminf(rintf(action), 255.0f) : (int)rintf(action);
+        s_rd[i + h * G] = (uint16_t)(Rq | (D[h] << 8));
         s_act[i + h * G] = action;
       }
     }
