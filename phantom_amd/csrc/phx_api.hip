@@ -21,7 +21,7 @@ size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
-hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if = nullptr, int32_t gen = 0);
 hipError_t phx_launch_stk_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_stk_materialise(const DevSpec& sp, hipStream_t st);
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
@@ -592,6 +592,7 @@ struct phx_env {
   bool use_fused = false, use_stk = false, use_ads = false, lds_ok = true;
   bool prices_compressed = false;   // buyer.prices is represented by seller.posted (fused Stackelberg kernel)
   std::atomic<int32_t> fsm_gen{0};  // launch generation of the time-parallel FSM rollout (DevSpec::fsm_gen_host)
+  int32_t sw_guard_gen = 0;         // number of the last replayed-actions call on the store-wave kernel (DevSpec::sc_sw_guard)
   DevMsg* inject_dev = nullptr;
   DevMsg inject_host[PHX_MAX_INJECT];
   int n_inject = 0;
@@ -835,6 +836,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     }
   }
   d.fsm_pos_tab = nullptr; d.fsm_irregular = nullptr;
+  d.sc_sw_exo_first = nullptr; d.sc_sw_guard = nullptr;
   if (d.fsm_fast.ok) {
     rc = upload(e, fsm_tab.data(), fsm_tab.size(), &d.fsm_pos_tab);
     if (rc != PHX_OK) { phx_destroy(e); return rc; }
@@ -873,6 +875,21 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       rc = upload(e, img.data(), img.size(), &dev_img);
       if (rc != PHX_OK) { phx_destroy(e); return rc; }
       d.sc_sw = sw; d.sc_sw_tables = dev_img;
+      // replays (REPLAY instantiation): the exogenous column of each shop's first customer where its customers' columns are consecutive
+      // (they are for every env the host layer builds: customers are numbered shop by shop), and the pre-scan's device word
+      std::vector<int32_t> first((size_t)d.S, 0);
+      bool consecutive = true;
+      for (int s2 = 0; s2 < d.S; ++s2) {
+        const int c0 = der.shop_cust_ptr[s2];
+        first[s2] = der.shop_cust_exo[c0];
+        for (int k = 0; k < Ku; ++k) consecutive = consecutive && der.shop_cust_exo[c0 + k] == first[s2] + k;
+      }
+      d.sc_sw_exo_first = nullptr;
+      if (consecutive) { rc = upload(e, first.data(), first.size(), &d.sc_sw_exo_first); if (rc != PHX_OK) { phx_destroy(e); return rc; } }
+      const int32_t zero = 0; const int32_t* gw = nullptr;
+      rc = upload(e, &zero, 1, &gw);
+      if (rc != PHX_OK) { phx_destroy(e); return rc; }
+      d.sc_sw_guard = (int32_t*)gw;
     }
   }
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
@@ -1217,6 +1234,17 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     // 23.1, T = 400 57 against 72-76; several rounds of workgroups: B = 16 384 221 against 242; SC256, B = 8 192, T = 100: 195 against 204)
     if (e->d.sc_sw.ok && io->T <= 0xFFFF && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
     else HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
+    return PHX_OK;
+  }
+  // Replayed actions and / or order sizes (a recorded policy, the reference's own numpy stream): the store-wave kernel's REPLAY
+  // instantiation where its shape serves the env.  Its tiles hold the stock in a byte: a call with an action that rounds below zero
+  // (a negative StockRequest takes the stock below zero) is found by a pre-scan of the call's actions and served by round 1's kernel
+  // -- both launches are issued, the device word decides which one runs.
+  if (e->d.sc_fast.ok && e->d.sc_sw.ok && e->d.variant_rollout != PHX_VR_GENERAL && e->d.variant_rollout != PHX_VR_TIME_PARALLEL && io->T <= 0xFFFF &&
+      (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40) && (!io->exo || e->d.sc_sw_exo_first) && e->d.sc_sw_guard) {
+    const int32_t gen = io->actions ? ++e->sw_guard_gen : 0;
+    HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream, gen));
+    if (io->actions) HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream, e->d.sc_sw_guard, gen));
     return PHX_OK;
   }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));

@@ -145,6 +145,8 @@ struct DevSpec {
   int32_t sc_wide_K, sc_wide_norm;   // phx_sc_step_wide_kernel: the shops' common customer count (0: the kernel does not apply) and normaliser
   ScSwPlan sc_sw;                // store-wave rollout kernel (round 4): plan (ok == 0: not applicable)
   const void* sc_sw_tables;      // its table image in device memory (phx_sc_sw_tables)
+  const int32_t* sc_sw_exo_first;// [S] exogenous column of each shop's first customer, or NULL: the customers' columns are not consecutive (exo replays go to round 1's kernel)
+  int32_t* sc_sw_guard;          // device word: the replay pre-scan stores the call's number here when an action rounds below zero
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
   ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)
   const uint32_t* fsm_pos_tab;   // [num_steps] flags / lookbacks / stage of every episode position (layout: phx_sc_rollout_fsm.hip)

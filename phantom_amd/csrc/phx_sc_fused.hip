@@ -311,6 +311,7 @@ struct RollArgs {
   const int32_t* shop_cust_ptr;  // [S+1]
   const int32_t* shop_cust_exo;
   int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick;
+  const int32_t* only_if; int32_t gen;   // non-NULL: the kernel runs only if *only_if == gen (the store-wave kernel declined this call's replayed actions)
   phx_rollout_io io;
 };
 
@@ -329,6 +330,7 @@ __device__ __forceinline__ void lds_barrier() {
 //         so the output phase writes whole 16-byte segments with magic-number row arithmetic only.
 template <int NT, bool REPLAY, bool WIDE>
 __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 6 : (NT == 320 ? 5 : 4)))) void phx_sc_rollout_kernel(const RollArgs a) {
+  if (a.only_if && *a.only_if != a.gen) return;   // (uniform) the store-wave kernel served this call
   // Software pipeline over chunks of TC steps.  Phase 1 (Philox draws) of chunk c + 1 does not
   // depend on the stock recurrence, so it runs on waves P1W.. while waves 0..P2W-1 walk the
   // recurrence (phase 2) of chunk c; item tiles {R|stock, D, sales} and the action tile are
@@ -988,10 +990,11 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
   return hipGetLastError();
 }
 
-hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if, int32_t gen) {
   // ~32..64 pairs per block (one wave in the sequential phase), TC steps so that the two item
   // tiles stay around 34 KB
   RollArgs a;
+  a.only_if = only_if; a.gen = gen;
   a.B = sp.B; a.S = sp.S; a.n_exo = sp.n_exo; a.num_steps = sp.num_steps; a.T = io.T;
   a.seed = sp.seed; a.env_offset = sp.env_offset;
   a.shop_norm = sp.shop_norm; a.shop_cust_ptr = sp.shop_cust_ptr; a.shop_cust_exo = sp.shop_cust_exo;
@@ -1064,7 +1067,7 @@ hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hi
     else nt = big ? 512 : 256;
   }
   if (nt_env) nt = nt_env;
-  phx_note_kernel("phx_sc_rollout_kernel");
+  phx_note_kernel(only_if ? "phx_sc_rollout_kernel[if an action rounds below zero]" : "phx_sc_rollout_kernel");
 #define PHX_LAUNCH_ROLLOUT(NT_)                                                                              \
   do {                                                                                                        \
     if (wide && !replay) hipLaunchKernelGGL((phx_sc_rollout_kernel<NT_, false, true>), grid, dim3(NT_), lds, st, a);  \

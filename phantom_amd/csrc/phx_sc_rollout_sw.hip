@@ -746,8 +746,17 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   return true;
 }
 
-hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+// Do any of the n replayed actions round below zero (or is one NaN)?  Then the stock can leave [0, 100] (StockRequest of a negative
+// size, supply_chain.py:98-103,139) and the call goes to round 1's kernel, whose tiles hold 32-bit words: *flag = gen.
+__global__ __launch_bounds__(256) void phx_sw_scan_actions_kernel(const float* __restrict__ act, int64_t n, int32_t* flag, int32_t gen) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) bad |= !(act[i] >= -0.5f);
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(flag, gen);
+}
+
+hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, int32_t guard_gen) {
   const ScSwPlan& p = sp.sc_sw;
+  const bool replay = io.actions != nullptr || io.exo != nullptr;
   SwArgs a; memset(&a, 0, sizeof a);
   a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
   const int remap_env = phx_knobs().rollout_remap;
@@ -763,6 +772,12 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
   a.tables = (const float4*)sp.sc_sw_tables;
   a.io = io;
+  a.n_exo = sp.n_exo; a.exo_first = sp.sc_sw_exo_first; a.guard = nullptr; a.guard_gen = guard_gen;
+  if (io.actions) {                       // the pre-scan of this call's actions decides between this kernel and round 1's (same stream: ordered)
+    const int64_t n = (int64_t)io.T * sp.B * sp.S;
+    a.guard = sp.sc_sw_guard;
+    hipLaunchKernelGGL(phx_sw_scan_actions_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 2048)), dim3(256), 0, st, io.actions, n, sp.sc_sw_guard, guard_gen);
+  }
   // trajectory fragments: the caller's list (phx_rollout_io.frags, validated by phx_rollout) or the io's own planes as the only one
   if (io.n_frag > 1) {
     a.n_frag = io.n_frag; a.frag_T = io.T / io.n_frag;
@@ -806,12 +821,13 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
         for (unsigned b = 0; b < grid.x; ++b) for (int w = 0; w < nwv; ++w) { const int rr = w < p.n_rec ? 0 : (w < p.n_rec + p.n_store ? 1 : 2); if (rr != r) continue; ++n; for (int q = 0; q < 8; ++q) sum[q] += (double)h[((size_t)b * 16 + w) * 8 + q]; }
         fprintf(stderr, "SW_TIMING %s waves (%d): setup %.0f (before 1st barrier %.0f, in it %.0f) | draws %.0f | outputs %.0f | rec %.0f | stores %.0f | barrier %.0f   cycles per wave and launch\n", role[r], n, sum[0]/n, sum[6]/n, sum[7]/n, sum[1]/n, sum[2]/n, sum[3]/n, sum[4]/n, sum[5]/n); } } } }
 #endif
-  phx_note_kernel("phx_sc_rollout_sw_kernel");
+  phx_note_kernel(replay ? "phx_sc_rollout_sw_kernel[replay]" : "phx_sc_rollout_sw_kernel");
   // more than 64 KB of dynamic LDS needs the attribute (once per instantiation and device)
-#define SW_LAUNCH(TC_, GT_, NREC_, NSTORE_, NWORK_) do { \
+#define SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, RP_) do { \
     static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev); \
-    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
-    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
+    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
+    hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
+#define SW_LAUNCH(TC_, GT_, NREC_, NSTORE_, NWORK_) do { if (replay) SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, true); else SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, false); } while (0)
   const int generic_env = phx_knobs().sw_generic;      // development: the run-time-shape instantiation
   const int work = p.nt / 64 - p.n_rec - p.n_store;
 #define SW_SHAPE(G_, NREC_, NSTORE_, NWORK_) (p.tc == 16 && p.G == G_ && p.n_rec == NREC_ && p.n_store == NSTORE_ && work == NWORK_)
@@ -825,5 +841,6 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   else SW_LAUNCH(16, 0, 0, 0, 0);
 #undef SW_SHAPE
 #undef SW_LAUNCH
+#undef SW_LAUNCH_
   return hipGetLastError();
 }
