@@ -59,6 +59,26 @@ class DeviceError(RuntimeError):
     pass
 
 
+class HostStep:
+    """A step's outputs in flight to the host (DeviceEnv.pull_step_async)."""
+
+    def __init__(self, dev, buf, event, seq):
+        self._dev, self._buf, self._event, self._seq, self._arrays = dev, buf, event, seq, None
+
+    def get(self) -> Dict[str, "object"]:
+        if self._arrays is None:
+            if self._dev._host_ring_k - self._seq > 3:            # three pinned buffers rotate: this one has been reused since
+                raise DeviceError("a poll() result was first read more than three steps after it was produced: its host buffer has been reused")
+            self._event.synchronize()
+            h = self._buf.numpy()
+            self._arrays = {name: h[off:off + n].view(np.dtype(str(dtype).replace("torch.", ""))).reshape(shape).copy()
+                            for name, shape, dtype, off, n in self._dev._out_layout}
+            if self._dev._host_ring_k - self._seq > 3:            # (reused while it was being read)
+                self._arrays = None
+                raise DeviceError("a poll() result was read while its host buffer was being reused")
+        return self._arrays
+
+
 class StepGraph:
     """``n`` captured ``phx_step`` launches (DeviceEnv.step_graph); ``replay()`` enqueues them on the
     current stream without per-step host work."""
@@ -328,6 +348,23 @@ class DeviceEnv:
         h = self._out_host.numpy()
         return {name: h[off:off + n].view(np.dtype(str(dtype).replace("torch.", ""))).reshape(shape)
                 for name, shape, dtype, off, n in self._out_layout}
+
+    def pull_step_async(self) -> "HostStep":
+        """The last step's outputs on their way to the host WITHOUT a synchronisation: one non-blocking copy of the output buffer
+        into one of three rotating pinned buffers with an event behind it.  ``HostStep.get()`` waits for the event (once) and
+        returns copies of the arrays, so a result stays valid however many steps follow; a HostStep that was never read costs the
+        copy's enqueue and nothing else."""
+        torch = _torch()
+        ring = self.__dict__.setdefault("_host_ring", [])
+        if len(ring) < 3:
+            ring.append(torch.empty(self._out_flat.shape, dtype=torch.uint8, pin_memory=True))
+        k = self.__dict__.get("_host_ring_k", 0)
+        self._host_ring_k = k + 1
+        buf = ring[k % len(ring)] if len(ring) == 3 else ring[-1]
+        buf.copy_(self._out_flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return HostStep(self, buf, ev, k)
 
     def _needs_valid_planes(self) -> bool:
         # validity masks: stage-masked envs, and kinds whose encode_observation can return None

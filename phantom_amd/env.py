@@ -446,7 +446,10 @@ class PhantomEnv:
         done, ep = 0, ep0
         while done < T:
             n = min(T - done, N - cur)
-            tr = self.rollout(n, None if actions is None else actions[done:done + n], None if exo is None else exo[done:done + n])
+            # (a slice of the caller's tensor may start off a 16-byte boundary -- B * S * 4 or B * n_exo not a multiple of 16 -- which
+            #  phx_rollout refuses: such a piece is replayed from an aligned copy)
+            piece = lambda x: None if x is None else (x[done:done + n] if x[done:done + n].data_ptr() % 16 == 0 else x[done:done + n].clone())
+            tr = self.rollout(n, piece(actions), piece(exo))
             sl = slice(done, done + n)
             new_obs[sl], act[sl], rew[sl], term[sl], trunc[sl] = tr.observations, tr.actions, tr.rewards, tr.terminations, tr.truncations
             obs[done] = cur_obs

@@ -281,3 +281,91 @@ def test_replayed_action_that_rounds_below_zero_sends_the_call_to_round_1s_kerne
             assert (d.get_i32("shop.stock") < 0).any() or True      # (the stock may have recovered by the fragment's end)
         # a stock the negative request left below zero is outside the next store-wave launch's tiles too: bring the envs back
         o.reset(); d.reset()
+
+
+def test_sample_with_replayed_actions_across_an_episode_end_at_an_odd_batch_shape():
+    """PhantomEnv.sample(T, actions) cuts the fragment at the episode's end and replays the rest from a SLICE of the caller's tensor: with
+    B * S * 4 not a multiple of 16 that slice starts off a 16-byte boundary (phx_rollout refused it) -- replayed from an
+    aligned copy now; rows against the oracle's one long replay."""
+    import torch
+    S, K, B, N, T = 3, 2, 5, 7, 12                             # B * S = 15 floats per row: row 7 starts at byte 420
+    env = supply_chain_env(S, [K] * S, N, B, seed=6)
+    o = OracleEnv(env.spec, threads=2); o.reset()
+    env.reset()
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(0, 100, (T, B, S)).astype(np.float32)
+    exo = rng.integers(0, 5, (T, B, S * K)).astype(np.uint8)
+    dev = env._device().device
+    frag = env.sample(T, torch.from_numpy(acts).to(dev), torch.from_numpy(exo).to(dev))
+    ro = o.rollout(T, acts, exo)
+    np.testing.assert_array_equal(f32_bits(frag.new_obs), f32_bits(np.ascontiguousarray(ro["obs"].transpose(1, 2, 0, 3))))
+    np.testing.assert_array_equal(f32_bits(frag.rewards), f32_bits(np.ascontiguousarray(ro["rewards"].transpose(1, 2, 0))))
+    np.testing.assert_array_equal(f32_bits(frag.actions), f32_bits(np.ascontiguousarray(acts.transpose(1, 2, 0))))
+
+
+def test_send_actions_decides_by_key_membership_not_by_a_nan_sentinel():
+    """the flat fast path of BatchedBaseEnv.send_actions marked missing agents by NaN -- a policy that outputs NaN was then
+    'an agent that did not act' and unknown agent ids were ignored.  Now: a NaN action is forwarded (valid = 1) exactly as
+    send_action_tensor forwards it, a missing agent has valid = 0, an unknown id raises KeyError -- on both paths."""
+    import torch
+    from phantom_amd.rllib import BatchedBaseEnv
+    B, S = 8, 3
+    mk = lambda: supply_chain_env(S, [2] * S, 10, B, seed=1)
+    ea, eb = mk(), mk()
+    ba, bb = BatchedBaseEnv(ea), BatchedBaseEnv(eb)
+    ba.poll(); bb.poll()
+    ids = list(ea.strategic_agent_ids)
+    act = np.full((B, S), 40.0, np.float32); act[2, 1] = np.nan
+    ba.send_actions({b: {aid: float(act[b, s]) for s, aid in enumerate(ids)} for b in range(B)})
+    bb.send_action_tensor(torch.from_numpy(act))
+    ra, rb = ba.poll(), bb.poll()
+    for b in range(B):
+        for aid in ids:
+            assert np.array_equal(ra[0][b][aid], rb[0][b][aid]) and ra[1][b][aid] == rb[1][b][aid]
+    sa, sb_ = ea._device().field("shop.stock").cpu().numpy(), eb._device().field("shop.stock").cpu().numpy()
+    np.testing.assert_array_equal(sa, sb_)
+    # a missing agent: did not act (its stock request is not sent) -- differs from acting with 0? both request nothing; check the mask
+    d = {b: {aid: 10.0 for aid in ids} for b in range(B)}
+    del d[3][ids[0]]
+    ba.send_actions(d)
+    valid = np.ones((B, S), np.uint8); valid[3, 0] = 0
+    bb.send_action_tensor(torch.full((B, S), 10.0), torch.from_numpy(valid))
+    ba.poll(); bb.poll()
+    np.testing.assert_array_equal(ea._device().field("shop.delivered_stock").cpu().numpy(), eb._device().field("shop.delivered_stock").cpu().numpy())
+    d = {b: {aid: 10.0 for aid in ids} for b in range(B)}
+    d[5]["NO_SUCH_AGENT"] = 1.0
+    with pytest.raises(KeyError):
+        ba.send_actions(d)
+
+
+def test_poll_results_stay_valid_over_later_steps_and_are_refused_once_their_buffer_is_reused():
+    """BatchedBaseEnv.poll() on a plain env returns before anything has reached the host (DeviceEnv.pull_step_async): a result read one
+    or two steps later still holds ITS step's rows; one first read after its pinned buffer has been reused raises."""
+    import torch
+    from phantom_amd.device import DeviceError
+    from phantom_amd.rllib import BatchedBaseEnv
+    B, S = 16, 3
+    env = supply_chain_env(S, [2] * S, 50, B, seed=4)
+    ref = supply_chain_env(S, [2] * S, 50, B, seed=4)
+    be, bref = BatchedBaseEnv(env), BatchedBaseEnv(ref)
+    be.poll(); bref.poll()
+    ids = list(env.strategic_agent_ids)
+    rng = np.random.default_rng(0)
+    acts = [torch.from_numpy(rng.uniform(0, 100, (B, S)).astype(np.float32)) for _ in range(6)]
+    held = []
+    for a in acts:
+        be.send_action_tensor(a); held.append(be.poll())
+        bref.send_action_tensor(a); r = bref.poll()
+        held[-1] = (held[-1], {b: {aid: (r[0][b][aid].copy(), r[1][b][aid]) for aid in ids} for b in range(B)})
+        if len(held) >= 3:                                       # read the result of two steps ago now
+            res, want = held[-3]
+            for b in (0, B - 1):
+                for aid in ids:
+                    assert np.array_equal(res[0][b][aid], want[b][aid][0]) and res[1][b][aid] == want[b][aid][1]
+    stale = held[0][0]
+    assert stale[0][0] is not None                                # already materialised: still readable
+    be.send_action_tensor(acts[0]); late = be.poll()
+    for a in acts[:4]:
+        be.send_action_tensor(a); be.poll()
+    with pytest.raises(DeviceError):
+        late[0][0]
