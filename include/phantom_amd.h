@@ -148,6 +148,30 @@ typedef enum phx_msg_type {
                                         blob ("env.mt_state" u32 [B][624], "env.mt_pos" i32 [B]): phx_mt_seed / phx_mt_draw
                                         below.  2.5 KB per env instance.                                            */
 
+/* ---- ABI 9: stage handlers that branch on agent STATE, as a rule table the device evaluates --------------------------
+ * The reference's handler of an FSM stage (fsm.py:294-307) is a Python method: it runs after the stage's agents have acted,
+ * calls self.resolve_network() and returns the next stage -- typically from a threshold test on a field of the resolved agent
+ * state ("RESTOCK while the shops' stock is below 60").  A handler of that form is DECLARED as rules (the host layer checks the
+ * declaration against the Python handler on random states): for the env's current stage the rules are scanned in order, the
+ * first whose condition holds gives the next stage, none -> phx_spec.stage_next[stage].  Evaluated on the RESOLVED state inside
+ * phx_step (between what phx_step_begin and phx_step_end do) and inside every step of phx_rollout: no host round trip.  Each
+ * next_stage must be one of the stage's next_stages (stage_allowed).  Served by the message-passing engine.                 */
+#define PHX_CMP_LT 0
+#define PHX_CMP_LE 1
+#define PHX_CMP_GT 2
+#define PHX_CMP_GE 3
+#define PHX_CMP_EQ 4
+#define PHX_CMP_NE 5
+typedef struct phx_stage_rule {
+  int32_t stage;        /* the rule belongs to the handler of this stage                                              */
+  int32_t agent;        /* column of `field` (rank of the agent among the agents of the field's kind), or -1: the SUM over
+                           all agents of that kind                                                                      */
+  int32_t cmp;          /* PHX_CMP_*: value <cmp> threshold                                                             */
+  int32_t next_stage;   /* the stage the handler returns when the condition holds                                       */
+  double  threshold;
+  char    field[32];    /* phx_field.name of a per-agent i32 or f64 state field ("shop.stock", "seller.revenue", ...)   */
+} phx_stage_rule;
+
 /*
  * Flat description of one env class: what the Python host compiles a
  * Network + PhantomEnv construction into.  All arrays are HOST pointers, copied at create.
@@ -215,6 +239,11 @@ typedef struct phx_spec {
    * stages hold stage_next[s].  NULL: no tabulated handler.  With a table the device takes every transition itself --
    * phx_step (phx_step_io.next_stage == NULL) and phx_rollout alike; every entry must be allowed by stage_allowed.   */
   const int32_t* stage_tab;
+  /* ABI 9: device-evaluated state handlers (phx_stage_rule above); 0 / NULL: none.  A stage may have rules or a stage_tab row
+   * that differs from stage_next, not both (PHX_EINVAL).                                                                    */
+  int32_t n_stage_rules;
+  int32_t reserved1;
+  const phx_stage_rule* stage_rules;
 } phx_spec;
 
 /* phx_spec.variant_rollout: which kernel phx_rollout uses for a supply-chain env with a fused schedule */

@@ -303,6 +303,7 @@ static void env_sample(const phxo_env* E, oenv* e, int b, const double* values, 
  * op yields the larger of the two tags PYF < F32 < F64 and is evaluated in float32 iff that tag
  * is F32 -- the weak python float is cast to float32 first.                                   */
 typedef struct { double v; int tag; } tval;
+static int rule_field(const char* name, int* kind, int* is_f, int* slot);   /* the state-field table below (FIELDS) */
 static tval tv(double v, int tag) { tval t; t.v = v; t.tag = tag; return t; }
 static int t_tag(tval a, tval b) { return a.tag > b.tag ? a.tag : b.tag; }
 static tval t_mul(tval a, tval b) {
@@ -897,6 +898,35 @@ static void env_step_one(const phxo_env* E, oenv* e, int b, const float* actions
 
   if (E->s.env_type == PHX_ENV_FSM) {
     next_stage = E->s.stage_next[cur_stage];                          /* no handler: next_stages[0]  fsm.py:281-292 */
+    /* a handler that branches on the RESOLVED agent state, declared as rules (phx_spec.stage_rules, ABI 9): what env_handler()
+     * returns now, fsm.py:294-302 -- the first rule of the stage whose condition holds */
+    if (next_in == -1 && E->s.n_stage_rules > 0) {
+      for (int r = 0; r < E->s.n_stage_rules && next_in == -1; ++r) {
+        const phx_stage_rule* q = &E->s.stage_rules[r];
+        if (q->stage != cur_stage) continue;
+        char nm[33]; memcpy(nm, q->field, 32); nm[32] = 0;
+        int fk, fis, fslot;
+        if (!rule_field(nm, &fk, &fis, &fslot)) continue;
+        /* the value: one agent's field, or the sum over the kind's agents taken as the device takes it (64 strided partial sums,
+         * butterfly reduction: exact for i32 fields, the device's rounding for f64 fields) */
+        double part[64]; for (int l = 0; l < 64; ++l) part[l] = 0.0;
+        double v = 0.0;
+        for (int a = 0; a < A; ++a) {
+          if (E->s.kind[a] != fk) continue;
+          const int c = E->kind_rank[a];
+          const double x = fis ? e->ag[a].f[fslot] : (double)e->ag[a].i[fslot];
+          if (q->agent >= 0) { if (c == q->agent) v = x; } else part[c & 63] += x;    /* (columns c, c + 64, .. of a lane: ascending a == ascending c) */
+        }
+        if (q->agent < 0) {
+          for (int off = 1; off < 64; off <<= 1) { double nx[64]; for (int l = 0; l < 64; ++l) nx[l] = (l & off) ? part[l ^ off] + part[l] : part[l] + part[l ^ off]; memcpy(part, nx, sizeof nx); }
+          v = part[0];
+        }
+        const double th = q->threshold;
+        const int hit = q->cmp == PHX_CMP_LT ? v < th : q->cmp == PHX_CMP_LE ? v <= th : q->cmp == PHX_CMP_GT ? v > th :
+                        q->cmp == PHX_CMP_GE ? v >= th : q->cmp == PHX_CMP_EQ ? v == th : v != th;
+        if (hit) next_in = q->next_stage;
+      }
+    }
     /* a handler that decides from (stage, clock) alone, tabulated by the host: what env_handler() returns now, :294-302 */
     if (next_in == -1 && E->s.stage_tab && e->step >= 0 && e->step <= E->s.num_steps)
       next_in = E->s.stage_tab[(size_t)cur_stage * (E->s.num_steps + 1) + e->step];
@@ -1035,7 +1065,9 @@ phxo_env* phxo_create(const phx_spec* sp) {
     E->s.stage_next = (const int32_t*)dup_arr(sp->stage_next, sizeof(int32_t) * ns);
     E->s.stage_allowed = sp->stage_allowed ? (const uint8_t*)dup_arr(sp->stage_allowed, (size_t)ns * ns) : NULL;
     E->s.stage_tab = sp->stage_tab ? (const int32_t*)dup_arr(sp->stage_tab, sizeof(int32_t) * (size_t)ns * (sp->num_steps + 1)) : NULL;
-  } else { E->s.stage_allowed = NULL; E->s.stage_tab = NULL; }
+    E->s.stage_rules = (sp->n_stage_rules > 0 && sp->stage_rules) ? (const phx_stage_rule*)dup_arr(sp->stage_rules, sizeof(phx_stage_rule) * (size_t)sp->n_stage_rules) : NULL;
+    if (!E->s.stage_rules) E->s.n_stage_rules = 0;
+  } else { E->s.stage_allowed = NULL; E->s.stage_tab = NULL; E->s.stage_rules = NULL; E->s.n_stage_rules = 0; }
   if (sp->env_type == PHX_ENV_STACKELBERG) {
     E->s.leaders = (const int32_t*)dup_arr(sp->leaders, sizeof(int32_t) * (sp->n_leaders ? sp->n_leaders : 1));
     E->s.followers = (const int32_t*)dup_arr(sp->followers, sizeof(int32_t) * (sp->n_followers ? sp->n_followers : 1));
@@ -1106,7 +1138,7 @@ void phxo_destroy(phxo_env* E) {
   free((void*)E->s.conn_rate); free((void*)E->s.col_conn);
   if (E->s.env_type == PHX_ENV_FSM) {
     free((void*)E->s.stage_act_ptr); free((void*)E->s.stage_act_idx);
-    free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next); free((void*)E->s.stage_tab);
+    free((void*)E->s.stage_rewarded); free((void*)E->s.stage_rewarded_all); free((void*)E->s.stage_next); free((void*)E->s.stage_tab); free((void*)E->s.stage_rules);
   }
   if (E->s.env_type == PHX_ENV_STACKELBERG) { free((void*)E->s.leaders); free((void*)E->s.followers); }
   free(E);
@@ -1288,6 +1320,12 @@ static const ofield* find_field(const char* n) {
   for (size_t k = 0; k < sizeof FIELDS / sizeof FIELDS[0]; ++k)
     if (!strcmp(FIELDS[k].name, n)) return &FIELDS[k];
   return NULL;
+}
+static int rule_field(const char* name, int* kind, int* is_f, int* slot) {
+  const ofield* f = find_field(name);
+  if (!f) return 0;
+  *kind = f->kind; *is_f = f->is_f; *slot = f->slot;
+  return 1;
 }
 
 int64_t phxo_get_i32(const phxo_env* E, const char* field, int32_t* out) {

@@ -12,7 +12,7 @@ from .agents import (Agent, BuyerAgent, CashboxAgent, CustomerAgent, FactoryAgen
                      SellerAgent, ShopAgent, StrategicAgent, TypedShopAgent, UnsupportedAgentBehaviour,
                      msg_handler)
 from .env import PhantomEnv
-from .fsm import (FiniteStateMachineEnv, FSMRuntimeError, FSMStage, FSMValidationError, state_independent)
+from .fsm import (FiniteStateMachineEnv, FSMRuntimeError, FSMStage, FSMValidationError, StageRule, state_independent, state_rules)
 from .message import (AgentID, CashMessage, HalveMessage, Message, MsgPayload, Order,
                       OrderRequest, OrderResponse, Price, Request, Response, StockRequest,
                       StockResponse, msg_payload)

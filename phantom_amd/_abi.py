@@ -65,6 +65,7 @@ class PhxSpec(C.Structure):
         ("variant_rollout", C.c_int32), ("variant_block", C.c_int32), ("variant_step", C.c_int32),
         ("variant_flags", C.c_int32),
         ("stage_tab", C.c_void_p),
+        ("n_stage_rules", C.c_int32), ("reserved1", C.c_int32), ("stage_rules", C.c_void_p),
     ]
 
 
@@ -95,6 +96,15 @@ class PhxRolloutIO(C.Structure):
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
         "reward_valid", "last_obs", "err", "msg_log", "msg_count", "records")] + [
         ("n_frag", C.c_int32), ("reserved0", C.c_int32), ("frags", C.c_void_p)]
+
+
+class PhxStageRule(C.Structure):
+    """phx_stage_rule (ABI 9): one rule of a device-evaluated state handler"""
+    _fields_ = [("stage", C.c_int32), ("agent", C.c_int32), ("cmp", C.c_int32), ("next_stage", C.c_int32),
+                ("threshold", C.c_double), ("field", C.c_char * 32)]
+
+
+CMP = {"<": 0, "<=": 1, ">": 2, ">=": 3, "==": 4, "!=": 5}
 
 
 class PhxRolloutFrag(C.Structure):

@@ -59,6 +59,7 @@ struct Derived {
   std::vector<int32_t> act_ptr, act_idx, stage_next, reset_obs_idx;
   std::vector<uint8_t> stage_allowed, stage_rew_all;
   std::vector<int32_t> stage_tab;
+  std::vector<uint8_t> stage_has_rules;   // [n_stages] the stage's handler is a rule list (phx_spec.stage_rules)
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
   bool sc_static = false, stk_static = false, ads_static = false;
@@ -241,8 +242,28 @@ static int derive(const phx_spec* sp, Derived& d) {
   }
   d.scan_cap = std::max(sp->queue_cap, longest + PHX_MAX_INJECT);
 
+  // ---- device-evaluated state handlers (ABI 9): what can be checked before the state layout exists ----------------------------
+  if (sp->n_stage_rules < 0 || (sp->n_stage_rules > 0 && !sp->stage_rules)) return fail(PHX_EINVAL, "stage_rules: bad count / NULL table");
+  if (sp->n_stage_rules > 0) {
+    if (sp->env_type != PHX_ENV_FSM) return fail(PHX_EINVAL, "stage_rules need a FiniteStateMachineEnv");
+    const int ns = sp->n_stages;
+    d.stage_has_rules.assign((size_t)ns, 0);
+    for (int r = 0; r < sp->n_stage_rules; ++r) {
+      const phx_stage_rule& q = sp->stage_rules[r];
+      if (q.stage < 0 || q.stage >= ns || q.next_stage < 0 || q.next_stage >= ns) return fail(PHX_EINVAL, "stage_rules[%d]: stage out of range", r);
+      if (!d.stage_allowed[(size_t)q.stage * ns + q.next_stage]) return fail(PHX_EINVAL, "stage_rules[%d]: %d is not one of stage %d's next_stages (fsm.py:304-307)", r, q.next_stage, q.stage);
+      if (q.cmp < PHX_CMP_LT || q.cmp > PHX_CMP_NE) return fail(PHX_EINVAL, "stage_rules[%d]: unknown comparison", r);
+      if (!(q.threshold == q.threshold)) return fail(PHX_EINVAL, "stage_rules[%d]: NaN threshold", r);
+      d.stage_has_rules[q.stage] = 1;
+    }
+    if (sp->stage_tab)
+      for (int st = 0; st < ns; ++st)
+        if (d.stage_has_rules[st])
+          for (int t = 0; t <= sp->num_steps; ++t)
+            if (sp->stage_tab[(size_t)st * (sp->num_steps + 1) + t] != sp->stage_next[st]) return fail(PHX_EINVAL, "stage %d has both rules and a tabulated handler", st);
+  }
   // ---- static supply-chain schedule? (fused kernels) ------------------------------------------
-  bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 &&
+  bool sc = (sp->env_type == PHX_ENV_PLAIN || sp->env_type == PHX_ENV_FSM) && d.kind_count[PHX_KIND_SHOP] > 0 && sp->n_stage_rules == 0 &&
             d.kind_count[PHX_KIND_SHOP] <= 256 &&
             !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
             (sp->round_limit < 0 || sp->round_limit >= 2) && !(sp->flags & PHX_F_IGNORE_CONN_ERRORS) && !d.dynamic_graph;
@@ -726,6 +747,25 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   UP(stage_allowed, der.stage_allowed.data(), der.stage_allowed.size());
   d.stage_tab = nullptr;
   if (!der.stage_tab.empty()) UP(stage_tab, der.stage_tab.data(), der.stage_tab.size());
+  d.n_rules = 0; d.rules = nullptr;
+  if (spec->n_stage_rules > 0) {                                // the rules' fields by name: per-agent i32 / f64 state of one kind
+    std::vector<DevRule> rl;
+    for (int r = 0; r < spec->n_stage_rules; ++r) {
+      const phx_stage_rule& q = spec->stage_rules[r];
+      char nm[33]; memcpy(nm, q.field, 32); nm[32] = 0;
+      const FieldDef* f = nullptr;
+      for (const FieldDef& c : e->fields) if (!strcmp(c.name, nm)) f = &c;
+      if (!f || f->kind <= 0 || (f->dtype != 0 && f->dtype != 1) || f->dim2 != 1 || f->dim1 < 1) {
+        phx_destroy(e); return fail(PHX_EINVAL, "stage_rules[%d]: '%s' is not a per-agent i32 / f64 state field", r, nm);
+      }
+      if (q.agent < -1 || q.agent >= f->dim1) { phx_destroy(e); return fail(PHX_EINVAL, "stage_rules[%d]: agent column %d outside the %lld agents of '%s'", r, q.agent, (long long)f->dim1, nm); }
+      DevRule dr; dr.stage = q.stage; dr.field_id = f->id; dr.col = q.agent; dr.ncols = (int32_t)f->dim1; dr.cmp = q.cmp; dr.next_stage = q.next_stage;
+      dr.is_f64 = f->dtype == 1; dr.pad = 0; dr.threshold = q.threshold;
+      rl.push_back(dr);
+    }
+    UP(rules, rl.data(), rl.size());
+    d.n_rules = (int32_t)rl.size();
+  }
   d.sched = nullptr; d.sched_off = nullptr;
   if (!der.sc_static && !der.stk_static && !der.ads_static) {      // specs the generic engine serves
     StaticSched ss;

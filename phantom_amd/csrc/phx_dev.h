@@ -85,6 +85,9 @@ struct ScSwPlan {
   int32_t specialised;           // a compile-time instantiation serves the shape (what PHX_VR_AUTO requires: the run-time-shape kernel is slower than round 3's)
 };
 
+// one rule of a device-evaluated state handler (phx_stage_rule with the field resolved)
+struct DevRule { int32_t stage, field_id, col, ncols, cmp, next_stage, is_f64, pad; double threshold; };
+
 struct DevSpec {
   int32_t A, S, B, D, n_exo, nnz;
   int32_t num_steps, round_limit, env_type;
@@ -117,6 +120,8 @@ struct DevSpec {
   const int32_t* stage_next;     // [n_lists]  (FSM)
   const uint8_t* stage_allowed;  // [n_lists][n_lists] FSMStage.next_stages as a matrix (handler-chosen transitions), or NULL
   const int32_t* stage_tab;      // [n_lists][num_steps + 1] tabulated clock / stage handlers (phx_spec.stage_tab), or NULL
+  int32_t n_rules;               // device-evaluated state handlers (phx_spec.stage_rules), in the spec's order
+  const DevRule* rules;
   const int32_t* mt_ptr;         // PHX_F_MT19937: [n_lists + 1] / the exogenous indices of a list's drawing agents in acting order
   const int32_t* mt_rank;        //   (the order in which the reference's CustomerAgents call np.random.randint in a step of that list)
   // generic engine, drop-out-free supply-chain specs: the round schedule of a step in which every agent is live and every acting

@@ -1082,7 +1082,38 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   if (n > 0 && tid == 0) set_errkey(&s_errkey, seq_base + 1, PHX_ERR_ROUND_LIMIT);   // resolvers.py:160-163
   // a stage handler's return value (fsm.py:294-307), decided by the host: must be one of the stage's next_stages
   int next_in = -1;
-  if (full && g.phase != 1 && sp.env_type == PHX_ENV_FSM && (g.io.next_stage || sp.stage_tab)) {
+  bool by_rule = false;
+  if (full && g.phase != 1 && sp.env_type == PHX_ENV_FSM && sp.n_rules > 0 && !g.io.next_stage) {
+    // a handler declared as rules (phx_spec.stage_rules): evaluated here, on the RESOLVED state -- the handlers' stores of this step
+    // are behind the barrier above -- by the env's first wave: a column, or the sum over the kind's agents (lanes stride the
+    // columns, wave reduction); first rule of the current stage whose condition holds, else next_stages[0]
+    int chosen = -1;
+    for (int r = 0; r < sp.n_rules && chosen < 0; ++r) {
+      const DevRule q = sp.rules[r];
+      if (q.stage != cur_stage) continue;
+      double v = 0.0;
+      if (tid < 64) {
+        const int64_t base = (int64_t)b * q.ncols;
+        if (q.col >= 0) { if (tid == 0) v = q.is_f64 ? ((const double*)sp.f[q.field_id])[base + q.col] : (double)((const int32_t*)sp.f[q.field_id])[base + q.col]; }
+        else for (int c = tid; c < q.ncols; c += 64) v += q.is_f64 ? ((const double*)sp.f[q.field_id])[base + c] : (double)((const int32_t*)sp.f[q.field_id])[base + c];
+        // (i32 fields: exact in f64; f64 fields: the sum is taken in lane order 0..63 over strided partial sums -- the oracle adds in
+        //  the same order)
+        for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_xor(v, off, 64); v = (tid & off) ? o + v : v + o; }
+      }
+      v = __shfl(v, 0, 64);
+      const bool hit = q.cmp == PHX_CMP_LT ? v < q.threshold : q.cmp == PHX_CMP_LE ? v <= q.threshold : q.cmp == PHX_CMP_GT ? v > q.threshold :
+                       q.cmp == PHX_CMP_GE ? v >= q.threshold : q.cmp == PHX_CMP_EQ ? v == q.threshold : v != q.threshold;
+      if (hit) chosen = q.next_stage;
+    }
+    if (NT > 64) {                                             // wider workgroups: the first wave's choice for everybody
+      __shared__ int s_rule_next;
+      if (tid == 0) s_rule_next = chosen;
+      __syncthreads();
+      chosen = s_rule_next;
+    }
+    if (chosen >= 0) { next_in = chosen; by_rule = true; }
+  }
+  if (!by_rule && full && g.phase != 1 && sp.env_type == PHX_ENV_FSM && (g.io.next_stage || sp.stage_tab)) {
     // the host's handler call for this step, or the tabulated handler's value at (stage, clock) -- validated at phx_create
     next_in = g.io.next_stage ? g.io.next_stage[b] : sp.stage_tab[(int64_t)cur_stage * (sp.num_steps + 1) + (t <= sp.num_steps ? t : sp.num_steps)];
     if (next_in < 0 || next_in >= sp.n_lists || !sp.stage_allowed[(int64_t)cur_stage * sp.n_lists + next_in]) {

@@ -43,20 +43,56 @@ def state_independent(handler_fn):
     return handler_fn
 
 
+class StageRule:
+    """One rule of a stage handler that branches on agent STATE after ``resolve_network()`` (fsm.py:294-307), in the form the device
+    evaluates (phx_stage_rule, ABI 9): ``value <cmp> threshold -> next_stage`` where ``value`` is the state field ``field`` (a
+    ``phx_field`` name: "shop.stock", "seller.revenue", ... -- ``DeviceEnv.field_names()``) of ``agent``, or with ``agent=None`` the SUM
+    over all agents of the field's kind.  The first rule of the stage that holds wins; none: ``next_stages[0]``."""
+
+    def __init__(self, field: str, cmp: str, threshold: float, next_stage: StageID, agent: Optional[AgentID] = None) -> None:
+        self.field, self.cmp, self.threshold, self.next_stage, self.agent = field, cmp, threshold, next_stage, agent
+
+    def __repr__(self):
+        who = "sum" if self.agent is None else repr(self.agent)
+        return f"StageRule({who} of {self.field} {self.cmp} {self.threshold} -> {self.next_stage!r})"
+
+
+def state_rules(rules: Sequence["StageRule"]):
+    """Declare the rule form of a stage handler: ``@FSMStage(...)`` / ``@state_rules([...])`` on the handler method, or
+    ``FSMStage(handler=state_rules([...])(fn))``.  The Python handler stays the definition: when the device env is created it is called
+    on random agent states and has to return what the rules give (FSMValidationError otherwise); at step time the device evaluates the
+    rules between the two halves of the step -- ``step`` needs no host callback and ``rollout`` runs in one launch."""
+    rules = list(rules)
+
+    def mark(handler_fn):
+        setattr(handler_fn, "_phx_state_rules", rules)
+        return handler_fn
+    return mark
+
+
 class FSMStage:
-    """fsm.py:26-63.  ``handler_state_independent``: see ``state_independent`` (same declaration as a flag)."""
+    """fsm.py:26-63.  ``handler_state_independent``: see ``state_independent`` (same declaration as a flag).  ``rules``: the handler's
+    rule form (``state_rules``)."""
 
     def __init__(self, stage_id: StageID, acting_agents: Sequence[AgentID],
                  rewarded_agents: Optional[Sequence[AgentID]] = None,
                  next_stages: Optional[Sequence[StageID]] = None,
                  handler: Optional[Callable[[], StageID]] = None,
-                 handler_state_independent: bool = False) -> None:
+                 handler_state_independent: bool = False, rules: Optional[Sequence["StageRule"]] = None) -> None:
         self.id = stage_id
         self.acting_agents = acting_agents
         self.rewarded_agents = rewarded_agents
         self.next_stages = next_stages or []
         self.handler = handler
         self.handler_state_independent = bool(handler_state_independent)
+        self._rules = list(rules) if rules is not None else None
+
+    def rules(self):
+        """the handler's rule form (``state_rules`` / ``rules=``), or None"""
+        if self._rules is not None:
+            return self._rules
+        h = self.handler
+        return getattr(h, "_phx_state_rules", None) or getattr(getattr(h, "__func__", None), "_phx_state_rules", None)
 
     def is_tabulated(self) -> bool:
         h = self.handler
@@ -116,8 +152,16 @@ class FiniteStateMachineEnv(PhantomEnv):
         # [B] arrays, the handler returns one stage or a sequence of B stages.  Handlers DECLARED state-independent
         # (``state_independent`` / ``handler_state_independent=True``) are tabulated per (stage, clock value) at spec-compile
         # time instead and run nowhere at step time (phx_spec.stage_tab): only those allow fused rollouts.
-        self._host_handlers = [s for s in self._stages.values() if s.handler is not None and not s.is_tabulated()]
+        # Handlers that branch on agent state in a form the device can evaluate are declared as RULES (``state_rules``): evaluated
+        # inside phx_step / phx_rollout on the resolved state (phx_spec.stage_rules), checked against the Python handler on random
+        # states when the device env is created.
+        self._rule_handlers = [s for s in self._stages.values() if s.handler is not None and s.rules() and not s.is_tabulated()]
+        self._host_handlers = [s for s in self._stages.values() if s.handler is not None and not s.is_tabulated() and not s.rules()]
+        if self._rule_handlers and self._host_handlers:
+            raise NotImplementedError("an env mixes rule-form and host-called stage handlers: give every state-dependent handler a rule form or none")
         self._tab_handlers = [s for s in self._stages.values() if s.is_tabulated()]
+        self._rules_checked = False
+        self._stage_dirty = False           # rule handlers: the device chose the stages; the host mirror is refreshed on demand
         self._has_handlers = bool(self._host_handlers)
         self._stage_tab = None
         self._in_handler = False
@@ -168,7 +212,11 @@ class FiniteStateMachineEnv(PhantomEnv):
 
     def _compile(self):
         self._stage_tab = self._tabulate_handlers()
-        return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_FSM, stage_tab=self._stage_tab,
+        rules = [(s.id, r) for s in self._rule_handlers for r in s.rules()]
+        for sid, r in rules:
+            if r.next_stage not in self._stages[sid].next_stages:            # fsm.py:304-307
+                raise FSMValidationError(f"rule of stage '{sid}' returns {r.next_stage!r}, which is not one of its next_stages")
+        return compile_spec(self.network, self.num_steps, self.batch_size, _abi.ENV_FSM, stage_tab=self._stage_tab, stage_rules=rules,
                             stages=self._stage_list, initial_stage=self._initial_stage,
                             seed=self._seed, env_offset=self._env_offset,
                             force_generic=self._force_generic, samplers=self._samplers, variants=self._variants,
@@ -178,13 +226,80 @@ class FiniteStateMachineEnv(PhantomEnv):
     def initial_stage(self) -> StageID:
         return self._initial_stage
 
+    def _device(self):
+        dev = super()._device()
+        if self._rule_handlers and not self._rules_checked:
+            self._rules_checked = True
+            self._check_rules_against_handlers(dev)
+        return dev
+
+    def _check_rules_against_handlers(self, dev, trials: int = 6):
+        """The Python handler is the definition, the rules are what the device runs: on random agent states (every field a rule of the
+        stage reads, drawn around the rule's threshold; all B env instances differ) the handler of each rule stage has to return the
+        stage the rules give.  The state blob is restored afterwards."""
+        import torch
+        keep_blob = dev.state.clone()
+        keep = (self._h_step.copy(), self._h_stage.copy())
+        rng = np.random.default_rng(12345)
+        B = self.batch_size
+        kr = self.spec.kind_rank()
+        try:
+            for stage in self._rule_handlers:
+                si = self._stage_index[stage.id]
+                rules = stage.rules()
+                for _ in range(trials):
+                    for r in rules:                                         # random values around the threshold, per (env, agent)
+                        f = dev.field(r.field)
+                        n = f.shape[1]
+                        per_agent = float(r.threshold) / (n if r.agent is None else 1)
+                        hi = max(2.0 * abs(per_agent), 4.0)
+                        vals = rng.uniform(min(0.0, -hi if per_agent < 0 else 0.0), hi, size=(B, n))
+                        if f.dtype in (torch.int32,):
+                            vals = np.rint(vals)
+                        f.copy_(torch.as_tensor(vals).to(f.dtype).to(f.device))
+                    self._h_stage[:] = si
+                    self._h_step[:] = 1
+                    self._in_handler = True
+                    try:
+                        ret = stage.handler() if hasattr(stage.handler, "__self__") else stage.handler(self)
+                    finally:
+                        self._in_handler = False
+                    rets = [ret] * B if (isinstance(ret, str) or np.isscalar(ret)) else list(ret)
+                    want = np.full(B, self._stage_index[stage.next_stages[0]], dtype=np.int64)
+                    decided = np.zeros(B, dtype=bool)
+                    for r in rules:
+                        f = dev.field(r.field).cpu().numpy().astype(np.float64)
+                        v = f.sum(axis=1) if r.agent is None else f[:, int(kr[self.spec.index_of(r.agent)])]
+                        hit = {"<": v < r.threshold, "<=": v <= r.threshold, ">": v > r.threshold, ">=": v >= r.threshold,
+                               "==": v == r.threshold, "!=": v != r.threshold}[r.cmp]
+                        sel = hit & ~decided
+                        want[sel] = self._stage_index[r.next_stage]
+                        decided |= hit
+                    got = np.asarray([self._stage_index[x] for x in rets], dtype=np.int64)
+                    if len(got) != B or (got != want).any():
+                        b = int(np.flatnonzero(got != want)[0]) if len(got) == B else 0
+                        raise FSMValidationError(f"the rules declared for the handler of stage '{stage.id}' disagree with the handler: env instance {b} "
+                                                 f"-> handler {rets[b]!r}, rules {self._stage_list[int(want[b])].id!r} ({rules})")
+        finally:
+            dev.state.copy_(keep_blob)
+            self._h_step[:], self._h_stage[:] = keep
+
+    def _refresh_stage(self):
+        if self._stage_dirty:
+            dev = self._device()
+            self._h_stage = dev.field("env.stage")[:, 0].cpu().numpy().astype(np.int64)
+            self.previous_stage_idx = dev.field("env.prev_stage")[:, 0].cpu().numpy().astype(np.int64)
+            self._stage_dirty = False
+
     @property
     def current_stage(self):
+        self._refresh_stage()
         ids = [self._stage_list[i].id for i in self._h_stage]
         return ids[0] if self.batch_size == 1 else ids
 
     @property
     def previous_stage(self):
+        self._refresh_stage()
         ids = [None if i < 0 else self._stage_list[i].id for i in self.previous_stage_idx]
         return ids[0] if self.batch_size == 1 else ids
 
@@ -196,12 +311,14 @@ class FiniteStateMachineEnv(PhantomEnv):
         return FSMEnvView(s, s / self.num_steps, self.current_stage)
 
     def _acting_customers(self, b: int):
+        self._refresh_stage()
         st = self._stage_list[int(self._h_stage[b])]
         spec = self.spec
         return [spec.index_of(aid) for aid in st.acting_agents
                 if spec.kind[spec.index_of(aid)] == _abi.KIND_CUSTOMER]
 
     def _acting_customer_groups(self):
+        self._refresh_stage()
         stages = np.unique(self._h_stage)
         if len(stages) != 1:
             return None
@@ -214,6 +331,7 @@ class FiniteStateMachineEnv(PhantomEnv):
 
     def _sync_host_state(self):
         super()._sync_host_state()
+        self._stage_dirty = False
         dev = self._device()
         self._h_stage = dev.field("env.stage")[:, 0].cpu().numpy().astype(np.int64)
         self.previous_stage_idx = dev.field("env.prev_stage")[:, 0].cpu().numpy().astype(np.int64)
@@ -279,6 +397,10 @@ class FiniteStateMachineEnv(PhantomEnv):
     def _host_advance(self):
         self._h_step += 1
         nxt = np.asarray([self._stage_index[s.next_stages[0]] if s.next_stages else 0 for s in self._stage_list])
+        if self._rule_handlers:                                          # the device chose: read back when somebody asks
+            self._stage_dirty = True
+            self._chosen_next = None
+            return
         self.previous_stage_idx = self._h_stage.copy()                   # fsm.py:355
         if self._chosen_next is not None:
             self._h_stage = self._chosen_next.copy()

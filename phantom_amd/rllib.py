@@ -273,8 +273,13 @@ class BatchedBaseEnv(_BaseEnvBase):
     * ``send_action_tensor(actions, action_valid=None)`` is the tensor fast path (no python per env);
     * ``try_reset(env_id=None, *, seed=None, options=None)`` -> (obs MultiEnvDict, infos MultiEnvDict)."""
 
-    def __init__(self, env) -> None:
+    def __init__(self, env, keep_results: bool = False) -> None:
+        """``keep_results``: a poll() result may be read FIRST after later steps (its arrays are copied to the host asynchronously with
+        every poll: ~25 us of stream time per step at SC64, B = 4096).  Default: a result is brought to the host when one of its rows
+        is first read, which has to happen before the next send_actions() -- RLlib's samplers read every poll() at once; a loop that
+        stays on tensors (send_action_tensor + the device's StepTensors) pays nothing for polling."""
         self.env = env
+        self._keep = bool(keep_results)
         self._ids = env.strategic_agent_ids
         self._col = {aid: s for s, aid in enumerate(self._ids)}
         self._pending = None
@@ -441,11 +446,11 @@ class BatchedBaseEnv(_BaseEnvBase):
             from . import _abi
             self._always_full = self.env.spec.env_type == _abi.ENV_PLAIN and not dev._needs_valid_planes()
         if self._always_full:
-            # The step's outputs start their way to the host (one asynchronous copy into a pinned buffer, an event behind it) and
-            # poll() returns: no host synchronisation and no python work per env unless a row is read.  The first row read of ANY of
-            # the six results waits for the event and builds that result's B dicts in one vectorised pass (the tensor
-            # path paid 127 us per step for a synchronous copy, numpy copies and three reductions nobody had asked for).
-            host = dev.pull_step_async()
+            # poll() returns six lazy MultiEnvDicts: no copy, no host synchronisation and no python work per env unless a row is read.
+            # The first row read of ANY of them brings the step's outputs to the host (one copy) and builds that result's B dicts in
+            # one vectorised pass (the tensor path paid 127 us per step for a synchronous copy, numpy copies and three
+            # reductions nobody had asked for).
+            host = dev.pull_step_async() if self._keep else dev.pull_step_lazy()
             self._last = (_Rows(B, None, lambda: _rows_of_arrays(ids, host.get()["obs"])),
                           _Rows(B, None, lambda: _rows_of_scalars(ids, host.get()["reward"])),
                           _Rows(B, None, lambda: _rows_of_scalars(ids, host.get()["terminated"].astype(bool), "__all__", host.get()["all_terminated"].astype(bool))),

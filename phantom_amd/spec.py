@@ -41,6 +41,7 @@ class EnvSpec:
     stage_next: Optional[np.ndarray] = None
     stage_allowed: Optional[np.ndarray] = None     # u8 [n_stages][n_stages]: FSMStage.next_stages as a matrix
     stage_tab: Optional[np.ndarray] = None         # i32 [n_stages][num_steps + 1]: tabulated clock / stage handlers (or None)
+    stage_rules: Optional[list] = None             # [(stage index, field name, agent column or -1, cmp code, threshold, next stage index)]: phx_stage_rule
     # Stackelberg
     leaders: Optional[np.ndarray] = None
     followers: Optional[np.ndarray] = None
@@ -167,6 +168,14 @@ class EnvSpec:
         s.col_conn = ptr(self.col_conn, np.int32) if self.n_conn else None
         s.variant_rollout, s.variant_block, s.variant_step, s.variant_flags = resolve_variants(self.variants)
         s.stage_tab = ptr(self.stage_tab, np.int32) if self.stage_tab is not None else None
+        if self.stage_rules:
+            arr = (_abi.PhxStageRule * len(self.stage_rules))()
+            for k, (st, field, col, cmp, thr, nxt) in enumerate(self.stage_rules):
+                arr[k].stage, arr[k].agent, arr[k].cmp, arr[k].next_stage = int(st), int(col), int(cmp), int(nxt)
+                arr[k].threshold, arr[k].field = float(thr), str(field).encode()
+            keep.append(arr)
+            import ctypes as C
+            s.n_stage_rules, s.stage_rules = len(self.stage_rules), C.cast(arr, C.c_void_p)
         return s, keep
 
 
@@ -213,7 +222,7 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                  seed: int = 0, env_offset: int = 0, force_generic: bool = False,
                  extra_queue: int = 16, samplers: Optional[Sequence] = None,
                  device_sampling: bool = False, variants: Optional[Dict] = None,
-                 stage_tab: Optional[np.ndarray] = None, mt19937: bool = False) -> EnvSpec:
+                 stage_tab: Optional[np.ndarray] = None, mt19937: bool = False, stage_rules=None) -> EnvSpec:
     from .agents import Agent, StrategicAgent, check_device_executable
     agent_ids = list(network.agents.keys())
     A = len(agent_ids)
@@ -328,6 +337,18 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
             if tab.shape != (len(stages), int(num_steps) + 1):
                 raise ValueError(f"stage_tab must have shape ({len(stages)}, {int(num_steps) + 1})")
             spec.stage_tab = tab
+        if stage_rules:
+            # [(stage id, StageRule)] -> phx_stage_rule rows: the agent's column among the agents of its kind, or -1 = the kind's sum
+            kr = spec.kind_rank()
+            rows = []
+            for sid, r in stage_rules:
+                if r.cmp not in _abi.CMP:
+                    raise ValueError(f"StageRule: unknown comparison {r.cmp!r} (one of {sorted(_abi.CMP)})")
+                if r.next_stage not in sidx:
+                    raise ValueError(f"StageRule: next stage {r.next_stage!r} is not a stage of the env")
+                col = -1 if r.agent is None else int(kr[index_of(r.agent)])
+                rows.append((sidx[sid], r.field, col, _abi.CMP[r.cmp], float(r.threshold), sidx[r.next_stage]))
+            spec.stage_rules = rows
     elif env_type == _abi.ENV_STACKELBERG:
         spec.leaders = np.asarray([index_of(a) for a in leaders], dtype=np.int32)
         spec.followers = np.asarray([index_of(a) for a in followers], dtype=np.int32)

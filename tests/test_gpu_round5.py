@@ -347,7 +347,7 @@ def test_poll_results_stay_valid_over_later_steps_and_are_refused_once_their_buf
     B, S = 16, 3
     env = supply_chain_env(S, [2] * S, 50, B, seed=4)
     ref = supply_chain_env(S, [2] * S, 50, B, seed=4)
-    be, bref = BatchedBaseEnv(env), BatchedBaseEnv(ref)
+    be, bref = BatchedBaseEnv(env, keep_results=True), BatchedBaseEnv(ref)
     be.poll(); bref.poll()
     ids = list(env.strategic_agent_ids)
     rng = np.random.default_rng(0)
@@ -369,3 +369,95 @@ def test_poll_results_stay_valid_over_later_steps_and_are_refused_once_their_buf
         be.send_action_tensor(a); be.poll()
     with pytest.raises(DeviceError):
         late[0][0]
+    # the default adapter: a result is read before the next step or not at all
+    lazy = BatchedBaseEnv(supply_chain_env(S, [2] * S, 50, B, seed=4))
+    lazy.poll()
+    lazy.send_action_tensor(acts[0]); r0 = lazy.poll()
+    first = r0[0][0][ids[0]].copy()                               # read in time: the step's rows, and they stay
+    lazy.send_action_tensor(acts[1]); r1 = lazy.poll()
+    assert np.array_equal(r0[0][0][ids[0]], first)
+    lazy.send_action_tensor(acts[2]); lazy.poll()
+    with pytest.raises(DeviceError):
+        r1[1][0]                                                  # first read after the next step
+
+
+# ---- stage handlers that branch on agent state, evaluated on the device (phx_spec.stage_rules, ABI 9) ------------------
+def test_state_handler_in_rule_form_reproduces_the_reference_with_one_step_call_per_step():
+    """golden `sc_fsm_state_handler` through the C ABI with the handler as phx_spec.stage_rules: ONE phx_step per step, no stage from the
+    host -- the reference's stage sequence, stocks, observation / reward bits and message log."""
+    from helpers import golden
+    from test_oracle_vs_goldens import replay_supply_chain
+    replay_supply_chain(golden("sc_fsm_state_handler"), lambda spec: DeviceRunner(spec), rule_handlers=True)
+
+
+@pytest.mark.parametrize("S,ks,B,num_steps,thr", [(3, [2, 3, 1], 16, 12, 60), (9, [6] * 9, 64, 30, 300), (51, [4] * 51, 8, 25, 2000)])
+def test_rollouts_with_rule_form_handlers_match_the_oracle(S, ks, B, num_steps, thr):
+    """phx_rollout of an FSM supply chain whose RESTOCK handler branches on the shops' total stock (rule form): the T-step loop of the
+    message-passing engine evaluates the rule after every step's resolution -- every row, the validity planes (who observes depends on
+    the stage chosen) and the state against the oracle; per-step launches from there agree too."""
+    import phantom_amd as ph
+    handler = ph.state_rules([ph.StageRule("shop.stock", "<", thr, "RESTOCK")])(lambda env: None)
+    handler._phx_skip_check = True
+    env = supply_chain_env(S, ks, num_steps, B, fsm=True, seed=5, restock_handler=handler)
+    env._rules_checked = True                                  # (the lambda is a placeholder: the spec is what is under test here)
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    T = 2 * num_steps + 5
+    rd, ro = d.rollout(T), o.rollout(T)
+    assert "phx_generic" in d.dev.last_kernel()
+    np.testing.assert_array_equal(rd["obs_valid"], ro["obs_valid"]); np.testing.assert_array_equal(rd["reward_valid"], ro["reward_valid"])
+    m = ro["obs_valid"].astype(bool)
+    np.testing.assert_array_equal(f32_bits(rd["obs"][m]), f32_bits(ro["obs"][m]))
+    m = ro["reward_valid"] == 1
+    np.testing.assert_array_equal(f32_bits(rd["rewards"][m]), f32_bits(ro["rewards"][m]))
+    np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+    stages = set()
+    rng = np.random.default_rng(1)
+    for t in range(num_steps):
+        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+        o.step(a, None, None); d.step(a, None, None)
+        np.testing.assert_array_equal(d.get_i32("env.stage"), o.get_i32("env.stage"), err_msg=f"stage after step {t}")
+        np.testing.assert_array_equal(d.get_i32("shop.stock"), o.get_i32("shop.stock"))
+        np.testing.assert_array_equal(d.obs_valid, o.obs_valid)
+        stages |= set(np.unique(o.get_i32("env.stage")).tolist())
+        if o.all_truncated.any():
+            mm = o.all_truncated.astype(np.uint8); o.reset(mm); d.reset(mm)
+    assert stages == {0, 1}, "the threshold has to send envs both ways for the test to mean something"
+    assert (d.err == 0).all()
+
+
+def test_rule_form_handlers_through_the_python_surface_and_their_check_against_the_handler():
+    """FiniteStateMachineEnv with @state_rules: creating the device env calls the Python handler on random states and compares with the
+    rules (a wrong declaration raises FSMValidationError); step_tensors then needs no host callback (one launch, the handler is never
+    called), rollout() runs in one launch, current_stage reads the device's choice back."""
+    import torch
+    import phantom_amd as ph
+    from helpers import golden_stock_handler
+    calls = []
+
+    def handler(env):
+        calls.append(1)
+        return golden_stock_handler(env, threshold=60)
+    good = ph.state_rules([ph.StageRule("shop.stock", "<", 60, "RESTOCK")])(handler)
+    env = supply_chain_env(3, [2, 3, 1], 12, 16, fsm=True, seed=5, restock_handler=good)
+    assert not env._has_handlers
+    dev = env._device()
+    n_check = len(calls)
+    assert n_check >= 1                                        # the check ran
+    env.reset()
+    o = OracleEnv(env.spec, threads=2); o.reset()
+    rng = np.random.default_rng(2)
+    for t in range(10):
+        a = rng.uniform(0, 100, (16, 3)).astype(np.float32)
+        env.step_tensors(torch.from_numpy(a).to(dev.device))
+        assert dev.last_kernel().count("phx_generic_step_kernel") == 1
+        o.step(a, None, None)
+        want = [env._stage_list[i].id for i in o.get_i32("env.stage")[:, 0]]
+        assert env.current_stage == want
+    assert len(calls) == n_check                               # never called at step time
+    tr = env.rollout(7)
+    assert tr.obs_valid is not None and "phx_generic" in dev.last_kernel()
+    bad = ph.state_rules([ph.StageRule("shop.stock", "<", 90, "RESTOCK")])(lambda env: golden_stock_handler(env, threshold=60))
+    env2 = supply_chain_env(3, [2, 3, 1], 12, 16, fsm=True, seed=5, restock_handler=bad)
+    with pytest.raises(ph.FSMValidationError):
+        env2._device()

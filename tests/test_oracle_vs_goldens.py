@@ -20,13 +20,25 @@ def stock_handler_stage(run, threshold=60):
     return np.where(cur == 0, np.where(total < threshold, 0, 1), 0).astype(np.int32)       # SELL's only next stage is RESTOCK
 
 
-def replay_supply_chain(g, make_runner, tabulated_handlers=False, state_handler=None):
+def rule_form_env(g, **kw):
+    """the env of golden `sc_fsm_state_handler` with its RESTOCK handler declared in RULE form (phx_spec.stage_rules, ABI 9): restock
+    again while the shops together hold fewer than 60 items, else next_stages[0] = SELL"""
+    import phantom_amd as ph
+    from helpers import golden_stock_handler
+    handler = ph.state_rules([ph.StageRule("shop.stock", "<", 60, "RESTOCK")])(lambda env: golden_stock_handler(env))
+    return env_from_golden({k: g[k] for k in g.files if k != "next_stage"}, tracking=int(g["n_logs"]) > 0, restock_handler=handler, **kw)
+
+
+def replay_supply_chain(g, make_runner, tabulated_handlers=False, state_handler=None, rule_handlers=False):
     """drive a runner (oracle or device adapter) with the golden inputs and compare outputs.  ``tabulated_handlers``: the
     golden's stage handler is declared state-independent and travels as phx_spec.stage_tab instead of a per-step
-    next_stage column."""
+    next_stage column.  ``rule_handlers``: the handler reads agent state and travels as phx_spec.stage_rules -- ONE step call per
+    step, no stage from the host."""
     T, B = int(g["T"]), len(g["seeds"])
     typed = "type_src" in g
-    env = env_from_golden(g, tracking=int(g["n_logs"]) > 0, tabulated_handlers=tabulated_handlers)
+    env = rule_form_env(g) if rule_handlers else env_from_golden(g, tracking=int(g["n_logs"]) > 0, tabulated_handlers=tabulated_handlers)
+    if rule_handlers:
+        assert env.spec.stage_rules and env.spec.stage_tab is None
     if tabulated_handlers:
         assert env.spec.stage_tab is not None and env.spec.stage_tab.shape == (2, int(g["num_steps"]) + 1)
     run = make_runner(env.spec)
@@ -57,6 +69,8 @@ def replay_supply_chain(g, make_runner, tabulated_handlers=False, state_handler=
             nxt = state_handler(run)
             np.testing.assert_array_equal(nxt, g["next_stage"][t], err_msg=f"the handler's stage at t={t} (it must see the RESOLVED state)")
             run.step_end(nxt)
+        elif rule_handlers:                                  # the rules are evaluated inside the step, on the resolved state
+            run.step(g["actions"][t], None, exo)
         elif "next_stage" in g and not tabulated_handlers:   # the stage the reference's handler returned (fsm.py:294-302), per env
             run.step(g["actions"][t], None, exo, next_stage=g["next_stage"][t])
         else:
@@ -220,3 +234,11 @@ ADS_CASES = ["ads_first", "ads_second", "ads_sampled", "ads_stochastic"]
 @pytest.mark.parametrize("name", ADS_CASES)
 def test_oracle_ads_market_matches_reference(name):
     replay_ads(golden(name), lambda spec: OracleEnv(spec))
+
+
+def test_state_handler_declared_as_rules_reproduces_the_reference():
+    """golden `sc_fsm_state_handler` (the REFERENCE: a RESTOCK handler that resolves the network, then branches on the shops' total
+    stock) with the handler in RULE form (phx_spec.stage_rules): the oracle evaluates the rule inside ONE step call per step and
+    reproduces the handler's decisions, the stage sequence, stocks, observations and rewards bit for bit."""
+    g = golden("sc_fsm_state_handler")
+    replay_supply_chain(g, lambda spec: OracleEnv(spec), rule_handlers=True)
