@@ -517,9 +517,7 @@ def run(args, rank, local_rank, world, watch):
     # stores only the non-zero words after phx_rollout's own in-line fill (phx_spec.variant_flags sparse).
     served_by = dev.last_kernel()                              # what phx_rollout launched for the bench fragment (phx_last_kernel)
     store_waves = "phx_sc_rollout_sw_kernel" in served_by
-    sparse = (not store_waves) and env._variants.get("flags", "auto") != "dense" and T * B * S >= (1 << 23)
-    use_pipe = False                                          # (round 3's --flag-pipeline experiment was removed: measured slower)
-    pipe_on = [False]
+    sparse = (not store_waves) and T * B * S >= (1 << 23)
 
     def launches(n, bufs=None):                             # n calls of NF fragments each, back to back
         bufs = bufs or trajs
@@ -584,9 +582,7 @@ def run(args, rank, local_rank, world, watch):
                    "trajectory_buffers": f"{n_buf} sets x {NF} fragments x {frag_bytes / NF / 1e6:.1f} MB, rotated (more than the 256 MB Infinity Cache)",
                    "steps_per_launch": T, "episodes_per_launch": T // NUM_STEPS, "fragments_per_call": NF, "steps_per_fragment": TF,
                    "autotune": tune,
-                   "flag_planes": ("zeros of the next buffer's terminated / truncated planes written on a side stream beside the current "
-                                   "fragment (PHX_RH_FLAGS_ZEROED), non-zero words by the kernel" if use_pipe else
-                                   ("zero-filled in line by phx_rollout, non-zero words by the kernel" if sparse else
+                   "flag_planes": (("zero-filled in line by phx_rollout, non-zero words by the kernel" if sparse else
                                     ("every word stored by the kernel's store waves, whole 16-byte pieces (no fill launch)" if store_waves
                                      else "every word stored by the kernel"))),
                    "served_by": served_by},

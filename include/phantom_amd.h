@@ -230,9 +230,7 @@ typedef struct phx_spec {
   int32_t variant_block;        /* time-parallel rollout kernels: (env, shop) pairs per workgroup; 0 = auto,
                                    PHX_VB_WHOLE_ENVS = whole envs per workgroup                */
   int32_t variant_step;         /* PHX_VS_*                                                   */
-  int32_t variant_flags;        /* ABI 7, time-parallel supply-chain rollout: PHX_VF_DENSE = the kernel stores every word of the flag planes;
-                                   PHX_VF_SPARSE = a streaming fill zeroes them and the kernel stores the non-zero words only (0 = auto:
-                                   sparse for fragments of >= 2^23 agent-steps)                                                    */
+  int32_t variant_reserved;     /* 0 (ABI 7-8: variant_flags, removed in ABI 9 -- how a kernel writes its flag planes is its own business) */
   /* ABI 6: stage handlers that decide from the clock and the current stage alone (fsm.py:294-307), tabulated by the
    * host at spec-compile time: stage_tab[s * (num_steps + 1) + t] = the stage the handler of stage s returns when the
    * clock reads t (1 .. num_steps; the clock is incremented before the handler runs, fsm.py:268); rows of handler-less
@@ -261,9 +259,6 @@ typedef struct phx_spec {
 #define PHX_VS_GENERIC       2  /* the message-passing engine (same as PHX_F_FORCE_GENERIC)                                       */
 #define PHX_VS_WIDE          3  /* plain supply chain, device-RNG orders: four (env, shop) pairs per thread, 16-byte accesses (AUTO
                                    takes it from 2^19 pairs per launch up; smaller launches are latency-bound either way)          */
-/* phx_spec.variant_flags */
-#define PHX_VF_DENSE         1
-#define PHX_VF_SPARSE        2
 
 typedef struct phx_env phx_env;   /* opaque */
 
@@ -322,10 +317,8 @@ typedef struct phx_step_io {
 
 /* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end.
  * Every buffer must be 16-byte aligned (the kernels write 16-byte pieces); phx_rollout returns PHX_EINVAL otherwise. */
-#define PHX_RH_FLAGS_ZEROED 1   /* EXPERIMENTAL (round 3; measured slower: the cross-stream waits cost more than the fill they hide; the round-4
-                                   default kernel stores every flag word and ignores it).  phx_rollout_io.hints: the caller has ALREADY zeroed `terminated` and `truncated` (e.g. on a side stream,
-                                   while the previous fragment was being written): where the serving kernel stores only the non-zero flag
-                                   words (phx_spec.variant_flags) its own fill is skipped; ignored by kernels that store every word */
+/* (ABI 9 removed three experimental pieces of ABI 7-8 that every measurement since had left behind: the PHX_RH_FLAGS_ZEROED hint, the
+ *  24-byte record layout phx_rollout_io.records and phx_spec.variant_flags -- DESIGN_HISTORY.md has their numbers.)                   */
 /* ABI 9: one trajectory fragment of a launch that writes SEVERAL (phx_rollout_io.frags): the planes of phx_rollout_io, each
  * [frag_T][B][S](..) -- separate allocations, e.g. the buffers a learner takes one at a time.                              */
 #define PHX_MAX_FRAGMENTS 8
@@ -341,7 +334,7 @@ typedef struct phx_rollout_frag {
 
 typedef struct phx_rollout_io {
   int32_t T;
-  int32_t hints;               /* ABI 7: PHX_RH_* (occupies what was padding: zero-initialised structs of older callers mean 0) */
+  int32_t hints;               /* 0 (reserved)                                              */
   const float*   actions;      /* [T][B][S] replayed policy, or NULL -> random U[0,100)     */
   const uint8_t* exo;          /* [T][B][n_exo] or NULL -> device RNG                       */
   float*    obs;               /* [T][B][S][D]  post-step observation                       */
@@ -359,15 +352,7 @@ typedef struct phx_rollout_io {
    * generic engine's launch loop); both NULL = not recorded.                               */
   phx_msg_rec* msg_log;        /* [T][B][trace_cap] or NULL                                 */
   int32_t*  msg_count;         /* [T][B] or NULL                                            */
-  /* ABI 7, EXPERIMENTAL opt-in RECORD layout (levels the boxes of round 3's kernel at 87 us per T = 400 fragment; the round-4
-   * store-wave kernel writes the planes in 61-66 us and does not serve it): [T][B][S] records of PHX_TRAJ_RECORD_BYTES = 24 bytes
-   *   { float obs[3]; float action; float reward; uint8_t terminated, truncated, pad[2]; }
-   * instead of the five planes obs / action_out / reward / terminated / truncated, which must then be NULL.  The same values
-   * (time-major, one record per (step, env instance, strategic agent)); a workgroup of the time-parallel supply-chain kernel
-   * writes ONE run of whole cache lines per step instead of seven narrow runs (0.59-0.66 against 0.46-0.59 of the
-   * peak for the store pattern alone), at 24 instead of 22 bytes per agent-step.  Served by the time-parallel supply-chain
-   * rollout only (plain env, obs dim 3, device RNG and policy): PHX_EUNSUPPORTED elsewhere.  NULL = the planes.             */
-  void*     records;
+  void*     reserved_ptr;      /* NULL (ABI 7-8: the record layout, removed in ABI 9)       */
   /* ABI 9: a fragment LIST.  n_frag >= 2 (<= PHX_MAX_FRAGMENTS) and frags != NULL (a HOST array, read during the call): the launch
    * advances the envs T steps as always and writes rows [f T / n_frag, (f + 1) T / n_frag) to frags[f] (T % n_frag == 0; obs,
    * action_out, reward, terminated, truncated, obs_valid, reward_valid of the io itself must then be NULL; actions / exo / msg_log /
@@ -381,7 +366,6 @@ typedef struct phx_rollout_io {
   int32_t   reserved0;
   const phx_rollout_frag* frags;
 } phx_rollout_io;
-#define PHX_TRAJ_RECORD_BYTES 24
 
 /* ---- entry points ---------------------------------------------------------------------- */
 int         phx_abi_version(void);

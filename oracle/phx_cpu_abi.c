@@ -114,24 +114,7 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   (void)stream;
   if (!e || !io || io->T <= 0) return PHX_EINVAL;
-  if (io->records) {                                     /* the record layout: the planes, interleaved (include/phantom_amd.h) */
-    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated) return PHX_EINVAL;
-    const int S = phxo_n_strategic(e->o);
-    if (e->env_type != PHX_ENV_PLAIN || phxo_obs_dim(e->o) != 3 || io->actions || io->exo || io->msg_log) return PHX_EUNSUPPORTED;
-    const size_t n = (size_t)io->T * (size_t)e->B * (size_t)S;
-    phx_rollout_io p = *io;
-    p.records = NULL;
-    p.obs = (float*)malloc(n * 12); p.action_out = (float*)malloc(n * 4); p.reward = (float*)malloc(n * 4);
-    p.terminated = (uint8_t*)malloc(n); p.truncated = (uint8_t*)malloc(n);
-    phxo_rollout(e->o, &p);
-    uint8_t* r = (uint8_t*)io->records;
-    for (size_t i = 0; i < n; ++i, r += PHX_TRAJ_RECORD_BYTES) {
-      memcpy(r, p.obs + 3 * i, 12); memcpy(r + 12, p.action_out + i, 4); memcpy(r + 16, p.reward + i, 4);
-      r[20] = p.terminated[i]; r[21] = p.truncated[i]; r[22] = 0; r[23] = 0;
-    }
-    free(p.obs); free(p.action_out); free(p.reward); free(p.terminated); free(p.truncated);
-    return PHX_OK;
-  }
+  if (io->hints != 0 || io->reserved_ptr) return PHX_EINVAL;
   if (io->n_frag >= 2 || io->frags) {                    /* ABI 9, a fragment list: the same steps, the rows handed out fragment by fragment */
     if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags || io->T % io->n_frag) return PHX_EINVAL;
     if (io->obs || io->action_out || io->reward || io->terminated || io->truncated || io->obs_valid || io->reward_valid) return PHX_EINVAL;

@@ -31,7 +31,6 @@ ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP, VR_STORE_WAVES = 0, 1, 2, 3, 4, 5
 VB_WHOLE_ENVS = -1
 VS_AUTO, VS_FUSED, VS_GENERIC, VS_WIDE = 0, 1, 2, 3
-RH_FLAGS_ZEROED = 1          # phx_rollout_io.hints
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES, F_MT19937 = 1, 2, 4, 8, 16
@@ -63,7 +62,7 @@ class PhxSpec(C.Structure):
         ("n_conn", C.c_int32), ("conn_rate", C.c_void_p), ("col_conn", C.c_void_p),
         ("stage_allowed", C.c_void_p),
         ("variant_rollout", C.c_int32), ("variant_block", C.c_int32), ("variant_step", C.c_int32),
-        ("variant_flags", C.c_int32),
+        ("variant_reserved", C.c_int32),
         ("stage_tab", C.c_void_p),
         ("n_stage_rules", C.c_int32), ("reserved1", C.c_int32), ("stage_rules", C.c_void_p),
     ]
@@ -94,7 +93,7 @@ class PhxStepIO(C.Structure):
 class PhxRolloutIO(C.Structure):
     _fields_ = [("T", C.c_int32), ("hints", C.c_int32)] + [(n, C.c_void_p) for n in (
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
-        "reward_valid", "last_obs", "err", "msg_log", "msg_count", "records")] + [
+        "reward_valid", "last_obs", "err", "msg_log", "msg_count", "reserved_ptr")] + [
         ("n_frag", C.c_int32), ("reserved0", C.c_int32), ("frags", C.c_void_p)]
 
 

@@ -724,7 +724,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.flags = spec->flags; d.queue_cap = spec->queue_cap; d.trace_cap = spec->trace_cap; d.scan_cap = der.scan_cap;
   d.n_lists = der.n_lists; d.initial_stage = spec->initial_stage; d.buyer_nnz = der.buyer_nnz; d.buyer_stride = der.kind_count[PHX_KIND_BUYER];
   d.seed = spec->seed; d.env_offset = spec->env_offset;
-  d.variant_rollout = spec->variant_rollout; d.variant_block = spec->variant_block; d.variant_step = spec->variant_step; d.variant_flags = spec->variant_flags;
+  d.variant_rollout = spec->variant_rollout; d.variant_block = spec->variant_block; d.variant_step = spec->variant_step;
   memcpy(d.kind_count, der.kind_count, sizeof d.kind_count);
   const int A = der.A;
 #define UP(dst, ptr, n) do { rc = upload(e, ptr, (size_t)(n), &d.dst); if (rc != PHX_OK) { phx_destroy(e); return rc; } } while (0)
@@ -1142,7 +1142,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (io->n_frag >= 2 || io->frags) {   // ABI 9: a fragment list
     if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags) return fail(PHX_EINVAL, "phx_rollout: a fragment list needs 2 .. %d fragments and `frags`", PHX_MAX_FRAGMENTS);
     if (io->T <= 0 || io->T % io->n_frag) return fail(PHX_EINVAL, "phx_rollout: T must be a positive multiple of n_frag");
-    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated || io->obs_valid || io->reward_valid || io->records)
+    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated || io->obs_valid || io->reward_valid)
       return fail(PHX_EINVAL, "phx_rollout: with a fragment list the io's own planes must be NULL");
     const bool need_valid = e->d.env_type != PHX_ENV_PLAIN;
     for (int f = 0; f < io->n_frag; ++f) {
@@ -1179,19 +1179,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     }
     return PHX_OK;
   }
-  if (io->records) {                  // opt-in record layout: the time-parallel supply-chain kernel only
-    if (io->obs || io->action_out || io->reward || io->terminated || io->truncated)
-      return fail(PHX_EINVAL, "phx_rollout: with `records` the five planes must be NULL");
-    if (io->T <= 0 || ((uintptr_t)io->records & 15u) || ((uintptr_t)io->last_obs & 15u)) return fail(PHX_EINVAL, "bad rollout io");
-    if (!(e->use_fused && e->d.env_type == PHX_ENV_PLAIN && !e->d.any_typed && e->d.D == 3 && e->d.sc_fast.ok && !io->actions && !io->exo &&
-          !io->msg_log && !io->msg_count && e->d.variant_rollout != PHX_VR_GENERAL && e->d.variant_rollout != PHX_VR_LAUNCH_LOOP))
-      return fail(PHX_EUNSUPPORTED, "phx_rollout: the record layout is served by the time-parallel supply-chain rollout only");
-    if ((int64_t)20 * e->d.B * e->d.S * PHX_TRAJ_RECORD_BYTES >= ((int64_t)1 << 32))       // 32-bit offsets within a chunk of rows
-      return fail(PHX_EUNSUPPORTED, "phx_rollout: batch too large for the record layout");
-    HIPCHK(use_device(e));
-    HIPCHK(phx_launch_sc_rollout_fast(e->d, *io, (hipStream_t)stream));
-    return PHX_OK;
-  }
+  if (io->hints != 0 || io->reserved_ptr) return fail(PHX_EINVAL, "phx_rollout: hints / reserved_ptr must be zero (ABI 9 removed PHX_RH_FLAGS_ZEROED and the record layout)");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
   // `terminated` may be NULL where the plane would be all zero AND the kernel that serves the launch can leave it out: the

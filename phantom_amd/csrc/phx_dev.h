@@ -66,7 +66,7 @@ struct DevKnobs {
   int rollout_ldskb;           // PHX_ROLLOUT_LDSKB (default 0)
   int rollout_nt;              // PHX_ROLLOUT_NT (default 0)
   int rollout_remap;           // PHX_ROLLOUT_REMAP (default -1)
-  int rollout_sparse_flags;    // PHX_ROLLOUT_SPARSE_FLAGS (default 1)
+  int rollout_sparse_flags;    // PHX_ROLLOUT_SPARSE_FLAGS (default 1: round 3's kernel zero-fills the flag planes of fragments >= 2^23 agent-steps and stores the non-zero words; 0 never, 2 always)
   int step_nt;                 // PHX_STEP_NT (default 0)
   int stk_rollout_nt;          // PHX_STK_ROLLOUT_NT (default 0)
   int stk_step_fast;           // PHX_STK_STEP_FAST (default 1)
@@ -145,7 +145,7 @@ struct DevSpec {
   const uint8_t* shop_cust_act;  // [n_lists][n_exo] customer (by position in shop_cust_*) acts in list
   const uint8_t* sc_shop_flags;  // [n_lists][nS] 1 shop acts, 2 a customer acts, 4 every customer acts, 8 observes, 16 rewarded
   int32_t max_cust;              // max customers of one shop
-  int32_t variant_rollout, variant_block, variant_step, variant_flags;   // phx_spec.variant_* (0 = the library's choice)
+  int32_t variant_rollout, variant_block, variant_step;   // phx_spec.variant_* (0 = the library's choice)
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   int32_t sc_wide_K, sc_wide_norm;   // phx_sc_step_wide_kernel: the shops' common customer count (0: the kernel does not apply) and normaliser
   ScSwPlan sc_sw;                // store-wave rollout kernel (round 4): plan (ok == 0: not applicable)

@@ -61,8 +61,7 @@ typedef const __attribute__((address_space(4))) char* fast_kptr_t;
 #define a (*(const FastArgs*)kp)
 #define io (a.io)
 #define FAST_REFRESH() asm volatile("" : "+s"(kp))
-// REC: the trajectory goes out as 24-byte records (phx_rollout_io.records) instead of the five planes
-template <int NT, bool REC>
+template <int NT>
 __global__ __launch_bounds__(NT, (NT > 512 ? NT / 256 : NT / 64)) void phx_sc_rollout_fast_kernel(const FastArgs a_) {
   fast_kptr_t kp = (fast_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   FAST_REFRESH();
@@ -283,74 +282,6 @@ __global__ __launch_bounds__(NT, (NT > 512 ? NT / 256 : NT / 64)) void phx_sc_ro
     const uint32_t PR = 3u * (uint32_t)G4;                              // 16-byte observation pieces per tile row
     const uint32_t row_bytes = utotal * 12u;                            // bytes between tile rows of the observation plane
     const int lane = tid & 63;
-    if constexpr (REC) {
-      // RECORD layout: a unit's four records are 96 bytes = six 16-byte pieces; piece 6 u + j is their position in the chunk's
-      // row-major record block.  They are transposed through LDS like the observation pieces of the plane layout, in the
-      // wave's OWN region of the staging tile (three pieces per unit) plus the unit's own 16 bytes of the R | D, action and
-      // stock tiles of this chunk, which the unit has just consumed (nobody reads them again before the next barrier): no
-      // more LDS than the plane layout.  Each store instruction then writes 64 consecutive pieces = 1 KB of whole lines.
-      char* const p_rec = (char*)io.records + row0 * 24;
-      const uint32_t PR6 = 6u * (uint32_t)G4, row_bytes24 = utotal * 24u;
-      const uint32_t mPR6 = (uint32_t)((0x100000000ull + PR6 - 1) / PR6);
-      for (int ub = (tid - first) - lane; ub < n_units; ub += nw) {
-        const int u = ub + lane;
-        char* const st_o = (char*)(s_ostage + 12 * ub);              // the wave's regions: 48 + 16 + 16 + 16 bytes per unit
-        char* const st_r = (char*)(s_rd + 4 * ub);
-        char* const st_a = (char*)(s_act + 4 * ub);
-        char* const st_x = (char*)(s_xb + 4 * ub);
-        if (u < n_units) {
-          const int r = (int)__umulhi((uint32_t)u, a.mG4);
-          const int gl0 = (u - (int)__umul24(r, G4)) << 2, i0 = (int)__umul24(r, G) + gl0;
-          const uint4 vr = *(const uint4*)(s_rd + i0), vx = *(const uint4*)(s_xb + i0), ve = *(const uint4*)(s_ptend + gl0);
-          const float4 va = *(const float4*)(s_act + i0);
-          const int rdv[4] = {(int)vr.x, (int)vr.y, (int)vr.z, (int)vr.w}, xbv[4] = {(int)vx.x, (int)vx.y, (int)vx.z, (int)vx.w};
-          const int ev[4] = {(int)ve.x, (int)ve.y, (int)ve.z, (int)ve.w};
-          const float av[4] = {va.x, va.y, va.z, va.w};
-          float w[24];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int R = rdv[k] & 255, D = rdv[k] >> 8, x0 = xbv[k];
-            const int sales = min(x0, D);                               // handle_order_request :105-122
-            const int missed = D - sales;
-            int xa = x0 - sales + min(R, PHX_SHOP_MAX_STOCK - x0);      // handle_stock_response :98-103
-            if (guard) xa = min(xa, PHX_SHOP_MAX_STOCK);
-            if (!guard || ((unsigned)x0 <= (unsigned)PHX_SHOP_MAX_STOCK)) {
-              w[6 * k] = s_tabs[xa]; w[6 * k + 1] = s_tabn[sales]; w[6 * k + 2] = s_tabn[missed];   // encode_observation :124-134
-              w[6 * k + 4] = (float)__dsub_rn((double)sales, s_pen[xa]);                          // compute_reward :147
-            } else {
-              float ob[3];
-              shop_obs_f32(xa, sales, missed, (float)a.norm, ob);
-              w[6 * k] = ob[0]; w[6 * k + 1] = ob[1]; w[6 * k + 2] = ob[2];
-              w[6 * k + 4] = (float)shop_reward(sales, xa);
-            }
-            w[6 * k + 3] = av[k];
-            w[6 * k + 5] = __uint_as_float((r == ev[k]) ? 0x100u : 0u);  // bytes: terminated 0, truncated (env.py:312-318), 0, 0
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the unit's tile words are in registers: their bytes are free
-          float4* so = (float4*)(st_o + 48 * lane);
-          so[0] = make_float4(w[0], w[1], w[2], w[3]); so[1] = make_float4(w[4], w[5], w[6], w[7]); so[2] = make_float4(w[8], w[9], w[10], w[11]);
-          *(float4*)(st_r + 16 * lane) = make_float4(w[12], w[13], w[14], w[15]);
-          *(float4*)(st_a + 16 * lane) = make_float4(w[16], w[17], w[18], w[19]);
-          *(float4*)(st_x + 16 * lane) = make_float4(w[20], w[21], w[22], w[23]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // wave-private regions: no barrier
-        const uint32_t q0 = 6u * (uint32_t)ub, qn = 6u * (uint32_t)n_units;
-#ifdef PHX_ABL_NOSTORE
-        if (a.norm != -12345) continue;                                  // dev ablation: everything but the stores
-#endif
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const uint32_t ql = (uint32_t)lane + 64u * (uint32_t)k, q = q0 + ql;           // piece ql of the wave = piece j of its unit l
-          if (q < qn) {
-            const uint32_t l = __umulhi(ql, 715827883u), j = ql - 6u * l;                 // ql / 6 for ql < 2^16
-            const char* src = j < 3u ? st_o + 48u * l + 16u * j : (j == 3u ? st_r : (j == 4u ? st_a : st_x)) + 16u * l;
-            const uint32_t rr = __umulhi(q, mPR6), pc = q - rr * PR6;                     // tile row and piece within the row
-            *(float4*)(p_rec + (size_t)rr * row_bytes24 + (size_t)(pc * 16u)) = *(const float4*)src;
-          }
-        }
-      }
-      return;
-    }
     for (int ub = (tid - first) - lane; ub < n_units; ub += nw) {       // ub: the wave's first unit (uniform per wave)
       const int u = ub + lane;
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vrw = va;
@@ -490,7 +421,11 @@ bool phx_sc_fast_plan(int B, int S, int K_uniform, bool norm_uniform, int num_st
   const int64_t total = (int64_t)B * S;
   const int g_env = phx_knobs().rollout_g;               // development default of variant_block
   if (block == 0) block = g_env;
-  auto pairs_ok = [&](int G) { return G >= 4 && G <= 192 && G % 4 == 0 && total % G == 0 && (G + S - 2) / S + 1 <= 255; };
+  // (the kernel's LDS -- phx_launch_sc_rollout_fast: constants + 11 tile words per item of a 20-row chunk -- has to fit the CU's 160 KB:
+  //  ADVICE r4, block = 184 .. 192 planned and then failed at launch)
+  auto lds_of = [&](int G) { const size_t epb_ = (size_t)((G + S - 2) / S + 1);
+    return (size_t)((G + 3) & ~3) * 12 + 128 + 104 * 4 + 32 * 4 + 102 * 8 + (size_t)PHX_FAST_TC * G * 4 * 11 + ((epb_ + 3) & ~(size_t)3) * 4 + 16; };
+  auto pairs_ok = [&](int G) { return G >= 4 && G <= 192 && G % 4 == 0 && total % G == 0 && (G + S - 2) / S + 1 <= 255 && lds_of(G) <= (size_t)160 * 1024; };
   // (1) whole envs per block, a multiple of 4 of them so that every tile row is a whole number of 16-byte segments;
   //     ~32..64 pairs per block (one recurrence wave)
   int epb = 0;
@@ -583,8 +518,8 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   // episodes' last rows: a streaming fill (whole lines, ~5 us per T = 400 fragment) writes the zeros, the kernel the exceptions.
   const int sparse_env = phx_knobs().rollout_sparse_flags;      // development
   const int64_t n_flag = (int64_t)io.T * sp.B * sp.S;
-  a.flags_sparse = (!io.records && (sp.variant_flags == PHX_VF_SPARSE || (sp.variant_flags != PHX_VF_DENSE && sparse_env && n_flag >= ((int64_t)1 << 23)))) ? 1 : 0;
-  if (a.flags_sparse && !(io.hints & PHX_RH_FLAGS_ZEROED)) {          // (the caller may have zeroed them already, beside the previous fragment)
+  a.flags_sparse = (sparse_env == 2 || (sparse_env && n_flag >= ((int64_t)1 << 23))) ? 1 : 0;      // (PHX_ROLLOUT_SPARSE_FLAGS: 0 never, 1 large fragments, 2 always)
+  if (a.flags_sparse) {
     phx_note_kernel("phx_zero_fill_kernel[flag planes]");
     hipError_t me;
     if (io.terminated && io.terminated == io.truncated + n_flag) me = zero_fill(io.truncated, 2 * n_flag, st);
@@ -598,20 +533,17 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
   const int nt_env = phx_knobs().rollout_nt;
   const int rec = ((p.G + 63) / 64) * 64;
   const int nt = (nt_env && nt_env >= rec + 64) ? nt_env : p.nt;
-  phx_note_kernel(io.records ? (p.whole_envs ? "phx_sc_rollout_fast_kernel[whole_envs,records]" : "phx_sc_rollout_fast_kernel[pairs,records]")
-                             : (p.whole_envs ? "phx_sc_rollout_fast_kernel[whole_envs]" : "phx_sc_rollout_fast_kernel[pairs]"));
-#define PHX_LAUNCH_FAST(NT_) do { if (io.records) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<NT_, true>), grid, dim3(NT_), lds, st, a); \
-                                 else hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<NT_, false>), grid, dim3(NT_), lds, st, a); } while (0)
+  phx_note_kernel(p.whole_envs ? "phx_sc_rollout_fast_kernel[whole_envs]" : "phx_sc_rollout_fast_kernel[pairs]");
+#define PHX_LAUNCH_FAST(NT_) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<NT_>), grid, dim3(NT_), lds, st, a)
   if (lds > 64 * 1024) {               // more than 64 KB of dynamic LDS needs the attribute (wide workgroups)
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      done = true;
+    // (per device, result checked: ADVICE r4 -- a second GPU of the process never got the attribute)
+    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev);
+    if (dev_done != dev) {
+      hipError_t ae = hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (ae != hipSuccess) return ae;
+      dev_done = dev;
     }
   }
   if (nt == 1024) PHX_LAUNCH_FAST(1024);

@@ -51,8 +51,6 @@ class Trajectory(NamedTuple):
     flat: "object" = None           # u8 [nbytes]: the one buffer every plane above is a section of (alloc_trajectory(flat=True))
     packed_flags: "object" = None   # u8 view of `flat`: bit-packed done flags for rollout collection (pack_done_flags)
     gather_nbytes: int = 0          # prefix of `flat` a learner needs from every rank (distributed.TrajectoryGather)
-    records: "object" = None        # u8 [T, B, S, 24]: the RECORD layout (alloc_trajectory(records=True)); observations /
-                                    # actions / rewards / terminations / truncations are then strided VIEWS of it
 
 
 class DeviceError(RuntimeError):
@@ -392,7 +390,7 @@ class DeviceEnv:
         return bool(np.isin(k, (_abi.KIND_SHOP, _abi.KIND_SELLER, _abi.KIND_BUYER)).all())
 
     def alloc_trajectory(self, T: int, record_messages: bool = False, flat: bool = False,
-                         terminations: bool = True, records: bool = False) -> Trajectory:
+                         terminations: bool = True) -> Trajectory:
         """Uninitialised device buffers for a T-step fragment (time-major).  ``record_messages``:
         also the per-step ordered message log (rollout.py:369-373, needs enable_tracking).
         ``flat``: every plane is a 256-byte aligned section of ONE buffer, ordered so that what a
@@ -404,16 +402,6 @@ class DeviceEnv:
         fsm = self._needs_valid_planes()
         if record_messages and self.spec.trace_cap <= 0:
             raise DeviceError("record_messages needs BatchResolver(enable_tracking=True)")
-        if records:
-            # phx_rollout_io.records: ONE buffer of 24-byte records {obs[3], action, reward, terminated, truncated, pad, pad} per
-            # (step, env instance, strategic agent); the usual fields are strided views of it (zero-copy: `.contiguous()` where a
-            # consumer needs a dense plane).  Served by the time-parallel supply-chain rollout only (phx_rollout refuses otherwise).
-            if flat or record_messages or fsm or D != 3:
-                raise DeviceError("alloc_trajectory(records=True): plain envs with 3-float observations only, not with flat / record_messages")
-            rec = e(T, B, S, 24, dtype=torch.uint8)
-            f = rec.view(torch.float32)                                # [T, B, S, 6]
-            return Trajectory(f[..., 0:3], f[..., 3], f[..., 4], rec[..., 20], rec[..., 21], e(B, S, D, dtype=torch.float32),
-                              records=rec)
         if flat:
             n = T * B * S
             words = (n + 63) // 64
@@ -478,10 +466,6 @@ class DeviceEnv:
             need("actions", actions, torch.float32, (B, S), lead=T)
         if exo is not None:
             need("exo", exo, torch.uint8, (B, self.n_exo), lead=T)
-        if out.records is not None:                        # record layout: one buffer; the plane fields are views of it
-            need("out.records", out.records, torch.uint8, (B, S, 24))
-            need("out.last_obs", out.last_obs, torch.float32, (S, D), lead=B)
-            return
         need("out.observations", out.observations, torch.float32, (B, S, D))
         need("out.actions", out.actions, torch.float32, (B, S))
         need("out.rewards", out.rewards, torch.float32, (B, S))
@@ -501,16 +485,9 @@ class DeviceEnv:
             need("out.msg_count", out.msg_count, torch.int32, (B,))
             need("out.msg_log", out.msg_log, torch.uint8, (B, self.spec.trace_cap, 16))
 
-    def zero_flags(self, traj: Trajectory):
-        """Zero the ``terminations`` / ``truncations`` planes of a fragment on the CURRENT stream: a collection loop does this for the
-        next buffer on a side stream while the current fragment is written, and passes ``flags_zeroed=True`` to ``rollout``."""
-        traj.truncations.zero_()
-        if traj.terminations is not None:
-            traj.terminations.zero_()
-
-    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None, flags_zeroed: bool = False) -> Trajectory:
-        """``flags_zeroed``: the caller has already zeroed ``out``'s flag planes (``zero_flags``) -- where the serving kernel stores
-        only the non-zero flag words (phx_spec.variant_flags) its own fill is skipped; kernels that store every word ignore it."""
+    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
+        """T fused steps into ``out`` (allocated here when None); ``actions`` f32 [T, B, S] / ``exo`` u8 [T, B, n_exo] replay a recorded
+        policy / recorded draws (None: the device's random policy / RNG stream)."""
         owned = out is None
         if owned:
             out = self.alloc_trajectory(T)
@@ -520,19 +497,16 @@ class DeviceEnv:
         # ~80 MB at B=4096).
         ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else None
         sig = lambda x: (x.data_ptr(), x.numel()) if hasattr(x, "data_ptr") else None     # address AND size: a buffer freed
-        key = (T, bool(flags_zeroed)) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))    # and reallocated smaller misses
+        key = (T,) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))    # and reallocated smaller misses
         cached = None if owned else self._rollout_io_cache.get(key)
         if cached is None:
             self._check_rollout_buffers(T, actions, exo, out)
             io = _abi.PhxRolloutIO()
             io.T = T
-            io.hints = _abi.RH_FLAGS_ZEROED if (flags_zeroed and not owned) else 0
+            io.hints = 0
             io.actions, io.exo = ptr(actions), ptr(exo)
-            if out.records is not None:
-                io.records = ptr(out.records)              # (the five planes stay NULL)
-            else:
-                io.obs, io.action_out, io.reward = ptr(out.observations), ptr(out.actions), ptr(out.rewards)
-                io.terminated, io.truncated = ptr(out.terminations), ptr(out.truncations)
+            io.obs, io.action_out, io.reward = ptr(out.observations), ptr(out.actions), ptr(out.rewards)
+            io.terminated, io.truncated = ptr(out.terminations), ptr(out.truncations)
             io.last_obs = ptr(out.last_obs)
             io.obs_valid, io.reward_valid = ptr(out.obs_valid), ptr(out.reward_valid)
             io.msg_log, io.msg_count = ptr(out.msg_log), ptr(out.msg_count)
@@ -567,7 +541,7 @@ class DeviceEnv:
         cached = self._rollout_io_cache.get(key)
         if cached is None:
             for o in outs:
-                if o.records is not None or o.msg_log is not None:
+                if o.msg_log is not None:
                     raise ValueError("rollout_fragments: plane fragments without message logs (alloc_trajectory(T))")
                 self._check_rollout_buffers(T, None, None, o)
             if any((o.terminations is None) != (outs[0].terminations is None) for o in outs):

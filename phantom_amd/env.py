@@ -504,7 +504,7 @@ class PhantomEnv:
         if candidates is None:
             # Round 4: the store-wave kernel (one 144-pair workgroup per CU at SC64 / B = 4096, dense flag planes written by its
             # store waves: 65 us per T = 400 fragment where the round-3 kernel takes 71-76) against round 3's kernel with its two
-            # workgroup shapes and -- new -- 144-pair workgroups.  Whole-env workgroups and {"flags": "dense"} on the round-3
+            # workgroup shapes and -- new -- 144-pair workgroups.  Whole-env workgroups on the round-3
             # kernel are NOT default candidates: where they win it is by <= 5 %, and their partially written boundary lines make
             # them sensitive to where the trajectory buffers land (up to 1.6x between two allocations of the same process).
             candidates = [{"rollout": "store_waves"}, {"rollout": "time_parallel", "block": 144},

@@ -166,7 +166,8 @@ class EnvSpec:
         s.n_conn = self.n_conn
         s.conn_rate = ptr(self.conn_rate, np.float64) if self.n_conn else None
         s.col_conn = ptr(self.col_conn, np.int32) if self.n_conn else None
-        s.variant_rollout, s.variant_block, s.variant_step, s.variant_flags = resolve_variants(self.variants)
+        s.variant_rollout, s.variant_block, s.variant_step = resolve_variants(self.variants)
+        s.variant_reserved = 0
         s.stage_tab = ptr(self.stage_tab, np.int32) if self.stage_tab is not None else None
         if self.stage_rules:
             arr = (_abi.PhxStageRule * len(self.stage_rules))()
@@ -185,11 +186,11 @@ VARIANT_STEP = {"auto": _abi.VS_AUTO, "fused": _abi.VS_FUSED, "generic": _abi.VS
 
 
 def resolve_variants(variants) -> tuple:
-    """(variant_rollout, variant_block, variant_step, variant_flags) of phx_spec from the host-side dict; unknown names raise."""
+    """(variant_rollout, variant_block, variant_step) of phx_spec from the host-side dict; unknown names raise."""
     v = dict(variants or {})
-    unknown = set(v) - {"rollout", "block", "step", "flags"}
+    unknown = set(v) - {"rollout", "block", "step"}
     if unknown:
-        raise ValueError(f"unknown kernel-variant keys {sorted(unknown)} (rollout, block, step, flags)")
+        raise ValueError(f"unknown kernel-variant keys {sorted(unknown)} (rollout, block, step)")
 
     def pick(table, x, what):
         if isinstance(x, str):
@@ -200,8 +201,7 @@ def resolve_variants(variants) -> tuple:
 
     blk = v.get("block", 0)
     blk = _abi.VB_WHOLE_ENVS if blk == "whole_envs" else int(blk or 0)
-    return (pick(VARIANT_ROLLOUT, v.get("rollout", 0), "rollout"), blk, pick(VARIANT_STEP, v.get("step", 0), "step"),
-            pick({"auto": 0, "dense": 1, "sparse": 2}, v.get("flags", 0), "flags"))
+    return (pick(VARIANT_ROLLOUT, v.get("rollout", 0), "rollout"), blk, pick(VARIANT_STEP, v.get("step", 0), "step"))
 
 
 def _max_emissions(kind: int, deg: int) -> int:

@@ -29,7 +29,7 @@ class OracleShardDev:
     def alloc_trajectory(self, T, **kw):
         return DeviceEnv.alloc_trajectory(self, T, **kw)
 
-    def rollout(self, T, actions=None, exo=None, out=None, flags_zeroed=False):
+    def rollout(self, T, actions=None, exo=None, out=None):
         r = self.o.rollout(T)
         if out is None:
             out = self.alloc_trajectory(T)

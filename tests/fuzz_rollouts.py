@@ -37,7 +37,7 @@ def run_rollout_case(case, journal=None):
         vrng = np.random.default_rng(case + 10_000_019)
         variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general", "store_waves", "store_waves"])),
                     "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36, 96, 144, 128][int(vrng.integers(0, 11))],
-                    "flags": ["auto", "dense", "sparse", "sparse"][int(vrng.integers(0, 4))]}
+                    }
         env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
                                variants=variants)
         fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")

@@ -155,9 +155,6 @@ PLAIN_VARIANTS = [
     ({"rollout": "time_parallel", "block": 16}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"rollout": "time_parallel", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     ({"rollout": "time_parallel"}, "phx_sc_rollout_fast_kernel"),
-    ({"rollout": "time_parallel", "flags": "sparse"}, "[flag planes]+phx_sc_rollout_fast_kernel"),   # (the streaming fill of the flag planes, then the kernel)
-    ({"rollout": "time_parallel", "flags": "sparse", "block": 32}, "[flag planes]+phx_sc_rollout_fast_kernel[pairs]"),
-    ({"rollout": "time_parallel", "flags": "dense", "block": 48}, "phx_sc_rollout_fast_kernel[pairs]"),
     # the round-4 store-wave kernel: the library's choice of workgroup, and 16 .. 144 pairs per workgroup
     ({}, "phx_sc_rollout_"),
     ({"rollout": "store_waves"}, "phx_sc_rollout_sw_kernel"),
@@ -646,7 +643,7 @@ def test_mt19937_streams_on_an_fsm_env_reproduce_the_seeded_reference_run(name):
 def test_rollout_graph_replays_the_same_fragments_as_rollout_calls():
     """DeviceEnv.rollout_graph: consecutive phx_rollout fragments captured once into a hipGraph; two replays give the fragments that
     the same sequence of rollout() calls gives (the time-parallel kernel, and the generic engine's T-step loop)."""
-    for kw in ({}, {"force_generic": True}, {"variants": {"flags": "sparse"}}):      # (sparse: the fill kernel inside the capture)
+    for kw in ({}, {"force_generic": True}, {"variants": {"rollout": "time_parallel"}}):
         ea = supply_chain_env(9, [6] * 9, 100, 64, seed=21, **kw)
         eb = supply_chain_env(9, [6] * 9, 100, 64, seed=21, **kw)
         for e in (ea, eb):
@@ -663,76 +660,22 @@ def test_rollout_graph_replays_the_same_fragments_as_rollout_calls():
                 np.testing.assert_array_equal(bufs[i].truncations.cpu().numpy(), tr.truncations.cpu().numpy())
 
 
-# ---- the RECORD layout of a trajectory (phx_rollout_io.records; VERDICT r2 item 2a: an opt-in layout with an indexer) ------------
-@pytest.mark.parametrize("variants", [{}, {"block": 32}, {"block": 16}, {"block": "whole_envs"}], ids=str)
-@pytest.mark.parametrize("S,K,B,num_steps", [(9, 6, 64, 100), (9, 6, 32, 23), (3, 2, 48, 40), (51, 4, 16, 100), (7, 3, 96, 30)])
-def test_record_layout_rollouts_match_oracle(S, K, B, num_steps, variants):
-    """alloc_trajectory(records=True): the time-parallel kernel writes one 24-byte record per (step, env, shop) -- obs[3], action,
-    reward, terminated, truncated, 2 pad bytes -- and the usual Trajectory fields are strided views of that buffer.  Ragged
-    fragment lengths, several episode ends per fragment, unaligned ticks, poked stocks: every view equals the oracle's plane, and
-    the env's state after the fragment equals the oracle's.  Envs / kernels that cannot serve the layout refuse."""
-    env = supply_chain_env(S, [K] * S, num_steps, B, seed=31 + S, env_offset=500, variants=variants)
-    o, d = OracleEnv(env.spec, threads=4), _dev(env.spec)
-    o.reset(); d.reset()
-    rng = np.random.default_rng(S * 10 + K)
-    for t in range(3):                                         # ticks no multiple of 4
-        a = rng.uniform(0, 100, (B, S)).astype(np.float32)
-        o.step(a, None, None); d.step(a, None, None)
-    dev = d.dev
-    if variants.get("block") == "whole_envs" and not any(c * S <= 96 and c * S >= 32 and B % c == 0 for c in range(4, 256, 4)):
-        pytest.skip("no whole-env workgroup shape for this env: the time-parallel kernel does not apply")
-    for T in (1, 7, 20, 41, 100, 3, 200):
-        tr = dev.alloc_trajectory(T, records=True)
-        tr.records.fill_(0xA5)
-        dev.rollout(T, out=tr)
-        assert "records" in dev.last_kernel(), dev.last_kernel()
-        ro = o.rollout(T)
-        np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]), err_msg=f"obs T={T}")
-        np.testing.assert_array_equal(f32_bits(tr.actions.cpu().numpy()), f32_bits(ro["actions"]), err_msg=f"actions T={T}")
-        np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]), err_msg=f"rewards T={T}")
-        np.testing.assert_array_equal(tr.truncations.cpu().numpy(), ro["truncated"]); np.testing.assert_array_equal(tr.terminations.cpu().numpy(), ro["terminated"])
-        np.testing.assert_array_equal(f32_bits(tr.last_obs.cpu().numpy()), f32_bits(ro["last_obs"]))
-        assert int(tr.records[..., 22:].max()) == 0            # the pad bytes are written (zero), not left behind
-        for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
-            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} after T={T}")
-    st = rng.integers(-40, 160, (B, S)).astype(np.int32)
-    o.set_i32("shop.stock", st); d.set_i32("shop.stock", st)
-    tr = dev.alloc_trajectory(20, records=True); dev.rollout(20, out=tr); ro = o.rollout(20)
-    np.testing.assert_array_equal(f32_bits(tr.observations.cpu().numpy()), f32_bits(ro["obs"]))
-    np.testing.assert_array_equal(f32_bits(tr.rewards.cpu().numpy()), f32_bits(ro["rewards"]))
-
-
-def test_record_layout_is_refused_where_no_kernel_serves_it():
-    from phantom_amd.device import DeviceError
-    envf = supply_chain_env(9, [6] * 9, 100, 16, fsm=True)
-    with pytest.raises(DeviceError):
-        _dev(envf.spec).dev.alloc_trajectory(10, records=True)
-    envg = supply_chain_env(9, [6] * 9, 100, 16, force_generic=True)
-    dg = _dev(envg.spec); dg.reset()
-    with pytest.raises(DeviceError):
-        dg.dev.rollout(10, out=dg.dev.alloc_trajectory(10, records=True))
-
-
 def test_bench_shape_fragment_sparse_flags_equal_dense_and_oracle_rows():
-    """The bench's launch shape (SC64, B = 4096, T = 400).  Round 3's kernel: the flag planes go out as one fill + the non-zero words by
-    default at this size, against the same kernel storing every flag word; round 4: the library's own choice for this shape is the
-    store-wave kernel (144 pairs per workgroup, one workgroup per CU, dense flags from its store waves) -- every plane of the three
+    """Round 4's bench launch shape (SC64, B = 4096, T = 400).  Round 3's kernel: the flag planes go out as one fill + the non-zero words
+    at this size; round 4: the library's own choice for this shape is the
+    store-wave kernel (144 pairs per workgroup, one workgroup per CU, dense flags from its store waves) -- every plane of the two
     bit-equal -- and the first episode's rows against the oracle."""
     import torch
     B, S, T = 4096, 9, 400
     ea = supply_chain_env(S, [6] * S, 100, B, seed=42, variants={"rollout": "time_parallel"})      # round-3 kernel: sparse at this size
-    eb = supply_chain_env(S, [6] * S, 100, B, seed=42, variants={"rollout": "time_parallel", "flags": "dense"})
     ec = supply_chain_env(S, [6] * S, 100, B, seed=42)                                             # the library's choice
-    for e in (ea, eb, ec):
+    for e in (ea, ec):
         e.reset()
     ta = ea._device().rollout(T)
     assert "phx_zero_fill_kernel[flag planes]" in ea._device().last_kernel()      # (the calling thread's LAST call)
-    tb = eb._device().rollout(T)
-    assert "fill" not in eb._device().last_kernel()
     tc = ec._device().rollout(T)
     assert ec._device().last_kernel() == "phx_sc_rollout_sw_kernel"
-    for name, x, y, z in zip(ta._fields[:6], ta[:6], tb[:6], tc[:6]):
-        assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8)), name
+    for name, x, z in zip(ta._fields[:6], ta[:6], tc[:6]):
         assert torch.equal(x.contiguous().view(torch.uint8), z.contiguous().view(torch.uint8)), name
     for f in ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick"):
         assert torch.equal(ea._device().field(f), ec._device().field(f)), f
@@ -753,33 +696,3 @@ def test_bench_shape_fragment_sparse_flags_equal_dense_and_oracle_rows():
     np.testing.assert_array_equal(ta.truncations[:100].cpu().numpy(), ro["truncated"])
 
 
-def test_rollout_with_flags_zeroed_by_the_caller_equals_the_in_line_fill():
-    """PHX_RH_FLAGS_ZEROED: a collection loop zeroes the next buffer's flag planes itself (DeviceEnv.zero_flags, e.g. on a side stream)
-    and phx_rollout skips its own fill; the fragments equal those of plain rollout calls.  Kernels that store every flag word ignore
-    the hint (a buffer full of garbage still comes out right)."""
-    import torch
-    for variants, T in (({"flags": "sparse"}, 57), ({"flags": "dense"}, 57), ({"rollout": "time_parallel"}, 300), ({}, 300)):
-        ea = supply_chain_env(9, [6] * 9, 100, 64 if T < 100 else 4096, seed=5, variants=variants)
-        eb = supply_chain_env(9, [6] * 9, 100, 64 if T < 100 else 4096, seed=5, variants=variants)
-        for e in (ea, eb):
-            e.reset()
-        da, db = ea._device(), eb._device()
-        side = torch.cuda.Stream()
-        bufs = [db.alloc_trajectory(T) for _ in range(2)]
-        for b in bufs:
-            b.truncations.fill_(7); b.terminations.fill_(7)
-        main = torch.cuda.current_stream()
-        db.zero_flags(bufs[0])
-        for i in range(4):
-            cur, nxt = bufs[i % 2], bufs[(i + 1) % 2]
-            e0, e1 = torch.cuda.Event(), torch.cuda.Event()
-            e0.record(main); side.wait_event(e0)
-            with torch.cuda.stream(side):
-                if variants.get("flags") != "dense":
-                    db.zero_flags(nxt)
-                e1.record(side)
-            db.rollout(T, out=cur, flags_zeroed=True)
-            ref = da.rollout(T)
-            for name in ("observations", "rewards", "truncations", "terminations"):
-                assert torch.equal(getattr(cur, name), getattr(ref, name)), (variants, i, name)
-            main.wait_event(e1)

@@ -531,9 +531,9 @@ def test_kernel_variant_names_resolve_to_the_header_constants():
     from phantom_amd.spec import resolve_variants
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "phantom_amd.h")).read()
     const = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (PHX_V[RSB]_[A-Z_]+)\s+\(?(-?\d+)\)?", hdr)}
-    assert resolve_variants(None) == (0, 0, 0, 0)
-    assert resolve_variants({"rollout": "store_waves", "block": 144, "step": "wide", "flags": "dense"}) == \
-        (const["PHX_VR_STORE_WAVES"], 144, const["PHX_VS_WIDE"], 1)
+    assert resolve_variants(None) == (0, 0, 0)
+    assert resolve_variants({"rollout": "store_waves", "block": 144, "step": "wide"}) == \
+        (const["PHX_VR_STORE_WAVES"], 144, const["PHX_VS_WIDE"])
     assert resolve_variants({"rollout": "time_parallel", "block": "whole_envs"})[:2] == (const["PHX_VR_TIME_PARALLEL"], const["PHX_VB_WHOLE_ENVS"])
     assert resolve_variants({"step": "generic"})[2] == const["PHX_VS_GENERIC"] == _abi.VS_GENERIC
     for bad in ({"rolout": "auto"}, {"rollout": "store-waves"}, {"step": "wider"}):
