@@ -229,6 +229,43 @@ def other_configs(device):
     add("SC256 B=8192 per GPU (config 4)", 256, 8192, 400, timed(lambda: dev.rollout_fragments(100, fr), 16),
         "fused rollout, 4 fragments of T=100 per call (phx_rollout_io.frags)", bytes_per_env_step=22 * 51)
     del env, dev, tr, tr4, fr; torch.cuda.empty_cache()
+    # BASELINE config 2's env with a RECORDED policy and recorded order sizes (phx_rollout_io.actions / exo: a learned policy's actions
+    # replayed, the reference's numpy stream): the store-wave kernel's REPLAY instantiation + the pre-scan of the call's actions
+    env = ph.SupplyChainEnv(n_shops=9, customers_per_shop=6, num_steps=100, batch_size=4096, seed=42, exogenous="device", device=device)
+    env.reset(); dev = env._device()
+    Tr = 400
+    acts_r = (torch.rand(Tr, 4096, 9, device=dev.device) * 100.0).contiguous()
+    exo_r = torch.randint(0, 5, (Tr, 4096, 54), dtype=torch.uint8, device=dev.device)
+    trr = [dev.alloc_trajectory(Tr) for _ in range(2)]
+    kr = [0]
+
+    def replay(a_, x_):
+        dev.rollout(Tr, a_, x_, out=trr[kr[0] & 1]); kr[0] += 1
+    add("SC64 B=4096 (config 2), replayed actions", 64, 4096, Tr, timed(lambda: replay(acts_r, None), 30), f"fused rollout T={Tr}, phx_rollout_io.actions",
+        bytes_per_env_step=26 * 9)                               # the 22-byte record + the action read
+    res[-1]["kernels"] = dev.last_kernel()
+    add("SC64 B=4096 (config 2), replayed actions + order sizes", 64, 4096, Tr, timed(lambda: replay(acts_r, exo_r), 30),
+        f"fused rollout T={Tr}, phx_rollout_io.actions + exo", bytes_per_env_step=26 * 9 + 54)
+    res[-1]["kernels"] = dev.last_kernel()
+    del env, dev, trr, acts_r, exo_r; torch.cuda.empty_cache()
+    # an FSM supply chain whose RESTOCK handler branches on the shops' total stock, declared in rule form (phx_spec.stage_rules, ABI 9):
+    # the message-passing engine evaluates the rule inside the step -- no host callback, and rollouts run in one launch
+    try:
+        def restock(env_):                                       # the Python handler (fsm.py:294-307): the definition the rule is checked against
+            env_.resolve_network()
+            tot = sum(np.asarray(a_.stock) for aid, a_ in env_.agents.items() if str(aid).startswith("SHOP"))
+            return np.where(tot < 300, "RESTOCK", "SELL").tolist()
+        handler = ph.state_rules([ph.StageRule("shop.stock", "<", 300, "RESTOCK")])(restock)
+        env = ph.SupplyChainFSMEnv(n_shops=9, customers_per_shop=6, num_steps=100, batch_size=4096, seed=42, exogenous="device", device=device,
+                                   restock_handler=handler)
+        env.reset(); dev = env._device()
+        acts = torch.rand(4096, 9, device=dev.device) * 100.0
+        add("SC64 FSM B=4096, state-dependent handler in rule form", 64, 4096, 1, timed(lambda: dev.step(acts), 60), "one launch per step (generic engine, rule evaluated on the device)")
+        tr = dev.rollout(50)
+        add("SC64 FSM B=4096, state-dependent handler in rule form", 64, 4096, 50, timed(lambda: dev.rollout(50, out=tr), 4), "rollout T=50, T-step loop in the kernel")
+        del env, dev, tr, acts; torch.cuda.empty_cache()
+    except Exception as exc:                                     # report, do not hide
+        res.append({"config": "SC64 FSM rule-form handler", "error": str(exc)[:300]})
     # config 5: Stackelberg market 128 leaders / 1024 followers, B = 4096
     env = market_env(128, 1024, 8, 100, 4096, exogenous="device", device=device)
     env.reset(); dev = env._device()
