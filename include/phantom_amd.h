@@ -316,7 +316,8 @@ typedef struct phx_step_io {
 } phx_step_io;
 
 /* ---- fused on-device rollout: T consecutive steps per launch, auto-reset at episode end.
- * Every buffer must be 16-byte aligned (the kernels write 16-byte pieces); phx_rollout returns PHX_EINVAL otherwise. */
+ * Every OUTPUT buffer must be 16-byte aligned (the kernels write 16-byte pieces); phx_rollout returns PHX_EINVAL otherwise.  The replayed
+ * inputs are read one element at a time: `actions` 4-byte aligned, `exo` any address (a row slice of a longer recording is fine). */
 /* (ABI 9 removed three experimental pieces of ABI 7-8 that every measurement since had left behind: the PHX_RH_FLAGS_ZEROED hint, the
  *  24-byte record layout phx_rollout_io.records and phx_spec.variant_flags -- DESIGN_HISTORY.md has their numbers.)                   */
 /* ABI 9: one trajectory fragment of a launch that writes SEVERAL (phx_rollout_io.frags): the planes of phx_rollout_io, each

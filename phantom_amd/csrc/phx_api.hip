@@ -1153,7 +1153,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
       const void* bufs[] = {fr.obs, fr.action_out, fr.reward, fr.terminated, fr.truncated, fr.obs_valid, fr.reward_valid};
       for (const void* p : bufs) if (((uintptr_t)p & 15u) != 0) return fail(PHX_EINVAL, "phx_rollout: every buffer must be 16-byte aligned");
     }
-    if (((uintptr_t)io->last_obs & 15u) || ((uintptr_t)io->actions & 15u) || ((uintptr_t)io->exo & 15u)) return fail(PHX_EINVAL, "phx_rollout: every buffer must be 16-byte aligned");
+    if (((uintptr_t)io->last_obs & 15u) || ((uintptr_t)io->actions & 3u)) return fail(PHX_EINVAL, "phx_rollout: every output buffer must be 16-byte aligned (replayed actions: 4-byte)");
     const int Tf = io->T / io->n_frag;
     // ONE launch where the store-wave supply-chain kernel serves the env (its store waves switch planes at the fragments' first rows) ...
     if (e->use_fused && e->d.env_type == PHX_ENV_PLAIN && !e->d.any_typed && e->d.sc_fast.ok && e->d.sc_sw.ok && !io->actions && !io->exo && !io->msg_log && !io->msg_count &&
@@ -1190,10 +1190,11 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if ((io->msg_log || io->msg_count) && (e->d.trace_cap <= 0 || !io->msg_log || !io->msg_count))
     return fail(PHX_EINVAL, "rollout message log needs trace_cap > 0 and both msg_log and msg_count");
   {                                   // the rollout kernels write 16-byte pieces
-    const void* bufs[] = {io->obs, io->action_out, io->reward, io->terminated, io->truncated, io->obs_valid, io->reward_valid,
-                          io->last_obs, io->actions, io->exo};
+    const void* bufs[] = {io->obs, io->action_out, io->reward, io->terminated, io->truncated, io->obs_valid, io->reward_valid, io->last_obs};
     for (const void* p : bufs)
-      if (((uintptr_t)p & 15u) != 0) return fail(PHX_EINVAL, "phx_rollout: every buffer must be 16-byte aligned");
+      if (((uintptr_t)p & 15u) != 0) return fail(PHX_EINVAL, "phx_rollout: every output buffer must be 16-byte aligned");
+    // (the replayed inputs are read one float / one byte at a time: a row slice of a longer recording is fine whatever B S is)
+    if (((uintptr_t)io->actions & 3u) != 0) return fail(PHX_EINVAL, "phx_rollout: `actions` must be 4-byte aligned");
   }
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");

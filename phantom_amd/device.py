@@ -453,7 +453,7 @@ class DeviceEnv:
                 raise ValueError(f"rollout: `{name}` is required for this env")
             if x.dtype != dtype or x.device != self.device or not x.is_contiguous():
                 raise ValueError(f"rollout: `{name}` must be a contiguous {dtype} tensor on {self.device}")
-            if x.data_ptr() % 16:
+            if x.data_ptr() % (16 if name.startswith("out.") else x.element_size()):
                 raise ValueError(f"rollout: `{name}` must start on a 16-byte boundary (a view at an odd offset?)")
             if tuple(x.shape[1:]) != tuple(tail) or (lead is not None and x.shape[0] != lead) \
                     or (lead is None and x.shape[0] < T):
@@ -549,8 +549,8 @@ class DeviceEnv:
             torch = _torch()
             for name, x, tail in (("actions", actions, (self.B, self.S)), ("exo", exo, (self.B, self.n_exo))):
                 if x is not None and (tuple(x.shape) != (k * T,) + tail or not x.is_contiguous() or x.device != self.device
-                                      or x.dtype != (torch.float32 if name == "actions" else torch.uint8) or x.data_ptr() % 16):
-                    raise ValueError(f"rollout_fragments: `{name}` must be a contiguous, 16-byte aligned [{k * T}, {tail[0]}, {tail[1]}] tensor on {self.device}")
+                                      or x.dtype != (torch.float32 if name == "actions" else torch.uint8)):
+                    raise ValueError(f"rollout_fragments: `{name}` must be a contiguous [{k * T}, {tail[0]}, {tail[1]}] tensor on {self.device}")
             arr = (_abi.PhxRolloutFrag * k)()
             for i, o in enumerate(outs):
                 arr[i].obs, arr[i].action_out, arr[i].reward = ptr(o.observations), ptr(o.actions), ptr(o.rewards)

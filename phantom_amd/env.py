@@ -446,9 +446,9 @@ class PhantomEnv:
         done, ep = 0, ep0
         while done < T:
             n = min(T - done, N - cur)
-            # (a slice of the caller's tensor may start off a 16-byte boundary -- B * S * 4 or B * n_exo not a multiple of 16 -- which
-            #  phx_rollout refuses: such a piece is replayed from an aligned copy)
-            piece = lambda x: None if x is None else (x[done:done + n] if x[done:done + n].data_ptr() % 16 == 0 else x[done:done + n].clone())
+            # (a slice of the caller's tensor may start off a 16-byte boundary -- B * S * 4 or B * n_exo not a multiple of 16: fine since
+            #  ABI 9, the replayed inputs are read element by element)
+            piece = lambda x: None if x is None else x[done:done + n]
             tr = self.rollout(n, piece(actions), piece(exo))
             sl = slice(done, done + n)
             new_obs[sl], act[sl], rew[sl], term[sl], trunc[sl] = tr.observations, tr.actions, tr.rewards, tr.terminations, tr.truncations

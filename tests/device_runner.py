@@ -81,6 +81,20 @@ class DeviceRunner:
                     obs_valid=None if tr.obs_valid is None else tr.obs_valid.cpu().numpy(),
                     reward_valid=None if tr.reward_valid is None else tr.reward_valid.cpu().numpy())
 
+    def rollout_fragments(self, Tf, k, actions=None, exo=None):
+        """k fragments of Tf rows from ONE phx_rollout call (phx_rollout_io.frags), concatenated like one k Tf-step rollout"""
+        a = None if actions is None else self._t(actions, np.float32)
+        x = None if exo is None else self._t(exo, np.uint8)
+        outs = [self.dev.alloc_trajectory(Tf) for _ in range(k)]
+        self.dev.rollout_fragments(Tf, outs, a, x)
+        if getattr(self, "on_launch", None) is not None:
+            self.on_launch(self.dev.last_kernel())
+        self.err = self.dev.err.cpu().numpy()
+        cat = lambda f: None if getattr(outs[0], f) is None else torch.cat([getattr(o, f) for o in outs]).cpu().numpy()
+        return dict(obs=cat("observations"), actions=cat("actions"), rewards=cat("rewards"), terminated=cat("terminations"),
+                    truncated=cat("truncations"), last_obs=outs[-1].last_obs.cpu().numpy(), obs_valid=cat("obs_valid"),
+                    reward_valid=cat("reward_valid"))
+
     def get_i32(self, field):
         return self.dev.field(field).cpu().numpy().reshape(self.B, -1)
 

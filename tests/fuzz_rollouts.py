@@ -32,6 +32,8 @@ def run_rollout_case(case, journal=None):
         K = int(rng.integers(1, 7))
         Ks = [K] * S if rng.random() < 0.8 else [int(rng.integers(1, 9)) for _ in range(S)]
         B = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 20, 32, 48, 64]))
+        if np.random.default_rng(case + 30_000_001).random() < 0.04:       # round 5: launches of more pair groups than resident workgroups
+            B = int(np.random.default_rng(case + 30_000_001).choice([128, 256, 512]))
         ns = int(rng.choice([1, 2, 5, 19, 20, 21, 40, 57, 100]))
         # a kernel variant drawn from the seed (phx_spec.variant_*; ignored where its preconditions do not hold)
         vrng = np.random.default_rng(case + 10_000_019)
@@ -69,11 +71,29 @@ def run_rollout_case(case, journal=None):
             st[b] = int(prng.integers(-30, ns + 10))
         o.set_i32("env.step", st); dv.set_i32("env.step", st)
     n = 0
+    xrng = np.random.default_rng(case + 40_000_007)             # round 5: fragment lists (ABI 9) and replayed policies / order sizes
     for _ in range(int(rng.integers(1, 4))):
         T = int(rng.choice([1, 2, 3, 7, 19, 20, 21, 39, 41, 64, 100, 130, 200, 257]))
+        mode = xrng.random()
+        acts = exo = None
+        if kind < 8 and not fsm and xrng.random() < 0.3:         # a recorded policy and / or recorded draws (plain supply chains)
+            which = int(xrng.integers(0, 3))
+            if which != 1:
+                acts = xrng.uniform(0, 140, (T, B, env.spec.n_strategic)).astype(np.float32)
+                acts[xrng.random(acts.shape) < 0.05] = 0.5
+                if xrng.random() < 0.15:                         # (a call with an action that rounds below zero: round 1's kernel, and the
+                    acts[int(xrng.integers(0, T)), int(xrng.integers(0, B)), 0] = -3.0   # stock may go negative -- the oracle's too)
+            if which != 0 and dv.n_exo:
+                exo = xrng.integers(0, 5, (T, B, dv.n_exo)).astype(np.uint8)
+        k = int(xrng.choice([2, 3, 4, 8])) if (mode < 0.25 and T >= 4) else 1
         if journal:
-            journal(f"case {case}: rollout T={T}")
-        ro, rd = o.rollout(T), dv.rollout(T)
+            journal(f"case {case}: rollout T={T} frags={k} replay={'a' if acts is not None else ''}{'x' if exo is not None else ''}")
+        if k > 1:
+            Tf = max(1, T // k); T = Tf * k
+            acts = None if acts is None else acts[:T]; exo = None if exo is None else exo[:T]
+            ro, rd = o.rollout(T, acts, exo), dv.rollout_fragments(Tf, k, acts, exo)
+        else:
+            ro, rd = o.rollout(T, acts, exo), dv.rollout(T, acts, exo)
         _cmp(rd, ro, valid)
         for f in fields:
             np.testing.assert_array_equal(dv.get_i32(f), o.get_i32(f), err_msg=f"case {case}: {f} after T={T}")
