@@ -42,3 +42,25 @@ env = ph.SupplyChainEnv(n_shops=3, customers_per_shop=4, batch_size=1024, typed=
                         agent_supertypes={f"SHOP{i}": ph.TypedShopAgent.Supertype(weights) for i in range(3)})
 env.reset()
 print("typed shops: obs dim", env.spec.obs_dim, "weights of env 0..3", env["SHOP0"].type.excess_stock_weight[:4])
+
+# 5. (ABI 9) eight one-episode fragments in separate buffers from ONE call: what a learner that takes 100-step fragments asks for
+env = ph.SupplyChainEnv(n_shops=9, customers_per_shop=6, batch_size=4096, seed=42, exogenous="device")
+env.reset()
+dev = env._device()
+bufs = [dev.alloc_trajectory(100) for _ in range(8)]
+dev.rollout_fragments(100, bufs)
+print("fragment list:", len(bufs), "x", tuple(bufs[0].observations.shape), "from", dev.last_kernel(),
+      "| episode ends per fragment", [int(b.truncations[:, :, 0].sum()) for b in bufs][:3], "...")
+
+# 6. (ABI 9) an FSM stage handler that branches on agent state, declared in rule form: the Python handler is the definition (checked
+#    against the rule on random states when the device env is created), the device evaluates the rule inside step() and rollout()
+def restock_again_while_stock_is_low(e):
+    e.resolve_network()
+    total = sum(np.asarray(a.stock) for aid, a in e.agents.items() if str(aid).startswith("SHOP"))
+    return np.where(total < 60, "RESTOCK", "SELL").tolist()
+
+handler = ph.state_rules([ph.StageRule("shop.stock", "<", 60, "RESTOCK")])(restock_again_while_stock_is_low)
+env = ph.SupplyChainFSMEnv(n_shops=3, customers_per_shop=2, num_steps=20, batch_size=256, seed=1, exogenous="device", restock_handler=handler)
+env.reset()
+tr = env.rollout(40)
+print("rule-form FSM handler: rollout in one launch,", env._device().last_kernel(), "| stages now:", sorted(set(env.current_stage)))

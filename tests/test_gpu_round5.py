@@ -461,3 +461,44 @@ def test_rule_form_handlers_through_the_python_surface_and_their_check_against_t
     env2 = supply_chain_env(3, [2, 3, 1], 12, 16, fsm=True, seed=5, restock_handler=bad)
     with pytest.raises(ph.FSMValidationError):
         env2._device()
+
+
+@pytest.mark.parametrize("first", [0, 20])
+def test_random_rule_tables_on_random_fsm_supply_chains_match_the_oracle(first):
+    """Random rule-form RESTOCK handlers -- one to three rules over stock / sales / missed_sales / delivered_stock of one shop or summed
+    over the shops, every comparison, thresholds around what the field reaches -- on random FSM supply chains: per-step launches and a
+    rollout (the engine's T-step loop) against the oracle, stage by stage."""
+    import phantom_amd as ph
+    for case in range(first, first + 20):
+        rng = np.random.default_rng(50_000 + case)
+        S = int(rng.choice([1, 2, 3, 5, 9, 17, 51, 70])); K = int(rng.integers(1, 7))
+        B = int(rng.choice([1, 3, 8, 32])); ns = int(rng.choice([5, 12, 30]))
+        rules = []
+        for _ in range(int(rng.integers(1, 4))):
+            field = str(rng.choice(["shop.stock", "shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock"]))
+            agent = None if rng.random() < 0.5 else f"SHOP{int(rng.integers(0, S))}"
+            scale = {"shop.stock": 60, "shop.sales": 2.5 * K, "shop.missed_sales": 1.5 * K, "shop.delivered_stock": 40}[field] * (S if agent is None else 1)
+            thr = float(np.rint(rng.uniform(0, 1.3 * scale))) + (0.5 if rng.random() < 0.2 else 0.0)
+            rules.append(ph.StageRule(field, str(rng.choice(["<", "<=", ">", ">=", "==", "!="])), thr,
+                                      str(rng.choice(["RESTOCK", "SELL"])), agent=agent))
+        handler = ph.state_rules(rules)(lambda env: None)
+        env = supply_chain_env(S, [K] * S, ns, B, fsm=True, seed=case, restock_handler=handler)
+        env._rules_checked = True                              # (placeholder handler: the spec is under test)
+        o, d = OracleEnv(env.spec, threads=4), DeviceRunner(env.spec)
+        o.reset(); d.reset()
+        for t in range(ns + 3):
+            a = rng.uniform(0, 100, (B, S)).astype(np.float32)
+            o.step(a, None, None); d.step(a, None, None)
+            np.testing.assert_array_equal(d.get_i32("env.stage"), o.get_i32("env.stage"), err_msg=f"case {case} {rules} stage after step {t}")
+            np.testing.assert_array_equal(d.obs_valid, o.obs_valid); np.testing.assert_array_equal(d.reward_valid, o.reward_valid)
+            np.testing.assert_array_equal(d.get_i32("shop.stock"), o.get_i32("shop.stock"))
+            if o.all_truncated.any():
+                mm = o.all_truncated.astype(np.uint8); o.reset(mm); d.reset(mm)
+        T = int(rng.integers(3, 2 * ns + 4))
+        rd, ro = d.rollout(T), o.rollout(T)
+        np.testing.assert_array_equal(rd["obs_valid"], ro["obs_valid"], err_msg=f"case {case} {rules}")
+        np.testing.assert_array_equal(rd["reward_valid"], ro["reward_valid"])
+        m = ro["obs_valid"].astype(bool)
+        np.testing.assert_array_equal(f32_bits(rd["obs"][m]), f32_bits(ro["obs"][m]))
+        np.testing.assert_array_equal(d.get_i32("env.stage"), o.get_i32("env.stage"))
+        assert (d.err == 0).all() and (o.err == 0).all()

@@ -16,7 +16,6 @@ ap.add_argument("--tag", default="")
 ap.add_argument("--bufs", type=int, default=0, help="trajectory buffers rotated over (0: enough for > 320 MB)")
 ap.add_argument("--block", default="0", help="variants['block']: pairs per workgroup, whole_envs, or 0 = auto")
 ap.add_argument("--rollout", default="auto", help="variants['rollout']")
-ap.add_argument("--tblock", type=int, default=0, help="phx_rollout_io.t_block (0 / 1: time-major)")
 ap.add_argument("--frags", type=int, default=1, help="fragments of T rows per call (phx_rollout_io.frags)")
 a = ap.parse_args()
 cls = ph.SupplyChainFSMEnv if a.fsm else ph.SupplyChainEnv
@@ -27,8 +26,7 @@ env.reset(); dev = env._device()
 S = a.shops
 alg = a.batch * a.T * 22 * S + a.batch * (S * 32 + 16)
 nb = a.bufs or max(2, -(-(320 << 20) // alg))
-kw = {"t_block": a.tblock} if a.tblock else {}
-trs = [dev.alloc_trajectory(a.T, **kw) for _ in range(nb)]
+trs = [dev.alloc_trajectory(a.T) for _ in range(nb)]
 tr = dev.rollout(a.T, out=trs[0])
 torch.cuda.synchronize()
 h = hashlib.sha1()
