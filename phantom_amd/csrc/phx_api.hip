@@ -663,6 +663,7 @@ extern "C++" const DevKnobs& phx_knobs() {
     k.fsm_fast = rd("PHX_FSM_FAST", -1);             // -1: unset; 0 off; 2 forces it at any batch size
     k.fsm_lean = rd("PHX_FSM_LEAN", 1);
     k.fsm_wide = rd("PHX_FSM_WIDE", 1);
+    k.fsm_batch = rd("PHX_FSM_BATCH", 1);
     k.generic_nt = rd("PHX_GENERIC_NT", 0);
     k.generic_remap = rd("PHX_GENERIC_REMAP", 1);
     k.generic_tablds = rd("PHX_GENERIC_TABLDS", 1);

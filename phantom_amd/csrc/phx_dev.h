@@ -56,6 +56,7 @@ struct DevKnobs {
   int fsm_fast;                // PHX_FSM_FAST (default -1 = unset; 0: off; 2: forced at any batch size)
   int fsm_lean;                // PHX_FSM_LEAN (default 1)
   int fsm_wide;                // PHX_FSM_WIDE (default 1)
+  int fsm_batch;               // PHX_FSM_BATCH (default 1): the lean FSM rollout loop stores four steps per batch as 16-byte pieces
   int generic_nt;              // PHX_GENERIC_NT (default 0)
   int generic_remap;           // PHX_GENERIC_REMAP (default 1)
   int generic_tablds;          // PHX_GENERIC_TABLDS (default 1)

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                        const int epb, const int remap, const uint32_t pK,
                                                                        const float inv_pK, const int wide, const int32_t* only_if, const int32_t gen,
-                                                                       const int pairs) {
+                                                                       const int pairs, const int batch) {
   // `pairs`: a block owns SC_NT CONSECUTIVE (env, shop) PAIRS instead of `epb` whole envs.  Every row segment a block writes
   // is then whole 128-byte lines of the f32 planes and whole 64-byte pieces of the u8 planes, every lane is active (4 envs
   // of 51 shops filled 204 of 256), and the launch no longer depends on WHERE the trajectory buffers lie: the partially
@@ -786,6 +786,15 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
   // 16-byte pieces through a wave-private LDS tile -- with its stores removed this loop takes 125 of 242 us, so the
   // memory system's cost per store instruction (three 4-byte stores at a 12-byte lane stride) is what it pays for
   float* s_ot = (float*)(s_next + ((nL + 3) & ~3)) + (threadIdx.x >> 6) * 192;
+  // `batch` (round 5; blocks of consecutive pairs, B S a multiple of 16): a full wave keeps FOUR steps' outputs in a wave-private LDS
+  // tile -- observations [4][64][3] f32, rewards and actions [4][64] f32, the four u8 planes [4][4][64] -- and writes them as 16-byte
+  // pieces: 3 + 1 + 1 + 1 store instructions per wave and four steps instead of 4 x (0.75 + 1 + 1 + 4).  The loop is bound by what
+  // the memory system charges per store INSTRUCTION (with its stores removed it takes 125 of 213-244 us at config 3), not per byte.
+  // (the tile starts on a 16-byte boundary and is addressed in whole 16-byte elements from the start of the LDS where it is read as
+  //  pieces, so that the compiler emits ds_read_b128)
+  const uint32_t bt_off = ((uint32_t)((const unsigned char*)((float*)(s_next + ((nL + 3) & ~3)) + (SC_NT / 64) * 192) - s_raw) + 15u) & ~15u;
+  unsigned char* const s_bt = s_raw + bt_off + (threadIdx.x >> 6) * 6144;
+  const float4* const s_bt4 = (const float4*)s_raw + ((bt_off >> 4) + (threadIdx.x >> 6) * 384);
   for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) s_fl[idx] = sp.sc_shop_flags[idx];
   for (int idx = threadIdx.x; idx < nL; idx += SC_NT) s_next[idx] = sp.stage_next[idx];
   if (threadIdx.x <= PHX_SHOP_MAX_STOCK) s_tabs[threadIdx.x] = (float)threadIdx.x / (float)PHX_SHOP_MAX_STOCK;
@@ -823,6 +832,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
   const int lanes_blk = pairs ? (int)((total - g0) < SC_NT ? (total - g0) : SC_NT) : (int)(b_end - b_first) * nS;
   const int n_wave = lanes_blk - (int)wave_off < 64 ? lanes_blk - (int)wave_off : 64;   // active lanes of this wave (a multiple of 4 when wide)
   const int n_pieces = (n_wave * 3) >> 2;
+  const int T4 = (batch && n_wave == 64) ? (io.T & ~3) : 0;                  // steps that leave in batches of four (uniform per wave)
 
   for (int t = 0; t < io.T; ++t) {
     const int64_t row = (int64_t)t * total + g0;                             // uniform over the block
@@ -858,7 +868,33 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
     } else if (observes) {                                                   // fsm.py:378
       ov = 1; rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
     }
-    if (wide) {
+    if (t < T4) {
+      const int lane = (int)(threadIdx.x & 63u), r = t & 3;
+      float* const to = (float*)(s_bt + r * 768);
+      to[lane * 3 + 0] = ob[0]; to[lane * 3 + 1] = ob[1]; to[lane * 3 + 2] = ob[2];
+      ((float*)(s_bt + 3072))[r * 64 + lane] = (float)rw;
+      ((float*)(s_bt + 4096))[r * 64 + lane] = action;
+      unsigned char* const tf = s_bt + 5120 + r * 64 + lane;                 // [plane][step][lane]
+      tf[0] = 0; tf[256] = (unsigned char)all_trunc; tf[512] = ov; tf[768] = rv;
+      if (r == 3) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // wave-private tile: no barrier
+        const int64_t row_b = (int64_t)(t - 3) * total + g0;                 // the batch's first row (uniform over the block)
+        const uint32_t utot = (uint32_t)total;                               // (4 total * 12 < 2^32: checked by the launcher)
+        char* const b_obs = (char*)(io.obs + row_b * 3) + (size_t)(wave_off * 12u);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                                        // 4 rows x 48 observation pieces
+          const uint32_t q = (uint32_t)lane + 64u * (uint32_t)k, rr = q / 48u, pc = q - 48u * rr;
+          *(float4*)(b_obs + (size_t)(rr * (utot * 12u) + pc * 16u)) = s_bt4[rr * 48u + pc];
+        }
+        const uint32_t rr4 = (uint32_t)lane >> 4, pc4 = (uint32_t)lane & 15u;   // 4 rows x 16 pieces of an f32 plane
+        *(float4*)((char*)(io.reward + row_b) + (size_t)(wave_off * 4u + rr4 * (utot * 4u) + pc4 * 16u)) = s_bt4[192u + rr4 * 16u + pc4];
+        *(float4*)((char*)(io.action_out + row_b) + (size_t)(wave_off * 4u + rr4 * (utot * 4u) + pc4 * 16u)) = s_bt4[256u + rr4 * 16u + pc4];
+        const uint32_t pl = (uint32_t)lane >> 4, qf = (uint32_t)lane & 15u, rrf = qf >> 2, pcf = qf & 3u;   // 4 planes x 4 rows x 4 pieces of a u8 plane
+        uint8_t* const fb = pl == 0 ? io.terminated : (pl == 1 ? io.truncated : (pl == 2 ? io.obs_valid : io.reward_valid));
+        *(float4*)((char*)(fb + row_b) + (size_t)(wave_off + rrf * utot + pcf * 16u)) = s_bt4[320u + pl * 16u + rrf * 4u + pcf];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // read before the next batch overwrites the tile
+      }
+    } else if (wide) {
       const int lane = (int)(threadIdx.x & 63u);
       s_ot[lane * 3 + 0] = ob[0]; s_ot[lane * 3 + 1] = ob[1]; s_ot[lane * 3 + 2] = ob[2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // wave-private tile: no barrier
@@ -869,11 +905,13 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_lean_kernel(const De
       float* po = (float*)(p_obs + (size_t)(lane_off * 12u));
       po[0] = ob[0]; po[1] = ob[1]; po[2] = ob[2];
     }
-    *(float*)(p_act + (size_t)(lane_off * 4u)) = action;
-    *(float*)(p_rew + (size_t)(lane_off * 4u)) = (float)rw;
-    *(uint8_t*)(p_ter + (size_t)lane_off) = 0; *(uint8_t*)(p_tru + (size_t)lane_off) = all_trunc;
-    if (io.obs_valid) *(uint8_t*)((char*)(io.obs_valid + row) + (size_t)lane_off) = ov;
-    if (io.reward_valid) *(uint8_t*)((char*)(io.reward_valid + row) + (size_t)lane_off) = rv;
+    if (t >= T4) {
+      *(float*)(p_act + (size_t)(lane_off * 4u)) = action;
+      *(float*)(p_rew + (size_t)(lane_off * 4u)) = (float)rw;
+      *(uint8_t*)(p_ter + (size_t)lane_off) = 0; *(uint8_t*)(p_tru + (size_t)lane_off) = all_trunc;
+      if (io.obs_valid) *(uint8_t*)((char*)(io.obs_valid + row) + (size_t)lane_off) = ov;
+      if (io.reward_valid) *(uint8_t*)((char*)(io.reward_valid + row) + (size_t)lane_off) = rv;
+    }
     lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2];
     prev_stage = stage; stage = s_next[stage];                               // fsm.py:355
     if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
@@ -971,8 +1009,8 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
       if (sp.S % 4 == 0) wide = (sp.B % epb == 0);
       else if ((SC_NT / sp.S) >= 4) { const int e4 = (SC_NT / sp.S) & ~3; if (sp.B % e4 == 0) { epb_l = e4; wide = 1; } }
     }
-    const size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (((size_t)sp.n_lists + 3) & ~(size_t)3) * 4 +
-                       (SC_NT / 64) * 192 * 4 + 16;
+    size_t lds = (104 + 32) * 4 + (((size_t)sp.n_lists * sp.S + 3) & ~(size_t)3) + (((size_t)sp.n_lists + 3) & ~(size_t)3) * 4 +
+                 (SC_NT / 64) * 192 * 4 + 16;
     phx_note_kernel(only_if ? "phx_sc_rollout_fsm_lean_kernel[if off-chain]" : "phx_sc_rollout_fsm_lean_kernel");
     // blocks of SC_NT consecutive pairs (whole lines per row segment, every lane active) unless the spec asks for whole envs
     // or the pair count is no multiple of 4 (the observation pieces of a wave)
@@ -980,8 +1018,13 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     const int pairs = (sp.variant_block != PHX_VB_WHOLE_ENVS && total % 4 == 0 && sp.f[F_ENV_ARRIVE]) ? 1 : 0;
     const unsigned grid = pairs ? (unsigned)((total + SC_NT - 1) / SC_NT) : (unsigned)((sp.B + epb_l - 1) / epb_l);
     if (pairs) wide = 1;
+    // four steps per store batch (16-byte pieces of every plane): blocks of consecutive pairs whose waves start on 16-pair boundaries,
+    // all four u8 planes present, 32-bit offsets within a batch's four rows
+    const int batch = (pairs && phx_knobs().fsm_batch && total % 16 == 0 && io.terminated && io.obs_valid && io.reward_valid && io.T >= 4 &&
+                       total * 48 < ((int64_t)1 << 32)) ? 1 : 0;
+    if (batch) lds += (size_t)(SC_NT / 64) * 6144 + 16;
     hipLaunchKernelGGL(phx_sc_rollout_fsm_lean_kernel, dim3(grid), dim3(SC_NT), lds, st, sp, io, epb_l, remap,
-                       pk, inv[sp.fsm_lean_K], wide, only_if, gen, pairs);
+                       pk, inv[sp.fsm_lean_K], wide, only_if, gen, pairs, batch);
     return hipGetLastError();
   }
   phx_note_kernel("phx_sc_rollout_fsm_kernel");

@@ -85,7 +85,7 @@ def run_rollout_case(case, journal=None):
                     acts[int(xrng.integers(0, T)), int(xrng.integers(0, B)), 0] = -3.0   # stock may go negative -- the oracle's too)
             if which != 0 and dv.n_exo:
                 exo = xrng.integers(0, 5, (T, B, dv.n_exo)).astype(np.uint8)
-        k = int(xrng.choice([2, 3, 4, 8])) if (mode < 0.25 and T >= 4) else 1
+        k = min(int(xrng.choice([2, 3, 4, 8])), T) if (mode < 0.25 and T >= 4) else 1      # (lease r05_1: T = 7 with 8 fragments was the generator's own invalid argument)
         if journal:
             journal(f"case {case}: rollout T={T} frags={k} replay={'a' if acts is not None else ''}{'x' if exo is not None else ''}")
         if k > 1:

@@ -476,7 +476,7 @@ def test_random_rule_tables_on_random_fsm_supply_chains_match_the_oracle(first):
         rules = []
         for _ in range(int(rng.integers(1, 4))):
             field = str(rng.choice(["shop.stock", "shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock"]))
-            agent = None if rng.random() < 0.5 else f"SHOP{int(rng.integers(0, S))}"
+            agent = None if rng.random() < 0.5 else ("SHOP" if S == 1 else f"SHOP{int(rng.integers(0, S))}")
             scale = {"shop.stock": 60, "shop.sales": 2.5 * K, "shop.missed_sales": 1.5 * K, "shop.delivered_stock": 40}[field] * (S if agent is None else 1)
             thr = float(np.rint(rng.uniform(0, 1.3 * scale))) + (0.5 if rng.random() < 0.2 else 0.0)
             rules.append(ph.StageRule(field, str(rng.choice(["<", "<=", ">", ">=", "==", "!="])), thr,
