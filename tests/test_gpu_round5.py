@@ -502,3 +502,21 @@ def test_random_rule_tables_on_random_fsm_supply_chains_match_the_oracle(first):
         np.testing.assert_array_equal(f32_bits(rd["obs"][m]), f32_bits(ro["obs"][m]))
         np.testing.assert_array_equal(d.get_i32("env.stage"), o.get_i32("env.stage"))
         assert (d.err == 0).all() and (o.err == 0).all()
+
+
+def test_fragment_list_without_the_terminations_plane():
+    """`terminated` left out of every fragment (the all-zero plane, phx_rollout_frag.terminated = NULL for all): the other planes equal the
+    oracle's rows, and the launch is still ONE store-wave launch."""
+    S, K, B, Tf, k = 9, 6, 64, 30, 3
+    env = supply_chain_env(S, [K] * S, 40, B, seed=8, variants={"rollout": "store_waves"})
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    outs = [d.dev.alloc_trajectory(Tf, terminations=False) for _ in range(k)]
+    d.dev.rollout_fragments(Tf, outs)
+    assert d.dev.last_kernel() == "phx_sc_rollout_sw_kernel"
+    ro = o.rollout(k * Tf)
+    for i, t in enumerate(outs):
+        assert t.terminations is None
+        _assert_rows(_planes(t), ro, i * Tf, (i + 1) * Tf, f"fragment {i}")
+    for f in STATE:
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
