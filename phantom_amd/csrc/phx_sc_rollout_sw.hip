@@ -331,7 +331,11 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       for (int h = 0; h < 4; ++h) {
         uint32_t yy = y[h];
         if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);  // the first K base-5 digits: y mod 5^K
+#ifdef SW_ABL_NODTAB     /* attribution of the LDS bank conflicts: the order sum by arithmetic instead of the byte gather (same value) */
+        D[h] = rp_exo ? Dx[h] : rng_digit_sum(yy, a.K, nullptr);
+#else
         D[h] = rp_exo ? Dx[h] : (int)s_dtab[yy];                         // the customers' order sizes summed, supply_chain.py:61-67
+#endif
       }
       const int i = __mul24(tla, G) + gl;
 #pragma unroll
@@ -448,7 +452,11 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
           o[3 * k] = *(const float*)(t_s + as_[k]);                     // encode_observation :124-134
           o[3 * k + 1] = *(const float*)(t_n + an_[k]);
           o[3 * k + 2] = *(const float*)(t_n + am_[k]);
+#ifdef SW_ABL_NORTAB     /* attribution: the reward as the f32 quotient (the same value, tests/test_host_logic.py) instead of the 8-copy table */
+          rw[k] = (float)((int)(ar_[k] >> 5) - 100) / 10.0f;
+#else
           rw[k] = *(const float*)(t_r + ar_[k]);                        // compute_reward :147, rounded once to f32
+#endif
         }
       } else {
 #pragma unroll
