@@ -617,6 +617,26 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   }
   };
 
+  // ---- REPLAY: the store waves TOUCH the replayed rows of the chunk the workers will draw two iterations from now -- one word per 64-byte
+  //      line, consumed (xor-ed into a word nobody reads) an iteration later, when it has long landed -- so that the workers' own loads
+  //      find the lines in the L2 instead of paying an HBM round trip under full write pressure once per draw pass
+  uint32_t pf_acc = 0, pf_a = 0, pf_x = 0;
+  auto touch_inputs = [&](int c) __attribute__((always_inline)) {
+    pf_acc ^= pf_a ^ pf_x; pf_a = 0; pf_x = 0;
+    if (!REPLAY || c < 0 || c >= n_chunks) return;
+    const int t0 = start_of(c), tc = rows_of(c);
+    if (rp_act) {
+      const int nl = (G >> 4) + 1;                                        // 64-byte lines of a row's G floats (+ 1: the segment need not start on one)
+      const int r = sl / nl, l = sl - r * nl;
+      if (r < tc) { const int w = l * 16 < G ? l * 16 : G - 1; pf_a = __float_as_uint(io.actions[(int64_t)(t0 + r) * total + g_base + w]); }
+    }
+    if (rp_exo) {
+      const int len = n_env * a.n_exo, nl = (len >> 6) + 1;                // bytes of the group's envs in a row of the exo plane
+      const int r = sl / nl, l = sl - r * nl;
+      if (r < tc) { const int w = l * 64 < len ? l * 64 : len - 1; pf_x = io.exo[((int64_t)(t0 + r) * a.B + b_first) * a.n_exo + w]; }
+    }
+  };
+
   // ---- schedule.  it = -2: the workers draw chunk 0;  it = -1: recurrence(0) beside draws(1);  it >= 0:
   //        workers: outputs(it), draws(it + 2) | recurrence lanes: recurrence(it + 1) | store waves: stores(it - 1), actions(it + 1)    one barrier
   for (int it = -2; it <= n_chunks; ++it) {
@@ -645,6 +665,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       STICK(3);
     } else {
       if (it == -2 && pass == 0) replicate_tables(tid, work_first);
+      if (REPLAY) touch_inputs(it + 3);
       if (it <= 0) flag_segments(it + 2);
       if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
       if (cr >= 0 && cr < n_chunks) store_actions(cr, start_of(cr), rows_of(cr));     // (drawn in the previous iteration)
@@ -653,6 +674,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     RSTAMP_WORK();
     sw_lds_barrier(); STICK(5);
   }
+  if (REPLAY && pf_acc == 0x5EEDF00Du && a.T < 0) a.env_arrive[0] = (int32_t)pf_acc;     // (never true: keeps the touches alive)
   }   // pair groups of the workgroup
 #ifndef PHX_RT_FILL
   RSTAMP(4);

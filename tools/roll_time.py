@@ -17,6 +17,7 @@ ap.add_argument("--bufs", type=int, default=0, help="trajectory buffers rotated 
 ap.add_argument("--block", default="0", help="variants['block']: pairs per workgroup, whole_envs, or 0 = auto")
 ap.add_argument("--rollout", default="auto", help="variants['rollout']")
 ap.add_argument("--frags", type=int, default=1, help="fragments of T rows per call (phx_rollout_io.frags)")
+ap.add_argument("--replay", default="", help="a: replayed actions, x: replayed order sizes, ax: both (phx_rollout_io.actions / exo)")
 a = ap.parse_args()
 cls = ph.SupplyChainFSMEnv if a.fsm else ph.SupplyChainEnv
 blk = a.block if a.block == "whole_envs" else int(a.block)
@@ -33,7 +34,11 @@ h = hashlib.sha1()
 for x in (tr.observations, tr.actions, tr.rewards, tr.truncations):
     h.update(x.cpu().numpy().tobytes())
 k = a.frags
-if k > 1:                      # k fragments per call, the call's buffers rotated like single fragments
+ra = (torch.rand(a.T, a.batch, S, device=dev.device) * 100.0).contiguous() if "a" in a.replay else None
+rx = torch.randint(0, 5, (a.T, a.batch, S * a.cust), dtype=torch.uint8, device=dev.device) if "x" in a.replay else None
+if a.replay:
+    call = lambda i: dev.rollout(a.T, ra, rx, out=trs[i % nb])
+elif k > 1:                      # k fragments per call, the call's buffers rotated like single fragments
     nb = max(nb, 2 * k) // k * k
     trs = trs + [dev.alloc_trajectory(a.T) for _ in range(nb - len(trs))]
     call = lambda i: dev.rollout_fragments(a.T, trs[(i * k) % nb:(i * k) % nb + k])
