@@ -230,7 +230,8 @@ def other_configs(device):
         "fused rollout, 4 fragments of T=100 per call (phx_rollout_io.frags)", bytes_per_env_step=22 * 51)
     del env, dev, tr, tr4, fr; torch.cuda.empty_cache()
     # BASELINE config 2's env with a RECORDED policy and recorded order sizes (phx_rollout_io.actions / exo: a learned policy's actions
-    # replayed, the reference's numpy stream): the store-wave kernel's REPLAY instantiation + the pre-scan of the call's actions
+    # replayed, the reference's numpy stream): the store-wave kernel's REPLAY instantiation, the caller vouching for the inputs'
+    # domain (actions clipped to the action space, order sizes < 5: PHX_RH_*_IN_DOMAIN), and with the device's pre-scan of the actions
     env = ph.SupplyChainEnv(n_shops=9, customers_per_shop=6, num_steps=100, batch_size=4096, seed=42, exogenous="device", device=device)
     env.reset(); dev = env._device()
     Tr = 400
@@ -239,13 +240,16 @@ def other_configs(device):
     trr = [dev.alloc_trajectory(Tr) for _ in range(2)]
     kr = [0]
 
-    def replay(a_, x_):
-        dev.rollout(Tr, a_, x_, out=trr[kr[0] & 1]); kr[0] += 1
-    add("SC64 B=4096 (config 2), replayed actions", 64, 4096, Tr, timed(lambda: replay(acts_r, None), 30), f"fused rollout T={Tr}, phx_rollout_io.actions",
-        bytes_per_env_step=26 * 9)                               # the 22-byte record + the action read
+    def replay(a_, x_, vouch=True):
+        dev.rollout(Tr, a_, x_, out=trr[kr[0] & 1], actions_in_domain=vouch, exo_in_domain=x_ is not None); kr[0] += 1
+    add("SC64 B=4096 (config 2), replayed actions", 64, 4096, Tr, timed(lambda: replay(acts_r, None), 30),
+        f"fused rollout T={Tr}, phx_rollout_io.actions, PHX_RH_ACTIONS_IN_DOMAIN", bytes_per_env_step=26 * 9)   # the 22-byte record + the action read
+    res[-1]["kernels"] = dev.last_kernel()
+    add("SC64 B=4096 (config 2), replayed actions, pre-scanned on the device", 64, 4096, Tr, timed(lambda: replay(acts_r, None, False), 30),
+        f"fused rollout T={Tr}, phx_rollout_io.actions, no hint", bytes_per_env_step=30 * 9)                      # + the scan's read
     res[-1]["kernels"] = dev.last_kernel()
     add("SC64 B=4096 (config 2), replayed actions + order sizes", 64, 4096, Tr, timed(lambda: replay(acts_r, exo_r), 30),
-        f"fused rollout T={Tr}, phx_rollout_io.actions + exo", bytes_per_env_step=26 * 9 + 54)
+        f"fused rollout T={Tr}, phx_rollout_io.actions + exo, both hints", bytes_per_env_step=26 * 9 + 54)
     res[-1]["kernels"] = dev.last_kernel()
     del env, dev, trr, acts_r, exo_r; torch.cuda.empty_cache()
     # an FSM supply chain whose RESTOCK handler branches on the shops' total stock, declared in rule form (phx_spec.stage_rules, ABI 9):

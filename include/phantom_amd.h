@@ -333,9 +333,19 @@ typedef struct phx_rollout_frag {
   uint8_t*  reward_valid;      /* [frag_T][B][S] or NULL                                    */
 } phx_rollout_frag;
 
+/* phx_rollout_io.hints: what the CALLER vouches for about the replayed inputs, so that a plain supply chain's replay can take the
+ * store-wave kernel (whose tiles hold R, D and the stock in bytes) without a scan of the inputs.  A hint that does not hold leaves the
+ * fragment unspecified.  (Bit 1 was PHX_RH_FLAGS_ZEROED until ABI 8: not reused.)                                               */
+#define PHX_RH_ACTIONS_IN_DOMAIN 2  /* every replayed action rounds to >= 0 -- e.g. clipped to ShopAgent's action space Box(0, SHOP_MAX_STOCK),
+                                       supply_chain.py:87-91, as RLlib's clip_actions does.  Without it the call's actions are pre-scanned on
+                                       the device (T B S floats read once more) and a call with an action that rounds below zero is served
+                                       by round 1's kernel.                                                                           */
+#define PHX_RH_EXO_IN_DOMAIN     4  /* every byte of `exo` is a draw of np.random.randint(CUSTOMER_MAX_ORDER_SIZE = 5), i.e. < 5
+                                       (supply_chain.py:64) -- what phx_mt_draw produces.  Without it replayed order sizes are served by
+                                       round 1's kernel (32-bit tiles, any byte value).                                               */
 typedef struct phx_rollout_io {
   int32_t T;
-  int32_t hints;               /* 0 (reserved)                                              */
+  int32_t hints;               /* PHX_RH_* below, 0 = none                                  */
   const float*   actions;      /* [T][B][S] replayed policy, or NULL -> random U[0,100)     */
   const uint8_t* exo;          /* [T][B][n_exo] or NULL -> device RNG                       */
   float*    obs;               /* [T][B][S][D]  post-step observation                       */

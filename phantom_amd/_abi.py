@@ -112,6 +112,7 @@ class PhxRolloutFrag(C.Structure):
 
 
 MAX_FRAGMENTS = 8
+RH_ACTIONS_IN_DOMAIN, RH_EXO_IN_DOMAIN = 2, 4      # phx_rollout_io.hints
 
 
 assert C.sizeof(PhxMsgRec) == 16

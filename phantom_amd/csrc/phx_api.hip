@@ -1140,6 +1140,8 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
   if (e->d.env_type != PHX_ENV_PLAIN && !(io->n_frag >= 2 || io->frags) && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
+  if ((io->hints & ~(PHX_RH_ACTIONS_IN_DOMAIN | PHX_RH_EXO_IN_DOMAIN)) != 0 || io->reserved_ptr)
+    return fail(PHX_EINVAL, "phx_rollout: unknown hint bits / reserved_ptr must be NULL (ABI 9 removed PHX_RH_FLAGS_ZEROED and the record layout)");
   if (io->n_frag >= 2 || io->frags) {   // ABI 9: a fragment list
     if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags) return fail(PHX_EINVAL, "phx_rollout: a fragment list needs 2 .. %d fragments and `frags`", PHX_MAX_FRAGMENTS);
     if (io->T <= 0 || io->T % io->n_frag) return fail(PHX_EINVAL, "phx_rollout: T must be a positive multiple of n_frag");
@@ -1157,8 +1159,9 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     if (((uintptr_t)io->last_obs & 15u) || ((uintptr_t)io->actions & 3u)) return fail(PHX_EINVAL, "phx_rollout: every output buffer must be 16-byte aligned (replayed actions: 4-byte)");
     const int Tf = io->T / io->n_frag;
     // ONE launch where the store-wave supply-chain kernel serves the env (its store waves switch planes at the fragments' first rows) ...
-    if (e->use_fused && e->d.env_type == PHX_ENV_PLAIN && !e->d.any_typed && e->d.sc_fast.ok && e->d.sc_sw.ok && !io->actions && !io->exo && !io->msg_log && !io->msg_count &&
-        e->d.variant_rollout != PHX_VR_GENERAL && io->T <= 0xFFFF && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) {
+    if (e->use_fused && e->d.env_type == PHX_ENV_PLAIN && !e->d.any_typed && e->d.sc_fast.ok && e->d.sc_sw.ok && !io->msg_log && !io->msg_count &&
+        (!io->actions || (io->hints & PHX_RH_ACTIONS_IN_DOMAIN)) && (!io->exo || (e->d.sc_sw_exo_first && (io->hints & PHX_RH_EXO_IN_DOMAIN))) &&   // replays: only vouched-for
+        e->d.variant_rollout != PHX_VR_GENERAL && io->T <= 0xFFFF && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) {                // ones (round 1's kernel has no fragment lists)
       HIPCHK(use_device(e));
       HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
       return PHX_OK;
@@ -1180,7 +1183,6 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     }
     return PHX_OK;
   }
-  if (io->hints != 0 || io->reserved_ptr) return fail(PHX_EINVAL, "phx_rollout: hints / reserved_ptr must be zero (ABI 9 removed PHX_RH_FLAGS_ZEROED and the record layout)");
   if (io->T <= 0 || !io->obs || !io->action_out || !io->reward || !io->truncated)
     return fail(PHX_EINVAL, "bad rollout io");
   // `terminated` may be NULL where the plane would be all zero AND the kernel that serves the launch can leave it out: the
@@ -1271,10 +1273,12 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   // (a negative StockRequest takes the stock below zero) is found by a pre-scan of the call's actions and served by round 1's kernel
   // -- both launches are issued, the device word decides which one runs.
   if (e->d.sc_fast.ok && e->d.sc_sw.ok && e->d.variant_rollout != PHX_VR_GENERAL && e->d.variant_rollout != PHX_VR_TIME_PARALLEL && io->T <= 0xFFFF &&
-      (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40) && (!io->exo || e->d.sc_sw_exo_first) && e->d.sc_sw_guard) {
-    const int32_t gen = io->actions ? ++e->sw_guard_gen : 0;
+      (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40) && e->d.sc_sw_guard &&
+      (!io->exo || (e->d.sc_sw_exo_first && (io->hints & PHX_RH_EXO_IN_DOMAIN)))) {      // (order sizes: only those the caller vouches for, see the hint)
+    const bool scan = io->actions && !(io->hints & PHX_RH_ACTIONS_IN_DOMAIN);
+    const int32_t gen = scan ? ++e->sw_guard_gen : 0;
     HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream, gen));
-    if (io->actions) HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream, e->d.sc_sw_guard, gen));
+    if (scan) HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream, e->d.sc_sw_guard, gen));
     return PHX_OK;
   }
   HIPCHK(phx_launch_sc_rollout(e->d, *io, (hipStream_t)stream));

@@ -299,8 +299,16 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
             const int tl = tla + h;
             if (aligned || (tl >= 0 && tl < tc)) {
               const uint8_t* row = io.exo + ((int64_t)(t0 + tl) * a.B + b) * a.n_exo + e0;
+              // CustomerAgent.generate_messages: the recorded np.random.randint(5) draws of the shop's K customers, supply_chain.py:61-67.
+              // K >= 4: two (unaligned) dword loads that stay inside the shop's K bytes -- the first four and the last four -- instead of
+              // K byte loads; a byte sum is one multiply (every draw is < 5)
               int d = 0;
-              for (int k = 0; k < K_; ++k) d += (int)row[k];            // CustomerAgent.generate_messages: the recorded np.random.randint(5) draws, supply_chain.py:61-67
+              if (K_ >= 4) {
+                uint32_t w0, w1;
+                __builtin_memcpy(&w0, row, 4); __builtin_memcpy(&w1, row + (K_ - 4), 4);
+                if (K_ > 4) w0 += (w1 >> (8 * (8 - K_))) ;             // the K - 4 bytes w0 does not hold: byte-wise add (no carries: draws < 5)
+                d = (int)((w0 * 0x01010101u) >> 24);
+              } else for (int k = 0; k < K_; ++k) d += (int)row[k];
               Dx[h] = d;
             }
           }
@@ -803,7 +811,8 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.tables = (const float4*)sp.sc_sw_tables;
   a.io = io;
   a.n_exo = sp.n_exo; a.exo_first = sp.sc_sw_exo_first; a.guard = nullptr; a.guard_gen = guard_gen;
-  if (io.actions) {                       // the pre-scan of this call's actions decides between this kernel and round 1's (same stream: ordered)
+  if (io.actions && guard_gen != 0) {     // the pre-scan of this call's actions decides between this kernel and round 1's (same stream: ordered);
+                                          // guard_gen == 0: the caller vouched for the actions (PHX_RH_ACTIONS_IN_DOMAIN)
     const int64_t n = (int64_t)io.T * sp.B * sp.S;
     a.guard = sp.sc_sw_guard;
     hipLaunchKernelGGL(phx_sw_scan_actions_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 2048)), dim3(256), 0, st, io.actions, n, sp.sc_sw_guard, guard_gen);

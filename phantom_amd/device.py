@@ -485,9 +485,12 @@ class DeviceEnv:
             need("out.msg_count", out.msg_count, torch.int32, (B,))
             need("out.msg_log", out.msg_log, torch.uint8, (B, self.spec.trace_cap, 16))
 
-    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None) -> Trajectory:
+    def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None, actions_in_domain: bool = False,
+                exo_in_domain: bool = False) -> Trajectory:
         """T fused steps into ``out`` (allocated here when None); ``actions`` f32 [T, B, S] / ``exo`` u8 [T, B, n_exo] replay a recorded
-        policy / recorded draws (None: the device's random policy / RNG stream)."""
+        policy / recorded draws (None: the device's random policy / RNG stream).  ``actions_in_domain`` / ``exo_in_domain``: the caller
+        vouches that every action rounds to >= 0 (clipped to the action space) / every exo byte is < 5 (``mt_draw`` output): a plain supply
+        chain's replay then takes the store-wave kernel without a scan of the inputs (phx_rollout_io.hints)."""
         owned = out is None
         if owned:
             out = self.alloc_trajectory(T)
@@ -497,13 +500,13 @@ class DeviceEnv:
         # ~80 MB at B=4096).
         ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else None
         sig = lambda x: (x.data_ptr(), x.numel()) if hasattr(x, "data_ptr") else None     # address AND size: a buffer freed
-        key = (T,) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))    # and reallocated smaller misses
+        key = (T, bool(actions_in_domain), bool(exo_in_domain)) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))    # and reallocated smaller misses
         cached = None if owned else self._rollout_io_cache.get(key)
         if cached is None:
             self._check_rollout_buffers(T, actions, exo, out)
             io = _abi.PhxRolloutIO()
             io.T = T
-            io.hints = 0
+            io.hints = (_abi.RH_ACTIONS_IN_DOMAIN if actions_in_domain else 0) | (_abi.RH_EXO_IN_DOMAIN if exo_in_domain else 0)
             io.actions, io.exo = ptr(actions), ptr(exo)
             io.obs, io.action_out, io.reward = ptr(out.observations), ptr(out.actions), ptr(out.rewards)
             io.terminated, io.truncated = ptr(out.terminations), ptr(out.truncations)
@@ -521,23 +524,24 @@ class DeviceEnv:
             self._check(rc, "phx_rollout")
         return out
 
-    def rollout_fragments(self, T: int, outs, actions=None, exo=None) -> List[Trajectory]:
+    def rollout_fragments(self, T: int, outs, actions=None, exo=None, actions_in_domain: bool = False,
+                          exo_in_domain: bool = False) -> List[Trajectory]:
         """``len(outs)`` consecutive T-step fragments from ONE ``phx_rollout`` call (``phx_rollout_io.frags``, ABI 9): the env
         advances ``len(outs) * T`` steps exactly as the same number of ``rollout(T, out=outs[i])`` calls would, fragment i holds
         rows ``[i T, (i + 1) T)``.  The fixed cost of a launch (pipeline fill, placing a 160 KB workgroup on every CU, the kernel
         boundary: ~9 us against 12.5 us of streaming per 100 steps of SC64 at B = 4096) is paid once per call instead of once per
         fragment where the store-wave supply-chain kernel serves the env; other envs run one launch per fragment inside the call.
-        ``actions`` / ``exo``: replayed inputs for all ``len(outs) * T`` steps.  The observation after the last step is in EVERY
+        ``actions`` / ``exo``: replayed inputs for all ``len(outs) * T`` steps (``*_in_domain``: as in ``rollout``).  The observation after the last step is in EVERY
         fragment's ``last_obs`` tensor only if they share it; it is written to ``outs[-1].last_obs``."""
         outs = list(outs)
         k = len(outs)
         if k == 1:
-            return [self.rollout(T, actions, exo, out=outs[0])]
+            return [self.rollout(T, actions, exo, out=outs[0], actions_in_domain=actions_in_domain, exo_in_domain=exo_in_domain)]
         if not 2 <= k <= _abi.MAX_FRAGMENTS:
             raise ValueError(f"rollout_fragments: 1 .. {_abi.MAX_FRAGMENTS} fragments per call, got {k}")
         ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else None
         sig = lambda x: (x.data_ptr(), x.numel()) if hasattr(x, "data_ptr") else None
-        key = ("frags", T) + tuple(sig(x) for o in outs for x in o[:8]) + (sig(actions), sig(exo))
+        key = ("frags", T, bool(actions_in_domain), bool(exo_in_domain)) + tuple(sig(x) for o in outs for x in o[:8]) + (sig(actions), sig(exo))
         cached = self._rollout_io_cache.get(key)
         if cached is None:
             for o in outs:
@@ -557,7 +561,8 @@ class DeviceEnv:
                 arr[i].terminated, arr[i].truncated = ptr(o.terminations), ptr(o.truncations)
                 arr[i].obs_valid, arr[i].reward_valid = ptr(o.obs_valid), ptr(o.reward_valid)
             io = _abi.PhxRolloutIO()
-            io.T, io.hints, io.n_frag = k * T, 0, k
+            io.T, io.n_frag = k * T, k
+            io.hints = (_abi.RH_ACTIONS_IN_DOMAIN if actions_in_domain else 0) | (_abi.RH_EXO_IN_DOMAIN if exo_in_domain else 0)
             io.frags = C.cast(arr, C.c_void_p)
             io.actions, io.exo = ptr(actions), ptr(exo)
             io.last_obs = ptr(outs[-1].last_obs)

@@ -407,10 +407,12 @@ class PhantomEnv:
             warnings.warn("PhantomEnv.rollout with exogenous='numpy' and no `exo` tensor: the customers' / publishers' "
                           "draws come from the device RNG stream, not from np.random as in step(); pass exo=[T, B, n_exo] "
                           "to replay recorded draws, or build the env with exogenous='device'", RuntimeWarning, stacklevel=2)
+        exo_ok = False
         if exo is None and self.exogenous == "mt19937" and self.spec.n_exo > 0:
             self._need_streams()
             exo = self._device().mt_draw(T)                     # the draws of the T steps from every instance's own stream
-        traj = self._device().rollout(T, actions, exo, out)
+            exo_ok = True                                       # (randint(5) draws: the store-wave kernel may replay them, PHX_RH_EXO_IN_DOMAIN)
+        traj = self._device().rollout(T, actions, exo, out, exo_in_domain=exo_ok)
         self._sync_host_state()
         self._obs_state = ("traj", traj.last_obs)               # what the strategic agents observe now (sample() starts from it)
         return traj

@@ -68,10 +68,10 @@ class DeviceRunner:
         self.err = d.err.cpu().numpy()
         self.msg_count = d.msg_count.cpu().numpy() if d.msg_count is not None else None
 
-    def rollout(self, T, actions=None, exo=None):
+    def rollout(self, T, actions=None, exo=None, **hints):
         a = None if actions is None else self._t(actions, np.float32)
         x = None if exo is None else self._t(exo, np.uint8)
-        tr = self.dev.rollout(T, a, x)
+        tr = self.dev.rollout(T, a, x, **hints)
         if getattr(self, "on_launch", None) is not None:        # (fuzz campaigns: the kernels of the launch are journalled BEFORE the host waits for them)
             self.on_launch(self.dev.last_kernel())
         self.err = self.dev.err.cpu().numpy()
@@ -81,12 +81,12 @@ class DeviceRunner:
                     obs_valid=None if tr.obs_valid is None else tr.obs_valid.cpu().numpy(),
                     reward_valid=None if tr.reward_valid is None else tr.reward_valid.cpu().numpy())
 
-    def rollout_fragments(self, Tf, k, actions=None, exo=None):
+    def rollout_fragments(self, Tf, k, actions=None, exo=None, **hints):
         """k fragments of Tf rows from ONE phx_rollout call (phx_rollout_io.frags), concatenated like one k Tf-step rollout"""
         a = None if actions is None else self._t(actions, np.float32)
         x = None if exo is None else self._t(exo, np.uint8)
         outs = [self.dev.alloc_trajectory(Tf) for _ in range(k)]
-        self.dev.rollout_fragments(Tf, outs, a, x)
+        self.dev.rollout_fragments(Tf, outs, a, x, **hints)
         if getattr(self, "on_launch", None) is not None:
             self.on_launch(self.dev.last_kernel())
         self.err = self.dev.err.cpu().numpy()

@@ -85,15 +85,22 @@ def run_rollout_case(case, journal=None):
                     acts[int(xrng.integers(0, T)), int(xrng.integers(0, B)), 0] = -3.0   # stock may go negative -- the oracle's too)
             if which != 0 and dv.n_exo:
                 exo = xrng.integers(0, 5, (T, B, dv.n_exo)).astype(np.uint8)
+        hints = {}
+        if acts is not None and float(acts.min()) >= 0.0 and xrng.random() < 0.5:
+            hints["actions_in_domain"] = True                    # (PHX_RH_*: only where they hold; order sizes without the hint -> round 1's kernel)
+        if exo is not None and xrng.random() < 0.7:
+            hints["exo_in_domain"] = True
+        if exo is not None and not hints.get("exo_in_domain") and xrng.random() < 0.3:
+            exo[xrng.random(exo.shape) < 0.02] = int(xrng.integers(5, 256))          # any byte is a valid order size there
         k = min(int(xrng.choice([2, 3, 4, 8])), T) if (mode < 0.25 and T >= 4) else 1      # (lease r05_1: T = 7 with 8 fragments was the generator's own invalid argument)
         if journal:
             journal(f"case {case}: rollout T={T} frags={k} replay={'a' if acts is not None else ''}{'x' if exo is not None else ''}")
         if k > 1:
             Tf = max(1, T // k); T = Tf * k
             acts = None if acts is None else acts[:T]; exo = None if exo is None else exo[:T]
-            ro, rd = o.rollout(T, acts, exo), dv.rollout_fragments(Tf, k, acts, exo)
+            ro, rd = o.rollout(T, acts, exo), dv.rollout_fragments(Tf, k, acts, exo, **hints)
         else:
-            ro, rd = o.rollout(T, acts, exo), dv.rollout(T, acts, exo)
+            ro, rd = o.rollout(T, acts, exo), dv.rollout(T, acts, exo, **hints)
         _cmp(rd, ro, valid)
         for f in fields:
             np.testing.assert_array_equal(dv.get_i32(f), o.get_i32(f), err_msg=f"case {case}: {f} after T={T}")

@@ -225,7 +225,9 @@ def test_replayed_actions_and_orders_through_the_store_wave_kernel(S, K, B, num_
     """phx_rollout_io.actions / exo: a recorded policy and / or recorded np.random.randint(5) order sizes through phx_sc_rollout_sw_kernel's
     REPLAY instantiation (not round 1's kernel any more) against the oracle: actions above 100, up to 1e9 and +inf (every R >= 100
     requests 100 - stock), in (-0.5, 0.5) (round to zero), halves (round-half-even); twice in a row (ticks that are not multiples of 4
-    when T is not), then a device-RNG launch from the state the replays left."""
+    when T is not), then a device-RNG launch from the state the replays left.  Order sizes reach that kernel only under the caller's
+    PHX_RH_EXO_IN_DOMAIN (bytes < 5); the second repetition also vouches for the actions (no pre-scan: the negative ones here are in
+    (-0.5, 0): they round to zero)."""
     env = supply_chain_env(S, [K] * S, num_steps, B, seed=21 + S, env_offset=9, variants={"rollout": "store_waves"})
     o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
     o.reset(); d.reset()
@@ -242,8 +244,9 @@ def test_replayed_actions_and_orders_through_the_store_wave_kernel(S, K, B, num_
             acts[rng.random((T, B, S)) < 0.05] = 254.6
         if what in ("exo", "both"):
             exo = rng.integers(0, 5, (T, B, d.n_exo)).astype(np.uint8)
-        rd = d.rollout(T, acts, exo)
-        assert d.dev.last_kernel().startswith("phx_sc_rollout_sw_kernel[replay]"), d.dev.last_kernel()
+        rd = d.rollout(T, acts, exo, exo_in_domain=exo is not None, actions_in_domain=rep == 1)
+        want = "phx_sc_rollout_sw_kernel[replay]" + ("+phx_sc_rollout_kernel[if an action rounds below zero]" if acts is not None and rep == 0 else "")
+        assert d.dev.last_kernel() == want, (d.dev.last_kernel(), want)
         ro = o.rollout(T, acts, exo)
         for k in ("obs", "actions", "rewards"):
             np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"{k} rep {rep}")
@@ -253,6 +256,32 @@ def test_replayed_actions_and_orders_through_the_store_wave_kernel(S, K, B, num_
             np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} rep {rep}")
     rd, ro = d.rollout(40), o.rollout(40)
     np.testing.assert_array_equal(f32_bits(rd["obs"]), f32_bits(ro["obs"]))
+    assert (d.err == 0).all()
+
+
+@pytest.mark.parametrize("S,K,B,num_steps,Tf,k", [(9, 6, 64, 23, 25, 4), (3, 2, 48, 22, 23, 3), (51, 4, 128, 20, 20, 5)])
+def test_vouched_replays_in_a_fragment_list_are_one_store_wave_launch(S, K, B, num_steps, Tf, k):
+    """A fragment list with replayed inputs the caller vouches for (both PHX_RH_* hints) is ONE REPLAY launch of the store-wave kernel;
+    without the hints it is k launches (round 1's kernel has no fragment lists) -- the oracle's rows both ways."""
+    env = supply_chain_env(S, [K] * S, num_steps, B, seed=4 + S, variants={"rollout": "store_waves"})
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(S + Tf)
+    for vouch in (True, False, True):
+        acts = rng.uniform(0, 130, (k * Tf, B, S)).astype(np.float32)
+        exo = rng.integers(0, 5, (k * Tf, B, d.n_exo)).astype(np.uint8)
+        seen = []
+        d.on_launch = seen.append
+        rd = d.rollout_fragments(Tf, k, acts, exo, actions_in_domain=vouch, exo_in_domain=vouch)
+        d.on_launch = None
+        assert seen == (["phx_sc_rollout_sw_kernel[replay]"] if vouch else ["phx_sc_rollout_kernel"]), seen
+        ro = o.rollout(k * Tf, acts, exo)
+        for key in ("obs", "actions", "rewards"):
+            np.testing.assert_array_equal(f32_bits(rd[key]), f32_bits(ro[key]), err_msg=f"{key} vouch={vouch}")
+        np.testing.assert_array_equal(rd["truncated"], ro["truncated"])
+        np.testing.assert_array_equal(f32_bits(rd["last_obs"]), f32_bits(ro["last_obs"]))
+        for f in STATE:
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"{f} vouch={vouch}")
     assert (d.err == 0).all()
 
 
@@ -281,6 +310,26 @@ def test_replayed_action_that_rounds_below_zero_sends_the_call_to_round_1s_kerne
             assert (d.get_i32("shop.stock") < 0).any() or True      # (the stock may have recovered by the fragment's end)
         # a stock the negative request left below zero is outside the next store-wave launch's tiles too: bring the envs back
         o.reset(); d.reset()
+
+
+def test_replayed_order_sizes_nobody_vouched_for_take_round_1s_kernel():
+    """Without PHX_RH_EXO_IN_DOMAIN replayed order sizes may hold any byte (a test's 200-unit order): round 1's kernel (32-bit tiles)
+    serves the call, with the oracle's rows -- sizes 0 .. 255 here; PhantomEnv.rollout's own MT19937 draws carry the hint."""
+    S, K, B, T = 9, 6, 64, 44
+    env = supply_chain_env(S, [K] * S, 30, B, seed=5, variants={"rollout": "store_waves"})
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    exo = np.random.default_rng(2).integers(0, 256, (T, B, d.n_exo)).astype(np.uint8)
+    rd, ro = d.rollout(T, None, exo), o.rollout(T, None, exo)
+    assert d.dev.last_kernel() == "phx_sc_rollout_kernel", d.dev.last_kernel()
+    for k in ("obs", "actions", "rewards"):
+        np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=k)
+    for f in STATE:
+        np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f)
+    env2 = supply_chain_env(S, [K] * S, 30, B, seed=5, variants={"rollout": "store_waves"}, exogenous="mt19937")
+    env2.reset(); env2.seed_streams(np.arange(B, dtype=np.uint64) + 5)
+    env2.rollout(T)
+    assert env2._device().last_kernel() == "phx_sc_rollout_sw_kernel[replay]", env2._device().last_kernel()
 
 
 def test_sample_with_replayed_actions_across_an_episode_end_at_an_odd_batch_shape():

@@ -17,6 +17,7 @@ ap.add_argument("--bufs", type=int, default=0, help="trajectory buffers rotated 
 ap.add_argument("--block", default="0", help="variants['block']: pairs per workgroup, whole_envs, or 0 = auto")
 ap.add_argument("--rollout", default="auto", help="variants['rollout']")
 ap.add_argument("--frags", type=int, default=1, help="fragments of T rows per call (phx_rollout_io.frags)")
+ap.add_argument("--vouch", type=int, default=1, help="1: the replayed inputs carry PHX_RH_ACTIONS_IN_DOMAIN / PHX_RH_EXO_IN_DOMAIN")
 ap.add_argument("--replay", default="", help="a: replayed actions, x: replayed order sizes, ax: both (phx_rollout_io.actions / exo)")
 a = ap.parse_args()
 cls = ph.SupplyChainFSMEnv if a.fsm else ph.SupplyChainEnv
@@ -37,7 +38,7 @@ k = a.frags
 ra = (torch.rand(a.T, a.batch, S, device=dev.device) * 100.0).contiguous() if "a" in a.replay else None
 rx = torch.randint(0, 5, (a.T, a.batch, S * a.cust), dtype=torch.uint8, device=dev.device) if "x" in a.replay else None
 if a.replay:
-    call = lambda i: dev.rollout(a.T, ra, rx, out=trs[i % nb])
+    call = lambda i: dev.rollout(a.T, ra, rx, out=trs[i % nb], actions_in_domain=bool(a.vouch), exo_in_domain=bool(a.vouch))
 elif k > 1:                      # k fragments per call, the call's buffers rotated like single fragments
     nb = max(nb, 2 * k) // k * k
     trs = trs + [dev.alloc_trajectory(a.T) for _ in range(nb - len(trs))]
@@ -55,5 +56,5 @@ for rep in range(3):
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / a.n * 1e3)
 tot = a.T * k
-alg_call = a.batch * tot * 22 * S + a.batch * (S * 32 + 16)
+alg_call = a.batch * tot * (22 * S + (4 * S if "a" in a.replay else 0) + (S * a.cust if "x" in a.replay else 0)) + a.batch * (S * 32 + 16)   # (+ the replayed inputs' reads)
 print(f"{a.tag:28s} T={a.T:5d} x{k} bufs={nb:2d} {best:8.2f} us/call  {best * 100 / tot:7.2f} us/100 steps  {alg_call / best / 1e3 / 8000:.3f} of 8 TB/s  sha {h.hexdigest()[:12]}  {dev.last_kernel()}", flush=True)
