@@ -28,7 +28,8 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
 hipError_t phx_launch_gen_last_obs(const DevSpec& sp, const float* obs, float* last_obs, hipStream_t st);
 size_t phx_stk_rollout_lds(const DevSpec& sp);
 #include "phx_sc_fast.h"
-hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if = nullptr, int32_t gen = 0);
+
 hipError_t phx_launch_ads_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_ads_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 
@@ -876,16 +877,62 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       if (fok && phx_sc_fast_plan(d.B, d.S, d.fsm_lean_K, true, d.num_steps, d.variant_block, false, &plan)) { plan.norm = d.fsm_lean_norm; d.fsm_fast = plan; }
     }
   }
+  // round 5: the store-wave kernel's FSM instantiation (phx_sc_rollout_sw.hip, MODE 2) for the same envs: per episode position along the
+  // handler-less chain the stage's flags (uniform over the shops) and whether a rewarded position lies at or before it; the episode's last
+  // position observes (its terminal dump, fsm.py:360-375, is then the row's own observation).  No lookback limit: the recurrence lanes
+  // carry fsm.py's caches.
+  memset(&d.fsm_sw, 0, sizeof d.fsm_sw); d.fsm_sw_tab = nullptr;
+  std::vector<uint16_t> fsm_sw_tab;
+  if (d.fsm_lean_K > 0 && spec->n_samplers == 0 && d.num_steps >= 16 && d.num_steps <= 4096 && d.n_lists <= 255 &&
+      (d.variant_rollout == PHX_VR_AUTO || d.variant_rollout == PHX_VR_STORE_WAVES)) {
+    bool ok = true;
+    for (int l = 0; l < d.n_lists && ok; ++l)
+      for (int s2 = 1; s2 < d.S; ++s2) ok = ok && der.sc_shop_flags[(size_t)l * d.S + s2] == der.sc_shop_flags[(size_t)l * d.S];
+    const int ns = d.num_steps;
+    fsm_sw_tab.assign((size_t)2 * ns, 0);
+    int sg = spec->initial_stage; bool has_rew = false;
+    for (int p = 0; p < ns && ok; ++p) {
+      if (sg < 0 || sg >= d.n_lists) { ok = false; break; }
+      const int f = der.sc_shop_flags[(size_t)sg * d.S];
+      has_rew = has_rew || (f & 16);
+      // (the SWF_* word of phx_sc_rollout_sw.hip: operand masks and flags at the tile word's bits)
+      fsm_sw_tab[p] = (uint16_t)(((f & 1) ? 0x407F : 0) | ((f & 2) ? 0x1F00 : 0) | ((f & 8) ? 0x0080 : 0) | ((f & 16) ? 0x2000 : 0) | (has_rew ? 0x8000 : 0));
+      fsm_sw_tab[ns + p] = (uint16_t)sg;
+      sg = spec->stage_next[sg];
+    }
+    ok = ok && (fsm_sw_tab[ns - 1] & 0x0080);
+    // the state a fragment leaves (delivered_stock, self._rewards, self._observations) is tracked over its last two chunks: the acting /
+    // rewarded / observing positions of the (cyclic) chain lie at most 16 steps apart, or never occur
+    for (uint16_t bit : {(uint16_t)0x4000, (uint16_t)0x2000, (uint16_t)0x0080}) {
+      int first = -1, prev = -1, gap = 0;
+      for (int p = 0; p < ns && ok; ++p) if (fsm_sw_tab[p] & bit) { if (first < 0) first = p; else gap = std::max(gap, p - prev); prev = p; }
+      if (first >= 0) gap = std::max(gap, first + ns - prev);
+      ok = ok && gap <= 16;
+    }
+    ScSwPlan sw;
+    if (ok && phx_sc_sw_plan(d.B, d.S, d.fsm_lean_K, true, ns, d.variant_block, &sw, ns) && (sw.specialised || d.variant_rollout == PHX_VR_STORE_WAVES) && sw.G != 144) {
+      sw.norm = d.fsm_lean_norm;
+      std::vector<uint8_t> img;
+      phx_sc_sw_tables(sw.K, sw.norm, &img);
+      const uint8_t* dev_img = nullptr;
+      rc = upload(e, img.data(), img.size(), &dev_img);
+      if (rc == PHX_OK) rc = upload(e, fsm_sw_tab.data(), fsm_sw_tab.size(), &d.fsm_sw_tab);
+      if (rc != PHX_OK) { phx_destroy(e); return rc; }
+      d.fsm_sw = sw; d.sc_sw_tables = dev_img;
+    }
+  }
   d.fsm_pos_tab = nullptr; d.fsm_irregular = nullptr;
   d.sc_sw_exo_first = nullptr; d.sc_sw_guard = nullptr;
-  if (d.fsm_fast.ok) {
-    rc = upload(e, fsm_tab.data(), fsm_tab.size(), &d.fsm_pos_tab);
-    if (rc != PHX_OK) { phx_destroy(e); return rc; }
+  if (d.fsm_fast.ok || d.fsm_sw.ok) {
     const int32_t zero = 0; const int32_t* flag = nullptr;
     rc = upload(e, &zero, 1, &flag);
     if (rc != PHX_OK) { phx_destroy(e); return rc; }
     d.fsm_irregular = (int32_t*)flag;
     d.fsm_gen_host = &e->fsm_gen;
+  }
+  if (d.fsm_fast.ok) {
+    rc = upload(e, fsm_tab.data(), fsm_tab.size(), &d.fsm_pos_tab);
+    if (rc != PHX_OK) { phx_destroy(e); return rc; }
   }
   if (der.sc_static && spec->env_type == PHX_ENV_PLAIN && !der.any_typed && d.S > 0) {
     // fast rollout kernel (phx_sc_rollout.hip): every shop with the same 1..6 customers and the same normaliser
@@ -1164,6 +1211,22 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
         e->d.variant_rollout != PHX_VR_GENERAL && io->T <= 0xFFFF && (e->d.variant_rollout == PHX_VR_STORE_WAVES || io->T >= 40)) {                // ones (round 1's kernel has no fragment lists)
       HIPCHK(use_device(e));
       HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream));
+      return PHX_OK;
+    }
+    // ... the same for an FSM supply chain on its FSM instantiation; the lane-per-pair loop that takes over when an env is off the stage
+    // chain has no fragment lists: one guarded launch per fragment behind it (each returns at entry unless the check found such an env)
+    if (e->use_fused && e->d.env_type == PHX_ENV_FSM && phx_fsm_sw_serves(e->d, *io, (hipStream_t)stream)) {
+      HIPCHK(use_device(e));
+      const int32_t gen = phx_fsm_next_gen(e->d);
+      HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream, gen));
+      for (int f = 0; f < io->n_frag; ++f) {
+        const phx_rollout_frag& fr = io->frags[f];
+        phx_rollout_io sub = *io;
+        sub.n_frag = 0; sub.frags = nullptr; sub.T = Tf;
+        sub.obs = fr.obs; sub.action_out = fr.action_out; sub.reward = fr.reward; sub.terminated = fr.terminated; sub.truncated = fr.truncated;
+        sub.obs_valid = fr.obs_valid; sub.reward_valid = fr.reward_valid;
+        HIPCHK(phx_launch_sc_rollout_fsm(e->d, sub, (hipStream_t)stream, e->d.fsm_irregular, gen));
+      }
       return PHX_OK;
     }
     // ... n_frag consecutive launches everywhere else

@@ -150,6 +150,8 @@ struct DevSpec {
   ScFastPlan sc_fast;            // fast rollout kernel: plan (ok == 0: not applicable)
   int32_t sc_wide_K, sc_wide_norm;   // phx_sc_step_wide_kernel: the shops' common customer count (0: the kernel does not apply) and normaliser
   ScSwPlan sc_sw;                // store-wave rollout kernel (round 4): plan (ok == 0: not applicable)
+  ScSwPlan fsm_sw;               // its FSM instantiation (FSM supply chains on the handler-less stage chain): plan
+  const uint16_t* fsm_sw_tab;    // [2][num_steps] SWF_* word of every episode position, then its stage (phx_sc_rollout_sw.hip)
   const void* sc_sw_tables;      // its table image in device memory (phx_sc_sw_tables)
   const int32_t* sc_sw_exo_first;// [S] exogenous column of each shop's first customer, or NULL: the customers' columns are not consecutive (exo replays go to round 1's kernel)
   int32_t* sc_sw_guard;          // device word: the replay pre-scan stores the call's number here when an action rounds below zero

@@ -984,15 +984,37 @@ hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStrea
   return hipGetLastError();
 }
 
-hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+// Does the store-wave kernel's FSM instantiation serve this launch?  (Its launch generation is baked into the kernel arguments: a
+// capturing stream takes the lane-per-pair loop, like phx_launch_sc_rollout_fsmfast.)
+bool phx_fsm_sw_serves(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  const int vr = sp.variant_rollout;
+  if (!sp.fsm_sw.ok || sp.fsm_lean_K <= 0 || sp.env_type != PHX_ENV_FSM || io.actions || io.exo || io.msg_log || io.msg_count || sp.n_samplers != 0 ||
+      io.T > 0xFFFF || !sp.f[F_ENV_ARRIVE] || !sp.fsm_irregular) return false;
+  // PHX_VR_AUTO: long fragments / fragment lists of batches the time-parallel FSM kernel does not take.  Measured on five boxes, SC256-FSM,
+  // B = 8192 (config 3), this kernel / the lane-per-pair loop: T = 400 854-894 us (every box) / 754-985 (bimodal by the buffers' placement);
+  // T = 100 268-275 / 226 (ten iterations per pair group of which three fill the pipeline); SC64-FSM, B = 4096: 57 / 37 (time-parallel kernel).
+  if (!(vr == PHX_VR_STORE_WAVES || (vr == PHX_VR_AUTO && io.T >= 200 && (int64_t)sp.B * sp.S > 65536))) return false;
+  if (!(io.n_frag >= 2) && (!io.obs_valid || !io.reward_valid)) return false;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
+hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if_in, int32_t gen_in) {
   const int epb = SC_NT / sp.S;
   const int remap_env = phx_knobs().rollout_remap;
   const int remap = remap_env >= 0 ? remap_env : 1;
-  // time-parallel kernel first where its plan applies; the lane-per-pair loop below then runs only if that kernel found
+  // store-wave / time-parallel kernel first where a plan applies; the lane-per-pair loop below then runs only if that kernel found
   // an env off the tabulated stage chain (a stage a handler or the caller set) and left the launch alone
-  const int32_t* only_if = nullptr; int32_t gen = 0;
+  const int32_t* only_if = only_if_in; int32_t gen = gen_in;
   const int vr = sp.variant_rollout;      // phx_spec.variant_rollout: PHX_VR_TIME_PARALLEL / LEAN / GENERAL pick the kernel per env
-  if (sp.fsm_fast.ok && sp.fsm_lean_K > 0 && (vr == PHX_VR_AUTO || vr == PHX_VR_TIME_PARALLEL)) {
+  if (!only_if && phx_fsm_sw_serves(sp, io, st)) {
+    gen = phx_fsm_next_gen(sp);
+    const hipError_t fe = phx_launch_sc_rollout_sw(sp, io, st, gen);
+    if (fe != hipSuccess) return fe;
+    only_if = sp.fsm_irregular;
+  }
+  if (!only_if && sp.fsm_fast.ok && sp.fsm_lean_K > 0 && (vr == PHX_VR_AUTO || vr == PHX_VR_TIME_PARALLEL)) {
     hipError_t fe = hipSuccess;
     if (phx_launch_sc_rollout_fsmfast(sp, io, st, &fe, &gen)) { if (fe != hipSuccess) return fe; only_if = sp.fsm_irregular; }
   }

@@ -475,6 +475,14 @@ __global__ __launch_bounds__(NT, NT / 64) void phx_sc_rollout_fsmfast_kernel(con
 
 static uint32_t fsm_magic32(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)(d > 0 ? d : 1)); }
 
+// the next launch generation of the env (see below: per env, never 0)
+int32_t phx_fsm_next_gen(const DevSpec& sp) {
+  std::atomic<int32_t>* gen_host = (std::atomic<int32_t>*)sp.fsm_gen_host;
+  int32_t launch_gen = gen_host->fetch_add(1) + 1;
+  if (launch_gen <= 0 || launch_gen == 0x7fffffff) { gen_host->store(1); launch_gen = 1; }
+  return launch_gen;
+}
+
 // true when the launch was issued (the caller then issues the lane-per-pair loop guarded by DevSpec::fsm_irregular)
 bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_, hipStream_t st, hipError_t* err, int32_t* gen_out) {
   *err = hipSuccess;
@@ -511,9 +519,7 @@ bool phx_launch_sc_rollout_fsmfast(const DevSpec& sp, const phx_rollout_io& io_,
   // lane-per-pair loop instead (same results)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
-  std::atomic<int32_t>* gen_host = (std::atomic<int32_t>*)sp.fsm_gen_host;
-  int32_t launch_gen = gen_host->fetch_add(1) + 1;
-  if (launch_gen <= 0 || launch_gen == 0x7fffffff) { gen_host->store(1); launch_gen = 1; }
+  const int32_t launch_gen = phx_fsm_next_gen(sp);
   a.gen = launch_gen; *gen_out = launch_gen;
   a.io = io_;
   a.timing = nullptr;

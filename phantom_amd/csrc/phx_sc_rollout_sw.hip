@@ -33,7 +33,7 @@
 #include <type_traits>
 #include <vector>
 
-struct SwFrag { float* obs; float* action_out; float* reward; uint8_t* terminated; uint8_t* truncated; };
+struct SwFrag { float* obs; float* action_out; float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* obs_valid; uint8_t* reward_valid; };
 struct SwArgs {
   int32_t B, S, epb, G, K, T, num_steps, xcd_remap, first_rows;
   int32_t n_rec_waves, n_store_waves;   // wave roles: [0, n_rec) recurrence, [n_rec, n_rec + n_store) stores, the rest work
@@ -43,8 +43,6 @@ struct SwArgs {
   int32_t norm;
   uint64_t seed; int64_t env_offset;
   int32_t *stock, *sales, *missed, *delivered, *env_step, *env_tick, *env_arrive;
-  unsigned long long* timing;           // PHX_TIMING builds only
-  unsigned long long* rt; int32_t launch_idx;   // PHX_TIMING builds only: 100 MHz wall-clock stamps per workgroup and launch
   const float4* tables;                 // the host-built image of the table sections (phx_sc_sw_tables)
   phx_rollout_io io;
   // ---- (past the argument lines the kernel warms at entry) ----
@@ -56,7 +54,31 @@ struct SwArgs {
   const int32_t* guard;                 // device word: == guard_gen -> a replayed action rounds below zero (the pre-scan of this call found
                                         // one): the stock would leave [0, 100], this kernel does nothing and round 1's kernel serves the call
   SwFrag frag[PHX_MAX_FRAGMENTS];       // row t of the launch is row t - f * frag_T of fragment f = t / frag_T
+  // FSM instantiation (FiniteStateMachineEnv supply chains on their handler-less stage chain, fsm.py:253-380)
+  const uint16_t* fsm_tab;              // [2][num_steps]: the SWF_* word of every episode position, then the stage it runs in
+  int32_t *env_stage, *env_prev_stage;
+  double* rew_cache; uint8_t* rew_cache_v; float* obs_cache; uint8_t* obs_cache_v;      // self._rewards / self._observations (fsm.py:334-350)
+  unsigned long long* timing;           // PHX_TIMING builds only
+  unsigned long long* rt; int32_t launch_idx;   // PHX_TIMING builds only: 100 MHz wall-clock stamps per workgroup and launch
 };
+// The word of an episode position p (the step that takes the env from step p to p + 1) in the stage the chain runs it in: the stage's
+// flags at the bits they have in the tile word, and the masks of the operands it switches off (no action: R = 0, no orders: D = 0) --
+//   tile word of the FSM instantiation = ((R | D << 8) | SWF_FLAGS) & position word        (R <= 100, D <= 24)
+#define SWF_RMASK 0x007Fu   /* the shops act (StockRequest): R passes                         */
+#define SWF_OBS 0x0080u     /* the shops observe: they act in the NEXT stage, fsm.py:320      */
+#define SWF_DMASK 0x1F00u   /* their customers order: D passes                                */
+#define SWF_REW 0x2000u     /* the shops are rewarded (self._rewards is updated, :335,350)    */
+#define SWF_ACT 0x4000u     /* the shops act                                                  */
+#define SWF_HASREW 0x8000u  /* a rewarded position <= p exists in the episode (never in a tile word) */
+#define SWF_FLAGS (SWF_OBS | SWF_REW | SWF_ACT)
+// What a row hands to the workers (s_fo, one u32 per item, written by the recurrence lane): everything the row emits as table indices --
+//   stock after | sales << 7 | missed sales << 12 | reward index << 17 | SWF_FO_LAUNCH
+// a silent row (no observation) and an observing row with nothing cached emit zeros: index 0 of the observation tables and
+// SWF_RW_ZERO of the reward table hold 0.0f.  SWF_FO_LAUNCH: the reward is the cache as the launch found it (s_rc0).
+#define SWF_RW_ZERO 100
+#define SWF_RW_LAUNCH 0x200  /* in the lane's running index: bit 26 of the s_fo word */
+#define SWF_RW_CACHED 0x400  /* in the lane's running index: set by a rewarded step of the episode (bit 27 of the s_fo word, unused there) */
+#define SWF_FO_LAUNCH (1u << 26)
 
 __device__ __forceinline__ void sw_lds_barrier() {       // orders LDS traffic only: the trajectory stores stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -65,9 +87,10 @@ __device__ __forceinline__ void sw_lds_barrier() {       // orders LDS traffic o
 }
 
 // LDS bytes of a workgroup (host and device agree through this one function)
-__host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_n) {
+__host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_n, int fsm_ns = 0) {
   const size_t G4p = (size_t)((G + 3) & ~3), items = (size_t)TC * G;
-  return G4p * 4 + (size_t)((epb + 3) & ~3) * 4 + 16            // pair table, ticks, flags
+  const size_t fsm = fsm_ns > 0 ? items * 2 * 2 + G4p * 4 + (size_t)((G + 15) & ~15) + (size_t)((epb + 3) & ~3) * 4 + (size_t)((2 * fsm_ns + 15) & ~15) : 0;   // (FSM sections, below)
+  return fsm + G4p * 4 + (size_t)((epb + 3) & ~3) * 4 + 16            // pair table, ticks, flags
        + 101 * 32 * 4 + 32 * 32 * 4 + 401 * 8 * 4 + 128          // observation tables (32 copies), reward table (8 copies), digit sums of k < 125
        + 15632                                                   // order sums of y < 5^K (5^6 reserved: the tables sit at fixed offsets)
        + items * 2 * 3 + items * 2 * 2                           // R | D tiles (3), stock tiles (2)
@@ -101,15 +124,22 @@ __device__ __forceinline__ void sw_store16(char* p, const float4 v) { __builtin_
 // REPLAY: the policy's actions and / or the customers' order sizes come from HBM (phx_rollout_io.actions / exo: a recorded policy,
 // the reference's own numpy stream -- phx_mt_draw) instead of the Philox block: the draw phase loads them (4 S and S K more bytes
 // read per env-step) and the rest of the pipeline is the same.
-template <int TC, int GT, int NREC, int NSTORE, int NWORK, bool REPLAY>
+// MODE 2 (FSM): a FiniteStateMachineEnv supply chain whose envs are all on the handler-less stage chain (checked per launch by
+// phx_sw_fsm_check_kernel; otherwise this kernel returns at entry and the lane-per-pair loop serves the launch).  The stage of a step
+// is a function of its episode position; its masks fold into the tile word's operands (no action: R = 0, no orders: D = 0), the
+// recurrence lane carries what fsm.py's caches hold (self._rewards / self._observations, delivered_stock) and hands the reward a row
+// emits to the workers as a table index; obs_valid / reward_valid are closed forms like the truncation plane.
+template <int TC, int GT, int NREC, int NSTORE, int NWORK, int MODE>
 __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_) {
+  constexpr bool REPLAY = MODE == 1, FSM = MODE == 2;
   sw_kptr_t kp = (sw_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   { uint32_t d0, d1, d2, d3, d4;          // every 64-byte line of the argument block into the scalar cache at once, not one miss per phase (setup 1.6 -> 1.2 us)
     static_assert(offsetof(SwArgs, n_groups) > 0x100 && offsetof(SwArgs, n_groups) <= 0x140, "the offsets below cover the argument block line by line (the fragment table is read once per chunk)");
     asm volatile("s_load_dword %0, %5, 0x0\n s_load_dword %1, %5, 0x40\n s_load_dword %2, %5, 0x80\n s_load_dword %3, %5, 0xc0\n s_load_dword %4, %5, 0x100\n s_waitcnt lgkmcnt(0)"
                  : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(kp) : "memory"); }
   SW_REFRESH();
-  if (REPLAY && a.guard && *a.guard == a.guard_gen) return;             // (uniform) an action outside the kernel's domain: round 1's kernel takes the call
+  if ((REPLAY || FSM) && a.guard && *a.guard == a.guard_gen) return;    // (uniform) an action outside the kernel's domain: round 1's kernel takes the call;
+                                                                        // FSM: an env off the stage chain or a stock outside [0, 100]: the lane-per-pair loop does
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, NT = GT ? 64 * (NREC + NSTORE + NWORK) : (int)blockDim.x, nS = a.S, G = GT ? GT : a.G;
   const int64_t total = (int64_t)a.B * nS;
@@ -129,10 +159,16 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   int* s_flags = s_tick0 + ((a.epb + 3) & ~3);                          // [4] per wave 0..3: bit 0 a tick is not a multiple of 4, 1 a stock outside [0, 100], 2 a step counter < 0
   uint16_t* s_rd0 = (uint16_t*)(s_flags + 4);                           // 3 x [TC][G]  R | D << 8                     (chunk c in c % 3)
   uint16_t* s_xx0 = s_rd0 + 3 * items;                                  // 2 x [TC][G]  stock before | stock after << 8 (chunk c in c & 1)
-  uint16_t* s_ftend = (uint16_t*)(s_xx0 + 2 * items);                   // [G] the row of the fragment that ends the pair's current episode (0xFFFF: none): the flag planes
+  uint32_t* s_fo0 = (uint32_t*)s_xx0;                                   // FSM: 2 x [TC][G] u32 in place of the stock tiles (chunk c in c & 1)
+  uint16_t* s_ftend = (uint16_t*)(s_xx0 + (FSM ? 4 : 2) * items);       // [G] the row of the fragment that ends the pair's current episode (0xFFFF: none): the flag planes
   int* s_x0w = (int*)((uint8_t*)s_ftend + 3 * G16p + 16);                        // [G] stocks at launch (used when one is outside [0, 100])
   float* s_out0 = (float*)(s_x0w + G4p);                                // 2 x { obs [TC][3 G], reward [TC][G] }   (chunk c in c & 1)
   float* s_act0 = s_out0 + 8 * items;                                   // 2 x [TC][G] action, drawn at iteration c - 2, stored at c - 1 (chunk c in c & 1)
+  // FSM sections
+  float* s_rc0 = s_act0 + 2 * items;                                    // [G] self._rewards[shop] at launch, as emitted (f32)
+  uint8_t* s_cv0 = (uint8_t*)(s_rc0 + G4p);                             // [G] is it valid
+  int* s_pst0 = (int*)(s_cv0 + G16p);                                   // [epb] episode position of the env at launch
+  uint16_t* s_pf = (uint16_t*)(s_pst0 + ((a.epb + 3) & ~3));            // [num_steps] SWF_* word of every episode position
 
   // i / d for the block's divisors: a literal where the shape is compile-time, the host's magic otherwise (i < 2^16)
   auto div_G = [&](uint32_t i) { return GT ? i / (uint32_t)(GT ? GT : 1) : __umulhi(i, a.mG); };
@@ -174,6 +210,12 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const uint32_t el = nS == 1 ? pt : __umulhi(pt, a.mS);               // (r0 + tid) / S
     if (tid < G) { x = a.stock[g_base + tid]; step = a.env_step[b_first + el]; }
     if (tid < n_env) tk = a.env_tick[b_first + tid];
+    float f_rc = 0.f; int f_cv = 0, f_ps = 0;
+    if (FSM) {
+      if (tid < G) { f_rc = (float)a.rew_cache[g_base + tid]; f_cv = a.rew_cache_v[g_base + tid] ? 1 : 0; }
+      if (tid < n_env) f_ps = a.env_step[b_first + tid];
+      if (pass == 0) for (int i = tid; i < a.num_steps; i += NT) s_pf[i] = a.fsm_tab[i];
+    }
     // the tables: the host-built image (17.9 KB, L2-resident after the first workgroups), loads issued before anything waits.  Digit
     // and order sums go where they live; the base values of the three value tables go to a scratch area (the staging tile, unused
     // until the first output phase) and are replicated per LDS bank after the barrier.  (The replicated tables as a 45.6 KB image
@@ -199,6 +241,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       s_ftend[tid] = (uint16_t)((step < a.num_steps && et < 0xFFFF) ? et : 0xFFFF);      // (a counter >= num_steps never ends an episode: recurrence)
     }
     if (tid < n_env) s_tick0[tid] = tk;
+    if (FSM) { if (tid < G) { s_rc0[tid] = f_rc; s_cv0[tid] = (uint8_t)f_cv; } if (tid < n_env) s_pst0[tid] = f_ps; }
     // launch-wide flags without a zeroing pass: the waves that can hold a pair or an env (the first four) publish theirs
     {
       const bool f0 = tid < n_env && (tk & 3) != 0;                                       // a tick that is not a multiple of 4
@@ -253,7 +296,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #else
   const bool draws_fixed = (nwk % G) == 0;
 #endif
-  int dl_gl = 0, dl_jr0 = 0, dl_s = 0; uint32_t dl_tick0 = 0; int64_t dl_genv = 0;
+  int dl_gl = 0, dl_jr0 = 0, dl_s = 0, dl_pos0 = 0; uint32_t dl_tick0 = 0; int64_t dl_genv = 0;
+  // FSM: q mod num_steps for q < 2^17 (the f32 quotient is off by one at most)
+  const uint32_t ns_u = (uint32_t)a.num_steps; const float inv_ns_f = 1.0f / (float)a.num_steps;
+  auto mod_ns = [&](uint32_t q) { uint32_t r = q - (uint32_t)((float)q * inv_ns_f) * ns_u; if ((int)r < 0) r += ns_u; if (r >= ns_u) r -= ns_u; return r; };
   const bool rp_act = REPLAY && io.actions != nullptr, rp_exo = REPLAY && io.exo != nullptr;
   if (wt >= 0) {
     dl_jr0 = (int)div_G((uint32_t)wt); dl_gl = wt - dl_jr0 * G;
@@ -261,6 +307,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     dl_s = (int)(pr & 255u);
     dl_genv = a.env_offset + b_first + (int)(pr >> 8);
     dl_tick0 = (uint32_t)s_tick0[pr >> 8];
+    if (FSM) dl_pos0 = s_pst0[pr >> 8];      // (fixed draws: carried forward chunk by chunk -- the episode position of the next chunk's first row)
   }
   auto draws_impl = [&](int t0, int tc, int buf, int buf2, auto ALIGNED, auto FIXED) __attribute__((always_inline)) {
     constexpr bool aligned = decltype(ALIGNED)::value, fixed = decltype(FIXED)::value;
@@ -271,13 +318,14 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const int djr = fixed ? nwk / G : 0;
     int jr = dl_jr0;
     for (int iw = wt; iw < n_work; iw += nwk, jr += djr) {
-      int gl = dl_gl, s = dl_s; int64_t genv = dl_genv; uint32_t tick_base = dl_tick0 + (uint32_t)t0;
+      int gl = dl_gl, s = dl_s, pos0 = dl_pos0; int64_t genv = dl_genv; uint32_t tick_base = dl_tick0 + (uint32_t)t0;
       if (!fixed) {
         jr = (int)div_G((uint32_t)iw); gl = iw - (int)__umul24(jr, G);
         const uint32_t pr = s_pair[gl];
         s = (int)(pr & 255u);
         genv = a.env_offset + b_first + (int)(pr >> 8);
         tick_base = (uint32_t)s_tick0[pr >> 8] + (uint32_t)t0;
+        if (FSM) pos0 = s_pst0[pr >> 8];
       }
       const int tla = 4 * jr - (aligned ? 0 : (int)(tick_base & 3u));
       if (!aligned && (tla + 3 < 0 || tla >= tc)) continue;
@@ -313,6 +361,21 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
             }
           }
         }
+      }
+      // FSM: the words of the four rows' episode positions ((position at launch + row) mod num_steps; tla >= -3): the lookups are in
+      // flight while the Philox block is computed
+      uint32_t pw[4] = {0u, 0u, 0u, 0u};
+#ifndef SWF_ABL_NOPW
+      if (FSM)
+#else
+      if (false)
+#endif
+      {
+        uint32_t pos;
+        if (fixed) { int p = pos0 + tla; if (p < 0) p += (int)ns_u; else if (p >= (int)ns_u) p -= (int)ns_u; pos = (uint32_t)p; }     // (-3 <= tla < tc <= num_steps)
+        else pos = mod_ns((uint32_t)(pos0 + t0 + tla) + ns_u);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { pw[h] = s_pf[pos]; pos = pos + 1u == ns_u ? 0u : pos + 1u; }
       }
       uint32_t w[4] = {0u, 0u, 0u, 0u};
       uint32_t y[4] = {0u, 0u, 0u, 0u}, aj[4] = {0u, 0u, 0u, 0u};
@@ -353,10 +416,18 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         // decode_action: int(round(action)), supply_chain.py:139.  A replayed action >= -0.5 (the call's pre-scan) rounds to R >= 0 and
         // min(R, 100 - stock) is the same for every R >= 100: 255 stands for all of them in the tile's byte
         const int Rq = rp_act ? (int)fminf(rintf(action), 255.0f) : (int)rintf(action);
+#ifdef SWF_ABL_NOPW
+        if (false)
+#else
+        if (FSM)        // the stage's masks folded into the operands (no action: no request; no orders: no demand), its flags beside them
+#endif
+          s_rd[i + h * G] = (uint16_t)((((uint32_t)Rq | ((uint32_t)D[h] << 8)) | SWF_FLAGS) & pw[h]);
+        else
         s_rd[i + h * G] = (uint16_t)(Rq | (D[h] << 8));
         s_act[i + h * G] = action;
       }
     }
+    if (FSM && fixed) { dl_pos0 += tc; if (dl_pos0 >= (int)ns_u) dl_pos0 -= (int)ns_u; }
   };
   auto draws = [&](int t0, int tc, int c) __attribute__((always_inline)) {
     if (wt < 0) return;
@@ -413,6 +484,61 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // ---- FSM: the same chain with the caches of fsm.py carried along (one lane per pair, the rows in order):
+  //   self._rewards[shop] (fsm.py:334-350): set at every rewarded step, cleared by reset (:234) -- what a row emits with its observation
+  //   (:378, or the terminal dump :360-375) goes to the workers as the reward table's index (in s_fo);  self._observations[shop] (:349) and
+  //   ShopAgent.delivered_stock (supply_chain.py:109-113, set when the shop acts) are only needed as the state the fragment leaves.
+  //   The episode's last row: its word's REW bit updates the cache BEFORE the row emits, the reset after it.  No stock outside [0, 100]
+  //   and no step counter outside [0, num_steps) reaches this instantiation (phx_sw_fsm_check_kernel).
+  int f_rws = 0, f_rew = -1, f_obs = -1, f_del = -1; bool fin_term = false;      // running reward index; the s_fo words of the most recent rewarded / observing row; ..
+  if (FSM && tid < G) f_rws = s_cv0[tid] ? SWF_RW_LAUNCH : SWF_RW_ZERO;
+  // (The rows cost the chain 19 VALU operations each against the plain one's 7, and every one of them shows in the launch's time --
+  //  the ablations in DESIGN.md: flags become lane masks by one v_bfe_i32 and select by one v_bfi_b32; the reset of an episode's last row
+  //  and the trackers of the state the fragment leaves are compiled in only for the chunks that need them: a wave none of whose lanes
+  //  ends an episode in the chunk, and every chunk but the fragment's last two -- the plan admits stage chains only whose acting /
+  //  observing / rewarded positions are at most 16 steps apart, so the most recent of each lies in those chunks or before the fragment.)
+  auto recurrence_fsm = [&](int c, int tc) __attribute__((always_inline)) {
+    const int tend = a.num_steps - 1 - step;
+    const bool ends = tend >= 0 && tend < tc;
+    if (tid >= G) return;
+    __builtin_amdgcn_s_setprio(3);
+    const uint16_t* rdw = s_rd0 + (c % 3) * items + tid;
+    uint32_t* fo = s_fo0 + (c & 1) * items + tid;
+    auto sel = [](int m, int yes, int no) { return (m & yes) | (~m & no); };                       // v_bfi_b32
+    auto one = [&](int h, int w, auto ENDS, auto TRACK) __attribute__((always_inline)) {
+      const int R = w & 127, D = (w >> 8) & 31;
+      const int sales = min(x, D), del = min(R, PHX_SHOP_MAX_STOCK - x), xn = x - sales + del;
+      const int pack = xn | (sales << 7) | ((D - sales) << 12);          // what the row would observe, and the operands of its reward
+      fin_xb = x; fin_rd = w;
+      const int m_rew = __builtin_amdgcn_sbfe(w, 13, 1), m_obs = __builtin_amdgcn_sbfe(w, 7, 1);  // all ones where the row is rewarded / observes
+      f_rws = sel(m_rew, 10 * sales - xn + (100 + SWF_RW_CACHED), f_rws);
+      fo[h * G] = (uint32_t)sel(m_obs, pack | (f_rws << 17), SWF_RW_ZERO << 17);
+      if (decltype(TRACK)::value) {
+        f_rew = sel(m_rew, pack, f_rew); f_obs = sel(m_obs, pack, f_obs);
+        f_del = sel(__builtin_amdgcn_sbfe(w, 14, 1), del, f_del);
+      }
+      x = xn;
+      if (decltype(ENDS)::value) { const bool last = h == tend; x = last ? 0 : xn; f_rws = last ? SWF_RW_ZERO : f_rws; }      // the caller's env.reset(): stock 0, nothing cached
+    };
+    auto chunk = [&](auto ENDS, auto TRACK) __attribute__((always_inline)) {
+      if (tc == TC) {
+        int rd[TC];
+#pragma unroll
+        for (int h = 0; h < TC; ++h) rd[h] = rdw[h * G];
+#pragma unroll
+        for (int h = 0; h < TC; ++h) one(h, rd[h], ENDS, TRACK);
+      } else for (int h = 0; h < tc; ++h) one(h, rdw[h * G], ENDS, TRACK);
+    };
+    const bool track = c >= n_chunks - 2, any_end = __ballot(ends) != 0ull;
+    if (track) chunk(std::true_type{}, std::true_type{});
+    else if (any_end) chunk(std::true_type{}, std::false_type{});
+    else chunk(std::false_type{}, std::false_type{});
+    fin_term = ends && tend == tc - 1;
+    step += tc;
+    if (ends) step -= a.num_steps;
+    __builtin_amdgcn_s_setprio(0);
+  };
+
   // ---- outputs of chunk c into the staged tile, by the workers -------------------------------------------------------
   // A work unit is 4 consecutive pairs of one tile row: 12 observation floats and 4 rewards, from the two u16 tiles and
   // the tables; written to LDS in the layout of the trajectory rows (the store waves copy whole rows of pieces).  Where
@@ -430,10 +556,11 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     // knows the alignment of every access (b64 reads, b128 writes) although the section offsets are run-time values
     const uint2* const t_rd = (const uint2*)smem + (((int)((const char*)s_rd0 - smem) + (c % 3) * items * 2) >> 3);
     const uint2* const t_xx = (const uint2*)smem + (((int)((const char*)s_xx0 - smem) + (c & 1) * items * 2) >> 3);
+    const uint4* const t_fo = (const uint4*)smem + (((int)((const char*)s_fo0 - smem) + (c & 1) * items * 4) >> 4);
     float4* const o_obs4 = (float4*)smem + (((int)((const char*)s_out0 - smem) >> 4) + (c & 1) * items);
     float4* const o_rew4 = o_obs4 + 3 * (items >> 2);
     const int n_units = tc * G4, dr = out_fixed ? nwk / G4 : 0;
-    const bool guard = weird && c == 0;
+    const bool guard = !FSM && weird && c == 0;
     const uint32_t c32 = ((uint32_t)tid & 31u) << 2, c8 = ((uint32_t)tid & 7u) << 2;      // the lane's table copies (byte offsets)
     const char* const t_s = (const char*)s_tabs; const char* const t_n = (const char*)s_tabn; const char* const t_r = (const char*)s_rtab;
     int r = ol_r0;
@@ -441,15 +568,26 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       int gl0 = ol_gl0;
       if (!out_fixed) { r = (int)div_G4((uint32_t)u); gl0 = (u - (int)__umul24(r, G4)) << 2; }
       const int j4 = (int)__umul24(r, G4) + (gl0 >> 2);                  // the unit's index: its four items start at 4 * j4
-      const uint2 vx = t_xx[j4], vr = t_rd[j4];
+      uint2 vx = make_uint2(0u, 0u), vr = vx;
+      uint4 vf = make_uint4(0u, 0u, 0u, 0u);
+      if (FSM) vf = t_fo[j4]; else { vx = t_xx[j4]; vr = t_rd[j4]; }     // FSM: one word per item holds everything the row emits
+      // (measured, dropped: waves whose units are all silent -- every second row of a RESTOCK / SELL chain, with the rows dealt by parity --
+      //  writing zeros without the lookups: +32 us per T = 400 launch of config 3; the iteration ends with its slowest wave either way)
       const uint32_t xw[4] = {vx.x & 0xffffu, vx.x >> 16, vx.y & 0xffffu, vx.y >> 16};
       const uint32_t rw4[4] = {vr.x & 0xffffu, vr.x >> 16, vr.y & 0xffffu, vr.y >> 16};
+      const uint32_t fo4[4] = {vf.x, vf.y, vf.z, vf.w};
       float o[12], rw[4];
       if (!guard) {
         // sixteen table lookups in ONE LDS round trip: the addresses first, then the loads
         uint32_t as_[4], an_[4], am_[4], ar_[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          if (FSM) {
+            const uint32_t w = fo4[k];
+            as_[k] = ((w & 127u) << 7) | c32; an_[k] = (((w >> 7) & 31u) << 7) | c32; am_[k] = (((w >> 12) & 31u) << 7) | c32;
+            ar_[k] = (((w >> 17) & 0x1FFu) << 5) | c8;                  // the cached reward the row emits
+            continue;
+          }
           const int x0 = (int)(xw[k] & 255u), xa = (int)(xw[k] >> 8), D = (int)(rw4[k] >> 8);
           const int sales = min(x0, D), missed = D - sales;             // handle_order_request :105-122 (sales == x0 - max(x0 - D, 0))
           as_[k] = ((uint32_t)xa << 7) | c32; an_[k] = ((uint32_t)sales << 7) | c32; am_[k] = ((uint32_t)missed << 7) | c32;
@@ -465,6 +603,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
 #else
           rw[k] = *(const float*)(t_r + ar_[k]);                        // compute_reward :147, rounded once to f32
 #endif
+        }
+        if (FSM && __builtin_expect(((fo4[0] | fo4[1] | fo4[2] | fo4[3]) & SWF_FO_LAUNCH) != 0u, 0)) {      // rows before the fragment's first rewarded step
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (fo4[k] & SWF_FO_LAUNCH) rw[k] = s_rc0[gl0 + k];
         }
       } else {
 #pragma unroll
@@ -571,6 +713,8 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       const uint32_t n = (r_hi - r_lo) * PF;
       char* const p_tru = (char*)(a.frag[fr].truncated + g_base);
       char* const p_ter = a.frag[fr].terminated ? (char*)(a.frag[fr].terminated + g_base) : nullptr;
+      char* const p_ov = FSM ? (char*)(a.frag[fr].obs_valid + g_base) : nullptr;
+      char* const p_rv = FSM ? (char*)(a.frag[fr].reward_valid + g_base) : nullptr;
 #pragma unroll 1
       for (uint32_t f = (uint32_t)sl; f < n; f += (uint32_t)nsl) {
         const uint32_t rr = div_PF(f), pc = f - rr * PF, t = r_lo + rr;
@@ -591,6 +735,34 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         const size_t off = (size_t)(t - f_lo) * (size_t)utotal + (size_t)(pc * 16u);
         *(uint4*)(p_tru + off) = v;                                          // (plain stores: a flag row of the block is G bytes, not whole lines)
         if (p_ter) *(uint4*)(p_ter + off) = make_uint4(0u, 0u, 0u, 0u);
+        if (FSM) {
+          // obs_valid / reward_valid of row t: functions of the pair's episode position p = (step at launch + t) mod num_steps -- with
+          // et = num_steps - 1 - step that is x - 1 - et (+ num_steps) -- and, for the rows of the launch's own episode before its first
+          // rewarded position, of the cache's validity at launch:   obs_valid = OBS(p),   reward_valid = OBS(p) ? (cached ? 1 : 2) : 0
+          // (fsm.py:360-378).  Envs in step (the usual case) share one position per piece: one lookup, splat.
+          const uint32_t et0 = ea.x & 0xFFFFu, sp0 = et0 | (et0 << 16);
+          const bool same = ((ea.x ^ sp0) | (ea.y ^ sp0) | (ea.z ^ sp0) | (ea.w ^ sp0) | (eb.x ^ sp0) | (eb.y ^ sp0) | (eb.z ^ sp0) | (eb.w ^ sp0)) == 0u;
+          auto pos_of = [&](uint32_t et) { int p = (int)x - 1 - (int)et; if (p < 0) p += (int)ns; return p; };
+          const uint32_t fl0 = s_pf[pos_of(et0)];
+          uint4 vo, vr;
+          if (same && (!(fl0 & SWF_OBS) || (fl0 & SWF_HASREW) || t > et0)) {
+            const uint32_t ob = (fl0 & SWF_OBS) ? 0x01010101u : 0u, rb = !(fl0 & SWF_OBS) ? 0u : ((fl0 & SWF_HASREW) ? 0x01010101u : 0x02020202u);
+            vo = make_uint4(ob, ob, ob, ob); vr = make_uint4(rb, rb, rb, rb);
+          } else {
+            uint32_t wo[4] = {0u, 0u, 0u, 0u}, wr[4] = {0u, 0u, 0u, 0u};
+            for (int b = 0; b < 16; ++b) {
+              const uint32_t et = s_ftend[16u * pc + b], fl = s_pf[pos_of(et)];
+              if (fl & SWF_OBS) {
+                const bool cached = (fl & SWF_HASREW) || (t <= et && s_cv0[16u * pc + b]);
+                wo[b >> 2] |= 1u << (8 * (b & 3)); wr[b >> 2] |= (cached ? 1u : 2u) << (8 * (b & 3));
+              }
+            }
+            vo = make_uint4(wo[0], wo[1], wo[2], wo[3]); vr = make_uint4(wr[0], wr[1], wr[2], wr[3]);
+          }
+#ifndef SWF_ABL_NOFLAGS
+          *(uint4*)(p_ov + off) = vo; *(uint4*)(p_rv + off) = vr;
+#endif
+        }
       }
     }
 #endif
@@ -601,14 +773,36 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   auto finish = [&]() __attribute__((always_inline)) {
   if (tid < G) {
     const int64_t g = g_base + tid;
-    const int R = fin_rd & 255, D = fin_rd >> 8;
+    const int R = FSM ? fin_rd & 127 : fin_rd & 255, D = FSM ? (fin_rd >> 8) & 31 : fin_rd >> 8;
     const int xb = fin_xb;
     const int sales = min(xb, D), missed = D - sales;
-    a.stock[g] = x; a.sales[g] = sales; a.missed[g] = missed; a.delivered[g] = min(R, PHX_SHOP_MAX_STOCK - xb);
-    if (io.last_obs) {
-      float ob[3];
-      shop_obs(x, sales, missed, a.norm, ob);
-      io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
+    a.stock[g] = x; a.sales[g] = sales; a.missed[g] = missed;
+    if (!FSM) {
+      a.delivered[g] = min(R, PHX_SHOP_MAX_STOCK - xb);
+      if (io.last_obs) {
+        float ob[3];
+        shop_obs(x, sales, missed, a.norm, ob);
+        io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
+      }
+    } else {
+      // what fsm.py's caches and the shop hold after the fragment's last step
+      if (f_del >= 0) a.delivered[g] = f_del;                            // the most recent acting step's delivery (never reset)
+      if (f_rew >= 0) a.rew_cache[g] = shop_reward((f_rew >> 7) & 31, f_rew & 127);        // the value outlives a reset, its validity does not
+      if (f_rws != SWF_RW_LAUNCH) a.rew_cache_v[g] = (f_rws & SWF_RW_CACHED) ? 1 : 0;
+      if (f_obs >= 0) {
+        float ob[3];
+        shop_obs_f32(f_obs & 127, (f_obs >> 7) & 31, (f_obs >> 12) & 31, (float)a.norm, ob);
+        a.obs_cache[g * 3] = ob[0]; a.obs_cache[g * 3 + 1] = ob[1]; a.obs_cache[g * 3 + 2] = ob[2];
+        a.obs_cache_v[g] = 1;
+      }
+      if (io.last_obs) {
+        // the observation the next fragment starts from: the one the last row emitted, or after an episode end the reset's (a shop
+        // that acts in the initial stage observes its reset state: stock 0, the last step's sales, fsm.py:237-251)
+        float ob[3] = {0.f, 0.f, 0.f};
+        if (fin_term) { if (s_pf[0] & SWF_ACT) shop_obs_f32(0, sales, missed, (float)a.norm, ob); }
+        else if (fin_rd & (int)SWF_OBS) shop_obs_f32(x, sales, missed, (float)a.norm, ob);
+        io.last_obs[g * 3 + 0] = ob[0]; io.last_obs[g * 3 + 1] = ob[1]; io.last_obs[g * 3 + 2] = ob[2];
+      }
     }
     const uint32_t pr = s_pair[tid];
     const int bl = (int)(pr >> 8);
@@ -619,6 +813,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       const int n_touch = (int)((p0 + nS - 1) / G - p0 / G) + 1;
       if (n_touch == 1 || atomicAdd(&a.env_arrive[b], 1) + 1 == n_touch) {
         a.env_step[b] = step; a.env_tick[b] = s_tick0[bl] + a.T;
+        if (FSM) {                                                       // the stage the next step runs in, and the last one's (fsm.py:355)
+          a.env_stage[b] = (int32_t)a.fsm_tab[a.num_steps + step];
+          a.env_prev_stage[b] = (int32_t)a.fsm_tab[a.num_steps + (step > 0 ? step - 1 : a.num_steps - 1)];
+        }
         if (n_touch > 1) a.env_arrive[b] = 0;
       }
     }
@@ -667,7 +865,11 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd);
       STICK(1);
     } else if (tid < rec_threads) {
+#ifdef SWF_ABL_PLAINREC
       if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
+#else
+      if (cr >= 0 && cr < n_chunks) { if (FSM) recurrence_fsm(cr, rows_of(cr)); else recurrence(cr, rows_of(cr)); }
+#endif
       else if (it == -2 && pass == 0) replicate_tables(tid, work_first);
       else if (cr == n_chunks) finish();
       STICK(3);
@@ -729,7 +931,8 @@ static const size_t SW_LDS_MAX = 160 * 1024;
 
 // Decides whether an env shape takes the store-wave kernel and with which workgroup shape.  `block`: phx_spec.variant_block
 // (0 = auto; > 0: pairs per workgroup, taken when it is a multiple of 16 that divides B * S).
-bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, ScSwPlan* p) {
+// `fsm_ns` > 0: the FSM instantiation's plan (its LDS sections sized for num_steps = fsm_ns positions).
+bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_steps, int block, ScSwPlan* p, int fsm_ns) {
   memset(p, 0, sizeof *p);
   if (K_uniform < 1 || K_uniform > 6 || !norm_uniform || S < 1 || S > 255 || block < 0 || num_steps >= 0xFFFF) return false;
   const int64_t total = (int64_t)B * S;
@@ -741,7 +944,7 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   auto epb_of = [&](int G) { return (G + S - 2) / S + 1; };                        // the most envs a block can touch
   auto pairs_ok = [&](int G) { return G >= 16 && G <= 256 && G % 16 == 0 && total % G == 0 && epb_of(G) <= 255; };
   auto tc_ok = [&](int G, int tc) {
-    return tc <= num_steps && (int64_t)tc * total * 12 < ((int64_t)1 << 32) && sw_lds_bytes(G, epb_of(G), tc, dtab_n) <= SW_LDS_MAX;
+    return tc <= num_steps && (int64_t)tc * total * 12 < ((int64_t)1 << 32) && sw_lds_bytes(G, epb_of(G), tc, dtab_n, fsm_ns) <= SW_LDS_MAX;
   };
   auto tc_for = [&](int G) {
     if (tc_env == 16 || tc_env == 20) return tc_ok(G, tc_env) ? tc_env : 0;
@@ -757,7 +960,7 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
     for (int cand = 192; cand >= 16; cand -= 16) {
       if (!pairs_ok(cand) || !tc_for(cand)) continue;
       const int64_t nblk = total / cand;
-      const size_t lds = sw_lds_bytes(cand, epb_of(cand), tc_for(cand), dtab_n);
+      const size_t lds = sw_lds_bytes(cand, epb_of(cand), tc_for(cand), dtab_n, fsm_ns);
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(SW_LDS_MAX / lds, 2));
       const int64_t slots = 256 * (int64_t)per_cu, rounds = (nblk + slots - 1) / slots;
       const double eff = (double)nblk / (double)(rounds * slots);
@@ -773,7 +976,7 @@ bool phx_sc_sw_plan(int B, int S, int K_uniform, bool norm_uniform, int num_step
   if (work < 1) work = 1;
   if (p->n_rec + p->n_store + work > 16) work = 16 - p->n_rec - p->n_store;
   p->nt = 64 * (p->n_rec + p->n_store + work);
-  p->lds = (int32_t)sw_lds_bytes(G, p->epb, p->tc, dtab_n);
+  p->lds = (int32_t)sw_lds_bytes(G, p->epb, p->tc, dtab_n, fsm_ns);
   // the shapes with a compile-time instantiation (any number of rounds of workgroups: a round of 144-pair workgroups costs the same
   // whether it is the launch's only one or one of four -- B = 8 192 / 16 384: 113 / 221 us per T = 400 against 137 / 242)
   p->specialised = (p->tc == 16 && ((G == 144 && p->n_rec == 3 && work == 9 && (p->n_store == 4 || p->n_store == 2)) ||
@@ -792,8 +995,23 @@ __global__ __launch_bounds__(256) void phx_sw_scan_actions_kernel(const float* _
   if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(flag, gen);
 }
 
+// FSM instantiation: is every env on the tabulated stage chain (its stage the one the table holds for its step counter, the counter inside
+// the episode) and every stock inside [0, 100]?  Otherwise *flag = gen: the store-wave launch returns at entry and the lane-per-pair loop
+// (phx_sc_fused.hip), launched behind it with the same word, serves the call.
+__global__ __launch_bounds__(256) void phx_sw_fsm_check_kernel(const int32_t* __restrict__ env_step, const int32_t* __restrict__ env_stage, const int32_t* __restrict__ stock,
+                                                               const uint16_t* __restrict__ tab, int num_steps, int S, int64_t total, int32_t* flag, int32_t gen) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / S;
+    const int stp = env_step[b];
+    bad |= (unsigned)stock[i] > (unsigned)PHX_SHOP_MAX_STOCK || stp < 0 || stp >= num_steps || env_stage[b] != (int)tab[num_steps + (stp < 0 || stp >= num_steps ? 0 : stp)];
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(flag, gen);
+}
+
 hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, int32_t guard_gen) {
-  const ScSwPlan& p = sp.sc_sw;
+  const bool fsm = sp.env_type == PHX_ENV_FSM;
+  const ScSwPlan& p = fsm ? sp.fsm_sw : sp.sc_sw;
   const bool replay = io.actions != nullptr || io.exo != nullptr;
   SwArgs a; memset(&a, 0, sizeof a);
   a.B = sp.B; a.S = sp.S; a.epb = p.epb; a.G = p.G; a.K = p.K; a.T = io.T; a.num_steps = sp.num_steps;
@@ -810,6 +1028,12 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.env_step = (int32_t*)sp.f[F_ENV_STEP]; a.env_tick = (int32_t*)sp.f[F_ENV_TICK]; a.env_arrive = (int32_t*)sp.f[F_ENV_ARRIVE];
   a.tables = (const float4*)sp.sc_sw_tables;
   a.io = io;
+  if (fsm) {
+    a.fsm_tab = sp.fsm_sw_tab;
+    a.env_stage = (int32_t*)sp.f[F_ENV_STAGE]; a.env_prev_stage = (int32_t*)sp.f[F_ENV_PREV_STAGE];
+    a.rew_cache = (double*)sp.f[F_ENV_REW_CACHE]; a.rew_cache_v = (uint8_t*)sp.f[F_ENV_REW_CACHE_VALID];
+    a.obs_cache = (float*)sp.f[F_ENV_OBS_CACHE]; a.obs_cache_v = (uint8_t*)sp.f[F_ENV_OBS_CACHE_VALID];
+  }
   a.n_exo = sp.n_exo; a.exo_first = sp.sc_sw_exo_first; a.guard = nullptr; a.guard_gen = guard_gen;
   if (io.actions && guard_gen != 0) {     // the pre-scan of this call's actions decides between this kernel and round 1's (same stream: ordered);
                                           // guard_gen == 0: the caller vouched for the actions (PHX_RH_ACTIONS_IN_DOMAIN)
@@ -817,13 +1041,20 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
     a.guard = sp.sc_sw_guard;
     hipLaunchKernelGGL(phx_sw_scan_actions_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 2048)), dim3(256), 0, st, io.actions, n, sp.sc_sw_guard, guard_gen);
   }
+  if (fsm) {                              // (same stream: the check is ordered before the launch it guards)
+    const int64_t total = (int64_t)sp.B * sp.S;
+    a.guard = sp.fsm_irregular;
+    hipLaunchKernelGGL(phx_sw_fsm_check_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, st, a.env_step, a.env_stage, a.stock,
+                       sp.fsm_sw_tab, sp.num_steps, sp.S, total, sp.fsm_irregular, guard_gen);
+  }
   // trajectory fragments: the caller's list (phx_rollout_io.frags, validated by phx_rollout) or the io's own planes as the only one
   if (io.n_frag > 1) {
     a.n_frag = io.n_frag; a.frag_T = io.T / io.n_frag;
-    for (int f = 0; f < io.n_frag; ++f) a.frag[f] = SwFrag{io.frags[f].obs, io.frags[f].action_out, io.frags[f].reward, io.frags[f].terminated, io.frags[f].truncated};
+    for (int f = 0; f < io.n_frag; ++f) a.frag[f] = SwFrag{io.frags[f].obs, io.frags[f].action_out, io.frags[f].reward, io.frags[f].terminated, io.frags[f].truncated,
+                                                           io.frags[f].obs_valid, io.frags[f].reward_valid};
   } else {
     a.n_frag = 1; a.frag_T = io.T;
-    a.frag[0] = SwFrag{io.obs, io.action_out, io.reward, io.terminated, io.truncated};
+    a.frag[0] = SwFrag{io.obs, io.action_out, io.reward, io.terminated, io.truncated, io.obs_valid, io.reward_valid};
   }
   // the grid: one workgroup per pair group up to what the chip holds at once, the rest of the groups are walked by the same workgroups
   a.n_groups = (int32_t)(((int64_t)sp.B * sp.S) / p.G);
@@ -860,18 +1091,20 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
         for (unsigned b = 0; b < grid.x; ++b) for (int w = 0; w < nwv; ++w) { const int rr = w < p.n_rec ? 0 : (w < p.n_rec + p.n_store ? 1 : 2); if (rr != r) continue; ++n; for (int q = 0; q < 8; ++q) sum[q] += (double)h[((size_t)b * 16 + w) * 8 + q]; }
         fprintf(stderr, "SW_TIMING %s waves (%d): setup %.0f (before 1st barrier %.0f, in it %.0f) | draws %.0f | outputs %.0f | rec %.0f | stores %.0f | barrier %.0f   cycles per wave and launch\n", role[r], n, sum[0]/n, sum[6]/n, sum[7]/n, sum[1]/n, sum[2]/n, sum[3]/n, sum[4]/n, sum[5]/n); } } } }
 #endif
-  phx_note_kernel(replay ? "phx_sc_rollout_sw_kernel[replay]" : "phx_sc_rollout_sw_kernel");
+  phx_note_kernel(fsm ? "phx_sc_rollout_sw_kernel[fsm]" : (replay ? "phx_sc_rollout_sw_kernel[replay]" : "phx_sc_rollout_sw_kernel"));
   // more than 64 KB of dynamic LDS needs the attribute (once per instantiation and device)
 #define SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, RP_) do { \
     static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev); \
     if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
     hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
-#define SW_LAUNCH(TC_, GT_, NREC_, NSTORE_, NWORK_) do { if (replay) SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, true); else SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, false); } while (0)
+#define SW_LAUNCH_PLAIN(TC_, GT_, NREC_, NSTORE_, NWORK_) do { if (replay) SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, 1); else SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, 0); } while (0)
+#define SW_LAUNCH(TC_, GT_, NREC_, NSTORE_, NWORK_) do { if (fsm) SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, 2); else SW_LAUNCH_PLAIN(TC_, GT_, NREC_, NSTORE_, NWORK_); } while (0)
   const int generic_env = phx_knobs().sw_generic;      // development: the run-time-shape instantiation
   const int work = p.nt / 64 - p.n_rec - p.n_store;
 #define SW_SHAPE(G_, NREC_, NSTORE_, NWORK_) (p.tc == 16 && p.G == G_ && p.n_rec == NREC_ && p.n_store == NSTORE_ && work == NWORK_)
-  if (!generic_env && SW_SHAPE(144, 3, 4, 9)) SW_LAUNCH(16, 144, 3, 4, 9);
-  else if (!generic_env && SW_SHAPE(144, 3, 2, 9)) SW_LAUNCH(16, 144, 3, 2, 9);
+  // (144-pair workgroups: no FSM instantiation -- its sections do not fit beside 16-row tiles of 144 pairs)
+  if (!generic_env && !fsm && SW_SHAPE(144, 3, 4, 9)) SW_LAUNCH_PLAIN(16, 144, 3, 4, 9);
+  else if (!generic_env && !fsm && SW_SHAPE(144, 3, 2, 9)) SW_LAUNCH_PLAIN(16, 144, 3, 2, 9);
   else if (!generic_env && SW_SHAPE(128, 2, 4, 8)) SW_LAUNCH(16, 128, 2, 4, 8);
   else if (!generic_env && SW_SHAPE(96, 2, 4, 6)) SW_LAUNCH(16, 96, 2, 4, 6);
   else if (!generic_env && SW_SHAPE(96, 2, 2, 6)) SW_LAUNCH(16, 96, 2, 2, 6);
@@ -880,6 +1113,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   else SW_LAUNCH(16, 0, 0, 0, 0);
 #undef SW_SHAPE
 #undef SW_LAUNCH
+#undef SW_LAUNCH_PLAIN
 #undef SW_LAUNCH_
   return hipGetLastError();
 }

@@ -244,6 +244,7 @@ FSM_VARIANTS = [
     ({"rollout": "time_parallel"}, "phx_sc_rollout_fsmfast_kernel"),
     ({"rollout": "time_parallel", "block": 32}, "phx_sc_rollout_fsmfast_kernel[pairs]"),
     ({"rollout": "lean"}, "phx_sc_rollout_fsm_lean_kernel"),
+    ({"rollout": "store_waves"}, "phx_sc_rollout_sw_kernel[fsm]"),          # round 5: the store-wave kernel's FSM instantiation (tests/test_gpu_fsm_sw.py)
     ({"rollout": "general"}, "phx_sc_rollout_fsm_kernel"),
     ({"rollout": "launch_loop"}, "phx_generic_step_kernel"),
 ]
@@ -287,7 +288,9 @@ def test_fsm_rollout_variants_match_oracle(S, K, B, num_steps, variants, kernel)
     # (the time-parallel FSM kernel's plan needs num_steps >= 20 and <= 40 KB of LDS: 51-shop envs take 48-pair blocks that exceed it)
     # and a position table whose lookbacks fit; the SC64 shape meets every precondition)
     tp_ok = (S, K, num_steps) == (9, 6, 100)
-    if variants["rollout"] != "time_parallel" or tp_ok:
+    # (the store-wave instantiation: 16-pair-aligned workgroups, an even num_steps >= 16 -- the chain's last position observes)
+    sw_ok = (B * S) % 16 == 0 and num_steps >= 20 and num_steps % 2 == 0
+    if (variants["rollout"] != "time_parallel" or tp_ok) and (variants["rollout"] != "store_waves" or sw_ok):
         assert any(kernel in u for u in used), (kernel, used)
 
 

@@ -26,7 +26,8 @@ env = cls(n_shops=a.shops, customers_per_shop=a.cust, num_steps=100, batch_size=
           variants={"block": blk, "rollout": a.rollout})
 env.reset(); dev = env._device()
 S = a.shops
-alg = a.batch * a.T * 22 * S + a.batch * (S * 32 + 16)
+PB = 24 if a.fsm else 22                    # bytes per pair and step: the FSM's obs_valid / reward_valid planes
+alg = a.batch * a.T * PB * S + a.batch * (S * 32 + 16)
 nb = a.bufs or max(2, -(-(320 << 20) // alg))
 trs = [dev.alloc_trajectory(a.T) for _ in range(nb)]
 tr = dev.rollout(a.T, out=trs[0])
@@ -56,5 +57,5 @@ for rep in range(3):
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / a.n * 1e3)
 tot = a.T * k
-alg_call = a.batch * tot * (22 * S + (4 * S if "a" in a.replay else 0) + (S * a.cust if "x" in a.replay else 0)) + a.batch * (S * 32 + 16)   # (+ the replayed inputs' reads)
+alg_call = a.batch * tot * (PB * S + (4 * S if "a" in a.replay else 0) + (S * a.cust if "x" in a.replay else 0)) + a.batch * (S * 32 + 16)   # (+ the replayed inputs' reads)
 print(f"{a.tag:28s} T={a.T:5d} x{k} bufs={nb:2d} {best:8.2f} us/call  {best * 100 / tot:7.2f} us/100 steps  {alg_call / best / 1e3 / 8000:.3f} of 8 TB/s  sha {h.hexdigest()[:12]}  {dev.last_kernel()}", flush=True)
