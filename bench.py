@@ -197,10 +197,28 @@ def other_configs(device):
     tr = dev.rollout(100)
     add("SC256 FSM B=8192 (config 3)", 256, 8192, 100, timed(lambda: dev.rollout(100, out=tr), 40), "fused FSM rollout T=100",
         bytes_per_env_step=24 * 51)                              # trajectory: obs 12 + action 4 + reward 4 + 4 flag bytes per shop
+    res[-1]["kernels"] = dev.last_kernel()
     tr4 = dev.alloc_trajectory(400)                              # the headline's fragment length: start-up / drain paid once per 400 steps
     add("SC256 FSM B=8192 (config 3)", 256, 8192, 400, timed(lambda: dev.rollout(400, out=tr4), 16), "fused FSM rollout T=400",
         bytes_per_env_step=24 * 51)
+    res[-1]["kernels"] = dev.last_kernel()                       # (PHX_VR_AUTO: the store-wave kernel's FSM instantiation from T = 200 on)
     del tr4
+    fr3 = [dev.alloc_trajectory(100) for _ in range(4)]
+    add("SC256 FSM B=8192 (config 3)", 256, 8192, 400, timed(lambda: dev.rollout_fragments(100, fr3), 16),
+        "fused FSM rollout, 4 fragments of T=100 per call (phx_rollout_io.frags)", bytes_per_env_step=24 * 51)
+    res[-1]["kernels"] = dev.last_kernel()
+    del fr3
+    try:                                                         # the lane-per-pair loop on the same launch (variants={"rollout": "lean"}): bimodal by the buffers' placement
+        envl = ph.SupplyChainFSMEnv(n_shops=51, customers_per_shop=4, num_steps=100, batch_size=8192, seed=42, exogenous="device", device=device,
+                                    variants={"rollout": "lean"})
+        envl.reset(); devl = envl._device()
+        trl = devl.alloc_trajectory(400)
+        add("SC256 FSM B=8192 (config 3)", 256, 8192, 400, timed(lambda: devl.rollout(400, out=trl), 16), "fused FSM rollout T=400, lane-per-pair loop",
+            bytes_per_env_step=24 * 51)
+        res[-1]["kernels"] = devl.last_kernel()
+        del envl, devl, trl
+    except Exception as exc:
+        res.append({"config": "SC256 FSM B=8192 (config 3)", "mode": "lane-per-pair loop", "error": str(exc)[:200]})
     acts = torch.rand(8192, 51, device=dev.device) * 100.0
     # per env-step: S * (43 + K) + 6 with device-RNG orders (no exo term: S * 43 + 6), + stage and valid planes
     step_bytes = 51 * 43 + 6 + 2 * 51 + 2

@@ -24,6 +24,7 @@
 __host__ __device__ inline size_t g_stk_paid_off(int nSell) { return ((size_t)nSell * (8 + 8 + 8 + 4 + 4 + 1) + 15) & ~(size_t)15; }
 #ifdef PHX_TIMING
 __device__ unsigned long long g_stk_tm[8];
+__device__ unsigned long long g_stk_rt[8];      // wall clock (100 MHz) of the last rollout launch: [0] min entry, [1] max exit, [2..4] sums of setup / loop / epilogue, [5] blocks, [6] sum of (entry - min entry)
 #define STICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); stm[k] += now_ - sprev; sprev = now_; } while (0)
 #else
 #define STICK(k) do {} while (0)
@@ -403,6 +404,9 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
 #define io (*(const phx_rollout_io*)(kp + 8))
 #define STKR_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
   STKR_REFRESH();
+#ifdef PHX_TIMING
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int A = sp.A, B = sp.B;
@@ -451,6 +455,17 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     const int a = tid + k * NT;
     rec[k] = 0; rw2[k] = 0; rt2[k] = 0xffffffffu;
     nbp[k][0] = nbp[k][1] = nbp[k][2] = nbp[k][3] = 0;
+    if (!dyn && sp.stk_packed) {
+      // the host's packed per-agent tables (the fast step kernel's): three independent loads per slot instead of a chain of up to twelve
+      // (record -> flags -> eight neighbour ranks) -- the block's setup was ~45 us of a launch's 180 us fixed cost at 4 096 envs
+      if (a < A) {
+        const uint32_t r = sp.stk_rec2[a];
+        const uint4 ag = *(const uint4*)(sp.stk_agent + 4 * a);
+        const double v = sp.param_f[a * PHX_NPF];
+        rec[k] = r; nbp[k][0] = ag.x; nbp[k][1] = ag.y; nbp[k][2] = ag.z; nbp[k][3] = ag.w;
+        if (!(r & 1u)) s_val[r >> 16] = v;
+      }
+    } else
     if (a < A) {
       const uint32_t r = sp.stk_rec[a];
       const bool seller = (r & 255u) == PHX_KIND_SELLER;
@@ -473,6 +488,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   __syncthreads();
 #ifdef PHX_TIMING
   unsigned long long stm[8] = {0}, sprev = __builtin_readcyclecounter();
+  const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // a buyer's cheapest current neighbour: first minimum in neighbour order (price slots hold the sellers' posted
@@ -496,6 +512,28 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       }
     }
     return best;
+  };
+
+  // The buyers' cheapest neighbour is needed twice per pair of steps -- by the observation after the leaders' step (min over the price
+  // slots) and by the order of the followers' step -- from the SAME posted prices: they change only in the booking pass of a step in
+  // which a seller acts, at a reset, and (dynamic graphs) with the connectivity a reset resamples.  The lane keeps the seller's rank per
+  // slot (one byte each: 0xFE not computed since the last change, 0xFF no neighbour) and reads its price back from LDS: one lookup instead
+  // of eight dependent ones (the kernel is bound by its ~150 instructions per agent and step, of which the two searches were ~55).
+  const bool cj_ok = nSell <= 253 && STKR_SLOTS <= 4;
+  bool my_sa_lead = false, my_sa_foll = false;
+#pragma unroll
+  for (int k = 0; k < STKR_SLOTS; ++k) if (rec[k] & 1u) { my_sa_lead |= ((rec[k] >> 1) & 1u) != 0; my_sa_foll |= ((rec[k] >> 4) & 1u) != 0; }
+  const bool sa_lead = __syncthreads_or(my_sa_lead) != 0, sa_foll = __syncthreads_or(my_sa_foll) != 0;     // does any seller act on a leaders' / followers' step
+  uint32_t cj = 0xFEFEFEFEu;
+  auto cheapest_c = [&](int k, int kr, int deg, int& jr) __attribute__((always_inline)) {
+    const uint32_t c = (cj >> (8 * k)) & 255u;
+    if (!cj_ok || c == 0xFEu) {
+      const double best = cheapest(k, kr, deg, jr);
+      cj = (cj & ~(255u << (8 * k))) | ((jr < 0 ? 255u : (uint32_t)jr) << (8 * k));
+      return best;
+    }
+    jr = c == 255u ? -1 : (int)c;
+    return jr >= 0 ? s_posted[jr] : 0.0;
   };
 
   for (int t = 0; t < io.T; ++t) {
@@ -538,7 +576,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
           int bought = 0; double paid = 0.0;
           if (action > 0.5f && deg > 0) {
             int jr;
-            const double best = cheapest(k, kr, deg, jr);
+            const double best = cheapest_c(k, kr, deg, jr);
             if (jr >= 0) { bought = 1; paid = best; atomicAdd(&s_count[jr], 1); }
           }
           s_bought[kr] = (uint8_t)bought; s_paid[kr] = paid;
@@ -565,6 +603,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       s_count[kr] = 0; s_sent[kr] = 0;
     }
     stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
+    if ((tt & 1) ? sa_lead : sa_foll) cj = 0xFEFEFEFEu;                      // (uniform) the booking pass may have changed posted prices
     STICK(2);
     // ---- obs / reward / flags -> trajectory row (stackelberg.py:142-196) -----------------------------
     const bool terminal = (tt == sp.num_steps);
@@ -592,7 +631,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
           ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
         } else {
           int jr;
-          const double mn = cheapest(k, kr, deg, jr);                        // min over the price slots (none: 1.0)
+          const double mn = cheapest_c(k, kr, deg, jr);                      // min over the price slots (none: 1.0)
           ob0 = (float)(jr >= 0 ? mn : 1.0); ob1 = (float)s_val[kr];
         }
       }
@@ -633,6 +672,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       for (int k = tid; k < nSell; k += NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
       for (int k = tid; k < nBuy; k += NT) { s_paid[k] = 0.0; s_bought[k] = 0; }
       for (int a = tid; a < A; a += NT) s_cv[a] = 0;
+      cj = 0xFEFEFEFEu;
       if (dyn) {                                                             // resample_connectivity network.py:438-447
         for (int i = tid; i < sp.n_conn; i += NT) s_conn[i] = (uint8_t)rng_connection(sp.seed, genv, episode, i, sp.conn_rate[i]);
         ++episode; ++n_resets;
@@ -643,6 +683,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   }
 #ifdef PHX_TIMING
   if (blockIdx.x < 64 && (tid & 63) == 0 && (tid >> 6) == 1) for (int q = 0; q < 8; ++q) atomicAdd(&g_stk_tm[q], stm[q]);
+  const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
 #endif
   if (dyn && n_resets > 0) {
     for (int i = tid; i < sp.n_conn; i += NT) fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i] = s_conn[i];
@@ -659,6 +700,14 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     fld<double>(sp, F_ENV_REW_CACHE)[abase + a] = s_cache[a]; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[abase + a] = s_cv[a];
   }
   if (tid == 0) { fld<int32_t>(sp, F_ENV_STEP)[b] = step; fld<int32_t>(sp, F_ENV_TICK)[b] = (int32_t)tick; }
+#ifdef PHX_TIMING
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long rt_exit = __builtin_amdgcn_s_memrealtime();
+    atomicMin(&g_stk_rt[0], rt_entry); atomicMax(&g_stk_rt[1], rt_exit);
+    atomicAdd(&g_stk_rt[2], rt_loop - rt_entry); atomicAdd(&g_stk_rt[3], rt_end - rt_loop); atomicAdd(&g_stk_rt[4], rt_exit - rt_end); atomicAdd(&g_stk_rt[5], 1ull);
+  }
+#endif
 }
 #undef sp
 #undef io
@@ -673,7 +722,11 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
 #ifdef PHX_TIMING
   { static int calls = 0; if (getenv("PHX_TIMING_DUMP") && ++calls == 10) { (void)hipDeviceSynchronize(); unsigned long long h[8];
       (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stk_tm), sizeof h); fprintf(stderr, "STK_TIMING cycles per step (wave 1 of blocks < 64): act %.0f | bar %.0f | book+bar %.0f | out %.0f | bar %.0f\n",
-      h[0] / (9.0 * 64 * io.T), h[1] / (9.0 * 64 * io.T), h[2] / (9.0 * 64 * io.T), h[3] / (9.0 * 64 * io.T), h[4] / (9.0 * 64 * io.T)); } }
+      h[0] / (9.0 * 64 * io.T), h[1] / (9.0 * 64 * io.T), h[2] / (9.0 * 64 * io.T), h[3] / (9.0 * 64 * io.T), h[4] / (9.0 * 64 * io.T)); }
+    if (getenv("PHX_TIMING_DUMP") && calls >= 8 && calls <= 10) {
+      if (calls > 8) { (void)hipDeviceSynchronize(); unsigned long long r[8]; (void)hipMemcpyFromSymbol(r, HIP_SYMBOL(g_stk_rt), sizeof r); const double n = (double)r[5];
+        fprintf(stderr, "STK_RT launch %d: wall %.1f us | per block: setup %.2f loop %.2f epilogue %.2f us | blocks %.0f\n", calls - 1, (r[1] - r[0]) * 0.01, r[2] * 0.01 / n, r[3] * 0.01 / n, r[4] * 0.01 / n, n); }
+      unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stk_rt), z, sizeof z); } }
 #endif
   // threads per env: a block whose STKR_SLOTS passes cover the agents
   const int nt_env = phx_knobs().stk_rollout_nt;
