@@ -42,7 +42,7 @@ def run_rollout_case(case, journal=None):
                     }
         env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
                                variants=variants)
-        fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick")
+        fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick") + (("env.stage", "env.prev_stage") if fsm else ())
         amax, valid = 100.0, fsm
         desc = f"sc S={S} Ks={Ks if len(set(Ks)) > 1 else Ks[0]} B={B} num_steps={ns} fsm={int(fsm)} variants={variants}"
     else:

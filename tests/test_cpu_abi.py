@@ -226,3 +226,31 @@ def test_fragment_list_through_the_abi_equals_one_long_rollout(lib):
     assert lib.phx_rollout(lst.h, C.byref(io2), None) < 0
     io2.T, io2.obs = T, _p(whole["obs"])                       # the io's own planes beside a list
     assert lib.phx_rollout(lst.h, C.byref(io2), None) < 0
+
+
+def test_replay_hints_are_accepted_and_unknown_hint_bits_refused(lib):
+    """phx_rollout_io.hints (ABI 9): PHX_RH_ACTIONS_IN_DOMAIN / PHX_RH_EXO_IN_DOMAIN are the caller's word about replayed inputs -- they
+    change no result (here: the CPU stub, which has no byte tiles) -- and any other bit (bit 1 was PHX_RH_FLAGS_ZEROED until ABI 8) is an
+    argument error, as in the product."""
+    B, S, T = 4, 3, 9
+    env = supply_chain_env(S, [2] * S, 5, B, seed=2)
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(0, 100, (T, B, S)).astype(np.float32)
+    exo = rng.integers(0, 5, (T, B, env.spec.n_exo)).astype(np.uint8)
+    outs = []
+    for hints in (0, _abi.RH_ACTIONS_IN_DOMAIN | _abi.RH_EXO_IN_DOMAIN):
+        r = CpuAbiRunner(lib, env.spec); r.reset()
+        obs, act, rew = np.zeros((T, B, S, 3), np.float32), np.zeros((T, B, S), np.float32), np.zeros((T, B, S), np.float32)
+        ter, tru, last = np.zeros((T, B, S), np.uint8), np.zeros((T, B, S), np.uint8), np.zeros((B, S, 3), np.float32)
+        io = _abi.PhxRolloutIO()
+        io.T, io.hints = T, hints
+        io.actions, io.exo = _p(acts), _p(exo)
+        io.obs, io.action_out, io.reward, io.terminated, io.truncated, io.last_obs, io.err = _p(obs), _p(act), _p(rew), _p(ter), _p(tru), _p(last), _p(r.err)
+        assert lib.phx_rollout(r.h, C.byref(io), None) == 0
+        outs.append((obs, rew, tru))
+        io.hints = hints | 1
+        assert lib.phx_rollout(r.h, C.byref(io), None) < 0
+        io.hints = 8
+        assert lib.phx_rollout(r.h, C.byref(io), None) < 0
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8))
