@@ -308,6 +308,11 @@ def other_configs(device):
     tr = dev.rollout(50)                                        # a 4.7 GB fragment: num_steps = 100, half an episode per launch
     add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 50, timed(lambda: dev.rollout(50, out=tr), 4), "fused rollout T=50",
         bytes_per_env_step=20 * S)
+    del tr; torch.cuda.empty_cache()
+    tr = dev.alloc_trajectory(100)                              # one whole episode per launch (9.4 GB): the launch's ~180 us of block start-up and cold first steps over 100 steps
+    dev.rollout(100, out=tr)
+    add("Stackelberg 128x1024 B=4096 (config 5)", S, 4096, 100, timed(lambda: dev.rollout(100, out=tr), 3), "fused rollout T=100",
+        bytes_per_env_step=20 * S)
     del env, dev, tr
     torch.cuda.empty_cache()
     # not a BASELINE config: the reference's digital-ads example at its own size (the exchange's

@@ -39,6 +39,9 @@ if "c3" in which:
             d.rollout(T, out=trs[k[0] & 1]); k[0] += 1
         line("config 3: SC256 FSM B=8192", T, 8192, 24 * 51, ev(f, n), d)
         del trs
+    fr = [d.alloc_trajectory(100) for _ in range(4)]
+    line("config 3: SC256 FSM B=8192, 4 x 100 frags", 400, 8192, 24 * 51, ev(lambda: d.rollout_fragments(100, fr), 8), d)
+    del fr
     del env, d; torch.cuda.empty_cache()
 if "c4" in which:
     env = ph.SupplyChainEnv(n_shops=51, customers_per_shop=4, num_steps=100, batch_size=8192, seed=42, exogenous="device")
@@ -58,6 +61,9 @@ if "c5" in which:
     env.reset(); d = env._device()
     tr = d.alloc_trajectory(50)
     line("config 5: Stackelberg 128x1024 B=4096", 50, 4096, 20 * 1152, ev(lambda: d.rollout(50, out=tr), 4), d)
+    del tr
+    tr = d.alloc_trajectory(100)
+    line("config 5: Stackelberg 128x1024 B=4096", 100, 4096, 20 * 1152, ev(lambda: d.rollout(100, out=tr), 3), d)
     del env, d, tr; torch.cuda.empty_cache()
 if "gen" in which:       # the generic engine where more waves no longer help (tools/gen_time.py sweep)
     B, S, K = 65536, 9, 6
