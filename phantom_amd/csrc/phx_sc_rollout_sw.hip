@@ -632,6 +632,91 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     }
   };
 
+  // ---- workers, FUSED form of outputs(co) + draws(cd) for the compile-time shapes in the steady state (every lane: exactly one unit of
+  //      four items and one row quad per chunk): the two phases touch different tiles, so their LDS round trips and the Philox block
+  //      can overlap -- tile reads of chunk co are in flight while the block of chunk cd is computed, the sixteen table lookups while
+  //      its words are split, the four order-sum lookups while the staged tile is written.  (Separately the output phase is ~100
+  //      instructions around two exposed LDS round trips, ~20 cycles per instruction.)  The one-in-3e5 rejected word is repaired after the fact.
+#ifdef SW_NO_FUSED_WORK
+  const bool fused_ok = false;
+#else
+  // (the FSM instantiation, already at 127 VGPRs, loses with it: config 3, T = 400 894 against 850 us)
+  const bool fused_ok = MODE == 0 && GT > 0 && TC == 16 && draws_fixed && out_fixed && !quad_extra && nwk == TC * G4 && nwk == (TC / 4) * G;
+#endif
+  auto work_fused = [&](int co, int cd, int t0d) __attribute__((always_inline)) {
+    if (wt < 0) return;
+    // (1) outputs: the unit's tile words
+    const uint2* const t_rd = (const uint2*)smem + (((int)((const char*)s_rd0 - smem) + (co % 3) * items * 2) >> 3);
+    const uint2* const t_xx = (const uint2*)smem + (((int)((const char*)s_xx0 - smem) + (co & 1) * items * 2) >> 3);
+    float4* const o_obs4 = (float4*)smem + (((int)((const char*)s_out0 - smem) >> 4) + (co & 1) * items);
+    float4* const o_rew4 = o_obs4 + 3 * (items >> 2);
+    const int j4 = (int)__umul24(ol_r0, G4) + (ol_gl0 >> 2);
+    const uint2 vx = t_xx[j4], vr = t_rd[j4];
+    // (2) draws: the Philox block of the lane's (pair, row quad) of chunk cd
+    uint16_t* const s_rd = s_rd0 + (cd % 3) * items;
+    float* const s_act = s_act0 + (cd & 1) * items;
+    const int tla = 4 * dl_jr0;
+    const uint32_t tick_a = dl_tick0 + (uint32_t)t0d + (uint32_t)tla;
+    uint32_t w[4], y[4], aj[4];
+    rng_block(a.seed, dl_genv, tick_a, dl_s, 0, 0, w);
+    bool rej = false;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
+    // (3) outputs: sixteen table lookups
+    const uint32_t c32 = ((uint32_t)tid & 31u) << 2, c8 = ((uint32_t)tid & 7u) << 2;
+    const char* const t_s = (const char*)s_tabs; const char* const t_n = (const char*)s_tabn; const char* const t_r = (const char*)s_rtab;
+    const uint32_t xw[4] = {vx.x & 0xffffu, vx.x >> 16, vx.y & 0xffffu, vx.y >> 16};
+    const uint32_t rw4[4] = {vr.x & 0xffffu, vr.x >> 16, vr.y & 0xffffu, vr.y >> 16};
+    uint32_t as_[4], an_[4], am_[4], ar_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x0 = (int)(xw[k] & 255u), xa = (int)(xw[k] >> 8), D = (int)(rw4[k] >> 8);
+      const int sales = min(x0, D), missed = D - sales;
+      as_[k] = ((uint32_t)xa << 7) | c32; an_[k] = ((uint32_t)sales << 7) | c32; am_[k] = ((uint32_t)missed << 7) | c32;
+      ar_[k] = ((uint32_t)(10 * sales - xa + 100) << 5) | c8;
+    }
+    float o[12], rw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[3 * k] = *(const float*)(t_s + as_[k]); o[3 * k + 1] = *(const float*)(t_n + an_[k]); o[3 * k + 2] = *(const float*)(t_n + am_[k]);
+      rw[k] = *(const float*)(t_r + ar_[k]);
+    }
+    // (4) draws: the four order sums
+    const bool k6 = a.K == 6;
+    int D[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      uint32_t yy = y[h];
+      if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);
+      D[h] = (int)s_dtab[yy];
+    }
+    // (5) outputs: the staged tile
+    float4* so = o_obs4 + 3 * j4;
+    so[0] = make_float4(o[0], o[1], o[2], o[3]); so[1] = make_float4(o[4], o[5], o[6], o[7]); so[2] = make_float4(o[8], o[9], o[10], o[11]);
+    o_rew4[j4] = make_float4(rw[0], rw[1], rw[2], rw[3]);
+    // (6) draws: the tile words and the actions
+    const int i = __mul24(tla, G) + dl_gl;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float action = rng_j_to_action(aj[h]);
+      s_rd[i + h * G] = (uint16_t)((int)rintf(action) | (D[h] << 8));
+      s_act[i + h * G] = action;
+    }
+    if (__builtin_expect(rej, 0)) {                                      // a rejected word: that row again, from the retry stream
+#pragma unroll 1
+      for (int h = 0; h < 4; ++h) {
+        uint32_t y2, j2;
+        if (!rng_split(w[h], y2, j2)) {
+          uint32_t jn; uint32_t yy = rng_group_y(a.seed, dl_genv, tick_a + (uint32_t)h, dl_s, 0, 1, &jn);
+          if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);
+          const float action = rng_j_to_action(jn);
+          s_rd[i + h * G] = (uint16_t)((int)rintf(action) | ((int)s_dtab[yy] << 8));
+          s_act[i + h * G] = action;
+        }
+      }
+    }
+  };
+
   // ---- the store waves: staged tile of chunk c -> trajectory rows ---------------------------------------------------------------
   // flat piece index q = row * P + piece over a staged tile, advancing by the store lanes per iteration: (piece, byte offset)
   // are carried incrementally -- no multiply in the loop; each instruction writes 64 consecutive 16-byte pieces (1 KB)
@@ -860,10 +945,15 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const int co = it, cr = it + 1, cd = it + 2, cs = it - 1;
     if (tid >= work_first) {
       // workers (letting every other worker wave draw first, so that LDS-heavy and VALU-heavy phases overlap on a SIMD, changes nothing)
+      if (fused_ok && co >= 0 && cd < n_chunks && rows_of(co) == TC && rows_of(cd) == TC && !(weird && co == 0)) {
+        work_fused(co, cd, start_of(cd));
+        STICK(2);
+      } else {
       if (co >= 0 && co < n_chunks) outputs(co, rows_of(co));
       STICK(2);
       if (cd < n_chunks) draws(start_of(cd), rows_of(cd), cd);
       STICK(1);
+      }
     } else if (tid < rec_threads) {
 #ifdef SWF_ABL_PLAINREC
       if (cr >= 0 && cr < n_chunks) recurrence(cr, rows_of(cr));
