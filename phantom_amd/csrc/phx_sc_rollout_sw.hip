@@ -641,7 +641,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   const bool fused_ok = false;
 #else
   // (the FSM instantiation, already at 127 VGPRs, loses with it: config 3, T = 400 894 against 850 us)
-  const bool fused_ok = MODE == 0 && GT > 0 && TC == 16 && draws_fixed && out_fixed && !quad_extra && nwk == TC * G4 && nwk == (TC / 4) * G;
+  // (replays: of the actions only -- 64.7 against 67.0 us per T = 400; with the order sizes too the fused form loses, 85.9 against 83.7)
+  const bool fused_mode = MODE == 0 || (MODE == 1 && !rp_exo);
+  const bool fused_ok = fused_mode && GT > 0 && TC == 16 && draws_fixed && out_fixed && !quad_extra && nwk == TC * G4 && nwk == (TC / 4) * G;
 #endif
   auto work_fused = [&](int co, int cd, int t0d) __attribute__((always_inline)) {
     if (wt < 0) return;
@@ -651,17 +653,44 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     float4* const o_obs4 = (float4*)smem + (((int)((const char*)s_out0 - smem) >> 4) + (co & 1) * items);
     float4* const o_rew4 = o_obs4 + 3 * (items >> 2);
     const int j4 = (int)__umul24(ol_r0, G4) + (ol_gl0 >> 2);
+    const int tla = 4 * dl_jr0;
+    // (0) REPLAY: the recorded inputs of the quad first -- the longest latency of the phase
+    float av[4] = {0.f, 0.f, 0.f, 0.f}; int Dx[4] = {0, 0, 0, 0};
+    if (REPLAY) {
+      const int64_t pair = g_base + dl_gl;
+      if (rp_act) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) av[h] = io.actions[(int64_t)(t0d + tla + h) * total + pair];
+      }
+      if (rp_exo) {
+        const int64_t b = dl_genv - a.env_offset;
+        const int K_ = a.K, e0 = a.exo_first[dl_s];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const uint8_t* row = io.exo + ((int64_t)(t0d + tla + h) * a.B + b) * a.n_exo + e0;
+          int d = 0;
+          if (K_ >= 4) {
+            uint32_t w0, w1;
+            __builtin_memcpy(&w0, row, 4); __builtin_memcpy(&w1, row + (K_ - 4), 4);
+            if (K_ > 4) w0 += (w1 >> (8 * (8 - K_)));
+            d = (int)((w0 * 0x01010101u) >> 24);
+          } else for (int k = 0; k < K_; ++k) d += (int)row[k];
+          Dx[h] = d;
+        }
+      }
+    }
     const uint2 vx = t_xx[j4], vr = t_rd[j4];
     // (2) draws: the Philox block of the lane's (pair, row quad) of chunk cd
     uint16_t* const s_rd = s_rd0 + (cd % 3) * items;
     float* const s_act = s_act0 + (cd & 1) * items;
-    const int tla = 4 * dl_jr0;
     const uint32_t tick_a = dl_tick0 + (uint32_t)t0d + (uint32_t)tla;
-    uint32_t w[4], y[4], aj[4];
-    rng_block(a.seed, dl_genv, tick_a, dl_s, 0, 0, w);
+    uint32_t w[4] = {0u, 0u, 0u, 0u}, y[4] = {0u, 0u, 0u, 0u}, aj[4] = {0u, 0u, 0u, 0u};
     bool rej = false;
+    if (!(rp_act && rp_exo)) {
+      rng_block(a.seed, dl_genv, tick_a, dl_s, 0, 0, w);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
+      for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
+    }
     // (3) outputs: sixteen table lookups
     const uint32_t c32 = ((uint32_t)tid & 31u) << 2, c8 = ((uint32_t)tid & 7u) << 2;
     const char* const t_s = (const char*)s_tabs; const char* const t_n = (const char*)s_tabn; const char* const t_r = (const char*)s_rtab;
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     for (int h = 0; h < 4; ++h) {
       uint32_t yy = y[h];
       if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);
-      D[h] = (int)s_dtab[yy];
+      D[h] = rp_exo ? Dx[h] : (int)s_dtab[yy];
     }
     // (5) outputs: the staged tile
     float4* so = o_obs4 + 3 * j4;
@@ -698,8 +727,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const int i = __mul24(tla, G) + dl_gl;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const float action = rng_j_to_action(aj[h]);
-      s_rd[i + h * G] = (uint16_t)((int)rintf(action) | (D[h] << 8));
+      const float action = rp_act ? av[h] : rng_j_to_action(aj[h]);
+      const int Rq = rp_act ? (int)fminf(rintf(action), 255.0f) : (int)rintf(action);
+      s_rd[i + h * G] = (uint16_t)(Rq | (D[h] << 8));
       s_act[i + h * G] = action;
     }
     if (__builtin_expect(rej, 0)) {                                      // a rejected word: that row again, from the retry stream
@@ -709,8 +739,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         if (!rng_split(w[h], y2, j2)) {
           uint32_t jn; uint32_t yy = rng_group_y(a.seed, dl_genv, tick_a + (uint32_t)h, dl_s, 0, 1, &jn);
           if (!k6) yy -= __umul24((uint32_t)((float)yy * a.inv_pK), a.pK);
-          const float action = rng_j_to_action(jn);
-          s_rd[i + h * G] = (uint16_t)((int)rintf(action) | ((int)s_dtab[yy] << 8));
+          const float action = rp_act ? av[h] : rng_j_to_action(jn);
+          const int Rq = rp_act ? (int)fminf(rintf(action), 255.0f) : (int)rintf(action);
+          s_rd[i + h * G] = (uint16_t)(Rq | ((rp_exo ? Dx[h] : (int)s_dtab[yy]) << 8));
           s_act[i + h * G] = action;
         }
       }
