@@ -251,7 +251,9 @@ typedef struct phx_spec {
 #define PHX_VR_GENERAL       3  /* plain env: phx_sc_rollout_kernel, round 1, also serves replays; FSM env: phx_sc_rollout_fsm_kernel */
 #define PHX_VR_LAUNCH_LOOP   4  /* generic engine: one phx_generic_step_kernel launch per step                                    */
 #define PHX_VR_STORE_WAVES   5  /* plain env: the store-wave kernel of round 4 (phx_sc_rollout_sw.hip: dedicated store waves, dense flag planes); also what
-                                   PHX_VR_AUTO picks where its workgroup shape applies; PHX_VR_TIME_PARALLEL keeps the round-3 kernel */
+                                   PHX_VR_AUTO picks where its workgroup shape applies; PHX_VR_TIME_PARALLEL keeps the round-3 kernel.
+                                   FSM supply chain (round 5): that kernel's FSM instantiation wherever its plan applies (PHX_VR_AUTO: for
+                                   fragments of >= 200 steps on batches above 65 536 (env, shop) pairs) */
 #define PHX_VB_WHOLE_ENVS   (-1)
 /* phx_spec.variant_step */
 #define PHX_VS_AUTO          0

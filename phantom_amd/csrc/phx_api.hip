@@ -1215,7 +1215,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     }
     // ... the same for an FSM supply chain on its FSM instantiation; the lane-per-pair loop that takes over when an env is off the stage
     // chain has no fragment lists: one guarded launch per fragment behind it (each returns at entry unless the check found such an env)
-    if (e->use_fused && e->d.env_type == PHX_ENV_FSM && phx_fsm_sw_serves(e->d, *io, (hipStream_t)stream)) {
+    if (e->use_fused && e->d.env_type == PHX_ENV_FSM && io->frags[0].terminated && phx_fsm_sw_serves(e->d, *io, (hipStream_t)stream)) {   // (`terminated`: the loop behind needs it)
       HIPCHK(use_device(e));
       const int32_t gen = phx_fsm_next_gen(e->d);
       HIPCHK(phx_launch_sc_rollout_sw(e->d, *io, (hipStream_t)stream, gen));
