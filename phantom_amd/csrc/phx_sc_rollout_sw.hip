@@ -1117,15 +1117,19 @@ __global__ __launch_bounds__(256) void phx_sw_scan_actions_kernel(const float* _
 }
 
 // FSM instantiation: is every env on the tabulated stage chain (its stage the one the table holds for its step counter, the counter inside
-// the episode) and every stock inside [0, 100]?  Otherwise *flag = gen: the store-wave launch returns at entry and the lane-per-pair loop
+// the episode), every stock inside [0, 100], and no reward cache invalid although the episode is past a rewarded position (a caller who
+// moved the step counter: the closed form of reward_valid assumes the cache of an env that walked there)?  Otherwise *flag = gen: the store-wave launch returns at entry and the lane-per-pair loop
 // (phx_sc_fused.hip), launched behind it with the same word, serves the call.
 __global__ __launch_bounds__(256) void phx_sw_fsm_check_kernel(const int32_t* __restrict__ env_step, const int32_t* __restrict__ env_stage, const int32_t* __restrict__ stock,
-                                                               const uint16_t* __restrict__ tab, int num_steps, int S, int64_t total, int32_t* flag, int32_t gen) {
+                                                               const uint8_t* __restrict__ rew_cache_v, const uint16_t* __restrict__ tab, int num_steps, int S,
+                                                               int64_t total, int32_t* flag, int32_t gen) {
   bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = i / S;
     const int stp = env_step[b];
-    bad |= (unsigned)stock[i] > (unsigned)PHX_SHOP_MAX_STOCK || stp < 0 || stp >= num_steps || env_stage[b] != (int)tab[num_steps + (stp < 0 || stp >= num_steps ? 0 : stp)];
+    const bool in_ep = stp >= 0 && stp < num_steps;
+    bad |= (unsigned)stock[i] > (unsigned)PHX_SHOP_MAX_STOCK || !in_ep || env_stage[b] != (int)tab[num_steps + (in_ep ? stp : 0)] ||
+           (in_ep && stp > 0 && (tab[stp - 1] & SWF_HASREW) && !rew_cache_v[i]);
   }
   if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(flag, gen);
 }
@@ -1166,7 +1170,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
     const int64_t total = (int64_t)sp.B * sp.S;
     a.guard = sp.fsm_irregular;
     hipLaunchKernelGGL(phx_sw_fsm_check_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, st, a.env_step, a.env_stage, a.stock,
-                       sp.fsm_sw_tab, sp.num_steps, sp.S, total, sp.fsm_irregular, guard_gen);
+                       a.rew_cache_v, sp.fsm_sw_tab, sp.num_steps, sp.S, total, sp.fsm_irregular, guard_gen);
   }
   // trajectory fragments: the caller's list (phx_rollout_io.frags, validated by phx_rollout) or the io's own planes as the only one
   if (io.n_frag > 1) {

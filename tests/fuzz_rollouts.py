@@ -70,6 +70,17 @@ def run_rollout_case(case, journal=None):
         for b in prng.integers(0, B, max(1, B // 3)):
             st[b] = int(prng.integers(-30, ns + 10))
         o.set_i32("env.step", st); dv.set_i32("env.step", st)
+    if kind < 8 and fsm and ns >= 2 and np.random.default_rng(case + 50_000_011).random() < 0.2:
+        # round 5 (late): FSM envs whose step counter a caller moved -- the stage moved with it (RESTOCK at even positions, SELL at odd ones:
+        # still on the chain, but the caches are those of the state before the move: right after a reset nothing is cached although rewarded
+        # positions now lie behind) or not (off the chain)
+        prng = np.random.default_rng(case + 50_000_011)
+        st = o.get_i32("env.step").copy().reshape(-1)
+        sg = o.get_i32("env.stage").copy().reshape(-1)
+        for b in prng.integers(0, B, max(1, B // 2)):
+            st[b] = int(prng.integers(0, ns)); sg[b] = st[b] % 2 if prng.random() < 0.8 else int(prng.integers(0, 2))
+        for r in (o, dv):
+            r.set_i32("env.step", st); r.set_i32("env.stage", sg)
     n = 0
     xrng = np.random.default_rng(case + 40_000_007)             # round 5: fragment lists (ABI 9) and replayed policies / order sizes
     for _ in range(int(rng.integers(1, 4))):

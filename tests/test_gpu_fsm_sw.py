@@ -103,6 +103,24 @@ def test_envs_out_of_step_and_caches_the_caller_left():
     assert (d.err == 0).all()
 
 
+def test_a_step_counter_moved_past_rewarded_positions_right_after_a_reset():
+    """reset() clears the reward cache (fsm.py:234); a caller who then moves the step counter (and the stage with it) past the episode's
+    first rewarded position leaves an env the closed form of reward_valid does not describe (nothing cached although a rewarded position
+    lies behind): the check kernel sends the launch to the loop -- reward_valid 2 until the next rewarded step, as in the oracle."""
+    S, K, B, ns = 9, 6, 128, 30
+    env = supply_chain_env(S, [K] * S, ns, B, fsm=True, seed=8, variants={"rollout": "store_waves", "block": 128})
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    st = np.full(B, 5, np.int32); st[::4] = 6
+    for r in (o, d):
+        r.set_i32("env.step", st); r.set_i32("env.stage", (st % 2).astype(np.int32))
+    for T in (45, 40):
+        ro, rd = o.rollout(T), d.rollout(T)
+        _cmp(rd, ro, f"T={T}"); _state(d, o, f"T={T}")
+    assert (rd["reward_valid"] != 2).all() and (ro["reward_valid"] != 2).all()      # (the second launch starts with a cache)
+    assert (d.err == 0).all()
+
+
 def test_off_chain_envs_and_out_of_range_stocks_take_the_loop_behind_the_same_launch():
     """An env whose stage is not the chain's for its step counter (a handler's or the caller's doing), a step counter outside the episode
     or a stock outside [0, 100]: the check kernel flags the launch, the store-wave launch returns at entry, the lane-per-pair loop serves
