@@ -760,7 +760,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     uint32_t pc = q - r0_ * P, off = r0_ * rb + pc * 16u;
     const uint32_t d_off = dr * rb + dp * 16u, wrap = rb - P * 16u;
     const float4* sp = (const float4*)src + q;
-    // SW_DEPTH pieces per trip: the LDS reads are issued together (one round trip), then the stores (6 or 8 per trip: no faster)
+    // SW_DEPTH pieces per trip: the LDS reads are issued together (one round trip), then the stores (6 or 8 per trip: no faster).
+    // (Round 5, after the workers' fused phase left the store waves as the busiest role -- 89 % at SC64: every trip a full, predicated
+    //  batch instead of full trips followed by single pieces: 4 per trip 114.1 against 112.5 us per 8 x 100-step call, 8 per trip 131 --
+    //  the stores' pace is the memory system's, not the LDS round trips'; bursts make it worse.)
     constexpr int SW_DEPTH = 4;
     for (; q + (uint32_t)(SW_DEPTH - 1) * dq < n; q += (uint32_t)SW_DEPTH * dq, sp += (uint32_t)SW_DEPTH * dq) {
       float4 v[SW_DEPTH];
