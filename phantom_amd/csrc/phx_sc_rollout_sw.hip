@@ -764,7 +764,13 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     // (Round 5, after the workers' fused phase left the store waves as the busiest role -- 89 % at SC64: every trip a full, predicated
     //  batch instead of full trips followed by single pieces: 4 per trip 114.1 against 112.5 us per 8 x 100-step call, 8 per trip 131 --
     //  the stores' pace is the memory system's, not the LDS round trips'; bursts make it worse.)
-    constexpr int SW_DEPTH = 4;
+        // (ONE piece per trip since late round 5: the stores of a lane then leave evenly over the iteration instead of in bursts of four --
+    //  the 8-fragment bench shape 111.5-112.3 against 113.6-118.4 us per call on a slow box, 108.6 against 112.1-113.7 on another, the
+    //  bench line +4 %; every other shape within noise.  SW_STORE_DEPTH: development.)
+#ifndef SW_STORE_DEPTH
+#define SW_STORE_DEPTH 1
+#endif
+    constexpr int SW_DEPTH = SW_STORE_DEPTH;
     for (; q + (uint32_t)(SW_DEPTH - 1) * dq < n; q += (uint32_t)SW_DEPTH * dq, sp += (uint32_t)SW_DEPTH * dq) {
       float4 v[SW_DEPTH];
 #pragma unroll
