@@ -858,13 +858,16 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
           v = make_uint4(w[0], w[1], w[2], w[3]);
         }
         const size_t off = (size_t)(t - f_lo) * (size_t)utotal + (size_t)(pc * 16u);
-#ifdef SW_FLAGS_NT
-        sw_store16(p_tru + off, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
-        if (p_ter) sw_store16(p_ter + off, make_float4(0.f, 0.f, 0.f, 0.f));
-#else
-        *(uint4*)(p_tru + off) = v;                                          // (plain stores: a flag row of the block is G bytes, not whole lines)
-        if (p_ter) *(uint4*)(p_ter + off) = make_uint4(0u, 0u, 0u, 0u);
-#endif
+        // plain stores: a flag row of the block is G bytes, not whole lines -- except for 128-pair workgroups, whose rows ARE whole 128-byte
+        // lines; there non-temporal stores win where there are four planes (FSM, config 3: 847 against 858 us per T = 400) and change
+        // nothing where there are two (config 4's share); 144-byte rows lose 3 % with them
+        constexpr bool flags_nt = FSM && GT == 128;
+        auto put = [&](char* q, const uint4 w) __attribute__((always_inline)) {
+          if (flags_nt) sw_store16(q, make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)));
+          else *(uint4*)q = w;
+        };
+        put(p_tru + off, v);
+        if (p_ter) put(p_ter + off, make_uint4(0u, 0u, 0u, 0u));
         if (FSM) {
           // obs_valid / reward_valid of row t: functions of the pair's episode position p = (step at launch + t) mod num_steps -- with
           // et = num_steps - 1 - step that is x - 1 - et (+ num_steps) -- and, for the rows of the launch's own episode before its first
@@ -890,12 +893,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
             vo = make_uint4(wo[0], wo[1], wo[2], wo[3]); vr = make_uint4(wr[0], wr[1], wr[2], wr[3]);
           }
 #ifndef SWF_ABL_NOFLAGS
-#ifdef SW_FLAGS_NT
-          sw_store16(p_ov + off, make_float4(__uint_as_float(vo.x), __uint_as_float(vo.y), __uint_as_float(vo.z), __uint_as_float(vo.w)));
-          sw_store16(p_rv + off, make_float4(__uint_as_float(vr.x), __uint_as_float(vr.y), __uint_as_float(vr.z), __uint_as_float(vr.w)));
-#else
-          *(uint4*)(p_ov + off) = vo; *(uint4*)(p_rv + off) = vr;
-#endif
+          put(p_ov + off, vo); put(p_rv + off, vr);
 #endif
         }
       }
