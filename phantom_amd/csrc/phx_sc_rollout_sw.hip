@@ -22,6 +22,12 @@
 //     they write before that, in the iterations in which the pipeline fills (dense 16-byte pieces, a closed form of the pairs' step
 //     counters at launch: no zero-fill launch before the kernel, no scattered flag stores in the steady state).
 // LDS: 10 bytes per item of tiles + 32 of staging (double-buffered) instead of 44 + nothing staged.
+// Round 5: fragment lists, several pair groups per workgroup, the REPLAY (MODE 1) and FSM (MODE 2) instantiations, the workers' fused
+// phase, one store piece per trip.
+// Development macros (never defined in the product build; tools/build_variant.py / scratch variants): PHX_TIMING, PHX_RT_ONLY, PHX_RT_FILL
+// (cycle and wall-clock stamps per role), PHX_ABL_NODRAW / PHX_ABL_NOSTORE, SW_ABL_NODTAB / SW_ABL_NORTAB (LDS bank-conflict attribution),
+// SWF_ABL_NOTRACK / NOFLAGS / PLAINREC / NOPW (what each part of the FSM instantiation costs), SW_NO_FIXED_DRAWS / SW_NO_FIXED_OUT /
+// SW_NO_FUSED_WORK, SW_STORE_DEPTH.
 #include "phx_dev.h"
 #include "phx_sc_fast.h"
 
