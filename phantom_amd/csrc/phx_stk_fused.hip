@@ -30,6 +30,18 @@ __device__ unsigned long long g_stk_rt[8];      // wall clock (100 MHz) of the l
 #define STICK(k) do {} while (0)
 #endif
 
+// SellerAgent.handle_order, n times in one round (stackelberg test agents: self.revenue += self.price * vol, one Order(1) per buying
+// neighbour): the sequential f64 sum of n EQUAL addends.  From a revenue of +0 (the followers' step resets it before the round) and for an
+// addend that is a float32 value (the price is the seller's f32 action) every partial sum k * amount has at most 24 + 11 significant bits:
+// each addition is exact, and so is ONE multiplication -- the popular sellers of a 128 x 1024 market book ~100 orders, and the whole
+// workgroup waits at the barrier behind that chain (PHX_TIMING: 1.8 k of a step's 8.7 k cycles).  Anything else keeps the loop.
+__device__ __forceinline__ double stk_book(double rev, double amount, int n) {
+  const bool exact = __double_as_longlong(rev) == 0ll && amount != 0.0 && (double)(float)amount == amount && n <= 2048;
+  if (exact) return __dmul_rn((double)n, amount);
+  for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+  return rev;
+}
+
 // BuyerAgent.prices in compressed form.  Every Price a seller posts goes to ALL of its neighbours
 // in the same round (decode_action returns one message per ctx.neighbour_ids entry) and the
 // topology is static, so the slot a buyer keeps for neighbour l always holds "the last price l
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(STK_NT) void phx_stk_step_kernel(const DevSpec sp, 
     const int n = s_count[kr];
     if (n > 0) {
       const double amount = __dmul_rn(s_price[kr], 1.0);                     // price * vol, vol = 1
-      for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+      rev = stk_book(rev, amount, n);
       tx += n;
     }
     s_rev[kr] = rev; s_tx[kr] = tx;
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_step_fast_kerne
     const int n = s_count[kr];
     if (n > 0) {
       const double amount = __dmul_rn(s_price[kr], 1.0);                     // price * vol, vol = 1
-      for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+      rev = stk_book(rev, amount, n);
       tx += n;
     }
     s_rev[kr] = rev; s_tx[kr] = tx;
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       const int n = s_count[kr];
       if (n > 0) {
         const double amount = __dmul_rn(s_price[kr], 1.0);
-        for (int k = 0; k < n; ++k) rev = __dadd_rn(rev, amount);
+        rev = stk_book(rev, amount, n);
         tx += n;
       }
       s_rev[kr] = rev; s_tx[kr] = tx;
