@@ -44,32 +44,38 @@ class Metric:
         return values[-1]
 
 
+#: how an episode's per-step values become one number (metrics.py:170-186): a table of reducers over the values stacked on axis 0
+#: (the batch axis stays); "none" keeps every step
+_REDUCERS = {
+    "last": lambda vals: vals[-1] if len(vals) else None,
+    "mean": lambda vals: np.mean(vals, axis=0),
+    "sum": lambda vals: np.sum(vals, axis=0),
+    "none": np.array,
+}
+#: (argument name, reducers it accepts, the reference's wording of the complaint)
+_ACTION_ARGS = (
+    ("train_reduce_action", ("last", "mean", "sum"), "metric must be one of: 'last', 'mean' or 'sum'"),
+    ("eval_reduce_action", ("last", "mean", "sum", "none"), "metric class must be one of: 'last', 'mean', 'sum' or 'none'"),
+)
+
+
 class SimpleMetric(Metric):
-    """metrics.py:141-186"""
+    """metrics.py:141-186 -- the reduce actions as a dispatch table (``_REDUCERS``)"""
 
     def __init__(self, train_reduce_action="mean", eval_reduce_action="none", fsm_stages=None,
                  description=None):
-        if train_reduce_action not in ("last", "mean", "sum"):
-            raise ValueError(f"train_reduce_action field of {self.__class__} metric must be one of: "
-                             f"'last', 'mean' or 'sum'. Got '{train_reduce_action}'.")
-        if eval_reduce_action not in ("last", "mean", "sum", "none"):
-            raise ValueError(f"eval_reduce_action field of {self.__class__} metric class must be one "
-                             f"of: 'last', 'mean', 'sum' or 'none'. Got '{eval_reduce_action}'.")
-        self.train_reduce_action = train_reduce_action
-        self.eval_reduce_action = eval_reduce_action
+        given = {"train_reduce_action": train_reduce_action, "eval_reduce_action": eval_reduce_action}
+        for name, accepted, wording in _ACTION_ARGS:
+            if given[name] not in accepted:
+                raise ValueError(f"{name} field of {self.__class__} {wording}. Got '{given[name]}'.")
+            setattr(self, name, given[name])
         super().__init__(fsm_stages, description)
 
     def reduce(self, values, mode):
         action = self.train_reduce_action if mode == "train" else self.eval_reduce_action
-        if action == "none":
-            return np.array(values)
-        if self.fsm_stages is not None:
+        if action != "none" and self.fsm_stages is not None:   # steps of other stages recorded the `not_recorded` marker
             values = [v for v in values if v is not not_recorded]
-        if action == "last":
-            return values[-1] if len(values) > 0 else None
-        if action == "mean":
-            return np.mean(values, axis=0)
-        return np.sum(values, axis=0)
+        return _REDUCERS[action](values)
 
 
 class SimpleAgentMetric(SimpleMetric):

@@ -539,3 +539,24 @@ def test_kernel_variant_names_resolve_to_the_header_constants():
     for bad in ({"rolout": "auto"}, {"rollout": "store-waves"}, {"step": "wider"}):
         with pytest.raises(ValueError):
             resolve_variants(bad)
+
+
+def test_simple_metric_reducers_and_their_argument_errors():
+    """metrics.py:141-186: last / mean / sum over the values stacked on axis 0 (the batch axis stays), 'none' keeps every step, values of
+    other FSM stages (`not_recorded`) are dropped before reducing, and the constructor refuses unknown actions with the reference's wording."""
+    import numpy as np
+    import pytest
+    from phantom_amd.metrics import SimpleMetric, not_recorded
+    vals = [np.array([1.0, 2.0]), np.array([3.0, 6.0]), np.array([5.0, 1.0])]
+    assert np.array_equal(SimpleMetric("mean").reduce(vals, "train"), [3.0, 3.0])
+    assert np.array_equal(SimpleMetric("sum").reduce(vals, "train"), [9.0, 9.0])
+    assert np.array_equal(SimpleMetric("last").reduce(vals, "train"), [5.0, 1.0])
+    assert SimpleMetric("last").reduce([], "train") is None
+    assert np.array_equal(SimpleMetric("mean", "none").reduce(vals, "evaluate"), np.array(vals))
+    staged = SimpleMetric("sum", "last", fsm_stages=["SELL"])
+    assert np.array_equal(staged.reduce([vals[0], not_recorded, vals[2]], "train"), [6.0, 3.0])
+    assert np.array_equal(staged.reduce([vals[0], not_recorded], "evaluate"), vals[0])
+    with pytest.raises(ValueError, match="train_reduce_action field of .* metric must be one of: 'last', 'mean' or 'sum'. Got 'none'"):
+        SimpleMetric("none")
+    with pytest.raises(ValueError, match="eval_reduce_action field of .* metric class must be one of: 'last', 'mean', 'sum' or 'none'. Got 'max'"):
+        SimpleMetric("mean", "max")
