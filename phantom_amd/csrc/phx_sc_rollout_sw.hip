@@ -1019,7 +1019,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       STICK(3);
     } else {
       if (it == -2 && pass == 0) replicate_tables(tid, work_first);
-      __builtin_amdgcn_s_setprio(2);      // the store lanes' single-piece trips are paced by their LDS round trips: issue them ahead of the workers (-1 % on the bench shape)
+#ifndef SW_STORE_PRIO
+#define SW_STORE_PRIO 2
+#endif
+      __builtin_amdgcn_s_setprio(SW_STORE_PRIO);      // the store lanes' single-piece trips are paced by their LDS round trips: issue them ahead of the workers (-1 % on the bench shape)
       if (REPLAY) touch_inputs(it + 3);
       if (it <= 0) flag_segments(it + 2);
       if (cs >= 0) stores(cs, start_of(cs), rows_of(cs));
