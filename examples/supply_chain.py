@@ -64,3 +64,14 @@ env = ph.SupplyChainFSMEnv(n_shops=3, customers_per_shop=2, num_steps=20, batch_
 env.reset()
 tr = env.rollout(40)
 print("rule-form FSM handler: rollout in one launch,", env._device().last_kernel(), "| stages now:", sorted(set(env.current_stage)))
+
+# 7. a handler-less FSM supply chain (RESTOCK -> SELL -> RESTOCK ...: BASELINE config 3's env) rolled out by the store-wave kernel's FSM
+#    instantiation: obs_valid / reward_valid planes beside the five of a plain env; a fragment list is one launch here too
+env = ph.SupplyChainFSMEnv(n_shops=9, customers_per_shop=6, num_steps=100, batch_size=2048, seed=3, exogenous="device",
+                           variants={"rollout": "store_waves"})
+env.reset()
+dev = env._device()
+bufs = [dev.alloc_trajectory(100) for _ in range(4)]
+dev.rollout_fragments(100, bufs)
+print("FSM fragment list: 4 x", tuple(bufs[0].observations.shape), "from", dev.last_kernel().split("+")[0],
+      "| shops observe on", int(bufs[0].obs_valid[:, 0, 0].sum()), "of 100 steps, rewards emitted on", int((bufs[0].reward_valid[:, 0, 0] == 1).sum()))
