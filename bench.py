@@ -1009,17 +1009,19 @@ def bench_rllib_adapter(env, B, S):
     from phantom_amd.rllib import BatchedBaseEnv
     if not hasattr(BatchedBaseEnv, "send_action_tensor"):
         return {"error": "adapter without the tensor fast path"}
-    be = BatchedBaseEnv(env)
-    res = {"envs": B}
+    be_keep, be_lazy = BatchedBaseEnv(env), BatchedBaseEnv(env, keep_results=False)
+    res = {"envs": B, "note": "tensor: the default adapter (every poll() result stays readable: one asynchronous copy per step); tensor_zero_copy: "
+                              "keep_results=False (a result is copied when first read, before the next step)"}
     acts = torch.rand(B, S, device=env._device().device) * 100.0
-    ids = sorted(be.get_agent_ids())
-    for mode, n in (("tensor", 50), ("multi_env_dict", 5), ("multi_env_dict_rows_read", 3)):
+    ids = sorted(be_keep.get_agent_ids())
+    for mode, n in (("tensor", 50), ("tensor_zero_copy", 50), ("multi_env_dict", 5), ("multi_env_dict_rows_read", 3)):
+        be = be_lazy if mode == "tensor_zero_copy" else be_keep
         env.reset()
         be._pending = None
         obs = be.poll()
         t0 = time.perf_counter()
         for _ in range(n):
-            if mode == "tensor":                 # [B, S] tensor in, one D2H copy out, lazy MultiEnvDicts (nothing read)
+            if mode.startswith("tensor"):        # [B, S] tensor in, lazy MultiEnvDicts out (nothing read)
                 be.send_action_tensor(acts)
             else:                                # RLlib's MultiEnvDict in: B x S python entries converted once
                 be.send_actions({b: {aid: 50.0 for aid in ids} for b in range(B)})
@@ -1047,6 +1049,7 @@ def bench_rllib_adapter(env, B, S):
                                              "note": "the measuring loop alone on plain dicts: what no adapter can go below"}
     # the bulk exit: T = 100 steps per call as fused device rollouts, the fragment as per-policy SampleBatch column dicts
     env.reset()
+    be = be_keep
     be.sample(NUM_STEPS)
     n = 5
     t0 = time.perf_counter()

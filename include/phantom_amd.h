@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 9
+#define PHX_ABI_VERSION 10
 
 /* ---- return codes (host-side failures) ---------------------------------------------- */
 #define PHX_OK            0
@@ -49,6 +49,8 @@ extern "C" {
 #define PHX_ERR_QUEUE_FULL  5 /* build-specific: per-round message capacity exceeded         */
 #define PHX_ERR_CONTEXT     6 /* KeyError: ctx[agent_id] of a non-neighbour  context.py:36-37  */
 #define PHX_ERR_FSM_TRANSITION 7 /* FSMRuntimeError: handler returned a stage outside next_stages  fsm.py:304-307 */
+#define PHX_ERR_HINT        8 /* build-specific (ABI 10): a replayed input violates a PHX_RH_* hint the caller vouched for
+                                 (phx_rollout_io.hints): the env's rows of that call are unspecified                  */
 /* BatchResolver(round_limit=None) loops until no message is left (resolvers.py:129-131), i.e. forever
  * on a message cycle; this build stops after PHX_MAX_ROUNDS rounds with PHX_ERR_ROUND_LIMIT.        */
 #define PHX_MAX_ROUNDS 4096
@@ -337,7 +339,10 @@ typedef struct phx_rollout_frag {
 
 /* phx_rollout_io.hints: what the CALLER vouches for about the replayed inputs, so that a plain supply chain's replay can take the
  * store-wave kernel (whose tiles hold R, D and the stock in bytes) without a scan of the inputs.  A hint that does not hold leaves the
- * fragment unspecified.  (Bit 1 was PHX_RH_FLAGS_ZEROED until ABI 8: not reused.)                                               */
+ * rows of the envs it fails for unspecified AND sets their err[b] = PHX_ERR_HINT wherever the kernel that serves the call relies on
+ * the hint (ABI 10: the store-wave kernel sees the offending action / order byte where it loads it; until ABI 9 nothing reported it).
+ * Kernels that do not rely on a hint (round 1's kernel, short fragments) ignore it: the reference's rows, no error.
+ * (Bit 1 was PHX_RH_FLAGS_ZEROED until ABI 8: not reused.)                                                                          */
 #define PHX_RH_ACTIONS_IN_DOMAIN 2  /* every replayed action rounds to >= 0 -- e.g. clipped to ShopAgent's action space Box(0, SHOP_MAX_STOCK),
                                        supply_chain.py:87-91, as RLlib's clip_actions does.  Without it the call's actions are pre-scanned on
                                        the device (T B S floats read once more) and a call with an action that rounds below zero is served

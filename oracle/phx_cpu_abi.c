@@ -114,11 +114,16 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   (void)stream;
   if (!e || !io || io->T <= 0) return PHX_EINVAL;
-  if ((io->hints & ~(PHX_RH_ACTIONS_IN_DOMAIN | PHX_RH_EXO_IN_DOMAIN)) != 0 || io->reserved_ptr) return PHX_EINVAL;   /* (the hints change nothing here) */
+  if ((io->hints & ~(PHX_RH_ACTIONS_IN_DOMAIN | PHX_RH_EXO_IN_DOMAIN)) != 0 || io->reserved_ptr) return PHX_EINVAL;   /* (the hints change nothing here: this path never relies on them, so it reports no PHX_ERR_HINT either) */
   if (io->n_frag >= 2 || io->frags) {                    /* ABI 9, a fragment list: the same steps, the rows handed out fragment by fragment */
     if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags || io->T % io->n_frag) return PHX_EINVAL;
     if (io->obs || io->action_out || io->reward || io->terminated || io->truncated || io->obs_valid || io->reward_valid) return PHX_EINVAL;
     const int Tf = io->T / io->n_frag, S = phxo_n_strategic(e->o);
+    for (int f = 0; f < io->n_frag; ++f) {                 /* the validation phx_rollout of the HIP library makes (phx_api.hip): every fragment's required planes */
+      const phx_rollout_frag* fr = &io->frags[f];
+      if (!fr->obs || !fr->action_out || !fr->reward || !fr->truncated || (e->env_type != PHX_ENV_PLAIN && (!fr->obs_valid || !fr->reward_valid))) return PHX_EINVAL;
+      if ((fr->terminated != NULL) != (io->frags[0].terminated != NULL)) return PHX_EINVAL;
+    }
     for (int f = 0; f < io->n_frag; ++f) {
       const phx_rollout_frag* fr = &io->frags[f];
       phx_rollout_io sub = *io;

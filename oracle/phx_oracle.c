@@ -1046,6 +1046,22 @@ phxo_env* phxo_create(const phx_spec* sp) {
   if (!sp || sp->abi_version != PHX_ABI_VERSION || sp->n_agents <= 0 || sp->batch <= 0) {
     snprintf(g_err, sizeof g_err, "bad spec"); return NULL;
   }
+  if (sp->env_type == PHX_ENV_FSM && sp->n_stage_rules > 0 && sp->stage_rules) {
+    /* the same validation phx_create makes (phx_api.hip): an unknown field name, a comparison code outside PHX_CMP_*, an agent column
+     * outside the kind or a stage outside the env are errors of the spec, not rules to be skipped */
+    for (int r = 0; r < sp->n_stage_rules; ++r) {
+      const phx_stage_rule* q = &sp->stage_rules[r];
+      char nm[33]; memcpy(nm, q->field, 32); nm[32] = 0;
+      int fk = 0, fis, fslot, ncols = 0;
+      const int known = rule_field(nm, &fk, &fis, &fslot);
+      if (known) for (int a = 0; a < sp->n_agents; ++a) ncols += sp->kind[a] == fk;
+      if (!known || fk <= 0 || ncols < 1 || q->agent < -1 || q->agent >= ncols || q->cmp < PHX_CMP_LT || q->cmp > PHX_CMP_NE ||
+          q->stage < 0 || q->stage >= sp->n_stages || q->next_stage < 0 || q->next_stage >= sp->n_stages) {
+        snprintf(g_err, sizeof g_err, "stage_rules[%d]: '%s' is not a per-agent state field of this env, or a code / column / stage is out of range", r, nm);
+        return NULL;
+      }
+    }
+  }
   phxo_env* E = (phxo_env*)calloc(1, sizeof *E);
   E->s = *sp; E->A = sp->n_agents; E->B = sp->batch;
   const int A = E->A;

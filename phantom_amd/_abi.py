@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing, ``load_libr
 import ctypes as C
 import os
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 NPI, NPF = 4, 8
 
 # phx_kind
@@ -36,7 +36,7 @@ TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES, F_MT19937 = 1, 2, 4, 8, 16
 
 (ERR_NONE, ERR_NETWORK, ERR_PAYLOAD, ERR_UNKNOWN_MSG, ERR_ROUND_LIMIT, ERR_QUEUE_FULL,
- ERR_CONTEXT, ERR_FSM_TRANSITION) = range(8)
+ ERR_CONTEXT, ERR_FSM_TRANSITION, ERR_HINT) = range(9)
 MAX_ROUNDS = 4096            # PHX_MAX_ROUNDS: cap on BatchResolver(round_limit=None) rounds
 
 _u8p, _i32p, _f32p, _f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/phantom_amd.h"
 
 #define PHX_SHOP_MAX_STOCK 100   // supply_chain.py:13
@@ -202,6 +204,23 @@ struct DevSpec {
   int32_t lean_lds;              // generic engine: the dynamic steps' sort / scan scratch is in the workspace, not in LDS (LEAN)
   const DevSpec* self_dev;       // this struct in device memory (kernels that read it through the scalar cache instead of 300 SGPRs)
 };
+
+// Per-device "done once" flags of a launcher (function attributes are per device): one bit per device id, updated atomically -- a process
+// may drive several GPUs from several host threads; setting an attribute twice is harmless, skipping it on a device is a failed launch.
+struct PhxPerDeviceOnce {
+  std::atomic<unsigned long long> bits{0ull};
+  bool done(int dev) const { return dev >= 0 && dev < 64 && ((bits.load(std::memory_order_acquire) >> dev) & 1ull); }
+  void mark(int dev) { if (dev >= 0 && dev < 64) bits.fetch_or(1ull << dev, std::memory_order_release); }
+};
+// compute units of the calling thread's current device (cached per device id)
+inline int phx_device_cu_count() {
+  static std::atomic<int> cu[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cu[dev].load(std::memory_order_relaxed);
+  if (n <= 0) { hipDeviceProp_t pr; n = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; cu[dev].store(n, std::memory_order_relaxed); }
+  return n;
+}
 
 // names of the kernels the calling thread's last phx_step / phx_rollout / phx_resolve launched (phx_last_kernel, tests)
 void phx_note_kernel(const char* name);

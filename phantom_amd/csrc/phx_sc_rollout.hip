@@ -537,13 +537,13 @@ hipError_t phx_launch_sc_rollout_fast(const DevSpec& sp, const phx_rollout_io& i
 #define PHX_LAUNCH_FAST(NT_) hipLaunchKernelGGL((phx_sc_rollout_fast_kernel<NT_>), grid, dim3(NT_), lds, st, a)
   if (lds > 64 * 1024) {               // more than 64 KB of dynamic LDS needs the attribute (wide workgroups)
     // (per device, result checked: ADVICE r4 -- a second GPU of the process never got the attribute)
-    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev);
-    if (dev_done != dev) {
+    static PhxPerDeviceOnce attr_done; int dev = 0; (void)hipGetDevice(&dev);
+    if (!attr_done.done(dev)) {
       hipError_t ae = hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)phx_sc_rollout_fast_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (ae != hipSuccess) return ae;
-      dev_done = dev;
+      attr_done.mark(dev);
     }
   }
   if (nt == 1024) PHX_LAUNCH_FAST(1024);

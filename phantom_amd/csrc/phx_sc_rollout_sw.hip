@@ -121,6 +121,14 @@ typedef const __attribute__((address_space(4))) char* sw_kptr_t;
 // (measured: 1-2 us per T = 400 launch; round 2's kernel, whose lanes wrote partial lines, was twice as slow with such stores).
 typedef float sw_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void sw_store16(char* p, const float4 v) { __builtin_nontemporal_store((sw_f4v){v.x, v.y, v.z, v.w}, (sw_f4v*)p); }
+// REPLAY, a hint the caller vouched for that does not hold (phx_rollout_io.hints): an action that rounds below zero under
+// PHX_RH_ACTIONS_IN_DOMAIN (its sign lands in `rq_or`, the OR of the quad's rounded requests), an order byte >= 5 under PHX_RH_EXO_IN_DOMAIN
+// (`xbad`: per raw dword (w & 0xF8F8F8F8) | ((w + 0x03030303) & 0x08080808) -- a byte >= 8, or one in [5, 8) where no byte carries).  The
+// env's rows are unspecified then, but not silently: err[b] = PHX_ERR_HINT (sticky like every soft error; lanes of one env write the same code).
+__device__ __forceinline__ uint32_t sw_exo_bad(uint32_t w) { return (w & 0xF8F8F8F8u) | ((w + 0x03030303u) & 0x08080808u); }
+__device__ __forceinline__ void sw_hint_violation(int32_t* err, int64_t b, int rq_or, uint32_t xbad) {
+  if (__builtin_expect((rq_or < 0) | (xbad != 0u), 0)) { if (err && err[b] == 0) err[b] = PHX_ERR_HINT; }
+}
 #define a (*(const SwArgs*)kp)
 #define io (a.io)
 #define SW_REFRESH() asm volatile("" : "+s"(kp))
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       // replayed inputs first: their loads are in flight while the Philox block (if one is needed) is computed
       float av[4] = {0.f, 0.f, 0.f, 0.f};
       int Dx[4] = {0, 0, 0, 0};
+      uint32_t xbad = 0u; int rq_or = 0;
       if (REPLAY) {
         const int64_t pair = g_base + gl;
         if (rp_act) {
@@ -360,9 +369,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
               if (K_ >= 4) {
                 uint32_t w0, w1;
                 __builtin_memcpy(&w0, row, 4); __builtin_memcpy(&w1, row + (K_ - 4), 4);
+                xbad |= sw_exo_bad(w0) | sw_exo_bad(w1);
                 if (K_ > 4) w0 += (w1 >> (8 * (8 - K_))) ;             // the K - 4 bytes w0 does not hold: byte-wise add (no carries: draws < 5)
                 d = (int)((w0 * 0x01010101u) >> 24);
-              } else for (int k = 0; k < K_; ++k) d += (int)row[k];
+              } else for (int k = 0; k < K_; ++k) { d += (int)row[k]; xbad |= row[k] >= 5 ? 1u : 0u; }
               Dx[h] = d;
             }
           }
@@ -431,7 +441,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         else
         s_rd[i + h * G] = (uint16_t)(Rq | (D[h] << 8));
         s_act[i + h * G] = action;
+        if (REPLAY) rq_or |= Rq;
       }
+      if (REPLAY) sw_hint_violation(io.err, genv - a.env_offset, rq_or, xbad);
     }
     if (FSM && fixed) { dl_pos0 += tc; if (dl_pos0 >= (int)ns_u) dl_pos0 -= (int)ns_u; }
   };
@@ -662,6 +674,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const int tla = 4 * dl_jr0;
     // (0) REPLAY: the recorded inputs of the quad first -- the longest latency of the phase
     float av[4] = {0.f, 0.f, 0.f, 0.f}; int Dx[4] = {0, 0, 0, 0};
+    uint32_t xbad = 0u; int rq_or = 0;
     if (REPLAY) {
       const int64_t pair = g_base + dl_gl;
       if (rp_act) {
@@ -678,9 +691,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
           if (K_ >= 4) {
             uint32_t w0, w1;
             __builtin_memcpy(&w0, row, 4); __builtin_memcpy(&w1, row + (K_ - 4), 4);
+            xbad |= sw_exo_bad(w0) | sw_exo_bad(w1);
             if (K_ > 4) w0 += (w1 >> (8 * (8 - K_)));
             d = (int)((w0 * 0x01010101u) >> 24);
-          } else for (int k = 0; k < K_; ++k) d += (int)row[k];
+          } else for (int k = 0; k < K_; ++k) { d += (int)row[k]; xbad |= row[k] >= 5 ? 1u : 0u; }
           Dx[h] = d;
         }
       }
@@ -737,7 +751,9 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       const int Rq = rp_act ? (int)fminf(rintf(action), 255.0f) : (int)rintf(action);
       s_rd[i + h * G] = (uint16_t)(Rq | (D[h] << 8));
       s_act[i + h * G] = action;
+      if (REPLAY) rq_or |= Rq;
     }
+    if (REPLAY) sw_hint_violation(io.err, dl_genv - a.env_offset, rq_or, xbad);
     if (__builtin_expect(rej, 0)) {                                      // a rejected word: that row again, from the retry stream
 #pragma unroll 1
       for (int h = 0; h < 4; ++h) {
@@ -1212,8 +1228,7 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   a.n_groups = (int32_t)(((int64_t)sp.B * sp.S) / p.G);
   unsigned n_wg = (unsigned)a.n_groups;
   if (phx_knobs().sw_persist) {
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = phx_device_cu_count();
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(SW_LDS_MAX / (size_t)p.lds, (size_t)(2048 / p.nt)));
     unsigned resident = (unsigned)n_cu * per_cu;
     if (n_wg > resident) n_wg = resident >= 8 ? resident & ~7u : resident;        // (a multiple of 8: virtual workgroup vb stays on the XCD of vb % 8)
@@ -1246,8 +1261,8 @@ hipError_t phx_launch_sc_rollout_sw(const DevSpec& sp, const phx_rollout_io& io,
   phx_note_kernel(fsm ? "phx_sc_rollout_sw_kernel[fsm]" : (replay ? "phx_sc_rollout_sw_kernel[replay]" : "phx_sc_rollout_sw_kernel"));
   // more than 64 KB of dynamic LDS needs the attribute (once per instantiation and device)
 #define SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, RP_) do { \
-    static int dev_done = -1; int dev = 0; (void)hipGetDevice(&dev); \
-    if (dev_done != dev) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; dev_done = dev; } \
+    static PhxPerDeviceOnce attr_done; int dev = 0; (void)hipGetDevice(&dev); \
+    if (!attr_done.done(dev)) { hipError_t e = hipFuncSetAttribute((const void*)phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_MAX); if (e != hipSuccess) return e; attr_done.mark(dev); } \
     hipLaunchKernelGGL((phx_sc_rollout_sw_kernel<TC_, GT_, NREC_, NSTORE_, NWORK_, RP_>), grid, dim3(p.nt), (size_t)p.lds, st, a); } while (0)
 #define SW_LAUNCH_PLAIN(TC_, GT_, NREC_, NSTORE_, NWORK_) do { if (replay) SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, 1); else SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, 0); } while (0)
 #define SW_LAUNCH(TC_, GT_, NREC_, NSTORE_, NWORK_) do { if (fsm) SW_LAUNCH_(TC_, GT_, NREC_, NSTORE_, NWORK_, 2); else SW_LAUNCH_PLAIN(TC_, GT_, NREC_, NSTORE_, NWORK_); } while (0)

@@ -63,6 +63,12 @@ class HostStep:
     def __init__(self, dev, buf, event, seq):
         self._dev, self._buf, self._event, self._seq, self._arrays = dev, buf, event, seq, None
 
+    def materialise(self) -> None:
+        """bring the arrays to the host now if nobody has read them yet (DeviceEnv calls this for a result that is still referenced
+        right before its pinned buffer is reused: a poll() result then outlives any number of later steps)"""
+        if self._arrays is None:
+            self.get()
+
     def get(self) -> Dict[str, "object"]:
         if self._arrays is None and self._buf is None:            # lazy: the copy is made now, from the step outputs themselves
             if self._dev._out_seq != self._seq:
@@ -86,10 +92,12 @@ class StepGraph:
     """``n`` captured ``phx_step`` launches (DeviceEnv.step_graph); ``replay()`` enqueues them on the
     current stream without per-step host work."""
 
-    def __init__(self, graph, actions, out, n):
-        self.graph, self.actions, self.out, self.n = graph, actions, out, n
+    def __init__(self, graph, actions, out, n, dev=None):
+        self.graph, self.actions, self.out, self.n, self._dev = graph, actions, out, n, dev
 
     def replay(self):
+        if self._dev is not None:
+            self._dev._out_seq += 1      # the replay rewrites the step outputs: a lazy poll() result of an earlier step must not read them
         self.graph.replay()
         return self.out
 
@@ -365,19 +373,28 @@ class DeviceEnv:
     def pull_step_async(self) -> "HostStep":
         """The last step's outputs on their way to the host WITHOUT a synchronisation: one non-blocking copy of the output buffer
         into one of three rotating pinned buffers with an event behind it.  ``HostStep.get()`` waits for the event (once) and
-        returns copies of the arrays, so a result stays valid however many steps follow; a HostStep that was never read costs the
-        copy (~25 us of stream time at SC64, B = 4096) and nothing on the host."""
+        returns copies of the arrays, so a result stays valid however many steps follow -- also one that is FIRST read many steps
+        later: a result that is still referenced when its buffer comes up for reuse is copied out before the reuse; a HostStep
+        nobody kept costs the copy (~25 us of stream time at SC64, B = 4096) and nothing on the host."""
+        import weakref
         torch = _torch()
         ring = self.__dict__.setdefault("_host_ring", [])
+        owners = self.__dict__.setdefault("_host_ring_owner", [None, None, None])
         if len(ring) < 3:
             ring.append(torch.empty(self._out_flat.shape, dtype=torch.uint8, pin_memory=True))
         k = self.__dict__.get("_host_ring_k", 0)
+        slot = k % 3 if len(ring) == 3 else len(ring) - 1
+        prev = owners[slot]() if owners[slot] is not None else None
+        if prev is not None:
+            prev.materialise()           # somebody still holds the result that lives in this buffer and has not read it: copy it out first
         self._host_ring_k = k + 1
-        buf = ring[k % len(ring)] if len(ring) == 3 else ring[-1]
+        buf = ring[slot]
         buf.copy_(self._out_flat, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return HostStep(self, buf, ev, k)
+        hs = HostStep(self, buf, ev, k)
+        owners[slot] = weakref.ref(hs)
+        return hs
 
     def _needs_valid_planes(self) -> bool:
         # validity masks: stage-masked envs, and kinds whose encode_observation can return None
@@ -531,8 +548,11 @@ class DeviceEnv:
         rows ``[i T, (i + 1) T)``.  The fixed cost of a launch (pipeline fill, placing a 160 KB workgroup on every CU, the kernel
         boundary: ~9 us against 12.5 us of streaming per 100 steps of SC64 at B = 4096) is paid once per call instead of once per
         fragment where the store-wave supply-chain kernel serves the env; other envs run one launch per fragment inside the call.
-        ``actions`` / ``exo``: replayed inputs for all ``len(outs) * T`` steps (``*_in_domain``: as in ``rollout``).  The observation after the last step is in EVERY
-        fragment's ``last_obs`` tensor only if they share it; it is written to ``outs[-1].last_obs``."""
+        ``actions`` / ``exo``: replayed inputs for all ``len(outs) * T`` steps (``*_in_domain``: as in ``rollout``).
+        ONE difference from separate calls: only the observation after the LAST step is produced (``phx_rollout_io.last_obs``, written to
+        ``outs[-1].last_obs``); the library has no per-fragment boundary observation, so the returned fragments i < k - 1 carry
+        ``last_obs=None`` (their ``last_obs`` tensors are left untouched) -- a learner that bootstraps from a fragment's boundary uses the
+        next fragment's first row inputs, or asks for one fragment per call."""
         outs = list(outs)
         k = len(outs)
         if k == 1:
@@ -567,14 +587,14 @@ class DeviceEnv:
             io.actions, io.exo = ptr(actions), ptr(exo)
             io.last_obs = ptr(outs[-1].last_obs)
             io.err = self.err.data_ptr()
-            cached = (io, C.byref(io), arr)
+            cached = (io, C.byref(io), arr, [o._replace(last_obs=None) for o in outs[:-1]] + [outs[-1]])
             if len(self._rollout_io_cache) >= 4:
                 self._rollout_io_cache.pop(next(iter(self._rollout_io_cache)))
             self._rollout_io_cache[key] = cached
         rc = self.lib.phx_rollout(self.handle, cached[1], self._stream())
         if rc != 0:
             self._check(rc, "phx_rollout")
-        return outs
+        return cached[3]
 
     # ---- per-env legacy-numpy MT19937 streams (ABI 7, PHX_F_MT19937) -------------------------------------------------
     def mt_seed(self, seeds):
@@ -651,7 +671,7 @@ class DeviceEnv:
                 a = actions[i] if actions is not None else policy(out).contiguous()
                 out = self.step(a, action_valid)
         torch.cuda.synchronize(self.device)
-        return StepGraph(g, actions, self._step_out, n)
+        return StepGraph(g, actions, self._step_out, n, self)
 
     def rollout_graph(self, T: int, trajectories):
         """Capture one ``phx_rollout`` of T steps per buffer of ``trajectories`` (from ``alloc_trajectory(T)``), in order, into a

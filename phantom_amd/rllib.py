@@ -273,11 +273,14 @@ class BatchedBaseEnv(_BaseEnvBase):
     * ``send_action_tensor(actions, action_valid=None)`` is the tensor fast path (no python per env);
     * ``try_reset(env_id=None, *, seed=None, options=None)`` -> (obs MultiEnvDict, infos MultiEnvDict)."""
 
-    def __init__(self, env, keep_results: bool = False) -> None:
-        """``keep_results``: a poll() result may be read FIRST after later steps (its arrays are copied to the host asynchronously with
-        every poll: ~25 us of stream time per step at SC64, B = 4096).  Default: a result is brought to the host when one of its rows
-        is first read, which has to happen before the next send_actions() -- RLlib's samplers read every poll() at once; a loop that
-        stays on tensors (send_action_tensor + the device's StepTensors) pays nothing for polling."""
+    def __init__(self, env, keep_results: bool = True) -> None:
+        """``keep_results`` (default): a poll() result stays readable however many steps / resets follow, whenever it is first read --
+        the contract of RLlib's BaseEnv and of every earlier version of this adapter ("rows outlive the next step").  Its arrays travel
+        to the host asynchronously with every poll (no host synchronisation; ~25 us of stream time per step at SC64, B = 4096) and a
+        result that is still referenced when its pinned buffer is reused is copied out first.
+        ``keep_results=False`` is the zero-copy opt-in for loops that stay on tensors (send_action_tensor + the device's StepTensors
+        and poll only for form's sake): a result is brought to the host when one of its rows is first read, which then has to happen
+        BEFORE the next send_actions() / send_action_tensor() / try_reset() / StepGraph.replay() (DeviceError otherwise)."""
         self.env = env
         self._keep = bool(keep_results)
         self._ids = env.strategic_agent_ids

@@ -13,6 +13,10 @@ import numpy as np
 
 from . import _abi
 
+# state-field prefix -> agent kind (phx_api.hip: layout()): what a StageRule's `field` may name
+_RULE_FIELD_KIND = {"shop": _abi.KIND_SHOP, "seller": _abi.KIND_SELLER, "buyer": _abi.KIND_BUYER, "cashbox": _abi.KIND_CASHBOX,
+                    "reqresp": _abi.KIND_REQRESP, "mock": _abi.KIND_MOCK_STRAT, "adv": _abi.KIND_ADVERTISER, "pub": _abi.KIND_PUBLISHER}
+
 
 @dataclass
 class EnvSpec:
@@ -346,7 +350,17 @@ def compile_spec(network, num_steps: int, batch_size: int = 1, env_type: int = _
                     raise ValueError(f"StageRule: unknown comparison {r.cmp!r} (one of {sorted(_abi.CMP)})")
                 if r.next_stage not in sidx:
                     raise ValueError(f"StageRule: next stage {r.next_stage!r} is not a stage of the env")
-                col = -1 if r.agent is None else int(kr[index_of(r.agent)])
+                col = -1
+                if r.agent is not None:
+                    # the column is the agent's rank AMONG THE AGENTS OF THE FIELD'S KIND: an agent of another kind would silently
+                    # address some other agent's value (phx_create only checks the column against the kind's size)
+                    a = index_of(r.agent)
+                    fk = _RULE_FIELD_KIND.get(str(r.field).split(".")[0])
+                    if fk is None or int(spec.kind[a]) != fk:
+                        from .fsm import FSMValidationError
+                        raise FSMValidationError(f"StageRule({r.field!r}, agent={r.agent!r}): the agent is a "
+                                                 f"{_abi.KIND_NAMES.get(int(spec.kind[a]), '?')}, the field belongs to another kind")
+                    col = int(kr[a])
                 rows.append((sidx[sid], r.field, col, _abi.CMP[r.cmp], float(r.threshold), sidx[r.next_stage]))
             spec.stage_rules = rows
     elif env_type == _abi.ENV_STACKELBERG:

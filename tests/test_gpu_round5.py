@@ -387,9 +387,11 @@ def test_send_actions_decides_by_key_membership_not_by_a_nan_sentinel():
         ba.send_actions(d)
 
 
-def test_poll_results_stay_valid_over_later_steps_and_are_refused_once_their_buffer_is_reused():
+def test_poll_results_stay_valid_over_later_steps_whenever_they_are_first_read():
     """BatchedBaseEnv.poll() on a plain env returns before anything has reached the host (DeviceEnv.pull_step_async): a result read one
-    or two steps later still holds ITS step's rows; one first read after its pinned buffer has been reused raises."""
+    or two steps later still holds ITS step's rows, and so does one FIRST read after its pinned buffer has come up for reuse (a result
+    that is still referenced is copied out before the reuse: ADVICE r5 -- "rows outlive the next step" is the default contract again);
+    the zero-copy mode (keep_results=False) is the opt-in whose results must be read before the next step."""
     import torch
     from phantom_amd.device import DeviceError
     from phantom_amd.rllib import BatchedBaseEnv
@@ -414,20 +416,29 @@ def test_poll_results_stay_valid_over_later_steps_and_are_refused_once_their_buf
     stale = held[0][0]
     assert stale[0][0] is not None                                # already materialised: still readable
     be.send_action_tensor(acts[0]); late = be.poll()
-    for a in acts[:4]:
+    bref.send_action_tensor(acts[0]); r = bref.poll()
+    want = {aid: (r[0][0][aid].copy(), r[1][0][aid], r[3][0][aid]) for aid in ids}
+    for a in acts[:5]:
         be.send_action_tensor(a); be.poll()
-    with pytest.raises(DeviceError):
-        late[0][0]
-    # the default adapter: a result is read before the next step or not at all
-    lazy = BatchedBaseEnv(supply_chain_env(S, [2] * S, 50, B, seed=4))
+        bref.send_action_tensor(a); bref.poll()
+    be.try_reset()
+    for aid in ids:                                               # first read five steps and a reset later: still the rows of ITS step
+        assert np.array_equal(late[0][0][aid], want[aid][0]) and late[1][0][aid] == want[aid][1] and late[3][0][aid] == want[aid][2]
+    assert BatchedBaseEnv(env)._keep                              # ... and that is the default
+    # the zero-copy opt-in: a result is read before the next step or not at all
+    lazy = BatchedBaseEnv(supply_chain_env(S, [2] * S, 50, B, seed=4), keep_results=False)
     lazy.poll()
     lazy.send_action_tensor(acts[0]); r0 = lazy.poll()
     first = r0[0][0][ids[0]].copy()                               # read in time: the step's rows, and they stay
     lazy.send_action_tensor(acts[1]); r1 = lazy.poll()
     assert np.array_equal(r0[0][0][ids[0]], first)
-    lazy.send_action_tensor(acts[2]); lazy.poll()
+    lazy.send_action_tensor(acts[2]); r2 = lazy.poll()
     with pytest.raises(DeviceError):
         r1[1][0]                                                  # first read after the next step
+    sg = lazy.env._device().step_graph(acts[0].to(lazy.env._device().device)[None].contiguous())
+    sg.replay()                                                   # a captured step rewrites the step outputs too
+    with pytest.raises(DeviceError):
+        r2[0][0]
 
 
 # ---- stage handlers that branch on agent state, evaluated on the device (phx_spec.stage_rules, ABI 9) ------------------
