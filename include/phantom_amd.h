@@ -261,6 +261,8 @@ typedef struct phx_spec {
 #define PHX_VS_AUTO          0
 #define PHX_VS_FUSED         1  /* the static-schedule kernel of the env's family (default where one applies)                      */
 #define PHX_VS_GENERIC       2  /* the message-passing engine (same as PHX_F_FORCE_GENERIC)                                       */
+#define PHX_VS_GENERIC_DYNAMIC 4 /* the message-passing engine WITHOUT its compiled schedule: the dynamic kernel (LDS atomics, block scans, rank sort)
+                                   for every step, also where phx_sched_step_kernel would serve the spec (ABI 10; tests compare the two)      */
 #define PHX_VS_WIDE          3  /* plain supply chain, device-RNG orders: four (env, shop) pairs per thread, 16-byte accesses (AUTO
                                    takes it from 2^19 pairs per launch up; smaller launches are latency-bound either way)          */
 

@@ -30,7 +30,7 @@ ENV_PLAIN, ENV_FSM, ENV_STACKELBERG = 0, 1, 2
 # phx_spec.variant_* (ABI 6)
 VR_AUTO, VR_TIME_PARALLEL, VR_LEAN, VR_GENERAL, VR_LAUNCH_LOOP, VR_STORE_WAVES = 0, 1, 2, 3, 4, 5
 VB_WHOLE_ENVS = -1
-VS_AUTO, VS_FUSED, VS_GENERIC, VS_WIDE = 0, 1, 2, 3
+VS_AUTO, VS_FUSED, VS_GENERIC, VS_WIDE, VS_GENERIC_DYNAMIC = 0, 1, 2, 3, 4
 SAMPLER_HOST, SAMPLER_UNIFORM = 0, 1
 TYPE_NONE, TYPE_CONST = -2, -1
 F_IGNORE_CONN_ERRORS, F_NO_PAYLOAD_CHECKS, F_FORCE_GENERIC, F_SHUFFLE_BATCHES, F_MT19937 = 1, 2, 4, 8, 16

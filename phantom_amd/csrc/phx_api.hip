@@ -19,6 +19,10 @@ size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx, boo
 size_t phx_generic_lean_ws_bytes(int Q, int scan_cap);
 size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
+bool phx_sched_compile(const phx_spec* spec, int A, int n_lists, const int32_t* act_ptr, const int32_t* act_idx, const uint8_t* act_mask,
+                       const uint8_t* obs_mask, const uint8_t* rew_mask, const int32_t* kind_rank, const int32_t* exo_rank, const int32_t* strat_rank,
+                       const int32_t* reset_obs_idx, int n_reset_obs, std::vector<int32_t>* blob, std::vector<int32_t>* recs, int* L_out, int* qmax_out);
+size_t phx_sched_lds_bytes(int words, int L, int qstride);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if = nullptr, int32_t gen = 0);
@@ -86,7 +90,7 @@ struct Derived {
 
 // phx_spec.variant_step == PHX_VS_GENERIC and variant_rollout == PHX_VR_LAUNCH_LOOP select the message-passing engine like PHX_F_FORCE_GENERIC
 static uint32_t eff_flags(const phx_spec* sp) {
-  return sp->flags | ((sp->variant_step == PHX_VS_GENERIC || sp->variant_rollout == PHX_VR_LAUNCH_LOOP) ? PHX_F_FORCE_GENERIC : 0u);
+  return sp->flags | ((sp->variant_step == PHX_VS_GENERIC || sp->variant_step == PHX_VS_GENERIC_DYNAMIC || sp->variant_rollout == PHX_VR_LAUNCH_LOOP) ? PHX_F_FORCE_GENERIC : 0u);
 }
 
 static int derive(const phx_spec* sp, Derived& d) {
@@ -668,6 +672,7 @@ extern "C++" const DevKnobs& phx_knobs() {
     k.generic_nt = rd("PHX_GENERIC_NT", 0);
     k.generic_remap = rd("PHX_GENERIC_REMAP", 1);
     k.generic_tablds = rd("PHX_GENERIC_TABLDS", 1);
+    k.generic_sched = rd("PHX_GENERIC_SCHED", 1);
     k.rollout_epb = rd("PHX_ROLLOUT_EPB", 0);
     k.rollout_fast = rd("PHX_ROLLOUT_FAST", -1);     // -1: unset; 0 switches the kernel off
     k.rollout_first = rd("PHX_ROLLOUT_FIRST", 0);
@@ -769,10 +774,37 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
     d.n_rules = (int32_t)rl.size();
   }
   d.sched = nullptr; d.sched_off = nullptr;
+  bool sched_every_list = false;
   if (!der.sc_static && !der.stk_static && !der.ads_static) {      // specs the generic engine serves
     StaticSched ss;
     build_static_schedule(spec, der, ss);
-    if (!ss.blob.empty()) { UP(sched, ss.blob.data(), ss.blob.size()); UP(sched_off, ss.off.data(), ss.off.size()); }
+    if (!ss.blob.empty()) {
+      UP(sched, ss.blob.data(), ss.blob.size()); UP(sched_off, ss.off.data(), ss.off.size());
+      sched_every_list = true;
+      for (int l = 0; l < der.n_lists; ++l) sched_every_list = sched_every_list && ss.off[l] >= 0;
+    }
+  }
+  // ... and, where the flow is the supply chain's, the same schedule COMPILED for the several-envs-per-wave kernel (phx_generic_sched.hip)
+  d.gs_ok = 0;
+  if (d.sched && der.D == 3 && !der.any_typed) {
+    const bool all = sched_every_list;
+    std::vector<int32_t> gblob, grecs; int gL = 0, gq = 0;
+    if (all && phx_sched_compile(spec, A, der.n_lists, der.act_ptr.data(), der.act_idx.data(), der.act_mask.data(), der.obs_mask.data(), der.rew_mask.data(),
+                                 der.kind_rank.data(), der.exo_rank.data(), der.strat_rank.data(), der.reset_obs_idx.data(), (int)der.reset_obs_idx.size(),
+                                 &gblob, &grecs, &gL, &gq)) {
+      int qstride = gq + 1;
+      while ((qstride & 31) != 9) ++qstride;                    // (the env instances of a wave start their queues 9 banks apart)
+      if (phx_sched_lds_bytes((int)gblob.size(), gL, qstride) <= 48 * 1024) {
+        UP(gs_blob, gblob.data(), gblob.size());
+        if (grecs.empty()) grecs.assign(2, 0);
+        UP(gs_rec, grecs.data(), grecs.size());
+        std::vector<uint8_t> zf((size_t)d.B, 0); const uint8_t* fl = nullptr; const int32_t zw = 0; const int32_t* wd = nullptr;
+        rc = upload(e, zf.data(), zf.size(), &fl); if (rc != PHX_OK) { phx_destroy(e); return rc; }
+        rc = upload(e, &zw, 1, &wd); if (rc != PHX_OK) { phx_destroy(e); return rc; }
+        d.gs_dyn_flag = (uint8_t*)fl; d.gs_dyn_word = (int32_t*)wd;
+        d.gs_ok = 1; d.gs_L = gL; d.gs_qstride = qstride; d.gs_words = (int32_t)gblob.size();
+      }
+    }
   }
   UP(stage_rew_all, der.stage_rew_all.data(), der.stage_rew_all.size());
   UP(reset_obs_idx, der.reset_obs_idx.data(), der.reset_obs_idx.size());

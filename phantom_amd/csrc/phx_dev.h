@@ -62,6 +62,7 @@ struct DevKnobs {
   int generic_nt;              // PHX_GENERIC_NT (default 0)
   int generic_remap;           // PHX_GENERIC_REMAP (default 1)
   int generic_tablds;          // PHX_GENERIC_TABLDS (default 1)
+  int generic_sched;           // PHX_GENERIC_SCHED (default 1): specs with a compiled schedule run on phx_sched_step_kernel (0: the dynamic kernel everywhere)
   int rollout_epb;             // PHX_ROLLOUT_EPB (default 0)
   int rollout_fast;            // PHX_ROLLOUT_FAST (default -1 = unset; 0: off)
   int rollout_first;           // PHX_ROLLOUT_FIRST (default 0)
@@ -201,6 +202,12 @@ struct DevSpec {
   // state blob field pointers
   void* f[F_COUNT];
   int64_t ws_stride;             // workspace bytes per env
+  // the message-passing engine with a COMPILED schedule (phx_generic_sched.hip): several env instances per wave
+  int32_t gs_ok, gs_L, gs_qstride, gs_words;   // applies / lanes per env instance / words per queue / words of gs_blob
+  const int32_t* gs_blob;        // [n_lists] word offset of each list's program, then the programs (layout: phx_sched_compile)
+  const int32_t* gs_rec;         // (sender | receiver << 16, type | round << 16) of every message of every list's step, in log order
+  uint8_t* gs_dyn_flag;          // [B] 1: the env's step is outside the schedule's premise (a done agent, an acting shop without an action)
+  int32_t* gs_dyn_word;          // == the launch's GenArgs::gs_gen: some env of that launch was flagged
   int32_t lean_lds;              // generic engine: the dynamic steps' sort / scan scratch is in the workspace, not in LDS (LEAN)
   const DevSpec* self_dev;       // this struct in device memory (kernels that read it through the scalar cache instead of 300 SGPRs)
 };
@@ -240,6 +247,9 @@ struct GenArgs {               // arguments of the generic engine kernel
   int32_t roll_t;
   int32_t roll_T;               // > 0: the kernel itself loops over steps roll_t .. roll_t + roll_T - 1 (queues, tables and the env's
                                 // workgroup stay resident; io.exo / io.msg_log / io.msg_count are then [T][B][..] bases); 0: one step
+  int32_t gs_gen;               // compiled-schedule launches: this launch's number (DevSpec::gs_dyn_word)
+  int32_t only_flagged;         // phx_generic_step_kernel behind a compiled-schedule launch: only the envs that launch flagged (a grid-stride loop
+                                // over the batch; returns at entry when none was)
   const float* roll_actions_in; // [T][B][S] replayed policy or NULL -> random policy
   float* roll_actions;          // [B][S] scratch the acting phase reads (= io.actions)
   phx_rollout_io roll;

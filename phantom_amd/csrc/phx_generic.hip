@@ -20,6 +20,8 @@
 //     compacts the responses into the next round's queue = the order network.send was called.
 // Queues live in LDS (template LDSQ = true); envs whose queue does not fit use a per-env
 // workspace carved from the caller's state blob.
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "phx_dev.h"
@@ -669,8 +671,17 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
 #define GTICK(k) PHX_REFRESH()
 #endif
 
-  const int b = xcd_block(g.xcd_remap != 0), tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int A = sp.A, S = sp.S, Q = sp.queue_cap;
+  // Behind a compiled-schedule launch (phx_generic_sched.hip; GenArgs::only_flagged): the envs that launch flagged -- a done agent, an
+  // acting shop without an action -- and nothing else: a grid-stride loop over the batch on a small grid, left at entry when the
+  // launch flagged none (the usual case: one scalar load).  Otherwise one env per workgroup, one trip.
+  if (g.only_flagged && *(const volatile int32_t*)sp.gs_dyn_word != g.gs_gen) return;
+  const int b_first = g.only_flagged ? (int)blockIdx.x : xcd_block(g.xcd_remap != 0);
+  const int b_stride = g.only_flagged ? (int)gridDim.x : sp.B;
+  for (int b = b_first; b < sp.B; b += b_stride) {
+  if (g.only_flagged) { __syncthreads(); if (!sp.gs_dyn_flag[b]) continue; }
+  PHX_REFRESH();
 
   char* mem = LDSQ ? smem : ((char*)sp.f[F_WORKSPACE] + (int64_t)b * sp.ws_stride);
   // queues: the round's messages, the responses by inbox position, and -- only where a handler still reads the old
@@ -1165,6 +1176,7 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   }
   __syncthreads();                                             // the next step reads the words and the state this one wrote
   }   // steps of the launch
+  }   // envs of the workgroup (one, unless only_flagged)
 #ifdef PHX_TIMING
   if (g.timing && threadIdx.x == 0 && blockIdx.x < 64) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
 #endif
@@ -1195,7 +1207,31 @@ size_t phx_generic_table_bytes(int A, int nnz) {
          3 * (size_t)((A * 4 + 15) & ~15) + (size_t)((A + 15) & ~15);
 }
 
+hipError_t phx_launch_sched(const DevSpec& sp, const GenArgs& g, hipStream_t st);
+
+static hipError_t launch_generic_dynamic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st);
+
+// The engine's entry.  Specs with a compiled schedule (DevSpec::gs_ok: static Network, supply-chain kinds) run whole steps and
+// T-step rollout loops on phx_sched_step_kernel; the dynamic kernel follows over the envs that launch flagged (it returns at entry
+// when there are none).  Everything else -- injected sends, bare resolves, the two halves of a split step, replayed shuffles, the
+// one-launch-per-step loop, every other kind -- is the dynamic kernel's.
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
+  if (sp.gs_ok && phx_knobs().generic_sched && sp.variant_step != PHX_VS_GENERIC_DYNAMIC && g_.phase == 0 && !g_.resolve_only && g_.n_inject == 0 &&
+      !g_.io.shuffle && (g_.roll_t < 0 || g_.roll_T > 0)) {
+    static std::atomic<int32_t> gen_counter{0};
+    GenArgs g = g_;
+    int32_t gen = gen_counter.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (gen <= 0) { gen_counter.store(1, std::memory_order_relaxed); gen = 1; }
+    g.gs_gen = gen; g.only_flagged = 0;
+    hipError_t e = phx_launch_sched(sp, g, st);
+    if (e != hipSuccess) return e;
+    g.only_flagged = 1;
+    return launch_generic_dynamic(sp, g, lds, st);
+  }
+  return launch_generic_dynamic(sp, g_, lds, st);
+}
+
+static hipError_t launch_generic_dynamic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
   GenArgs g = g_;
   const bool lean = lds && sp.lean_lds != 0;
   size_t bytes = (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, sp.n_adx, lean) + 15) & ~(size_t)15;
@@ -1225,14 +1261,15 @@ hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hi
   int kmax = 0;
   for (int k = 0; k < PHX_KIND_COUNT; ++k) if (sp.kind_count[k] > 0) kmax = k;
   const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
-  phx_note_kernel(g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel");
+  phx_note_kernel(g.only_flagged ? "phx_generic_step_kernel[flagged envs]" : (g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel"));
   const bool roll = g.roll_t >= 0;
-#define PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, R_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_, R_, false>), dim3(sp.B), dim3(NT_), bytes, st, sp.self_dev, g)
+  const dim3 grid((unsigned)(g.only_flagged ? std::min(sp.B, 512) : sp.B));
+#define PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, R_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_, R_, false>), grid, dim3(NT_), bytes, st, sp.self_dev, g)
 #define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) do { if (roll) PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, true); else PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, false); } while (0)
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)
   if (lean) {                                                // (lean_lds_spec: supply-chain kinds only, 64 < A <= 256)
-    if (roll) hipLaunchKernelGGL((phx_generic_step_kernel<128, true, false, PHX_KIND_CUSTOMER, true, true>), dim3(sp.B), dim3(128), bytes, st, sp.self_dev, g);
-    else hipLaunchKernelGGL((phx_generic_step_kernel<128, true, false, PHX_KIND_CUSTOMER, false, true>), dim3(sp.B), dim3(128), bytes, st, sp.self_dev, g);
+    if (roll) hipLaunchKernelGGL((phx_generic_step_kernel<128, true, false, PHX_KIND_CUSTOMER, true, true>), grid, dim3(128), bytes, st, sp.self_dev, g);
+    else hipLaunchKernelGGL((phx_generic_step_kernel<128, true, false, PHX_KIND_CUSTOMER, false, true>), grid, dim3(128), bytes, st, sp.self_dev, g);
   } else if (!lds) { bytes = 0; PHX_LAUNCH_GENERIC(256, false, false); }
   else if (tablds) { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, true); else PHX_LAUNCH_GENERIC(128, true, true); }
   else { if (nt == 64) PHX_LAUNCH_GENERIC(64, true, false); else PHX_LAUNCH_GENERIC(128, true, false); }

@@ -186,7 +186,8 @@ class EnvSpec:
 
 VARIANT_ROLLOUT = {"auto": _abi.VR_AUTO, "time_parallel": _abi.VR_TIME_PARALLEL, "lean": _abi.VR_LEAN,
                    "general": _abi.VR_GENERAL, "launch_loop": _abi.VR_LAUNCH_LOOP, "store_waves": _abi.VR_STORE_WAVES}
-VARIANT_STEP = {"auto": _abi.VS_AUTO, "fused": _abi.VS_FUSED, "generic": _abi.VS_GENERIC, "wide": _abi.VS_WIDE}
+VARIANT_STEP = {"auto": _abi.VS_AUTO, "fused": _abi.VS_FUSED, "generic": _abi.VS_GENERIC, "wide": _abi.VS_WIDE,
+                "generic_dynamic": _abi.VS_GENERIC_DYNAMIC}
 
 
 def resolve_variants(variants) -> tuple:
