@@ -1378,6 +1378,11 @@ int64_t phxo_set_i32(phxo_env* E, const char* field, const int32_t* in) {
   if (!strcmp(field, "env.step")) { for (int b = 0; b < E->B; ++b) E->env[b].step = in[b]; return E->B; }          /* tests: counters a caller moved */
   if (!strcmp(field, "env.episode")) { for (int b = 0; b < E->B; ++b) E->env[b].episode = in[b]; return E->B; }
   if (!strcmp(field, "env.stage")) { for (int b = 0; b < E->B; ++b) E->env[b].stage = in[b]; return E->B; }   /* tests: a stage off the default chain */
+  if (!strcmp(field, "env.trunc") || !strcmp(field, "env.term")) {      /* tests: a done flag the caller set, [B][S] (the agent then has no context, env.py:338-348) */
+    const int tr = !strcmp(field, "env.trunc");
+    for (int b = 0; b < E->B; ++b) for (int s2 = 0; s2 < E->S; ++s2) (tr ? E->env[b].trunc : E->env[b].term)[s2] = (uint8_t)(in[(size_t)b * E->S + s2] != 0);
+    return (int64_t)E->B * E->S;
+  }
   const ofield* f = find_field(field);
   if (!f || f->is_f) return -1;
   int n = E->kind_count[f->kind];

@@ -10,9 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIB_DIR, "libphantom_amd.so")
-SOURCES = ["phx_api.hip", "phx_generic.hip", "phx_generic_sched.hip", "phx_sc_fused.hip", "phx_sc_rollout.hip", "phx_sc_rollout_sw.hip", "phx_sc_rollout_fsm.hip", "phx_stk_fused.hip",
+SOURCES = ["phx_api.hip", "phx_generic.hip", "phx_sc_fused.hip", "phx_sc_rollout.hip", "phx_sc_rollout_sw.hip", "phx_sc_rollout_fsm.hip", "phx_stk_fused.hip",
            "phx_ads_fused.hip"]
-HEADERS = ["phx_dev.h", "phx_epilogue.h", "phx_sc_fast.h", os.path.join("..", "..", "include", "phantom_amd.h")]
+HEADERS = ["phx_dev.h", "phx_epilogue.h", "phx_sc_fast.h", "phx_generic_sched.hip", os.path.join("..", "..", "include", "phantom_amd.h")]
 # -ffp-contract=off: rewards are f64 "sales - 0.1*stock" with product and difference rounded
 # separately, as the reference's Python floats are (supply_chain.py:147)
 # The kernels are written and tuned for gfx950 (MI355X) only.  PHX_OFFLOAD_ARCH="gfx950;gfx942" adds code

@@ -794,14 +794,14 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
                                  &gblob, &grecs, &gL, &gq)) {
       int qstride = gq + 1;
       while ((qstride & 31) != 9) ++qstride;                    // (the env instances of a wave start their queues 9 banks apart)
-      if (phx_sched_lds_bytes((int)gblob.size(), gL, qstride) <= 48 * 1024) {
+      if (phx_sched_lds_bytes((int)gblob.size(), gL, qstride) <= 48 * 1024 &&
+          phx_generic_queue_bytes(der.A, der.S, spec->queue_cap, der.scan_cap, 0, false) <= 48 * 1024) {      // (the tail workgroups run the dynamic engine in LDS)
         UP(gs_blob, gblob.data(), gblob.size());
         if (grecs.empty()) grecs.assign(2, 0);
         UP(gs_rec, grecs.data(), grecs.size());
-        std::vector<uint8_t> zf((size_t)d.B, 0); const uint8_t* fl = nullptr; const int32_t zw = 0; const int32_t* wd = nullptr;
+        std::vector<int32_t> zf((size_t)d.B, 0); const int32_t* fl = nullptr;
         rc = upload(e, zf.data(), zf.size(), &fl); if (rc != PHX_OK) { phx_destroy(e); return rc; }
-        rc = upload(e, &zw, 1, &wd); if (rc != PHX_OK) { phx_destroy(e); return rc; }
-        d.gs_dyn_flag = (uint8_t*)fl; d.gs_dyn_word = (int32_t*)wd;
+        d.gs_dyn_flag = (int32_t*)fl;
         d.gs_ok = 1; d.gs_L = gL; d.gs_qstride = qstride; d.gs_words = (int32_t)gblob.size();
       }
     }

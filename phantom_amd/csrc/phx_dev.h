@@ -206,8 +206,8 @@ struct DevSpec {
   int32_t gs_ok, gs_L, gs_qstride, gs_words;   // applies / lanes per env instance / words per queue / words of gs_blob
   const int32_t* gs_blob;        // [n_lists] word offset of each list's program, then the programs (layout: phx_sched_compile)
   const int32_t* gs_rec;         // (sender | receiver << 16, type | round << 16) of every message of every list's step, in log order
-  uint8_t* gs_dyn_flag;          // [B] 1: the env's step is outside the schedule's premise (a done agent, an acting shop without an action)
-  int32_t* gs_dyn_word;          // == the launch's GenArgs::gs_gen: some env of that launch was flagged
+  int32_t* gs_dyn_flag;          // [B] 0 between launches; 2 | 1: the env's step is outside the schedule's premise (a done agent, an acting shop
+                                 // without an action) -- published by the env's schedule workgroup, awaited and zeroed by the launch's tail workgroups
   int32_t lean_lds;              // generic engine: the dynamic steps' sort / scan scratch is in the workspace, not in LDS (LEAN)
   const DevSpec* self_dev;       // this struct in device memory (kernels that read it through the scalar cache instead of 300 SGPRs)
 };
@@ -247,9 +247,7 @@ struct GenArgs {               // arguments of the generic engine kernel
   int32_t roll_t;
   int32_t roll_T;               // > 0: the kernel itself loops over steps roll_t .. roll_t + roll_T - 1 (queues, tables and the env's
                                 // workgroup stay resident; io.exo / io.msg_log / io.msg_count are then [T][B][..] bases); 0: one step
-  int32_t gs_gen;               // compiled-schedule launches: this launch's number (DevSpec::gs_dyn_word)
-  int32_t only_flagged;         // phx_generic_step_kernel behind a compiled-schedule launch: only the envs that launch flagged (a grid-stride loop
-                                // over the batch; returns at entry when none was)
+  int32_t gs_reserved0, gs_reserved1;
   const float* roll_actions_in; // [T][B][S] replayed policy or NULL -> random policy
   float* roll_actions;          // [B][S] scratch the acting phase reads (= io.actions)
   phx_rollout_io roll;

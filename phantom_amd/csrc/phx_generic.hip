@@ -651,13 +651,12 @@ static_assert(alignof(GenArgs) == 8 && sizeof(const DevSpec*) == 8, "kernarg lay
 #endif
 // LEAN (two-wave supply chains whose acting lists all have a static schedule): order / slot / scanbuf -- the scratch only a DYNAMIC
 // step sorts and scans in -- live in the env's workspace in the blob instead of LDS: 11.5 instead of 14.6 KB per SC256 env
+// The engine for ONE env instance b, by the calling workgroup of NT threads (whole steps, halves, bare resolves, the T-step loop): the
+// body of phx_generic_step_kernel, and -- in the same launch as the compiled schedule -- what phx_sched_step_kernel's tail workgroups run
+// for the env instances that kernel flags (phx_generic_sched.hip).  Contains workgroup barriers: uniform calls only.
 template <int NT, bool LDSQ, bool TABLDS, int KMAX, bool ROLL, bool LEAN>
-// (the supply-chain rollout instantiation of two-wave workgroups is held to 96 VGPRs: five waves per SIMD = the ten workgroups per CU the queues allow)
-__global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && KMAX <= PHX_KIND_CUSTOMER) ? 5 : 1)) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
-  phx_kptr_t spc = (phx_kptr_t)spp_;
-  phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+__device__ __forceinline__ void phx_generic_env(phx_kptr_t spc, phx_kptr_t kp, char* const smem, const int b) {
   PHX_REFRESH();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   __shared__ int wave_sums[NT / 64];
   __shared__ int s_errkey, s_nterm, s_ntrunc, s_dyn;
@@ -673,15 +672,6 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
 
   const int tid = threadIdx.x;
   const int A = sp.A, S = sp.S, Q = sp.queue_cap;
-  // Behind a compiled-schedule launch (phx_generic_sched.hip; GenArgs::only_flagged): the envs that launch flagged -- a done agent, an
-  // acting shop without an action -- and nothing else: a grid-stride loop over the batch on a small grid, left at entry when the
-  // launch flagged none (the usual case: one scalar load).  Otherwise one env per workgroup, one trip.
-  if (g.only_flagged && *(const volatile int32_t*)sp.gs_dyn_word != g.gs_gen) return;
-  const int b_first = g.only_flagged ? (int)blockIdx.x : xcd_block(g.xcd_remap != 0);
-  const int b_stride = g.only_flagged ? (int)gridDim.x : sp.B;
-  for (int b = b_first; b < sp.B; b += b_stride) {
-  if (g.only_flagged) { __syncthreads(); if (!sp.gs_dyn_flag[b]) continue; }
-  PHX_REFRESH();
 
   char* mem = LDSQ ? smem : ((char*)sp.f[F_WORKSPACE] + (int64_t)b * sp.ws_stride);
   // queues: the round's messages, the responses by inbox position, and -- only where a handler still reads the old
@@ -1176,14 +1166,27 @@ __global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && 
   }
   __syncthreads();                                             // the next step reads the words and the state this one wrote
   }   // steps of the launch
-  }   // envs of the workgroup (one, unless only_flagged)
 #ifdef PHX_TIMING
   if (g.timing && threadIdx.x == 0 && blockIdx.x < 64) for (int q = 0; q < 16; ++q) atomicAdd(&g.timing[q], gtm[q]);
 #endif
 }
 
+// one env instance per workgroup
+template <int NT, bool LDSQ, bool TABLDS, int KMAX, bool ROLL, bool LEAN>
+// (the supply-chain rollout instantiation of two-wave workgroups is held to 96 VGPRs: five waves per SIMD = the ten workgroups per CU the queues allow)
+__global__ __launch_bounds__(NT, LEAN ? PHX_LEAN_WAVES : ((ROLL && NT == 128 && KMAX <= PHX_KIND_CUSTOMER) ? 5 : 1)) void phx_generic_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
+  phx_kptr_t spc = (phx_kptr_t)spp_;
+  phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  PHX_REFRESH();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  phx_generic_env<NT, LDSQ, TABLDS, KMAX, ROLL, LEAN>(spc, kp, smem, xcd_block(g.xcd_remap != 0));
+}
+
 #undef sp
 #undef g
+
+size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx, bool lean);
+#include "phx_generic_sched.hip"      // phx_sched_step_kernel (its tail workgroups call phx_generic_env) and its launcher
 
 // ---- PhantomEnv.reset (env.py:185-237; fsm.py:195-251; stackelberg.py:53-109) -------------------
 template <int NT>
@@ -1207,26 +1210,16 @@ size_t phx_generic_table_bytes(int A, int nnz) {
          3 * (size_t)((A * 4 + 15) & ~15) + (size_t)((A + 15) & ~15);
 }
 
-hipError_t phx_launch_sched(const DevSpec& sp, const GenArgs& g, hipStream_t st);
-
 static hipError_t launch_generic_dynamic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st);
 
 // The engine's entry.  Specs with a compiled schedule (DevSpec::gs_ok: static Network, supply-chain kinds) run whole steps and
-// T-step rollout loops on phx_sched_step_kernel; the dynamic kernel follows over the envs that launch flagged (it returns at entry
-// when there are none).  Everything else -- injected sends, bare resolves, the two halves of a split step, replayed shuffles, the
+// T-step rollout loops on phx_sched_step_kernel (whose tail workgroups step the envs it flags on the dynamic engine, same launch).  Everything else -- injected sends, bare resolves, the two halves of a split step, replayed shuffles, the
 // one-launch-per-step loop, every other kind -- is the dynamic kernel's.
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g_, bool lds, hipStream_t st) {
   if (sp.gs_ok && phx_knobs().generic_sched && sp.variant_step != PHX_VS_GENERIC_DYNAMIC && g_.phase == 0 && !g_.resolve_only && g_.n_inject == 0 &&
       !g_.io.shuffle && (g_.roll_t < 0 || g_.roll_T > 0)) {
-    static std::atomic<int32_t> gen_counter{0};
-    GenArgs g = g_;
-    int32_t gen = gen_counter.fetch_add(1, std::memory_order_relaxed) + 1;
-    if (gen <= 0) { gen_counter.store(1, std::memory_order_relaxed); gen = 1; }
-    g.gs_gen = gen; g.only_flagged = 0;
-    hipError_t e = phx_launch_sched(sp, g, st);
-    if (e != hipSuccess) return e;
-    g.only_flagged = 1;
-    return launch_generic_dynamic(sp, g, lds, st);
+    const GenArgs& g = g_;
+    return phx_launch_sched(sp, g, st);
   }
   return launch_generic_dynamic(sp, g_, lds, st);
 }
@@ -1261,9 +1254,9 @@ static hipError_t launch_generic_dynamic(const DevSpec& sp, const GenArgs& g_, b
   int kmax = 0;
   for (int k = 0; k < PHX_KIND_COUNT; ++k) if (sp.kind_count[k] > 0) kmax = k;
   const bool sc_only = kmax <= PHX_KIND_CUSTOMER;
-  phx_note_kernel(g.only_flagged ? "phx_generic_step_kernel[flagged envs]" : (g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel"));
+  phx_note_kernel(g.roll_T > 0 ? "phx_generic_step_kernel[T-step loop]" : "phx_generic_step_kernel");
   const bool roll = g.roll_t >= 0;
-  const dim3 grid((unsigned)(g.only_flagged ? std::min(sp.B, 512) : sp.B));
+  const dim3 grid((unsigned)sp.B);
 #define PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, R_) hipLaunchKernelGGL((phx_generic_step_kernel<NT_, L_, T_, K_, R_, false>), grid, dim3(NT_), bytes, st, sp.self_dev, g)
 #define PHX_LAUNCH_GENERIC_K(NT_, L_, T_, K_) do { if (roll) PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, true); else PHX_LAUNCH_GENERIC_R(NT_, L_, T_, K_, false); } while (0)
 #define PHX_LAUNCH_GENERIC(NT_, L_, T_) do { if (sc_only) PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_CUSTOMER); else PHX_LAUNCH_GENERIC_K(NT_, L_, T_, PHX_KIND_COUNT - 1); } while (0)

@@ -20,12 +20,14 @@
 //     which writes observations / rewards / flags straight from them; in a rollout launch (the T-step loop) it stays there
 //     from one step to the next, together with fsm.py's reward / observation caches;
 //   * what the schedule's premise excludes is checked per env at entry (a done agent, an acting shop without an action): such
-//     envs are flagged and left to phx_generic_step_kernel, launched behind this kernel over the flagged envs only (it returns
-//     at entry when no env was flagged).
+//     envs are flagged and stepped by the DYNAMIC engine in the same launch -- the grid's last ceil(B / 256) workgroups (the
+//     "tail") wait for the flags of their 256 envs (one word per env, published within the first microsecond of the schedule
+//     workgroups, all of which have been dispatched before a tail workgroup is) and run phx_generic_env over the flagged ones.
+//     Usually none is, and the tail costs a load per env; a second launch (round 6's first form) cost 2.7 us per step.
 // Reference: env.py:239-336, network.py:233-265, resolvers.py:128-163, agents.py:96-155, supply_chain.py:36-150, fsm.py:253-380.
+// (compiled as part of phx_generic.hip's translation unit: phx_generic_env is defined there)
 #include "phx_dev.h"
 
-typedef const __attribute__((address_space(4))) char* phx_kptr_t;
 #define sp (*(const DevSpec*)spc)
 #define g (*(const GenArgs*)(kp + 8))
 #define GS_REFRESH() asm volatile("" : "+s"(spc), "+s"(kp))
@@ -50,7 +52,44 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
   constexpr int EPB = 256 / L;                                  // env instances per workgroup
   const int tid = threadIdx.x, j = tid & (L - 1), slot = tid / L;
   const int nS = sp.kind_count[PHX_KIND_SHOP], B = sp.B, S = sp.S;
-  const int b_raw = xcd_block(true) * EPB + slot;
+  const int n_sched = (B + EPB - 1) / EPB;                       // schedule workgroups; the grid's rest is the tail
+  if ((int)blockIdx.x >= n_sched) {
+    // ---- tail: the env instances the schedule workgroups flag, on the dynamic engine ---------------------------------------------
+    __shared__ int s_list[256];
+    __shared__ int s_n;
+    const int bt = ((int)blockIdx.x - n_sched) * 256 + tid;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    if (bt < B) {
+      // the env's word: 0 = its schedule workgroup has not decided yet, 2 | flagged once it has; consumed (zeroed) here, so that the next
+      // launch -- or the next replay of a captured one -- starts from zeros again (no launch numbers: hipGraphs replay their arguments)
+      int v = 0, spins = 0;
+      do {                                                      // (bounded: a word that never arrives must not hang the GPU)
+        v = __hip_atomic_load(sp.gs_dyn_flag + bt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0) break;
+        __builtin_amdgcn_s_sleep(8);
+      } while (++spins < (1 << 22));
+      if (v != 0) __hip_atomic_store(sp.gs_dyn_flag + bt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v & 1) s_list[atomicAdd(&s_n, 1)] = bt;
+    }
+    __syncthreads();
+    const int n_flagged = s_n;
+    if (n_flagged == 0) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                     // the flagged envs' state is what earlier launches left: nothing of this launch precedes it
+    for (int i = 0; i < n_flagged; ++i) {
+      int bsel = s_list[0];                                      // ascending env order (the atomics handed the slots out in arrival order)
+      for (int k = 1; k < n_flagged; ++k) bsel = (s_list[k] < bsel) ? s_list[k] : bsel;
+      __syncthreads();
+      if (tid == 0) for (int k = 0; k < n_flagged; ++k) if (s_list[k] == bsel) s_list[k] = 0x7fffffff;
+      phx_generic_env<256, true, false, PHX_KIND_CUSTOMER, ROLL, false>(spc, kp, smem, bsel);
+      __syncthreads();
+    }
+    return;
+  }
+  int wg = (int)blockIdx.x;
+  { const unsigned n = (unsigned)n_sched, x = blockIdx.x & 7u, q = n >> 3, rem = n & 7u;       // xcd_block() over the schedule workgroups
+    wg = (int)(x * q + (x < rem ? x : rem) + (blockIdx.x >> 3)); }
+  const int b_raw = wg * EPB + slot;
   const bool in_range = b_raw < B;
   const int b = in_range ? b_raw : B - 1;                       // (lanes past the batch compute on the last env and store nothing)
   const bool shop = j < nS;
@@ -112,8 +151,7 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
     const int acts0 = shop ? (tab[list_off[l0] + tab[list_off[l0] + 12] + jj] & 4) : 0;
     dyn = dyn || env_any(shop && acts0 && !act_has);
   }
-  if (in_range && j == 0) sp.gs_dyn_flag[b] = dyn ? 1 : 0;
-  if (__ballot(in_range && dyn) != 0ull && (tid & 63) == 0) *sp.gs_dyn_word = g.gs_gen;
+  if (in_range && j == 0) __hip_atomic_store(sp.gs_dyn_flag + b, dyn ? 3 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool on = in_range && !dyn;                                    // this lane's env is stepped here
 
   GsQuad quad; quad.q = 0xffffffffu; quad.w[0] = quad.w[1] = quad.w[2] = quad.w[3] = 0u;
@@ -395,6 +433,7 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
 
 #undef sp
 #undef g
+#undef GS_REFRESH
 
 // ---- host: the compiled schedule ------------------------------------------------------------------------------------------------
 // Program of one acting list (int32 words; offsets relative to the list's first word):
@@ -558,8 +597,10 @@ size_t phx_sched_lds_bytes(int words, int L, int qstride) { return (size_t)((wor
 
 hipError_t phx_launch_sched(const DevSpec& sp, const GenArgs& g, hipStream_t st) {
   const int L = sp.gs_L, EPB = 256 / L;
-  const dim3 grid((unsigned)((sp.B + EPB - 1) / EPB));
-  const size_t lds = phx_sched_lds_bytes(sp.gs_words, L, sp.gs_qstride);
+  const dim3 grid((unsigned)((sp.B + EPB - 1) / EPB + (sp.B + 255) / 256));      // schedule workgroups + tail
+  // LDS: the schedule's tables and queues, or what the dynamic engine needs for one env (the tail workgroups), whichever is larger
+  const size_t lds = std::max(phx_sched_lds_bytes(sp.gs_words, L, sp.gs_qstride),
+                              (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, 0, false) + 15) & ~(size_t)15);
   const bool roll = g.roll_t >= 0;
   phx_note_kernel(roll ? "phx_sched_step_kernel[T-step loop]" : "phx_sched_step_kernel");
 #define GS_LAUNCH(L_) do { if (roll) hipLaunchKernelGGL((phx_sched_step_kernel<L_, true>), grid, dim3(256), lds, st, sp.self_dev, g); \

@@ -27,7 +27,11 @@ def run(name, S, K, B, fsm, n=150, T=50, roll_only=False):
         def one():
             d.step(acts[k[0] % 4]); k[0] += 1
         print(f"{name:28s} phx_step                     {ev(one, n):8.2f} us/step   [{d.last_kernel()}]", flush=True)
-        del env, d
+        # the same launches from a hipGraph (no per-step host work: what the GPU itself needs per step)
+        ag = torch.stack([acts[i % 4] for i in range(50)]).contiguous()
+        sg = d.step_graph(ag)
+        print(f"{name:28s} phx_step, hipGraph of 50     {ev(sg.replay, 6) / 50:8.2f} us/step", flush=True)
+        del env, d, sg
     for var in ("auto", "launch_loop"):
         env = supply_chain_env(S, [K] * S, 100, B, fsm=fsm, force_generic=True, seed=1, exogenous="device", variants={"rollout": var})
         d = env._device(); env.reset()
