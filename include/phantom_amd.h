@@ -352,6 +352,33 @@ typedef struct phx_rollout_frag {
 #define PHX_RH_EXO_IN_DOMAIN     4  /* every byte of `exo` is a draw of np.random.randint(CUSTOMER_MAX_ORDER_SIZE = 5), i.e. < 5
                                        (supply_chain.py:64) -- what phx_mt_draw produces.  Without it replayed order sizes are served by
                                        round 1's kernel (32-bit tiles, any byte value).                                               */
+/* ABI 10: a POLICY evaluated on the device inside the fused rollout (what the reference's collection loop calls for every agent and
+ * step, utils/rllib/rollout.py:300-363): one small MLP shared by the env's strategic agents, fed with the agent's previous observation
+ * (the reset observation at an episode's first step; at the fragment's first step what encode_observation gives on the state the env
+ * is in).  f32 throughout; the arithmetic is DEFINED here (the oracle restates it bit for bit):
+ *     x[0 .. D)            the observation (D = phx_obs_dim)
+ *     h0[i] = act(c),  c = b[0][i];  for k = 0 .. D-1 ascending:        c = fmaf(w[0][i * D + k], x[k], c)
+ *     h1[i] = act(c),  c = b[1][i];  for k = 0 .. width[0]-1 ascending: c = fmaf(w[1][i * width[0] + k], h0[k], c)      (n_hidden == 2)
+ *     y = b[n_hidden][0];            for k = 0 .. width[last]-1 ascending: y = fmaf(w[n_hidden][k], h[k], y)
+ *     a = fmaf(out_scale, y, out_bias);   action = (a < out_lo ? out_lo : (a > out_hi ? out_hi : a)) + 0.0f      (an exact zero is +0)
+ *     act = PHX_ACT_RELU: c > 0 ? c : +0;   PHX_ACT_HARD_TANH: c < -1 ? -1 : (c > 1 ? 1 : c)
+ * (fmaf = the correctly rounded fused multiply-add of C99 / v_fma_f32: one rounding per term, on every machine).  The layouts are
+ * torch.nn.Linear's own (weight [out][in] row-major, bias [out]): the parameters of a module are passed as they are, device pointers,
+ * read during the launch.  Weights and observations must be finite.  Served for plain supply-chain envs (ShopAgent observations,
+ * D = 3) by phx_sc_rollout_policy_kernel, one lane per (env, shop); out_lo >= 0 (ShopAgent's action space is Box(0, SHOP_MAX_STOCK)).  */
+#define PHX_ACT_RELU      0
+#define PHX_ACT_HARD_TANH 1
+#define PHX_POLICY_MAX_WIDTH 64
+typedef struct phx_policy_mlp {
+  int32_t n_hidden;            /* hidden layers: 1 or 2                                     */
+  int32_t width[2];            /* their units, 1 .. PHX_POLICY_MAX_WIDTH                    */
+  int32_t activation;          /* PHX_ACT_*                                                 */
+  float   out_scale, out_bias; /* a = fmaf(out_scale, y, out_bias)                          */
+  float   out_lo, out_hi;      /* action = clip(a, out_lo, out_hi)                          */
+  const float* w[3];           /* device: [width0][D], [width1][width0] (or the output row when n_hidden == 1), [1][width_last] */
+  const float* b[3];           /* device: [width0], [width1] (or [1]), [1]                  */
+} phx_policy_mlp;
+
 typedef struct phx_rollout_io {
   int32_t T;
   int32_t hints;               /* PHX_RH_* below, 0 = none                                  */
@@ -385,6 +412,9 @@ typedef struct phx_rollout_io {
   int32_t   n_frag;
   int32_t   reserved0;
   const phx_rollout_frag* frags;
+  /* ABI 10: the policy of the rollout evaluated on the device (a HOST struct, read during the call), or NULL -> `actions` / the random
+   * policy.  Excludes `actions`, fragment lists and message logs (PHX_EINVAL); PHX_EUNSUPPORTED for envs the policy kernel does not serve. */
+  const phx_policy_mlp* policy;
 } phx_rollout_io;
 
 /* ---- entry points ---------------------------------------------------------------------- */

@@ -1256,6 +1256,26 @@ static float policy_action(const phxo_env* E, const oenv* e, int b, int s) {
   return (float)j * (100.0f / 274877.0f);
 }
 
+/* phx_policy_mlp (include/phantom_amd.h): the device-evaluated policy of a rollout, restated term by term -- fmaf is C99's correctly
+ * rounded fused multiply-add, so the value does not depend on the machine; the host copies of the weights are made by the test harness
+ * (the struct's pointers are HOST pointers here).                                                                                      */
+static float policy_mlp_action(const phx_policy_mlp* p, const float* x, int D) {
+  float h[2][PHX_POLICY_MAX_WIDTH];
+  const float* in = x; int n_in = D;
+  for (int l = 0; l < p->n_hidden; ++l) {
+    for (int i = 0; i < p->width[l]; ++i) {
+      float c = p->b[l][i];
+      for (int k = 0; k < n_in; ++k) c = fmaf(p->w[l][(size_t)i * n_in + k], in[k], c);
+      h[l][i] = p->activation == PHX_ACT_HARD_TANH ? (c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c)) : (c > 0.0f ? c : 0.0f);
+    }
+    in = h[l]; n_in = p->width[l];
+  }
+  float y = p->b[p->n_hidden][0];
+  for (int k = 0; k < n_in; ++k) y = fmaf(p->w[p->n_hidden][k], in[k], y);
+  const float a = fmaf(p->out_scale, y, p->out_bias);
+  return (a < p->out_lo ? p->out_lo : (a > p->out_hi ? p->out_hi : a)) + 0.0f;
+}
+
 /* rollout = the list-of-envs loop of utils/rllib/rollout.py:361-363, with the caller's
  * reset-after-num_steps folded in (auto-reset at the end of the terminal step).          */
 static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
@@ -1266,6 +1286,8 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
   double* rw = (double*)alloca(sizeof(double) * (S ? S : 1));
   uint8_t* u8 = (uint8_t*)alloca(5 * (S ? S : 1));
   e->log = NULL; e->err = io->err ? io->err[b] : 0; e->shuffle_b = NULL;
+  if (io->policy)                                                     /* what the agents observe now: the policy's input at the fragment's first step */
+    for (int s = 0; s < S; ++s) { for (int d = 0; d < D; ++d) o[s * D + d] = 0.0f; agent_encode_obs(E, e, E->strat_idx[s], o + s * D); }
   for (int t = 0; t < T; ++t) {
     if (io->msg_log) {   /* rollout.py:369-373: tracked_messages recorded per step, cleared before the next */
       e->log = io->msg_log + ((size_t)t * B + b) * E->s.trace_cap; e->log_cap = E->s.trace_cap;
@@ -1281,7 +1303,8 @@ static void rollout_one(phxo_env* E, const phx_rollout_io* io, int b) {
         act[s] = !acts ? 0.0f : io->actions ? io->actions[((size_t)t * B + b) * S + s]
                                             : policy_action(E, e, b, s);
       } else {
-        act[s] = io->actions ? io->actions[((size_t)t * B + b) * S + s] : policy_action(E, e, b, s);
+        act[s] = io->policy ? policy_mlp_action(io->policy, o + s * D, D)      /* compute_action on the previous observation, rollout.py:300-363 */
+               : io->actions ? io->actions[((size_t)t * B + b) * S + s] : policy_action(E, e, b, s);
       }
     }
     uint8_t at = 0, au = 0;

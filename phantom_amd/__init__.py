@@ -28,5 +28,6 @@ from . import samplers
 from .samplers import (LambdaSampler, NormalArraySampler, NormalSampler, Sampler,
                        UniformArraySampler, UniformFloatSampler, UniformIntSampler)
 from .views import AgentView, Context, EnvView, FSMEnvView, View
-from . import ads_market, metrics, rllib
+from . import ads_market, metrics, policy, rllib
+from .policy import MLPPolicy
 from .distributed import all_gather_trajectory, make_sharded_env, shard_batch

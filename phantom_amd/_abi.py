@@ -94,7 +94,18 @@ class PhxRolloutIO(C.Structure):
     _fields_ = [("T", C.c_int32), ("hints", C.c_int32)] + [(n, C.c_void_p) for n in (
         "actions", "exo", "obs", "action_out", "reward", "terminated", "truncated", "obs_valid",
         "reward_valid", "last_obs", "err", "msg_log", "msg_count", "reserved_ptr")] + [
-        ("n_frag", C.c_int32), ("reserved0", C.c_int32), ("frags", C.c_void_p)]
+        ("n_frag", C.c_int32), ("reserved0", C.c_int32), ("frags", C.c_void_p), ("policy", C.c_void_p)]
+
+
+class PhxPolicyMLP(C.Structure):
+    """phx_policy_mlp (ABI 10): the device-evaluated policy of a rollout"""
+    _fields_ = [("n_hidden", C.c_int32), ("width", C.c_int32 * 2), ("activation", C.c_int32),
+                ("out_scale", C.c_float), ("out_bias", C.c_float), ("out_lo", C.c_float), ("out_hi", C.c_float),
+                ("w", C.c_void_p * 3), ("b", C.c_void_p * 3)]
+
+
+ACT_RELU, ACT_HARD_TANH = 0, 1
+POLICY_MAX_WIDTH = 64
 
 
 class PhxStageRule(C.Structure):

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIB_DIR, "libphantom_amd.so")
-SOURCES = ["phx_api.hip", "phx_generic.hip", "phx_sc_fused.hip", "phx_sc_rollout.hip", "phx_sc_rollout_sw.hip", "phx_sc_rollout_fsm.hip", "phx_stk_fused.hip",
+SOURCES = ["phx_api.hip", "phx_generic.hip", "phx_sc_fused.hip", "phx_sc_rollout.hip", "phx_sc_rollout_sw.hip", "phx_sc_rollout_fsm.hip", "phx_sc_policy.hip", "phx_stk_fused.hip",
            "phx_ads_fused.hip"]
 HEADERS = ["phx_dev.h", "phx_epilogue.h", "phx_sc_fast.h", "phx_generic_sched.hip", os.path.join("..", "..", "include", "phantom_amd.h")]
 # -ffp-contract=off: rewards are f64 "sales - 0.1*stock" with product and difference rounded

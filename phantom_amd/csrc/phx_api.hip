@@ -19,6 +19,8 @@ size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx, boo
 size_t phx_generic_lean_ws_bytes(int Q, int scan_cap);
 size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
+const char* phx_sc_policy_unsupported(const DevSpec& sp, const phx_rollout_io& io);
+hipError_t phx_launch_sc_rollout_policy(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 bool phx_sched_compile(const phx_spec* spec, int A, int n_lists, const int32_t* act_ptr, const int32_t* act_idx, const uint8_t* act_mask,
                        const uint8_t* obs_mask, const uint8_t* rew_mask, const int32_t* kind_rank, const int32_t* exo_rank, const int32_t* strat_rank,
                        const int32_t* reset_obs_idx, int n_reset_obs, std::vector<int32_t>* blob, std::vector<int32_t>* recs, int* L_out, int* qmax_out);
@@ -1221,6 +1223,8 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
   if ((io->hints & ~(PHX_RH_ACTIONS_IN_DOMAIN | PHX_RH_EXO_IN_DOMAIN)) != 0 || io->reserved_ptr)
     return fail(PHX_EINVAL, "phx_rollout: unknown hint bits / reserved_ptr must be NULL (ABI 9 removed PHX_RH_FLAGS_ZEROED and the record layout)");
+  if (io->policy && (io->actions || io->n_frag >= 2 || io->frags || io->msg_log || io->msg_count))
+    return fail(PHX_EINVAL, "phx_rollout: `policy` excludes replayed actions, fragment lists and message logs");
   if (io->n_frag >= 2 || io->frags) {   // ABI 9: a fragment list
     if (io->n_frag < 2 || io->n_frag > PHX_MAX_FRAGMENTS || !io->frags) return fail(PHX_EINVAL, "phx_rollout: a fragment list needs 2 .. %d fragments and `frags`", PHX_MAX_FRAGMENTS);
     if (io->T <= 0 || io->T % io->n_frag) return fail(PHX_EINVAL, "phx_rollout: T must be a positive multiple of n_frag");
@@ -1297,6 +1301,13 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (e->d.n_samplers > 0 && !e->d.device_sampling)
     return fail(PHX_EUNSUPPORTED, "phx_rollout auto-resets on the device: every sampler must be PHX_SAMPLER_UNIFORM");
   HIPCHK(use_device(e));
+  if (io->policy) {                   // ABI 10: the policy evaluated on the device, one lane per (env, shop) (phx_sc_policy.hip)
+    if (!e->use_fused) return fail(PHX_EUNSUPPORTED, "phx_rollout: `policy` needs a plain supply-chain env on its fused schedule");
+    const char* why = phx_sc_policy_unsupported(e->d, *io);
+    if (why) return fail(strstr(why, "phx_policy_mlp") ? PHX_EINVAL : PHX_EUNSUPPORTED, "phx_rollout: %s", why);
+    HIPCHK(phx_launch_sc_rollout_policy(e->d, *io, (hipStream_t)stream));
+    return PHX_OK;
+  }
   if (e->use_ads && e->n_inject == 0) {
     if (!io->obs_valid || !io->reward_valid) return fail(PHX_EINVAL, "FSM rollouts need obs_valid and reward_valid outputs");
     HIPCHK(phx_launch_ads_rollout(e->d, *io, (hipStream_t)stream));

@@ -503,11 +503,15 @@ class DeviceEnv:
             need("out.msg_log", out.msg_log, torch.uint8, (B, self.spec.trace_cap, 16))
 
     def rollout(self, T: int, actions=None, exo=None, out: Optional[Trajectory] = None, actions_in_domain: bool = False,
-                exo_in_domain: bool = False) -> Trajectory:
+                exo_in_domain: bool = False, policy=None) -> Trajectory:
         """T fused steps into ``out`` (allocated here when None); ``actions`` f32 [T, B, S] / ``exo`` u8 [T, B, n_exo] replay a recorded
         policy / recorded draws (None: the device's random policy / RNG stream).  ``actions_in_domain`` / ``exo_in_domain``: the caller
         vouches that every action rounds to >= 0 (clipped to the action space) / every exo byte is < 5 (``mt_draw`` output): a plain supply
-        chain's replay then takes the store-wave kernel without a scan of the inputs (phx_rollout_io.hints)."""
+        chain's replay then takes the store-wave kernel without a scan of the inputs (phx_rollout_io.hints).
+        ``policy``: a ``phantom_amd.policy.MLPPolicy`` evaluated on the device for every (env, strategic agent) and step from the agent's
+        previous observation (phx_rollout_io.policy, ABI 10): T ON-POLICY steps in one launch (plain supply-chain envs)."""
+        if policy is not None and actions is not None:
+            raise ValueError("rollout: `policy` and replayed `actions` exclude each other")
         owned = out is None
         if owned:
             out = self.alloc_trajectory(T)
@@ -517,7 +521,7 @@ class DeviceEnv:
         # ~80 MB at B=4096).
         ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else None
         sig = lambda x: (x.data_ptr(), x.numel()) if hasattr(x, "data_ptr") else None     # address AND size: a buffer freed
-        key = (T, bool(actions_in_domain), bool(exo_in_domain)) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo))    # and reallocated smaller misses
+        key = (T, bool(actions_in_domain), bool(exo_in_domain)) + tuple(sig(x) for x in out[:10]) + (sig(actions), sig(exo), id(policy))    # and reallocated smaller misses
         cached = None if owned else self._rollout_io_cache.get(key)
         if cached is None:
             self._check_rollout_buffers(T, actions, exo, out)
@@ -531,7 +535,13 @@ class DeviceEnv:
             io.obs_valid, io.reward_valid = ptr(out.obs_valid), ptr(out.reward_valid)
             io.msg_log, io.msg_count = ptr(out.msg_log), ptr(out.msg_count)
             io.err = self.err.data_ptr()
-            cached = (io, C.byref(io))
+            pol_keep = None
+            if policy is not None:
+                if policy.obs_dim != self.D:
+                    raise ValueError(f"rollout: the policy takes {policy.obs_dim} inputs, the env's observations have {self.D}")
+                pol_keep = policy.on(self.device)              # (device weights + the argument struct: kept alive with the cached block)
+                io.policy = C.addressof(pol_keep[2])
+            cached = (io, C.byref(io), pol_keep, policy)
             if not owned:
                 if len(self._rollout_io_cache) >= 4:           # tiny LRU: drop the oldest entry
                     self._rollout_io_cache.pop(next(iter(self._rollout_io_cache)))

@@ -68,7 +68,7 @@ class DeviceRunner:
         self.err = d.err.cpu().numpy()
         self.msg_count = d.msg_count.cpu().numpy() if d.msg_count is not None else None
 
-    def rollout(self, T, actions=None, exo=None, **hints):
+    def rollout(self, T, actions=None, exo=None, **hints):        # (hints: actions_in_domain / exo_in_domain / policy)
         a = None if actions is None else self._t(actions, np.float32)
         x = None if exo is None else self._t(exo, np.uint8)
         tr = self.dev.rollout(T, a, x, **hints)

@@ -169,7 +169,7 @@ class OracleEnv:
         self.err[:] = 0
         self.L.phxo_resolve(self.h, _p(self.err), _p(self.msg_log), _p(self.msg_count))
 
-    def rollout(self, T, actions=None, exo=None, record_messages=False):
+    def rollout(self, T, actions=None, exo=None, record_messages=False, policy=None):
         B, S, D = self.B, self.S, self.D
         out = dict(obs=np.zeros((T, B, S, D), np.float32), actions=np.zeros((T, B, S), np.float32),
                    rewards=np.zeros((T, B, S), np.float32), terminated=np.zeros((T, B, S), np.uint8),
@@ -184,6 +184,9 @@ class OracleEnv:
         io.terminated, io.truncated = _p(out["terminated"]), _p(out["truncated"])
         io.obs_valid, io.reward_valid = _p(out["obs_valid"]), _p(out["reward_valid"])
         io.last_obs, io.err = _p(out["last_obs"]), _p(self.err)
+        if policy is not None:                                  # phantom_amd.policy.MLPPolicy: the restatement reads the host copies of the weights
+            self._pol = policy.host_struct()
+            io.policy = C.addressof(self._pol)
         if record_messages:
             out["msg_log"] = np.zeros((T, B, self.spec.trace_cap), LOG_DTYPE)
             out["msg_count"] = np.zeros((T, B), np.int32)
