@@ -423,6 +423,10 @@ const char* phx_last_error(void);
 /* names of the kernels the calling thread's last phx_step / phx_rollout / phx_resolve launched, joined by '+'
  * (kernel-variant tests: phx_spec.variant_*) */
 const char* phx_last_kernel(void);
+/* ABI 10: what PHX_VR_AUTO measured when it last had two kernels for a rollout shape of this handle -- e.g. "T=400 n_frag=0: store-wave
+ * 861.2 us, lane-per-pair chain 772.4 us -> lane-per-pair chain" -- or "" (FSM supply chains: the first phx_rollout of a (T, n_frag) shape
+ * times both from a copy of the state blob, restores it, and the handle keeps the winner; nothing is timed while a stream is capturing). */
+const char* phx_autotune_note(const phx_env* env);
 
 /* sizes derived from the spec, so the caller (torch) can own every buffer */
 int64_t phx_state_nbytes(const phx_spec* spec);

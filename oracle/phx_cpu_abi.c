@@ -26,6 +26,7 @@ struct phx_env { phxo_env* o; int B, A, nnz, n_conn, n_samplers, trace_cap, n_ex
 int phx_abi_version(void) { return PHX_ABI_VERSION; }
 const char* phx_last_error(void) { return phxo_last_error(); }
 const char* phx_last_kernel(void) { return "cpu restatement (oracle/phx_oracle.c)"; }
+const char* phx_autotune_note(const phx_env* e) { (void)e; return ""; }
 
 int64_t phx_state_nbytes(const phx_spec* spec) { return (spec && spec->abi_version == PHX_ABI_VERSION) ? 256 : -1; }
 

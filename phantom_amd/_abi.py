@@ -133,7 +133,7 @@ LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
 # PHX_LIB_PATH: development override (A/B runs of experimental builds); the default is the in-tree library
 LIB_PATH = os.environ.get("PHX_LIB_PATH") or os.path.join(LIB_DIR, "libphantom_amd.so")
 
-EXPORTS = ("phx_abi_version", "phx_last_error", "phx_last_kernel", "phx_state_nbytes", "phx_obs_dim",
+EXPORTS = ("phx_abi_version", "phx_last_error", "phx_last_kernel", "phx_autotune_note", "phx_state_nbytes", "phx_obs_dim",
            "phx_n_strategic", "phx_n_exo", "phx_create", "phx_destroy", "phx_n_fields",
            "phx_field_info", "phx_uses_fused", "phx_sync_fields", "phx_reset", "phx_step", "phx_step_begin", "phx_step_end", "phx_inject",
            "phx_resolve", "phx_rollout", "phx_get_state", "phx_set_state", "phx_trace",
@@ -168,6 +168,8 @@ def bind_signatures(lib):
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.phx_abi_version.restype = i32
     lib.phx_last_kernel.restype = C.c_char_p
+    lib.phx_autotune_note.restype = C.c_char_p
+    lib.phx_autotune_note.argtypes = [C.c_void_p]
     lib.phx_last_error.restype = C.c_char_p
     lib.phx_state_nbytes.restype = i64
     lib.phx_state_nbytes.argtypes = [C.POINTER(PhxSpec)]

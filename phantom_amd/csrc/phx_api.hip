@@ -624,6 +624,12 @@ struct phx_env {
   DevMsg* inject_dev = nullptr;
   DevMsg inject_host[PHX_MAX_INJECT];
   int n_inject = 0;
+  // PHX_VR_AUTO by measurement (FSM supply chains): the kernel chosen for a (T, n_frag) shape on THIS box, 0 = the store-wave
+  // instantiation, 1 = the lane-per-pair chain; the state blob's copy the probe launches start from and restore
+  void* state_blob = nullptr; int64_t state_nbytes = 0;
+  void* probe_snapshot = nullptr;
+  std::unordered_map<uint64_t, int> fsm_auto;
+  std::string fsm_auto_note;        // "T=400: store-wave 861.2 us, loop 772.4 us -> loop" (phx_last_error's sibling: phx_autotune_note)
 };
 
 template <typename T>
@@ -675,6 +681,7 @@ extern "C++" const DevKnobs& phx_knobs() {
     k.generic_remap = rd("PHX_GENERIC_REMAP", 1);
     k.generic_tablds = rd("PHX_GENERIC_TABLDS", 1);
     k.generic_sched = rd("PHX_GENERIC_SCHED", 1);
+    k.autotune = rd("PHX_AUTOTUNE", 1);
     k.rollout_epb = rd("PHX_ROLLOUT_EPB", 0);
     k.rollout_fast = rd("PHX_ROLLOUT_FAST", -1);     // -1: unset; 0 switches the kernel off
     k.rollout_first = rd("PHX_ROLLOUT_FIRST", 0);
@@ -1014,6 +1021,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
       d.sc_sw_guard = (int32_t*)gw;
     }
   }
+  e->state_blob = state_blob; e->state_nbytes = need;
   for (auto& f : e->fields) d.f[f.id] = (char*)state_blob + f.offset;
   d.ws_stride = ws_stride;
   d.lean_lds = lean_lds_spec(spec, der) ? 1 : 0;
@@ -1053,6 +1061,7 @@ void phx_destroy(phx_env* e) {
   if (!e) return;
   for (void* p : e->dev_allocs) (void)hipFree(p);
   if (e->inject_dev) (void)hipFree(e->inject_dev);
+  if (e->probe_snapshot) (void)hipFree(e->probe_snapshot);
   delete e;
 }
 
@@ -1068,6 +1077,7 @@ int phx_field_info(const phx_env* e, int index, phx_field* out) {
   return PHX_OK;
 }
 
+const char* phx_autotune_note(const phx_env* e) { return e ? e->fsm_auto_note.c_str() : ""; }
 int phx_uses_fused(const phx_env* e) { return e && (e->use_fused || e->use_stk || e->use_ads) ? 1 : 0; }
 
 
@@ -1216,8 +1226,75 @@ int phx_resolve(phx_env* e, int32_t* err, phx_msg_rec* msg_log, int32_t* msg_cou
   return PHX_OK;
 }
 
+static int rollout_impl(phx_env* e, const phx_rollout_io* io, void* stream);
+
+// PHX_VR_AUTO for an FSM supply chain, where the size rule would take the store-wave instantiation (on four boxes of seven
+// the lane-per-pair loop was the faster kernel for config 3 and AUTO took the other one): the FIRST call of a (T, n_frag) shape on a handle
+// times both -- one warm-up and two timed launches each, from a copy of the state blob that is restored before the call's own launch --
+// and the handle keeps the winner for that shape.  Both kernels produce the same bits (tests/test_gpu_fsm_sw.py), the outputs of the
+// probe launches are overwritten by the call's own.  Not while a stream is capturing (phx_fsm_sw_serves declines there already).
+static bool fsm_auto_applies(phx_env* e, const phx_rollout_io* io, void* stream) {
+  if (!phx_knobs().autotune || !e->use_fused || e->d.env_type != PHX_ENV_FSM || e->d.variant_rollout != PHX_VR_AUTO || io->policy) return false;
+  if (io->n_frag >= 2 && (!io->frags || !io->frags[0].terminated)) return false;
+  if (io->n_frag < 2 && (io->frags || !io->obs || !io->terminated)) return false;
+  return phx_fsm_sw_serves(e->d, *io, (hipStream_t)stream);
+}
+struct FsmAutoScope {             // the handle's spec with one candidate forced, for the duration of a call
+  phx_env* e; int32_t vr, ok;
+  FsmAutoScope(phx_env* e_, int choice) : e(e_), vr(e_->d.variant_rollout), ok(e_->d.fsm_sw.ok) { if (choice == 0) e->d.variant_rollout = PHX_VR_STORE_WAVES; else e->d.fsm_sw.ok = 0; }
+  ~FsmAutoScope() { e->d.variant_rollout = vr; e->d.fsm_sw.ok = ok; }
+};
+static int fsm_auto_probe(phx_env* e, const phx_rollout_io* io, void* stream, int* choice) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!e->probe_snapshot) HIPCHK(hipMalloc(&e->probe_snapshot, (size_t)e->state_nbytes));
+  HIPCHK(hipMemcpyAsync(e->probe_snapshot, e->state_blob, (size_t)e->state_nbytes, hipMemcpyDeviceToDevice, st));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  float us[2] = {0.f, 0.f};
+  int rc = PHX_OK;
+  for (int c = 0; c < 2 && rc == PHX_OK; ++c) {
+    FsmAutoScope scope(e, c);
+    rc = rollout_impl(e, io, stream);                                         // warm-up (first-touch of the planes, the code object)
+    if (rc == PHX_OK) { (void)hipEventRecord(e0, st); rc = rollout_impl(e, io, stream); }
+    if (rc == PHX_OK) rc = rollout_impl(e, io, stream);
+    if (rc == PHX_OK) {
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess) rc = fail(PHX_EHIP, "autotune: hipEventSynchronize");
+      else { float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); us[c] = ms * 500.0f; }
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  HIPCHK(hipMemcpyAsync(e->state_blob, e->probe_snapshot, (size_t)e->state_nbytes, hipMemcpyDeviceToDevice, st));
+  if (rc != PHX_OK) return rc;
+  *choice = us[1] < us[0] ? 1 : 0;
+  char buf[192];
+  snprintf(buf, sizeof buf, "T=%d n_frag=%d: store-wave %.1f us, lane-per-pair chain %.1f us -> %s", io->T, io->n_frag, us[0], us[1], *choice ? "lane-per-pair chain" : "store-wave");
+  e->fsm_auto_note = buf;
+  return PHX_OK;
+}
+
 int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
   note_reset();
+  if (!e || !io) return fail(PHX_EINVAL, "null argument");
+  if (io->T > 0 && fsm_auto_applies(e, io, stream)) {
+    HIPCHK(use_device(e));
+    const uint64_t key = ((uint64_t)(uint32_t)io->T << 8) | (uint64_t)(uint32_t)(io->n_frag & 0xff);
+    auto it = e->fsm_auto.find(key);
+    int choice = 0;
+    if (it != e->fsm_auto.end()) choice = it->second;
+    else {
+      const int rc = fsm_auto_probe(e, io, stream, &choice);
+      if (rc != PHX_OK) return rc;
+      e->fsm_auto[key] = choice;
+      note_reset();
+    }
+    FsmAutoScope scope(e, choice);
+    return rollout_impl(e, io, stream);
+  }
+  return rollout_impl(e, io, stream);
+}
+
+static int rollout_impl(phx_env* e, const phx_rollout_io* io, void* stream) {
   if (!e || !io) return fail(PHX_EINVAL, "null argument");
   if (e->d.env_type != PHX_ENV_PLAIN && !(io->n_frag >= 2 || io->frags) && (!io->obs_valid || !io->reward_valid))
     return fail(PHX_EINVAL, "FSM / Stackelberg rollouts need obs_valid and reward_valid outputs");
@@ -1277,7 +1354,7 @@ int phx_rollout(phx_env* e, const phx_rollout_io* io, void* stream) {
       if (io->exo) sub.exo = io->exo + row * e->d.n_exo;
       if (io->msg_log) sub.msg_log = io->msg_log + row * e->d.trace_cap;
       if (io->msg_count) sub.msg_count = io->msg_count + row;
-      const int rc = phx_rollout(e, &sub, stream);
+      const int rc = rollout_impl(e, &sub, stream);
       if (rc != PHX_OK) return rc;
     }
     return PHX_OK;

@@ -62,6 +62,7 @@ struct DevKnobs {
   int generic_nt;              // PHX_GENERIC_NT (default 0)
   int generic_remap;           // PHX_GENERIC_REMAP (default 1)
   int generic_tablds;          // PHX_GENERIC_TABLDS (default 1)
+  int autotune;                // PHX_AUTOTUNE (default 1): PHX_VR_AUTO times its two FSM candidates on a handle's first call of a shape (0: the size rule alone)
   int generic_sched;           // PHX_GENERIC_SCHED (default 1): specs with a compiled schedule run on phx_sched_step_kernel (0: the dynamic kernel everywhere)
   int rollout_epb;             // PHX_ROLLOUT_EPB (default 0)
   int rollout_fast;            // PHX_ROLLOUT_FAST (default -1 = unset; 0: off)

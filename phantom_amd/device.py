@@ -194,6 +194,10 @@ class DeviceEnv:
         """names of the kernels this thread's last step / rollout / resolve call launched, joined by '+'"""
         return (self.lib.phx_last_kernel() or b"").decode()
 
+    def autotune_note(self) -> str:
+        """what PHX_VR_AUTO measured when it last had two kernels for a rollout shape of this env (phx_autotune_note), or ''"""
+        return (self.lib.phx_autotune_note(self.handle) or b"").decode()
+
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 

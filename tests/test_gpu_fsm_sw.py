@@ -206,7 +206,12 @@ def test_config3_shape_full_size_property_and_sample_against_the_oracle():
     d = DeviceRunner(env.spec)
     d.reset()
     rd = d.rollout(T)
-    assert d.dev.last_kernel() == SW + "+" + LOOP, d.dev.last_kernel()
+    # PHX_VR_AUTO by measurement (round 6): at this size the store-wave instantiation and the lane-per-pair loop are both timed on the
+    # handle's first call of the shape (from a copy of the state that is restored) and the faster one on THIS box serves the call
+    first = d.dev.last_kernel()
+    assert first in (SW + "+" + LOOP, "phx_sc_rollout_fsm_lean_kernel"), first
+    note = d.dev.autotune_note()
+    assert note.startswith(f"T={T} n_frag=0: store-wave ") and ("-> store-wave" in note) == first.startswith(SW), note
     Bo = 512
     envo = supply_chain_env(S, [K] * S, ns, Bo, fsm=True, seed=42)
     o = OracleEnv(envo.spec, threads=NCPU); o.reset()
@@ -219,3 +224,16 @@ def test_config3_shape_full_size_property_and_sample_against_the_oracle():
     assert (ov[1::2] == 1).all() and (ov[0::2] == 0).all()      # SELL steps (odd positions) are followed by RESTOCK: the shops observe
     assert rd["truncated"].sum() == 2 * B * S and (rd["truncated"][ns - 1] == 1).all() and (rd["truncated"][2 * ns - 1] == 1).all()
     assert (d.err == 0).all()
+    # the second call of the shape: no probe (the note stays), the same kernel, and the oracle's rows from the state the first one left
+    rd2, ro2 = d.rollout(T), o.rollout(T)
+    assert d.dev.last_kernel() == first and d.dev.autotune_note() == note
+    for k in ("obs", "actions", "rewards"):
+        np.testing.assert_array_equal(f32_bits(rd2[k][:, :Bo]), f32_bits(ro2[k]), err_msg=k)
+    # ... and the OTHER kernel, forced, gives the same bits on the same shape (what the choice rests on)
+    other = "lean" if first.startswith(SW) else "store_waves"
+    env2 = supply_chain_env(S, [K] * S, ns, B, fsm=True, seed=42, variants={"rollout": other})
+    d2 = DeviceRunner(env2.spec); d2.reset()
+    r2 = d2.rollout(T)
+    assert d2.dev.last_kernel() != first
+    for k in ("obs", "actions", "rewards", "truncated", "obs_valid", "reward_valid"):
+        np.testing.assert_array_equal(r2[k], rd[k], err_msg=k)

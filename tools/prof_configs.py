@@ -27,6 +27,8 @@ def ev(fn, n):
 def line(name, T, B, bytes_per_env_step, us, dev):
     alg = bytes_per_env_step * B * T
     print(f"{name:44s} T={T:4d} {us:9.1f} us/launch  {alg / 1e6:8.1f} MB algorithmic  {alg / us / 1e3 / 8000:.3f} of 8 TB/s   [{dev.last_kernel()}]", flush=True)
+    if dev.autotune_note():
+        print(f"{'':44s} PHX_VR_AUTO measured: {dev.autotune_note()}", flush=True)
 
 
 if "c3" in which:
