@@ -139,3 +139,25 @@ def test_a_replay_hint_that_does_not_hold_is_reported_per_env(S, K, B, T):
         for key in ("obs", "actions", "rewards"):
             np.testing.assert_array_equal(f32_bits(rd[key][:, good]), f32_bits(ro[key][:, good]), err_msg=f"{what}: {key}")
         np.testing.assert_array_equal(d.get_i32("shop.stock")[good], o.get_i32("shop.stock")[good])
+
+
+def test_scale_node_script_dry_run_on_one_gpu(tmp_path):
+    """tools/scale_node.sh --dry-run: the first-contact script for an 8-GPU node with every rank on the GPU that exists
+    (PHX_BENCH_SHARE_GPU): each stage leaves one JSON line (a bench line or an error line), the 1 / 2 / 8-rank curve stages report a `value`
+    over the gloo control plane, the NCCL_ALGO stage records its environment, and the summary tabulates them."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    out = str(tmp_path / "scale")
+    p = subprocess.run(["bash", os.path.join(root, "tools", "scale_node.sh"), "--dry-run", out], capture_output=True, text=True, timeout=2400,
+                       env={**os.environ, "STAGE_TIMEOUT": "420"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = {}
+    for name in ("curve_n1", "curve_n2", "curve_n8", "gather_ring_n8"):
+        lines[name] = json.load(open(os.path.join(out, name + ".json")))
+    for name, n in (("curve_n1", 1), ("curve_n2", 2), ("curve_n8", 8)):
+        d = lines[name]
+        assert d.get("n_gpus") == n and d.get("value") and d["value"] > 0, (name, d.get("error"), p.stdout[-1500:])
+    assert lines["gather_ring_n8"].get("n_gpus") == 8
+    summ = open(os.path.join(out, "summary.txt")).read()
+    assert "== scaling" in summ and "N=8" in summ and "NCCL_ALGO=Ring" in summ
