@@ -62,11 +62,35 @@ class HostStep:
 
     def __init__(self, dev, buf, event, seq):
         self._dev, self._buf, self._event, self._seq, self._arrays = dev, buf, event, seq, None
+        self._consumed = False          # read_into() has copied the arrays out: nothing is left to keep alive
+
+    def read_into(self, dst: Dict[str, "object"]) -> None:
+        """the arrays copied straight into ``dst`` (same names, shapes and dtypes): one copy instead of get()'s copy + the caller's"""
+        if self._arrays is not None:
+            for k, v in self._arrays.items():
+                np.copyto(dst[k], v)
+            return
+        if self._buf is None:                                     # lazy: from the step outputs themselves
+            if self._dev._out_seq != self._seq:
+                raise DeviceError("a poll() result was first read after a later step / reset had overwritten the step outputs: read it "
+                                  "before the next send_actions(), or build the adapter with keep_results=True")
+            for k, v in self._dev.pull_step().items():
+                np.copyto(dst[k], v)
+            return
+        if self._dev._host_ring_k - self._seq > 3:
+            raise DeviceError("a poll() result was first read more than three steps after it was produced: its host buffer has been reused")
+        self._event.synchronize()
+        h = self._buf.numpy()
+        for name, shape, dtype, off, n in self._dev._out_layout:
+            np.copyto(dst[name], h[off:off + n].view(np.dtype(str(dtype).replace("torch.", ""))).reshape(shape))
+        if self._dev._host_ring_k - self._seq > 3:
+            raise DeviceError("a poll() result was read while its host buffer was being reused")
+        self._consumed = True
 
     def materialise(self) -> None:
         """bring the arrays to the host now if nobody has read them yet (DeviceEnv calls this for a result that is still referenced
         right before its pinned buffer is reused: a poll() result then outlives any number of later steps)"""
-        if self._arrays is None:
+        if self._arrays is None and not self._consumed:
             self.get()
 
     def get(self) -> Dict[str, "object"]:

@@ -210,24 +210,39 @@ class SubEnvView:
         return getattr(self._env, name)
 
 
-class _Rows(Mapping):
+class _Rows(dict):
     """MultiEnvDict {env_id: row} over batched arrays: ONE object per poll() result.  A consumer that reads rows (an RLlib
     sampler reads every one) gets REAL dicts, all B of them built in one vectorised pass on the first access (``make_all``:
-    C-level ``tolist`` / ``zip`` / ``dict`` -- ~1 us per env instead of a python object and an ``index`` call per entry);
-    envs whose dicts omit keys (FSM / Stackelberg validity masks) fall back to per-row views (``make_row``)."""
+    C-level ``tolist`` / ``zip`` / ``dict``); from then on this IS a plain dict (a dict subclass whose ``__missing__`` fills
+    it: every later ``rows[b]`` is a C-level lookup -- round 5's Mapping paid a Python ``__getitem__`` per row).  Envs whose
+    dicts omit keys (FSM / Stackelberg validity masks) fall back to per-row views (``make_row``)."""
+    __slots__ = ("_n", "_make", "_make_all")
 
     def __init__(self, n: int, make_row, make_all=None):
-        self._n, self._make, self._make_all, self._all = n, make_row, make_all, None
+        dict.__init__(self)
+        self._n, self._make, self._make_all = n, make_row, make_all
 
-    def __getitem__(self, b):
-        b = int(b)
-        if not 0 <= b < self._n:
-            raise KeyError(b)
+    def _fill(self):
         if self._make_all is not None:
-            if self._all is None:
-                self._all = self._make_all()
-            return self._all[b]
-        return self._make(b)
+            rows, self._make_all = self._make_all(), None
+            dict.update(self, zip(range(self._n), rows))
+        elif self._make is not None and dict.__len__(self) < self._n:
+            for b in range(self._n):
+                if not dict.__contains__(self, b):
+                    dict.__setitem__(self, b, self._make(b))
+
+    def __missing__(self, b):
+        if (self._make_all is None and self._make is None) or not isinstance(b, (int, np.integer)) or not 0 <= b < self._n:
+            raise KeyError(b)
+        if self._make_all is None:                              # per-row views: made on demand, kept
+            row = self._make(int(b))
+            dict.__setitem__(self, int(b), row)
+            return row
+        self._fill()
+        return dict.__getitem__(self, int(b))
+
+    def __contains__(self, b):
+        return isinstance(b, (int, np.integer)) and 0 <= b < self._n
 
     def __iter__(self):
         return iter(range(self._n))
@@ -235,31 +250,60 @@ class _Rows(Mapping):
     def __len__(self):
         return self._n
 
+    def keys(self):
+        return range(self._n)
+
     def values(self):                                        # (one pass over the materialised rows, no per-key lookups)
-        if self._make_all is not None:
-            if self._all is None:
-                self._all = self._make_all()
-            return self._all
-        return [self._make(b) for b in range(self._n)]
+        self._fill()
+        return [dict.__getitem__(self, b) for b in range(self._n)]
 
     def items(self):
         return zip(range(self._n), self.values())
 
+    def get(self, b, default=None):
+        try:
+            return self[b]
+        except KeyError:
+            return default
+
+
+def _rows_of_views(ids, views, B):
+    """[{agent_id: views[b S + s]} for b] from a flat list of per-(env, agent) arrays: ``zip`` stops after S items of the SHARED
+    iterator, so consecutive dicts take consecutive runs -- no slicing, no Python-level loop body beyond the comprehension"""
+    it = iter(views)
+    return [dict(zip(ids, it)) for _ in range(B)]
+
 
 def _rows_of_arrays(ids, arr):
     """[{agent_id: arr[b, s]} for b]: one numpy row view per (env, agent), made by iterating the flattened array in C."""
-    S = len(ids)
-    flat = list(arr.reshape((-1,) + arr.shape[2:]))
-    return [dict(zip(ids, flat[k:k + S])) for k in range(0, len(flat), S)]
+    return _rows_of_views(ids, list(arr.reshape((-1,) + arr.shape[2:])), arr.shape[0])
 
 
 def _rows_of_scalars(ids, arr, extra_key=None, extra=None):
     """[{agent_id: python scalar} for b] (+ {extra_key: extra[b]}): ``tolist`` converts the whole array at once."""
-    rows = [dict(zip(ids, r)) for r in arr.tolist()]
+    rows = _rows_of_views(ids, arr.ravel().tolist(), arr.shape[0])
     if extra_key is not None:
         for d, v in zip(rows, extra.tolist()):
             d[extra_key] = v
     return rows
+
+
+class _HostBlock:
+    """Host arrays a poll() result's rows alias, with the per-(env, agent) observation views made ONCE: creating 36 864 numpy views
+    was the largest single cost of reading a step's rows at B = 4096.  A block is recycled only when nothing refers
+    to the result that used it (``owner`` is a weak reference to that result's token); otherwise a new block is made -- rows handed
+    out never change under their reader."""
+    __slots__ = ("arrays", "obs_views", "owner")
+
+    def __init__(self, like):
+        self.arrays = {k: v.copy() for k, v in like.items()}
+        o = self.arrays["obs"]
+        self.obs_views = list(o.reshape((-1,) + o.shape[2:]))
+        self.owner = None
+
+
+class _Token:
+    __slots__ = ("__weakref__", "block")
 
 
 class BatchedBaseEnv(_BaseEnvBase):
@@ -288,6 +332,9 @@ class BatchedBaseEnv(_BaseEnvBase):
         self._pending = None
         self._first = True
         self._always_full = None
+        self._blocks = []                                          # host blocks with pre-made observation views (_HostBlock)
+        from operator import itemgetter
+        self._pick = itemgetter(*self._ids) if len(self._ids) > 1 else None
 
     # ---- BaseEnv surface -----------------------------------------------------------------------------------------
     @property
@@ -393,10 +440,18 @@ class BatchedBaseEnv(_BaseEnvBase):
             # outside the env's strategic agents are left to the entry-by-entry path below, which decides by key membership
             # (``aid in actions``, env.py:330) and raises KeyError for an unknown agent id
             try:
-                nan = float("nan")
-                rows = [action_dict[b] for b in range(B)]
-                flat = np.array([row.get(aid, nan) for row in rows for aid in ids], dtype=np.float32)
-                if sum(map(len, rows)) == B * S and not np.isnan(flat).any():
+                rows = list(map(action_dict.__getitem__, range(B)))
+                if self._pick is not None and sum(map(len, rows)) == B * S:
+                    # (itemgetter raises KeyError for a missing agent; equal sizes + every id present = exactly the env's agents)
+                    try:                                     # python / numpy scalars: one C-level pass
+                        import itertools
+                        flat = np.fromiter(itertools.chain.from_iterable(map(self._pick, rows)), np.float32, B * S)
+                    except (TypeError, ValueError):          # 1-element arrays (Box(1,) actions as RLlib hands them over)
+                        flat = np.array(list(map(self._pick, rows)), dtype=np.float32)
+                else:
+                    nan = float("nan")
+                    flat = np.array([row.get(aid, nan) for row in rows for aid in ids], dtype=np.float32)
+                if flat.size == B * S and sum(map(len, rows)) == B * S and not np.isnan(flat).any():
                     act = flat.reshape(B, S)
                     valid = np.ones((B, S), dtype=np.uint8)
             except (KeyError, TypeError, ValueError):
@@ -454,10 +509,25 @@ class BatchedBaseEnv(_BaseEnvBase):
             # one vectorised pass (the tensor path paid 127 us per step for a synchronous copy, numpy copies and three
             # reductions nobody had asked for).
             host = dev.pull_step_async() if self._keep else dev.pull_step_lazy()
-            self._last = (_Rows(B, None, lambda: _rows_of_arrays(ids, host.get()["obs"])),
-                          _Rows(B, None, lambda: _rows_of_scalars(ids, host.get()["reward"])),
-                          _Rows(B, None, lambda: _rows_of_scalars(ids, host.get()["terminated"].astype(bool), "__all__", host.get()["all_terminated"].astype(bool))),
-                          _Rows(B, None, lambda: _rows_of_scalars(ids, host.get()["truncated"].astype(bool), "__all__", host.get()["all_truncated"].astype(bool))),
+            tok = _Token(); tok.block = None
+            blocks = self._blocks
+
+            def arrays():                                        # the step's arrays in a host block of this adapter (first read of any of the six)
+                if tok.block is None:
+                    blk = next((x for x in blocks if x.owner is None or x.owner() is None), None)
+                    if blk is None:
+                        blk = _HostBlock(host.get())
+                        blocks.append(blk)
+                    else:
+                        host.read_into(blk.arrays)               # (one copy: pinned buffer -> the block)
+                    import weakref
+                    blk.owner = weakref.ref(tok)
+                    tok.block = blk
+                return tok.block.arrays
+            self._last = (_Rows(B, None, lambda: (arrays(), _rows_of_views(ids, tok.block.obs_views, B))[1]),
+                          _Rows(B, None, lambda: _rows_of_scalars(ids, arrays()["reward"])),
+                          _Rows(B, None, lambda: _rows_of_scalars(ids, arrays()["terminated"].astype(bool), "__all__", arrays()["all_terminated"].astype(bool))),
+                          _Rows(B, None, lambda: _rows_of_scalars(ids, arrays()["truncated"].astype(bool), "__all__", arrays()["all_truncated"].astype(bool))),
                           _Rows(B, None, lambda: [{aid: {} for aid in ids} for _ in range(B)]),     # infos[aid] = {} (agents.py:301-306)
                           _Rows(B, lambda b: {}))
             return self._last
