@@ -19,6 +19,8 @@ size_t phx_generic_queue_bytes(int A, int S, int Q, int scan_cap, int n_adx, boo
 size_t phx_generic_lean_ws_bytes(int Q, int scan_cap);
 size_t phx_generic_table_bytes(int A, int nnz);
 hipError_t phx_launch_generic(const DevSpec& sp, const GenArgs& g, bool lds, hipStream_t st);
+hipError_t phx_launch_sc_rollout_fsm_rules(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
+static const int SC_RULES_MAX_S = 256;      // (whole envs per 256-lane workgroup)
 const char* phx_sc_policy_unsupported(const DevSpec& sp, const phx_rollout_io& io);
 hipError_t phx_launch_sc_rollout_policy(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st);
 bool phx_sched_compile(const phx_spec* spec, int A, int n_lists, const int32_t* act_ptr, const int32_t* act_idx, const uint8_t* act_mask,
@@ -69,7 +71,7 @@ struct Derived {
   std::vector<uint8_t> stage_has_rules;   // [n_stages] the stage's handler is a rule list (phx_spec.stage_rules)
   std::vector<uint8_t> act_mask, obs_mask, rew_mask;
   // supply-chain schedule
-  bool sc_static = false, stk_static = false, ads_static = false;
+  bool sc_static = false, stk_static = false, ads_static = false, sc_rules_fused = false;
   int ads_pub = -1, ads_adx = -1, ads_pub_stage = 0;
   bool dynamic_graph = false;      // StochasticNetwork with some rate < 1: edges differ per env
   std::vector<int32_t> shop_agent, shop_norm, shop_cust_ptr, shop_cust_exo, shop_cust_agent;
@@ -282,6 +284,20 @@ static int derive(const phx_spec* sp, Derived& d) {
     else if (k != PHX_KIND_FACTORY) sc = false;
   }
   d.sc_static = sc;
+  // the same topology with stage handlers in rule form: phx_rollout has a fused loop that evaluates the rules (phx_sc_rollout_fsm_kernel<true>);
+  // phx_step / the engine's other entries stay on the message-passing engine
+  {
+    bool scr = sp->env_type == PHX_ENV_FSM && d.kind_count[PHX_KIND_SHOP] > 0 && sp->n_stage_rules > 0 && d.kind_count[PHX_KIND_SHOP] <= 256 &&
+               !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 && (sp->round_limit < 0 || sp->round_limit >= 2) &&
+               !(sp->flags & PHX_F_IGNORE_CONN_ERRORS) && !d.dynamic_graph && !d.any_typed && sp->n_samplers == 0 && d.D == 3 && d.S == d.kind_count[PHX_KIND_SHOP];
+    for (int a = 0; a < A && scr; ++a) {
+      const int k = sp->kind[a]; const int32_t* pi = sp->param_i + a * PHX_NPI;
+      if (k == PHX_KIND_SHOP) scr = sp->kind[pi[0]] == PHX_KIND_FACTORY && edge(a, pi[0]) && edge(pi[0], a);
+      else if (k == PHX_KIND_CUSTOMER) scr = edge(a, pi[0]) && edge(pi[0], a);
+      else if (k != PHX_KIND_FACTORY) scr = false;
+    }
+    d.sc_rules_fused = scr;
+  }
   // ---- static Stackelberg-market schedule? (fused kernel) ----------------------------------------
   bool stk = sp->env_type == PHX_ENV_STACKELBERG && d.kind_count[PHX_KIND_SELLER] > 0 &&
              !(eff_flags(sp) & (PHX_F_FORCE_GENERIC | PHX_F_IGNORE_CONN_ERRORS | PHX_F_SHUFFLE_BATCHES)) && sp->trace_cap == 0 &&
@@ -618,6 +634,7 @@ struct phx_env {
   std::vector<void*> dev_allocs;
   int device = 0;
   bool use_fused = false, use_stk = false, use_ads = false, lds_ok = true;
+  bool sc_rules_fused = false;      // rule-form FSM supply chain: phx_rollout takes phx_sc_rollout_fsm_kernel<true>
   bool prices_compressed = false;   // buyer.prices is represented by seller.posted (fused Stackelberg kernel)
   std::atomic<int32_t> fsm_gen{0};  // launch generation of the time-parallel FSM rollout (DevSpec::fsm_gen_host)
   int32_t sw_guard_gen = 0;         // number of the last replayed-actions call on the store-wave kernel (DevSpec::sc_sw_guard)
@@ -1027,6 +1044,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
   d.lean_lds = lean_lds_spec(spec, der) ? 1 : 0;
   e->lds_ok = ws_stride == 0 || d.lean_lds;
   e->use_fused = der.sc_static;
+  e->sc_rules_fused = der.sc_rules_fused && d.n_rules > 0 && SC_RULES_MAX_S >= d.S;
   e->use_stk = der.stk_static;
   e->use_ads = der.ads_static;
   d.ads_pub = der.ads_pub; d.ads_adx = der.ads_adx; d.ads_pub_stage = der.ads_pub_stage;
@@ -1395,6 +1413,12 @@ static int rollout_impl(phx_env* e, const phx_rollout_io* io, void* stream) {
     // engine (the env stays there, like after a host-injected message)
     HIPCHK(phx_launch_stk_materialise(e->d, (hipStream_t)stream));
     e->prices_compressed = false; e->use_stk = false;
+  }
+  if (e->sc_rules_fused && e->d.variant_rollout != PHX_VR_LAUNCH_LOOP && e->d.variant_step != PHX_VS_GENERIC_DYNAMIC && !io->msg_log && !io->msg_count && e->n_inject == 0) {
+    // an FSM supply chain whose handlers are rules: the fused lane-per-pair loop evaluates them (round 6; until then the engine's T-step loop)
+    if (!io->obs_valid || !io->reward_valid || !io->terminated) return fail(PHX_EINVAL, "FSM rollouts need terminated, obs_valid and reward_valid outputs");
+    HIPCHK(phx_launch_sc_rollout_fsm_rules(e->d, *io, (hipStream_t)stream));
+    return PHX_OK;
   }
   if (!e->use_fused && !(e->use_stk && e->prices_compressed)) {
     // Launch loop for every other env (any topology of the device kinds, tracking off): per step ONE

@@ -627,10 +627,19 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
 // terminal dump of the cached dicts (fsm.py:349-378) are all sequential in time, so this kernel
 // keeps the lane-per-pair loop and relies on the batch for parallelism (SC256 x B = 8192 gives
 // 6 500 waves).  Per-(stage, shop) mask bits are staged in LDS once per block.
+// RULES (round 6): stage handlers declared in rule form (phx_spec.stage_rules: "restock while the shops together hold
+// fewer than 60 items", fsm.py:294-307) evaluated HERE, on the state the step's messages left: every rule's value -- one shop's field or
+// the sum over the env's shops -- is accumulated by the env's lanes with LDS atomics into a double-buffered row (one workgroup barrier per
+// step: a block holds whole envs), the first rule of the stage that holds picks the next stage, and the agents acting in THAT stage are
+// the ones that observe (fsm.py:320).  Until round 6 such envs rolled out on the message-passing engine only.
+template <bool RULES>
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                   const int epb, const int remap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fl[];   // [n_lists][S]
   const int nS = sp.S, A = sp.A, nL = sp.n_lists;
+  const int n_rules = RULES ? sp.n_rules : 0;
+  int* const s_red = (int*)(s_fl + (((size_t)nL * nS + 15) & ~(size_t)15));   // RULES: [3][epb][n_rules] sums, rows rotate step by step
+  if (RULES) for (int idx = threadIdx.x; idx < 3 * epb * n_rules; idx += SC_NT) s_red[idx] = 0;
   for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) {
     const int l = idx / nS, s = idx - l * nS, a_shop = sp.shop_agent[s];
     const uint8_t* cact = sp.shop_cust_act + (int64_t)l * sp.n_exo;
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   const int64_t b_first = (int64_t)xcd_block(remap != 0) * epb;
   const int64_t b_end = (b_first + epb < sp.B) ? b_first + epb : sp.B;
   const bool active = (int)threadIdx.x < (int)(b_end - b_first) * nS;
-  const int64_t g = b_first * nS + threadIdx.x;
+  const int64_t g = b_first * nS + (active ? (int)threadIdx.x : 0);
   const int b = active ? (int)(b_first + threadIdx.x / nS) : (int)b_first;
   const int s = active ? (int)(threadIdx.x % nS) : 0;
   int step = fld<int32_t>(sp, F_ENV_STEP)[b];
@@ -651,7 +660,9 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   int stage = fld<int32_t>(sp, F_ENV_STAGE)[b];
   int prev_stage = fld<int32_t>(sp, F_ENV_PREV_STAGE)[b];
   __syncthreads();          // mask bits staged; per-env words read before their shop-0 lane rewrites them
-  if (!active) return;
+  if (!RULES && !active) return;       // (RULES: every lane stays for the per-step barrier; lanes past the block's envs store nothing)
+  const int el = active ? (int)(threadIdx.x / nS) : 0;
+  int red_p = 0;
 
   const int a_shop = sp.shop_agent[s];
   const float norm = (float)sp.param_i[a_shop * PHX_NPI + 1];
@@ -702,6 +713,35 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     }
     const float action = io.actions ? io.actions[o] : rng_j_to_action(aj);
     sc_shop_step(st, has_action, action, any_order, D);
+    if (RULES) {
+      // the rules' values on the RESOLVED state (what env_handler() reads, fsm.py:294-302): this step's row of sums, one LDS atomic per rule
+      // and lane.  Three rows rotate: the one zeroed here for the NEXT step was last read two steps ago -- every wave finished those reads
+      // before the previous step's barrier (with two rows a fast wave would zero what a slow one is still reading)
+      int* const row = s_red + (red_p * epb + el) * n_rules;
+      int* const nxt = s_red + ((red_p == 2 ? 0 : red_p + 1) * epb + el) * n_rules;
+      for (int r = 0; r < n_rules; ++r) {
+        const DevRule q = sp.rules[r];
+        if (active && s == 0) nxt[r] = 0;
+        if (!active || q.stage != stage || (q.col >= 0 && q.col != s)) continue;
+        const int x = q.field_id == F_SHOP_STOCK ? st.stock : q.field_id == F_SHOP_SALES ? st.sales : q.field_id == F_SHOP_MISSED ? st.missed : st.delivered;
+        atomicAdd(&row[r], x);
+      }
+      __syncthreads();
+      int chosen = -1;
+      for (int r = 0; r < n_rules && chosen < 0; ++r) {
+        const DevRule q = sp.rules[r];
+        if (q.stage != stage) continue;
+        const double v = (double)row[r];                        // (i32 fields: the sum is exact whatever the order)
+        const bool hit = q.cmp == PHX_CMP_LT ? v < q.threshold : q.cmp == PHX_CMP_LE ? v <= q.threshold : q.cmp == PHX_CMP_GT ? v > q.threshold :
+                         q.cmp == PHX_CMP_GE ? v >= q.threshold : q.cmp == PHX_CMP_EQ ? v == q.threshold : v != q.threshold;
+        if (hit) chosen = q.next_stage;
+      }
+      red_p = red_p == 2 ? 0 : red_p + 1;
+      if (chosen >= 0) {                                         // the handler chose: the agents acting in THAT stage observe (fsm.py:320)
+        next_stage = chosen;
+        fl = (fl & ~8) | ((sp.stage_rew_all[stage] || (s_fl[next_stage * nS + s] & 1)) ? 8 : 0);
+      }
+    }
     ++step; ++tick;
     const bool all_trunc = (step == sp.num_steps);                           // env.py:312-318
     float ob[4] = {0.f, 0.f, 0.f, 0.f};
@@ -719,6 +759,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     } else if (observes) {                                                   // fsm.py:378
       ov = 1; rv = rcv ? 1 : 2; rw = rcv ? rc : 0.0;
     }
+    if (!RULES || active) {
     if (OD == 4) *(float4*)(io.obs + o * 4) = make_float4(ob[0], ob[1], ob[2], ob[3]);
     else { io.obs[o * 3 + 0] = ob[0]; io.obs[o * 3 + 1] = ob[1]; io.obs[o * 3 + 2] = ob[2]; }
     io.action_out[o] = action;
@@ -726,6 +767,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     io.terminated[o] = 0; io.truncated[o] = all_trunc;
     if (io.obs_valid) io.obs_valid[o] = ov;
     if (io.reward_valid) io.reward_valid[o] = rv;
+    }
     lo[0] = ob[0]; lo[1] = ob[1]; lo[2] = ob[2]; lo[3] = ob[3];
     prev_stage = stage; stage = next_stage;                                  // fsm.py:355
     if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
@@ -739,6 +781,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
       if (s_fl[sp.initial_stage * nS + s] & 1) { shop_obs_f32(st.stock, st.sales, st.missed, norm, lo); lo[3] = tobs; }
     }
   }
+  if (RULES && !active) return;
   fld<int32_t>(sp, F_SHOP_STOCK)[g] = st.stock; fld<int32_t>(sp, F_SHOP_SALES)[g] = st.sales;
   fld<int32_t>(sp, F_SHOP_MISSED)[g] = st.missed; fld<int32_t>(sp, F_SHOP_DELIVERED)[g] = st.delivered;
   fld<double>(sp, F_ENV_REW_CACHE)[g] = rc; fld<uint8_t>(sp, F_ENV_REW_CACHE_VALID)[g] = rcv;
@@ -1050,8 +1093,18 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     return hipGetLastError();
   }
   phx_note_kernel("phx_sc_rollout_fsm_kernel");
-  hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
+  hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel<false>, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
                      (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb, remap);
+  return hipGetLastError();
+}
+
+// FSM supply chains whose stage handlers are declared as rules (phx_spec.stage_rules): the lane-per-pair loop with the rules evaluated in it
+hipError_t phx_launch_sc_rollout_fsm_rules(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
+  const int epb = SC_NT / sp.S;
+  const int remap_env = phx_knobs().rollout_remap;
+  const size_t lds = (((size_t)sp.n_lists * sp.S + 15) & ~(size_t)15) + (size_t)3 * epb * sp.n_rules * sizeof(int) + 16;
+  phx_note_kernel("phx_sc_rollout_fsm_kernel[rules]");
+  hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel<true>, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, remap_env >= 0 ? remap_env : 1);
   return hipGetLastError();
 }
 

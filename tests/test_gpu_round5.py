@@ -464,7 +464,7 @@ def test_rollouts_with_rule_form_handlers_match_the_oracle(S, ks, B, num_steps, 
     o.reset(); d.reset()
     T = 2 * num_steps + 5
     rd, ro = d.rollout(T), o.rollout(T)
-    assert d.dev.last_kernel() == "phx_sched_step_kernel[T-step loop]", d.dev.last_kernel()      # (round 6: the engine's compiled schedule evaluates the rule)
+    assert d.dev.last_kernel() == "phx_sc_rollout_fsm_kernel[rules]", d.dev.last_kernel()      # (round 6: a FUSED loop evaluates the rule)
     np.testing.assert_array_equal(rd["obs_valid"], ro["obs_valid"]); np.testing.assert_array_equal(rd["reward_valid"], ro["reward_valid"])
     m = ro["obs_valid"].astype(bool)
     np.testing.assert_array_equal(f32_bits(rd["obs"][m]), f32_bits(ro["obs"][m]))
@@ -516,7 +516,7 @@ def test_rule_form_handlers_through_the_python_surface_and_their_check_against_t
         assert env.current_stage == want
     assert len(calls) == n_check                               # never called at step time
     tr = env.rollout(7)
-    assert tr.obs_valid is not None and "phx_sched_step_kernel" in dev.last_kernel()
+    assert tr.obs_valid is not None and dev.last_kernel() == "phx_sc_rollout_fsm_kernel[rules]", dev.last_kernel()
     bad = ph.state_rules([ph.StageRule("shop.stock", "<", 90, "RESTOCK")])(lambda env: golden_stock_handler(env, threshold=60))
     env2 = supply_chain_env(3, [2, 3, 1], 12, 16, fsm=True, seed=5, restock_handler=bad)
     with pytest.raises(ph.FSMValidationError):

@@ -161,3 +161,70 @@ def test_scale_node_script_dry_run_on_one_gpu(tmp_path):
     assert lines["gather_ring_n8"].get("n_gpus") == 8
     summ = open(os.path.join(out, "summary.txt")).read()
     assert "== scaling" in summ and "N=8" in summ and "NCCL_ALGO=Ring" in summ
+
+
+def test_golden_state_handler_through_the_fused_rule_rollout():
+    """golden `sc_fsm_state_handler` (the REFERENCE running a RESTOCK handler that resolves the network and branches on the shops' total
+    stock) through ONE phx_rollout with the handler in rule form: the fused lane-per-pair loop evaluates the rule -- the
+    reference's observations, rewards, validity bits, truncations and final stage over 70 steps and three episodes, actions and order sizes
+    replayed; the same call on the message-passing engine's compiled schedule (force_generic) agrees."""
+    import phantom_amd as ph
+    from helpers import env_from_golden, golden, golden_stock_handler
+    g = golden("sc_fsm_state_handler")
+    T, B = int(g["T"]), len(g["seeds"])
+    assert g["reset_before"][[0, 30, 60]].all() and g["reset_before"].sum() == 3 * B      # resets exactly at the episode ends: a rollout's auto-reset
+    for generic in (False, True):
+        handler = ph.state_rules([ph.StageRule("shop.stock", "<", 60, "RESTOCK")])(lambda env: golden_stock_handler(env))
+        env = env_from_golden({k: g[k] for k in g.files if k != "next_stage"}, restock_handler=handler, force_generic=generic)
+        d = DeviceRunner(env.spec); d.reset()
+        rd = d.rollout(T, g["actions"], g["exo"])
+        want = "phx_sched_step_kernel[T-step loop]" if generic else "phx_sc_rollout_fsm_kernel[rules]"
+        assert d.dev.last_kernel() == want, d.dev.last_kernel()
+        np.testing.assert_array_equal(rd["obs_valid"], g["obs_valid"]); np.testing.assert_array_equal(rd["reward_valid"], g["reward_valid"])
+        m = g["obs_valid"].astype(bool)
+        np.testing.assert_array_equal(f32_bits(rd["obs"][m]), f32_bits(g["obs"][m]))
+        m = g["reward_valid"] == 1
+        np.testing.assert_array_equal(f32_bits(rd["rewards"][m]), f32_bits(g["reward"][m].astype(np.float32)))
+        np.testing.assert_array_equal(rd["truncated"], g["truncated"] | g["all_truncated"][:, :, None])
+        np.testing.assert_array_equal(d.get_i32("shop.stock")[:, :], 0 * g["stock"][-1] if g["all_truncated"][-1].all() else g["stock"][-1])
+        assert (d.err == 0).all()
+
+
+@pytest.mark.parametrize("S,ks,B,ns,rules", [
+    (9, [6] * 9, 200, 17, [("shop.stock", "<", 300, "RESTOCK", None)]),
+    (51, [4] * 51, 23, 12, [("shop.sales", ">=", 40, "SELL", None), ("shop.stock", "<", 1500, "RESTOCK", None)]),
+    (3, [2, 3, 1], 64, 9, [("shop.stock", "<=", 20, "RESTOCK", "SHOP1"), ("shop.missed_sales", ">", 3, "RESTOCK", None)]),
+    (4, [3] * 4, 129, 10, [("shop.delivered_stock", "==", 0, "RESTOCK", "SHOP0")]),
+])
+def test_fused_rule_rollout_matches_the_oracle_and_the_engine(S, ks, B, ns, rules):
+    """phx_sc_rollout_fsm_kernel<RULES>: several rules per stage (the first that holds decides), single-agent columns and sums, every
+    comparison operator family, batches that do not fill the last workgroup, episode ends and fragments that continue from the state
+    the previous one left -- every plane against the oracle, and the engine's compiled schedule (force_generic) on the same spec."""
+    import phantom_amd as ph
+    def build(**kw):
+        h = ph.state_rules([ph.StageRule(f, c, th, nx, agent=ag) for f, c, th, nx, ag in rules])(lambda env: None)
+        h._phx_skip_check = True
+        env = supply_chain_env(S, ks, ns, B, fsm=True, seed=13, restock_handler=h, **kw)
+        env._rules_checked = True
+        return env
+    env, envg = build(), build(force_generic=True)
+    o, d, dg = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec), DeviceRunner(envg.spec)
+    o.reset(); d.reset(); dg.reset()
+    stages = set()
+    for T in (2 * ns + 3, 7, 1):
+        ro = o.rollout(T)
+        rd = d.rollout(T); assert d.dev.last_kernel() == "phx_sc_rollout_fsm_kernel[rules]", d.dev.last_kernel()
+        rg = dg.rollout(T); assert dg.dev.last_kernel() == "phx_sched_step_kernel[T-step loop]", dg.dev.last_kernel()
+        for r, what in ((rd, "fused"), (rg, "engine")):
+            np.testing.assert_array_equal(r["obs_valid"], ro["obs_valid"], err_msg=what); np.testing.assert_array_equal(r["reward_valid"], ro["reward_valid"], err_msg=what)
+            m = ro["obs_valid"].astype(bool)
+            np.testing.assert_array_equal(f32_bits(r["obs"][m]), f32_bits(ro["obs"][m]), err_msg=what)
+            m = ro["reward_valid"] == 1
+            np.testing.assert_array_equal(f32_bits(r["rewards"][m]), f32_bits(ro["rewards"][m]), err_msg=what)
+            np.testing.assert_array_equal(f32_bits(r["actions"]), f32_bits(ro["actions"]), err_msg=what)
+            np.testing.assert_array_equal(r["truncated"], ro["truncated"], err_msg=what)
+            np.testing.assert_array_equal(f32_bits(r["last_obs"]), f32_bits(ro["last_obs"]), err_msg=what)
+        for f in STATE + ("env.stage", "env.prev_stage"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f); np.testing.assert_array_equal(dg.get_i32(f), o.get_i32(f), err_msg=f)
+        stages |= set(np.unique(o.get_i32("env.stage")).tolist())
+    assert (d.err == 0).all() and (dg.err == 0).all()
