@@ -40,11 +40,43 @@ def run_rollout_case(case, journal=None):
         variants = {"rollout": str(vrng.choice(["auto", "auto", "time_parallel", "lean", "general", "store_waves", "store_waves"])),
                     "block": [0, 0, "whole_envs", 16, 32, 48, 64, 36, 96, 144, 128][int(vrng.integers(0, 11))],
                     }
+        # round 6: the message-passing engine's compiled schedule (force_generic: per-step launches with partial action masks -- the envs it
+        # flags run the dynamic engine in the same launch -- and its T-step loop), FSM stage handlers in rule form (the fused rule loop, or
+        # the engine), and rollouts whose policy is an MLP evaluated on the device (plain envs)
+        r6 = np.random.default_rng(case + 60_000_013)
+        mode6 = float(r6.random())
+        extra = {}
+        if mode6 < 0.25:
+            extra["force_generic"] = True
+        rules6 = None
+        if 0.25 <= mode6 < 0.40 or (mode6 < 0.25 and r6.random() < 0.3):
+            fsm = True
+            import phantom_amd as ph
+            fld = str(r6.choice(["shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock"]))
+            rules6 = [ph.StageRule(fld, str(r6.choice(["<", "<=", ">", ">=", "==", "!="])), float(r6.integers(0, 60 * S)), "RESTOCK",
+                                   agent=(f"SHOP{int(r6.integers(0, S))}" if S > 1 and r6.random() < 0.3 else None))]
+            if r6.random() < 0.4:
+                rules6.insert(0, ph.StageRule("shop.stock", "<", float(r6.integers(0, 30 * S)), "RESTOCK"))
+            h = ph.state_rules(rules6)(lambda env_: None)
+            h._phx_skip_check = True
+            extra["restock_handler"] = h
+        policy6 = None
+        if 0.40 <= mode6 < 0.52 and not fsm:
+            import phantom_amd as ph
+            widths = [int(r6.integers(1, 65))] + ([int(r6.integers(1, 65))] if r6.random() < 0.4 else [])
+            dims = [3] + widths + [1]
+            policy6 = ph.MLPPolicy([r6.normal(0, 1.2 / np.sqrt(dims[l]), (dims[l + 1], dims[l])).astype(np.float32) for l in range(len(dims) - 1)],
+                                   [r6.normal(0, 0.4, (dims[l + 1],)).astype(np.float32) for l in range(len(dims) - 1)],
+                                   activation=str(r6.choice(["relu", "hard_tanh"])), out_scale=float(r6.uniform(10, 80)), out_bias=float(r6.uniform(0, 70)))
         env = supply_chain_env(S, Ks, ns, B, fsm=fsm, seed=int(rng.integers(0, 1000)), env_offset=int(rng.integers(0, 5000)),
-                               variants=variants)
+                               variants=variants, **extra)
+        if rules6 is not None:
+            env._rules_checked = True
         fields = ("shop.stock", "shop.sales", "shop.missed_sales", "shop.delivered_stock", "env.step", "env.tick") + (("env.stage", "env.prev_stage") if fsm else ())
         amax, valid = 100.0, fsm
-        desc = f"sc S={S} Ks={Ks if len(set(Ks)) > 1 else Ks[0]} B={B} num_steps={ns} fsm={int(fsm)} variants={variants}"
+        desc = (f"sc S={S} Ks={Ks if len(set(Ks)) > 1 else Ks[0]} B={B} num_steps={ns} fsm={int(fsm)} variants={variants}"
+                + (" engine" if extra.get("force_generic") else "") + (f" rules={[(r.field, r.cmp, r.threshold, r.agent) for r in rules6]}" if rules6 else "")
+                + (f" policy={[w.shape[0] for w in policy6.weights[:-1]]} {policy6.activation}" if policy6 else ""))
     else:
         L = int(rng.choice([2, 4, 8, 16])); d = min(int(rng.choice([1, 2, 4])), L)
         Fw = int(rng.choice([4, 8, 32, 100])); B = int(rng.choice([1, 3, 8, 16])); ns = int(rng.choice([2, 7, 10, 33]))
@@ -57,11 +89,26 @@ def run_rollout_case(case, journal=None):
     o, dv = OracleEnv(env.spec, threads=4), DeviceRunner(env.spec)
     if journal:
         dv.on_launch = lambda k: journal(f"case {case}: launched {k}")
-    assert dv.dev.uses_fused
+    engine = kind < 8 and (bool(extra.get("force_generic")) or rules6 is not None)
+    assert dv.dev.uses_fused or engine
     o.reset(); dv.reset()
     for _ in range(int(rng.integers(0, 4))):                      # fragments that do not start on a tick quad / at a reset
         a = rng.uniform(0, amax, (B, env.spec.n_strategic)).astype(np.float32)
-        o.step(a, None, None); dv.step(a, None, None)
+        av = None
+        if engine and r6.random() < 0.5:                         # shops without an action: those envs leave the compiled schedule
+            av = (r6.random((B, env.spec.n_strategic)) < 0.85).astype(np.uint8)
+        o.step(a, av, None); dv.step(a, av, None)
+        if engine:                                               # the per-step outputs of the engine's kernels, not only the state they leave
+            np.testing.assert_array_equal(dv.obs_valid, o.obs_valid, err_msg=f"case {case}: step obs_valid")
+            m = o.obs_valid.astype(bool)
+            np.testing.assert_array_equal(f32_bits(dv.obs[m]), f32_bits(o.obs[m]), err_msg=f"case {case}: step obs")
+            np.testing.assert_array_equal(dv.reward_valid, o.reward_valid, err_msg=f"case {case}: step reward_valid")
+            m = o.reward_valid == 1
+            np.testing.assert_array_equal(dv.reward[m].view(np.uint64), o.reward[m].view(np.uint64), err_msg=f"case {case}: step reward")
+            np.testing.assert_array_equal(dv.all_truncated, o.all_truncated)
+            done = (o.all_truncated | o.all_terminated).astype(np.uint8)
+            if done.any():
+                o.reset(done); dv.reset(done)
     if kind < 8 and not fsm and np.random.default_rng(case + 20_000_003).random() < 0.15:
         # step counters a caller moved (round 4: the store-wave kernel derives the flag planes of a whole fragment from them):
         # ahead, behind, below zero (the first episode end is further away), at or above num_steps (the episode never ends)
@@ -87,7 +134,7 @@ def run_rollout_case(case, journal=None):
         T = int(rng.choice([1, 2, 3, 7, 19, 20, 21, 39, 41, 64, 100, 130, 200, 257]))
         mode = xrng.random()
         acts = exo = None
-        if kind < 8 and not fsm and xrng.random() < 0.3:         # a recorded policy and / or recorded draws (plain supply chains)
+        if kind < 8 and (not fsm or engine) and policy6 is None and xrng.random() < 0.3:         # a recorded policy and / or recorded draws (plain supply chains; the engine: any)
             which = int(xrng.integers(0, 3))
             if which != 1:
                 acts = xrng.uniform(0, 140, (T, B, env.spec.n_strategic)).astype(np.float32)
@@ -106,7 +153,11 @@ def run_rollout_case(case, journal=None):
         k = min(int(xrng.choice([2, 3, 4, 8])), T) if (mode < 0.25 and T >= 4) else 1      # (lease r05_1: T = 7 with 8 fragments was the generator's own invalid argument)
         if journal:
             journal(f"case {case}: rollout T={T} frags={k} replay={'a' if acts is not None else ''}{'x' if exo is not None else ''}")
-        if k > 1:
+        if kind < 8 and policy6 is not None:                      # T on-policy steps in one launch (no fragment lists, no replayed actions)
+            k = 1
+            exo = xrng.integers(0, 5, (T, B, dv.n_exo)).astype(np.uint8) if (dv.n_exo and xrng.random() < 0.3) else None
+            ro, rd = o.rollout(T, None, exo, policy=policy6), dv.rollout(T, None, exo, policy=policy6)
+        elif k > 1:
             Tf = max(1, T // k); T = Tf * k
             acts = None if acts is None else acts[:T]; exo = None if exo is None else exo[:T]
             ro, rd = o.rollout(T, acts, exo), dv.rollout_fragments(Tf, k, acts, exo, **hints)
