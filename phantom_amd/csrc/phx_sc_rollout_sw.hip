@@ -93,11 +93,17 @@ __device__ __forceinline__ void sw_lds_barrier() {       // orders LDS traffic o
 }
 
 // LDS bytes of a workgroup (host and device agree through this one function)
+// copies of the observation tables (one per LDS bank of a 32-lane group; development: SW_NC48 = 16 halves them for the 48-pair shape, whose
+// workgroup then fits a CU twice -- tools/build_variant.py; product build: 32 everywhere)
+#ifndef SW_NC48
+#define SW_NC48 32
+#endif
+__host__ __device__ inline int sw_ncopy(int G) { return G == 48 ? SW_NC48 : 32; }
 __host__ __device__ inline size_t sw_lds_bytes(int G, int epb, int TC, int dtab_n, int fsm_ns = 0) {
   const size_t G4p = (size_t)((G + 3) & ~3), items = (size_t)TC * G;
   const size_t fsm = fsm_ns > 0 ? items * 2 * 2 + G4p * 4 + (size_t)((G + 15) & ~15) + (size_t)((epb + 3) & ~3) * 4 + (size_t)((2 * fsm_ns + 15) & ~15) : 0;   // (FSM sections, below)
   return fsm + G4p * 4 + (size_t)((epb + 3) & ~3) * 4 + 16            // pair table, ticks, flags
-       + 101 * 32 * 4 + 32 * 32 * 4 + 401 * 8 * 4 + 128          // observation tables (32 copies), reward table (8 copies), digit sums of k < 125
+       + (size_t)(101 + 32) * sw_ncopy(G) * 4 + 401 * 8 * 4 + 128  // observation tables (32 copies), reward table (8 copies), digit sums of k < 125
        + 15632                                                   // order sums of y < 5^K (5^6 reserved: the tables sit at fixed offsets)
        + items * 2 * 3 + items * 2 * 2                           // R | D tiles (3), stock tiles (2)
        + (size_t)((G + 15) & ~15) * 3 + 16                       // episode-end rows (3) + pad
@@ -162,10 +168,12 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
   // The value tables are REPLICATED so that a lane's lookup lands in the lane's own LDS bank (ds_read_b32: 32 banks, lane
   // groups of 32): entry v of copy c at dword v * 32 + c, lane l reads copy l & 31 -- no bank conflicts whatever the values.
   float* s_tabs = (float*)smem;                                         // [101][32] stock / 100        encode_observation,
-  float* s_tabn = s_tabs + 101 * 32;                                    // [32][32]  x / norm           supply_chain.py:124-134
+  constexpr int NC = (GT == 48) ? SW_NC48 : 32, NCL = (NC == 32) ? 7 : 6;      // table copies; log2 of an entry's bytes
+  static_assert(NC == 32 || NC == 16, "SW_NC48: 32 or 16");
+  float* s_tabn = s_tabs + 101 * NC;                                    // [32][32]  x / norm           supply_chain.py:124-134
   // compute_reward (:147): f32(f64 sales - 0.1 * stock) depends on n = 10 * sales - stock only and equals the f32 quotient n / 10
   // for every reachable (sales <= 30, stock <= 100) (tests/test_host_logic.py); 8 copies: lanes l, l + 8, .. share one
-  float* s_rtab = s_tabn + 32 * 32;                                     // [401][8]  f32(n / 10), n = 10 * sales - stock + 100
+  float* s_rtab = s_tabn + 32 * NC;                                     // [401][8]  f32(n / 10), n = 10 * sales - stock + 100
   uint8_t* s_ds = (uint8_t*)(s_rtab + 401 * 8);                         // [125] base-5 digit sum of k < 5^3
   uint8_t* s_dtab = s_ds + 128;                                         // [5^K <= 15625] digit sum of y: the customers' order sizes summed
   uint32_t* s_pair = (uint32_t*)(s_dtab + 15632);                       // [G] shop | env_local << 8
@@ -279,10 +287,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     const float* const bv = (const float*)s_out0;
     float4* const w32 = (float4*)s_tabs;                                 // s_tabs [101][32] and s_tabn [32][32] are adjacent: 133 entries x 8 pieces
     float4* const w8 = (float4*)s_rtab;                                  // [401][8]: 2 pieces per entry
-    constexpr int N32 = (101 + 32) * 8, N8 = 401 * 2;
+    constexpr int N32 = (101 + 32) * (NC / 4), N8 = 401 * 2;
     for (int i = t; i < N32 + N8; i += nthr) {
       const bool wide = i < N32;
-      const int e = wide ? i >> 3 : (i - N32) >> 1;
+      const int e = wide ? i / (NC / 4) : (i - N32) >> 1;
       const float v = bv[wide ? (e < 101 ? SW_IMG_TABS + e : SW_IMG_TABN + (e - 101)) : SW_IMG_RTAB + e];
       (wide ? w32 + i : w8 + (i - N32))[0] = make_float4(v, v, v, v);
     }
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     float4* const o_rew4 = o_obs4 + 3 * (items >> 2);
     const int n_units = tc * G4, dr = out_fixed ? nwk / G4 : 0;
     const bool guard = !FSM && weird && c == 0;
-    const uint32_t c32 = ((uint32_t)tid & 31u) << 2, c8 = ((uint32_t)tid & 7u) << 2;      // the lane's table copies (byte offsets)
+    const uint32_t c32 = ((uint32_t)tid & (uint32_t)(NC - 1)) << 2, c8 = ((uint32_t)tid & 7u) << 2;      // the lane's table copies (byte offsets)
     const char* const t_s = (const char*)s_tabs; const char* const t_n = (const char*)s_tabn; const char* const t_r = (const char*)s_rtab;
     int r = ol_r0;
     for (int u = wt; u < n_units; u += nwk, r += dr) {
@@ -602,13 +610,13 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
         for (int k = 0; k < 4; ++k) {
           if (FSM) {
             const uint32_t w = fo4[k];
-            as_[k] = ((w & 127u) << 7) | c32; an_[k] = (((w >> 7) & 31u) << 7) | c32; am_[k] = (((w >> 12) & 31u) << 7) | c32;
+            as_[k] = ((w & 127u) << NCL) | c32; an_[k] = (((w >> 7) & 31u) << NCL) | c32; am_[k] = (((w >> 12) & 31u) << NCL) | c32;
             ar_[k] = (((w >> 17) & 0x1FFu) << 5) | c8;                  // the cached reward the row emits
             continue;
           }
           const int x0 = (int)(xw[k] & 255u), xa = (int)(xw[k] >> 8), D = (int)(rw4[k] >> 8);
           const int sales = min(x0, D), missed = D - sales;             // handle_order_request :105-122 (sales == x0 - max(x0 - D, 0))
-          as_[k] = ((uint32_t)xa << 7) | c32; an_[k] = ((uint32_t)sales << 7) | c32; am_[k] = ((uint32_t)missed << 7) | c32;
+          as_[k] = ((uint32_t)xa << NCL) | c32; an_[k] = ((uint32_t)sales << NCL) | c32; am_[k] = ((uint32_t)missed << NCL) | c32;
           ar_[k] = ((uint32_t)(10 * sales - xa + 100) << 5) | c8;
         }
 #pragma unroll
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
           if (r == 0) x0 = s_x0w[gl0 + k];                               // the launch's first row: the stock as the caller left it
           const int sales = min(x0, D), missed = D - sales;
           if ((unsigned)x0 <= (unsigned)PHX_SHOP_MAX_STOCK) {
-            o[3 * k] = s_tabs[xa << 5]; o[3 * k + 1] = s_tabn[sales << 5]; o[3 * k + 2] = s_tabn[missed << 5];
+            o[3 * k] = s_tabs[xa * NC]; o[3 * k + 1] = s_tabn[sales * NC]; o[3 * k + 2] = s_tabn[missed * NC];
             rw[k] = s_rtab[(10 * sales - xa + 100) << 3];
           } else {                                                      // a stock the caller set outside [0, 100]: the formulas
             float ob[3];
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
       for (int h = 0; h < 4; ++h) rej |= !rng_split(w[h], y[h], aj[h]);
     }
     // (3) outputs: sixteen table lookups
-    const uint32_t c32 = ((uint32_t)tid & 31u) << 2, c8 = ((uint32_t)tid & 7u) << 2;
+    const uint32_t c32 = ((uint32_t)tid & (uint32_t)(NC - 1)) << 2, c8 = ((uint32_t)tid & 7u) << 2;
     const char* const t_s = (const char*)s_tabs; const char* const t_n = (const char*)s_tabn; const char* const t_r = (const char*)s_rtab;
     const uint32_t xw[4] = {vx.x & 0xffffu, vx.x >> 16, vx.y & 0xffffu, vx.y >> 16};
     const uint32_t rw4[4] = {vr.x & 0xffffu, vr.x >> 16, vr.y & 0xffffu, vr.y >> 16};
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     for (int k = 0; k < 4; ++k) {
       const int x0 = (int)(xw[k] & 255u), xa = (int)(xw[k] >> 8), D = (int)(rw4[k] >> 8);
       const int sales = min(x0, D), missed = D - sales;
-      as_[k] = ((uint32_t)xa << 7) | c32; an_[k] = ((uint32_t)sales << 7) | c32; am_[k] = ((uint32_t)missed << 7) | c32;
+      as_[k] = ((uint32_t)xa << NCL) | c32; an_[k] = ((uint32_t)sales << NCL) | c32; am_[k] = ((uint32_t)missed << NCL) | c32;
       ar_[k] = ((uint32_t)(10 * sales - xa + 100) << 5) | c8;
     }
     float o[12], rw[4];
