@@ -66,6 +66,16 @@ if [ "$WHAT" = gen ] || [ "$WHAT" = all ]; then
     pmc f_step_$w FETCH_SIZE -- $GS
   done
 fi
+if [ "$WHAT" = ads ] || [ "$WHAT" = all ]; then
+  # the digital-ads market (0.22-0.23 of the peak for three rounds): what bounds it
+  A="python $R/tools/ads_time.py"
+  trace trace_ads $A
+  grep "us" $OUT/trace_ads.log | grep -v amdgpu >> $OUT/summary.txt
+  pmc sq_ads SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- $A
+  pmc sq2_ads SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR -- $A
+  pmc w_ads WRITE_SIZE -- $A
+  pmc f_ads FETCH_SIZE -- $A
+fi
 if [ "$WHAT" = policy ] || [ "$WHAT" = all ]; then
   P="python $R/tools/policy_time.py"
   trace trace_policy $P
