@@ -32,18 +32,22 @@ struct PolArgs {
   phx_policy_mlp pol;
 };
 
+// act(c) as ONE v_med3_f32: ReLU = the median of (c, 0, +inf), hard-tanh = the median of (c, -1, 1).  Finite c: the values of the header's
+// definition (c > 0 ? c : +0 / the two-sided clip); a -0 that med3 may let through where the definition says +0 changes no sum's value and the
+// definition's closing "+ 0.0f" removes it from the action.
 template <int ACT>
 __device__ __forceinline__ float pol_act(float c) {
-  if (ACT == PHX_ACT_HARD_TANH) return c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);
-  return c > 0.0f ? c : 0.0f;
+  if (ACT == PHX_ACT_HARD_TANH) return __builtin_amdgcn_fmed3f(c, -1.0f, 1.0f);
+  return __builtin_amdgcn_fmed3f(c, 0.0f, __builtin_inff());
 }
+typedef float pol_f2 __attribute__((ext_vector_type(2)));
 
 // LDS image of the network (floats), staged once per workgroup -- every lane reads the same addresses (broadcast reads, 16 bytes =
 // four weights per instruction; LDS returns in order, so the compiler keeps many reads in flight, which scalar loads do not allow).
 // Hidden widths are PADDED to multiples of 8 with zero weights and zero biases: a padded unit is act(0) = 0 and adds fmaf(0, 0, c) = c
 // to every sum it enters -- the value of every sum is unchanged (only the sign of an exact zero can differ, which the definition's
 // closing "+ 0.0f" removes from the action), and no loop below carries a guard.
-//   [0, 4 W0p)                      layer 0, per unit (w[i][0], w[i][1], w[i][2], b[i])
+//   [0, 4 W0p)                      layer 0, per PAIR of units (2p, 2p + 1): (w[.][0] x 2, w[.][1] x 2 | w[.][2] x 2, b[.] x 2) -- two units per v_pk_fma_f32
 //   one hidden layer:  o1 = 4 W0p:  the output row w[1][0 .. W0p), then b[1][0] (+ 3 pad)
 //   two hidden layers: o1 = 4 W0p:  layer 1, W1p rows of W0p floats; then b[1][0 .. W1p), the output row w[2][0 .. W1p), b[2][0] (+ 3 pad)
 __host__ __device__ inline int pol_img_floats(int n_hidden, int W0p, int W1p) {
@@ -63,8 +67,9 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
   {                                                                    // stage the network
     for (int i = tid; i < W0p; i += NT) {
       const bool in = i < W0;
-      s_img[4 * i + 0] = in ? a.pol.w[0][i * 3 + 0] : 0.0f; s_img[4 * i + 1] = in ? a.pol.w[0][i * 3 + 1] : 0.0f;
-      s_img[4 * i + 2] = in ? a.pol.w[0][i * 3 + 2] : 0.0f; s_img[4 * i + 3] = in ? a.pol.b[0][i] : 0.0f;
+      float* const q = s_img + 8 * (i >> 1) + (i & 1);
+      q[0] = in ? a.pol.w[0][i * 3 + 0] : 0.0f; q[2] = in ? a.pol.w[0][i * 3 + 1] : 0.0f;
+      q[4] = in ? a.pol.w[0][i * 3 + 2] : 0.0f; q[6] = in ? a.pol.b[0][i] : 0.0f;
     }
     float* o1 = s_img + 4 * W0p;
     if (!TWO) {
@@ -107,14 +112,22 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
 
   for (int t = 0; t < a.T; ++t) {
     // ---- compute_action: the MLP on the previous observation (phx_policy_mlp, include/phantom_amd.h) --------------------------------
-    auto unit0 = [&](int i) { const float4 w = img0[i]; return pol_act<ACT>(__fmaf_rn(w.z, x[2], __fmaf_rn(w.y, x[1], __fmaf_rn(w.x, x[0], w.w)))); };
+    // two units per packed fused multiply-add (each element is the fmaf of the definition)
+    auto pair0 = [&](int p, float& ha, float& hb) __attribute__((always_inline)) {
+      const float4 u = img0[2 * p], v = img0[2 * p + 1];
+      pol_f2 c = {v.z, v.w};
+      c = __builtin_elementwise_fma((pol_f2){u.x, u.y}, (pol_f2){x[0], x[0]}, c);
+      c = __builtin_elementwise_fma((pol_f2){u.z, u.w}, (pol_f2){x[1], x[1]}, c);
+      c = __builtin_elementwise_fma((pol_f2){v.x, v.y}, (pol_f2){x[2], x[2]}, c);
+      ha = pol_act<ACT>(c.x); hb = pol_act<ACT>(c.y);
+    };
     float y;
     if (!TWO) {
       y = o1[W0p];
       for (int i0 = 0; i0 < W0p; i0 += 8) {                            // eight units at a time: their reads are in flight together
         float h[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) h[u] = unit0(i0 + u);
+        for (int u = 0; u < 8; u += 2) pair0((i0 + u) >> 1, h[u], h[u + 1]);
         const float4 wa = *(const float4*)(o1 + i0), wb = *(const float4*)(o1 + i0 + 4);
         y = __fmaf_rn(wa.x, h[0], y); y = __fmaf_rn(wa.y, h[1], y); y = __fmaf_rn(wa.z, h[2], y); y = __fmaf_rn(wa.w, h[3], y);      // ascending unit order
         y = __fmaf_rn(wb.x, h[4], y); y = __fmaf_rn(wb.y, h[5], y); y = __fmaf_rn(wb.z, h[6], y); y = __fmaf_rn(wb.w, h[7], y);
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
       for (int i0 = 0; i0 < W0p; i0 += 8) {
         float h[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) h[u] = unit0(i0 + u);
+        for (int u = 0; u < 8; u += 2) pair0((i0 + u) >> 1, h[u], h[u + 1]);
 #pragma unroll
         for (int u = 0; u < 8; ++u) hcol[(i0 + u) * NT] = h[u];
       }
