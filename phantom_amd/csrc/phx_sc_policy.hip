@@ -56,7 +56,9 @@ __host__ __device__ inline int pol_img_floats(int n_hidden, int W0p, int W1p) {
 
 // NT threads per workgroup: 256 with one hidden layer; 128 with two (the first layer's activations live in a wave-private LDS column
 // per lane, [unit][lane]: bank-conflict free -- a register array cannot be indexed by a run-time width)
-template <int ACT, bool TWO, int NT>
+// EXO: the order sizes are replayed from io.exo (global loads inside the step loop); the device-drawn instantiation has NO load in its loop, so
+// that no s_waitcnt vmcnt ever waits for the previous step's trajectory stores (loads and stores share the counter on gfx950)
+template <int ACT, bool TWO, int NT, bool EXO>
 __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_img[];
   const int tid = threadIdx.x, S = a.S;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
 
     // ---- PhantomEnv.step for the pair (env.py:239-303 with the supply chain's closed form) -------------------------------------------
     int D = 0;                                                         // the shop's customers' order sizes summed, supply_chain.py:61-67
-    if (a.io.exo) {
+    if (EXO) {
       const uint8_t* row = a.io.exo + ((int64_t)t * a.B + b) * a.n_exo;
       for (int k = 0; k < K; ++k) D += (int)row[a.shop_cust_exo[c0 + k]];
     } else {
@@ -238,7 +240,8 @@ hipError_t phx_launch_sc_rollout_policy(const DevSpec& sp, const phx_rollout_io&
   const int n_img = pol_img_floats(a.pol.n_hidden, W0p, W1p);
   const size_t lds = (size_t)n_img * 4 + (two ? (size_t)W0p * NT * sizeof(float) : 0);      // <= 18.7 + 32 KB
   phx_note_kernel("phx_sc_rollout_policy_kernel");
-#define POL_LAUNCH(ACT_, TWO_, NT_) hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_>), grid, dim3(NT_), lds, st, a)
+#define POL_LAUNCH(ACT_, TWO_, NT_) do { if (io.exo) hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, true>), grid, dim3(NT_), lds, st, a); \
+    else hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, false>), grid, dim3(NT_), lds, st, a); } while (0)
   if (a.pol.activation == PHX_ACT_HARD_TANH) { if (two) POL_LAUNCH(PHX_ACT_HARD_TANH, true, 128); else POL_LAUNCH(PHX_ACT_HARD_TANH, false, 256); }
   else { if (two) POL_LAUNCH(PHX_ACT_RELU, true, 128); else POL_LAUNCH(PHX_ACT_RELU, false, 256); }
 #undef POL_LAUNCH

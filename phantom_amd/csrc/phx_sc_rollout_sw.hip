@@ -830,7 +830,10 @@ __global__ __launch_bounds__(1024) void phx_sc_rollout_sw_kernel(const SwArgs a_
     for (int r = 0; r < tc;) {
       while (t0 + r >= lo + Tf) { lo += Tf; ++f; }
       const int left = lo + Tf - (t0 + r), n = tc - r < left ? tc - r : left;
-      body(f, t0 + r - lo, r, n);                                        // fragment, first row in it, first row of the tile, rows
+      // (the fragment index as an SGPR: the store role is a divergent branch to the compiler, which otherwise reads the fragment's plane
+      //  pointers with VECTOR loads from the argument block -- and the s_waitcnt vmcnt(0) behind each drains the wave's trajectory stores,
+      //  loads and stores share the counter: three drains per chunk)
+      body(__builtin_amdgcn_readfirstlane(f), t0 + r - lo, r, n);        // fragment, first row in it, first row of the tile, rows
       r += n;
     }
   };
