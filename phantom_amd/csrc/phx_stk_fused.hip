@@ -404,7 +404,13 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_step_fast_kerne
 // before (PHX_TIMING, 512 threads, everything looked up per step): 15.3 k cycles per step = acting 6.3 k (Philox per
 // acting agent and step) + booking 1.8 k + outputs 7.0 k (four dependent table loads per agent), a quarter of the
 // lanes idle in the third pass over the agents.
-template <bool DYN, int NT>
+//
+// FAST (round 6): 1 = static graph, every buyer with at most eight neighbours (DevSpec::stk_packed) and the random policy, 2 = the same with
+// replayed actions, 0 = everything else decided at run time.  With FAST == 1 the step loop holds NO global load: the general form's loads
+// (io.actions, the neighbour table of a buyer with more than eight neighbours) sit behind run-time conditions that are never true for such a
+// spec, but the s_waitcnt vmcnt(0) the compiler puts behind them at the joins is executed by every step -- and loads and stores share the
+// counter on gfx950, so every step waited for the previous row's stores (the kernel's only HBM traffic) to be acknowledged.
+template <bool DYN, int NT, int FAST>
 __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(const DevSpec* __restrict__ spp_, const phx_rollout_io io_) {
   // The spec (device memory, DevSpec::self_dev) and the rollout arguments (kernarg) are read through the scalar cache where they
   // are used: constant-address-space pointers whose provenance is hidden again at every step (STKR_REFRESH).  By value the two
@@ -437,7 +443,10 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   // the buyers' values in LDS, not in a register pair per slot: with 64 VGPRs (8 waves per SIMD: the step is a latency
   // chain) the 512-thread instantiation spilled 10 VGPRs to scratch -- 0.54 GB of FETCH_SIZE per T = 50 launch at
   // 128 x 1024, B = 4096 (profiles/r03a), and a scratch reload on the step's critical path
-  double* s_val = (double*)(((uintptr_t)(s_conn + (DYN ? sp.n_conn : 0)) + 7) & ~(uintptr_t)7);   // [nBuy]
+  // (an offset from `smem`, not pointer bits rounded up: through uintptr_t the pointer loses its LDS address space, s_val[] became FLAT loads,
+  //  and the s_waitcnt vmcnt(0) lgkmcnt(0) behind each -- one per observing buyer and step -- waited for the row's stores in flight: round 6)
+  const int val_off = ((int)((char*)(s_conn + (DYN ? sp.n_conn : 0)) - smem) + 7) & ~7;
+  double* s_val = (double*)(smem + val_off);                                                       // [nBuy]
   // (Measured and dropped, round 3: the row's four u8 planes staged in LDS and stored as 16-byte pieces after the step's last
   //  barrier instead of one byte store per lane and plane -- 12 fewer store instructions per lane and step, but one more
   //  dependent stage on a step that is a latency chain: 26.9 -> 29.0 us per step at 128 x 1024, B = 4096.)
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     const int a = tid + k * NT;
     rec[k] = 0; rw2[k] = 0; rt2[k] = 0xffffffffu;
     nbp[k][0] = nbp[k][1] = nbp[k][2] = nbp[k][3] = 0;
-    if (!dyn && sp.stk_packed) {
+    if (FAST || (!dyn && sp.stk_packed)) {
       // the host's packed per-agent tables (the fast step kernel's): three independent loads per slot instead of a chain of up to twelve
       // (record -> flags -> eight neighbour ranks) -- the block's setup was ~45 us of a launch's 180 us fixed cost at 4 096 envs
       if (a < A) {
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   // prices); jr < 0: no neighbour this episode
   auto cheapest = [&](int k, int kr, int deg, int& jr) __attribute__((always_inline)) {
     double best = 0.0; jr = -1;
-    if (!dyn && deg <= 8) {
+    if (FAST || (!dyn && deg <= 8)) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (j < deg) {
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       if (a < A && ((rec[k] >> lsh) & 1u)) {
         const int kr = (int)(rec[k] >> 16), deg = (int)((rec[k] >> 8) & 255u);
         const bool seller = (rec[k] & 1u) != 0;
-        if (io.actions) action = *(const float*)((const char*)(io.actions + row) + (size_t)((uint32_t)a * 4u));
+        if (FAST == 2 || (FAST == 0 && io.actions)) action = *(const float*)((const char*)(io.actions + row) + (size_t)((uint32_t)a * 4u));
         else {                                                               // the agent's word of this tick: rank j
           uint32_t word = rw2[k];
           if (rt2[k] != tick) {                                              // not kept from the agent's previous acting tick
@@ -750,8 +759,10 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
   if (STKR_SLOTS * nt < sp.A) return hipErrorInvalidConfiguration;
   const size_t lds = phx_stk_rollout_lds(sp);
   phx_note_kernel("phx_stk_rollout_kernel");
-#define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
-                                  else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); } while (0)
+#define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_, 0>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
+                                  else if (!sp.stk_packed) hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 0>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
+                                  else if (io.actions) hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 2>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
+                                  else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 1>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); } while (0)
   switch (nt) {
     case 128: PHX_LAUNCH_STKR(128); break;
     case 256: PHX_LAUNCH_STKR(256); break;
