@@ -81,4 +81,13 @@ if [ "$WHAT" = policy ] || [ "$WHAT" = all ]; then
   trace trace_policy $P
   grep "us/step" $OUT/trace_policy.log >> $OUT/summary.txt
 fi
+if [ "$WHAT" = stk ]; then      # config 5's kernel alone: what bounds a step (instruction issue / LDS / the stores)
+  K="python $R/tools/prof_configs.py c5"
+  trace trace_stk $K
+  grep "config 5" $OUT/trace_stk.log >> $OUT/summary.txt
+  pmc sq_stk SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- $K
+  pmc sq2_stk SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU -- $K
+  pmc w_stk WRITE_SIZE -- $K
+  pmc f_stk FETCH_SIZE -- $K
+fi
 cat $OUT/summary.txt

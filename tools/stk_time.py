@@ -1,49 +1,38 @@
 #!/usr/bin/env python
-"""Time the Stackelberg-market kernels (BASELINE config 5: 128 sellers x 1024 buyers, B = 4096): one launch per step and
-the fused rollout, with a checksum of the outputs so kernel variants (PHX_LIB_PATH) can be A/B-compared in one gpurun call.
-   python tools/stk_time.py [--batch 4096 --T 50 --tag name]"""
-import argparse, hashlib, os, sys
+"""Config 5 (Stackelberg 128 x 1024) fused rollouts: launch time against T and B -- the fixed cost of a launch (per-block setup, the last
+round's tail) against the marginal cost of a step.    python tools/stk_time.py [B,B,..] [T,T,..]"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
+import phantom_amd as ph
 from helpers import market_env
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--T", type=int, default=50)
-ap.add_argument("--tag", default=""); ap.add_argument("--which", default="both")
-a = ap.parse_args()
-B, S = a.batch, 1152
-env = market_env(128, 1024, 8, 100, B)
-d = env._device(); env.reset()
-g = torch.Generator(device="cuda"); g.manual_seed(3)
-acts = [torch.rand(B, S, device="cuda", generator=g) for _ in range(4)]
-valid = [torch.zeros(B, S, dtype=torch.uint8, device="cuda") for _ in range(2)]
-valid[0][:, :128] = 1; valid[1][:, 128:] = 1
-h = hashlib.sha1()
-if a.which in ("both", "step"):
-    for t in range(8):
-        st = d.step(acts[t % 4], action_valid=valid[t % 2])
-        for x in (st.observations, st.rewards, st.obs_valid, st.reward_valid): h.update(x.cpu().numpy().tobytes())
+
+def ev(fn, n):
+    for _ in range(2):
+        fn()
     torch.cuda.synchronize()
-    best = 1e9
-    for rep in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for t in range(40): d.step(acts[t % 4], action_valid=valid[t % 2])
-        e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 40 * 1e3)
-    print(f"{a.tag:24s} step    {best:8.2f} us/step   sha {h.hexdigest()[:12]}", flush=True)
-if a.which in ("both", "rollout"):
-    h = hashlib.sha1()
-    tr = d.rollout(a.T)
-    for x in (tr.observations, tr.actions, tr.rewards, tr.truncations, tr.obs_valid, tr.reward_valid): h.update(x.cpu().numpy().tobytes())
-    for _ in range(2): d.rollout(a.T, out=tr)
-    torch.cuda.synchronize()
-    best = 1e9
-    for rep in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4): d.rollout(a.T, out=tr)
-        e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / (4 * a.T) * 1e3)
-    print(f"{a.tag:24s} rollout {best:8.2f} us/step   sha {h.hexdigest()[:12]}", flush=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+BS = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1024, 2048, 4096, 8192)
+TS = tuple(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (2, 10, 25, 50, 100)
+for B in BS:
+    env = market_env(128, 1024, 8, 100, B, exogenous="device")
+    env.reset(); d = env._device()
+    prev = None
+    for T in TS:
+        tr = d.alloc_trajectory(T)
+        us = ev(lambda: d.rollout(T, out=tr), 4)
+        alg = 20 * 1152 * B * T
+        marg = "" if prev is None else f"  marginal {(us - prev[1]) / (T - prev[0]):7.2f} us/step = {20 * 1152 * B / ((us - prev[1]) / (T - prev[0])) / 1e3 / 8000:.3f}"
+        print(f"B={B:5d} T={T:4d} {us:9.1f} us/launch  {alg / us / 1e3 / 8000:.3f} of 8 TB/s{marg}   [{d.last_kernel()}]", flush=True)
+        prev = (T, us)
+        del tr
+    del env, d; torch.cuda.empty_cache()
