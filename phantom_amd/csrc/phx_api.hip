@@ -879,6 +879,8 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
 #undef UP
   d.max_cust = der.max_cust;
   d.fsm_lean_K = 0; d.fsm_lean_norm = 0;
+  d.sc_all_or_none = 1;
+  for (size_t i = 0; i < der.sc_shop_flags.size(); ++i) if ((der.sc_shop_flags[i] & 2) && !(der.sc_shop_flags[i] & 4)) d.sc_all_or_none = 0;
   std::vector<uint32_t> fsm_tab;             // position table of the time-parallel FSM rollout
   if (der.sc_static && spec->env_type == PHX_ENV_FSM && !der.any_typed && d.S > 0 && d.D == 3) {
     // lean FSM rollout loop: every shop with the same 1..6 customers and normaliser, a shop's customers act all or none per stage

@@ -160,6 +160,7 @@ struct DevSpec {
   const int32_t* sc_sw_exo_first;// [S] exogenous column of each shop's first customer, or NULL: the customers' columns are not consecutive (exo replays go to round 1's kernel)
   int32_t* sc_sw_guard;          // device word: the replay pre-scan stores the call's number here when an action rounds below zero
   int32_t fsm_lean_K, fsm_lean_norm;   // lean FSM rollout (phx_sc_fused.hip): every shop's customer count (0: not applicable) / normaliser
+  int32_t sc_all_or_none;              // every (acting list, shop): the shop's customers act all or none (sc_shop_flags: bit 2 implies bit 4)
   ScFastPlan fsm_fast;           // time-parallel FSM rollout (phx_sc_rollout_fsm.hip): block shape (ok == 0: not applicable)
   const uint32_t* fsm_pos_tab;   // [num_steps] flags / lookbacks / stage of every episode position (layout: phx_sc_rollout_fsm.hip)
   int32_t* fsm_irregular;        // device word the launch uses to send envs off the tabulated stage chain to the general loop

@@ -632,14 +632,25 @@ __global__ __launch_bounds__(NT, NT >= 1024 ? 8 : (NT >= 768 ? 6 : (NT == 384 ? 
 // the sum over the env's shops -- is accumulated by the env's lanes with LDS atomics into a double-buffered row (one workgroup barrier per
 // step: a block holds whole envs), the first rule of the stage that holds picks the next stage, and the agents acting in THAT stage are
 // the ones that observe (fsm.py:320).  Until round 6 such envs rolled out on the message-passing engine only.
-template <bool RULES>
+// STATIC (round 6): device-drawn actions and orders, no tabulated handler, no typed shop, every shop's customers acting all or none per
+// stage (phx_sc_fsm_static) -- the per-stage words (stage_next, stage_rew_all) are staged in LDS and the step loop holds NO global load.
+// The general form reads them -- and the replayed planes, the per-customer masks, the samplers' parameters -- from global memory behind
+// run-time conditions; the s_waitcnt vmcnt(0) behind each such load also waits for the previous step's row stores (loads and stores share
+// the counter on gfx950), a chain of up to eight L2 round trips per step whether or not the loads are executed.
+template <bool RULES, bool STATIC>
 __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec sp, const phx_rollout_io io,
                                                                   const int epb, const int remap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fl[];   // [n_lists][S]
   const int nS = sp.S, A = sp.A, nL = sp.n_lists;
   const int n_rules = RULES ? sp.n_rules : 0;
   int* const s_red = (int*)(s_fl + (((size_t)nL * nS + 15) & ~(size_t)15));   // RULES: [3][epb][n_rules] sums, rows rotate step by step
+  int* const s_nx = s_red + (RULES ? 3 * epb * n_rules : 0);                  // STATIC: [n_lists] stage_next | stage_rew_all << 16
+  // RULES: the rules themselves, [n_rules] DevRule (40 bytes each, 8-byte aligned): the loop that looks for the first rule that holds ends
+  // per lane, so its index is a VGPR to the compiler and sp.rules[r] a vector load from global memory
+  DevRule* const s_rules = (DevRule*)((char*)s_fl + (((int)((char*)(s_nx + (STATIC ? nL : 0)) - (char*)s_fl) + 7) & ~7));
+  if (RULES) for (int idx = threadIdx.x; idx < n_rules * (int)(sizeof(DevRule) / 4); idx += SC_NT) ((int*)s_rules)[idx] = ((const int*)sp.rules)[idx];
   if (RULES) for (int idx = threadIdx.x; idx < 3 * epb * n_rules; idx += SC_NT) s_red[idx] = 0;
+  if (STATIC) for (int idx = threadIdx.x; idx < nL; idx += SC_NT) s_nx[idx] = (sp.stage_next[idx] & 0xFFFF) | (sp.stage_rew_all[idx] ? 0x10000 : 0);
   for (int idx = threadIdx.x; idx < nL * nS; idx += SC_NT) {
     const int l = idx / nS, s = idx - l * nS, a_shop = sp.shop_agent[s];
     const uint8_t* cact = sp.shop_cust_act + (int64_t)l * sp.n_exo;
@@ -680,7 +691,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   uint8_t ocv = fld<uint8_t>(sp, F_ENV_OBS_CACHE_VALID)[g];
   float lo[4] = {0.f, 0.f, 0.f, 0.f};
   // typed shop: weight and 4th observation from the sampler column, redrawn at every auto-reset
-  const int tsrc = sp.any_typed ? sp.shop_type_src[s] : PHX_TYPE_NONE;
+  const int tsrc = (!STATIC && sp.any_typed) ? sp.shop_type_src[s] : PHX_TYPE_NONE;
   const bool typed = tsrc != PHX_TYPE_NONE;
   double tw = typed ? shop_type_value(sp, b, s) : 0.0;
   const double tnorm = typed ? sp.shop_type_prm[2 * s + 1] : 1.0;
@@ -692,26 +703,28 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
   for (int t = 0; t < io.T; ++t) {
     const int64_t o = (int64_t)t * total + g;
     int fl = s_fl[stage * nS + s];
-    int next_stage = sp.stage_next[stage];
-    if (sp.stage_tab) {                                        // a tabulated clock / stage handler's choice, fsm.py:294-302,320
+    const int nxw = STATIC ? s_nx[stage] : 0;
+    int next_stage = STATIC ? (nxw & 0xFFFF) : sp.stage_next[stage];
+    const bool rew_all = STATIC ? (nxw >> 16) != 0 : false;
+    if (!STATIC && sp.stage_tab) {                             // a tabulated clock / stage handler's choice, fsm.py:294-302,320
       next_stage = sp.stage_tab[(int64_t)stage * (sp.num_steps + 1) + (step + 1 <= sp.num_steps ? step + 1 : sp.num_steps)];
       fl = (fl & ~8) | ((sp.stage_rew_all[stage] || (s_fl[next_stage * nS + s] & 1)) ? 8 : 0);
     }
     const bool has_action = (fl & 1) != 0, any_order = (fl & 2) != 0;
     const uint8_t* cact = sp.shop_cust_act + (int64_t)stage * sp.n_exo;
     int D = 0; uint32_t aj = 0;
-    const bool need_orders = !io.exo && any_order;
-    if (need_orders || !io.actions) {                      // one Philox block per four ticks
+    const bool need_orders = (STATIC || !io.exo) && any_order;
+    if (STATIC || need_orders || !io.actions) {            // one Philox block per four ticks
       rng_quad_block(rc_rng, sp.seed, genv, tick, s);
       const int Dr = rng_orders_from_block(rc_rng.w, sp.seed, genv, tick, s, need_orders ? K : 0,
-                                           (fl & 4) ? nullptr : cact + c_lo, &aj);
+                                           (STATIC || (fl & 4)) ? nullptr : cact + c_lo, &aj);
       if (need_orders) D = Dr;
     }
-    if (io.exo) {
+    if (!STATIC && io.exo) {
       const uint8_t* row = io.exo + ((int64_t)t * sp.B + b) * sp.n_exo;
       if (any_order) for (int k = c_lo; k < c_hi; ++k) if (cact[k]) D += row[sp.shop_cust_exo[k]];
     }
-    const float action = io.actions ? io.actions[o] : rng_j_to_action(aj);
+    const float action = (!STATIC && io.actions) ? io.actions[o] : rng_j_to_action(aj);
     sc_shop_step(st, has_action, action, any_order, D);
     if (RULES) {
       // the rules' values on the RESOLVED state (what env_handler() reads, fsm.py:294-302): this step's row of sums, one LDS atomic per rule
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
       int* const row = s_red + (red_p * epb + el) * n_rules;
       int* const nxt = s_red + ((red_p == 2 ? 0 : red_p + 1) * epb + el) * n_rules;
       for (int r = 0; r < n_rules; ++r) {
-        const DevRule q = sp.rules[r];
+        const DevRule q = s_rules[r];
         if (active && s == 0) nxt[r] = 0;
         if (!active || q.stage != stage || (q.col >= 0 && q.col != s)) continue;
         const int x = q.field_id == F_SHOP_STOCK ? st.stock : q.field_id == F_SHOP_SALES ? st.sales : q.field_id == F_SHOP_MISSED ? st.missed : st.delivered;
@@ -729,7 +742,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
       __syncthreads();
       int chosen = -1;
       for (int r = 0; r < n_rules && chosen < 0; ++r) {
-        const DevRule q = sp.rules[r];
+        const DevRule q = s_rules[r];
         if (q.stage != stage) continue;
         const double v = (double)row[r];                        // (i32 fields: the sum is exact whatever the order)
         const bool hit = q.cmp == PHX_CMP_LT ? v < q.threshold : q.cmp == PHX_CMP_LE ? v <= q.threshold : q.cmp == PHX_CMP_GT ? v > q.threshold :
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
       red_p = red_p == 2 ? 0 : red_p + 1;
       if (chosen >= 0) {                                         // the handler chose: the agents acting in THAT stage observe (fsm.py:320)
         next_stage = chosen;
-        fl = (fl & ~8) | ((sp.stage_rew_all[stage] || (s_fl[next_stage * nS + s] & 1)) ? 8 : 0);
+        fl = (fl & ~8) | (((STATIC ? rew_all : sp.stage_rew_all[stage] != 0) || (s_fl[next_stage * nS + s] & 1)) ? 8 : 0);
       }
     }
     ++step; ++tick;
@@ -772,7 +785,7 @@ __global__ __launch_bounds__(SC_NT) void phx_sc_rollout_fsm_kernel(const DevSpec
     prev_stage = stage; stage = next_stage;                                  // fsm.py:355
     if (all_trunc) {                                                         // the caller's env.reset(), fsm.py:195-251
       st.stock = 0; step = 0; stage = sp.initial_stage; rcv = 0;
-      if (tsrc >= 0) {                                                       // env.py:211-212, agents.py:167-168
+      if (!STATIC && tsrc >= 0) {                                            // env.py:211-212, agents.py:167-168
         tw = rng_uniform(sp.seed, genv, episode, tsrc, sp.sampler_param + 4 * tsrc);
         tobs = (float)(tw / tnorm);
       }
@@ -1043,6 +1056,11 @@ bool phx_fsm_sw_serves(const DevSpec& sp, const phx_rollout_io& io, hipStream_t 
   return true;
 }
 
+// the STATIC instantiations of phx_sc_rollout_fsm_kernel serve the launch (see the kernel's header)
+static bool phx_sc_fsm_static(const DevSpec& sp, const phx_rollout_io& io) {
+  return !io.exo && !io.actions && !sp.stage_tab && !sp.any_typed && sp.n_samplers == 0 && sp.sc_all_or_none && sp.n_lists < 65536;
+}
+
 hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if_in, int32_t gen_in) {
   const int epb = SC_NT / sp.S;
   const int remap_env = phx_knobs().rollout_remap;
@@ -1093,8 +1111,12 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
     return hipGetLastError();
   }
   phx_note_kernel("phx_sc_rollout_fsm_kernel");
-  hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel<false>, dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
-                     (size_t)sp.n_lists * sp.S + 16, st, sp, io, epb, remap);
+  if (phx_sc_fsm_static(sp, io))
+    hipLaunchKernelGGL((phx_sc_rollout_fsm_kernel<false, true>), dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
+                       (((size_t)sp.n_lists * sp.S + 15) & ~(size_t)15) + (size_t)sp.n_lists * sizeof(int) + 16, st, sp, io, epb, remap);
+  else
+    hipLaunchKernelGGL((phx_sc_rollout_fsm_kernel<false, false>), dim3((sp.B + epb - 1) / epb), dim3(SC_NT),
+                       (((size_t)sp.n_lists * sp.S + 15) & ~(size_t)15) + 16, st, sp, io, epb, remap);
   return hipGetLastError();
 }
 
@@ -1102,9 +1124,13 @@ hipError_t phx_launch_sc_rollout_fsm(const DevSpec& sp, const phx_rollout_io& io
 hipError_t phx_launch_sc_rollout_fsm_rules(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   const int epb = SC_NT / sp.S;
   const int remap_env = phx_knobs().rollout_remap;
-  const size_t lds = (((size_t)sp.n_lists * sp.S + 15) & ~(size_t)15) + (size_t)3 * epb * sp.n_rules * sizeof(int) + 16;
+  const size_t lds = (((size_t)sp.n_lists * sp.S + 15) & ~(size_t)15) + (size_t)3 * epb * sp.n_rules * sizeof(int) + (size_t)sp.n_lists * sizeof(int) + 8 +
+                     (size_t)sp.n_rules * sizeof(DevRule) + 16;
   phx_note_kernel("phx_sc_rollout_fsm_kernel[rules]");
-  hipLaunchKernelGGL(phx_sc_rollout_fsm_kernel<true>, dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, remap_env >= 0 ? remap_env : 1);
+  if (phx_sc_fsm_static(sp, io))
+    hipLaunchKernelGGL((phx_sc_rollout_fsm_kernel<true, true>), dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, remap_env >= 0 ? remap_env : 1);
+  else
+    hipLaunchKernelGGL((phx_sc_rollout_fsm_kernel<true, false>), dim3((sp.B + epb - 1) / epb), dim3(SC_NT), lds, st, sp, io, epb, remap_env >= 0 ? remap_env : 1);
   return hipGetLastError();
 }
 
