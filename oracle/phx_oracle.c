@@ -32,6 +32,21 @@ int phxo_max_threads(void) {
 #endif
 }
 
+/* The device's division by a loop-invariant divisor (phx_dev.h: div_by_recip -- the policy kernel's observations): with r = 1 / n rounded once,
+   q0 = x * r, e = fmaf(-n, q0, x), q = fmaf(e, r, q0) IS the IEEE quotient x / n (Markstein's correction step) on the domain the kernel applies
+   it to.  Counts the pairs 0 <= x < x_end, 1 <= n <= n_max where it is not (tests/test_host_logic.py: exhaustively, expected 0). */
+int64_t phxo_check_recip_div(int n_max, int x_end) {
+  int64_t bad = 0;
+  for (int n = 1; n <= n_max; ++n) {
+    const float fn = (float)n, r = 1.0f / fn;
+    for (int x = 0; x < x_end; ++x) {
+      const float fx = (float)x, q0 = fx * r, e = fmaf(-fn, q0, fx), q = fmaf(e, r, q0), ref = fx / fn;
+      bad += memcmp(&q, &ref, 4) != 0;
+    }
+  }
+  return bad;
+}
+
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
   int src, dst, type;

@@ -431,8 +431,9 @@ __device__ __forceinline__ bool rng_split(uint32_t u, uint32_t& y, uint32_t& j) 
   return l >= PHX_RNG_REJ;
 }
 __device__ __forceinline__ uint32_t rng_pick(const uint32_t w[4], uint32_t tick) {
-  const uint32_t k = tick & 3u;
-  return k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+  // two levels of selects on the tick's low bits (written as a chain of comparisons the compiler built exec-masked branches around the moves)
+  const uint32_t lo = (tick & 1u) ? w[1] : w[0], hi = (tick & 1u) ? w[3] : w[2];
+  return (tick & 2u) ? hi : lo;
 }
 // (y, j) of customer group g, starting at `attempt0` (the cold / generic path: one Philox call per try)
 __device__ __forceinline__ uint32_t rng_group_y(uint64_t seed, int64_t genv, uint32_t tick, int shop, int g,
@@ -585,6 +586,17 @@ __device__ __forceinline__ void shop_obs_f32(int stock, int sales, int missed, f
   o[0] = (float)stock / (float)PHX_SHOP_MAX_STOCK;
   o[1] = (float)sales / norm;
   o[2] = (float)missed / norm;
+}
+
+// x / n for a divisor that does not change over a loop: r = 1.0f / n once (an IEEE division, correctly rounded), then per quotient
+// q0 = x r, e = fmaf(-n, q0, x) (exact), q = fmaf(e, r, q0) -- Markstein's correction: three instructions instead of the ~11 of v_div_scale /
+// v_rcp / refinement / v_div_fmas / v_div_fixup, and the IEEE quotient bit for bit for every integer 0 <= x < 32768, 1 <= n <= 4096
+// (DIV_RECIP_X / DIV_RECIP_N: checked exhaustively with the host's fmaf, oracle phxo_check_recip_div, tests/test_host_logic.py).
+#define DIV_RECIP_X 32768
+#define DIV_RECIP_N 4096
+__device__ __forceinline__ float div_by_recip(float x, float n, float r) {
+  const float q0 = x * r;
+  return __fmaf_rn(__fmaf_rn(-n, q0, x), r, q0);
 }
 
 // ---- numpy scalar promotion of the ads market's floats (NEP 50; see the oracle's restatement) ----

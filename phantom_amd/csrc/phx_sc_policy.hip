@@ -96,8 +96,15 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
   const int c0 = a.shop_cust_ptr[s], K = a.shop_cust_ptr[s + 1] - c0;
   const int64_t genv = a.env_offset + b;
   const float out_scale = a.pol.out_scale, out_bias = a.pol.out_bias, out_lo = a.pol.out_lo, out_hi = a.pol.out_hi;
+  // the divisors never change: their reciprocals once (IEEE divisions), a quotient = a multiply and Markstein's correction (phx_dev.h: div_by_recip)
+  const float r_stock = 1.0f / (float)PHX_SHOP_MAX_STOCK, r_norm = 1.0f / norm_f;
+  const bool norm_small = norm_i >= 1 && norm_i <= DIV_RECIP_N;
   auto encode = [&](int st, int sl, int ms, float* o) {                // ShopAgent.encode_observation, supply_chain.py:124-134
-    if ((((unsigned)st + (1u << 24)) | ((unsigned)sl + (1u << 24)) | ((unsigned)ms + (1u << 24)) | ((unsigned)norm_i + (1u << 24))) < (2u << 24))
+    if (__builtin_expect(norm_small && (unsigned)(st | sl | ms) < (unsigned)DIV_RECIP_X, 1)) {
+      o[0] = div_by_recip((float)st, (float)PHX_SHOP_MAX_STOCK, r_stock);
+      o[1] = div_by_recip((float)sl, norm_f, r_norm);
+      o[2] = div_by_recip((float)ms, norm_f, r_norm);
+    } else if ((((unsigned)st + (1u << 24)) | ((unsigned)sl + (1u << 24)) | ((unsigned)ms + (1u << 24)) | ((unsigned)norm_i + (1u << 24))) < (2u << 24))
       shop_obs_f32(st, sl, ms, norm_f, o);
     else shop_obs(st, sl, ms, norm_i, o);
   };

@@ -40,6 +40,8 @@ def lib():
         L.phxo_last_error.restype = C.c_char_p
         L.phxo_set_threads.argtypes = [C.c_int]
         L.phxo_max_threads.restype = C.c_int
+        L.phxo_check_recip_div.restype = C.c_int64
+        L.phxo_check_recip_div.argtypes = [C.c_int, C.c_int]
         for n in ("phxo_obs_dim", "phxo_n_strategic", "phxo_n_exo"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [vp]

@@ -245,6 +245,13 @@ def test_f32_division_equals_reference_f64_quotient_cast():
     assert (q64.view(np.uint32) == q32.view(np.uint32)).all()
 
 
+def test_division_by_a_kept_reciprocal_is_the_ieee_quotient():
+    """phx_dev.h div_by_recip (the policy kernel's observations): q0 = x r, q = fmaf(fmaf(-n, q0, x), r, q0) with r = 1 / n rounded once is
+    x / n bit for bit on the whole domain the kernel applies it to (0 <= x < 32768, 1 <= n <= 4096) -- exhaustively, with the host's fmaf."""
+    import oracle
+    assert oracle.lib().phxo_check_recip_div(4096, 32768) == 0
+
+
 def test_numpy_stream_vector_draw_equals_scalar_draws():
     """PhantomEnv._draw_exo draws one vector per env; the reference's customers draw scalars."""
     np.random.seed(123)

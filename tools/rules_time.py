@@ -19,14 +19,16 @@ def ev(fn, n):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-def restock(env_):
-    env_.resolve_network()
-    tot = sum(np.asarray(a_.stock) for aid, a_ in env_.agents.items() if str(aid).startswith("SHOP"))
-    return np.where(tot < 300, "RESTOCK", "SELL").tolist()
+def restock_below(thr):
+    def restock(env_):
+        env_.resolve_network()
+        tot = sum(np.asarray(a_.stock) for aid, a_ in env_.agents.items() if str(aid).startswith("SHOP"))
+        return np.where(tot < thr, "RESTOCK", "SELL").tolist()
+    return restock
 
 
 for S, K, B, thr in ((9, 6, 4096, 300), (9, 6, 65536, 300), (51, 4, 8192, 1700)):
-    handler = ph.state_rules([ph.StageRule("shop.stock", "<", thr, "RESTOCK")])(restock)
+    handler = ph.state_rules([ph.StageRule("shop.stock", "<", thr, "RESTOCK")])(restock_below(thr))
     env = ph.SupplyChainFSMEnv(n_shops=S, customers_per_shop=K, num_steps=100, batch_size=B, seed=42, exogenous="device", restock_handler=handler)
     env.reset(); d = env._device()
     for T in (50, 100):
