@@ -119,6 +119,9 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
   const float* const o1 = s_img + 4 * W0p;
   __syncthreads();
 
+  float* p_obs = a.io.obs + pair * 3; float* p_act = a.io.action_out + pair; float* p_rew = a.io.reward + pair;
+  const bool has_ter = a.io.terminated != nullptr;                     // (uniform: a scalar branch)
+  uint8_t* p_ter = a.io.terminated + pair; uint8_t* p_tru = a.io.truncated + pair;
   for (int t = 0; t < a.T; ++t) {
     // ---- compute_action: the MLP on the previous observation (phx_policy_mlp, include/phantom_amd.h) --------------------------------
     // two units per packed fused multiply-add (each element is the fmaf of the definition)
@@ -197,14 +200,13 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
     float ob[3];
     encode(stock, sales, missed, ob);
     const float rw = (float)shop_reward(sales, stock);                 // compute_reward :147, rounded once to f32
-    if (on) {                                                          // the trajectory row, rollout.py:361-389
-      const int64_t o = (int64_t)t * total + pair;
-      float* po = a.io.obs + o * 3;
-      po[0] = ob[0]; po[1] = ob[1]; po[2] = ob[2];
-      a.io.action_out[o] = action;
-      a.io.reward[o] = rw;
-      if (a.io.terminated) a.io.terminated[o] = 0;
-      a.io.truncated[o] = trunc ? 1 : 0;
+    if (on) {                                                          // the trajectory row, rollout.py:361-389 (running pointers: one 64-bit add per plane and step)
+      p_obs[0] = ob[0]; p_obs[1] = ob[1]; p_obs[2] = ob[2];
+      *p_act = action;
+      *p_rew = rw;
+      if (has_ter) { *p_ter = 0; p_ter += total; }
+      *p_tru = trunc ? 1 : 0;
+      p_obs += total * 3; p_act += total; p_rew += total; p_tru += total;
     }
     ++tick;
     if (trunc) {                                                       // the caller's env.reset(): ShopAgent.reset zeroes the stock (:149-150); sales stay (App. B)
