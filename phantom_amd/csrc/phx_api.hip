@@ -26,7 +26,7 @@ hipError_t phx_launch_sc_rollout_policy(const DevSpec& sp, const phx_rollout_io&
 bool phx_sched_compile(const phx_spec* spec, int A, int n_lists, const int32_t* act_ptr, const int32_t* act_idx, const uint8_t* act_mask,
                        const uint8_t* obs_mask, const uint8_t* rew_mask, const int32_t* kind_rank, const int32_t* exo_rank, const int32_t* strat_rank,
                        const int32_t* reset_obs_idx, int n_reset_obs, std::vector<int32_t>* blob, std::vector<int32_t>* recs, int* L_out, int* qmax_out);
-size_t phx_sched_lds_bytes(int words, int L, int qstride);
+size_t phx_sched_lds_bytes(int words, int L, int qstride, int n_rules, int n_lists);
 hipError_t phx_launch_reset(const DevSpec& sp, const uint8_t* mask, const double* sampler_values, const uint8_t* conn_values, float* obs, uint8_t* obs_valid, hipStream_t st);
 hipError_t phx_launch_sc_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st);
 hipError_t phx_launch_sc_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st, const int32_t* only_if = nullptr, int32_t gen = 0);
@@ -820,7 +820,7 @@ int phx_create(const phx_spec* spec, int device, void* state_blob, int64_t state
                                  &gblob, &grecs, &gL, &gq)) {
       int qstride = gq + 1;
       while ((qstride & 31) != 9) ++qstride;                    // (the env instances of a wave start their queues 9 banks apart)
-      if (phx_sched_lds_bytes((int)gblob.size(), gL, qstride) <= 48 * 1024 &&
+      if (der.n_lists < 65536 && phx_sched_lds_bytes((int)gblob.size(), gL, qstride, d.n_rules, der.n_lists) <= 48 * 1024 &&
           phx_generic_queue_bytes(der.A, der.S, spec->queue_cap, der.scan_cap, 0, false) <= 48 * 1024) {      // (the tail workgroups run the dynamic engine in LDS)
         UP(gs_blob, gblob.data(), gblob.size());
         if (grecs.empty()) grecs.assign(2, 0);

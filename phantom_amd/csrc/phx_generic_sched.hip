@@ -43,7 +43,11 @@ __device__ __forceinline__ void gs_wave_sync() {
 // the customers' draws of one tick: group g's word (retry stream on a rejected word), dev_dev.h: rng_group_y
 struct GsQuad { uint32_t w[4]; uint32_t q; };     // group 0's attempt-0 block of the shop's current tick quad (rollouts: 4 ticks per block)
 
-template <int L, bool ROLL>
+// PURE (round 6, the T-step loop only): device-drawn actions and orders, no message log, no host-chosen or tabulated stage -- nothing in
+// the loop reads global memory (the schedule, the queues and the rules are in LDS, per-stage words come through the scalar cache).  The
+// general form's loads sit behind run-time conditions, but the s_waitcnt vmcnt(0) the compiler puts behind each at the joins is executed by
+// every step, and loads and stores share that counter on gfx950: every step waited for the previous row's stores to be acknowledged.
+template <int L, bool ROLL, bool PURE>
 __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __restrict__ spp_, const GenArgs g_) {
   phx_kptr_t spc = (phx_kptr_t)spp_;
   phx_kptr_t kp = (phx_kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -129,6 +133,12 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
   }
   int32_t* const q_env = tab + ((words + 3) & ~3) + slot * (2 * sp.gs_qstride);          // the env's two queues: payloads by queue position
   const int qstride = sp.gs_qstride;
+  // the device-evaluated stage rules, [n_rules] DevRule behind the queues: the scan below ends per lane (envs of a wave may differ), so its
+  // index is a VGPR to the compiler and sp.rules[rr] would be a vector load from global memory
+  DevRule* const s_rules = (DevRule*)(smem + (((((words + 3) & ~3) + EPB * 2 * qstride) * 4 + 7) & ~7));
+  for (int k = tid; k < sp.n_rules * (int)(sizeof(DevRule) / 4); k += 256) ((int32_t*)s_rules)[k] = ((const int32_t*)sp.rules)[k];
+  int32_t* const s_nx = (int32_t*)(s_rules + sp.n_rules);        // FSM: [n_lists] stage_next | stage_rew_all << 16 (fsm.py:281-307,320)
+  if (sp.env_type == PHX_ENV_FSM) for (int k = tid; k < sp.n_lists; k += 256) s_nx[k] = (sp.stage_next[k] & 0xFFFF) | (sp.stage_rew_all[k] ? 0x10000 : 0);
   __syncthreads();
   GS_REFRESH();
 
@@ -165,8 +175,8 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
     const uint32_t tick = (uint32_t)w_tick;
     const int t = w_step + 1;                                    // env.py:252
     const int cur_stage = w_stage;
-    const uint8_t* exo_b = g.io.exo ? g.io.exo + step_env * sp.n_exo : nullptr;
-    phx_msg_rec* log_b = g.io.msg_log ? g.io.msg_log + step_env * trace_cap : nullptr;
+    const uint8_t* exo_b = (!PURE && g.io.exo) ? g.io.exo + step_env * sp.n_exo : nullptr;
+    phx_msg_rec* log_b = (!PURE && g.io.msg_log) ? g.io.msg_log + step_env * trace_cap : nullptr;
 
     // ---- the policy of a rollout (rollout.py:300-363): every strategic agent's action of the tick -- replayed, or the random policy
     //      = the shop's word of the tick (group 0's block, which also holds its first six customers' order sizes) ----------------
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
     uint32_t y0 = 0u; bool have_y0 = false;
     if (ROLL) {
       has_action = true;
-      if (g.roll_actions_in) action = g.roll_actions_in[((int64_t)(g.roll_t + it) * B + b) * S + jj];
+      if (!PURE && g.roll_actions_in) action = g.roll_actions_in[((int64_t)(g.roll_t + it) * B + b) * S + jj];
       else {
         if ((tick >> 2) != quad.q) { rng_block(seed, genv, tick, jj, 0, 0, quad.w); quad.q = tick >> 2; }
         uint32_t jr;
@@ -301,9 +311,9 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
       int next_in = -1, nstage = 0;
       if (fsm) {
         bool by_rule = false;
-        if (sp.n_rules > 0 && !g.io.next_stage) {
+        if (sp.n_rules > 0 && (PURE || !g.io.next_stage)) {
           for (int rr = 0; rr < sp.n_rules && !by_rule; ++rr) {
-            const DevRule q = sp.rules[rr];
+            const DevRule q = s_rules[rr];
             if (q.stage != list) continue;
             // (every rule field of a supply-chain spec is a ShopAgent attribute: i32, held in this lane's registers)
             int x = q.field_id == F_SHOP_STOCK ? stock : q.field_id == F_SHOP_SALES ? sales : q.field_id == F_SHOP_MISSED ? missed : delivered;
@@ -323,14 +333,14 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
           }
           by_rule = next_in >= 0;
         }
-        if (!by_rule && (g.io.next_stage || sp.stage_tab)) {
+        if (!PURE && !by_rule && (g.io.next_stage || sp.stage_tab)) {
           next_in = g.io.next_stage ? g.io.next_stage[b] : sp.stage_tab[(int64_t)list * (num_steps + 1) + (t <= num_steps ? t : num_steps)];
           if (next_in < 0 || next_in >= n_lists || !sp.stage_allowed[(int64_t)list * n_lists + next_in]) {
             if (m) err_code = PHX_ERR_FSM_TRANSITION;            // FSMRuntimeError, after the resolution (fsm.py:304-307)
             next_in = -1;
           }
         }
-        nstage = next_in >= 0 ? next_in : sp.stage_next[list];
+        nstage = next_in >= 0 ? next_in : (s_nx[list] & 0xFFFF);
       }
 
       // ---- encode_observation / compute_reward / is_done of the strategic agents (env.py:273-301; fsm.py:309-380) -----------------
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
         if (shop) {
           // who observes: the list's mask, or after a handler-chosen transition the agents acting in the NEXT stage (fsm.py:320)
           int obs_bit = sf & 1;
-          if (fsm && next_in >= 0 && !sp.stage_rew_all[list]) obs_bit = ((tab + list_off[nstage])[(tab + list_off[nstage])[12] + jj] >> 2) & 1;
+          if (fsm && next_in >= 0 && !(s_nx[list] >> 16)) obs_bit = ((tab + list_off[nstage])[(tab + list_off[nstage])[12] + jj] >> 2) & 1;
           ov = obs_bit; rv = 0; rw = 0.0; ob[0] = ob[1] = ob[2] = 0.f;
           if (ov) {
             if ((((unsigned)stock + (1u << 24)) | ((unsigned)sales + (1u << 24)) | ((unsigned)missed + (1u << 24)) | ((unsigned)norm_i + (1u << 24))) < (2u << 24))
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void phx_sched_step_kernel(const DevSpec* __re
         if (g.roll.obs_valid) g.roll.obs_valid[o] = (uint8_t)ov;
         if (g.roll.reward_valid) g.roll.reward_valid[o] = (uint8_t)rv;
       }
-      if (on && j == 0 && g.io.err && err_code && g.io.err[b] == 0) g.io.err[b] = err_code;
+      if (!PURE && on && j == 0 && g.io.err && err_code && g.io.err[b] == 0) g.io.err[b] = err_code;
       cur_ob[0] = ob[0]; cur_ob[1] = ob[1]; cur_ob[2] = ob[2];
     }
     const int prev_stage = cur_stage;
@@ -593,18 +603,23 @@ bool phx_sched_compile(const phx_spec* spec, int A, int n_lists, const int32_t* 
   return true;
 }
 
-size_t phx_sched_lds_bytes(int words, int L, int qstride) { return (size_t)((words + 3) & ~3) * 4 + (size_t)(256 / L) * 2 * (size_t)qstride * 4; }
+// (tables + the workgroup's queues + the LDS copies of the rules and of the per-stage words)
+size_t phx_sched_lds_bytes(int words, int L, int qstride, int n_rules, int n_lists) {
+  return (size_t)((words + 3) & ~3) * 4 + (size_t)(256 / L) * 2 * (size_t)qstride * 4 + 8 + (size_t)n_rules * sizeof(DevRule) + (size_t)n_lists * 4;
+}
 
 hipError_t phx_launch_sched(const DevSpec& sp, const GenArgs& g, hipStream_t st) {
   const int L = sp.gs_L, EPB = 256 / L;
   const dim3 grid((unsigned)((sp.B + EPB - 1) / EPB + (sp.B + 255) / 256));      // schedule workgroups + tail
   // LDS: the schedule's tables and queues, or what the dynamic engine needs for one env (the tail workgroups), whichever is larger
-  const size_t lds = std::max(phx_sched_lds_bytes(sp.gs_words, L, sp.gs_qstride),
+  const size_t lds = std::max(phx_sched_lds_bytes(sp.gs_words, L, sp.gs_qstride, sp.n_rules, sp.n_lists),
                               (phx_generic_queue_bytes(sp.A, sp.S, sp.queue_cap, sp.scan_cap, 0, false) + 15) & ~(size_t)15);
   const bool roll = g.roll_t >= 0;
   phx_note_kernel(roll ? "phx_sched_step_kernel[T-step loop]" : "phx_sched_step_kernel");
-#define GS_LAUNCH(L_) do { if (roll) hipLaunchKernelGGL((phx_sched_step_kernel<L_, true>), grid, dim3(256), lds, st, sp.self_dev, g); \
-                           else hipLaunchKernelGGL((phx_sched_step_kernel<L_, false>), grid, dim3(256), lds, st, sp.self_dev, g); } while (0)
+  const bool pure = roll && !g.roll_actions_in && !g.io.exo && !g.io.msg_log && !g.io.next_stage && !sp.stage_tab;
+#define GS_LAUNCH(L_) do { if (pure) hipLaunchKernelGGL((phx_sched_step_kernel<L_, true, true>), grid, dim3(256), lds, st, sp.self_dev, g); \
+                           else if (roll) hipLaunchKernelGGL((phx_sched_step_kernel<L_, true, false>), grid, dim3(256), lds, st, sp.self_dev, g); \
+                           else hipLaunchKernelGGL((phx_sched_step_kernel<L_, false, false>), grid, dim3(256), lds, st, sp.self_dev, g); } while (0)
   if (L == 8) GS_LAUNCH(8); else if (L == 16) GS_LAUNCH(16); else if (L == 32) GS_LAUNCH(32); else GS_LAUNCH(64);
 #undef GS_LAUNCH
   return hipGetLastError();
