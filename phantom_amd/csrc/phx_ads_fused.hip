@@ -66,9 +66,14 @@ __device__ __forceinline__ int ads_count(bool flag, int* red_i) {
   return n;
 }
 
-template <int NT, bool ROLLOUT>
+// REPLAY (rollouts): recorded actions and / or draws come from HBM (phx_rollout_io.actions / exo).  The device-drawn instantiation has NO
+// global load on a step's common path -- the acting lists' masks are four bits in a register, the publisher's click probabilities sit in LDS,
+// the two stages alternate by the static schedule's premise (phx_api.hip) -- because on gfx950 a load behind the row's stores waits for them
+// (s_waitcnt vmcnt counts both), and a load behind a condition that is never true still leaves its wait at the join.
+template <int NT, bool ROLLOUT, bool REPLAY>
 __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const AdsArgs args) {
   __shared__ double red_v[NT / 64];
+  __shared__ double s_pp[8];                                   // PublisherAgent's click probabilities [user - 1][theme], digital_ads_market.py:167-196
   __shared__ int red_i[2 * (NT / 64)];
   __shared__ int s_win[4];                                     // winner's aux, cost tag; second's r
   __shared__ double s_cost;
@@ -127,6 +132,10 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     budget = tsrc >= 0 ? fld<double>(sp, F_ENV_SAMPLER)[(int64_t)b * sp.n_samplers + tsrc] : sp.param_f[a * PHX_NPF];
   }
   const int btag = strong ? PHX_TAG_F64 : PHX_TAG_PYF;
+  // who observes / is rewarded after a step of list 0 / 1 (fsm.py:328-335): bits 0-1 / 2-3
+  const int mbits = mine ? ((sp.obs_mask[a] ? 1 : 0) | (sp.obs_mask[(int64_t)sp.A + a] ? 2 : 0) | (sp.rew_mask[a] ? 4 : 0) | (sp.rew_mask[(int64_t)sp.A + a] ? 8 : 0)) : 0;
+  if (r < 8) s_pp[r] = sp.param_f[pub * PHX_NPF + r];
+  __syncthreads();
   const int T = ROLLOUT ? args.rio.T : 1;
   RngQuadCache rq; rq.q = 0xffffffffu;
   const int64_t total = (int64_t)sp.B * N;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     float action = 0.f; bool has = false;
     if (mine) {
       if (ROLLOUT) {
-        if (args.rio.actions) action = args.rio.actions[(int64_t)t * total + g];
+        if (REPLAY && args.rio.actions) action = args.rio.actions[(int64_t)t * total + g];
         else {                                                 // one Philox block serves four ticks of the agent
           uint32_t j; rng_quad_block(rq, sp.seed, genv, tick, r);
           rng_orders_from_block(rq.w, sp.seed, genv, tick, r, 0, nullptr, &j);
@@ -150,7 +159,8 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
         if (has) action = args.sio.actions[g];
       }
     }
-    const uint8_t* exo_b = ROLLOUT ? (args.rio.exo ? args.rio.exo + ((int64_t)t * sp.B + b) * sp.n_exo : nullptr)
+    const uint8_t* exo_b = !REPLAY ? nullptr
+                         : ROLLOUT ? (args.rio.exo ? args.rio.exo + ((int64_t)t * sp.B + b) * sp.n_exo : nullptr)
                                    : (args.sio.exo ? args.sio.exo + (int64_t)b * sp.n_exo : nullptr);
     ++step;                                                    // env.py:252
     if (stage == sp.ads_pub_stage) {
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
           ads_seen = 1;
           if (exo_b && ppi[1] < 1) { if (!err) err = PHX_ERR_QUEUE_FULL; }
           else {
-            const double p = sp.param_f[pub * PHX_NPF + (wuser - 1) * 4 + wth];
+            const double p = s_pp[(wuser - 1) * 4 + wth];
             clicked = exo_b ? exo_b[pub_x + 1] : rng_publisher(sp.seed, genv, tick, pub, 1, p);
             answered = true;
           }
@@ -210,20 +220,20 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
       }
     }
     // ---- FiniteStateMachineEnv epilogue fsm.py:309-380 ---------------------------------------------------
-    const int next_stage = sp.stage_next[stage];
+    const int next_stage = stage == 0 ? 1 : 0;                 // the static schedule's premise: stage_next = {1, 0} (phx_api.hip)
     uint8_t ov = 0, rv = 0, dv = 0, tm = 0;
     double rw = 0.0;
     float ob[3] = {0.f, 0.f, 0.f};
     if (live) {
       dv = 1;
-      if (sp.obs_mask[(int64_t)list * sp.A + a] && user != 0) {                           // :328-331, None when user 0
+      if (((mbits >> (list & 1)) & 1) && user != 0) {                           // :328-331, None when user 0
         ov = 1;
         ob[0] = (float)budget;
         ob[1] = (float)t_div(tv(left, left_tag), tv(budget, btag)).v;
         ob[2] = (float)(user - 1);
         oc[0] = ob[0]; oc[1] = ob[1]; oc[2] = ob[2]; ocv = 1;                             // self._observations.update :349
       }
-      if (sp.rew_mask[(int64_t)list * sp.A + a]) { rc = (double)clicks; rcv = 1; }         // :334-335, :335-343
+      if ((mbits >> (2 + (list & 1))) & 1) { rc = (double)clicks; rcv = 1; }         // :334-335, :335-343
       tm = left <= 0.0 ? 1 : 0;                                                           // :345-349
       if (tm) term = 1;
     }
@@ -307,11 +317,11 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-template <bool ROLLOUT>
+template <bool ROLLOUT, bool REPLAY>
 static hipError_t ads_launch(const DevSpec& sp, const AdsArgs& a, hipStream_t st) {
   const int n = sp.S;
   phx_note_kernel(ROLLOUT ? "phx_ads_kernel[rollout]" : "phx_ads_kernel[step]");
-#define PHX_ADS(NT_) hipLaunchKernelGGL((phx_ads_kernel<NT_, ROLLOUT>), dim3(sp.B), dim3(NT_), 0, st, sp, a)
+#define PHX_ADS(NT_) hipLaunchKernelGGL((phx_ads_kernel<NT_, ROLLOUT, REPLAY>), dim3(sp.B), dim3(NT_), 0, st, sp, a)
   if (n <= 64) PHX_ADS(64); else if (n <= 128) PHX_ADS(128); else if (n <= 256) PHX_ADS(256);
   else if (n <= 512) PHX_ADS(512); else PHX_ADS(1024);
 #undef PHX_ADS
@@ -319,9 +329,9 @@ static hipError_t ads_launch(const DevSpec& sp, const AdsArgs& a, hipStream_t st
 }
 hipError_t phx_launch_ads_step(const DevSpec& sp, const phx_step_io& io, hipStream_t st) {
   AdsArgs a; memset(&a, 0, sizeof a); a.sio = io;
-  return ads_launch<false>(sp, a, st);
+  return ads_launch<false, true>(sp, a, st);
 }
 hipError_t phx_launch_ads_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
   AdsArgs a; memset(&a, 0, sizeof a); a.rio = io;
-  return ads_launch<true>(sp, a, st);
+  return (io.actions || io.exo) ? ads_launch<true, true>(sp, a, st) : ads_launch<true, false>(sp, a, st);
 }

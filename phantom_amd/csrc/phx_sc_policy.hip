@@ -58,7 +58,11 @@ __host__ __device__ inline int pol_img_floats(int n_hidden, int W0p, int W1p) {
 // per lane, [unit][lane]: bank-conflict free -- a register array cannot be indexed by a run-time width)
 // EXO: the order sizes are replayed from io.exo (global loads inside the step loop); the device-drawn instantiation has NO load in its loop, so
 // that no s_waitcnt vmcnt ever waits for the previous step's trajectory stores (loads and stores share the counter on gfx950)
-template <int ACT, bool TWO, int NT, bool EXO>
+// SW (two hidden layers whose widths are multiples of 8 and 4): the second layer's weights as SGPR operands -- four rows x eight k per trip
+// through the scalar cache (s_load_dwordx8 from torch's own [W1][W0] layout), 32 fused multiply-adds on four independent chains; LDS then
+// carries the first layer's activations only (one 4-byte read per lane and k, shared by the four rows).  The LDS form reads every weight as
+// a broadcast: 64 lanes x 4 bytes of LDS return bandwidth per multiply-add -- the layer was LDS-bound (32 us per step for 3-64-64-1).
+template <int ACT, bool TWO, int NT, bool EXO, bool SW>
 __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_img[];
   const int tid = threadIdx.x, S = a.S;
@@ -154,6 +158,28 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
       }
       const float* const ob1 = o1 + W1p * W0p; const float* const ow2 = ob1 + W1p;
       y = ow2[W1p];
+      if (SW) {
+        typedef const __attribute__((address_space(4))) float* pol_cfp;
+        const pol_cfp w1 = (pol_cfp)(uintptr_t)a.pol.w[1];
+        for (int j0 = 0; j0 < W1; j0 += 4) {                           // four units: four independent chains over k, ascending k each
+          const float4 bj = *(const float4*)(ob1 + j0);
+          float c0 = bj.x, c1 = bj.y, c2 = bj.z, c3 = bj.w;
+          const pol_cfp r0 = w1 + j0 * W0, r1 = r0 + W0, r2 = r1 + W0, r3 = r2 + W0;
+          for (int k0 = 0; k0 < W0; k0 += 8) {
+            float h[8], wa[8], wb[8], wc[8], wd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { wa[u] = r0[k0 + u]; wb[u] = r1[k0 + u]; wc[u] = r2[k0 + u]; wd[u] = r3[k0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = hcol[(k0 + u) * NT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              c0 = __fmaf_rn(wa[u], h[u], c0); c1 = __fmaf_rn(wb[u], h[u], c1); c2 = __fmaf_rn(wc[u], h[u], c2); c3 = __fmaf_rn(wd[u], h[u], c3);
+            }
+          }
+          const float4 wo = *(const float4*)(ow2 + j0);
+          y = __fmaf_rn(wo.x, pol_act<ACT>(c0), y); y = __fmaf_rn(wo.y, pol_act<ACT>(c1), y); y = __fmaf_rn(wo.z, pol_act<ACT>(c2), y); y = __fmaf_rn(wo.w, pol_act<ACT>(c3), y);
+        }
+      } else
       for (int j0 = 0; j0 < W1p; j0 += 8) {                            // eight units of the second layer: eight independent chains over k
         float c[8];
         { const float4 ba = *(const float4*)(ob1 + j0), bb = *(const float4*)(ob1 + j0 + 4);
@@ -249,8 +275,12 @@ hipError_t phx_launch_sc_rollout_policy(const DevSpec& sp, const phx_rollout_io&
   const int n_img = pol_img_floats(a.pol.n_hidden, W0p, W1p);
   const size_t lds = (size_t)n_img * 4 + (two ? (size_t)W0p * NT * sizeof(float) : 0);      // <= 18.7 + 32 KB
   phx_note_kernel("phx_sc_rollout_policy_kernel");
-#define POL_LAUNCH(ACT_, TWO_, NT_) do { if (io.exo) hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, true>), grid, dim3(NT_), lds, st, a); \
-    else hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, false>), grid, dim3(NT_), lds, st, a); } while (0)
+  const bool sw = two && (a.pol.width[0] & 7) == 0 && (a.pol.width[1] & 3) == 0;
+#define POL_LAUNCH(ACT_, TWO_, NT_) do { \
+    if (TWO_ && sw) { if (io.exo) hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, true, TWO_>), grid, dim3(NT_), lds, st, a); \
+                      else hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, false, TWO_>), grid, dim3(NT_), lds, st, a); } \
+    else if (io.exo) hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, true, false>), grid, dim3(NT_), lds, st, a); \
+    else hipLaunchKernelGGL((phx_sc_rollout_policy_kernel<ACT_, TWO_, NT_, false, false>), grid, dim3(NT_), lds, st, a); } while (0)
   if (a.pol.activation == PHX_ACT_HARD_TANH) { if (two) POL_LAUNCH(PHX_ACT_HARD_TANH, true, 128); else POL_LAUNCH(PHX_ACT_HARD_TANH, false, 256); }
   else { if (two) POL_LAUNCH(PHX_ACT_RELU, true, 128); else POL_LAUNCH(PHX_ACT_RELU, false, 256); }
 #undef POL_LAUNCH
