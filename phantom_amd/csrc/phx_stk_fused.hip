@@ -447,6 +447,21 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   //  and the s_waitcnt vmcnt(0) lgkmcnt(0) behind each -- one per observing buyer and step -- waited for the row's stores in flight: round 6)
   const int val_off = ((int)((char*)(s_conn + (DYN ? sp.n_conn : 0)) - smem) + 7) & ~7;
   double* s_val = (double*)(smem + val_off);                                                       // [nBuy]
+  // FAST: a 4-byte ordering KEY per posted price, [nSell + 1] with +inf behind the last seller.  A posted price is 1.0 (a reset) or a seller's
+  // action, a float32: the key is the price itself as f32 (exact), a buyer's search for its cheapest neighbour compares 4-byte keys -- four
+  // candidates in flight at a time, unused neighbour slots pointing at the +inf entry, no branch -- and decides exactly like the f64 search
+  // (same first minimum, NaN never smaller); the price comes back from s_posted.  A state blob whose posted prices are NOT float32 values
+  // (written by hand) switches the block to RANK keys -- the number of posted prices below this one, recomputed whenever prices change
+  // (rerank): the same order as the f64 values, whatever they are.
+  float* s_postf = (float*)(s_val + nBuy);
+  auto rerank = [&]() __attribute__((always_inline)) {
+    for (int kr = tid; kr < nSell; kr += NT) {
+      const double v = s_posted[kr];
+      int c = 0;
+      for (int l = 0; l < nSell; ++l) c += s_posted[l] < v ? 1 : 0;
+      s_postf[kr] = (v != v) ? (float)v : (float)c;            // (a NaN price keeps a NaN key: never smaller, like the f64 compare)
+    }
+  };
   // (Measured and dropped, round 3: the row's four u8 planes staged in LDS and stored as 16-byte pieces after the step's last
   //  barrier instead of one byte store per lane and plane -- 12 fewer store instructions per lane and step, but one more
   //  dependent stage on a step that is a latency chain: 26.9 -> 29.0 us per step at 128 x 1024, B = 4096.)
@@ -457,10 +472,14 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   int n_resets = 0;
   if (dyn) for (int i = tid; i < sp.n_conn; i += NT) s_conn[i] = fld<uint8_t>(sp, F_NET_CONN_ON)[(int64_t)b * sp.n_conn + i];
 
+  bool my_pf_bad = false;
   for (int k = tid; k < nSell; k += NT) {
-    s_posted[k] = fld<double>(sp, F_SELLER_POSTED)[sbase + k]; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
+    const double pv = fld<double>(sp, F_SELLER_POSTED)[sbase + k];
+    s_posted[k] = pv; s_price[k] = fld<double>(sp, F_SELLER_PRICE)[sbase + k];
     s_rev[k] = fld<double>(sp, F_SELLER_REVENUE)[sbase + k]; s_tx[k] = fld<int32_t>(sp, F_SELLER_TX)[sbase + k];
+    if (FAST) { const float pf = (float)pv; s_postf[k] = pf; my_pf_bad |= !((double)pf == pv) && (pv == pv); }
   }
+  if (FAST && tid == 0) s_postf[nSell] = __builtin_inff();
   for (int k = tid; k < nBuy; k += NT) {
     s_paid[k] = fld<double>(sp, F_BUYER_PAID)[bbase + k]; s_bought[k] = (uint8_t)fld<int32_t>(sp, F_BUYER_BOUGHT)[bbase + k];
   }
@@ -471,11 +490,12 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   // deg << 8 | kind_rank << 16; nbp: a buyer's neighbours (seller ranks, packed u16), for a seller nbp[0] = its degree;
   // rw2 / rt2: the agent's word of tick rt2, kept from the Philox block of its previous acting tick
   uint32_t rec[STKR_SLOTS], nbp[STKR_SLOTS][4], rw2[STKR_SLOTS], rt2[STKR_SLOTS];
+  uint32_t nb8[STKR_SLOTS][2];                                  // FAST: a buyer's eight neighbour ranks as BYTES (at most 254 sellers; unused slots: nSell, the +inf key), a seller's degree in [0]
 #pragma unroll
   for (int k = 0; k < STKR_SLOTS; ++k) {
     const int a = tid + k * NT;
     rec[k] = 0; rw2[k] = 0; rt2[k] = 0xffffffffu;
-    nbp[k][0] = nbp[k][1] = nbp[k][2] = nbp[k][3] = 0;
+    nbp[k][0] = nbp[k][1] = nbp[k][2] = nbp[k][3] = 0; nb8[k][0] = nb8[k][1] = 0;
     if (FAST || (!dyn && sp.stk_packed)) {
       // the host's packed per-agent tables (the fast step kernel's): three independent loads per slot instead of a chain of up to twelve
       // (record -> flags -> eight neighbour ranks) -- the block's setup was ~45 us of a launch's 180 us fixed cost at 4 096 envs
@@ -485,6 +505,18 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
         const double v = sp.param_f[a * PHX_NPF];
         rec[k] = r; nbp[k][0] = ag.x; nbp[k][1] = ag.y; nbp[k][2] = ag.z; nbp[k][3] = ag.w;
         if (!(r & 1u)) s_val[r >> 16] = v;
+        if (FAST) {
+          if (r & 1u) nb8[k][0] = ag.x;                          // a seller: its degree
+          else {                                                 // a buyer: ranks as bytes, neighbour slots j >= deg point at the +inf key of s_postf
+            const int deg = (int)((r >> 8) & 255u);
+            const uint32_t w4[4] = {ag.x, ag.y, ag.z, ag.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t l = j < deg ? ((w4[j >> 1] >> ((j & 1) * 16)) & 0xffffu) : (uint32_t)nSell;
+              nb8[k][j >> 2] |= (l & 255u) << ((j & 3) * 8);
+            }
+          }
+        }
       }
     } else
     if (a < A) {
@@ -507,6 +539,8 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   int step = fld<int32_t>(sp, F_ENV_STEP)[b];
   uint32_t tick = (uint32_t)fld<int32_t>(sp, F_ENV_TICK)[b];
   __syncthreads();
+  const bool pf_rank = FAST && __syncthreads_or(my_pf_bad) != 0;      // (uniform; for the whole launch)
+  if (pf_rank) { rerank(); __syncthreads(); }
 #ifdef PHX_TIMING
   unsigned long long stm[8] = {0}, sprev = __builtin_readcyclecounter();
   const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
@@ -516,7 +550,21 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
   // prices); jr < 0: no neighbour this episode
   auto cheapest = [&](int k, int kr, int deg, int& jr) __attribute__((always_inline)) {
     double best = 0.0; jr = -1;
-    if (FAST || (!dyn && deg <= 8)) {
+    if (FAST) {                                                // 4-byte keys, four in flight at a time, no branch: see s_postf
+      float bf = 0.f; uint32_t bl = 0u;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const uint32_t w = nb8[k][h >> 1] >> ((h & 1) * 16), l0 = w & 0xffu, l1 = (w >> 8) & 0xffu;
+        const float p0 = s_postf[l0], p1 = s_postf[l1];
+        if (h == 0) { bf = p0; bl = l0; }
+        else { const bool lt = p0 < bf; bf = lt ? p0 : bf; bl = lt ? l0 : bl; }
+        { const bool lt = p1 < bf; bf = lt ? p1 : bf; bl = lt ? l1 : bl; }
+        if (h & 1) __builtin_amdgcn_sched_barrier(0);                        // (the scheduler would put all eight reads in flight: a spill at 64 VGPRs)
+      }
+      jr = deg > 0 ? (int)bl : -1;
+      return deg > 0 ? s_posted[bl] : 0.0;
+    }
+    if (!dyn && deg <= 8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (j < deg) {
@@ -557,6 +605,14 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     return jr >= 0 ? s_posted[jr] : 0.0;
   };
 
+  // terminated (all zero: no agent of this market terminates) and truncated (the row's __all__ flag for every agent) are the same byte
+  // for the whole row: A / 8 lanes write them as 8-byte pieces instead of every lane one byte per plane and slot (16-byte pieces cost the
+  // 64-VGPR instantiations a spill, and a spill's reload is a load in the store loop)
+#ifndef STKR_WIDE_FLAGS
+#define STKR_WIDE_FLAGS(NT_, FAST_) ((NT_) < 512 || (FAST_) == 2)    // (the 64-VGPR random-policy forms: the two stores cost a spill whose reload is a load in the store loop)
+#endif
+  const bool wide_flags = FAST && STKR_WIDE_FLAGS(NT, FAST) && ((((uintptr_t)io.terminated | (uintptr_t)io.truncated) & 7u) == 0) && (A & 7) == 0 && (A >> 3) <= NT;
+  const bool wf_lane = wide_flags && tid < (A >> 3);
   for (int t = 0; t < io.T; ++t) {
     STKR_REFRESH();
     const int tt = step + 1;                                                 // env.py:252
@@ -566,9 +622,15 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     // loop it costs ~90 VGPRs and the occupancy with them
 #pragma unroll
     for (int k = 0; k < STKR_SLOTS; ++k)
-      asm volatile("" : "+v"(rec[k]), "+v"(nbp[k][0]), "+v"(nbp[k][1]), "+v"(nbp[k][2]), "+v"(nbp[k][3]));
+      if (FAST) asm volatile("" : "+v"(rec[k]), "+v"(nb8[k][0]), "+v"(nb8[k][1]));
+      else asm volatile("" : "+v"(rec[k]), "+v"(nbp[k][0]), "+v"(nbp[k][1]), "+v"(nbp[k][2]), "+v"(nbp[k][3]));
     int ltid = tid;
     asm volatile("" : "+v"(ltid));
+    if (wf_lane) {                                                           // the row's two uniform planes, 8 bytes per lane (wide_flags above); here,
+      const uint32_t tv = (tt == sp.num_steps) ? 0x01010101u : 0u;           // where few values are live (in the output phase it cost a spill)
+      *(uint2*)((char*)(io.terminated + row) + (size_t)((uint32_t)ltid * 8u)) = make_uint2(0u, 0u);
+      *(uint2*)((char*)(io.truncated + row) + (size_t)((uint32_t)ltid * 8u)) = make_uint2(tv, tv);
+    }
     // ---- acting phase ---------------------------------------------------------------------------
     float act[STKR_SLOTS];
 #pragma unroll
@@ -620,11 +682,14 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
         tx += n;
       }
       s_rev[kr] = rev; s_tx[kr] = tx;
-      if (s_sent[kr]) s_posted[kr] = s_price[kr];
+      if (s_sent[kr]) { s_posted[kr] = s_price[kr]; if (FAST) s_postf[kr] = (float)s_price[kr]; }
       s_count[kr] = 0; s_sent[kr] = 0;
     }
     stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
-    if ((tt & 1) ? sa_lead : sa_foll) cj = 0xFEFEFEFEu;                      // (uniform) the booking pass may have changed posted prices
+    if ((tt & 1) ? sa_lead : sa_foll) {                                      // (uniform) the booking pass may have changed posted prices
+      cj = 0xFEFEFEFEu;
+      if (FAST && pf_rank) { rerank(); stk_lds_barrier(); }
+    }
     STICK(2);
     // ---- obs / reward / flags -> trajectory row (stackelberg.py:142-196) -----------------------------
     const bool terminal = (tt == sp.num_steps);
@@ -647,7 +712,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       if (fl & 2u) {
         ov = 1;
         if (seller) {
-          int sd = (int)nbp[k][0];
+          int sd = (int)(FAST ? nb8[k][0] : nbp[k][0]);
           if (dyn) { sd = 0; for (int e = sp.row_ptr[a]; e < sp.row_ptr[a + 1]; ++e) sd += s_conn[sp.col_conn[e]] ? 1 : 0; }
           ob0 = sd ? (float)((double)s_tx[kr] / (double)sd) : 0.f; ob1 = (float)s_price[kr];
         } else {
@@ -670,7 +735,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       *(float2*)(p_obs + (size_t)(ua * 8u)) = make_float2(ob0, ob1);
       *(float*)(p_act + (size_t)(ua * 4u)) = act[k];
       *(float*)(p_rew + (size_t)(ua * 4u)) = (float)rw;
-      *(uint8_t*)(p_ter + (size_t)ua) = 0; *(uint8_t*)(p_tru + (size_t)ua) = terminal;
+      if (!wide_flags) { *(uint8_t*)(p_ter + (size_t)ua) = 0; *(uint8_t*)(p_tru + (size_t)ua) = terminal; }
       *(uint8_t*)(p_ov + (size_t)ua) = ov; *(uint8_t*)(p_rv + (size_t)ua) = rv;
       if (last && io.last_obs) {
         // the observation the next fragment starts from: after a terminal step, the reset's (the
@@ -690,7 +755,7 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     stk_lds_barrier();      // orders LDS only: the row's stores stay in flight
     STICK(4);
     if (terminal) {                                                          // the caller's env.reset()
-      for (int k = tid; k < nSell; k += NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; }
+      for (int k = tid; k < nSell; k += NT) { s_posted[k] = 1.0; s_price[k] = 0.0; s_rev[k] = 0.0; s_tx[k] = 0; if (FAST) s_postf[k] = 1.0f; }
       for (int k = tid; k < nBuy; k += NT) { s_paid[k] = 0.0; s_bought[k] = 0; }
       for (int a = tid; a < A; a += NT) s_cv[a] = 0;
       cj = 0xFEFEFEFEu;
@@ -736,7 +801,8 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
 
 size_t phx_stk_rollout_lds(const DevSpec& sp) {
   const size_t nSell = sp.kind_count[PHX_KIND_SELLER], nBuy = sp.kind_count[PHX_KIND_BUYER], A = sp.A;
-  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32 + 8 + 8 * nBuy;   // + the buyers' values
+  return 8 * (3 * nSell + A + nBuy) + 4 * (2 * nSell) + nSell + A + nBuy + (sp.dynamic_graph ? (size_t)sp.n_conn : 0) + 32 + 8 + 8 * nBuy +   // + the buyers' values
+         4 * (nSell + 1) + 8;                                                                                                                     // + the posted prices' keys
 }
 
 hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, hipStream_t st) {
@@ -760,7 +826,7 @@ hipError_t phx_launch_stk_rollout(const DevSpec& sp, const phx_rollout_io& io, h
   const size_t lds = phx_stk_rollout_lds(sp);
   phx_note_kernel("phx_stk_rollout_kernel");
 #define PHX_LAUNCH_STKR(NT_) do { if (sp.dynamic_graph) hipLaunchKernelGGL((phx_stk_rollout_kernel<true, NT_, 0>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
-                                  else if (!sp.stk_packed) hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 0>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
+                                  else if (!sp.stk_packed || sp.kind_count[PHX_KIND_SELLER] > 254) hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 0>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
                                   else if (io.actions) hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 2>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); \
                                   else hipLaunchKernelGGL((phx_stk_rollout_kernel<false, NT_, 1>), dim3(sp.B), dim3(NT_), lds, st, sp.self_dev, io); } while (0)
   switch (nt) {
