@@ -136,6 +136,10 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
   const int mbits = mine ? ((sp.obs_mask[a] ? 1 : 0) | (sp.obs_mask[(int64_t)sp.A + a] ? 2 : 0) | (sp.rew_mask[a] ? 4 : 0) | (sp.rew_mask[(int64_t)sp.A + a] ? 8 : 0)) : 0;
   if (r < 8) s_pp[r] = sp.param_f[pub * PHX_NPF + r];
   __syncthreads();
+  // what an auto-reset reads -- the budget sampler's parameters, the three connection rates -- in registers too: the step loop holds no load
+  double sprm[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tsrc >= 0) { const double* q = sp.sampler_param + 4 * tsrc; sprm[0] = q[0]; sprm[1] = q[1]; sprm[2] = q[2]; sprm[3] = q[3]; }
+  const double cr_adx = (dyn && mine) ? sp.conn_rate[c_adx] : 0.0, cr_pub = (dyn && mine) ? sp.conn_rate[c_pub] : 0.0, cr_ap = dyn ? sp.conn_rate[c_ap] : 0.0;
   const int T = ROLLOUT ? args.rio.T : 1;
   RngQuadCache rq; rq.q = 0xffffffffu;
   const int64_t total = (int64_t)sp.B * N;
@@ -267,11 +271,11 @@ __global__ __launch_bounds__(NT) void phx_ads_kernel(const DevSpec sp, const Ads
     if (!ROLLOUT && r == 0) { args.sio.all_terminated[b] = all_term; args.sio.all_truncated[b] = all_trunc; }
     if (ROLLOUT && terminal) {
       // the caller's env.reset(): samplers env.py:211-212, agents :353-374, done sets, reward cache fsm.py:195-251
-      if (tsrc >= 0) budget = rng_uniform(sp.seed, genv, episode, tsrc, sp.sampler_param + 4 * tsrc);
+      if (tsrc >= 0) budget = rng_uniform(sp.seed, genv, episode, tsrc, sprm);
       if (dyn) {                                               // resample_connectivity network.py:438-447
-        if (mine) { e_adx = rng_connection(sp.seed, genv, episode, c_adx, sp.conn_rate[c_adx]) != 0;
-                    e_pub = rng_connection(sp.seed, genv, episode, c_pub, sp.conn_rate[c_pub]) != 0; }
-        e_ap = rng_connection(sp.seed, genv, episode, c_ap, sp.conn_rate[c_ap]) != 0;
+        if (mine) { e_adx = rng_connection(sp.seed, genv, episode, c_adx, cr_adx) != 0;
+                    e_pub = rng_connection(sp.seed, genv, episode, c_pub, cr_pub) != 0; }
+        e_ap = rng_connection(sp.seed, genv, episode, c_ap, cr_ap) != 0;
       }
       ++episode; ++n_resets;
       left = budget; left_tag = btag; bid = 0.0; bid_tag = PHX_TAG_PYF; clicks = wins = user = 0;

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
   const int64_t pair = (int64_t)b * S + s, total = (int64_t)a.B * S;
   int stock = a.stock[pair], sales = a.sales[pair], missed = a.missed[pair], delivered = a.delivered[pair];
   int step = a.env_step[b]; uint32_t tick = (uint32_t)a.env_tick[b];
+  // (a "use" of every loaded word HERE: `delivered` is overwritten by the first step without ever being read, and the s_waitcnt vmcnt(0) that
+  //  protects its register from the load still in flight would otherwise sit inside the step loop -- where it waits for the row's stores)
+  asm volatile("" :: "v"(stock), "v"(sales), "v"(missed), "v"(delivered), "v"(step), "v"(tick));
   const int norm_i = a.shop_norm[s];
   const float norm_f = (float)norm_i;
   const int c0 = a.shop_cust_ptr[s], K = a.shop_cust_ptr[s + 1] - c0;
