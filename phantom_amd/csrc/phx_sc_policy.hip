@@ -161,7 +161,35 @@ __global__ __launch_bounds__(NT) void phx_sc_rollout_policy_kernel(const PolArgs
       }
       const float* const ob1 = o1 + W1p * W0p; const float* const ow2 = ob1 + W1p;
       y = ow2[W1p];
-      if (SW) {
+      if (SW && ((W0 | W1) & 7) == 0) {
+        // eight units x eight k per trip: 64 weights in SGPRs (eight s_load_dwordx8 in flight together), 64 v_fmac_f32 with an SGPR operand on
+        // eight independent chains (ascending k each) -- no packing moves, one scalar-cache and one LDS round trip per 64 multiply-adds
+        typedef const __attribute__((address_space(4))) float* pol_cfp;
+        const pol_cfp w1 = (pol_cfp)(uintptr_t)a.pol.w[1];
+        for (int j0 = 0; j0 < W1; j0 += 8) {
+          const float4 ba = *(const float4*)(ob1 + j0), bb = *(const float4*)(ob1 + j0 + 4);
+          float c[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+          const pol_cfp rb = w1 + j0 * W0;
+          for (int k0 = 0; k0 < W0; k0 += 8) {
+            float w[8][8], h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+              for (int v = 0; v < 8; ++v) w[u][v] = rb[u * W0 + k0 + v];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) h[v] = hcol[(k0 + v) * NT];
+            // (measured and dropped: a scheduling barrier here, so that all eight scalar loads are in flight before the first multiply-add --
+            //  64 weight SGPRs live at once spill into VGPR lanes: 27.0 against 24.5 us per step for 3-64-64-1)
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+#pragma unroll
+              for (int u = 0; u < 8; ++u) asm("v_fmac_f32 %0, %1, %2" : "+v"(c[u]) : "s"(w[u][v]), "v"(h[v]));      // c = fma(w, h, c): the definition's fmaf
+          }
+          const float4 wa = *(const float4*)(ow2 + j0), wb = *(const float4*)(ow2 + j0 + 4);
+          y = __fmaf_rn(wa.x, pol_act<ACT>(c[0]), y); y = __fmaf_rn(wa.y, pol_act<ACT>(c[1]), y); y = __fmaf_rn(wa.z, pol_act<ACT>(c[2]), y); y = __fmaf_rn(wa.w, pol_act<ACT>(c[3]), y);
+          y = __fmaf_rn(wb.x, pol_act<ACT>(c[4]), y); y = __fmaf_rn(wb.y, pol_act<ACT>(c[5]), y); y = __fmaf_rn(wb.z, pol_act<ACT>(c[6]), y); y = __fmaf_rn(wb.w, pol_act<ACT>(c[7]), y);
+        }
+      } else if (SW) {
         typedef const __attribute__((address_space(4))) float* pol_cfp;
         const pol_cfp w1 = (pol_cfp)(uintptr_t)a.pol.w[1];
         for (int j0 = 0; j0 < W1; j0 += 4) {                           // four units: four independent chains over k, ascending k each
