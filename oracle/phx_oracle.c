@@ -1429,6 +1429,20 @@ int64_t phxo_set_i32(phxo_env* E, const char* field, const int32_t* in) {
       if (E->s.kind[a] == f->kind) E->env[b].ag[a].i[f->slot] = in[(size_t)b * n + E->kind_rank[a]];
   return (int64_t)E->B * n;
 }
+/* tests: posted prices written by hand, [B][n_sellers] in seller order.  The oracle keeps what the reference keeps -- every buyer's price slots
+   (BuyerAgent.seller_prices, stackelberg.py) -- so a seller's posted price is written into the slot of every buyer it is a neighbour of. */
+int64_t phxo_set_f64(phxo_env* E, const char* field, const double* in) {
+  if (strcmp(field, "seller.posted")) return -1;
+  const int nS = E->kind_count[PHX_KIND_SELLER];
+  for (int b = 0; b < E->B; ++b)
+    for (int a = 0; a < E->A; ++a)
+      if (E->s.kind[a] == PHX_KIND_BUYER)
+        for (int k = 0; k < E->s.row_ptr[a + 1] - E->s.row_ptr[a]; ++k) {
+          const int nb = E->s.col[E->s.row_ptr[a] + k];
+          if (E->s.kind[nb] == PHX_KIND_SELLER) E->env[b].ag[a].vec[k] = in[(size_t)b * nS + E->kind_rank[nb]];
+        }
+  return (int64_t)E->B * nS;
+}
 int64_t phxo_get_f64(const phxo_env* E, const char* field, double* out) {
   if (!strcmp(field, "buyer.prices")) {
     /* [B][nnz-of-buyers] flattened in agent order */

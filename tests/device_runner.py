@@ -102,6 +102,9 @@ class DeviceRunner:
         self.dev.field(field).copy_(torch.from_numpy(np.ascontiguousarray(arr, np.int32)).reshape(
             self.dev.field(field).shape))
 
+    def set_f64(self, field, arr):
+        self.dev.field(field).copy_(torch.from_numpy(np.ascontiguousarray(arr, np.float64)).reshape(self.dev.field(field).shape))
+
     def get_u8(self, field):
         return self.dev.field(field).cpu().numpy().reshape(self.B, -1)
 

@@ -40,6 +40,8 @@ def lib():
         L.phxo_last_error.restype = C.c_char_p
         L.phxo_set_threads.argtypes = [C.c_int]
         L.phxo_max_threads.restype = C.c_int
+        L.phxo_set_f64.restype = C.c_int64
+        L.phxo_set_f64.argtypes = [vp, C.c_char_p, vp]
         L.phxo_check_recip_div.restype = C.c_int64
         L.phxo_check_recip_div.argtypes = [C.c_int, C.c_int]
         for n in ("phxo_obs_dim", "phxo_n_strategic", "phxo_n_exo"):
@@ -205,6 +207,10 @@ class OracleEnv:
     def set_i32(self, field, arr):
         arr = np.ascontiguousarray(arr, np.int32)
         assert self.L.phxo_set_i32(self.h, field.encode(), _p(arr)) >= 0
+
+    def set_f64(self, field, arr):
+        arr = np.ascontiguousarray(arr, np.float64)
+        assert self.L.phxo_set_f64(self.h, field.encode(), _p(arr)) >= 0
 
     def get_u8(self, field):
         buf = np.zeros(self.B * max(self.spec.n_conn, 1), np.uint8)

@@ -228,3 +228,35 @@ def test_fused_rule_rollout_matches_the_oracle_and_the_engine(S, ks, B, ns, rule
             np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f); np.testing.assert_array_equal(dg.get_i32(f), o.get_i32(f), err_msg=f)
         stages |= set(np.unique(o.get_i32("env.stage")).tolist())
     assert (d.err == 0).all() and (dg.err == 0).all()
+
+
+@pytest.mark.parametrize("L,Fw,deg,B", [(6, 20, 3, 37), (40, 300, 8, 11), (128, 256, 8, 5)])
+def test_market_rollout_from_posted_prices_written_by_hand(L, Fw, deg, B):
+    """The fused market rollout searches a buyer's cheapest neighbour on 4-byte keys: the posted price itself where every posted price of the
+    env is a float32 value (1.0 after a reset, a seller's float32 action afterwards), RANK keys where a caller wrote other doubles into
+    `seller.posted`.  Both against the oracle -- float32 values, full-precision doubles, ties among them, coarse ties -- over
+    the sellers' first postings, an episode end and a second fragment."""
+    from helpers import f64_bits, market_env
+    ns = 8
+    env = market_env(L, Fw, deg, ns, B, seed=9, exogenous="device")
+    o, d = OracleEnv(env.spec, threads=8), DeviceRunner(env.spec)
+    o.reset(); d.reset()
+    rng = np.random.default_rng(L + B)
+    p = rng.random((B, L))                                    # 53-bit doubles: not float32 values
+    p[0] = p[0].astype(np.float32)                            # env 0: float32 values (the key is the price)
+    p[1, ::2] = p[1, 1]                                       # ties at full precision
+    p[2] = np.round(p[2], 1)                                  # coarse ties of non-float32 values (0.1, 0.2, ...)
+    p[3] = 1.0 + p[3] * 2.0 ** -40                            # differences far below float32 resolution
+    o.set_f64("seller.posted", p); d.set_f64("seller.posted", p)
+    for T in (1, 3, 2 * ns + 1):
+        ro, rd = o.rollout(T), d.rollout(T)
+        assert d.dev.last_kernel() == "phx_stk_rollout_kernel"
+        for k in ("obs", "actions", "rewards", "last_obs"):
+            np.testing.assert_array_equal(f32_bits(rd[k]), f32_bits(ro[k]), err_msg=f"T={T} {k}")
+        for k in ("truncated", "terminated", "obs_valid", "reward_valid"):
+            np.testing.assert_array_equal(rd[k], ro[k], err_msg=f"T={T} {k}")
+        for f in ("seller.price", "seller.revenue", "buyer.paid"):
+            np.testing.assert_array_equal(f64_bits(d.get_f64(f)), f64_bits(o.get_f64(f)), err_msg=f"T={T} {f}")
+        for f in ("seller.tx", "buyer.bought"):
+            np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"T={T} {f}")
+    assert (d.err == 0).all()
