@@ -35,7 +35,7 @@ def _cmp(rd, ro, what):
     np.testing.assert_array_equal(f32_bits(rd["last_obs"]), f32_bits(ro["last_obs"]), err_msg=what)
 
 
-@pytest.mark.parametrize("widths,act", [((32,), "relu"), ((64, 64), "relu"), ((5,), "hard_tanh"), ((8, 3), "hard_tanh"), ((1,), "relu"), ((17, 33), "relu")])
+@pytest.mark.parametrize("widths,act", [((32,), "relu"), ((64, 64), "relu"), ((5,), "hard_tanh"), ((8, 3), "hard_tanh"), ((1,), "relu"), ((17, 33), "relu"), ((16, 12), "relu"), ((24, 8), "hard_tanh")])
 @pytest.mark.parametrize("S,ks,B,ns", [(9, [6] * 9, 61, 23), (51, [4] * 51, 9, 30), (3, [2, 7, 1], 100, 11)])
 def test_on_policy_rollout_matches_the_oracle(widths, act, S, ks, B, ns):
     """T on-policy steps in one launch == the oracle's (policy on the previous observation, then env.step), bit for bit: the actions the
