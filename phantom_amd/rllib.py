@@ -216,11 +216,14 @@ class _Rows(dict):
     C-level ``tolist`` / ``zip`` / ``dict``); from then on this IS a plain dict (a dict subclass whose ``__missing__`` fills
     it: every later ``rows[b]`` is a C-level lookup -- round 5's Mapping paid a Python ``__getitem__`` per row).  Envs whose
     dicts omit keys (FSM / Stackelberg validity masks) fall back to per-row views (``make_row``)."""
-    __slots__ = ("_n", "_make", "_make_all")
+    __slots__ = ("_n", "_make", "_make_all", "_hold")
 
-    def __init__(self, n: int, make_row, make_all=None):
+    def __init__(self, n: int, make_row, make_all=None, hold=None):
         dict.__init__(self)
         self._n, self._make, self._make_all = n, make_row, make_all
+        # what the rows alias (a poll() result's token: its host block is not recycled while this MultiEnvDict is referenced -- the fill
+        # function, which also refers to it, is dropped once the rows are built)
+        self._hold = hold
 
     def _fill(self):
         if self._make_all is not None:
@@ -293,13 +296,23 @@ class _HostBlock:
     was the largest single cost of reading a step's rows at B = 4096.  A block is recycled only when nothing refers
     to the result that used it (``owner`` is a weak reference to that result's token); otherwise a new block is made -- rows handed
     out never change under their reader."""
-    __slots__ = ("arrays", "obs_views", "owner")
+    __slots__ = ("arrays", "obs_views", "obs_rows", "owner")
 
     def __init__(self, like):
         self.arrays = {k: v.copy() for k, v in like.items()}
         o = self.arrays["obs"]
         self.obs_views = list(o.reshape((-1,) + o.shape[2:]))
+        self.obs_rows = None
         self.owner = None
+
+    def rows(self, ids, B):
+        """The B observation rows {agent_id: view} over this block's views, made ONCE per block as well (4 096 dicts of nine entries are
+        0.9 ms of every step's first read): the views do not change when the block is refilled, so neither do the dicts.  They travel with
+        the block: treat them as read-only, like the views (a result's rows are valid while its MultiEnvDict is referenced)."""
+        r = self.obs_rows
+        if r is None or r[0] is not ids:
+            r = self.obs_rows = (ids, _rows_of_views(ids, self.obs_views, B))
+        return r[1]
 
 
 class _Token:
@@ -524,7 +537,7 @@ class BatchedBaseEnv(_BaseEnvBase):
                     blk.owner = weakref.ref(tok)
                     tok.block = blk
                 return tok.block.arrays
-            self._last = (_Rows(B, None, lambda: (arrays(), _rows_of_views(ids, tok.block.obs_views, B))[1]),
+            self._last = (_Rows(B, None, lambda: (arrays(), tok.block.rows(ids, B))[1], hold=tok),
                           _Rows(B, None, lambda: _rows_of_scalars(ids, arrays()["reward"])),
                           _Rows(B, None, lambda: _rows_of_scalars(ids, arrays()["terminated"].astype(bool), "__all__", arrays()["all_terminated"].astype(bool))),
                           _Rows(B, None, lambda: _rows_of_scalars(ids, arrays()["truncated"].astype(bool), "__all__", arrays()["all_truncated"].astype(bool))),

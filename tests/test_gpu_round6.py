@@ -260,3 +260,43 @@ def test_market_rollout_from_posted_prices_written_by_hand(L, Fw, deg, B):
         for f in ("seller.tx", "buyer.bought"):
             np.testing.assert_array_equal(d.get_i32(f), o.get_i32(f), err_msg=f"T={T} {f}")
     assert (d.err == 0).all()
+
+
+def test_a_fully_read_poll_result_keeps_its_rows_while_it_is_referenced():
+    """RLlib's sampler reads EVERY dict of a poll() result.  Until late round 6 the host block a result's observation rows alias was released
+    as soon as all six dicts had been built (the only references to the result's token were the fill functions, dropped after use): the next
+    step's first read recycled the block and the kept result's observations became the new step's.  The observation MultiEnvDict now holds
+    the token; rows and views are valid while the MultiEnvDict they came from is referenced (the rows of a block are made once, with its views)."""
+    import torch
+    from phantom_amd.rllib import BatchedBaseEnv
+    B, S = 64, 3
+    env = supply_chain_env(S, [2] * S, 10, B, seed=1)
+    be = BatchedBaseEnv(env)
+    res = be.poll()
+    ids = list(env.strategic_agent_ids)
+
+    def read_all(r):
+        for dct in r[:5]:
+            for b in range(B):
+                row = dct[b]
+                for k in row:
+                    row[k]
+    read_all(res)
+    kept = []
+    rng = np.random.default_rng(2)
+    for i in range(6):
+        be.send_action_tensor(torch.from_numpy(rng.uniform(0, 100, (B, S)).astype(np.float32)))
+        r = be.poll(); read_all(r)
+        kept.append((r, {b: {aid: r[0][b][aid].copy() for aid in ids} for b in (0, 5, B - 1)}, [r[1][b][ids[0]] for b in range(B)]))
+    for r, want, rew in kept:                                     # every kept result still shows ITS step
+        for b, row in want.items():
+            for aid in ids:
+                assert np.array_equal(r[0][b][aid], row[aid]), (b, aid)
+        assert [r[1][b][ids[0]] for b in range(B)] == rew
+    assert len({id(r[0][0]) for r, _, _ in kept}) == len(kept)    # (six live results: six blocks, six sets of rows)
+    del kept, r
+    import gc; gc.collect()
+    n_blocks = len(be._blocks)
+    for i in range(4):                                            # nothing is kept any more: the blocks -- and their rows -- are reused
+        be.send_action_tensor(torch.zeros(B, S)); r = be.poll(); read_all(r); del r
+    assert len(be._blocks) == n_blocks
