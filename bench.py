@@ -1064,11 +1064,18 @@ def bench_rllib_adapter(env, B, S):
                               "keep_results=False (a result is copied when first read, before the next step)"}
     acts = torch.rand(B, S, device=env._device().device) * 100.0
     ids = sorted(be_keep.get_agent_ids())
-    for mode, n in (("tensor", 50), ("tensor_zero_copy", 50), ("multi_env_dict", 5), ("multi_env_dict_rows_read", 3)):
+    def read_rows(o):                          # every env's observation / reward row materialised, as a sampler would
+        for b in range(B):
+            row, rw = o[0][b], o[1][b]
+            for aid in ids:
+                row[aid], rw.get(aid)
+    for mode, n in (("tensor", 50), ("tensor_zero_copy", 50), ("multi_env_dict", 5), ("multi_env_dict_rows_read", 5)):
         be = be_lazy if mode == "tensor_zero_copy" else be_keep
         env.reset()
         be._pending = None
         obs = be.poll()
+        if mode == "multi_env_dict_rows_read":   # one untimed step: the adapter's first host block (36 864 observation views + 4 096 row dicts,
+            be.send_action_tensor(acts); obs = be.poll(); read_rows(obs)      # ~6 ms once) is made here, not inside a five-step average
         t0 = time.perf_counter()
         for _ in range(n):
             if mode.startswith("tensor"):        # [B, S] tensor in, lazy MultiEnvDicts out (nothing read)
@@ -1076,11 +1083,8 @@ def bench_rllib_adapter(env, B, S):
             else:                                # RLlib's MultiEnvDict in: B x S python entries converted once
                 be.send_actions({b: {aid: 50.0 for aid in ids} for b in range(B)})
             obs = be.poll()
-            if mode == "multi_env_dict_rows_read":   # and every env's observation / reward row materialised, as a sampler would
-                for b in range(B):
-                    row, rw = obs[0][b], obs[1][b]
-                    for aid in ids:
-                        row[aid], rw.get(aid)
+            if mode == "multi_env_dict_rows_read":
+                read_rows(obs)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         res[mode] = {"ms_per_step": dt * 1e3, "agent_steps_per_sec": N_AGENTS * B / dt, "steps": n}
