@@ -605,14 +605,12 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
     return jr >= 0 ? s_posted[jr] : 0.0;
   };
 
-  // terminated (all zero: no agent of this market terminates) and truncated (the row's __all__ flag for every agent) are the same byte
-  // for the whole row: A / 8 lanes write them as 8-byte pieces instead of every lane one byte per plane and slot (16-byte pieces cost the
-  // 64-VGPR instantiations a spill, and a spill's reload is a load in the store loop)
-#ifndef STKR_WIDE_FLAGS
-#define STKR_WIDE_FLAGS(NT_, FAST_) ((NT_) < 512 || (FAST_) == 2)    // (the 64-VGPR random-policy forms: the two stores cost a spill whose reload is a load in the store loop)
-#endif
-  const bool wide_flags = FAST && STKR_WIDE_FLAGS(NT, FAST) && ((((uintptr_t)io.terminated | (uintptr_t)io.truncated) & 7u) == 0) && (A & 7) == 0 && (A >> 3) <= NT;
-  const bool wf_lane = wide_flags && tid < (A >> 3);
+  // (Measured and dropped, round 6: terminated / truncated -- the same byte for a whole row, the rows that end an episode known from the step
+  //  counter at entry -- written for ALL T rows of the env as 16-byte pieces before the first step, like the supply-chain kernel's flag planes:
+  //  6 of a lane's 21 store instructions per step leave the loop, yet the marginal cost of a step does not move (5.9 us per block-step in a
+  //  one-round launch either way; compute alone, without any store, is 3.4), a one-round launch pays the 230 KB burst per block up front
+  //  (+5 %) and B = 4 096 gains 0-3 %.  As 8-byte pieces inside the loop they cost the 64-VGPR instantiations a spill.)
+  const bool wide_flags = false;
   for (int t = 0; t < io.T; ++t) {
     STKR_REFRESH();
     const int tt = step + 1;                                                 // env.py:252
@@ -626,11 +624,6 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       else asm volatile("" : "+v"(rec[k]), "+v"(nbp[k][0]), "+v"(nbp[k][1]), "+v"(nbp[k][2]), "+v"(nbp[k][3]));
     int ltid = tid;
     asm volatile("" : "+v"(ltid));
-    if (wf_lane) {                                                           // the row's two uniform planes, 8 bytes per lane (wide_flags above); here,
-      const uint32_t tv = (tt == sp.num_steps) ? 0x01010101u : 0u;           // where few values are live (in the output phase it cost a spill)
-      *(uint2*)((char*)(io.terminated + row) + (size_t)((uint32_t)ltid * 8u)) = make_uint2(0u, 0u);
-      *(uint2*)((char*)(io.truncated + row) + (size_t)((uint32_t)ltid * 8u)) = make_uint2(tv, tv);
-    }
     // ---- acting phase ---------------------------------------------------------------------------
     float act[STKR_SLOTS];
 #pragma unroll
@@ -732,9 +725,13 @@ __global__ __launch_bounds__(NT, STKR_MINWAVES(NT)) void phx_stk_rollout_kernel(
       // scalar row bases + 32-bit lane offsets: the stores take the SGPR-base + VGPR-offset form (per-slot 64-bit
       // pointers kept across the step loop cost ~50 VGPRs)
       const uint32_t ua = (uint32_t)a;
-      *(float2*)(p_obs + (size_t)(ua * 8u)) = make_float2(ob0, ob1);
-      *(float*)(p_act + (size_t)(ua * 4u)) = act[k];
-      *(float*)(p_rew + (size_t)(ua * 4u)) = (float)rw;
+      // NON-TEMPORAL stores for the three f32 planes (a wave writes whole 128-byte lines of them): the row then leaves for HBM while the next
+      // step's acting phase computes, instead of sitting dirty in the L2 until the next row's burst evicts it -- the blocks of a round run in
+      // step, so without this HBM idles through every compute phase and every store phase waits for it (round 6: 5.3 -> ? us per block-step)
+      typedef float stk_f2v __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store((stk_f2v){ob0, ob1}, (stk_f2v*)(p_obs + (size_t)(ua * 8u)));
+      __builtin_nontemporal_store(act[k], (float*)(p_act + (size_t)(ua * 4u)));
+      __builtin_nontemporal_store((float)rw, (float*)(p_rew + (size_t)(ua * 4u)));
       if (!wide_flags) { *(uint8_t*)(p_ter + (size_t)ua) = 0; *(uint8_t*)(p_tru + (size_t)ua) = terminal; }
       *(uint8_t*)(p_ov + (size_t)ua) = ov; *(uint8_t*)(p_rv + (size_t)ua) = rv;
       if (last && io.last_obs) {
