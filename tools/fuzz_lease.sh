@@ -7,6 +7,7 @@ TAG=${1:-lease}; BASE=${2:-10000000}; NP=${3:-32}; PER=${4:-8000}
 OUT=$R/gpurun_out/fuzz_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"; cd "$R"
 make -C oracle -s liboracle.so && touch oracle/liboracle.so      # once, before the workers: 32 of them rebuilding it at the same time raced (lease r05_1)
+export PHX_FUZZ_DUMP=$OUT           # a per-step mismatch leaves its inputs, both outputs and both states here (mismatch_<case>.npz)
 t0=$(date +%s)
 for i in $(seq 0 $((NP - 1))); do
   lo=$((BASE + i * PER)); hi=$((lo + PER))
